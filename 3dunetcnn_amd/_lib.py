@@ -1,0 +1,96 @@
+"""ctypes binding of libmi355unet3d.so (the C ABI declared in include/mi355_unet3d.h).
+
+The product path has exactly one implementation: the HIP library built for gfx950 by `build.py`. If it is missing
+or cannot be loaded this module raises -- there is no CPU or PyTorch fallback.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libmi355unet3d.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+
+class MiAct(Structure):
+    _fields_ = [("p", c_void_p), ("n", c_int32), ("d", c_int32), ("h", c_int32), ("w", c_int32),
+                ("c", c_int32), ("ld", c_int32)]
+
+
+class MiConvDesc(Structure):
+    _fields_ = [("kd", c_int32), ("stride", c_int32), ("pad", c_int32), ("in_mode", c_int32),
+                ("act_slope", c_float),
+                ("in_scale", c_void_p), ("in_shift", c_void_p), ("bias", c_void_p),
+                ("residual", c_void_p), ("residual_ld", c_int32),
+                ("out_chscale", c_void_p),
+                ("off_z", c_int32), ("off_y", c_int32), ("off_x", c_int32),
+                ("out_d", c_int32), ("out_h", c_int32), ("out_w", c_int32)]
+
+
+IN_PLAIN, IN_AFFINE_ACT, IN_ZERO_INSERT = 0, 1, 2
+
+STATUS = {0: "ok", -1: "invalid argument (shape/alignment/null)", -2: "unsupported combination",
+          -3: "kernel launch failed", -4: "workspace too small"}
+
+# name -> (restype, argtypes); every symbol of include/mi355_unet3d.h
+SIGNATURES = {
+    "mi355_packed_weight_elems": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "mi355_pack_conv_weight": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "mi355_conv3d_fwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, POINTER(MiAct), POINTER(MiConvDesc), c_void_p]),
+    "mi355_conv3d_wgrad_workspace": (c_size_t, [POINTER(MiAct), POINTER(MiAct), POINTER(MiConvDesc)]),
+    "mi355_conv3d_wgrad": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), c_void_p, POINTER(MiConvDesc), c_void_p, c_size_t, c_void_p]),
+    "mi355_gn_workspace": (c_size_t, [POINTER(MiAct)]),
+    "mi355_gn_stats": (ctypes.c_int, [POINTER(MiAct), c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mi355_gn_act_bwd": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), POINTER(MiAct), c_void_p, c_int32, c_int32, c_float,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mi355_upsample2x_fwd": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), c_int32, c_int32, c_int32, c_void_p]),
+    "mi355_upsample2x_bwd": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), c_int32, c_int32, c_int32, c_void_p]),
+    "mi355_ncdhw_to_ndhwc": (ctypes.c_int, [c_void_p, POINTER(MiAct), c_void_p]),
+    "mi355_ndhwc_to_ncdhw": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p]),
+    "mi355_add": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), POINTER(MiAct), c_void_p]),
+    "mi355_chscale": (ctypes.c_int, [POINTER(MiAct), c_void_p, POINTER(MiAct), c_void_p]),
+    "mi355_proj_fwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "mi355_proj_workspace": (c_size_t, [POINTER(MiAct), c_int32]),
+    "mi355_proj_bwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p, POINTER(MiAct), c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "mi355_dice_workspace": (c_size_t, [c_int32, c_int32, c_int64]),
+    "mi355_dice_fwd_bwd": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32,
+                                          c_float, c_float, c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "mi355_adam_step": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                                       c_float, c_int32, c_float, c_void_p]),
+    "mi355_version": (c_char_p, []),
+}
+
+
+def bind(cdll):
+    """Attach restype/argtypes for every declared symbol; raises AttributeError if one is missing."""
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(cdll, name)
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+_cached = None
+
+
+def load_library(path=None):
+    """Load the HIP library. torch must be imported first so that its bundled libamdhip64.so.7 is the HIP runtime
+    both sides share (same SONAME as the toolkit's; streams and pointers are then interchangeable)."""
+    global _cached
+    if path is None and _cached is not None:
+        return _cached
+    import torch  # noqa: F401  (loads torch's HIP runtime before ours resolves libamdhip64.so.7)
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} not found: the MI355X HIP library has not been built. Run `python __graft_entry__.py build` "
+            "(or `python 3dunetcnn_amd/build.py`). There is no CPU fallback for this package.")
+    lib = bind(ctypes.CDLL(p))
+    if path is None:
+        _cached = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: mi355 status {rc} ({STATUS.get(rc, 'unknown')})")

@@ -1,0 +1,296 @@
+// conv3d forward / dgrad / transposed-conv forward on gfx950 fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Replaces torch.nn.Conv3d (reference: unet3d/models/pytorch/classification/resnet.py:12-22, called from
+// myronenko.py:17-21) with the GroupNorm-apply+ReLU prologue (myronenko.py:18-19), the residual add
+// (myronenko.py:56), Dropout3d scale (myronenko.py:78-79), F.pad window (segmentation/unet.py:34-40) and the
+// channel-slice write of torch.cat (unet.py:42) fused in.
+//
+// Formulation: im2col-free implicit GEMM. M = output voxels (32 per MFMA tile), N = output channels,
+// K = taps x input channels. A workgroup stages the (haloed) input tile of KC input channels in LDS once per
+// channel chunk -- normalised, activated and zero-padded on the way in -- and every tap reads it at a shifted
+// LDS address. Weights are pre-packed [tap][ci/4][co][4] so each lane fetches the B fragments of 4 consecutive
+// MFMA k-steps with one 16-byte global load (L2 resident, software-prefetched one tap ahead).
+// K ordering inside an 8-channel group: lanes 0-31 own channels 0..3, lanes 32-63 channels 4..7, k-step s uses
+// (s, 4+s); A and B use the same permutation so the sum is unchanged.
+#include "hipcompat.h"
+#include "../../include/mi355_unet3d.h"
+
+struct ConvArgs {
+  const float* x; int xld;
+  const float* wp;
+  float* y; int yld;
+  const float* res; int resld;
+  const float* in_scale; const float* in_shift; float slope;
+  const float* out_chscale; const float* bias;
+  int N, Di, Hi, Wi, Cin, CinP;
+  int Do, Ho, Wo, Cout, CoutP;   // logical output extent
+  int yD, yH, yW, offz, offy, offx;  // destination buffer extent and window shift
+  int pad;
+  int tilesZ, tilesY, tilesX, coTiles;
+};
+
+template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT, int INMODE>
+__global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(TZ * TY * TX == 32 * WM * MT, "tile voxels must equal 32*WM*MT");
+  static_assert(KC % 8 == 0, "channel chunk is a multiple of 8");
+  constexpr int HZ = (TZ - 1) * STRIDE + KD, HY = (TY - 1) * STRIDE + KD, HX = (TX - 1) * STRIDE + KD;
+  constexpr int HV = HZ * HY * HX;
+  constexpr int VS = KC + PADV;
+  constexpr int Q = KC / 4;
+  constexpr int J = KC / 8;
+  constexpr int T = KD * KD * KD;
+  DYN_LDS(lds);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, li = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  int b = blockIdx.x;
+  const int cot = b % a.coTiles; b /= a.coTiles;
+  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+  const int tz0 = (b % a.tilesZ) * TZ; b /= a.tilesZ;
+  const int n = b;
+  const int co_base = cot * (32 * WN * NT) + wn * (32 * NT);
+
+  // A fragment base addresses (floats) for this lane's voxel of each M tile.
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int tv = (wm * MT + mt) * 32 + li;
+    const int tz = tv / (TY * TX), ty = (tv / TX) % TY, tx = tv % TX;
+    abase[mt] = (((tz * STRIDE) * HY + ty * STRIDE) * HX + tx * STRIDE) * VS + half * 4;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const int CQ = a.CinP / 4;
+  const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
+  const int sq = tid % Q;       // this thread's channel quad inside the chunk (fixed: 256 % Q == 0)
+  const int sv0 = tid / Q;
+
+  for (int c0 = 0; c0 < a.CinP; c0 += KC) {
+    // ---- stage the haloed input tile for channels [c0, c0+KC) ----
+    __syncthreads();
+    {
+      const int c = c0 + 4 * sq;
+      const bool cvalid = c < a.Cin;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (INMODE == MI355_IN_AFFINE_ACT && cvalid) {
+        sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
+        sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
+      }
+      for (int hv = sv0; hv < HV; hv += 256 / Q) {
+        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+        int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
+        bool ok = cvalid;
+        if (INMODE == MI355_IN_ZERO_INSERT) {
+          ok = ok && iz >= 0 && iy >= 0 && ix >= 0 && ((iz | iy | ix) & 1) == 0;
+          iz >>= 1; iy >>= 1; ix >>= 1;
+          ok = ok && iz < a.Di && iy < a.Hi && ix < a.Wi;
+        } else {
+          ok = ok && iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi;
+        }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+          v = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + c);
+          if (INMODE == MI355_IN_AFFINE_ACT) {
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+            v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+          }
+        }
+        *reinterpret_cast<float4*>(lds + hv * VS + 4 * sq) = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- 27 taps x KC/8 k-groups, B fragments prefetched one tap ahead ----
+    const int cq0 = c0 / 4 + half;
+    float4 bcur[J][NT], bnext[J][NT];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        bcur[j][nt] = wp4[((size_t)(0 * CQ + cq0 + 2 * j)) * a.CoutP + co_base + nt * 32 + li];
+
+    for (int tap = 0; tap < T; ++tap) {
+      const int tn = tap + 1 < T ? tap + 1 : tap;
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bnext[j][nt] = wp4[((size_t)(tn * CQ + cq0 + 2 * j)) * a.CoutP + co_base + nt * 32 + li];
+
+      const int dz = tap / (KD * KD), dy = (tap / KD) % KD, dx = tap % KD;
+      const int toff = ((dz * HY + dy) * HX + dx) * VS;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        float4 af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const float4*>(lds + abase[mt] + toff + j * 8);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = MFMA_32x32x2(af[mt].x, bcur[j][nt].x, acc[mt][nt]);
+            acc[mt][nt] = MFMA_32x32x2(af[mt].y, bcur[j][nt].y, acc[mt][nt]);
+            acc[mt][nt] = MFMA_32x32x2(af[mt].z, bcur[j][nt].z, acc[mt][nt]);
+            acc[mt][nt] = MFMA_32x32x2(af[mt].w, bcur[j][nt].w, acc[mt][nt]);
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bcur[j][nt] = bnext[j][nt];
+    }
+  }
+
+  // ---- epilogue: bias, residual, dropout scale, windowed store ----
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int tv = (wm * MT + mt) * 32 + row;
+      const int oz = tz0 + tv / (TY * TX), oy = ty0 + (tv / TX) % TY, ox = tx0 + tv % TX;
+      if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
+      const int sz = oz + a.offz, sy = oy + a.offy, sx = ox + a.offx;
+      if (sz < 0 || sy < 0 || sx < 0 || sz >= a.yD || sy >= a.yH || sx >= a.yW) continue;
+      const size_t ovox = (((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+      const size_t svox = (((size_t)n * a.yD + sz) * a.yH + sy) * a.yW + sx;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = co_base + nt * 32 + li;
+        if (co >= a.Cout) continue;
+        float v = acc[mt][nt][r];
+        if (a.bias) v += a.bias[co];
+        if (a.res) v += a.res[ovox * a.resld + co];
+        if (a.out_chscale) v *= a.out_chscale[(size_t)n * a.Cout + co];
+        a.y[svox * a.yld + co] = v;
+      }
+    }
+  }
+}
+
+// ---- weight packing ---------------------------------------------------------------------------
+// mode 0: w OIDHW [cout][cin][T]              -> wp[t][ciP/4][coP][4]           (forward)
+// mode 1: same w, dgrad pack: roles swapped: "out" = ci, "in" = co, tap flipped  (dgrad of Conv3d)
+// mode 2: ConvTranspose3d weight IODHW [cin][cout][T], forward = correlation of the zero-inserted input with
+//         flipped taps: wp[t'][ci][co] = w[ci][co][flip(t')]
+// mode 3: ConvTranspose3d dgrad = plain stride-2 correlation of dy: "in" = co, "out" = ci, taps not flipped.
+__global__ void pack_weight_kernel(const float* w, float* wp, int cout, int cin, int T, int coutP, int cinP, int mode) {
+  // logical packed dims: O (out), I (in)
+  const size_t total = (size_t)T * (cinP / 4) * coutP * 4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int e = idx & 3;
+    size_t r = idx >> 2;
+    const int o = r % coutP; r /= coutP;
+    const int iq = r % (cinP / 4); r /= (cinP / 4);
+    const int t = (int)r;
+    const int i = iq * 4 + e;
+    float v = 0.f;
+    if (o < cout && i < cin) {
+      const int tf = T - 1 - t;
+      if (mode == 0) v = w[((size_t)o * cin + i) * T + t];
+      else if (mode == 1) v = w[((size_t)i * cout + o) * T + tf];   // w[co=i][ci=o], here cout/cin are the packed roles
+      else if (mode == 2) v = w[((size_t)i * cout + o) * T + tf];   // w[ci=i][co=o][flip]
+      else v = w[((size_t)o * cin + i) * T + t];                      // mode 3: w[ci=o][co=i][t]
+    }
+    wp[idx] = v;
+  }
+}
+
+extern "C" size_t mi355_packed_weight_elems(int32_t cout, int32_t cin, int32_t kd, int32_t mode) {
+  (void)mode;
+  const int coutP = (cout + 31) / 32 * 32, cinP = (cin + 7) / 8 * 8;
+  return (size_t)kd * kd * kd * cinP * coutP;
+}
+
+// cout/cin are the PACKED roles (for dgrad packs pass cout := original cin, cin := original cout).
+extern "C" int mi355_pack_conv_weight(const float* w, float* wp, int32_t cout, int32_t cin, int32_t kd, int32_t mode, void* stream) {
+  if (!w || !wp || cout <= 0 || cin <= 0 || (kd != 1 && kd != 3) || mode < 0 || mode > 3) return MI355_EINVAL;
+  const int coutP = (cout + 31) / 32 * 32, cinP = (cin + 7) / 8 * 8;
+  const int T = kd * kd * kd;
+  const size_t total = (size_t)T * cinP * coutP;
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  LAUNCH(pack_weight_kernel, dim3(grid), dim3(256), 0, stream, w, wp, cout, cin, T, coutP, cinP, mode);
+  return LAUNCH_CHECK();
+}
+
+// ---- dispatch ---------------------------------------------------------------------------------
+template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT>
+static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
+  constexpr int HZ = (TZ - 1) * STRIDE + KD, HY = (TY - 1) * STRIDE + KD, HX = (TX - 1) * STRIDE + KD;
+  constexpr size_t lds = (size_t)HZ * HY * HX * (KC + PADV) * sizeof(float);
+  static_assert(lds <= 64 * 1024, "LDS tile must fit the default 64 KiB dynamic window");
+  a.tilesZ = ceil_div(a.Do, TZ); a.tilesY = ceil_div(a.Ho, TY); a.tilesX = ceil_div(a.Wo, TX);
+  a.coTiles = ceil_div(a.Cout, 32 * WN * NT);
+  const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
+  if (in_mode == MI355_IN_PLAIN) {
+    LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_PLAIN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  } else if (in_mode == MI355_IN_AFFINE_ACT) {
+    LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_AFFINE_ACT>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  } else {
+    if (STRIDE != 1) return MI355_EUNSUPPORTED;
+    LAUNCH((conv3d_mfma<KD, 1, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_ZERO_INSERT>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  }
+  return LAUNCH_CHECK();
+}
+
+extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
+  if (!x || !y || !wp || !d || !x->p || !y->p) return MI355_EINVAL;
+  if ((d->kd != 1 && d->kd != 3) || (d->stride != 1 && d->stride != 2)) return MI355_EUNSUPPORTED;
+  if (x->c % 4 || x->ld % 4 || x->ld < x->c || y->ld < y->c || x->n != y->n) return MI355_EINVAL;
+  if (((uintptr_t)x->p & 15) || ((uintptr_t)wp & 15)) return MI355_EINVAL;
+  if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift)) return MI355_EINVAL;
+  if (d->in_mode < 0 || d->in_mode > 2) return MI355_EINVAL;
+  if (d->in_mode == MI355_IN_ZERO_INSERT && d->stride != 1) return MI355_EINVAL;
+  ConvArgs a;
+  a.x = (const float*)x->p; a.xld = x->ld; a.wp = wp; a.y = (float*)y->p; a.yld = y->ld;
+  a.res = d->residual; a.resld = d->residual_ld;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope;
+  a.out_chscale = d->out_chscale; a.bias = d->bias;
+  a.N = x->n; a.Di = x->d; a.Hi = x->h; a.Wi = x->w; a.Cin = x->c; a.CinP = (x->c + 7) / 8 * 8;
+  a.Do = d->out_d; a.Ho = d->out_h; a.Wo = d->out_w; a.Cout = y->c; a.CoutP = (y->c + 31) / 32 * 32;
+  a.yD = y->d; a.yH = y->h; a.yW = y->w; a.offz = d->off_z; a.offy = d->off_y; a.offx = d->off_x;
+  a.pad = d->pad;
+  if (a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0) return MI355_EINVAL;
+  if (a.res && a.resld < a.Cout) return MI355_EINVAL;
+  const int im = d->in_mode;
+  const int cout = a.Cout;
+  if (d->kd == 1) {
+    if (d->stride != 1 || im == MI355_IN_ZERO_INSERT) return MI355_EUNSUPPORTED;
+    // 1x1x1: flatten voxels along x so tiles are 256 consecutive voxels (no halo). The affine prologue needs n,
+    // so keep n separate and flatten (d,h,w).
+    ConvArgs f = a;
+    const long long vin = (long long)a.Di * a.Hi * a.Wi, vout = (long long)a.Do * a.Ho * a.Wo;
+    const long long vy = (long long)a.yD * a.yH * a.yW;
+    if (vin != vout || vy != vout || a.offz || a.offy || a.offx || vin > 0x7fffffffLL) return MI355_EUNSUPPORTED;
+    f.Di = f.Hi = 1; f.Wi = (int)vin; f.Do = f.Ho = 1; f.Wo = (int)vout; f.yD = f.yH = 1; f.yW = (int)vy; f.pad = 0;
+    if (cout > 32) return launch_cfg<1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 2>(f, im, stream);
+    return launch_cfg<1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 1>(f, im, stream);
+  }
+  if (d->stride == 2) {
+    if (cout > 32) return launch_cfg<3, 2, 4, 4, 8, 8, 0, 4, 1, 1, 2>(a, im, stream);
+    return launch_cfg<3, 2, 4, 4, 8, 8, 0, 4, 1, 1, 1>(a, im, stream);
+  }
+  // stride 1, 3x3x3
+  const long long vox = (long long)a.Do * a.Ho * a.Wo * a.N;
+  if (vox >= 256LL * 512) {
+    if (cout > 32) return launch_cfg<3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 2>(a, im, stream);
+    return launch_cfg<3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 1>(a, im, stream);
+  }
+  // small volumes: 64-voxel tiles so that the grid still covers the chip
+  if (cout > 32) return launch_cfg<3, 1, 2, 4, 8, 32, 4, 2, 2, 1, 1>(a, im, stream);
+  return launch_cfg<3, 1, 4, 4, 8, 32, 4, 4, 1, 1, 1>(a, im, stream);
+}

@@ -1,0 +1,243 @@
+// conv3d weight gradient on gfx950 fp32 MFMA.
+//
+// Replaces autograd's conv3d weight-gradient for the reference's Conv3d layers
+// (unet3d/models/pytorch/classification/resnet.py:12-22):
+//   dw[co][ci][t] = sum_{n,q} dy[n,q,co] * in(x)[n, stride*q + t - pad, ci]
+// where in() is the same fused GroupNorm-apply + (Leaky)ReLU input transform as the forward
+// (myronenko.py:18-19), recomputed from x and the saved per-(n,c) scale/shift instead of storing the
+// activated tensor.
+//
+// GEMM view per tap: D[co][ci] (32x32 MFMA tile) += A[co][voxel] * B[voxel][ci], K = voxels (2 per MFMA).
+// A workgroup owns one (32 co) x (32 ci) pair, walks a contiguous range of output-voxel tiles (split-K),
+// stages dy[tile][32co] and the haloed x tile [halo][32ci] in LDS in their natural voxel-major layout (so both
+// MFMA operands are conflict-free ds_read_b32: 32 consecutive channels per half-wave), and keeps the 27
+// tap accumulators distributed over its 4 waves (7/7/7/6). Partial tiles go to a workspace slab; a second
+// kernel reduces the slabs in a fixed order (deterministic, no atomics) and writes OIDHW.
+#include "hipcompat.h"
+#include "../../include/mi355_unet3d.h"
+
+struct WgradArgs {
+  const float* x; int xld;
+  const float* dy; int dyld;
+  float* ws;
+  const float* in_scale; const float* in_shift; float slope;
+  int N, Di, Hi, Wi, Cin;
+  int Do, Ho, Wo, Cout;
+  int pad;
+  int tilesZ, tilesY, tilesX, ntiles;  // output-voxel tiles (per whole batch: ntiles = N*tilesZ*tilesY*tilesX)
+  int splits, ciTiles, coTiles;
+};
+
+template <int KD, int STRIDE, int TZ, int TY, int TX, int INMODE>
+__global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
+  constexpr int T = KD * KD * KD;
+  constexpr int TV = TZ * TY * TX;
+  constexpr int HZ = (TZ - 1) * STRIDE + KD, HY = (TY - 1) * STRIDE + KD, HX = (TX - 1) * STRIDE + KD;
+  constexpr int HV = HZ * HY * HX;
+  constexpr int WV = (T == 1) ? 4 : 1;          // waves split voxels (1x1x1) or taps (3x3x3)
+  constexpr int NTW = (T == 1) ? 1 : (T + 3) / 4;  // taps per wave
+  static_assert(TX % 2 == 0 && TV % (2 * WV) == 0, "voxel pairs");
+  DYN_LDS(lds);
+  float* lds_dy = lds;              // [TV][32]
+  float* lds_x = lds + TV * 32;     // [HV][32]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, li = lane & 31;
+  const int split = blockIdx.x, cit = blockIdx.y, cot = blockIdx.z;
+  const int ci0 = cit * 32, co0 = cot * 32;
+
+  int toff[NTW];
+#pragma unroll
+  for (int ti = 0; ti < NTW; ++ti) {
+    int tap = (T == 1) ? 0 : wave + 4 * ti;
+    if (tap >= T) tap = T - 1;
+    const int dz = tap / (KD * KD), dyy = (tap / KD) % KD, dx = tap % KD;
+    toff[ti] = ((dz * HY + dyy) * HX + dx) * 32;
+  }
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int ti = 0; ti < NTW; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+
+  const int per = (a.ntiles + a.splits - 1) / a.splits;
+  const int t_begin = split * per;
+  const int t_end = t_begin + per < a.ntiles ? t_begin + per : a.ntiles;
+  const int sq = tid & 7, sv0 = tid >> 3;   // staging: 8 quads per 32-channel row
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int b = tile;
+    const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+    const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+    const int tz0 = (b % a.tilesZ) * TZ; b /= a.tilesZ;
+    const int n = b;
+    __syncthreads();
+    // ---- stage dy tile ----
+    {
+      const int c = co0 + 4 * sq;
+      const bool cvalid = c < a.Cout;   // Cout % 4 == 0 is required
+      for (int v = sv0; v < TV; v += 32) {
+        const int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cvalid && oz < a.Do && oy < a.Ho && ox < a.Wo)
+          val = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.dyld + c);
+        *reinterpret_cast<float4*>(lds_dy + v * 32 + 4 * sq) = val;
+      }
+    }
+    // ---- stage haloed x tile with the fused input transform ----
+    {
+      const int c = ci0 + 4 * sq;
+      const bool cvalid = c < a.Cin;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (INMODE == MI355_IN_AFFINE_ACT && cvalid) {
+        sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
+        sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
+      }
+      for (int hv = sv0; hv < HV; hv += 32) {
+        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+        const int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cvalid && iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi) {
+          v = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + c);
+          if (INMODE == MI355_IN_AFFINE_ACT) {
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+            v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+          }
+        }
+        *reinterpret_cast<float4*>(lds_x + hv * 32 + 4 * sq) = v;
+      }
+    }
+    __syncthreads();
+    // ---- K loop over voxel pairs ----
+    constexpr int KSTEPS = TV / 2 / WV;
+    const int ks0 = (T == 1) ? wave * KSTEPS : 0;
+#pragma unroll 4
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int v = 2 * (ks0 + ks) + half;
+      const int tz = v / (TY * TX), ty = (v / TX) % TY, tx = v % TX;
+      const float av = lds_dy[v * 32 + li];
+      const int xb = (((tz * STRIDE) * HY + ty * STRIDE) * HX + tx * STRIDE) * 32 + li;
+#pragma unroll
+      for (int ti = 0; ti < NTW; ++ti) {
+        const float bv = lds_x[xb + toff[ti]];
+        acc[ti] = MFMA_32x32x2(av, bv, acc[ti]);
+      }
+    }
+  }
+
+  // ---- write the partial tiles: ws[pair][slab][tap][32 co][32 ci] ----
+  const int SL = a.splits * WV;
+  const size_t pair = (size_t)cot * a.ciTiles + cit;
+  const int slab = split * WV + ((T == 1) ? wave : 0);
+#pragma unroll
+  for (int ti = 0; ti < NTW; ++ti) {
+    const int tap = (T == 1) ? 0 : wave + 4 * ti;
+    if (tap >= T) continue;
+    float* dst = a.ws + (((pair * SL + slab) * T + tap) * 1024);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;   // co within tile
+      dst[row * 32 + li] = acc[ti][r];
+    }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles) {
+  const size_t total = (size_t)T * Cout * Cin;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int ci = idx % Cin; size_t r = idx / Cin;
+    const int co = r % Cout; const int tap = (int)(r / Cout);
+    const size_t pair = (size_t)(co / 32) * ciTiles + ci / 32;
+    const float* src = ws + ((pair * SL) * T + tap) * 1024 + (co % 32) * 32 + (ci % 32);
+    float s = 0.f;
+    for (int k = 0; k < SL; ++k) s += src[(size_t)k * T * 1024];
+    dw[((size_t)co * Cin + ci) * T + tap] = s;
+  }
+}
+
+struct WgradPlan { int tz, ty, tx, ntiles, tilesZ, tilesY, tilesX, splits, ciTiles, coTiles, wv; size_t ws_bytes; int ok; };
+
+static WgradPlan plan_wgrad(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  WgradPlan p; memset(&p, 0, sizeof(p));
+  if (!x || !dy || !d) return p;
+  if ((d->kd != 1 && d->kd != 3) || (d->stride != 1 && d->stride != 2)) return p;
+  if (d->kd == 1 && d->stride != 1) return p;
+  int Do = dy->d, Ho = dy->h, Wo = dy->w;
+  if (d->kd == 1) { p.tz = 1; p.ty = 1; p.tx = 256; long long v = (long long)Do * Ho * Wo; if (v > 0x7fffffffLL) return p; Do = 1; Ho = 1; Wo = (int)v; p.wv = 4; }
+  else if (d->stride == 1) { p.tz = 4; p.ty = 4; p.tx = 8; p.wv = 1; }
+  else { p.tz = 2; p.ty = 2; p.tx = 8; p.wv = 1; }
+  p.tilesZ = ceil_div(Do, p.tz); p.tilesY = ceil_div(Ho, p.ty); p.tilesX = ceil_div(Wo, p.tx);
+  const long long nt = (long long)dy->n * p.tilesZ * p.tilesY * p.tilesX;
+  if (nt <= 0 || nt > 0x7fffffffLL) return p;
+  p.ntiles = (int)nt;
+  p.ciTiles = ceil_div(x->c, 32); p.coTiles = ceil_div(dy->c, 32);
+  const int pairs = p.ciTiles * p.coTiles;
+  int splits = ceil_div(1024, pairs);
+  const int max_splits = p.ntiles >= 8 ? p.ntiles / 8 : 1;   // >= 8 tiles per workgroup amortise the slab write
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  // make every split non-empty
+  const int per = ceil_div(p.ntiles, splits);
+  splits = ceil_div(p.ntiles, per);
+  p.splits = splits;
+  const int T = d->kd * d->kd * d->kd;
+  p.ws_bytes = (size_t)pairs * splits * p.wv * T * 1024 * sizeof(float);
+  p.ok = 1;
+  return p;
+}
+
+extern "C" size_t mi355_conv3d_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  WgradPlan p = plan_wgrad(x, dy, d);
+  return p.ok ? p.ws_bytes : 0;
+}
+
+template <int KD, int STRIDE, int TZ, int TY, int TX>
+static int launch_wgrad(WgradArgs& a, int in_mode, void* stream) {
+  constexpr int HZ = (TZ - 1) * STRIDE + KD, HY = (TY - 1) * STRIDE + KD, HX = (TX - 1) * STRIDE + KD;
+  constexpr size_t lds = (size_t)(TZ * TY * TX + HZ * HY * HX) * 32 * sizeof(float);
+  static_assert(lds <= 64 * 1024, "LDS tile must fit the default 64 KiB dynamic window");
+  dim3 grid(a.splits, a.ciTiles, a.coTiles);
+  if (in_mode == MI355_IN_PLAIN)
+    LAUNCH((conv3d_wgrad_mfma<KD, STRIDE, TZ, TY, TX, MI355_IN_PLAIN>), grid, dim3(256), lds, stream, a);
+  else
+    LAUNCH((conv3d_wgrad_mfma<KD, STRIDE, TZ, TY, TX, MI355_IN_AFFINE_ACT>), grid, dim3(256), lds, stream, a);
+  return LAUNCH_CHECK();
+}
+
+extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !dy || !dw || !d || !ws || !x->p || !dy->p) return MI355_EINVAL;
+  if (x->c % 4 || x->ld % 4 || dy->c % 4 || dy->ld % 4 || x->n != dy->n) return MI355_EINVAL;
+  if (((uintptr_t)x->p & 15) || ((uintptr_t)dy->p & 15)) return MI355_EINVAL;
+  if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
+  if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift)) return MI355_EINVAL;
+  WgradPlan p = plan_wgrad(x, dy, d);
+  if (!p.ok) return MI355_EUNSUPPORTED;
+  if (ws_bytes < p.ws_bytes) return MI355_EWORKSPACE;
+  WgradArgs a;
+  a.x = (const float*)x->p; a.xld = x->ld; a.dy = (const float*)dy->p; a.dyld = dy->ld; a.ws = (float*)ws;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope;
+  a.N = x->n; a.Di = x->d; a.Hi = x->h; a.Wi = x->w; a.Cin = x->c;
+  a.Do = dy->d; a.Ho = dy->h; a.Wo = dy->w; a.Cout = dy->c; a.pad = d->pad;
+  a.tilesZ = p.tilesZ; a.tilesY = p.tilesY; a.tilesX = p.tilesX; a.ntiles = p.ntiles;
+  a.splits = p.splits; a.ciTiles = p.ciTiles; a.coTiles = p.coTiles;
+  int rc;
+  if (d->kd == 1) {
+    const long long vi = (long long)x->d * x->h * x->w, vo = (long long)dy->d * dy->h * dy->w;
+    if (vi != vo) return MI355_EINVAL;
+    a.Di = a.Hi = 1; a.Wi = (int)vi; a.Do = a.Ho = 1; a.Wo = (int)vo; a.pad = 0;
+    rc = launch_wgrad<1, 1, 1, 1, 256>(a, d->in_mode, stream);
+  } else if (d->stride == 1) {
+    rc = launch_wgrad<3, 1, 4, 4, 8>(a, d->in_mode, stream);
+  } else {
+    rc = launch_wgrad<3, 2, 2, 2, 8>(a, d->in_mode, stream);
+  }
+  if (rc) return rc;
+  const int T = d->kd * d->kd * d->kd;
+  const size_t total = (size_t)T * a.Cout * a.Cin;
+  int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
+  LAUNCH(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, stream, (const float*)ws, dw, a.Cout, a.Cin, T, p.splits * p.wv, p.ciTiles);
+  return LAUNCH_CHECK();
+}

@@ -1,0 +1,31 @@
+// Dialect header for the kernels in this directory.
+// Product build: hipcc --offload-arch=gfx950 (CDNA4 only; no other backend is supported).
+// MI355_EMU is defined ONLY by tools/emu/build_emu.sh (CPU test infrastructure, see tools/emu/emu.h).
+#pragma once
+
+#ifdef MI355_EMU
+#include "emu.h"
+#include <cstring>
+#else
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <cmath>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_32x32x2_f32: exact f32 in / f32 accumulate, 64 cycles per SIMD (157 TFLOP/s chip peak).
+// lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
+// lane holds D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] for r in [0,16).
+#define MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) float name[]
+#define LAUNCH(kernel, grid, block, lds, stream, ...) \
+  hipLaunchKernelGGL(kernel, (grid), (block), (lds), (hipStream_t)(stream), __VA_ARGS__)
+#define LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? 0 : -3)
+#endif
+
+#define MI355_OK 0
+#define MI355_EINVAL (-1)
+#define MI355_EUNSUPPORTED (-2)
+#define MI355_ELAUNCH (-3)
+#define MI355_EWORKSPACE (-4)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,178 @@
+// Fused sigmoid-Dice loss (forward + gradient) and fused Adam -- HBM-bound streaming kernels.
+//
+// Dice: monai.losses.DiceLoss(include_background=True, sigmoid=True) as selected by
+// examples/brats2020/brats2020_config.json:112-116 through unet3d/scripts/script_utils.py:61-77 and evaluated at
+// unet3d/train/training_utils.py:111. MONAI is un-vendored; formula per SURVEY.md Appendix C:
+//   p = sigmoid(z); per (n,c): I = sum p*y, D = sum p + sum y (sum p^2 + sum y^2 if squared_pred);
+//   f = 1 - (2I + smooth_nr)/(D + smooth_dr); loss = mean f   (batch=True sums I, D over n first).
+// Adam: torch.optim.Adam defaults (script_utils.py:80-81), single flat parameter buffer.
+#include "hipcompat.h"
+#include "../../include/mi355_unet3d.h"
+
+#define DICE_MAX_BLOCKS 128
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+
+__global__ void dice_partial_kernel(const float* logits, const void* target, int target_u8, long long V, int sigmoid, int squared,
+                                    float* ws) {
+  __shared__ float red[3][256];
+  const int nc = blockIdx.y, blk = blockIdx.x, B = gridDim.x;
+  const long long per = (V + B - 1) / B;
+  const long long vb = (long long)blk * per, ve = vb + per < V ? vb + per : V;
+  const float* z = logits + (size_t)nc * V;
+  const unsigned char* t8 = (const unsigned char*)target + (size_t)nc * V;
+  const float* tf = (const float*)target + (size_t)nc * V;
+  float sI = 0.f, sP = 0.f, sY = 0.f;
+  for (long long v = vb + threadIdx.x; v < ve; v += blockDim.x) {
+    const float p = sigmoid ? sigmoidf_(z[v]) : z[v];
+    const float y = target_u8 ? (float)t8[v] : tf[v];
+    sI += p * y;
+    sP += squared ? p * p : p;
+    sY += squared ? y * y : y;
+  }
+  red[0][threadIdx.x] = sI; red[1][threadIdx.x] = sP; red[2][threadIdx.x] = sY;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+      red[2][threadIdx.x] += red[2][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float* d = ws + ((size_t)nc * B + blk) * 3;
+    d[0] = red[0][0]; d[1] = red[1][0]; d[2] = red[2][0];
+  }
+}
+
+// single block: sums -> loss and per-(n,c) gradient coefficients (a, b): dL/dp = -a*y + b*(1 or 2p)
+__global__ void dice_finalize_kernel(const float* ws, int B, int N, int C, int batch, float snr, float sdr, float grad_scale,
+                                     float* stats, float* coef, float* loss) {
+  __shared__ double sums[3 * 1024];
+  __shared__ double fsum[256];
+  const int NC = N * C;
+  for (int i = threadIdx.x; i < NC; i += blockDim.x) {
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int k = 0; k < B; ++k) { const float* p = ws + ((size_t)i * B + k) * 3; a += (double)p[0]; b += (double)p[1]; c += (double)p[2]; }
+    sums[3 * i] = a; sums[3 * i + 1] = b; sums[3 * i + 2] = c;
+    stats[3 * i] = (float)a; stats[3 * i + 1] = (float)b; stats[3 * i + 2] = (float)c;
+  }
+  __syncthreads();
+  double f = 0.0;
+  const int K = batch ? C : NC;     // number of terms in the mean
+  for (int i = threadIdx.x; i < NC; i += blockDim.x) {
+    double I, D;
+    if (batch) {
+      const int c = i % C; I = 0.0; D = 0.0;
+      for (int n = 0; n < N; ++n) { I += sums[3 * (n * C + c)]; D += sums[3 * (n * C + c) + 1] + sums[3 * (n * C + c) + 2]; }
+    } else { I = sums[3 * i]; D = sums[3 * i + 1] + sums[3 * i + 2]; }
+    const double den = D + (double)sdr;
+    coef[2 * i] = (float)((double)grad_scale * 2.0 / (K * den));
+    coef[2 * i + 1] = (float)((double)grad_scale * (2.0 * I + (double)snr) / (K * den * den));
+    if (!batch || i < C) f += 1.0 - (2.0 * I + (double)snr) / den;
+  }
+  fsum[threadIdx.x] = f;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) fsum[threadIdx.x] += fsum[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) loss[0] = (float)(fsum[0] / K);
+}
+
+__global__ void dice_grad_kernel(const float* logits, const void* target, int target_u8, long long V, int NC, int sigmoid, int squared,
+                                 const float* coef, float* dlogits) {
+  const long long total = (long long)NC * V;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int nc = (int)(idx / V);
+    const float zz = logits[idx];
+    const float p = sigmoid ? sigmoidf_(zz) : zz;
+    const float y = target_u8 ? (float)((const unsigned char*)target)[idx] : ((const float*)target)[idx];
+    float g = -coef[2 * nc] * y + coef[2 * nc + 1] * (squared ? 2.f * p : 1.f);
+    if (sigmoid) g *= p * (1.f - p);
+    dlogits[idx] = g;
+  }
+}
+
+static int dice_blocks(long long V) { long long b = V / 4096; if (b < 1) b = 1; if (b > DICE_MAX_BLOCKS) b = DICE_MAX_BLOCKS; return (int)b; }
+
+// ws (floats): partials [NC][B][3] | stats [NC][3] | coef [NC][2]
+extern "C" size_t mi355_dice_workspace(int32_t n, int32_t c, int64_t voxels) {
+  const size_t NC = (size_t)n * c;
+  return (NC * dice_blocks(voxels) * 3 + NC * 5) * sizeof(float);
+}
+
+extern "C" int mi355_dice_fwd_bwd(const float* logits, const void* target, int32_t target_is_u8, int32_t n, int32_t c, int64_t voxels,
+                                  int32_t sigmoid, int32_t batch, int32_t squared_pred, float smooth_nr, float smooth_dr,
+                                  float* loss, float* dlogits, float grad_scale, void* ws, size_t ws_bytes, void* stream) {
+  if (!logits || !target || !loss || !ws || n <= 0 || c <= 0 || voxels <= 0) return MI355_EINVAL;
+  if ((size_t)n * c > 1024) return MI355_EUNSUPPORTED;
+  if (ws_bytes < mi355_dice_workspace(n, c, voxels)) return MI355_EWORKSPACE;
+  const int NC = n * c, B = dice_blocks(voxels);
+  float* part = (float*)ws; float* stats = part + (size_t)NC * B * 3; float* coef = stats + (size_t)NC * 3;
+  LAUNCH(dice_partial_kernel, dim3(B, NC), dim3(256), 0, stream, logits, target, target_is_u8, (long long)voxels, sigmoid, squared_pred, part);
+  int rc = LAUNCH_CHECK(); if (rc) return rc;
+  LAUNCH(dice_finalize_kernel, dim3(1), dim3(256), 0, stream, (const float*)part, B, n, c, batch, smooth_nr, smooth_dr, grad_scale, stats, coef, loss);
+  rc = LAUNCH_CHECK(); if (rc) return rc;
+  if (dlogits) {
+    const long long total = (long long)NC * voxels;
+    long long grid = (total + 255) / 256; if (grid > 16384) grid = 16384;
+    LAUNCH(dice_grad_kernel, dim3((unsigned)grid), dim3(256), 0, stream, logits, target, target_is_u8, (long long)voxels, NC, sigmoid, squared_pred,
+           (const float*)coef, dlogits);
+    rc = LAUNCH_CHECK();
+  }
+  return rc;
+}
+
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long count, float lr, float b1, float b2, float eps,
+                            float wd, float bc1, float bc2_sqrt, float gscale) {
+  const long long n4 = count / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float pe[4] = {pv.x, pv.y, pv.z, pv.w}, ge[4] = {gv.x, gv.y, gv.z, gv.w};
+    float me[4] = {mv.x, mv.y, mv.z, mv.w}, ve[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gg = ge[e] * gscale;
+      if (wd != 0.f) gg += wd * pe[e];
+      me[e] = b1 * me[e] + (1.f - b1) * gg;
+      ve[e] = b2 * ve[e] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(ve[e]) / bc2_sqrt + eps;
+      pe[e] -= (lr / bc1) * (me[e] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pe[0], pe[1], pe[2], pe[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(me[0], me[1], me[2], me[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+  }
+  // tail
+  const long long tail0 = n4 * 4;
+  const long long t = tail0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count) {
+    float gg = g[t] * gscale;
+    if (wd != 0.f) gg += wd * p[t];
+    const float mm = b1 * m[t] + (1.f - b1) * gg;
+    const float vv = b2 * v[t] + (1.f - b2) * gg * gg;
+    m[t] = mm; v[t] = vv;
+    p[t] -= (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+  }
+}
+
+extern "C" int mi355_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                               float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || count <= 0 || step < 1) return MI355_EINVAL;
+  if (((uintptr_t)param & 15) || ((uintptr_t)grad & 15) || ((uintptr_t)exp_avg & 15) || ((uintptr_t)exp_avg_sq & 15)) return MI355_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  long long grid = (count / 4 + 255) / 256; if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
+  LAUNCH(adam_kernel, dim3((unsigned)grid), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, (long long)count, lr, beta1, beta2, eps,
+         weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  return LAUNCH_CHECK();
+}
+
+extern "C" const char* mi355_version(void) {
+#ifdef MI355_EMU
+  return "mi355_unet3d cpu-emulator (tests only) 0.1";
+#else
+  return "mi355_unet3d gfx950 0.1";
+#endif
+}

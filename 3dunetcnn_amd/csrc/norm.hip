@@ -1,0 +1,271 @@
+// GroupNorm / InstanceNorm statistics and the backward of act(GroupNorm(x)) -- HBM-bound streaming kernels.
+//
+// Replaces torch.nn.GroupNorm(G, C, eps=1e-5, affine) as built by
+// unet3d/models/pytorch/classification/myronenko.py:23-31 (G = 8, or G = C when C < 8 or C % 8 != 0), and
+// InstanceNorm3d(affine) of MONAI DynUNet (G == C). The normalise+affine+ReLU *apply* is not a kernel here: it is
+// folded into a per-(n,c) scale/shift pair that the consuming conv applies while staging its LDS tile
+// (conv3d_fwd.hip / conv3d_wgrad.hip), so the normalised tensor never exists in HBM.
+//
+// Algorithmic traffic: stats = 1 read of x; backward = reads of (x, dA) twice + 1 write of dx.
+#include "hipcompat.h"
+#include "../../include/mi355_unet3d.h"
+
+#define GN_MAX_BLOCKS_PER_SAMPLE 256
+
+// per-(n, block, c) partial sums of v0 and v1 where
+//  MODE 0 (stats):    v0 = x,  v1 = x*x
+//  MODE 1 (backward): v0 = du, v1 = du*xhat, du = dA * act'(scale*x+shift), xhat = (x-mean)*rstd
+template <int MODE>
+__global__ void gn_partial_kernel(const float* x, int xld, const float* dA, int dald, long long V, int C, int Q, int R,
+                                  int G, float slope, const float* mean_rstd, const float* scale, const float* shift,
+                                  float* ws) {
+  DYN_LDS(lds);  // [R][Q][8]
+  const int tid = threadIdx.x;
+  const int q = tid % Q, r = tid / Q;
+  const int n = blockIdx.y, blk = blockIdx.x, B = gridDim.x;
+  const long long per = (V + B - 1) / B;
+  const long long vb = (long long)blk * per;
+  const long long ve = vb + per < V ? vb + per : V;
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  float mean[4], rstd[4], sc[4], sh[4];
+  if (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * q + e;
+      const int g = c / (C / G);
+      mean[e] = mean_rstd[((size_t)n * G + g) * 2];
+      rstd[e] = mean_rstd[((size_t)n * G + g) * 2 + 1];
+      sc[e] = scale[(size_t)n * C + c];
+      sh[e] = shift[(size_t)n * C + c];
+    }
+  }
+  const float* xn = x + (size_t)n * V * xld + 4 * q;
+  const float* dn = (MODE == 1) ? dA + (size_t)n * V * dald + 4 * q : nullptr;
+  for (long long v = vb + r; v < ve; v += R) {
+    const float4 xv = *reinterpret_cast<const float4*>(xn + (size_t)v * xld);
+    const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s0[e] += xe[e]; s1[e] += xe[e] * xe[e]; }
+    } else {
+      const float4 dv = *reinterpret_cast<const float4*>(dn + (size_t)v * dald);
+      const float de[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float u = xe[e] * sc[e] + sh[e];
+        const float du = u > 0.f ? de[e] : de[e] * slope;
+        const float xh = (xe[e] - mean[e]) * rstd[e];
+        s0[e] += du; s1[e] += du * xh;
+      }
+    }
+  }
+  float* my = lds + (size_t)tid * 8;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { my[e] = s0[e]; my[4 + e] = s1[e]; }
+  __syncthreads();
+  if (r == 0) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = 0.f;
+    for (int rr = 0; rr < R; ++rr) {
+      const float* o = lds + (size_t)(rr * Q + q) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] += o[e];
+    }
+    float* dst = ws + (((size_t)n * B + blk) * C + 4 * q) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dst[2 * e] = t[e]; dst[2 * e + 1] = t[4 + e]; }
+  }
+}
+
+__device__ __forceinline__ double block_sum_double(double v, double* red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// one block per (n, g)
+__global__ void gn_stats_finalize_kernel(const float* ws, int B, int C, int G, long long V, float eps, const float* gamma,
+                                         const float* beta, float* mean_rstd, float* scale, float* shift) {
+  __shared__ double red[256];
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int cpg = C / G;
+  double s = 0.0, ss = 0.0;
+  for (int i = threadIdx.x; i < B * cpg; i += blockDim.x) {
+    const int blk = i / cpg, c = g * cpg + i % cpg;
+    const float* p = ws + (((size_t)n * B + blk) * C + c) * 2;
+    s += (double)p[0]; ss += (double)p[1];
+  }
+  s = block_sum_double(s, red);
+  ss = block_sum_double(ss, red);
+  const double M = (double)V * cpg;
+  const double mean = s / M;
+  double var = ss / M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  if (threadIdx.x == 0) {
+    mean_rstd[((size_t)n * G + g) * 2] = (float)mean;
+    mean_rstd[((size_t)n * G + g) * 2 + 1] = (float)rstd;
+  }
+  for (int i = threadIdx.x; i < cpg; i += blockDim.x) {
+    const int c = g * cpg + i;
+    const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+    scale[(size_t)n * C + c] = (float)(ga * rstd);
+    shift[(size_t)n * C + c] = (float)(be - mean * ga * rstd);
+  }
+}
+
+// one block per (n, g): per-channel sums -> coefficients (k1, c0, c1) with dx = k1*du + c0 + c1*x, and the
+// per-(n,c) sums for dgamma/dbeta.
+__global__ void gn_bwd_finalize_kernel(const float* ws, int B, int C, int G, long long V, const float* gamma,
+                                       const float* mean_rstd, float* coef, float* nc_sums) {
+  __shared__ double red[256];
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int cpg = C / G;
+  double m1 = 0.0, m2 = 0.0;
+  // per-channel sums first (deterministic order: each thread owns whole channels)
+  for (int i = threadIdx.x; i < cpg; i += blockDim.x) {
+    const int c = g * cpg + i;
+    double s1 = 0.0, s2 = 0.0;
+    for (int blk = 0; blk < B; ++blk) {
+      const float* p = ws + (((size_t)n * B + blk) * C + c) * 2;
+      s1 += (double)p[0]; s2 += (double)p[1];
+    }
+    nc_sums[((size_t)n * C + c) * 2] = (float)s1;
+    nc_sums[((size_t)n * C + c) * 2 + 1] = (float)s2;
+    const double ga = gamma ? (double)gamma[c] : 1.0;
+    m1 += ga * s1; m2 += ga * s2;
+  }
+  m1 = block_sum_double(m1, red);
+  m2 = block_sum_double(m2, red);
+  const double M = (double)V * cpg;
+  m1 /= M; m2 /= M;
+  const double mean = (double)mean_rstd[((size_t)n * G + g) * 2], rstd = (double)mean_rstd[((size_t)n * G + g) * 2 + 1];
+  for (int i = threadIdx.x; i < cpg; i += blockDim.x) {
+    const int c = g * cpg + i;
+    const double ga = gamma ? (double)gamma[c] : 1.0;
+    float* k = coef + ((size_t)n * C + c) * 4;
+    k[0] = (float)(rstd * ga);
+    k[1] = (float)(-rstd * m1 + rstd * rstd * m2 * mean);
+    k[2] = (float)(-rstd * rstd * m2);
+    k[3] = 0.f;
+  }
+}
+
+__global__ void gn_bwd_param_kernel(const float* nc_sums, int N, int C, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int n = 0; n < N; ++n) { s1 += (double)nc_sums[((size_t)n * C + c) * 2]; s2 += (double)nc_sums[((size_t)n * C + c) * 2 + 1]; }
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+}
+
+__global__ void gn_bwd_apply_kernel(const float* x, int xld, const float* dA, int dald, float* dx, int dxld,
+                                    const float* addend, int addld, long long V, int C, int N, float slope,
+                                    const float* scale, const float* shift, const float* coef) {
+  const int Q = C / 4;
+  const long long total = (long long)N * V * Q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % Q);
+    const long long nv = idx / Q;
+    const int n = (int)(nv / V);
+    const int c = 4 * q;
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)nv * xld + c);
+    const float4 dv = *reinterpret_cast<const float4*>(dA + (size_t)nv * dald + c);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + (size_t)n * C + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + (size_t)n * C + c);
+    const float xe[4] = {xv.x, xv.y, xv.z, xv.w}, de[4] = {dv.x, dv.y, dv.z, dv.w};
+    const float se[4] = {sc.x, sc.y, sc.z, sc.w}, he[4] = {sh.x, sh.y, sh.z, sh.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float* k = coef + ((size_t)n * C + c + e) * 4;
+      const float u = xe[e] * se[e] + he[e];
+      const float du = u > 0.f ? de[e] : de[e] * slope;
+      o[e] = k[0] * du + k[1] + k[2] * xe[e];
+    }
+    if (addend) {
+      const float4 av = *reinterpret_cast<const float4*>(addend + (size_t)nv * addld + c);
+      o[0] += av.x; o[1] += av.y; o[2] += av.z; o[3] += av.w;
+    }
+    *reinterpret_cast<float4*>(dx + (size_t)nv * dxld + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+static int gn_blocks_per_sample(long long V) {
+  long long b = V / 2048;
+  if (b < 1) b = 1;
+  if (b > GN_MAX_BLOCKS_PER_SAMPLE) b = GN_MAX_BLOCKS_PER_SAMPLE;
+  return (int)b;
+}
+
+// workspace layout (floats): partials [N][B][C][2] | coef [N][C][4] | nc_sums [N][C][2]
+extern "C" size_t mi355_gn_workspace(const mi355_act* x) {
+  if (!x) return 0;
+  const long long V = (long long)x->d * x->h * x->w;
+  const int B = gn_blocks_per_sample(V);
+  return ((size_t)x->n * B * x->c * 2 + (size_t)x->n * x->c * 6) * sizeof(float);
+}
+
+static int gn_check(const mi355_act* x, int groups) {
+  if (!x || !x->p || x->c % 4 || x->ld % 4 || x->ld < x->c || groups <= 0 || x->c % groups) return MI355_EINVAL;
+  if (x->c / 4 > 256) return MI355_EUNSUPPORTED;
+  if ((uintptr_t)x->p & 15) return MI355_EINVAL;
+  return 0;
+}
+
+extern "C" int mi355_gn_stats(const mi355_act* x, int32_t groups, float eps, const float* gamma, const float* beta,
+                              float* mean_rstd, float* scale, float* shift, void* ws, size_t ws_bytes, void* stream) {
+  int rc = gn_check(x, groups);
+  if (rc) return rc;
+  if (!mean_rstd || !scale || !shift || !ws) return MI355_EINVAL;
+  if (ws_bytes < mi355_gn_workspace(x)) return MI355_EWORKSPACE;
+  const long long V = (long long)x->d * x->h * x->w;
+  const int B = gn_blocks_per_sample(V), C = x->c, Q = C / 4, R = 256 / Q > 0 ? 256 / Q : 1;
+  LAUNCH((gn_partial_kernel<0>), dim3(B, x->n), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream,
+         (const float*)x->p, x->ld, (const float*)nullptr, 0, V, C, Q, R, groups, 0.f, (const float*)nullptr,
+         (const float*)nullptr, (const float*)nullptr, (float*)ws);
+  rc = LAUNCH_CHECK(); if (rc) return rc;
+  LAUNCH(gn_stats_finalize_kernel, dim3(groups, x->n), dim3(256), 0, stream, (const float*)ws, B, C, groups, V, eps, gamma, beta,
+         mean_rstd, scale, shift);
+  return LAUNCH_CHECK();
+}
+
+extern "C" int mi355_gn_act_bwd(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const float* addend, int32_t addend_ld,
+                                int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
+                                const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                void* ws, size_t ws_bytes, void* stream) {
+  int rc = gn_check(x, groups);
+  if (rc) return rc;
+  if (!dA || !dx || !dA->p || !dx->p || !mean_rstd || !scale || !shift || !ws) return MI355_EINVAL;
+  if (dA->c != x->c || dx->c != x->c || dA->ld % 4 || dx->ld % 4 || ((uintptr_t)dA->p & 15) || ((uintptr_t)dx->p & 15)) return MI355_EINVAL;
+  if (addend && (addend_ld % 4 || ((uintptr_t)addend & 15))) return MI355_EINVAL;
+  if (ws_bytes < mi355_gn_workspace(x)) return MI355_EWORKSPACE;
+  const long long V = (long long)x->d * x->h * x->w;
+  const int B = gn_blocks_per_sample(V), C = x->c, N = x->n, Q = C / 4, R = 256 / Q > 0 ? 256 / Q : 1;
+  float* part = (float*)ws;
+  float* coef = part + (size_t)N * B * C * 2;
+  float* ncs = coef + (size_t)N * C * 4;
+  LAUNCH((gn_partial_kernel<1>), dim3(B, N), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream,
+         (const float*)x->p, x->ld, (const float*)dA->p, dA->ld, V, C, Q, R, groups, act_slope, mean_rstd, scale, shift, part);
+  rc = LAUNCH_CHECK(); if (rc) return rc;
+  LAUNCH(gn_bwd_finalize_kernel, dim3(groups, N), dim3(256), 0, stream, (const float*)part, B, C, groups, V, gamma, mean_rstd, coef, ncs);
+  rc = LAUNCH_CHECK(); if (rc) return rc;
+  if (dgamma || dbeta) {
+    LAUNCH(gn_bwd_param_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, (const float*)ncs, N, C, dgamma, dbeta);
+    rc = LAUNCH_CHECK(); if (rc) return rc;
+  }
+  const long long total = (long long)N * V * Q;
+  long long grid = (total + 255) / 256; if (grid > 8192) grid = 8192;
+  LAUNCH(gn_bwd_apply_kernel, dim3((unsigned)grid), dim3(256), 0, stream, (const float*)x->p, x->ld, (const float*)dA->p, dA->ld,
+         (float*)dx->p, dx->ld, addend, addend_ld, V, C, N, act_slope, scale, shift, (const float*)coef);
+  return LAUNCH_CHECK();
+}

@@ -1,0 +1,339 @@
+// HBM-bound streaming kernels around the conv stack: trilinear x2 upsample (+pad/crop, + concat slice write),
+// layout changes at the module boundary, residual-gradient add, Dropout3d scale, and the few-class 1x1x1 projection.
+//
+// Reference call sites: unet3d/models/pytorch/classification/decoder.py:105-106 (F.interpolate trilinear x2,
+// align_corners=False), segmentation/unet.py:34-42 (F.pad + torch.cat), autoencoder/variational.py:59-60 and
+// segmentation/unet.py:50 (final 1x1x1 conv), classification/myronenko.py:70-79 (Dropout3d).
+#include "hipcompat.h"
+#include "../../include/mi355_unet3d.h"
+
+__device__ __forceinline__ void tri_src(int u, int n, int& i0, int& i1, float& l0, float& l1) {
+  // PyTorch area_pixel_compute_source_index(scale=0.5, align_corners=False): src = max(0.5*(u+0.5)-0.5, 0)
+  float s = 0.5f * ((float)u + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+
+__global__ void upsample2x_fwd_kernel(const float* lo, int lold, int N, int Dl, int Hl, int Wl, int C,
+                                      float* cat, int catld, int Dc, int Hc, int Wc, int offz, int offy, int offx) {
+  const int Q = C / 4;
+  const long long total = (long long)N * Dc * Hc * Wc * Q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % Q); long long r = idx / Q;
+    const int x = (int)(r % Wc); r /= Wc;
+    const int y = (int)(r % Hc); r /= Hc;
+    const int z = (int)(r % Dc); const int n = (int)(r / Dc);
+    const int uz = z - offz, uy = y - offy, ux = x - offx;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (uz >= 0 && uy >= 0 && ux >= 0 && uz < 2 * Dl && uy < 2 * Hl && ux < 2 * Wl) {
+      int z0, z1, y0, y1, x0, x1; float lz0, lz1, ly0, ly1, lx0, lx1;
+      tri_src(uz, Dl, z0, z1, lz0, lz1); tri_src(uy, Hl, y0, y1, ly0, ly1); tri_src(ux, Wl, x0, x1, lx0, lx1);
+      const int zs[2] = {z0, z1}, ys[2] = {y0, y1}, xs[2] = {x0, x1};
+      const float wz[2] = {lz0, lz1}, wy[2] = {ly0, ly1}, wx[2] = {lx0, lx1};
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const float w = wz[a] * wy[b] * wx[c];
+            const float4 v = *reinterpret_cast<const float4*>(lo + ((((size_t)n * Dl + zs[a]) * Hl + ys[b]) * Wl + xs[c]) * lold + 4 * q);
+            o.x += w * v.x; o.y += w * v.y; o.z += w * v.z; o.w += w * v.w;
+          }
+    }
+    *reinterpret_cast<float4*>(cat + ((((size_t)n * Dc + z) * Hc + y) * Wc + x) * catld + 4 * q) = o;
+  }
+}
+
+__device__ __forceinline__ float tri_weight(int u, int n, int d) {
+  if (u < 0 || u >= 2 * n) return 0.f;
+  int i0, i1; float l0, l1;
+  tri_src(u, n, i0, i1, l0, l1);
+  return (i0 == d ? l0 : 0.f) + (i1 == d ? l1 : 0.f);
+}
+
+__global__ void upsample2x_bwd_kernel(const float* dcat, int catld, int N, int Dc, int Hc, int Wc, int C,
+                                      float* dlo, int lold, int Dl, int Hl, int Wl, int offz, int offy, int offx) {
+  const int Q = C / 4;
+  const long long total = (long long)N * Dl * Hl * Wl * Q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % Q); long long r = idx / Q;
+    const int x = (int)(r % Wl); r /= Wl;
+    const int y = (int)(r % Hl); r /= Hl;
+    const int z = (int)(r % Dl); const int n = (int)(r / Dl);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = -1; a <= 2; ++a) {
+      const int uz = 2 * z + a; const float wz = tri_weight(uz, Dl, z); const int cz = uz + offz;
+      if (wz == 0.f || cz < 0 || cz >= Dc) continue;
+      for (int b = -1; b <= 2; ++b) {
+        const int uy = 2 * y + b; const float wy = tri_weight(uy, Hl, y); const int cy = uy + offy;
+        if (wy == 0.f || cy < 0 || cy >= Hc) continue;
+        for (int c = -1; c <= 2; ++c) {
+          const int ux = 2 * x + c; const float wx = tri_weight(ux, Wl, x); const int cx = ux + offx;
+          if (wx == 0.f || cx < 0 || cx >= Wc) continue;
+          const float w = wz * wy * wx;
+          const float4 v = *reinterpret_cast<const float4*>(dcat + ((((size_t)n * Dc + cz) * Hc + cy) * Wc + cx) * catld + 4 * q);
+          o.x += w * v.x; o.y += w * v.y; o.z += w * v.z; o.w += w * v.w;
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(dlo + ((((size_t)n * Dl + z) * Hl + y) * Wl + x) * lold + 4 * q) = o;
+  }
+}
+
+static inline unsigned grid_for(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+static int act_ok(const mi355_act* t) {
+  return t && t->p && t->c > 0 && t->c % 4 == 0 && t->ld % 4 == 0 && t->ld >= t->c && !((uintptr_t)t->p & 15);
+}
+
+extern "C" int mi355_upsample2x_fwd(const mi355_act* lo, const mi355_act* cat, int32_t offz, int32_t offy, int32_t offx, void* stream) {
+  if (!act_ok(lo) || !act_ok(cat) || lo->c != cat->c || lo->n != cat->n) return MI355_EINVAL;
+  const long long total = (long long)cat->n * cat->d * cat->h * cat->w * (cat->c / 4);
+  LAUNCH(upsample2x_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)lo->p, lo->ld, lo->n, lo->d, lo->h, lo->w, lo->c,
+         (float*)cat->p, cat->ld, cat->d, cat->h, cat->w, offz, offy, offx);
+  return LAUNCH_CHECK();
+}
+
+extern "C" int mi355_upsample2x_bwd(const mi355_act* dcat, const mi355_act* dlo, int32_t offz, int32_t offy, int32_t offx, void* stream) {
+  if (!act_ok(dlo) || !act_ok(dcat) || dlo->c != dcat->c || dlo->n != dcat->n) return MI355_EINVAL;
+  const long long total = (long long)dlo->n * dlo->d * dlo->h * dlo->w * (dlo->c / 4);
+  LAUNCH(upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)dcat->p, dcat->ld, dcat->n, dcat->d, dcat->h, dcat->w,
+         dcat->c, (float*)dlo->p, dlo->ld, dlo->d, dlo->h, dlo->w, offz, offy, offx);
+  return LAUNCH_CHECK();
+}
+
+// ---- layout ------------------------------------------------------------------------------------
+__global__ void ncdhw_to_ndhwc_kernel(const float* src, float* dst, int dld, int N, int C, long long V) {
+  const long long total = (long long)N * V * C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    // read-coalesced over v for small C: idx = (n*C + c)*V + v
+    const long long v = idx % V; const long long nc = idx / V;
+    const int c = (int)(nc % C); const long long n = nc / C;
+    dst[((size_t)n * V + v) * dld + c] = src[idx];
+  }
+}
+__global__ void ndhwc_to_ncdhw_kernel(const float* src, int sld, float* dst, int N, int C, long long V) {
+  const long long total = (long long)N * V * C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long v = idx % V; const long long nc = idx / V;
+    const int c = (int)(nc % C); const long long n = nc / C;
+    dst[idx] = src[((size_t)n * V + v) * sld + c];
+  }
+}
+
+extern "C" int mi355_ncdhw_to_ndhwc(const float* src, const mi355_act* dst, void* stream) {
+  if (!src || !dst || !dst->p || dst->ld < dst->c) return MI355_EINVAL;
+  const long long V = (long long)dst->d * dst->h * dst->w;
+  LAUNCH(ncdhw_to_ndhwc_kernel, dim3(grid_for((long long)dst->n * V * dst->c)), dim3(256), 0, stream, src, (float*)dst->p, dst->ld, dst->n, dst->c, V);
+  return LAUNCH_CHECK();
+}
+extern "C" int mi355_ndhwc_to_ncdhw(const mi355_act* src, float* dst, void* stream) {
+  if (!dst || !src || !src->p || src->ld < src->c) return MI355_EINVAL;
+  const long long V = (long long)src->d * src->h * src->w;
+  LAUNCH(ndhwc_to_ncdhw_kernel, dim3(grid_for((long long)src->n * V * src->c)), dim3(256), 0, stream, (const float*)src->p, src->ld, dst, src->n, src->c, V);
+  return LAUNCH_CHECK();
+}
+
+// ---- add / channel scale ---------------------------------------------------------------------------
+__global__ void add_kernel(const float* a, int ald, const float* b, int bld, float* y, int yld, long long NV, int C) {
+  const int Q = C / 4;
+  const long long total = NV * Q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % Q); const long long v = idx / Q;
+    const float4 av = *reinterpret_cast<const float4*>(a + (size_t)v * ald + 4 * q);
+    const float4 bv = *reinterpret_cast<const float4*>(b + (size_t)v * bld + 4 * q);
+    *reinterpret_cast<float4*>(y + (size_t)v * yld + 4 * q) = make_float4(av.x + bv.x, av.y + bv.y, av.z + bv.z, av.w + bv.w);
+  }
+}
+__global__ void chscale_kernel(const float* x, int xld, const float* s, float* y, int yld, long long V, int N, int C) {
+  const int Q = C / 4;
+  const long long total = (long long)N * V * Q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % Q); const long long nv = idx / Q; const int n = (int)(nv / V);
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)nv * xld + 4 * q);
+    const float4 sv = *reinterpret_cast<const float4*>(s + (size_t)n * C + 4 * q);
+    *reinterpret_cast<float4*>(y + (size_t)nv * yld + 4 * q) = make_float4(xv.x * sv.x, xv.y * sv.y, xv.z * sv.z, xv.w * sv.w);
+  }
+}
+
+static int same_shape(const mi355_act* a, const mi355_act* b) {
+  return a->n == b->n && a->d == b->d && a->h == b->h && a->w == b->w && a->c == b->c;
+}
+
+extern "C" int mi355_add(const mi355_act* a, const mi355_act* b, const mi355_act* y, void* stream) {
+  if (!act_ok(a) || !act_ok(b) || !act_ok(y) || !same_shape(a, b) || !same_shape(a, y)) return MI355_EINVAL;
+  const long long NV = (long long)a->n * a->d * a->h * a->w;
+  LAUNCH(add_kernel, dim3(grid_for(NV * (a->c / 4))), dim3(256), 0, stream, (const float*)a->p, a->ld, (const float*)b->p, b->ld, (float*)y->p, y->ld, NV, a->c);
+  return LAUNCH_CHECK();
+}
+extern "C" int mi355_chscale(const mi355_act* x, const float* chscale, const mi355_act* y, void* stream) {
+  if (!act_ok(x) || !act_ok(y) || !same_shape(x, y) || !chscale) return MI355_EINVAL;
+  const long long V = (long long)x->d * x->h * x->w;
+  LAUNCH(chscale_kernel, dim3(grid_for((long long)x->n * V * (x->c / 4))), dim3(256), 0, stream, (const float*)x->p, x->ld, chscale, (float*)y->p, y->ld, V, x->n, x->c);
+  return LAUNCH_CHECK();
+}
+
+// ---- few-class 1x1x1 projection: NDHWC in, NCDHW logits out ---------------------------------------------
+#define PROJ_MAX_COUT 8
+#define PROJ_MAX_CIN 96
+#define PROJ_TV 128
+
+__global__ void proj_fwd_kernel(const float* x, int xld, const float* w, const float* bias, float* out, int N, long long V, int Cin, int Cout) {
+  DYN_LDS(lds);                    // x tile [PROJ_TV][Cin+1] | w [Cout][Cin]
+  const int XS = Cin + 1;
+  float* lx = lds; float* lw = lds + PROJ_TV * XS;
+  const int tid = threadIdx.x, Q = Cin / 4;
+  for (int i = tid; i < Cout * Cin; i += 256) lw[i] = w[i];
+  const long long tilesPerN = (V + PROJ_TV - 1) / PROJ_TV;
+  const long long ntiles = (long long)N * tilesPerN;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = (int)(tile / tilesPerN); const long long v0 = (tile % tilesPerN) * PROJ_TV;
+    __syncthreads();
+    for (int i = tid; i < PROJ_TV * Q; i += 256) {
+      const int v = i / Q, q = i % Q;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v0 + v < V) val = *reinterpret_cast<const float4*>(x + ((size_t)n * V + v0 + v) * xld + 4 * q);
+      float* d = lx + v * XS + 4 * q; d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+    }
+    __syncthreads();
+    {
+      const int v = tid & (PROJ_TV - 1), h = tid >> 7;   // 256 threads: 128 voxels x 2 class-parities
+      if (v0 + v < V) {
+        float acc[PROJ_MAX_COUT / 2];
+#pragma unroll
+        for (int k = 0; k < PROJ_MAX_COUT / 2; ++k) { const int co = h + 2 * k; acc[k] = (bias && co < Cout) ? bias[co] : 0.f; }
+        for (int ci = 0; ci < Cin; ++ci) {
+          const float xv = lx[v * XS + ci];
+#pragma unroll
+          for (int k = 0; k < PROJ_MAX_COUT / 2; ++k) { const int co = h + 2 * k; if (co < Cout) acc[k] += xv * lw[co * Cin + ci]; }
+        }
+#pragma unroll
+        for (int k = 0; k < PROJ_MAX_COUT / 2; ++k) { const int co = h + 2 * k; if (co < Cout) out[((size_t)n * Cout + co) * V + v0 + v] = acc[k]; }
+      }
+    }
+  }
+}
+
+// dx tile + per-block partial dw/dbias
+__global__ void proj_bwd_kernel(const float* x, int xld, const float* w, const float* dz, float* dx, int dxld, float* ws,
+                                int N, long long V, int Cin, int Cout) {
+  DYN_LDS(lds);                    // x tile [TV][Cin+1] | dz tile [Cout][TV] | w [Cout][Cin]
+  const int XS = Cin + 1;
+  float* lx = lds; float* lz = lx + PROJ_TV * XS; float* lw = lz + PROJ_MAX_COUT * PROJ_TV;
+  const int tid = threadIdx.x, Q = Cin / 4;
+  for (int i = tid; i < Cout * Cin; i += 256) lw[i] = w[i];
+  const int npairs = Cout * Cin + Cout;     // dw entries then dbias entries
+  float part[(PROJ_MAX_COUT * PROJ_MAX_CIN + PROJ_MAX_COUT + 255) / 256];
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(part) / sizeof(float)); ++k) part[k] = 0.f;
+  const long long tilesPerN = (V + PROJ_TV - 1) / PROJ_TV;
+  const long long ntiles = (long long)N * tilesPerN;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = (int)(tile / tilesPerN); const long long v0 = (tile % tilesPerN) * PROJ_TV;
+    __syncthreads();
+    for (int i = tid; i < PROJ_TV * Q; i += 256) {
+      const int v = i / Q, q = i % Q;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v0 + v < V) val = *reinterpret_cast<const float4*>(x + ((size_t)n * V + v0 + v) * xld + 4 * q);
+      float* d = lx + v * XS + 4 * q; d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+    }
+    for (int i = tid; i < Cout * PROJ_TV; i += 256) {
+      const int co = i / PROJ_TV, v = i % PROJ_TV;
+      lz[co * PROJ_TV + v] = (v0 + v < V) ? dz[((size_t)n * Cout + co) * V + v0 + v] : 0.f;
+    }
+    __syncthreads();
+    // partial dw / dbias: entry e -> (co, ci) or bias co
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(part) / sizeof(float)); ++k) {
+      const int e = tid + 256 * k;
+      if (e < npairs) {
+        float s = 0.f;
+        if (e < Cout * Cin) {
+          const int co = e / Cin, ci = e % Cin;
+          for (int v = 0; v < PROJ_TV; ++v) s += lz[co * PROJ_TV + v] * lx[v * XS + ci];
+        } else {
+          const int co = e - Cout * Cin;
+          for (int v = 0; v < PROJ_TV; ++v) s += lz[co * PROJ_TV + v];
+        }
+        part[k] += s;
+      }
+    }
+    // dx for this tile: thread (v = i / Q, quad) computes 4 channels
+    if (dx) {
+      for (int i = tid; i < PROJ_TV * Q; i += 256) {
+        const int v = i / Q, q = i % Q;
+        if (v0 + v >= V) continue;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int co = 0; co < Cout; ++co) {
+          const float g = lz[co * PROJ_TV + v];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += g * lw[co * Cin + 4 * q + e];
+        }
+        *reinterpret_cast<float4*>(dx + ((size_t)n * V + v0 + v) * dxld + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(part) / sizeof(float)); ++k) {
+    const int e = tid + 256 * k;
+    if (e < npairs) ws[(size_t)blockIdx.x * npairs + e] = part[k];
+  }
+}
+
+__global__ void proj_reduce_kernel(const float* ws, int nblocks, int npairs, int ndw, float* dw, float* dbias) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= npairs) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += (double)ws[(size_t)b * npairs + e];
+  if (e < ndw) dw[e] = (float)s;
+  else if (dbias) dbias[e - ndw] = (float)s;
+}
+
+static int proj_blocks(const mi355_act* x) {
+  const long long V = (long long)x->d * x->h * x->w;
+  long long t = (long long)x->n * ((V + PROJ_TV - 1) / PROJ_TV);
+  if (t > 1024) t = 1024;
+  if (t < 1) t = 1;
+  return (int)t;
+}
+
+extern "C" size_t mi355_proj_workspace(const mi355_act* x, int32_t cout) {
+  if (!x) return 0;
+  return (size_t)proj_blocks(x) * ((size_t)cout * x->c + cout) * sizeof(float);
+}
+
+extern "C" int mi355_proj_fwd(const mi355_act* x, const float* w, const float* bias, float* logits, int32_t cout, void* stream) {
+  if (!act_ok(x) || !w || !logits || cout < 1 || cout > PROJ_MAX_COUT || x->c > PROJ_MAX_CIN) return MI355_EINVAL;
+  const long long V = (long long)x->d * x->h * x->w;
+  const size_t lds = ((size_t)PROJ_TV * (x->c + 1) + (size_t)cout * x->c) * sizeof(float);
+  if (lds > 64 * 1024) return MI355_EUNSUPPORTED;
+  int grid = proj_blocks(x) * 8; long long t = (long long)x->n * ((V + PROJ_TV - 1) / PROJ_TV); if (grid > t) grid = (int)t;
+  LAUNCH(proj_fwd_kernel, dim3(grid), dim3(256), lds, stream, (const float*)x->p, x->ld, w, bias, logits, x->n, V, x->c, cout);
+  return LAUNCH_CHECK();
+}
+
+extern "C" int mi355_proj_bwd(const mi355_act* x, const float* w, const float* dlogits, const mi355_act* dx,
+                              float* dw, float* dbias, int32_t cout, void* ws, size_t ws_bytes, void* stream) {
+  if (!act_ok(x) || !w || !dlogits || !dw || !ws || cout < 1 || cout > PROJ_MAX_COUT || x->c > PROJ_MAX_CIN) return MI355_EINVAL;
+  if (dx && (!act_ok(dx) || !same_shape(x, dx))) return MI355_EINVAL;
+  if (ws_bytes < mi355_proj_workspace(x, cout)) return MI355_EWORKSPACE;
+  const long long V = (long long)x->d * x->h * x->w;
+  const size_t lds = ((size_t)PROJ_TV * (x->c + 1) + (size_t)PROJ_MAX_COUT * PROJ_TV + (size_t)cout * x->c) * sizeof(float);
+  if (lds > 64 * 1024) return MI355_EUNSUPPORTED;
+  const int nb = proj_blocks(x);
+  const int npairs = cout * x->c + cout;
+  LAUNCH(proj_bwd_kernel, dim3(nb), dim3(256), lds, stream, (const float*)x->p, x->ld, w, dlogits, dx ? (float*)dx->p : (float*)nullptr,
+         dx ? dx->ld : 0, (float*)ws, x->n, V, x->c, cout);
+  int rc = LAUNCH_CHECK(); if (rc) return rc;
+  LAUNCH(proj_reduce_kernel, dim3(ceil_div(npairs, 128)), dim3(128), 0, stream, (const float*)ws, nb, npairs, cout * x->c, dw, dbias);
+  return LAUNCH_CHECK();
+}

@@ -1,0 +1,236 @@
+"""Thin tensor-level wrappers over the C ABI (include/mi355_unet3d.h).
+
+`Act` is an NDHWC fp32 view: a contiguous torch buffer [N, D, H, W, LD] plus a channel window [c0, c0+c).
+A window narrower than LD is how torch.cat of the reference (segmentation/unet.py:42) is expressed: producers write
+their channel slice of the concat buffer directly.
+
+`Backend` owns a library handle, the stream getter and one growable workspace. The default backend is the HIP library
+on the current CUDA(=HIP) device; it raises if the library is missing. (tests/ may construct a Backend around the CPU
+emulator build of the same sources -- test infrastructure only, never used by the modules of this package.)
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import IN_AFFINE_ACT, IN_PLAIN, IN_ZERO_INSERT, MiAct, MiConvDesc, check
+
+
+class Act:
+    __slots__ = ("buf", "c0", "c")
+
+    def __init__(self, buf, c0=0, c=None):
+        assert buf.dim() == 5 and buf.is_contiguous() and buf.dtype == torch.float32
+        self.buf = buf
+        self.c0 = c0
+        self.c = buf.shape[-1] - c0 if c is None else c
+        assert self.c0 % 4 == 0 and self.c0 + self.c <= buf.shape[-1]
+
+    @property
+    def shape(self):  # logical (n, d, h, w, c)
+        n, d, h, w, _ = self.buf.shape
+        return (n, d, h, w, self.c)
+
+    @property
+    def ld(self):
+        return self.buf.shape[-1]
+
+    def ptr(self):
+        return self.buf.data_ptr() + 4 * self.c0
+
+    def desc(self):
+        n, d, h, w, ld = self.buf.shape
+        return MiAct(self.ptr(), n, d, h, w, self.c, ld)
+
+    def slice(self, c0, c):
+        return Act(self.buf, self.c0 + c0, c)
+
+    def tensor(self):
+        """Logical view as a torch tensor [N, D, H, W, C] (strided)."""
+        return self.buf[..., self.c0:self.c0 + self.c]
+
+    def to_ncdhw(self):
+        return self.tensor().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class Backend:
+    def __init__(self, lib=None, device=None):
+        self.lib = lib if lib is not None else _lib.load_library()
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("3dunetcnn_amd needs an MI355X (no HIP device visible); there is no CPU fallback")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self._ws = None
+
+    # -- plumbing ------------------------------------------------------------------------------------------------
+    def stream(self):
+        if self.device.type == "cuda":
+            return torch.cuda.current_stream(self.device).cuda_stream
+        return 0
+
+    def ws(self, nbytes):
+        if self._ws is None or self._ws.numel() * 4 < nbytes:
+            self._ws = None
+            self._ws = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=torch.float32, device=self.device)
+        return self._ws
+
+    def empty_act(self, n, d, h, w, c, ld=None):
+        return Act(torch.empty(n, d, h, w, ld or c, dtype=torch.float32, device=self.device), 0, c)
+
+    def zeros_act(self, n, d, h, w, c, ld=None):
+        return Act(torch.zeros(n, d, h, w, ld or c, dtype=torch.float32, device=self.device), 0, c)
+
+    # -- weights -------------------------------------------------------------------------------------------------
+    def pack_weight(self, w, mode, out=None):
+        """w: Conv3d weight [O, I, k, k, k] (modes 0, 1) or ConvTranspose3d weight [I, O, k, k, k] (modes 2, 3)."""
+        assert w.is_contiguous() and w.dtype == torch.float32
+        kd = w.shape[2]
+        if mode == 0:
+            cout, cin = w.shape[0], w.shape[1]
+        elif mode == 1:
+            cout, cin = w.shape[1], w.shape[0]
+        elif mode == 2:
+            cout, cin = w.shape[1], w.shape[0]
+        else:
+            cout, cin = w.shape[0], w.shape[1]
+        n = self.lib.mi355_packed_weight_elems(cout, cin, kd, mode)
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=w.device)
+        assert out.numel() >= n
+        check(self.lib.mi355_pack_conv_weight(w.data_ptr(), out.data_ptr(), cout, cin, kd, mode, self.stream()), "pack_conv_weight")
+        return out
+
+    # -- conv ----------------------------------------------------------------------------------------------------
+    def _desc(self, kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep):
+        d = MiConvDesc()
+        d.kd, d.stride, d.pad, d.in_mode, d.act_slope = kd, stride, pad, in_mode, slope
+        d.in_scale, d.in_shift, d.bias = _p(scale), _p(shift), _p(bias)
+        if residual is not None:
+            d.residual, d.residual_ld = residual.ptr(), residual.ld
+        d.out_chscale = _p(chscale)
+        d.off_z, d.off_y, d.off_x = off
+        d.out_d, d.out_h, d.out_w = out_dhw
+        keep.extend([scale, shift, bias, residual, chscale])
+        return d
+
+    def conv_fwd(self, x, wp, y, kd, stride=1, pad=None, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, bias=None,
+                 residual=None, chscale=None, off=(0, 0, 0), out_dhw=None):
+        pad = kd // 2 if pad is None else pad
+        if out_dhw is None:
+            out_dhw = y.shape[1:4]
+        keep = []
+        d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep)
+        xd, yd = x.desc(), y.desc()
+        check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wp.data_ptr(), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
+
+    def conv_wgrad(self, x, dy, dw, kd, stride=1, pad=None, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None):
+        pad = kd // 2 if pad is None else pad
+        keep = []
+        d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, None, None, None, (0, 0, 0), dy.shape[1:4], keep)
+        xd, dyd = x.desc(), dy.desc()
+        nbytes = self.lib.mi355_conv3d_wgrad_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))
+        if nbytes == 0:
+            raise RuntimeError("conv3d_wgrad: unsupported configuration")
+        ws = self.ws(nbytes)
+        assert dw.is_contiguous()
+        check(self.lib.mi355_conv3d_wgrad(ctypes.byref(xd), ctypes.byref(dyd), dw.data_ptr(), ctypes.byref(d), ws.data_ptr(),
+                                          ws.numel() * 4, self.stream()), "conv3d_wgrad")
+
+    # -- norm ----------------------------------------------------------------------------------------------------
+    def gn_stats(self, x, groups, eps, gamma, beta):
+        n, c = x.shape[0], x.c
+        mean_rstd = torch.empty(n, groups, 2, dtype=torch.float32, device=self.device)
+        scale = torch.empty(n, c, dtype=torch.float32, device=self.device)
+        shift = torch.empty(n, c, dtype=torch.float32, device=self.device)
+        xd = x.desc()
+        ws = self.ws(self.lib.mi355_gn_workspace(ctypes.byref(xd)))
+        check(self.lib.mi355_gn_stats(ctypes.byref(xd), groups, eps, _p(gamma), _p(beta), mean_rstd.data_ptr(), scale.data_ptr(),
+                                      shift.data_ptr(), ws.data_ptr(), ws.numel() * 4, self.stream()), "gn_stats")
+        return mean_rstd, scale, shift
+
+    def gn_act_bwd(self, x, dA, dx, groups, slope, gamma, mean_rstd, scale, shift, dgamma, dbeta, addend=None):
+        xd, dad, dxd = x.desc(), dA.desc(), dx.desc()
+        ws = self.ws(self.lib.mi355_gn_workspace(ctypes.byref(xd)))
+        check(self.lib.mi355_gn_act_bwd(ctypes.byref(xd), ctypes.byref(dad), ctypes.byref(dxd),
+                                        None if addend is None else addend.ptr(), 0 if addend is None else addend.ld,
+                                        groups, slope, _p(gamma), mean_rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                        _p(dgamma), _p(dbeta), ws.data_ptr(), ws.numel() * 4, self.stream()), "gn_act_bwd")
+
+    # -- resample / layout / pointwise ---------------------------------------------------------------------------
+    def upsample2x_fwd(self, lo, cat, off):
+        a, b = lo.desc(), cat.desc()
+        check(self.lib.mi355_upsample2x_fwd(ctypes.byref(a), ctypes.byref(b), off[0], off[1], off[2], self.stream()), "upsample2x_fwd")
+
+    def upsample2x_bwd(self, dcat, dlo, off):
+        a, b = dcat.desc(), dlo.desc()
+        check(self.lib.mi355_upsample2x_bwd(ctypes.byref(a), ctypes.byref(b), off[0], off[1], off[2], self.stream()), "upsample2x_bwd")
+
+    def ncdhw_to_ndhwc(self, src, dst):
+        assert src.is_contiguous() and src.dtype == torch.float32
+        d = dst.desc()
+        check(self.lib.mi355_ncdhw_to_ndhwc(src.data_ptr(), ctypes.byref(d), self.stream()), "ncdhw_to_ndhwc")
+
+    def ndhwc_to_ncdhw(self, src, dst):
+        assert dst.is_contiguous() and dst.dtype == torch.float32
+        s = src.desc()
+        check(self.lib.mi355_ndhwc_to_ncdhw(ctypes.byref(s), dst.data_ptr(), self.stream()), "ndhwc_to_ncdhw")
+
+    def add(self, a, b, y):
+        ad, bd, yd = a.desc(), b.desc(), y.desc()
+        check(self.lib.mi355_add(ctypes.byref(ad), ctypes.byref(bd), ctypes.byref(yd), self.stream()), "add")
+
+    def chscale(self, x, s, y):
+        xd, yd = x.desc(), y.desc()
+        check(self.lib.mi355_chscale(ctypes.byref(xd), s.data_ptr(), ctypes.byref(yd), self.stream()), "chscale")
+
+    # -- projection ----------------------------------------------------------------------------------------------
+    def proj_fwd(self, x, w, bias, logits):
+        cout = w.shape[0]
+        xd = x.desc()
+        assert logits.is_contiguous()
+        check(self.lib.mi355_proj_fwd(ctypes.byref(xd), w.data_ptr(), _p(bias), logits.data_ptr(), cout, self.stream()), "proj_fwd")
+
+    def proj_bwd(self, x, w, dlogits, dx, dw, dbias):
+        cout = w.shape[0]
+        xd = x.desc()
+        dxd = dx.desc() if dx is not None else None
+        ws = self.ws(self.lib.mi355_proj_workspace(ctypes.byref(xd), cout))
+        check(self.lib.mi355_proj_bwd(ctypes.byref(xd), w.data_ptr(), dlogits.data_ptr(), ctypes.byref(dxd) if dxd is not None else None,
+                                      dw.data_ptr(), _p(dbias), cout, ws.data_ptr(), ws.numel() * 4, self.stream()), "proj_bwd")
+
+    # -- loss / optimizer ----------------------------------------------------------------------------------------
+    def dice(self, logits, target, sigmoid=True, batch=False, squared_pred=False, smooth_nr=1e-5, smooth_dr=1e-5,
+             want_grad=True, grad_scale=1.0):
+        assert logits.is_contiguous() and target.is_contiguous() and logits.dtype == torch.float32
+        assert target.dtype in (torch.uint8, torch.float32) and target.shape == logits.shape
+        n, c = logits.shape[0], logits.shape[1]
+        vox = logits[0, 0].numel()
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        dlogits = torch.empty_like(logits) if want_grad else None
+        ws = self.ws(self.lib.mi355_dice_workspace(n, c, vox))
+        check(self.lib.mi355_dice_fwd_bwd(logits.data_ptr(), target.data_ptr(), 1 if target.dtype == torch.uint8 else 0, n, c, vox,
+                                          int(sigmoid), int(batch), int(squared_pred), smooth_nr, smooth_dr, loss.data_ptr(),
+                                          _p(dlogits), grad_scale, ws.data_ptr(), ws.numel() * 4, self.stream()), "dice_fwd_bwd")
+        return loss, dlogits
+
+    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+        check(self.lib.mi355_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                                       weight_decay, step, grad_scale, self.stream()), "adam_step")
+
+
+_default = {}
+
+
+def default_backend():
+    """HIP backend for the current device (created on first use; raises without library or GPU)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("3dunetcnn_amd needs an MI355X (no HIP device visible); there is no CPU fallback")
+    dev = torch.cuda.current_device()
+    if dev not in _default:
+        _default[dev] = Backend()
+    return _default[dev]

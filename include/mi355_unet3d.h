@@ -1,0 +1,156 @@
+/* mi355_unet3d.h -- C ABI of libmi355unet3d.so (gfx950 / MI355X only).
+ *
+ * The reference (ellisdg/3DUnetCNN) has no native layer: its hot path is torch ATen ops called from
+ *   unet3d/models/pytorch/classification/myronenko.py:17-21,47-58   (GroupNorm -> ReLU -> Conv3d, residual add)
+ *   unet3d/models/pytorch/classification/resnet.py:12-22            (conv3x3x3 / conv1x1x1, bias=False)
+ *   unet3d/models/pytorch/segmentation/unet.py:27-44                (upsample -> pad -> cat)
+ *   unet3d/models/pytorch/classification/decoder.py:99-106          (ConvTranspose3d k3 s2 p1 | 1x1x1 + trilinear x2)
+ *   unet3d/train/training_utils.py:59-72,101-112                    (fwd -> criterion -> backward -> optimizer.step)
+ * Each entry point below names the ATen call(s) it replaces. SURVEY.md section 8(b) is the contract.
+ *
+ * Conventions
+ *  - All activations are fp32, NDHWC ("channels last 3d") views: element (n,z,y,x,c) lives at
+ *    p[(((n*D+z)*H+y)*W+x)*ld + c], ld >= C, ld % 4 == 0, p 16-byte aligned. ld > C is how the
+ *    skip-concat is expressed: producers write straight into a channel slice of the concat buffer.
+ *  - Ownership: the caller owns every buffer including workspaces; the library never allocates
+ *    device memory and keeps no global mutable state.
+ *  - Async: every call only enqueues work on `stream` (a hipStream_t passed as void*); no call
+ *    synchronises. Re-entrant; one thread per device or one process per device are both fine.
+ *  - Errors: 0 on success, negative mi355 status otherwise (no C++ exceptions cross the boundary).
+ */
+#ifndef MI355_UNET3D_H
+#define MI355_UNET3D_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_STATUS_OK 0
+#define MI355_STATUS_EINVAL (-1)       /* bad shape / alignment / null pointer */
+#define MI355_STATUS_EUNSUPPORTED (-2) /* combination not implemented */
+#define MI355_STATUS_ELAUNCH (-3)      /* hipGetLastError() != hipSuccess after launch */
+#define MI355_STATUS_EWORKSPACE (-4)   /* workspace too small */
+
+/* NDHWC fp32 activation view. */
+typedef struct mi355_act {
+  void* p;
+  int32_t n, d, h, w, c, ld;
+} mi355_act;
+
+/* Input-side fusion of the conv kernels. */
+#define MI355_IN_PLAIN 0       /* conv reads x as is */
+#define MI355_IN_AFFINE_ACT 1  /* conv reads act(scale[n,c]*x + shift[n,c]) : fused GroupNorm/InstanceNorm apply + (Leaky)ReLU */
+#define MI355_IN_ZERO_INSERT 2 /* conv reads the x2 zero-inserted x : ConvTranspose3d(k3,s2,p1) fwd and stride-2 dgrad */
+
+typedef struct mi355_conv_desc {
+  int32_t kd;        /* cubic kernel extent: 1 or 3 */
+  int32_t stride;    /* 1 or 2 (applies to IN_PLAIN / IN_AFFINE_ACT) */
+  int32_t pad;       /* front zero padding per axis (kd/2 for the reference's convs) */
+  int32_t in_mode;   /* MI355_IN_* */
+  float act_slope;   /* IN_AFFINE_ACT: 0 -> ReLU (myronenko.py:13), 0.01 -> LeakyReLU (DynUNet) */
+  const float* in_scale; /* [n][cin]  IN_AFFINE_ACT */
+  const float* in_shift; /* [n][cin]  IN_AFFINE_ACT */
+  const float* bias;     /* [cout] or NULL (ConvTranspose3d / DynUNet output block keep a bias) */
+  const float* residual; /* NULL or NDHWC tensor with the logical output shape, added in the epilogue (myronenko.py:56) */
+  int32_t residual_ld;
+  const float* out_chscale; /* NULL or [n][cout]: per-(n,channel) scale after the residual add = Dropout3d mask/(1-p) (myronenko.py:78-79) */
+  /* output window: logical output voxel (z,y,x) is stored at (z+off_z, y+off_y, x+off_x) of y when that
+     lies inside y's (d,h,w); this is F.pad with positive (zero fill, caller pre-zeroes) or negative (crop)
+     amounts, unet.py:34-40. */
+  int32_t off_z, off_y, off_x;
+  int32_t out_d, out_h, out_w; /* logical output extent (before the window shift) */
+} mi355_conv_desc;
+
+/* ---- weight packing -------------------------------------------------------------------------- */
+/* Packed layout consumed by mi355_conv3d_fwd: wp[tap][cinP/4][coutP][4], cinP = roundup(cin,8),
+ * coutP = roundup(cout,32), zero filled. mode 0: forward pack of a Conv3d weight (OIDHW, resnet.py:12-22).
+ * mode 1: dgrad pack of the same weight (taps flipped, roles of ci/co swapped) so that dgrad is run by
+ * mi355_conv3d_fwd on dy. mode 2: forward pack of a ConvTranspose3d weight (IODHW, decoder.py:99-102);
+ * mode 3: dgrad pack of a ConvTranspose3d weight (= plain stride-2 correlation of dy). */
+size_t mi355_packed_weight_elems(int32_t cout, int32_t cin, int32_t kd, int32_t mode);
+int mi355_pack_conv_weight(const float* w, float* wp, int32_t cout, int32_t cin, int32_t kd, int32_t mode, void* stream);
+
+/* ---- convolution ------------------------------------------------------------------------------ */
+/* Replaces torch.nn.Conv3d.forward (F.conv3d) for k in {1,3}, stride in {1,2}, bias-free or biased, with the
+ * GroupNorm-apply + ReLU prologue and the residual / dropout epilogue fused; also runs dgrad (packed mode 1/3)
+ * and ConvTranspose3d forward (packed mode 2 + MI355_IN_ZERO_INSERT). fp32 in, fp32 accumulate on
+ * v_mfma_f32_32x32x2_f32 (exact fp32). */
+int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* desc, void* stream);
+
+/* Weight gradient dw[co][ci][tap] (OIDHW, written not accumulated) =
+ *   sum_{n,q} dy[n,q,co] * in(x)[n, stride*q + tap - pad, ci]           (autograd of F.conv3d wrt weight)
+ * with the same input-side fusion as the forward (desc->in_mode PLAIN or AFFINE_ACT). Two-pass, deterministic:
+ * per-workgroup partial slabs in `ws` then a reduction. ws_bytes from mi355_conv3d_wgrad_workspace. */
+size_t mi355_conv3d_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* desc);
+int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* desc,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* ---- GroupNorm / InstanceNorm ----------------------------------------------------------------- */
+/* Statistics of torch.nn.GroupNorm(G, C, eps, affine) (myronenko.py:23-31) / InstanceNorm3d (G == C):
+ * writes mean_rstd[n][g][2] and the folded per-(n,c) scale = gamma*rstd, shift = beta - mean*gamma*rstd
+ * that the next conv applies in its prologue. ws: >= mi355_gn_workspace(x) bytes. */
+size_t mi355_gn_workspace(const mi355_act* x);
+int mi355_gn_stats(const mi355_act* x, int32_t groups, float eps, const float* gamma, const float* beta,
+                   float* mean_rstd, float* scale, float* shift, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of act(GroupNorm(x)) given dA = dLoss/d(act output):
+ *   du = dA * act'(u), dgamma[c] = sum du*xhat, dbeta[c] = sum du,
+ *   dx = rstd*(gamma*du - mean_g(gamma*du) - xhat*mean_g(gamma*du*xhat)) (+ addend if not NULL)
+ * dgamma/dbeta are written (not accumulated). dx may alias dA. */
+int mi355_gn_act_bwd(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const float* addend, int32_t addend_ld,
+                     int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
+                     const float* scale, const float* shift, float* dgamma, float* dbeta,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ---- upsample + pad + concat ------------------------------------------------------------------ */
+/* F.interpolate(scale_factor=2, mode="trilinear", align_corners=False) (decoder.py:105-106) followed by
+ * F.pad to the skip size (unet.py:34-40) and the "upsampled channels first" half of torch.cat (unet.py:42):
+ * writes channels [0, lo.c) of `cat` (cat->c == lo->c, cat->ld = total channels); voxels of cat outside the
+ * shifted window are zero filled. off_* = diff//2 per axis (python floor division, may be -1 = crop). */
+int mi355_upsample2x_fwd(const mi355_act* lo, const mi355_act* cat, int32_t off_z, int32_t off_y, int32_t off_x, void* stream);
+/* Transposed operation: dlo (written) from the channel slice dcat. */
+int mi355_upsample2x_bwd(const mi355_act* dcat, const mi355_act* dlo, int32_t off_z, int32_t off_y, int32_t off_x, void* stream);
+
+/* ---- layout at the module boundary ------------------------------------------------------------ */
+/* NCDHW contiguous (the reference's layout, training_utils.py:109) <-> NDHWC view. */
+int mi355_ncdhw_to_ndhwc(const float* src, const mi355_act* dst, void* stream);
+int mi355_ndhwc_to_ncdhw(const mi355_act* src, float* dst, void* stream);
+/* y = a + b (NDHWC views with possibly different ld); y may alias a. */
+int mi355_add(const mi355_act* a, const mi355_act* b, const mi355_act* y, void* stream);
+/* y[n,v,c] = x[n,v,c] * chscale[n][c]  (Dropout3d backward / standalone forward). y may alias x. */
+int mi355_chscale(const mi355_act* x, const float* chscale, const mi355_act* y, void* stream);
+
+/* ---- 1x1x1 projection to a few classes -------------------------------------------------------- */
+/* final_convolution (variational.py:59-60; unet.py:50) and DynUNet's output block: Conv3d(cin -> cout<=8, k=1),
+ * reading NDHWC and writing the logits directly in the reference's NCDHW layout. w is OIDHW = [cout][cin]. */
+int mi355_proj_fwd(const mi355_act* x, const float* w, const float* bias, float* logits_ncdhw, int32_t cout, void* stream);
+/* backward: dx (NDHWC, written), dw[cout][cin] and dbias[cout] (written). ws >= mi355_proj_workspace bytes. */
+size_t mi355_proj_workspace(const mi355_act* x, int32_t cout);
+int mi355_proj_bwd(const mi355_act* x, const float* w, const float* dlogits_ncdhw, const mi355_act* dx,
+                   float* dw, float* dbias, int32_t cout, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- Dice loss -------------------------------------------------------------------------------- */
+/* monai.losses.DiceLoss as configured by examples/brats2020/brats2020_config.json:112-116 (sigmoid=True,
+ * include_background=True, smooth_nr=smooth_dr=1e-5, reduction="mean"), plus `batch` and `squared_pred`.
+ * logits fp32 NCDHW, target uint8 or fp32 NCDHW (target_is_u8). Writes loss[0] and, if dlogits != NULL,
+ * dloss/dlogits (scaled by grad_scale). stats: [n*c*3] floats scratch kept for inspection (I, sum p, sum y). */
+size_t mi355_dice_workspace(int32_t n, int32_t c, int64_t voxels);
+int mi355_dice_fwd_bwd(const float* logits, const void* target, int32_t target_is_u8, int32_t n, int32_t c, int64_t voxels,
+                       int32_t sigmoid, int32_t batch, int32_t squared_pred, float smooth_nr, float smooth_dr,
+                       float* loss, float* dlogits, float grad_scale, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- optimizer -------------------------------------------------------------------------------- */
+/* torch.optim.Adam(lr, betas, eps, weight_decay=0, amsgrad=False).step() (script_utils.py:80-81) over one flat
+ * parameter buffer; grad is multiplied by grad_scale first (1/world_size after the RCCL sum). step is 1-based. */
+int mi355_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+
+/* Library / build identification: returns e.g. "mi355_unet3d gfx950 <version>". */
+const char* mi355_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_UNET3D_H */

@@ -1,0 +1,242 @@
+"""Per-op parity cases shared by the CPU-emulator tests (test_ops_emu.py, small sizes) and the GPU tests
+(test_ops_gpu.py). Each case runs an op through the C ABI (via 3dunetcnn_amd.ops.Backend) and compares with the
+torch-CPU oracle (oracle/torch_ops.py). Tolerance: 1e-3 relative (max|a-b| / max|b|), BASELINE.json north_star;
+the fp32 MFMA path is normally ~1e-6."""
+import importlib
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import torch_ops as O  # noqa: E402
+
+ops = importlib.import_module("3dunetcnn_amd.ops")
+Act = ops.Act
+TOL = 1e-3
+
+
+def rel_err(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def to_act(be, t, ld=None, c0=0):
+    """NCDHW cpu tensor -> Act on the backend device with leading dimension ld and channel offset c0."""
+    n, c, d, h, w = t.shape
+    ld = ld or c
+    buf = torch.full((n, d, h, w, ld), 7.0, dtype=torch.float32)  # poison other channels
+    buf[..., c0:c0 + c] = t.permute(0, 2, 3, 4, 1)
+    return Act(buf.to(be.device).contiguous(), c0, c)
+
+
+def from_act(a):
+    return a.tensor().detach().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def dev(be, t):
+    return None if t is None else t.to(be.device).contiguous()
+
+
+def case_conv_fwd(be, n, cin, cout, dhw, kd=3, stride=1, norm=False, groups=None, slope=0.0, residual=False, chscale=False,
+                  bias=False, xld=None, yld=None, yc0=0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dhw
+    x = torch.randn(n, cin, d, h, w, generator=g)
+    wt = torch.randn(cout, cin, kd, kd, kd, generator=g) * (1.0 / (cin * kd ** 3) ** 0.5)
+    gamma = beta = None
+    normspec = None
+    if norm:
+        groups = groups or (8 if cin >= 8 and cin % 8 == 0 else cin)
+        gamma = torch.rand(cin, generator=g) + 0.5
+        beta = torch.randn(cin, generator=g) * 0.3
+        normspec = (groups, gamma, beta, 1e-5, slope)
+    b = torch.randn(cout, generator=g) if bias else None
+    pad = kd // 2
+    od, oh, ow = [(s + 2 * pad - kd) // stride + 1 for s in dhw]
+    res = torch.randn(n, cout, od, oh, ow, generator=g) if residual else None
+    cs = (torch.rand(n, cout, generator=g) > 0.3).float() * 1.25 if chscale else None
+    ref = O.conv_block(x, wt, stride, pad, normspec, b, res, cs)
+
+    xa = to_act(be, x, xld)
+    ya = to_act(be, torch.zeros(n, cout, od, oh, ow), yld, yc0)
+    wp = be.pack_weight(dev(be, wt), 0)
+    kw = {}
+    if norm:
+        mr, sc, sh = be.gn_stats(xa, groups, 1e-5, dev(be, gamma), dev(be, beta))
+        kw = dict(in_mode=ops.IN_AFFINE_ACT, slope=slope, scale=sc, shift=sh)
+    ra = to_act(be, res) if residual else None
+    be.conv_fwd(xa, wp, ya, kd, stride, pad, bias=dev(be, b), residual=ra, chscale=dev(be, cs), **kw)
+    out = from_act(ya)
+    e = rel_err(out, ref)
+    # untouched channels of a wider concat buffer must keep the poison value
+    if yld and yld > cout:
+        other = torch.ones(yld, dtype=torch.bool)
+        other[yc0:yc0 + cout] = False
+        assert bool((ya.buf.cpu()[..., other] == 7.0).all()), "conv wrote outside its channel slice"
+    return e
+
+
+def case_conv_dgrad(be, n, cin, cout, dhw, stride=1, seed=1):
+    """dgrad through mi355_conv3d_fwd with the mode-1 pack (stride 1) / zero-insert (stride 2)."""
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dhw
+    x = torch.randn(n, cin, d, h, w, generator=g, requires_grad=True)
+    wt = torch.randn(cout, cin, 3, 3, 3, generator=g) * (1.0 / (cin * 27) ** 0.5)
+    y = F.conv3d(x, wt, None, stride=stride, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    dya = to_act(be, dy)
+    dxa = to_act(be, torch.zeros(n, cin, d, h, w))
+    wpd = be.pack_weight(dev(be, wt), 1)
+    if stride == 1:
+        be.conv_fwd(dya, wpd, dxa, 3, 1, 1)
+    else:
+        be.conv_fwd(dya, wpd, dxa, 3, 1, 1, in_mode=ops.IN_ZERO_INSERT, out_dhw=(d, h, w))
+    return rel_err(from_act(dxa), dx_ref)
+
+
+def case_conv_wgrad(be, n, cin, cout, dhw, kd=3, stride=1, norm=False, slope=0.0, seed=2):
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dhw
+    x = torch.randn(n, cin, d, h, w, generator=g)
+    wt = (torch.randn(cout, cin, kd, kd, kd, generator=g) * 0.1).requires_grad_(True)
+    normspec = None
+    gamma = beta = None
+    groups = 8 if cin >= 8 and cin % 8 == 0 else cin
+    if norm:
+        gamma = torch.rand(cin, generator=g) + 0.5
+        beta = torch.randn(cin, generator=g) * 0.3
+        normspec = (groups, gamma, beta, 1e-5, slope)
+    pad = kd // 2
+    y = O.conv_block(x, wt, stride, pad, normspec)
+    dy = torch.randn(y.shape, generator=g)
+    (dw_ref,) = torch.autograd.grad(y, wt, dy)
+    xa, dya = to_act(be, x), to_act(be, dy)
+    dw = torch.full(wt.shape, 3.0, dtype=torch.float32, device=be.device)
+    kw = {}
+    if norm:
+        mr, sc, sh = be.gn_stats(xa, groups, 1e-5, dev(be, gamma), dev(be, beta))
+        kw = dict(in_mode=ops.IN_AFFINE_ACT, slope=slope, scale=sc, shift=sh)
+    be.conv_wgrad(xa, dya, dw, kd, stride, pad, **kw)
+    return rel_err(dw, dw_ref)
+
+
+def case_gn(be, n, c, dhw, groups, slope=0.0, ld=None, seed=3):
+    """stats + act(GN) backward (incl. addend) against autograd of F.group_norm -> (leaky)relu."""
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dhw
+    x = (torch.randn(n, c, d, h, w, generator=g) * 1.7 + 0.4).requires_grad_(True)
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(c, generator=g) * 0.3).requires_grad_(True)
+    a = O.norm_act(x, groups, gamma, beta, 1e-5, slope)
+    dA = torch.randn(a.shape, generator=g)
+    add = torch.randn(a.shape, generator=g)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(a, (x, gamma, beta), dA)
+    dx_ref = dx_ref + add
+    xa = to_act(be, x.detach(), ld)
+    mr, sc, sh = be.gn_stats(xa, groups, 1e-5, dev(be, gamma.detach()), dev(be, beta.detach()))
+    xd = x.detach()
+    xg = xd.reshape(n, groups, -1)
+    mean_ref = xg.mean(-1)
+    rstd_ref = (xg.var(-1, unbiased=False) + 1e-5).rsqrt()
+    e_stats = max(rel_err(mr[..., 0], mean_ref), rel_err(mr[..., 1], rstd_ref))
+    dAa = to_act(be, dA)
+    dxa = to_act(be, torch.zeros_like(dA))
+    dgam = torch.empty(c, device=be.device)
+    dbet = torch.empty(c, device=be.device)
+    be.gn_act_bwd(xa, dAa, dxa, groups, slope, dev(be, gamma.detach()), mr, sc, sh, dgam, dbet, addend=to_act(be, add))
+    return dict(stats=e_stats, dx=rel_err(from_act(dxa), dx_ref), dgamma=rel_err(dgam, dg_ref), dbeta=rel_err(dbet, db_ref))
+
+
+def case_upsample(be, n, c, lo_dhw, target_dhw, c_skip=8, seed=4):
+    g = torch.Generator().manual_seed(seed)
+    lo = torch.randn(n, c, *lo_dhw, generator=g, requires_grad=True)
+    up = O.upsample_pad(lo, target_dhw)
+    dcat = torch.randn(n, c + c_skip, *target_dhw, generator=g)
+    (dlo_ref,) = torch.autograd.grad(up, lo, dcat[:, :c])
+    off = tuple((t - 2 * l) // 2 for t, l in zip(target_dhw, lo_dhw))
+    loa = to_act(be, lo.detach())
+    cat = to_act(be, torch.zeros(n, c, *target_dhw), ld=c + c_skip, c0=0)
+    be.upsample2x_fwd(loa, cat, off)
+    e_f = rel_err(from_act(cat), up)
+    dcata = to_act(be, dcat).slice(0, c)
+    dloa = to_act(be, torch.zeros_like(lo.detach()))
+    be.upsample2x_bwd(dcata, dloa, off)
+    return dict(fwd=e_f, bwd=rel_err(from_act(dloa), dlo_ref))
+
+
+def case_proj(be, n, cin, cout, dhw, bias=False, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, *dhw, generator=g, requires_grad=True)
+    w = (torch.randn(cout, cin, 1, 1, 1, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(cout, generator=g).requires_grad_(True) if bias else None
+    y = F.conv3d(x, w, b)
+    dy = torch.randn(y.shape, generator=g)
+    grads = torch.autograd.grad(y, (x, w) + ((b,) if bias else ()), dy)
+    xa = to_act(be, x.detach())
+    logits = torch.empty(n, cout, *dhw, device=be.device)
+    be.proj_fwd(xa, dev(be, w.detach().reshape(cout, cin)), dev(be, b.detach()) if bias else None, logits)
+    dxa = to_act(be, torch.zeros_like(x.detach()))
+    dw = torch.empty(cout, cin, device=be.device)
+    dbias = torch.empty(cout, device=be.device) if bias else None
+    be.proj_bwd(xa, dev(be, w.detach().reshape(cout, cin)), dev(be, dy), dxa, dw, dbias)
+    out = dict(fwd=rel_err(logits, y), dx=rel_err(from_act(dxa), grads[0]), dw=rel_err(dw, grads[1].reshape(cout, cin)))
+    if bias:
+        out["dbias"] = rel_err(dbias, grads[2])
+    return out
+
+
+def nested_masks(n, dhw, seed=0):
+    """BraTS-like nested binary masks WT >= TC >= ET: three concentric ellipsoids, uint8 [n,3,d,h,w]."""
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dhw
+    zz, yy, xx = torch.meshgrid(torch.arange(d), torch.arange(h), torch.arange(w), indexing="ij")
+    out = torch.zeros(n, 3, d, h, w, dtype=torch.uint8)
+    for i in range(n):
+        cz, cy, cx = [s / 2 + float(torch.rand(1, generator=g) * 2 - 1) * min(8, s / 8) for s in dhw]
+        for k, frac in enumerate((0.30, 0.20, 0.10)):
+            r = ((zz - cz) / (frac * d)) ** 2 + ((yy - cy) / (frac * h)) ** 2 + ((xx - cx) / (frac * w)) ** 2
+            out[i, k] = (r <= 1.0).to(torch.uint8)
+    return out
+
+
+def case_dice(be, n, c, dhw, batch=False, squared=False, u8=True, seed=6):
+    g = torch.Generator().manual_seed(seed)
+    z = (torch.randn(n, c, *dhw, generator=g) * 2).requires_grad_(True)
+    t = nested_masks(n, dhw, seed)[:, :c] if c <= 3 else (torch.rand(n, c, *dhw, generator=g) > 0.7).to(torch.uint8)
+    tt = t if u8 else t.float()
+    ref = O.dice_loss(z, t, True, batch, squared)
+    (dz_ref,) = torch.autograd.grad(ref, z)
+    loss, dz = be.dice(dev(be, z.detach()), dev(be, tt), True, batch, squared)
+    return dict(loss=abs(float(loss.cpu()) - float(ref)) / abs(float(ref)), grad=rel_err(dz, dz_ref))
+
+
+def case_adam(be, count, steps=3, wd=0.0, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.randn(count, generator=g)
+    m = torch.zeros(count)
+    v = torch.zeros(count)
+    pd, md, vd = dev(be, p), dev(be, m), dev(be, v)
+    pr = p.clone()
+    for s in range(1, steps + 1):
+        gr = torch.randn(count, generator=g) * 0.1
+        O.adam_step(pr, gr, m, v, 1e-3, 0.9, 0.999, 1e-8, wd, s)
+        be.adam_step(pd, dev(be, gr), md, vd, 1e-3, 0.9, 0.999, 1e-8, wd, s)
+    return rel_err(pd, pr)
+
+
+def case_layout(be, n, c, dhw, seed=8):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, c, *dhw, generator=g)
+    a = to_act(be, torch.zeros_like(x))
+    be.ncdhw_to_ndhwc(dev(be, x), a)
+    e1 = rel_err(from_act(a), x)
+    back = torch.empty_like(x, device=be.device)
+    be.ndhwc_to_ncdhw(a, back)
+    return max(e1, rel_err(back, x))

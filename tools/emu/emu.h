@@ -1,0 +1,203 @@
+// TEST INFRASTRUCTURE ONLY -- never part of the product path.
+//
+// A tiny CPU emulator for the restricted HIP dialect used by 3dunetcnn_amd/csrc/*.hip.
+// It exists so the kernels' index arithmetic (LDS halo tiles, MFMA fragment maps,
+// epilogues) can be exercised by `pytest -m "not gpu"` in a container without a GPU.
+// The product library (libmi355unet3d.so) is built by hipcc for gfx950 and never
+// includes this file; only tools/emu/build_emu.sh defines MI355_EMU.
+//
+// Model: one OS thread runs one workgroup at a time; every work-item is a ucontext
+// fiber; __syncthreads() and the wave-level collectives (shuffles, MFMA) are
+// counting barriers that yield to the round-robin scheduler. MFMA is emulated as the
+// k-ordered fmaf chain the hardware implements (MI355X guide: "bit-for-bit a k-ordered
+// f32 fmaf chain"), so emulated results match the GPU's bitwise for the f32 MFMA path.
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+#include <atomic>
+#include <algorithm>
+
+struct emu_dim3 { unsigned x, y, z; emu_dim3(unsigned x_=1, unsigned y_=1, unsigned z_=1):x(x_),y(y_),z(z_){} };
+typedef emu_dim3 dim3;
+typedef void* hipStream_t;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __restrict__
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+
+struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x,y,z,w}; }
+static inline float2 make_float2(float x, float y) { return float2{x,y}; }
+typedef float f32x16 __attribute__((vector_size(64)));
+typedef float f32x4  __attribute__((vector_size(16)));
+
+namespace emu {
+
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = false;
+};
+
+struct BlockState {
+  std::vector<Fiber> fibers;
+  ucontext_t sched;
+  int cur = -1;
+  unsigned nthreads = 0;
+  // block barrier
+  unsigned bar_count = 0; unsigned bar_gen = 0;
+  // wave barriers
+  unsigned wbar_count[32]; unsigned wbar_gen[32];
+  // exchange scratch
+  double xchg[2048];
+  float  mfma_a[2048]; float mfma_b[2048];
+  std::function<void()> body;
+  char* dyn_lds = nullptr;
+};
+
+extern thread_local BlockState* g_bs;
+extern thread_local emu_dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+
+inline void set_tid(int t) {
+  g_threadIdx.x = t % g_blockDim.x;
+  g_threadIdx.y = (t / g_blockDim.x) % g_blockDim.y;
+  g_threadIdx.z = t / (g_blockDim.x * g_blockDim.y);
+}
+
+inline void yield() {
+  BlockState* bs = g_bs;
+  int me = bs->cur;
+  swapcontext(&bs->fibers[me].ctx, &bs->sched);
+}
+
+inline void block_barrier() {
+  BlockState* bs = g_bs;
+  unsigned gen = bs->bar_gen;
+  if (++bs->bar_count == bs->nthreads) { bs->bar_count = 0; bs->bar_gen++; return; }
+  while (bs->bar_gen == gen) yield();
+}
+
+inline int flat_tid() {
+  return g_threadIdx.x + g_blockDim.x * (g_threadIdx.y + g_blockDim.y * g_threadIdx.z);
+}
+
+inline void wave_barrier() {
+  BlockState* bs = g_bs;
+  int w = flat_tid() / 64;
+  unsigned wsize = std::min(64u, bs->nthreads - w * 64);
+  unsigned gen = bs->wbar_gen[w];
+  if (++bs->wbar_count[w] == wsize) { bs->wbar_count[w] = 0; bs->wbar_gen[w]++; return; }
+  while (bs->wbar_gen[w] == gen) yield();
+}
+
+void fiber_entry();
+
+void run_block(BlockState& bs);
+
+template <class F>
+void launch(emu_dim3 grid, emu_dim3 block, size_t lds_bytes, F body) {
+  size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+  unsigned nthr = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), nblocks);
+  const char* env = getenv("MI355_EMU_THREADS");
+  if (env) nthr = std::max(1, std::min<int>(atoi(env), (int)nblocks));
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    BlockState bs;
+    bs.nthreads = block.x * block.y * block.z;
+    bs.fibers.resize(bs.nthreads);
+    for (auto& f : bs.fibers) f.stack = (char*)malloc(128 * 1024);
+    bs.dyn_lds = (char*)aligned_alloc(64, std::max<size_t>(64, (lds_bytes + 63) / 64 * 64));
+    bs.body = body;
+    g_bs = &bs;
+    g_blockDim = block; g_gridDim = grid;
+    for (;;) {
+      size_t b = next.fetch_add(1);
+      if (b >= nblocks) break;
+      g_blockIdx.x = b % grid.x; g_blockIdx.y = (b / grid.x) % grid.y; g_blockIdx.z = b / ((size_t)grid.x * grid.y);
+      run_block(bs);
+    }
+    for (auto& f : bs.fibers) free(f.stack);
+    free(bs.dyn_lds);
+    g_bs = nullptr;
+  };
+  if (nthr <= 1) { worker(); return; }
+  std::vector<std::thread> ts;
+  for (unsigned i = 0; i < nthr; ++i) ts.emplace_back(worker);
+  for (auto& t : ts) t.join();
+}
+
+}  // namespace emu
+
+#define threadIdx (emu::g_threadIdx)
+#define blockIdx  (emu::g_blockIdx)
+#define blockDim  (emu::g_blockDim)
+#define gridDim   (emu::g_gridDim)
+
+static inline void __syncthreads() { emu::block_barrier(); }
+
+#define DYN_LDS(name) float* name = reinterpret_cast<float*>(emu::g_bs->dyn_lds)
+
+template <class T>
+static inline T emu_shfl(T v, int src_lane) {
+  emu::BlockState* bs = emu::g_bs;
+  int t = emu::flat_tid();
+  int wbase = (t / 64) * 64;
+  static_assert(sizeof(T) <= 8, "shfl type");
+  memcpy(&bs->xchg[t], &v, sizeof(T));
+  emu::wave_barrier();
+  T r; memcpy(&r, &bs->xchg[wbase + (src_lane & 63)], sizeof(T));
+  emu::wave_barrier();
+  return r;
+}
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return emu_shfl(v, (emu::flat_tid() % 64) ^ mask); }
+template <class T> static inline T __shfl_down(T v, int d, int width = 64) { (void)width; int l = emu::flat_tid() % 64; return emu_shfl(v, l + d < 64 ? l + d : l); }
+template <class T> static inline T __shfl(T v, int src, int width = 64) { (void)width; return emu_shfl(v, src); }
+
+// D = A(32x2) * B(2x32) + C ; lane l supplies A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+// lane holds C[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] for r in [0,16).
+static inline f32x16 emu_mfma_32x32x2(float a, float b, f32x16 c) {
+  emu::BlockState* bs = emu::g_bs;
+  int t = emu::flat_tid();
+  int wbase = (t / 64) * 64, l = t % 64;
+  bs->mfma_a[t] = a; bs->mfma_b[t] = b;
+  emu::wave_barrier();
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    acc = fmaf(bs->mfma_a[wbase + row], bs->mfma_b[wbase + col], acc);            // k = 0
+    acc = fmaf(bs->mfma_a[wbase + 32 + row], bs->mfma_b[wbase + 32 + col], acc);  // k = 1
+    c[r] = acc;
+  }
+  emu::wave_barrier();
+  return c;
+}
+#define MFMA_32x32x2(a, b, c) emu_mfma_32x32x2(a, b, c)
+
+static inline float atomicAdd(float* p, float v) {
+  std::atomic_ref<float> r(*p); float old = r.load();
+  while (!r.compare_exchange_weak(old, old + v)) {}
+  return old;
+}
+static inline double atomicAdd(double* p, double v) {
+  std::atomic_ref<double> r(*p); double old = r.load();
+  while (!r.compare_exchange_weak(old, old + v)) {}
+  return old;
+}
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+#define LAUNCH(kernel, grid, block, lds, stream, ...) \
+  emu::launch((grid), (block), (lds), [=]() { kernel(__VA_ARGS__); })
+#define LAUNCH_CHECK() 0
