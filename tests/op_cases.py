@@ -40,7 +40,7 @@ def from_act(a):
 
 
 def dev(be, t):
-    return None if t is None else t.to(be.device).contiguous()
+    return None if t is None else t.detach().clone().to(be.device).contiguous()
 
 
 def case_conv_fwd(be, n, cin, cout, dhw, kd=3, stride=1, norm=False, groups=None, slope=0.0, residual=False, chscale=False,
@@ -214,7 +214,7 @@ def case_dice(be, n, c, dhw, batch=False, squared=False, u8=True, seed=6):
     ref = O.dice_loss(z, t, True, batch, squared)
     (dz_ref,) = torch.autograd.grad(ref, z)
     loss, dz = be.dice(dev(be, z.detach()), dev(be, tt), True, batch, squared)
-    return dict(loss=abs(float(loss.cpu()) - float(ref)) / abs(float(ref)), grad=rel_err(dz, dz_ref))
+    return dict(loss=abs(float(loss.cpu()) - float(ref.detach())) / abs(float(ref.detach())), grad=rel_err(dz, dz_ref))
 
 
 def case_adam(be, count, steps=3, wd=0.0, seed=7):

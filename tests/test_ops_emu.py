@@ -1,0 +1,84 @@
+"""Kernel-logic parity on CPU: the SAME kernel sources compiled against tools/emu (fibers + fmaf-chain MFMA) vs the
+torch-CPU oracle. Small shapes only; the real parity gate is test_ops_gpu.py (-m gpu)."""
+import pytest
+
+import op_cases as C
+
+TOL = C.TOL
+
+
+def ok(r):
+    vals = r.values() if isinstance(r, dict) else [r]
+    return all(v < TOL for v in vals)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=8, cout=32, dhw=(6, 7, 9)),
+    dict(n=2, cin=4, cout=32, dhw=(5, 8, 8), norm=True),
+    dict(n=1, cin=32, cout=32, dhw=(9, 10, 12), stride=2),
+    dict(n=2, cin=8, cout=64, dhw=(8, 8, 8), stride=2, norm=True, slope=0.01),
+    dict(n=2, cin=64, cout=32, dhw=(5, 6, 7), kd=1),
+    dict(n=1, cin=32, cout=64, dhw=(9, 6, 7), kd=1, bias=True),
+    dict(n=1, cin=32, cout=32, dhw=(6, 6, 8), norm=True, yld=64, yc0=32, residual=True, chscale=True),
+    dict(n=1, cin=32, cout=96, dhw=(6, 6, 8), xld=64),
+])
+def test_conv_fwd(emu_backend, kw):
+    assert C.case_conv_fwd(emu_backend, **kw) < TOL
+
+
+def test_conv_fwd_big_tile(emu_backend):
+    # >= 131072 voxels selects the 4x8x8 / KC=16 configuration used at 128^3
+    assert C.case_conv_fwd(emu_backend, 1, 8, 64, (8, 16, 128 * 8), residual=True) < TOL
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=32, cout=64, dhw=(6, 7, 8)),
+    dict(n=1, cin=32, cout=32, dhw=(8, 8, 8), stride=2),
+    dict(n=1, cin=8, cout=32, dhw=(7, 9, 8), stride=2),
+])
+def test_conv_dgrad(emu_backend, kw):
+    assert C.case_conv_dgrad(emu_backend, **kw) < TOL
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=2, cin=32, cout=32, dhw=(6, 7, 8)),
+    dict(n=1, cin=4, cout=32, dhw=(8, 8, 8), norm=True),
+    dict(n=1, cin=64, cout=96, dhw=(5, 5, 9), norm=True, slope=0.01),
+    dict(n=1, cin=32, cout=32, dhw=(9, 8, 12), stride=2),
+    dict(n=2, cin=64, cout=32, dhw=(5, 6, 7), kd=1),
+])
+def test_conv_wgrad(emu_backend, kw):
+    assert C.case_conv_wgrad(emu_backend, **kw) < TOL
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=2, c=32, dhw=(5, 6, 7), groups=8),
+    dict(n=2, c=4, dhw=(5, 6, 7), groups=4),
+    dict(n=1, c=96, dhw=(4, 4, 4), groups=96, slope=0.01, ld=128),
+])
+def test_groupnorm(emu_backend, kw):
+    assert ok(C.case_gn(emu_backend, **kw))
+
+
+@pytest.mark.parametrize("lo,tgt", [((3, 4, 5), (6, 8, 10)), ((4, 3, 5), (7, 5, 9)), ((2, 2, 2), (5, 4, 4))])
+def test_upsample(emu_backend, lo, tgt):
+    assert ok(C.case_upsample(emu_backend, 2, 8, lo, tgt))
+
+
+def test_proj(emu_backend):
+    assert ok(C.case_proj(emu_backend, 2, 32, 3, (5, 6, 7)))
+    assert ok(C.case_proj(emu_backend, 1, 64, 3, (9, 6, 7), bias=True))
+
+
+def test_dice(emu_backend):
+    assert ok(C.case_dice(emu_backend, 2, 3, (12, 12, 12)))
+    assert ok(C.case_dice(emu_backend, 2, 3, (12, 12, 12), batch=True, squared=True, u8=False))
+
+
+def test_adam(emu_backend):
+    assert C.case_adam(emu_backend, 1003) < 1e-5
+    assert C.case_adam(emu_backend, 4096, wd=0.01) < 1e-5
+
+
+def test_layout(emu_backend):
+    assert C.case_layout(emu_backend, 2, 4, (5, 6, 7)) == 0.0

@@ -1,0 +1,87 @@
+"""Per-op parity on a real MI355X through the C ABI of libmi355unet3d.so vs the torch-CPU fp32 oracle."""
+import pytest
+
+import op_cases as C
+
+pytestmark = pytest.mark.gpu
+TOL = C.TOL
+
+
+def ok(r):
+    vals = r.values() if isinstance(r, dict) else [r]
+    return all(v < TOL for v in vals)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=8, cout=32, dhw=(6, 7, 9)),
+    dict(n=2, cin=4, cout=32, dhw=(32, 32, 32), norm=True),
+    dict(n=2, cin=32, cout=32, dhw=(48, 64, 64), norm=True, residual=True, chscale=True),     # 4x8x8 tile config
+    dict(n=1, cin=64, cout=32, dhw=(32, 64, 64), norm=True, yld=64, yc0=32),
+    dict(n=1, cin=32, cout=32, dhw=(33, 30, 36), stride=2),
+    dict(n=2, cin=64, cout=64, dhw=(16, 16, 16), stride=2),
+    dict(n=1, cin=128, cout=256, dhw=(16, 16, 16), norm=True),
+    dict(n=2, cin=256, cout=256, dhw=(8, 8, 8), norm=True, residual=True),
+    dict(n=1, cin=96, cout=64, dhw=(12, 20, 9), norm=True, groups=96, slope=0.01),
+    dict(n=2, cin=256, cout=128, dhw=(16, 16, 16), kd=1),
+    dict(n=1, cin=32, cout=64, dhw=(19, 6, 7), kd=1, bias=True),
+    dict(n=1, cin=32, cout=96, dhw=(6, 6, 8), xld=64),
+])
+def test_conv_fwd(hip_backend, kw):
+    assert C.case_conv_fwd(hip_backend, **kw) < TOL
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=32, cout=64, dhw=(16, 17, 18)),
+    dict(n=2, cin=32, cout=32, dhw=(32, 64, 64)),
+    dict(n=1, cin=256, cout=256, dhw=(8, 8, 8)),
+    dict(n=1, cin=32, cout=32, dhw=(32, 32, 32), stride=2),
+    dict(n=1, cin=64, cout=64, dhw=(15, 17, 16), stride=2),
+])
+def test_conv_dgrad(hip_backend, kw):
+    assert C.case_conv_dgrad(hip_backend, **kw) < TOL
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=2, cin=32, cout=32, dhw=(32, 32, 32), norm=True),
+    dict(n=1, cin=4, cout=32, dhw=(32, 32, 32), norm=True),
+    dict(n=1, cin=64, cout=96, dhw=(15, 15, 19), norm=True, slope=0.01),
+    dict(n=2, cin=256, cout=256, dhw=(8, 8, 8), norm=True),
+    dict(n=1, cin=32, cout=32, dhw=(33, 32, 36), stride=2),
+    dict(n=2, cin=256, cout=64, dhw=(16, 16, 16), kd=1),
+])
+def test_conv_wgrad(hip_backend, kw):
+    assert C.case_conv_wgrad(hip_backend, **kw) < TOL
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=2, c=32, dhw=(64, 64, 64), groups=8),
+    dict(n=2, c=4, dhw=(64, 64, 64), groups=4),
+    dict(n=1, c=96, dhw=(8, 8, 8), groups=96, slope=0.01, ld=128),
+    dict(n=2, c=256, dhw=(8, 8, 8), groups=8),
+])
+def test_groupnorm(hip_backend, kw):
+    assert ok(C.case_gn(hip_backend, **kw))
+
+
+@pytest.mark.parametrize("lo,tgt", [((16, 16, 16), (32, 32, 32)), ((8, 7, 9), (15, 13, 17)), ((4, 4, 4), (9, 8, 8))])
+def test_upsample(hip_backend, lo, tgt):
+    assert ok(C.case_upsample(hip_backend, 2, 32, lo, tgt))
+
+
+def test_proj(hip_backend):
+    assert ok(C.case_proj(hip_backend, 2, 32, 3, (32, 32, 32)))
+    assert ok(C.case_proj(hip_backend, 1, 64, 3, (19, 16, 17), bias=True))
+
+
+def test_dice(hip_backend):
+    assert ok(C.case_dice(hip_backend, 2, 3, (64, 64, 64)))
+    assert ok(C.case_dice(hip_backend, 2, 3, (32, 32, 32), batch=True, squared=True, u8=False))
+
+
+def test_adam(hip_backend):
+    assert C.case_adam(hip_backend, 1000003) < 1e-5
+    assert C.case_adam(hip_backend, 4096, wd=0.01) < 1e-5
+
+
+def test_layout(hip_backend):
+    assert C.case_layout(hip_backend, 2, 4, (33, 32, 31)) == 0.0
