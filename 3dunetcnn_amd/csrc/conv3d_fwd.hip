@@ -115,25 +115,32 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
 
     // ---- 27 taps x KC/8 k-groups, B fragments prefetched one tap ahead ----
     const int cq0 = c0 / 4 + half;
+    // k-groups of this chunk that exist (CinP is a multiple of 8 but not necessarily of KC); wave-uniform
+    const int jn = (a.CinP - c0) / 8 < J ? (a.CinP - c0) / 8 : J;
     float4 bcur[J][NT], bnext[J][NT];
 #pragma unroll
     for (int j = 0; j < J; ++j)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        bcur[j][nt] = wp4[((size_t)(0 * CQ + cq0 + 2 * j)) * a.CoutP + co_base + nt * 32 + li];
+      for (int nt = 0; nt < NT; ++nt) {
+        bcur[j][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < jn) bcur[j][nt] = wp4[((size_t)(0 * CQ + cq0 + 2 * j)) * a.CoutP + co_base + nt * 32 + li];
+      }
 
     for (int tap = 0; tap < T; ++tap) {
       const int tn = tap + 1 < T ? tap + 1 : tap;
 #pragma unroll
       for (int j = 0; j < J; ++j)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          bnext[j][nt] = wp4[((size_t)(tn * CQ + cq0 + 2 * j)) * a.CoutP + co_base + nt * 32 + li];
+        for (int nt = 0; nt < NT; ++nt) {
+          bnext[j][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (j < jn) bnext[j][nt] = wp4[((size_t)(tn * CQ + cq0 + 2 * j)) * a.CoutP + co_base + nt * 32 + li];
+        }
 
       const int dz = tap / (KD * KD), dy = (tap / KD) % KD, dx = tap % KD;
       const int toff = ((dz * HY + dy) * HX + dx) * VS;
 #pragma unroll
       for (int j = 0; j < J; ++j) {
+        if (j >= jn) continue;
         float4 af[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const float4*>(lds + abase[mt] + toff + j * 8);

@@ -1,0 +1,475 @@
+"""HipUNet3D: drop-in for the reference's UNet3D (unet3d/models/pytorch/segmentation/unet.py:47-50) on MI355X.
+
+Same constructor kwargs as the reference's config surface (autoencoder/variational.py:37-42), same parameter names,
+shapes (OIDHW) and default initialisation order (so the same torch seed gives the same weights and checkpoints
+interchange), NCDHW fp32 in / NCDHW fp32 logits out, differentiable. The arithmetic is
+entirely the HIP library (include/mi355_unet3d.h): the holder modules below only own parameters and are never called.
+
+Forward graph (reference lines in brackets), all activations NDHWC:
+  encoder level i  : residual blocks [myronenko.py:47-58] = gn_stats -> conv3(GN+ReLU prologue) -> gn_stats ->
+                     conv3(GN+ReLU prologue, + identity | 1x1 shortcut, * Dropout3d mask) ; stride-2 conv3 down
+                     [myronenko.py:104-105, unet.py:8-16]. The level output is written straight into the channel
+                     slice of the decoder's concat buffer (no torch.cat copy).
+  decoder level    : block -> 1x1 conv -> trilinear x2 (or ConvTranspose3d k3 s2 p1) -> pad/crop window -> concat
+                     [unet.py:27-44, decoder.py:99-106].
+  head             : 1x1 projection to n_outputs written as NCDHW [variational.py:59-60, unet.py:50].
+Backward is explicit (no autograd graph inside): wgrad / dgrad (same MFMA conv kernel on flipped packs) /
+GroupNorm+ReLU backward / transposed upsample, parameter gradients written into one flat buffer.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops as _ops
+from ._lib import IN_AFFINE_ACT, IN_PLAIN, IN_ZERO_INSERT
+
+GN_EPS = 1e-5
+
+
+def _groups(planes, norm_groups=8):
+    """GroupNorm group count of the reference block (myronenko.py:23-31)."""
+    if planes < norm_groups or planes % norm_groups:
+        return planes
+    return norm_groups
+
+
+# ---- parameter holders (names == reference attribute names; never called) --------------------------------------
+class _ConvBlock(nn.Module):
+    def __init__(self, cin, cout, stride=1, kernel_size=3):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(_groups(cin), cin)
+        self.conv = nn.Conv3d(cin, cout, kernel_size, stride=stride, padding=kernel_size // 2, bias=False)
+
+
+class _ResBlock(nn.Module):
+    def __init__(self, cin, cout, kernel_size=3):
+        super().__init__()
+        self.conv1 = _ConvBlock(cin, cout, kernel_size=kernel_size)
+        self.conv2 = _ConvBlock(cout, cout, kernel_size=kernel_size)
+        self.sample = nn.Conv3d(cin, cout, 1, bias=False) if cin != cout else None
+
+
+class _Layer(nn.Module):
+    def __init__(self, n_blocks, cin, cout, dropout=None, kernel_size=3):
+        super().__init__()
+        self.blocks = nn.ModuleList()
+        for _ in range(n_blocks):
+            self.blocks.append(_ResBlock(cin, cout, kernel_size))
+            cin = cout
+        self.dropout_p = dropout
+
+
+class _Encoder(nn.Module):
+    def __init__(self, n_features, base_width, layer_blocks, feature_dilation, downsampling_stride, dropout=0.2, kernel_size=3):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        self.downsampling_convolutions = nn.ModuleList()
+        self.widths = []
+        cin = n_features
+        for i, nb in enumerate(layer_blocks):
+            cout = base_width * (feature_dilation ** i)
+            self.layers.append(_Layer(nb, cin, cout, dropout if (dropout and i == 0) else None, kernel_size))
+            if i != len(layer_blocks) - 1:
+                self.downsampling_convolutions.append(
+                    nn.Conv3d(cout, cout, kernel_size, stride=downsampling_stride, padding=kernel_size // 2, bias=False))
+            self.widths.append(cout)
+            cin = cout
+
+
+class _Decoder(nn.Module):
+    def __init__(self, base_width, layer_blocks, feature_reduction_scale, use_transposed_convolutions, kernel_size=3):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        self.pre_upsampling_blocks = nn.ModuleList()
+        self.upsampling_blocks = nn.ModuleList() if use_transposed_convolutions else []
+        self.level_widths = []
+        nl = len(layer_blocks)
+        for i, nb in enumerate(layer_blocks):
+            depth = nl - (i + 1)
+            # MirroredDecoder.calculate_layer_widths (decoder.py:111-122) + UNetDecoder override (unet.py:20-25)
+            if depth > 0:
+                out_w = int(base_width * (feature_reduction_scale ** (depth - 1)))
+                in_w = out_w * feature_reduction_scale
+            else:
+                out_w = in_w = base_width
+            if depth != nl - 1:
+                in_w *= 2
+            self.level_widths.append((in_w, out_w))
+            if depth != 0:
+                self.layers.append(_Layer(nb, in_w, in_w, None, kernel_size))
+                if use_transposed_convolutions:
+                    self.pre_upsampling_blocks.append(nn.Sequential())
+                    self.upsampling_blocks.append(nn.ConvTranspose3d(in_w, out_w, kernel_size, stride=2, padding=1))
+                else:
+                    self.pre_upsampling_blocks.append(nn.Conv3d(in_w, out_w, 1, bias=False))
+            else:
+                self.layers.append(_Layer(nb, in_w, out_w, None, kernel_size))
+
+
+class _Saved:
+    """Activations and statistics a residual block keeps for its backward."""
+    __slots__ = ("x", "h1", "st1", "st2", "out", "chscale")
+
+
+class _UNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        need_grad = any(ctx.needs_input_grad)   # False under torch.no_grad() / for frozen inference
+        logits, saved = model._forward_impl(x, need_grad)
+        ctx.model = model
+        ctx.saved = saved
+        ctx.x_requires_grad = x.requires_grad
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        grads, dx = model._backward_impl(ctx.saved, dlogits.contiguous(), ctx.x_requires_grad)
+        ctx.saved = None
+        return (None, dx) + tuple(grads)
+
+
+class HipUNet3D(nn.Module):
+    def __init__(self, input_shape=None, n_features=1, base_width=32, encoder_blocks=None, decoder_blocks=None,
+                 feature_dilation=2, downsampling_stride=2, interpolation_mode="trilinear", n_outputs=1, layer_widths=None,
+                 decoder_mirrors_encoder=False, activation=None, use_transposed_convolutions=False, kernel_size=3):
+        super().__init__()
+        if layer_widths is not None:
+            # unusable in the reference as well (IndexError at decoder.py:112-114)
+            raise ValueError("layer_widths is not supported (the reference UNet3D raises IndexError for it)")
+        if kernel_size != 3:
+            raise NotImplementedError("HipUNet3D implements the reference default kernel_size=3")
+        if downsampling_stride != 2:
+            raise NotImplementedError("HipUNet3D implements the reference default downsampling_stride=2")
+        if interpolation_mode != "trilinear" and not use_transposed_convolutions:
+            raise NotImplementedError("only trilinear interpolation (reference default) or transposed convolutions")
+        if n_features % 4 != 0:
+            raise NotImplementedError("n_features must be a multiple of 4 (NDHWC float4 rows)")
+        self.input_shape = input_shape
+        self.base_width = base_width
+        self.n_features = n_features
+        self.n_outputs = n_outputs
+        self.use_transposed_convolutions = use_transposed_convolutions
+        if encoder_blocks is None:
+            encoder_blocks = [1, 2, 2, 4]
+        if decoder_mirrors_encoder:
+            decoder_blocks = encoder_blocks
+        elif decoder_blocks is None:
+            decoder_blocks = [1] * len(encoder_blocks)
+        if len(decoder_blocks) != len(encoder_blocks):
+            raise ValueError("decoder_blocks must have one entry per encoder level")
+        self.encoder = _Encoder(n_features, base_width, encoder_blocks, feature_dilation, downsampling_stride, kernel_size=kernel_size)
+        self.decoder = _Decoder(base_width, decoder_blocks, feature_dilation, use_transposed_convolutions, kernel_size)
+        # the reference draws a throw-away final conv (variational.py:54) before UNet3D replaces it (unet.py:50):
+        # reproduce the RNG consumption so the same seed yields the same weights.
+        nn.Conv3d(base_width, n_features, 1, bias=False)
+        self.final_convolution = nn.Conv3d(base_width, n_outputs, 1, bias=False)
+        if activation == "sigmoid":
+            self.activation = nn.Sigmoid()
+        elif activation == "softmax":
+            self.activation = nn.Softmax(dim=1)
+        else:
+            self.activation = None
+        self._be = None
+        self._flat = None          # flat parameter buffer (views are the nn.Parameters)
+        self._flat_grad = None
+        self._packed = {}          # id(param) -> (version, {mode: packed tensor})
+        self._packs_dirty = True
+        self.dropout_generator = None
+
+    # ---- flat parameter storage --------------------------------------------------------------------------------
+    def _params(self):
+        return list(self.parameters())
+
+    def flatten_parameters(self):
+        """(Re)point every nn.Parameter at a slice of one flat device buffer (16-byte aligned slices) so that the fused
+        Adam and the gradient all-reduce run over single contiguous tensors. Idempotent; re-run after .cuda()/.to()."""
+        ps = self._params()
+        dev = ps[0].device
+        offs, total = [], 0
+        for p in ps:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        ok = self._flat is not None and self._flat.device == dev and self._flat.numel() == total and all(
+            p.data_ptr() == self._flat.data_ptr() + 4 * o for p, o in zip(ps, offs))
+        if ok:
+            return self._flat
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o in zip(ps, offs):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+        self._flat = flat
+        self._offsets = offs
+        self._flat_grad = None
+        self._packs_dirty = True
+        return flat
+
+    def flat_grad(self):
+        if self._flat_grad is None or self._flat_grad.device != self._flat.device or self._flat_grad.numel() != self._flat.numel():
+            self._flat_grad = torch.zeros_like(self._flat)
+        return self._flat_grad
+
+    def mark_parameters_updated(self):
+        """Called by optimizers that write the flat buffer through raw pointers (no torch version bump)."""
+        self._packs_dirty = True
+
+    def _packed_weight(self, p, mode):
+        ent = self._packed.get(id(p))
+        if ent is None or ent[0] != p._version or self._packs_dirty_local or ent[2] != p.data_ptr():
+            ent = [p._version, {}, p.data_ptr()]
+            self._packed[id(p)] = ent
+        if mode not in ent[1]:
+            ent[1][mode] = self._be.pack_weight(p.data, mode)
+        return ent[1][mode]
+
+    # ---- forward -----------------------------------------------------------------------------------------------
+    def forward(self, x):
+        if x.device.type != "cuda" and self._be is None:
+            raise RuntimeError("HipUNet3D runs on an MI355X only: move the module and its input to the GPU (.cuda()); "
+                               "there is no CPU fallback")
+        if x.dim() != 5 or x.shape[1] != self.n_features:
+            raise ValueError(f"expected input [N, {self.n_features}, D, H, W], got {tuple(x.shape)}")
+        self.flatten_parameters()
+        y = _UNetFunction.apply(self, x.contiguous().float(), *self._params())
+        if self.activation is not None:
+            y = self.activation(y)
+        return y
+
+    def _block_fwd(self, be, blk, x, out, chscale, keep):
+        """One residual block. x: Act input; out: Act destination (maybe a concat slice)."""
+        n, d, h, w, cin = x.shape
+        cout = blk.conv1.conv.out_channels
+        c1, c2 = blk.conv1, blk.conv2
+        st1 = be.gn_stats(x, c1.norm1.num_groups, GN_EPS, c1.norm1.weight.data, c1.norm1.bias.data)
+        h1 = be.empty_act(n, d, h, w, cout)
+        be.conv_fwd(x, self._packed_weight(c1.conv.weight, 0), h1, 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2])
+        st2 = be.gn_stats(h1, c2.norm1.num_groups, GN_EPS, c2.norm1.weight.data, c2.norm1.bias.data)
+        if blk.sample is not None:
+            idn = be.empty_act(n, d, h, w, cout)
+            be.conv_fwd(x, self._packed_weight(blk.sample.weight, 0), idn, 1)
+        else:
+            idn = x
+        be.conv_fwd(h1, self._packed_weight(c2.conv.weight, 0), out, 3, 1, in_mode=IN_AFFINE_ACT, scale=st2[1], shift=st2[2],
+                    residual=idn, chscale=chscale)
+        if keep:
+            s = _Saved()
+            s.x, s.h1, s.st1, s.st2, s.out, s.chscale = x, h1, st1, st2, out, chscale
+            return s
+        return None
+
+    def _layer_fwd(self, be, layer, x, out_last, keep):
+        """All blocks of a layer; the last block writes into out_last. Returns list of saved blocks."""
+        saved = []
+        nb = len(layer.blocks)
+        n, d, h, w, _ = x.shape
+        for j, blk in enumerate(layer.blocks):
+            cout = blk.conv1.conv.out_channels
+            out = out_last if j == nb - 1 else be.empty_act(n, d, h, w, cout)
+            chscale = None
+            if j == 0 and layer.dropout_p and self.training:
+                # Dropout3d(p) after block 0 (myronenko.py:75-80): per-(n, channel) Bernoulli keep mask / (1-p)
+                p = layer.dropout_p
+                keepmask = torch.rand(n, cout, device=be.device, generator=self.dropout_generator) >= p
+                chscale = keepmask.float() / (1.0 - p)
+            saved.append(self._block_fwd(be, blk, x, out, chscale, keep))
+            x = out
+        return saved
+
+    def _forward_impl(self, x, keep):
+        be = self._be = self._be or _ops.default_backend()
+        self._packs_dirty_local = self._packs_dirty
+        n, _, D, H, W = x.shape
+        enc, dec = self.encoder, self.decoder
+        L = len(enc.layers)
+        # spatial sizes per level (stride-2 k3 p1 conv: ceil(n/2))
+        sizes = [(D, H, W)]
+        for _ in range(L - 1):
+            sizes.append(tuple((s - 1) // 2 + 1 for s in sizes[-1]))
+        xa = be.empty_act(n, D, H, W, self.n_features)
+        be.ncdhw_to_ndhwc(x, xa)
+        # concat buffers for decoder levels: level i (resolution of encoder level i, i < L-1) holds [up | skip]
+        cats = []
+        for i in range(L - 1):
+            up_c = dec.level_widths[L - 2 - i][1]      # out width of the decoder layer feeding this level
+            skip_c = enc.widths[i]
+            d_, h_, w_ = sizes[i]
+            cats.append((be.empty_act(n, d_, h_, w_, up_c + skip_c), up_c, skip_c))
+        saved = {"enc": [], "dec": [], "sizes": sizes, "xa": xa, "cats": cats, "n": n}
+        cur = xa
+        enc_out = []
+        for i, layer in enumerate(enc.layers):
+            d_, h_, w_ = sizes[i]
+            if i < L - 1:
+                cat, up_c, skip_c = cats[i]
+                out = cat.slice(up_c, skip_c)
+            else:
+                out = be.empty_act(n, d_, h_, w_, enc.widths[i])
+            saved["enc"].append(self._layer_fwd(be, layer, cur, out, keep))
+            enc_out.append(out)
+            if i < L - 1:
+                dn = sizes[i + 1]
+                nxt = be.empty_act(n, dn[0], dn[1], dn[2], enc.widths[i])
+                be.conv_fwd(out, self._packed_weight(enc.downsampling_convolutions[i].weight, 0), nxt, 3, 2)
+                cur = nxt
+        # decoder
+        cur = enc_out[-1]
+        for k in range(L - 1):
+            layer = dec.layers[k]
+            lvl = L - 2 - k                      # resolution level this decoder stage upsamples TO
+            in_w, out_w = dec.level_widths[k]
+            d_, h_, w_ = sizes[lvl + 1]
+            lay_out = be.empty_act(n, d_, h_, w_, in_w)
+            sv = self._layer_fwd(be, layer, cur, lay_out, keep)
+            cat, up_c, skip_c = cats[lvl]
+            tgt = sizes[lvl]
+            off = tuple((t - 2 * s) // 2 for t, s in zip(tgt, (d_, h_, w_)))
+            if self.use_transposed_convolutions:
+                up = dec.upsampling_blocks[k]
+                off = tuple((t - (2 * s - 1)) // 2 for t, s in zip(tgt, (d_, h_, w_)))
+                cat.tensor()[..., :up_c].zero_()
+                be.conv_fwd(lay_out, self._packed_weight(up.weight, 2), cat.slice(0, up_c), 3, 1, pad=1, in_mode=IN_ZERO_INSERT,
+                            bias=up.bias.data, off=off, out_dhw=tuple(2 * s - 1 for s in (d_, h_, w_)))
+                pre_out = None
+            else:
+                pre_out = be.empty_act(n, d_, h_, w_, out_w)
+                be.conv_fwd(lay_out, self._packed_weight(dec.pre_upsampling_blocks[k].weight, 0), pre_out, 1)
+                be.upsample2x_fwd(pre_out, cat.slice(0, up_c), off)
+            saved["dec"].append((sv, lay_out, off))
+            cur = cat
+        d_, h_, w_ = sizes[0]
+        last_out = be.empty_act(n, d_, h_, w_, dec.level_widths[-1][1])
+        saved["last"] = self._layer_fwd(be, dec.layers[-1], cur, last_out, keep)
+        saved["last_out"] = last_out
+        logits = torch.empty(n, self.n_outputs, D, H, W, dtype=torch.float32, device=x.device)
+        wf = self.final_convolution.weight
+        be.proj_fwd(last_out, wf.data.reshape(self.n_outputs, -1), None, logits)
+        self._packs_dirty = False
+        self._packs_dirty_local = False
+        return logits, (saved if keep else None)
+
+    # ---- backward ----------------------------------------------------------------------------------------------
+    def _gslice(self, p):
+        o = self._goff[id(p)]
+        return self._gbuf[o:o + p.numel()].view(p.shape)
+
+    def _block_bwd(self, be, blk, s, d_out, need_dx, dx_out=None):
+        """d_out: Act gradient wrt the block output (modified in place by the dropout scale). Returns Act dx or None."""
+        c1, c2 = blk.conv1, blk.conv2
+        n, d, h, w, cin = s.x.shape
+        cout = c1.conv.out_channels
+        if s.chscale is not None:
+            be.chscale(d_out, s.chscale, d_out)
+        st1, st2 = s.st1, s.st2
+        be.conv_wgrad(s.h1, d_out, self._gslice(c2.conv.weight), 3, 1, in_mode=IN_AFFINE_ACT, scale=st2[1], shift=st2[2])
+        dA2 = be.empty_act(n, d, h, w, cout)
+        be.conv_fwd(d_out, self._packed_weight(c2.conv.weight, 1), dA2, 3, 1)
+        be.gn_act_bwd(s.h1, dA2, dA2, c2.norm1.num_groups, 0.0, c2.norm1.weight.data, st2[0], st2[1], st2[2],
+                      self._gslice(c2.norm1.weight), self._gslice(c2.norm1.bias))
+        dh1 = dA2
+        be.conv_wgrad(s.x, dh1, self._gslice(c1.conv.weight), 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2])
+        dA1 = be.empty_act(n, d, h, w, cin)
+        be.conv_fwd(dh1, self._packed_weight(c1.conv.weight, 1), dA1, 3, 1)
+        if blk.sample is not None:
+            be.conv_wgrad(s.x, d_out, self._gslice(blk.sample.weight), 1)
+            d_id = None
+            if need_dx:
+                d_id = be.empty_act(n, d, h, w, cin)
+                be.conv_fwd(d_out, self._packed_weight(blk.sample.weight, 1), d_id, 1)
+        else:
+            d_id = d_out
+        dx = None
+        if need_dx:
+            dx = dx_out if dx_out is not None else dA1
+        be.gn_act_bwd(s.x, dA1, dx if dx is not None else dA1, c1.norm1.num_groups, 0.0, c1.norm1.weight.data, st1[0], st1[1], st1[2],
+                      self._gslice(c1.norm1.weight), self._gslice(c1.norm1.bias), addend=d_id if need_dx else None)
+        return dx
+
+    def _layer_bwd(self, be, layer, saved, d_out, need_dx):
+        for j in range(len(layer.blocks) - 1, -1, -1):
+            d_out = self._block_bwd(be, layer.blocks[j], saved[j], d_out, need_dx or j > 0)
+        return d_out
+
+    def _backward_impl(self, saved, dlogits, need_dx):
+        be = self._be
+        ps = self._params()
+        # fresh flat gradient buffer unless the caller is not accumulating into our previous one
+        gbuf = self.flat_grad()
+        if any(p.grad is not None for p in ps):
+            # autograd will ADD what we return to existing .grad tensors (which may alias the flat buffer): use scratch
+            gbuf = torch.zeros_like(self._flat)
+        self._gbuf = gbuf
+        self._goff = {id(p): o for p, o in zip(ps, self._offsets)}
+        self._packs_dirty_local = False
+        enc, dec = self.encoder, self.decoder
+        L = len(enc.layers)
+        sizes, cats, n = saved["sizes"], saved["cats"], saved["n"]
+        # head
+        last_out = saved["last_out"]
+        wf = self.final_convolution.weight
+        d_last = be.empty_act(*last_out.shape)
+        be.proj_bwd(last_out, wf.data.reshape(self.n_outputs, -1), dlogits, d_last, self._gslice(wf).view(self.n_outputs, -1), None)
+        d_cur = self._layer_bwd(be, dec.layers[-1], saved["last"], d_last, True)   # gradient wrt cats[0] (full width)
+        # decoder, shallow -> deep
+        d_skips = [None] * (L - 1)
+        for k in range(L - 2, -1, -1):
+            lvl = L - 2 - k
+            cat, up_c, skip_c = cats[lvl]
+            sv, lay_out, off = saved["dec"][k]
+            d_cat = d_cur                                   # Act with cat's full channel count
+            d_skips[lvl] = d_cat.slice(up_c, skip_c)
+            in_w, out_w = dec.level_widths[k]
+            d_lay = be.empty_act(*lay_out.shape)
+            if self.use_transposed_convolutions:
+                up = dec.upsampling_blocks[k]
+                d_up = d_cat.slice(0, up_c)
+                # ConvTranspose3d backward: dgrad = stride-2 correlation of the (window of the) output gradient
+                dyw, dshape = self._window(be, d_up, off, tuple(2 * s - 1 for s in lay_out.shape[1:4]))
+                be.conv_fwd(dyw, self._packed_weight(up.weight, 3), d_lay, 3, 2, pad=1)
+                be.conv_wgrad(dyw, lay_out, self._gslice(up.weight), 3, 2, pad=1)
+                self._gslice(up.bias).copy_(dyw.tensor().sum(dim=(0, 1, 2, 3)))
+            else:
+                pre = dec.pre_upsampling_blocks[k]
+                d_pre = be.empty_act(lay_out.shape[0], lay_out.shape[1], lay_out.shape[2], lay_out.shape[3], out_w)
+                be.upsample2x_bwd(d_cat.slice(0, up_c), d_pre, off)
+                be.conv_wgrad(lay_out, d_pre, self._gslice(pre.weight), 1)
+                be.conv_fwd(d_pre, self._packed_weight(pre.weight, 1), d_lay, 1)
+            d_cur = self._layer_bwd(be, dec.layers[k], sv, d_lay, True)
+        # encoder, deep -> shallow; d_cur is the gradient wrt the deepest encoder output
+        dx = None
+        for i in range(L - 1, -1, -1):
+            need = need_dx or i > 0
+            d_in = self._layer_bwd(be, enc.layers[i], saved["enc"][i], d_cur, need)
+            if i > 0:
+                # gradient wrt encoder level i-1 output = dgrad of the stride-2 conv (+ the skip gradient from the concat)
+                dw = enc.downsampling_convolutions[i - 1].weight
+                out_prev = saved["enc"][i - 1][-1].out
+                be.conv_wgrad(out_prev, d_in, self._gslice(dw), 3, 2)
+                dprev = be.empty_act(n, *sizes[i - 1], enc.widths[i - 1])
+                be.conv_fwd(d_in, self._packed_weight(dw, 1), dprev, 3, 1, pad=1, in_mode=IN_ZERO_INSERT,
+                            residual=d_skips[i - 1], out_dhw=sizes[i - 1])
+                d_cur = dprev
+            else:
+                dx = d_in
+        grads = [self._gslice(p) for p in ps]
+        dx_t = None
+        if need_dx and dx is not None:
+            dx_t = torch.empty(n, self.n_features, *sizes[0], dtype=torch.float32, device=dlogits.device)
+            be.ndhwc_to_ncdhw(dx, dx_t)
+        self._gbuf = None
+        return grads, dx_t
+
+    def _window(self, be, d_up, off, win):
+        """Gradient restricted to the F.pad window (unet.py:34-40) as a dense Act of extent `win`."""
+        t = d_up.tensor()
+        sl = []
+        for o, wlen, full in zip(off, win, t.shape[1:4]):
+            lo, hi = max(o, 0), min(o + wlen, full)
+            sl.append(slice(lo, hi))
+        sub = t[:, sl[0], sl[1], sl[2], :]
+        n = t.shape[0]
+        out = be.zeros_act(n, win[0], win[1], win[2], d_up.c)
+        dst = out.tensor()[:, max(-off[0], 0):max(-off[0], 0) + sub.shape[1], max(-off[1], 0):max(-off[1], 0) + sub.shape[2],
+                           max(-off[2], 0):max(-off[2], 0) + sub.shape[3], :]
+        dst.copy_(sub)
+        return out, win
