@@ -37,6 +37,7 @@ SIGNATURES = {
     "mi355_packed_weight_elems": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "mi355_pack_conv_weight": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mi355_conv3d_fwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, POINTER(MiAct), POINTER(MiConvDesc), c_void_p]),
+    "mi355_conv3d_fwd_config": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), POINTER(MiConvDesc), c_char_p, c_size_t]),
     "mi355_conv3d_wgrad_workspace": (c_size_t, [POINTER(MiAct), POINTER(MiAct), POINTER(MiConvDesc)]),
     "mi355_conv3d_wgrad": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), c_void_p, POINTER(MiConvDesc), c_void_p, c_size_t, c_void_p]),
     "mi355_gn_workspace": (c_size_t, [POINTER(MiAct)]),

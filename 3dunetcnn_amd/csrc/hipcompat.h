@@ -6,9 +6,11 @@
 #ifdef MI355_EMU
 #include "emu.h"
 #include <cstring>
+#include <cstdio>
 #else
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <cstdio>
 #include <cmath>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

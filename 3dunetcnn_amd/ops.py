@@ -66,6 +66,7 @@ class Backend:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
         self._ws = None
+        self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
 
     # -- plumbing ------------------------------------------------------------------------------------------------
     def stream(self):
@@ -126,7 +127,22 @@ class Backend:
         keep = []
         d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep)
         xd, yd = x.desc(), y.desc()
+        if self.prof is None:
+            check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wp.data_ptr(), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
+            return
+        # profiling: HIP events on the launch stream around this one kernel, keyed by the kernel's trace name
+        name = ctypes.create_string_buffer(96)
+        self.lib.mi355_conv3d_fwd_config(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d), name, 96)
+        nvox = x.shape[0] * out_dhw[0] * out_dhw[1] * out_dhw[2]
+        flops = 2.0 * nvox * x.c * y.c * kd ** 3
+        if in_mode == IN_ZERO_INSERT:
+            flops /= 8.0   # algorithmic work of a stride-2 transposed conv: 27/8 taps per output voxel on average
+        byts = 4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * x.c + nvox * y.c + kd ** 3 * x.c * y.c)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wp.data_ptr(), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
+        e1.record()
+        self.prof.append((name.value.decode(), flops, byts, e0, e1))
 
     def conv_wgrad(self, x, dy, dw, kd, stride=1, pad=None, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None):
         pad = kd // 2 if pad is None else pad
@@ -138,8 +154,17 @@ class Backend:
             raise RuntimeError("conv3d_wgrad: unsupported configuration")
         ws = self.ws(nbytes)
         assert dw.is_contiguous()
+        if self.prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         check(self.lib.mi355_conv3d_wgrad(ctypes.byref(xd), ctypes.byref(dyd), dw.data_ptr(), ctypes.byref(d), ws.data_ptr(),
                                           ws.numel() * 4, self.stream()), "conv3d_wgrad")
+        if self.prof is not None:
+            e1.record()
+            nvox = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3]
+            flops = 2.0 * nvox * x.c * dy.c * kd ** 3
+            byts = 4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * x.c + nvox * dy.c + kd ** 3 * x.c * dy.c)
+            self.prof.append((f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1))
 
     # -- norm ----------------------------------------------------------------------------------------------------
     def gn_stats(self, x, groups, eps, gamma, beta):

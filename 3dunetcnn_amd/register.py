@@ -1,0 +1,44 @@
+"""register(): make the MI355X modules discoverable through the reference's own lookup paths, unchanged:
+
+  * models:     getattr(unet3d.models.pytorch, model_name)(**kwargs)   (unet3d/models/build.py:9-13)
+  * criteria:   getattr(unet3d.losses, name) first                     (unet3d/scripts/script_utils.py:61-77)
+  * optimizers: getattr(torch.optim, name)                             (unet3d/scripts/script_utils.py:80-81)
+
+so a config with {"model": {"name": "HipUNet3D", ...}, "loss": {"name": "HipDiceLoss", ...},
+"optimizer": {"name": "HipAdam", ...}} trains through unet3d.train.run_training as is. With replace=True the
+reference names themselves ("UNet3D", "DynUNet", "DiceLoss") resolve to the MI355X implementations.
+"""
+import importlib
+
+import torch
+
+
+def register(replace=False):
+    from .dynunet import HipDynUNet
+    from .losses import HipDiceLoss
+    from .optim import HipAdam
+    from .unet import HipUNet3D
+    done = {}
+    try:
+        models = importlib.import_module("unet3d.models.pytorch")
+        models.HipUNet3D = HipUNet3D
+        models.HipDynUNet = HipDynUNet
+        done["models"] = ["HipUNet3D", "HipDynUNet"]
+        if replace:
+            models.UNet3D = HipUNet3D
+            models.DynUNet = HipDynUNet
+            done["models"] += ["UNet3D", "DynUNet"]
+    except ImportError:
+        done["models"] = []
+    try:
+        losses = importlib.import_module("unet3d.losses")
+        losses.HipDiceLoss = HipDiceLoss
+        done["losses"] = ["HipDiceLoss"]
+        if replace:
+            losses.DiceLoss = HipDiceLoss
+            done["losses"].append("DiceLoss")
+    except ImportError:
+        done["losses"] = []
+    torch.optim.HipAdam = HipAdam
+    done["optim"] = ["HipAdam"]
+    return done

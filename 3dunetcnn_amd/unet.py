@@ -127,7 +127,7 @@ class _UNetFunction(torch.autograd.Function):
         model = ctx.model
         grads, dx = model._backward_impl(ctx.saved, dlogits.contiguous(), ctx.x_requires_grad)
         ctx.saved = None
-        return (None, dx) + tuple(grads)
+        return (None, dx) + (None,) * len(grads)   # parameter .grad is set by _backward_impl (zero-copy views of the flat buffer)
 
 
 class HipUNet3D(nn.Module):
@@ -177,6 +177,9 @@ class HipUNet3D(nn.Module):
         self._packed = {}          # id(param) -> (version, {mode: packed tensor})
         self._packs_dirty = True
         self.dropout_generator = None
+        self.grad_ready_callback = None        # set by ddp.GradientBucketReducer
+        self.backward_start_callback = None
+        self._written = []
 
     # ---- flat parameter storage --------------------------------------------------------------------------------
     def _params(self):
@@ -351,7 +354,14 @@ class HipUNet3D(nn.Module):
     # ---- backward ----------------------------------------------------------------------------------------------
     def _gslice(self, p):
         o = self._goff[id(p)]
+        self._written.append(p)
         return self._gbuf[o:o + p.numel()].view(p.shape)
+
+    def _flush_ready(self):
+        """Report parameters whose gradient kernels have been enqueued (DDP launches the bucket all-reduce from here)."""
+        if self._written and self.grad_ready_callback is not None:
+            self.grad_ready_callback(self._written)
+        self._written = []
 
     def _block_bwd(self, be, blk, s, d_out, need_dx, dx_out=None):
         """d_out: Act gradient wrt the block output (modified in place by the dropout scale). Returns Act dx or None."""
@@ -383,6 +393,7 @@ class HipUNet3D(nn.Module):
             dx = dx_out if dx_out is not None else dA1
         be.gn_act_bwd(s.x, dA1, dx if dx is not None else dA1, c1.norm1.num_groups, 0.0, c1.norm1.weight.data, st1[0], st1[1], st1[2],
                       self._gslice(c1.norm1.weight), self._gslice(c1.norm1.bias), addend=d_id if need_dx else None)
+        self._flush_ready()
         return dx
 
     def _layer_bwd(self, be, layer, saved, d_out, need_dx):
@@ -395,10 +406,17 @@ class HipUNet3D(nn.Module):
         ps = self._params()
         # fresh flat gradient buffer unless the caller is not accumulating into our previous one
         gbuf = self.flat_grad()
-        if any(p.grad is not None for p in ps):
-            # autograd will ADD what we return to existing .grad tensors (which may alias the flat buffer): use scratch
+        accumulate = any(p.grad is not None for p in ps)
+        if accumulate:
+            # existing .grad tensors (which may alias the flat buffer) must be ADDED to: compute into scratch
+            if self.grad_ready_callback is not None:
+                raise RuntimeError("gradient accumulation with the DDP reducer is not supported: call "
+                                   "optimizer.zero_grad(set_to_none=True) before every backward")
             gbuf = torch.zeros_like(self._flat)
         self._gbuf = gbuf
+        self._written = []
+        if self.backward_start_callback is not None:
+            self.backward_start_callback(gbuf)
         self._goff = {id(p): o for p, o in zip(ps, self._offsets)}
         self._packs_dirty_local = False
         enc, dec = self.encoder, self.decoder
@@ -451,7 +469,15 @@ class HipUNet3D(nn.Module):
                 d_cur = dprev
             else:
                 dx = d_in
-        grads = [self._gslice(p) for p in ps]
+        self._flush_ready()
+        grads = []
+        for p, o in zip(ps, self._offsets):
+            g = gbuf[o:o + p.numel()].view(p.shape)
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+            grads.append(g)
         dx_t = None
         if need_dx and dx is not None:
             dx_t = torch.empty(n, self.n_features, *sizes[0], dtype=torch.float32, device=dlogits.device)

@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py -- training volumes/sec of the MI355X-native 3D U-Net hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one optimizer step of the reference's inner loop (unet3d/train/training_utils.py:59-72:
+zero_grad -> forward -> Dice -> backward -> Adam.step) on one synthetic batch per GPU:
+BASELINE.json configs[1] = UNet3D 4ch -> 3cls (default widths, 23 970 216 params), 128^3 patch, batch 2 per GPU, fp32.
+Weak scaling: every rank processes its own batch; the only exchange is the bucketed RCCL gradient all-reduce
+overlapped with backward (3dunetcnn_amd/ddp.py). value = world * batch * K / max-over-ranks elapsed.
+
+Extra objects on the JSON line (tier contract):
+  roofline     -- dominant kernel (by summed HIP-event time inside the timed region): algorithmic FLOPs / time vs the
+                  fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md), since the 3x3x3 convs are compute-bound in fp32
+                  (SURVEY.md 7.3 #1); `hbm_gbps` gives the same launches' algorithmic bytes / time for reference.
+  cpu_baseline -- the oracle (CPU restatement of the reference graph, oracle/unet3d_ref.py) timed on this host for one
+                  training step at N=1, same volume size (rank 0, N=1 runs only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="volumes per GPU (BASELINE configs[1]: 2)")
+    ap.add_argument("--size", type=int, default=128, help="cubic patch edge (BASELINE configs[1]: 128)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="disable the per-launch HIP events (roofline -> null)")
+    return ap.parse_args()
+
+
+def cpu_baseline(size):
+    """One training step of the oracle graph on the host CPU (bounded sample: N=1, same patch size)."""
+    from oracle import torch_ops as O
+    from oracle import unet3d_ref as R
+    unet = importlib.import_module("3dunetcnn_amd.unet")
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    holder = unet.HipUNet3D(n_features=4, n_outputs=3)          # parameter container only (never run on CPU)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in holder.state_dict().items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=1e-3)
+
+    def step(dhw):
+        x, y = R.synthetic_case(1, 4, dhw)
+        opt.zero_grad()
+        t0 = time.perf_counter()
+        out = R.unet3d_forward(sd, x)
+        loss = O.dice_loss(out, y)
+        loss.backward()
+        opt.step()
+        return time.perf_counter() - t0
+
+    step((32, 32, 32))                                           # warm-up (thread pools, oneDNN primitives)
+    dt = step((size, size, size))
+    return {"value": 1.0 / dt, "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"1 training step (fwd + Dice + bwd + Adam) of the CPU oracle graph, N=1, {size}^3, fp32, {cores} threads, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    unet = importlib.import_module("3dunetcnn_amd.unet")
+    losses = importlib.import_module("3dunetcnn_amd.losses")
+    optim = importlib.import_module("3dunetcnn_amd.optim")
+    ddp = importlib.import_module("3dunetcnn_amd.ddp")
+    ops = importlib.import_module("3dunetcnn_amd.ops")
+    from oracle import unet3d_ref as R   # synthetic_case only (input generator; not part of the measured path)
+
+    torch.manual_seed(1234)
+    model = unet.HipUNet3D(n_features=4, n_outputs=3).to(dev)
+    model.train()                                                 # Dropout3d active, as in the reference's training loop
+    model.flatten_parameters()
+    criterion = losses.HipDiceLoss(sigmoid=True)
+    optimizer = optim.HipAdam(model.parameters(), lr=1e-3)
+    reducer = None
+    if world > 1:
+        reducer = ddp.GradientBucketReducer(model)
+        reducer.broadcast_parameters(0)
+
+    S, B = args.size, args.batch
+    x, y = R.synthetic_case(B, 4, (S, S, S), seed=rank)
+    x, y = x.to(dev), y.to(dev)                                   # inputs resident in HBM before the timed region
+    be = ops.default_backend()
+
+    def step():
+        optimizer.zero_grad(set_to_none=True)
+        out = model(x)
+        loss = criterion(out, y)
+        loss.backward()
+        if reducer is not None:
+            reducer.wait()
+        optimizer.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if not args.no_kernel_events:
+        be.prof = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, be.prof = be.prof, None
+    loss_val = float(loss.item())
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    roofline = None
+    if prof:
+        agg = {}
+        for name, fl, by, e0, e1 in prof:
+            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += fl
+            a[2] += by
+            a[3] += 1
+        name, (secs, fl, by, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
+        ach = fl / secs / 1e12
+        roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": cnt, "avg_launch_ms": round(secs / cnt * 1e3, 4),
+                    "hbm_gbps_algorithmic": round(by / secs / 1e9, 1), "hbm_frac": round(by / secs / 1e9 / HBM_PEAK_GBPS, 4),
+                    "share_of_step": round(secs / dt, 4),
+                    "all_kernels": {k: {"s": round(v[0], 5), "tflops": round(v[1] / v[0] / 1e12, 2), "launches": v[3]}
+                                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+
+    if rank == 0:
+        out = {"metric": "training volumes/sec (128^3, 4ch->3cls)", "value": round(world * B * args.steps / dt, 4), "unit": "volumes/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"BASELINE configs[1]: UNet3D 4ch->3cls (23970216 params), {S}^3 patch, batch {B}/GPU, fp32, "
+                                      f"fwd + sigmoid-Dice + bwd + Adam, Dropout3d on", "global_batch": world * B,
+                          "parallelism": f"dp{world}"},
+               "final_loss": round(loss_val, 6), "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

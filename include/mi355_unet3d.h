@@ -79,6 +79,10 @@ int mi355_pack_conv_weight(const float* w, float* wp, int32_t cout, int32_t cin,
  * v_mfma_f32_32x32x2_f32 (exact fp32). */
 int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* desc, void* stream);
 
+/* Writes the (demangled) name of the kernel instantiation mi355_conv3d_fwd launches for this problem, e.g.
+ * "conv3d_mfma<3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 1, 1>", so HIP-event timings can be matched to a rocprofv3 trace. */
+int mi355_conv3d_fwd_config(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* desc, char* out, size_t n);
+
 /* Weight gradient dw[co][ci][tap] (OIDHW, written not accumulated) =
  *   sum_{n,q} dy[n,q,co] * in(x)[n, stride*q + tap - pad, ci]           (autograd of F.conv3d wrt weight)
  * with the same input-side fusion as the forward (desc->in_mode PLAIN or AFFINE_ACT). Two-pass, deterministic:

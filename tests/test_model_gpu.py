@@ -1,0 +1,126 @@
+"""Whole-network parity on a real MI355X: HipUNet3D (+ HipDiceLoss, HipAdam) through the C ABI vs the CPU fp32 oracle
+(oracle/unet3d_ref.py = restatement of the reference graph, pinned against the reference itself by
+tests/test_oracle_pinned.py and tests/golden/). Tolerance 1e-3 relative (BASELINE.json north_star)."""
+import importlib
+import os
+
+import pytest
+import torch
+
+import op_cases as C
+from oracle import torch_ops as O
+from oracle import unet3d_ref as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+unet = importlib.import_module("3dunetcnn_amd.unet")
+losses = importlib.import_module("3dunetcnn_amd.losses")
+optim = importlib.import_module("3dunetcnn_amd.optim")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _run_pair(kw, enc, dhw, n, tc=False, seed=1234):
+    torch.manual_seed(seed)
+    m = unet.HipUNet3D(**kw).cuda().eval()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x, y = R.synthetic_case(n, kw["n_features"], dhw, kw["n_outputs"])
+    ref = R.unet3d_forward(sd, x, enc, None, tc)
+    lref = O.dice_loss(ref, y)
+    lref.backward()
+    out = m(x.cuda())
+    crit = losses.HipDiceLoss(sigmoid=True)
+    loss = crit(out, y.cuda())
+    loss.backward()
+    errs = {"logits": C.rel_err(out, ref), "loss": abs(float(loss) - float(lref)) / abs(float(lref))}
+    worst, wk = 0.0, None
+    for k, p in m.named_parameters():
+        e = C.rel_err(p.grad, sd[k].grad)
+        if e > worst:
+            worst, wk = e, k
+    errs["grad"] = worst
+    errs["grad_key"] = wk
+    return errs
+
+
+@pytest.mark.parametrize("dhw,n", [((32, 32, 32), 2), ((64, 64, 64), 1), ((30, 31, 29), 1)])
+def test_unet3d_default_fwd_bwd(dhw, n):
+    e = _run_pair(dict(n_features=4, n_outputs=3), (1, 2, 2, 4), dhw, n)
+    print(e)
+    assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] < TOL, e
+
+
+def test_unet3d_transposed_conv_variant():
+    e = _run_pair(dict(n_features=4, n_outputs=3, use_transposed_convolutions=True), (1, 2, 2, 4), (32, 32, 32), 1, tc=True)
+    print(e)
+    assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] < TOL, e
+
+
+def test_unet3d_five_levels():
+    # BASELINE configs[3] topology (encoder_blocks=[1,2,2,2,4], 96.8M params) at a reduced patch so the CPU oracle is quick
+    e = _run_pair(dict(n_features=4, n_outputs=3, encoder_blocks=[1, 2, 2, 2, 4]), (1, 2, 2, 2, 4), (32, 48, 32), 1)
+    print(e)
+    assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] < TOL, e
+
+
+def test_training_steps_match_torch_adam():
+    """3 optimizer steps (eval-mode graph so no dropout RNG) of HipUNet3D+HipDiceLoss+HipAdam vs oracle+torch.optim.Adam."""
+    torch.manual_seed(7)
+    kw = dict(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1, 2])
+    m = unet.HipUNet3D(**kw).cuda().eval()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x, y = R.synthetic_case(2, 4, (32, 32, 32), 3)
+    opt_ref = torch.optim.Adam(list(sd.values()), lr=1e-3)
+    opt = optim.HipAdam(m.parameters(), lr=1e-3)
+    crit = losses.HipDiceLoss(sigmoid=True)
+    xg, yg = x.cuda(), y.cuda()
+    lh, lr_ = [], []
+    for _ in range(3):
+        opt_ref.zero_grad()
+        l0 = O.dice_loss(R.unet3d_forward(sd, x, (1, 1, 2)), y)
+        l0.backward()
+        opt_ref.step()
+        opt.zero_grad()
+        l1 = crit(m(xg), yg)
+        l1.backward()
+        opt.step()
+        lh.append(float(l1))
+        lr_.append(float(l0))
+    assert all(abs(a - b) / abs(b) < TOL for a, b in zip(lh, lr_)), (lh, lr_)
+    worst = max(C.rel_err(p, sd[k]) for k, p in m.named_parameters())
+    assert worst < TOL, worst
+
+
+def test_golden_reference_vectors():
+    """Fixture generated in the build container by importing the REFERENCE UNet3D (oracle/make_golden.py)."""
+    path = os.path.join(GOLD, "unet3d_small.pt")
+    g = torch.load(path)
+    m = unet.HipUNet3D(**g["kwargs"]).cuda().eval()
+    m.load_state_dict(g["state_dict"])
+    out = m(g["x"].cuda())
+    crit = losses.HipDiceLoss(sigmoid=True)
+    loss = crit(out, g["y"].cuda())
+    loss.backward()
+    assert C.rel_err(out, g["logits"]) < TOL
+    assert abs(float(loss) - float(g["loss"])) / abs(float(g["loss"])) < TOL
+    for k, p in m.named_parameters():
+        assert C.rel_err(p.grad, g["grads"][k]) < TOL, k
+
+
+def test_no_grad_inference_and_state_dict_roundtrip(tmp_path):
+    torch.manual_seed(3)
+    m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1, 2]).cuda().eval()
+    x = torch.randn(1, 4, 24, 24, 24).cuda()
+    with torch.no_grad():
+        a = m(x)
+    torch.save(m.state_dict(), tmp_path / "model.pth")
+    m2 = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1, 2]).cuda().eval()
+    m2.load_state_dict(torch.load(tmp_path / "model.pth"))
+    with torch.no_grad():
+        b = m2(x)
+    assert torch.equal(a, b)
+
+
+def test_cpu_input_fails_loudly():
+    m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1])
+    with pytest.raises(RuntimeError):
+        m(torch.randn(1, 4, 8, 8, 8))
