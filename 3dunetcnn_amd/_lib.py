@@ -24,10 +24,12 @@ class MiConvDesc(Structure):
                 ("residual", c_void_p), ("residual_ld", c_int32),
                 ("out_chscale", c_void_p),
                 ("off_z", c_int32), ("off_y", c_int32), ("off_x", c_int32),
-                ("out_d", c_int32), ("out_h", c_int32), ("out_w", c_int32)]
+                ("out_d", c_int32), ("out_h", c_int32), ("out_w", c_int32),
+                ("in_slope", c_void_p), ("out_mode", c_int32)]
 
 
-IN_PLAIN, IN_AFFINE_ACT, IN_ZERO_INSERT = 0, 1, 2
+IN_PLAIN, IN_AFFINE_ACT, IN_ZERO_INSERT, IN_S2D = 0, 1, 2, 3
+OUT_PLAIN, OUT_D2S = 0, 1
 
 STATUS = {0: "ok", -1: "invalid argument (shape/alignment/null)", -2: "unsupported combination",
           -3: "kernel launch failed", -4: "workspace too small"}
@@ -50,9 +52,10 @@ SIGNATURES = {
     "mi355_ndhwc_to_ncdhw": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p]),
     "mi355_add": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), POINTER(MiAct), c_void_p]),
     "mi355_chscale": (ctypes.c_int, [POINTER(MiAct), c_void_p, POINTER(MiAct), c_void_p]),
-    "mi355_proj_fwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "mi355_proj_fwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "mi355_proj_workspace": (c_size_t, [POINTER(MiAct), c_int32]),
-    "mi355_proj_bwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p, POINTER(MiAct), c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "mi355_proj_bwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p, c_float, c_void_p, c_void_p, POINTER(MiAct), c_void_p, c_void_p, c_int32,
+                                      c_void_p, c_size_t, c_void_p]),
     "mi355_dice_workspace": (c_size_t, [c_int32, c_int32, c_int64]),
     "mi355_dice_fwd_bwd": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32,
                                           c_float, c_float, c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),

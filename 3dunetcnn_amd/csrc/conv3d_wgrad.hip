@@ -26,6 +26,9 @@ struct WgradArgs {
   int pad;
   int tilesZ, tilesY, tilesX, ntiles;  // output-voxel tiles (per whole batch: ntiles = N*tilesZ*tilesY*tilesX)
   int splits, ciTiles, coTiles;
+  const float* in_slope;   // per-input-channel negative slope (NULL: scalar slope)
+  int dymode;              // MI355_OUT_D2S: dy is the fine tensor of a ConvTranspose3d(k2,s2); logical Cout = 8*fC (1x1x1 only)
+  int cD, cH, cW, fC;
 };
 
 template <int KD, int STRIDE, int TZ, int TY, int TX, int INMODE>
@@ -77,6 +80,19 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
     {
       const int c = co0 + 4 * sq;
       const bool cvalid = c < a.Cout;   // Cout % 4 == 0 is required
+      if (KD == 1 && a.dymode == MI355_OUT_D2S) {
+        const int p = cvalid ? c / a.fC : 0, k = c - p * a.fC;
+        for (int v = sv0; v < TV; v += 32) {
+          const int ox = tx0 + v;
+          float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (cvalid && ox < a.Wo) {
+            const int xx = ox % a.cW, yy = (ox / a.cW) % a.cH, zz = ox / (a.cW * a.cH);
+            const size_t fv = (((size_t)n * (2 * a.cD) + 2 * zz + (p >> 2)) * (2 * a.cH) + 2 * yy + ((p >> 1) & 1)) * (2 * a.cW) + 2 * xx + (p & 1);
+            val = *reinterpret_cast<const float4*>(a.dy + fv * a.dyld + k);
+          }
+          *reinterpret_cast<float4*>(lds_dy + v * 32 + 4 * sq) = val;
+        }
+      } else
       for (int v = sv0; v < TV; v += 32) {
         const int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -90,9 +106,11 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
       const int c = ci0 + 4 * sq;
       const bool cvalid = c < a.Cin;
       float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
       if (INMODE == MI355_IN_AFFINE_ACT && cvalid) {
         sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
         sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
+        if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + c);
       }
       for (int hv = sv0; hv < HV; hv += 32) {
         const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
@@ -102,8 +120,8 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
           v = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + c);
           if (INMODE == MI355_IN_AFFINE_ACT) {
             v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-            v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
-            v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+            v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
+            v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
           }
         }
         *reinterpret_cast<float4*>(lds_x + hv * 32 + 4 * sq) = v;
@@ -157,7 +175,7 @@ __global__ void wgrad_reduce_kernel(const float* ws, float* dw, int Cout, int Ci
   }
 }
 
-struct WgradPlan { int tz, ty, tx, ntiles, tilesZ, tilesY, tilesX, splits, ciTiles, coTiles, wv; size_t ws_bytes; int ok; };
+struct WgradPlan { int tz, ty, tx, ntiles, tilesZ, tilesY, tilesX, splits, ciTiles, coTiles, wv, coutL; size_t ws_bytes; int ok; };
 
 static WgradPlan plan_wgrad(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
   WgradPlan p; memset(&p, 0, sizeof(p));
@@ -165,14 +183,20 @@ static WgradPlan plan_wgrad(const mi355_act* x, const mi355_act* dy, const mi355
   if ((d->kd != 1 && d->kd != 3) || (d->stride != 1 && d->stride != 2)) return p;
   if (d->kd == 1 && d->stride != 1) return p;
   int Do = dy->d, Ho = dy->h, Wo = dy->w;
+  int coutL = dy->c;   // logical output channels
+  if (d->out_mode == MI355_OUT_D2S) {
+    if (d->kd != 1 || dy->d != 2 * x->d || dy->h != 2 * x->h || dy->w != 2 * x->w) return p;
+    Do = x->d; Ho = x->h; Wo = x->w; coutL = 8 * dy->c;
+  }
   if (d->kd == 1) { p.tz = 1; p.ty = 1; p.tx = 256; long long v = (long long)Do * Ho * Wo; if (v > 0x7fffffffLL) return p; Do = 1; Ho = 1; Wo = (int)v; p.wv = 4; }
   else if (d->stride == 1) { p.tz = 4; p.ty = 4; p.tx = 8; p.wv = 1; }
   else { p.tz = 2; p.ty = 2; p.tx = 8; p.wv = 1; }
   p.tilesZ = ceil_div(Do, p.tz); p.tilesY = ceil_div(Ho, p.ty); p.tilesX = ceil_div(Wo, p.tx);
   const long long nt = (long long)dy->n * p.tilesZ * p.tilesY * p.tilesX;
+  p.coutL = coutL;
   if (nt <= 0 || nt > 0x7fffffffLL) return p;
   p.ntiles = (int)nt;
-  p.ciTiles = ceil_div(x->c, 32); p.coTiles = ceil_div(dy->c, 32);
+  p.ciTiles = ceil_div(x->c, 32); p.coTiles = ceil_div(coutL, 32);
   const int pairs = p.ciTiles * p.coTiles;
   int splits = ceil_div(1024, pairs);
   const int max_splits = p.ntiles >= 8 ? p.ntiles / 8 : 1;   // >= 8 tiles per workgroup amortise the slab write
@@ -223,9 +247,12 @@ extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float
   a.Do = dy->d; a.Ho = dy->h; a.Wo = dy->w; a.Cout = dy->c; a.pad = d->pad;
   a.tilesZ = p.tilesZ; a.tilesY = p.tilesY; a.tilesX = p.tilesX; a.ntiles = p.ntiles;
   a.splits = p.splits; a.ciTiles = p.ciTiles; a.coTiles = p.coTiles;
+  a.in_slope = d->in_slope; a.dymode = d->out_mode; a.cD = x->d; a.cH = x->h; a.cW = x->w; a.fC = dy->c;
+  a.Cout = p.coutL;
   int rc;
   if (d->kd == 1) {
-    const long long vi = (long long)x->d * x->h * x->w, vo = (long long)dy->d * dy->h * dy->w;
+    const long long vi = (long long)x->d * x->h * x->w;
+    const long long vo = d->out_mode == MI355_OUT_D2S ? vi : (long long)dy->d * dy->h * dy->w;
     if (vi != vo) return MI355_EINVAL;
     a.Di = a.Hi = 1; a.Wi = (int)vi; a.Do = a.Ho = 1; a.Wo = (int)vo; a.pad = 0;
     rc = launch_wgrad<1, 1, 1, 1, 256>(a, d->in_mode, stream);

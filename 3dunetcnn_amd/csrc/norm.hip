@@ -13,7 +13,8 @@
 #define GN_MAX_BLOCKS_PER_SAMPLE 256
 
 // per-(n, block, c) partial sums of v0 and v1 where
-//  MODE 0 (stats):    v0 = x,  v1 = x*x
+//  MODE 0 (stats):    v0 = x - K_c,  v1 = (x - K_c)^2 with the per-(n,c) shift K_c = x[n, voxel 0, c] (a sample of the
+//                     channel, so the sums do not cancel catastrophically when |mean| >> std; finalize undoes the shift)
 //  MODE 1 (backward): v0 = du, v1 = du*xhat, du = dA * act'(scale*x+shift), xhat = (x-mean)*rstd
 template <int MODE>
 __global__ void gn_partial_kernel(const float* x, int xld, const float* dA, int dald, long long V, int C, int Q, int R,
@@ -41,12 +42,17 @@ __global__ void gn_partial_kernel(const float* x, int xld, const float* dA, int 
   }
   const float* xn = x + (size_t)n * V * xld + 4 * q;
   const float* dn = (MODE == 1) ? dA + (size_t)n * V * dald + 4 * q : nullptr;
+  float kc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == 0) {
+    const float4 k4 = *reinterpret_cast<const float4*>(xn);
+    kc[0] = k4.x; kc[1] = k4.y; kc[2] = k4.z; kc[3] = k4.w;
+  }
   for (long long v = vb + r; v < ve; v += R) {
     const float4 xv = *reinterpret_cast<const float4*>(xn + (size_t)v * xld);
     const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
     if (MODE == 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { s0[e] += xe[e]; s1[e] += xe[e] * xe[e]; }
+      for (int e = 0; e < 4; ++e) { const float t = xe[e] - kc[e]; s0[e] += t; s1[e] += t * t; }
     } else {
       const float4 dv = *reinterpret_cast<const float4*>(dn + (size_t)v * dald);
       const float de[4] = {dv.x, dv.y, dv.z, dv.w};
@@ -91,30 +97,61 @@ __device__ __forceinline__ double block_sum_double(double v, double* red) {
   return r;
 }
 
-// one block per (n, g)
-__global__ void gn_stats_finalize_kernel(const float* ws, int B, int C, int G, long long V, float eps, const float* gamma,
-                                         const float* beta, float* mean_rstd, float* scale, float* shift) {
+// one block per (n, g). Per channel c of the group (shift K_c = x[n,0,c]): S1 = sum(x-K), S2 = sum((x-K)^2) over all
+// partial blocks -> channel mean m_c = K + S1/V and centred second moment M2_c = S2 - S1^2/V; the group statistics are
+// combined from those in double (parallel-variance formula), in a fixed order (deterministic).
+__global__ void gn_stats_finalize_kernel(const float* ws, const float* x, int xld, int B, int C, int G, long long V, float eps,
+                                         const float* gamma, const float* beta, float* mean_rstd, float* scale, float* shift) {
   __shared__ double red[256];
+  __shared__ double p1[256], p2[256];
   const int g = blockIdx.x, n = blockIdx.y;
   const int cpg = C / G;
-  double s = 0.0, ss = 0.0;
-  for (int i = threadIdx.x; i < B * cpg; i += blockDim.x) {
-    const int blk = i / cpg, c = g * cpg + i % cpg;
-    const float* p = ws + (((size_t)n * B + blk) * C + c) * 2;
-    s += (double)p[0]; ss += (double)p[1];
+  const int tid = threadIdx.x;
+  double msum = 0.0, m2sum = 0.0;     // this thread's channels: sum of m_c, and of M2_c + V*m_c^2-style terms (second pass below)
+  double mc_local[4]; double m2_local[4];   // cpg <= 1024 -> at most 4 channel rounds of 256
+  int rounds = 0;
+  for (int c0 = 0; c0 < cpg; c0 += 256, ++rounds) {
+    const int nch = cpg - c0 < 256 ? cpg - c0 : 256;
+    const int S = 256 / nch;                       // slices of the block range per channel
+    const int i = tid % nch, sl = tid / nch;
+    double a1 = 0.0, a2 = 0.0;
+    if (sl < S) {
+      const int c = g * cpg + c0 + i;
+      for (int blk = sl; blk < B; blk += S) {
+        const float* p = ws + (((size_t)n * B + blk) * C + c) * 2;
+        a1 += (double)p[0]; a2 += (double)p[1];
+      }
+    }
+    p1[tid] = a1; p2[tid] = a2;
+    __syncthreads();
+    double mc = 0.0, m2 = 0.0;
+    if (tid < nch) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < S; ++k) { s1 += p1[k * nch + tid]; s2 += p2[k * nch + tid]; }
+      const double K = (double)x[(size_t)n * V * xld + g * cpg + c0 + tid];
+      mc = K + s1 / (double)V;
+      m2 = s2 - s1 * s1 / (double)V;
+      if (m2 < 0.0) m2 = 0.0;
+      msum += mc;
+    }
+    mc_local[rounds] = mc; m2_local[rounds] = m2;
+    __syncthreads();
   }
-  s = block_sum_double(s, red);
-  ss = block_sum_double(ss, red);
+  const double mean = block_sum_double(msum, red) / (double)cpg;
+  rounds = 0;
+  for (int c0 = 0; c0 < cpg; c0 += 256, ++rounds) {
+    const int nch = cpg - c0 < 256 ? cpg - c0 : 256;
+    if (tid < nch) { const double d = mc_local[rounds] - mean; m2sum += m2_local[rounds] + (double)V * d * d; }
+  }
   const double M = (double)V * cpg;
-  const double mean = s / M;
-  double var = ss / M - mean * mean;
+  double var = block_sum_double(m2sum, red) / M;
   if (var < 0.0) var = 0.0;
   const double rstd = 1.0 / sqrt(var + (double)eps);
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     mean_rstd[((size_t)n * G + g) * 2] = (float)mean;
     mean_rstd[((size_t)n * G + g) * 2 + 1] = (float)rstd;
   }
-  for (int i = threadIdx.x; i < cpg; i += blockDim.x) {
+  for (int i = tid; i < cpg; i += blockDim.x) {
     const int c = g * cpg + i;
     const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
     scale[(size_t)n * C + c] = (float)(ga * rstd);
@@ -122,7 +159,7 @@ __global__ void gn_stats_finalize_kernel(const float* ws, int B, int C, int G, l
   }
 }
 
-// one block per (n, g): per-channel sums -> coefficients (k1, c0, c1) with dx = k1*du + c0 + c1*x, and the
+// one block per (n, g): per-channel sums -> coefficients (k0, c0, k2, mean) with dx = k0*du + c0 + k2*(x - mean), and the
 // per-(n,c) sums for dgamma/dbeta.
 __global__ void gn_bwd_finalize_kernel(const float* ws, int B, int C, int G, long long V, const float* gamma,
                                        const float* mean_rstd, float* coef, float* nc_sums) {
@@ -153,9 +190,9 @@ __global__ void gn_bwd_finalize_kernel(const float* ws, int B, int C, int G, lon
     const double ga = gamma ? (double)gamma[c] : 1.0;
     float* k = coef + ((size_t)n * C + c) * 4;
     k[0] = (float)(rstd * ga);
-    k[1] = (float)(-rstd * m1 + rstd * rstd * m2 * mean);
+    k[1] = (float)(-rstd * m1);
     k[2] = (float)(-rstd * rstd * m2);
-    k[3] = 0.f;
+    k[3] = (float)mean;
   }
 }
 
@@ -190,7 +227,7 @@ __global__ void gn_bwd_apply_kernel(const float* x, int xld, const float* dA, in
       const float* k = coef + ((size_t)n * C + c + e) * 4;
       const float u = xe[e] * se[e] + he[e];
       const float du = u > 0.f ? de[e] : de[e] * slope;
-      o[e] = k[0] * du + k[1] + k[2] * xe[e];
+      o[e] = k[0] * du + k[1] + k[2] * (xe[e] - k[3]);
     }
     if (addend) {
       const float4 av = *reinterpret_cast<const float4*>(addend + (size_t)nv * addld + c);
@@ -217,7 +254,7 @@ extern "C" size_t mi355_gn_workspace(const mi355_act* x) {
 
 static int gn_check(const mi355_act* x, int groups) {
   if (!x || !x->p || x->c % 4 || x->ld % 4 || x->ld < x->c || groups <= 0 || x->c % groups) return MI355_EINVAL;
-  if (x->c / 4 > 256) return MI355_EUNSUPPORTED;
+  if (x->c / 4 > 256 || x->c / groups > 1024) return MI355_EUNSUPPORTED;
   if ((uintptr_t)x->p & 15) return MI355_EINVAL;
   return 0;
 }
@@ -234,8 +271,8 @@ extern "C" int mi355_gn_stats(const mi355_act* x, int32_t groups, float eps, con
          (const float*)x->p, x->ld, (const float*)nullptr, 0, V, C, Q, R, groups, 0.f, (const float*)nullptr,
          (const float*)nullptr, (const float*)nullptr, (float*)ws);
   rc = LAUNCH_CHECK(); if (rc) return rc;
-  LAUNCH(gn_stats_finalize_kernel, dim3(groups, x->n), dim3(256), 0, stream, (const float*)ws, B, C, groups, V, eps, gamma, beta,
-         mean_rstd, scale, shift);
+  LAUNCH(gn_stats_finalize_kernel, dim3(groups, x->n), dim3(256), 0, stream, (const float*)ws, (const float*)x->p, x->ld, B, C, groups,
+         V, eps, gamma, beta, mean_rstd, scale, shift);
   return LAUNCH_CHECK();
 }
 

@@ -187,7 +187,19 @@ extern "C" int mi355_chscale(const mi355_act* x, const float* chscale, const mi3
 #define PROJ_MAX_CIN 96
 #define PROJ_TV 128
 
-__global__ void proj_fwd_kernel(const float* x, int xld, const float* w, const float* bias, float* out, int N, long long V, int Cin, int Cout) {
+// optional fused prologue act(scale[n,c]*x + shift[n,c]) applied while staging the x tile (same as the conv kernels)
+__device__ __forceinline__ float4 proj_prologue(float4 v, const float* sc, const float* sh, float slope, int n, int Cin, int c) {
+  if (!sc) return v;
+  const float4 s4 = *reinterpret_cast<const float4*>(sc + (size_t)n * Cin + c);
+  const float4 h4 = *reinterpret_cast<const float4*>(sh + (size_t)n * Cin + c);
+  v.x = v.x * s4.x + h4.x; v.y = v.y * s4.y + h4.y; v.z = v.z * s4.z + h4.z; v.w = v.w * s4.w + h4.w;
+  v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+  v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+  return v;
+}
+
+__global__ void proj_fwd_kernel(const float* x, int xld, const float* sc, const float* sh, float slope, const float* w, const float* bias,
+                                float* out, int N, long long V, int Cin, int Cout) {
   DYN_LDS(lds);                    // x tile [PROJ_TV][Cin+1] | w [Cout][Cin]
   const int XS = Cin + 1;
   float* lx = lds; float* lw = lds + PROJ_TV * XS;
@@ -201,7 +213,7 @@ __global__ void proj_fwd_kernel(const float* x, int xld, const float* w, const f
     for (int i = tid; i < PROJ_TV * Q; i += 256) {
       const int v = i / Q, q = i % Q;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v0 + v < V) val = *reinterpret_cast<const float4*>(x + ((size_t)n * V + v0 + v) * xld + 4 * q);
+      if (v0 + v < V) val = proj_prologue(*reinterpret_cast<const float4*>(x + ((size_t)n * V + v0 + v) * xld + 4 * q), sc, sh, slope, n, Cin, 4 * q);
       float* d = lx + v * XS + 4 * q; d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
     }
     __syncthreads();
@@ -224,8 +236,8 @@ __global__ void proj_fwd_kernel(const float* x, int xld, const float* w, const f
 }
 
 // dx tile + per-block partial dw/dbias
-__global__ void proj_bwd_kernel(const float* x, int xld, const float* w, const float* dz, float* dx, int dxld, float* ws,
-                                int N, long long V, int Cin, int Cout) {
+__global__ void proj_bwd_kernel(const float* x, int xld, const float* sc, const float* sh, float slope, const float* w, const float* dz,
+                                float* dx, int dxld, float* ws, int N, long long V, int Cin, int Cout) {
   DYN_LDS(lds);                    // x tile [TV][Cin+1] | dz tile [Cout][TV] | w [Cout][Cin]
   const int XS = Cin + 1;
   float* lx = lds; float* lz = lx + PROJ_TV * XS; float* lw = lz + PROJ_MAX_COUT * PROJ_TV;
@@ -243,7 +255,7 @@ __global__ void proj_bwd_kernel(const float* x, int xld, const float* w, const f
     for (int i = tid; i < PROJ_TV * Q; i += 256) {
       const int v = i / Q, q = i % Q;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v0 + v < V) val = *reinterpret_cast<const float4*>(x + ((size_t)n * V + v0 + v) * xld + 4 * q);
+      if (v0 + v < V) val = proj_prologue(*reinterpret_cast<const float4*>(x + ((size_t)n * V + v0 + v) * xld + 4 * q), sc, sh, slope, n, Cin, 4 * q);
       float* d = lx + v * XS + 4 * q; d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
     }
     for (int i = tid; i < Cout * PROJ_TV; i += 256) {
@@ -311,19 +323,23 @@ extern "C" size_t mi355_proj_workspace(const mi355_act* x, int32_t cout) {
   return (size_t)proj_blocks(x) * ((size_t)cout * x->c + cout) * sizeof(float);
 }
 
-extern "C" int mi355_proj_fwd(const mi355_act* x, const float* w, const float* bias, float* logits, int32_t cout, void* stream) {
+extern "C" int mi355_proj_fwd(const mi355_act* x, const float* in_scale, const float* in_shift, float act_slope, const float* w,
+                              const float* bias, float* logits, int32_t cout, void* stream) {
   if (!act_ok(x) || !w || !logits || cout < 1 || cout > PROJ_MAX_COUT || x->c > PROJ_MAX_CIN) return MI355_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return MI355_EINVAL;
   const long long V = (long long)x->d * x->h * x->w;
   const size_t lds = ((size_t)PROJ_TV * (x->c + 1) + (size_t)cout * x->c) * sizeof(float);
   if (lds > 64 * 1024) return MI355_EUNSUPPORTED;
   int grid = proj_blocks(x) * 8; long long t = (long long)x->n * ((V + PROJ_TV - 1) / PROJ_TV); if (grid > t) grid = (int)t;
-  LAUNCH(proj_fwd_kernel, dim3(grid), dim3(256), lds, stream, (const float*)x->p, x->ld, w, bias, logits, x->n, V, x->c, cout);
+  LAUNCH(proj_fwd_kernel, dim3(grid), dim3(256), lds, stream, (const float*)x->p, x->ld, in_scale, in_shift, act_slope, w, bias, logits, x->n, V, x->c, cout);
   return LAUNCH_CHECK();
 }
 
-extern "C" int mi355_proj_bwd(const mi355_act* x, const float* w, const float* dlogits, const mi355_act* dx,
-                              float* dw, float* dbias, int32_t cout, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int mi355_proj_bwd(const mi355_act* x, const float* in_scale, const float* in_shift, float act_slope, const float* w,
+                              const float* dlogits, const mi355_act* dx, float* dw, float* dbias, int32_t cout,
+                              void* ws, size_t ws_bytes, void* stream) {
   if (!act_ok(x) || !w || !dlogits || !dw || !ws || cout < 1 || cout > PROJ_MAX_COUT || x->c > PROJ_MAX_CIN) return MI355_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return MI355_EINVAL;
   if (dx && (!act_ok(dx) || !same_shape(x, dx))) return MI355_EINVAL;
   if (ws_bytes < mi355_proj_workspace(x, cout)) return MI355_EWORKSPACE;
   const long long V = (long long)x->d * x->h * x->w;
@@ -331,7 +347,7 @@ extern "C" int mi355_proj_bwd(const mi355_act* x, const float* w, const float* d
   if (lds > 64 * 1024) return MI355_EUNSUPPORTED;
   const int nb = proj_blocks(x);
   const int npairs = cout * x->c + cout;
-  LAUNCH(proj_bwd_kernel, dim3(nb), dim3(256), lds, stream, (const float*)x->p, x->ld, w, dlogits, dx ? (float*)dx->p : (float*)nullptr,
+  LAUNCH(proj_bwd_kernel, dim3(nb), dim3(256), lds, stream, (const float*)x->p, x->ld, in_scale, in_shift, act_slope, w, dlogits, dx ? (float*)dx->p : (float*)nullptr,
          dx ? dx->ld : 0, (float*)ws, x->n, V, x->c, cout);
   int rc = LAUNCH_CHECK(); if (rc) return rc;
   LAUNCH(proj_reduce_kernel, dim3(ceil_div(npairs, 128)), dim3(128), 0, stream, (const float*)ws, nb, npairs, cout * x->c, dw, dbias);

@@ -1,0 +1,155 @@
+"""Shared engine of the drop-in modules: flat parameter/gradient storage, packed-weight cache and the autograd bridge.
+
+A network built on `HipNetBase` owns ordinary nn.Parameters (reference names/shapes, so state_dicts interchange) that are
+views into ONE flat device buffer; its gradients are written by the HIP kernels into one flat gradient buffer (what the
+fused Adam and the RCCL bucket all-reduce operate on). Subclasses implement `_forward_impl(x, keep)` and
+`_backward_impl_body(be, saved, dlogits, need_dx)` with explicit forward/backward over the C ABI (no autograd graph inside).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops as _ops
+
+
+class _NetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        need_grad = any(ctx.needs_input_grad)   # False under torch.no_grad() / for frozen inference
+        logits, saved = model._forward_impl(x, need_grad)
+        ctx.model = model
+        ctx.saved = saved
+        ctx.x_requires_grad = x.requires_grad
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        grads, dx = model._backward_impl(ctx.saved, dlogits.contiguous(), ctx.x_requires_grad)
+        ctx.saved = None
+        return (None, dx) + (None,) * len(grads)   # parameter .grad is set by _backward_impl (zero-copy views of the flat buffer)
+
+
+class HipNetBase(nn.Module):
+    n_in_channels = None    # set by subclasses: expected input channel count
+
+    def _init_engine(self):
+        self._be = None
+        self._flat = None          # flat parameter buffer (views are the nn.Parameters)
+        self._flat_grad = None
+        self._packed = {}          # id(param) -> [version, {mode: packed tensor}, data_ptr]
+        self._packs_dirty = True
+        self._packs_dirty_local = False
+        self.grad_ready_callback = None        # set by ddp.GradientBucketReducer
+        self.backward_start_callback = None
+        self._written = []
+
+    # ---- flat parameter storage --------------------------------------------------------------------------------
+    def _params(self):
+        return list(self.parameters())
+
+    def flatten_parameters(self):
+        """(Re)point every nn.Parameter at a slice of one flat device buffer (16-byte aligned slices) so that the fused
+        Adam and the gradient all-reduce run over single contiguous tensors. Idempotent; re-run after .cuda()/.to()."""
+        ps = self._params()
+        dev = ps[0].device
+        offs, total = [], 0
+        for p in ps:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        ok = self._flat is not None and self._flat.device == dev and self._flat.numel() == total and all(
+            p.data_ptr() == self._flat.data_ptr() + 4 * o for p, o in zip(ps, offs))
+        if ok:
+            return self._flat
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o in zip(ps, offs):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+        self._flat = flat
+        self._offsets = offs
+        self._flat_grad = None
+        self._packs_dirty = True
+        return flat
+
+    def flat_grad(self):
+        if self._flat_grad is None or self._flat_grad.device != self._flat.device or self._flat_grad.numel() != self._flat.numel():
+            self._flat_grad = torch.zeros_like(self._flat)
+        return self._flat_grad
+
+    def mark_parameters_updated(self):
+        """Called by optimizers that write the flat buffer through raw pointers (no torch version bump)."""
+        self._packs_dirty = True
+
+    def _packed_weight(self, p, mode, transform=None):
+        """Packed (kernel-layout) copy of weight `p`, cached until the parameter changes. `transform` (optional) maps the
+        parameter tensor to the OIDHW tensor that is packed (used for ConvTranspose3d(k2,s2) -> 1x1x1 GEMM weights)."""
+        ent = self._packed.get(id(p))
+        if ent is None or ent[0] != p._version or self._packs_dirty_local or ent[2] != p.data_ptr():
+            ent = [p._version, {}, p.data_ptr()]
+            self._packed[id(p)] = ent
+        if mode not in ent[1]:
+            w = p.data if transform is None else transform(p.data).contiguous()
+            ent[1][mode] = self._be.pack_weight(w, mode)
+        return ent[1][mode]
+
+    # ---- forward / backward bridge -------------------------------------------------------------------------------
+    def _check_input(self, x):
+        if x.device.type != "cuda" and self._be is None:
+            raise RuntimeError(f"{type(self).__name__} runs on an MI355X only: move the module and its input to the GPU "
+                               "(.cuda()); there is no CPU fallback")
+        if x.dim() != 5 or x.shape[1] != self.n_in_channels:
+            raise ValueError(f"expected input [N, {self.n_in_channels}, D, H, W], got {tuple(x.shape)}")
+
+    def _run(self, x):
+        self._check_input(x)
+        self.flatten_parameters()
+        return _NetFunction.apply(self, x.contiguous().float(), *self._params())
+
+    def _begin_forward(self):
+        be = self._be = self._be or _ops.default_backend()
+        self._packs_dirty_local = self._packs_dirty
+        return be
+
+    def _end_forward(self):
+        self._packs_dirty = False
+        self._packs_dirty_local = False
+
+    def _gslice(self, p):
+        o = self._goff[id(p)]
+        self._written.append(p)
+        return self._gbuf[o:o + p.numel()].view(p.shape)
+
+    def _flush_ready(self):
+        """Report parameters whose gradient kernels have been enqueued (DDP launches the bucket all-reduce from here)."""
+        if self._written and self.grad_ready_callback is not None:
+            self.grad_ready_callback(self._written)
+        self._written = []
+
+    def _backward_impl(self, saved, dlogits, need_dx):
+        be = self._be
+        ps = self._params()
+        gbuf = self.flat_grad()
+        accumulate = any(p.grad is not None for p in ps)
+        if accumulate:
+            # existing .grad tensors (which may alias the flat buffer) must be ADDED to: compute into scratch
+            if self.grad_ready_callback is not None:
+                raise RuntimeError("gradient accumulation with the DDP reducer is not supported: call "
+                                   "optimizer.zero_grad(set_to_none=True) before every backward")
+            gbuf = torch.zeros_like(self._flat)
+        self._gbuf = gbuf
+        self._written = []
+        if self.backward_start_callback is not None:
+            self.backward_start_callback(gbuf)
+        self._goff = {id(p): o for p, o in zip(ps, self._offsets)}
+        self._packs_dirty_local = False
+        dx_t = self._backward_impl_body(be, saved, dlogits, need_dx)
+        self._flush_ready()
+        grads = []
+        for p, o in zip(ps, self._offsets):
+            g = gbuf[o:o + p.numel()].view(p.shape)
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+            grads.append(g)
+        self._gbuf = None
+        return grads, dx_t

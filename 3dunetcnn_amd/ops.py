@@ -13,7 +13,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import IN_AFFINE_ACT, IN_PLAIN, IN_ZERO_INSERT, MiAct, MiConvDesc, check
+from ._lib import IN_AFFINE_ACT, IN_PLAIN, IN_S2D, IN_ZERO_INSERT, OUT_D2S, OUT_PLAIN, MiAct, MiConvDesc, check  # noqa: F401
 
 
 class Act:
@@ -107,8 +107,11 @@ class Backend:
         return out
 
     # -- conv ----------------------------------------------------------------------------------------------------
-    def _desc(self, kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep):
+    def _desc(self, kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep, in_slope=None,
+              out_mode=OUT_PLAIN):
         d = MiConvDesc()
+        d.in_slope, d.out_mode = _p(in_slope), out_mode
+        keep.append(in_slope)
         d.kd, d.stride, d.pad, d.in_mode, d.act_slope = kd, stride, pad, in_mode, slope
         d.in_scale, d.in_shift, d.bias = _p(scale), _p(shift), _p(bias)
         if residual is not None:
@@ -120,12 +123,12 @@ class Backend:
         return d
 
     def conv_fwd(self, x, wp, y, kd, stride=1, pad=None, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, bias=None,
-                 residual=None, chscale=None, off=(0, 0, 0), out_dhw=None):
+                 residual=None, chscale=None, off=(0, 0, 0), out_dhw=None, in_slope=None, out_mode=OUT_PLAIN):
         pad = kd // 2 if pad is None else pad
         if out_dhw is None:
-            out_dhw = y.shape[1:4]
+            out_dhw = x.shape[1:4] if out_mode == OUT_D2S else y.shape[1:4]
         keep = []
-        d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep)
+        d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep, in_slope, out_mode)
         xd, yd = x.desc(), y.desc()
         if self.prof is None:
             check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wp.data_ptr(), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
@@ -134,7 +137,7 @@ class Backend:
         name = ctypes.create_string_buffer(96)
         self.lib.mi355_conv3d_fwd_config(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d), name, 96)
         nvox = x.shape[0] * out_dhw[0] * out_dhw[1] * out_dhw[2]
-        flops = 2.0 * nvox * x.c * y.c * kd ** 3
+        flops = 2.0 * nvox * x.c * y.c * kd ** 3 * (8 if (in_mode == IN_S2D or out_mode == OUT_D2S) else 1)
         if in_mode == IN_ZERO_INSERT:
             flops /= 8.0   # algorithmic work of a stride-2 transposed conv: 27/8 taps per output voxel on average
         byts = 4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * x.c + nvox * y.c + kd ** 3 * x.c * y.c)
@@ -144,10 +147,13 @@ class Backend:
         e1.record()
         self.prof.append((name.value.decode(), flops, byts, e0, e1))
 
-    def conv_wgrad(self, x, dy, dw, kd, stride=1, pad=None, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None):
+    def conv_wgrad(self, x, dy, dw, kd, stride=1, pad=None, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, in_slope=None,
+                   out_mode=OUT_PLAIN):
+        """out_mode=OUT_D2S: dy is the fine output of a ConvTranspose3d(k2,s2); dw is [8*dy.c, x.c] (parity-major rows)."""
         pad = kd // 2 if pad is None else pad
         keep = []
-        d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, None, None, None, (0, 0, 0), dy.shape[1:4], keep)
+        d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, None, None, None, (0, 0, 0),
+                       x.shape[1:4] if out_mode == OUT_D2S else dy.shape[1:4], keep, in_slope, out_mode)
         xd, dyd = x.desc(), dy.desc()
         nbytes = self.lib.mi355_conv3d_wgrad_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))
         if nbytes == 0:
@@ -214,19 +220,21 @@ class Backend:
         check(self.lib.mi355_chscale(ctypes.byref(xd), s.data_ptr(), ctypes.byref(yd), self.stream()), "chscale")
 
     # -- projection ----------------------------------------------------------------------------------------------
-    def proj_fwd(self, x, w, bias, logits):
+    def proj_fwd(self, x, w, bias, logits, scale=None, shift=None, slope=0.0):
         cout = w.shape[0]
         xd = x.desc()
         assert logits.is_contiguous()
-        check(self.lib.mi355_proj_fwd(ctypes.byref(xd), w.data_ptr(), _p(bias), logits.data_ptr(), cout, self.stream()), "proj_fwd")
+        check(self.lib.mi355_proj_fwd(ctypes.byref(xd), _p(scale), _p(shift), slope, w.data_ptr(), _p(bias), logits.data_ptr(), cout,
+                                      self.stream()), "proj_fwd")
 
-    def proj_bwd(self, x, w, dlogits, dx, dw, dbias):
+    def proj_bwd(self, x, w, dlogits, dx, dw, dbias, scale=None, shift=None, slope=0.0):
         cout = w.shape[0]
         xd = x.desc()
         dxd = dx.desc() if dx is not None else None
         ws = self.ws(self.lib.mi355_proj_workspace(ctypes.byref(xd), cout))
-        check(self.lib.mi355_proj_bwd(ctypes.byref(xd), w.data_ptr(), dlogits.data_ptr(), ctypes.byref(dxd) if dxd is not None else None,
-                                      dw.data_ptr(), _p(dbias), cout, ws.data_ptr(), ws.numel() * 4, self.stream()), "proj_bwd")
+        check(self.lib.mi355_proj_bwd(ctypes.byref(xd), _p(scale), _p(shift), slope, w.data_ptr(), dlogits.data_ptr(),
+                                      ctypes.byref(dxd) if dxd is not None else None, dw.data_ptr(), _p(dbias), cout, ws.data_ptr(),
+                                      ws.numel() * 4, self.stream()), "proj_bwd")
 
     # -- loss / optimizer ----------------------------------------------------------------------------------------
     def dice(self, logits, target, sigmoid=True, batch=False, squared_pred=False, smooth_nr=1e-5, smooth_dr=1e-5,

@@ -21,7 +21,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import ops as _ops
+from .engine import HipNetBase
 from ._lib import IN_AFFINE_ACT, IN_PLAIN, IN_ZERO_INSERT
 
 GN_EPS = 1e-5
@@ -112,25 +112,7 @@ class _Saved:
     __slots__ = ("x", "h1", "st1", "st2", "out", "chscale")
 
 
-class _UNetFunction(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, model, x, *params):
-        need_grad = any(ctx.needs_input_grad)   # False under torch.no_grad() / for frozen inference
-        logits, saved = model._forward_impl(x, need_grad)
-        ctx.model = model
-        ctx.saved = saved
-        ctx.x_requires_grad = x.requires_grad
-        return logits
-
-    @staticmethod
-    def backward(ctx, dlogits):
-        model = ctx.model
-        grads, dx = model._backward_impl(ctx.saved, dlogits.contiguous(), ctx.x_requires_grad)
-        ctx.saved = None
-        return (None, dx) + (None,) * len(grads)   # parameter .grad is set by _backward_impl (zero-copy views of the flat buffer)
-
-
-class HipUNet3D(nn.Module):
+class HipUNet3D(HipNetBase):
     def __init__(self, input_shape=None, n_features=1, base_width=32, encoder_blocks=None, decoder_blocks=None,
                  feature_dilation=2, downsampling_stride=2, interpolation_mode="trilinear", n_outputs=1, layer_widths=None,
                  decoder_mirrors_encoder=False, activation=None, use_transposed_convolutions=False, kernel_size=3):
@@ -171,70 +153,13 @@ class HipUNet3D(nn.Module):
             self.activation = nn.Softmax(dim=1)
         else:
             self.activation = None
-        self._be = None
-        self._flat = None          # flat parameter buffer (views are the nn.Parameters)
-        self._flat_grad = None
-        self._packed = {}          # id(param) -> (version, {mode: packed tensor})
-        self._packs_dirty = True
+        self.n_in_channels = n_features
         self.dropout_generator = None
-        self.grad_ready_callback = None        # set by ddp.GradientBucketReducer
-        self.backward_start_callback = None
-        self._written = []
-
-    # ---- flat parameter storage --------------------------------------------------------------------------------
-    def _params(self):
-        return list(self.parameters())
-
-    def flatten_parameters(self):
-        """(Re)point every nn.Parameter at a slice of one flat device buffer (16-byte aligned slices) so that the fused
-        Adam and the gradient all-reduce run over single contiguous tensors. Idempotent; re-run after .cuda()/.to()."""
-        ps = self._params()
-        dev = ps[0].device
-        offs, total = [], 0
-        for p in ps:
-            offs.append(total)
-            total += (p.numel() + 3) // 4 * 4
-        ok = self._flat is not None and self._flat.device == dev and self._flat.numel() == total and all(
-            p.data_ptr() == self._flat.data_ptr() + 4 * o for p, o in zip(ps, offs))
-        if ok:
-            return self._flat
-        flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        for p, o in zip(ps, offs):
-            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
-            p.data = flat[o:o + p.numel()].view(p.shape)
-        self._flat = flat
-        self._offsets = offs
-        self._flat_grad = None
-        self._packs_dirty = True
-        return flat
-
-    def flat_grad(self):
-        if self._flat_grad is None or self._flat_grad.device != self._flat.device or self._flat_grad.numel() != self._flat.numel():
-            self._flat_grad = torch.zeros_like(self._flat)
-        return self._flat_grad
-
-    def mark_parameters_updated(self):
-        """Called by optimizers that write the flat buffer through raw pointers (no torch version bump)."""
-        self._packs_dirty = True
-
-    def _packed_weight(self, p, mode):
-        ent = self._packed.get(id(p))
-        if ent is None or ent[0] != p._version or self._packs_dirty_local or ent[2] != p.data_ptr():
-            ent = [p._version, {}, p.data_ptr()]
-            self._packed[id(p)] = ent
-        if mode not in ent[1]:
-            ent[1][mode] = self._be.pack_weight(p.data, mode)
-        return ent[1][mode]
+        self._init_engine()
 
     # ---- forward -----------------------------------------------------------------------------------------------
     def forward(self, x):
-        if x.device.type != "cuda" and self._be is None:
-            raise RuntimeError("HipUNet3D runs on an MI355X only: move the module and its input to the GPU (.cuda()); "
-                               "there is no CPU fallback")
-        if x.dim() != 5 or x.shape[1] != self.n_features:
-            raise ValueError(f"expected input [N, {self.n_features}, D, H, W], got {tuple(x.shape)}")
-        self.flatten_parameters()
-        y = _UNetFunction.apply(self, x.contiguous().float(), *self._params())
+        y = self._run(x)
         if self.activation is not None:
             y = self.activation(y)
         return y
@@ -280,8 +205,7 @@ class HipUNet3D(nn.Module):
         return saved
 
     def _forward_impl(self, x, keep):
-        be = self._be = self._be or _ops.default_backend()
-        self._packs_dirty_local = self._packs_dirty
+        be = self._begin_forward()
         n, _, D, H, W = x.shape
         enc, dec = self.encoder, self.decoder
         L = len(enc.layers)
@@ -347,22 +271,10 @@ class HipUNet3D(nn.Module):
         logits = torch.empty(n, self.n_outputs, D, H, W, dtype=torch.float32, device=x.device)
         wf = self.final_convolution.weight
         be.proj_fwd(last_out, wf.data.reshape(self.n_outputs, -1), None, logits)
-        self._packs_dirty = False
-        self._packs_dirty_local = False
+        self._end_forward()
         return logits, (saved if keep else None)
 
     # ---- backward ----------------------------------------------------------------------------------------------
-    def _gslice(self, p):
-        o = self._goff[id(p)]
-        self._written.append(p)
-        return self._gbuf[o:o + p.numel()].view(p.shape)
-
-    def _flush_ready(self):
-        """Report parameters whose gradient kernels have been enqueued (DDP launches the bucket all-reduce from here)."""
-        if self._written and self.grad_ready_callback is not None:
-            self.grad_ready_callback(self._written)
-        self._written = []
-
     def _block_bwd(self, be, blk, s, d_out, need_dx, dx_out=None):
         """d_out: Act gradient wrt the block output (modified in place by the dropout scale). Returns Act dx or None."""
         c1, c2 = blk.conv1, blk.conv2
@@ -401,24 +313,7 @@ class HipUNet3D(nn.Module):
             d_out = self._block_bwd(be, layer.blocks[j], saved[j], d_out, need_dx or j > 0)
         return d_out
 
-    def _backward_impl(self, saved, dlogits, need_dx):
-        be = self._be
-        ps = self._params()
-        # fresh flat gradient buffer unless the caller is not accumulating into our previous one
-        gbuf = self.flat_grad()
-        accumulate = any(p.grad is not None for p in ps)
-        if accumulate:
-            # existing .grad tensors (which may alias the flat buffer) must be ADDED to: compute into scratch
-            if self.grad_ready_callback is not None:
-                raise RuntimeError("gradient accumulation with the DDP reducer is not supported: call "
-                                   "optimizer.zero_grad(set_to_none=True) before every backward")
-            gbuf = torch.zeros_like(self._flat)
-        self._gbuf = gbuf
-        self._written = []
-        if self.backward_start_callback is not None:
-            self.backward_start_callback(gbuf)
-        self._goff = {id(p): o for p, o in zip(ps, self._offsets)}
-        self._packs_dirty_local = False
+    def _backward_impl_body(self, be, saved, dlogits, need_dx):
         enc, dec = self.encoder, self.decoder
         L = len(enc.layers)
         sizes, cats, n = saved["sizes"], saved["cats"], saved["n"]
@@ -469,21 +364,11 @@ class HipUNet3D(nn.Module):
                 d_cur = dprev
             else:
                 dx = d_in
-        self._flush_ready()
-        grads = []
-        for p, o in zip(ps, self._offsets):
-            g = gbuf[o:o + p.numel()].view(p.shape)
-            if p.grad is None:
-                p.grad = g
-            else:
-                p.grad.add_(g)
-            grads.append(g)
         dx_t = None
         if need_dx and dx is not None:
             dx_t = torch.empty(n, self.n_features, *sizes[0], dtype=torch.float32, device=dlogits.device)
             be.ndhwc_to_ncdhw(dx, dx_t)
-        self._gbuf = None
-        return grads, dx_t
+        return dx_t
 
     def _window(self, be, d_up, off, win):
         """Gradient restricted to the F.pad window (unet.py:34-40) as a dense Act of extent `win`."""

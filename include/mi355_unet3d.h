@@ -43,6 +43,16 @@ typedef struct mi355_act {
 #define MI355_IN_PLAIN 0       /* conv reads x as is */
 #define MI355_IN_AFFINE_ACT 1  /* conv reads act(scale[n,c]*x + shift[n,c]) : fused GroupNorm/InstanceNorm apply + (Leaky)ReLU */
 #define MI355_IN_ZERO_INSERT 2 /* conv reads the x2 zero-inserted x : ConvTranspose3d(k3,s2,p1) fwd and stride-2 dgrad */
+#define MI355_IN_S2D 3         /* kd == 1 only: x is a FINE tensor (2d,2h,2w,c); the conv sees its space-to-depth view
+                                  (d,h,w,8c), logical channel p*c + k with p = 4a+2b+e  <->  x[2z+a,2y+b,2x+e,k].
+                                  dgrad of ConvTranspose3d(k2,s2) (MONAI DynUNet up block). x->d/h/w are the FINE extents. */
+
+/* Output-side layout of the conv kernels. */
+#define MI355_OUT_PLAIN 0
+#define MI355_OUT_D2S 1        /* kd == 1 only: y is a FINE tensor (2d,2h,2w,c); logical output channel p*c + k of coarse voxel
+                                  (z,y,x) is stored at y[2z+a,2y+b,2x+e,k]: ConvTranspose3d(k2,s2,bias=False) forward as one
+                                  GEMM with 8c logical output channels. For mi355_conv3d_wgrad the same flag says dy is such a
+                                  fine tensor (wgrad of the transposed conv). y->d/h/w are the FINE extents. */
 
 typedef struct mi355_conv_desc {
   int32_t kd;        /* cubic kernel extent: 1 or 3 */
@@ -61,6 +71,10 @@ typedef struct mi355_conv_desc {
      amounts, unet.py:34-40. */
   int32_t off_z, off_y, off_x;
   int32_t out_d, out_h, out_w; /* logical output extent (before the window shift) */
+  const float* in_slope; /* NULL or [cin]: per-input-channel negative slope overriding act_slope (IN_AFFINE_ACT). A concat buffer
+                            whose first channels are a raw tensor (slope 1, scale 1, shift 0 = identity) and whose last channels
+                            are a normalised+LeakyReLU'd skip (MONAI UnetUpBlock: cat((up, skip), 1) -> conv) needs this. */
+  int32_t out_mode;      /* MI355_OUT_* */
 } mi355_conv_desc;
 
 /* ---- weight packing -------------------------------------------------------------------------- */
@@ -128,12 +142,17 @@ int mi355_chscale(const mi355_act* x, const float* chscale, const mi355_act* y, 
 
 /* ---- 1x1x1 projection to a few classes -------------------------------------------------------- */
 /* final_convolution (variational.py:59-60; unet.py:50) and DynUNet's output block: Conv3d(cin -> cout<=8, k=1),
- * reading NDHWC and writing the logits directly in the reference's NCDHW layout. w is OIDHW = [cout][cin]. */
-int mi355_proj_fwd(const mi355_act* x, const float* w, const float* bias, float* logits_ncdhw, int32_t cout, void* stream);
-/* backward: dx (NDHWC, written), dw[cout][cin] and dbias[cout] (written). ws >= mi355_proj_workspace bytes. */
+ * reading NDHWC and writing the logits directly in the reference's NCDHW layout. w is OIDHW = [cout][cin].
+ * in_scale/in_shift ([n][cin], both or neither NULL) + act_slope: the same fused norm-apply + (Leaky)ReLU prologue as the
+ * conv kernels (DynUNet's output block reads InstanceNorm3d -> LeakyReLU of the last up block). */
+int mi355_proj_fwd(const mi355_act* x, const float* in_scale, const float* in_shift, float act_slope, const float* w,
+                   const float* bias, float* logits_ncdhw, int32_t cout, void* stream);
+/* backward: dx (NDHWC, written; gradient wrt the ACTIVATED input when a prologue is given), dw[cout][cin] and dbias[cout]
+ * (written). ws >= mi355_proj_workspace bytes. */
 size_t mi355_proj_workspace(const mi355_act* x, int32_t cout);
-int mi355_proj_bwd(const mi355_act* x, const float* w, const float* dlogits_ncdhw, const mi355_act* dx,
-                   float* dw, float* dbias, int32_t cout, void* ws, size_t ws_bytes, void* stream);
+int mi355_proj_bwd(const mi355_act* x, const float* in_scale, const float* in_shift, float act_slope, const float* w,
+                   const float* dlogits_ncdhw, const mi355_act* dx, float* dw, float* dbias, int32_t cout,
+                   void* ws, size_t ws_bytes, void* stream);
 
 /* ---- Dice loss -------------------------------------------------------------------------------- */
 /* monai.losses.DiceLoss as configured by examples/brats2020/brats2020_config.json:112-116 (sigmoid=True,

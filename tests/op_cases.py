@@ -127,18 +127,81 @@ def case_conv_wgrad(be, n, cin, cout, dhw, kd=3, stride=1, norm=False, slope=0.0
     return rel_err(dw, dw_ref)
 
 
-def case_gn(be, n, c, dhw, groups, slope=0.0, ld=None, seed=3):
-    """stats + act(GN) backward (incl. addend) against autograd of F.group_norm -> (leaky)relu."""
+def case_tconv2(be, n, cin, cout, dhw, norm=True, yld=None, seed=9):
+    """ConvTranspose3d(k2, s2, bias=False) (MONAI UnetUpBlock.transp_conv) as one 1x1x1 GEMM with a depth-to-space epilogue,
+    its dgrad through the space-to-depth prologue and its wgrad; input = LeakyReLU(InstanceNorm(x)) applied in the prologue."""
     g = torch.Generator().manual_seed(seed)
     d, h, w = dhw
-    x = (torch.randn(n, c, d, h, w, generator=g) * 1.7 + 0.4).requires_grad_(True)
-    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)
-    beta = (torch.randn(c, generator=g) * 0.3).requires_grad_(True)
+    x = torch.randn(n, cin, d, h, w, generator=g).requires_grad_(True)
+    wt = (torch.randn(cin, cout, 2, 2, 2, generator=g) * (1.0 / cin ** 0.5)).requires_grad_(True)
+    gamma = torch.rand(cin, generator=g) + 0.5
+    beta = torch.randn(cin, generator=g) * 0.3
+    a = O.norm_act(x, cin, gamma, beta, 1e-5, 0.01) if norm else x
+    a.retain_grad()
+    y = F.conv_transpose3d(a, wt, None, stride=2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xa = to_act(be, x.detach())
+    kw = {}
+    if norm:
+        mr, sc, sh = be.gn_stats(xa, cin, 1e-5, dev(be, gamma), dev(be, beta))
+        kw = dict(in_mode=ops.IN_AFFINE_ACT, slope=0.01, scale=sc, shift=sh)
+    w1 = dev(be, wt.detach().permute(2, 3, 4, 1, 0).reshape(8 * cout, cin, 1, 1, 1))
+    ya = to_act(be, torch.zeros(n, cout, 2 * d, 2 * h, 2 * w), yld)
+    be.conv_fwd(xa, be.pack_weight(w1, 0), ya, 1, out_mode=ops.OUT_D2S, **kw)
+    e_f = rel_err(from_act(ya), y)
+    dya = to_act(be, dy, yld)
+    dxa = to_act(be, torch.zeros(n, cin, d, h, w))
+    be.conv_fwd(dya, be.pack_weight(w1, 1), dxa, 1, in_mode=ops.IN_S2D)
+    e_d = rel_err(from_act(dxa), a.grad)
+    dw1 = torch.full((8 * cout, cin), 3.0, dtype=torch.float32, device=be.device)
+    be.conv_wgrad(xa, dya, dw1, 1, out_mode=ops.OUT_D2S, **kw)
+    dw = dw1.view(2, 2, 2, cout, cin).permute(4, 3, 0, 1, 2)
+    return dict(fwd=e_f, dgrad=e_d, wgrad=rel_err(dw, wt.grad))
+
+
+def case_conv_cat_slope(be, n, c_up, c_skip, cout, dhw, stride=1, seed=10):
+    """Conv over a concat buffer whose first c_up channels are raw (identity prologue) and whose last c_skip channels get
+    InstanceNorm + LeakyReLU(0.01) in the prologue (per-channel slope): fwd and wgrad."""
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dhw
+    up = torch.randn(n, c_up, d, h, w, generator=g)
+    sk = torch.randn(n, c_skip, d, h, w, generator=g) * 1.5 + 0.3
+    gamma = torch.rand(c_skip, generator=g) + 0.5
+    beta = torch.randn(c_skip, generator=g) * 0.3
+    wt = (torch.randn(cout, c_up + c_skip, 3, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    a = torch.cat((up, O.norm_act(sk, c_skip, gamma, beta, 1e-5, 0.01)), 1)
+    y = F.conv3d(a, wt, None, stride=stride, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    (dw_ref,) = torch.autograd.grad(y, wt, dy)
+    cat = to_act(be, torch.cat((up, sk), 1))
+    mr, sc, sh = be.gn_stats(cat.slice(c_up, c_skip), c_skip, 1e-5, dev(be, gamma), dev(be, beta))
+    ones = torch.ones(n, c_up, device=be.device)
+    scale = torch.cat((ones, sc), 1).contiguous()
+    shift = torch.cat((0 * ones, sh), 1).contiguous()
+    slope = torch.cat((ones[0], torch.full((c_skip,), 0.01, device=be.device))).contiguous()
+    kw = dict(in_mode=ops.IN_AFFINE_ACT, slope=0.01, scale=scale, shift=shift, in_slope=slope)
+    ya = to_act(be, torch.zeros_like(y.detach()))
+    be.conv_fwd(cat, be.pack_weight(dev(be, wt.detach()), 0), ya, 3, stride, **kw)
+    dw = torch.empty(wt.shape, dtype=torch.float32, device=be.device)
+    be.conv_wgrad(cat, to_act(be, dy), dw, 3, stride, **kw)
+    return dict(fwd=rel_err(from_act(ya), y), wgrad=rel_err(dw, dw_ref))
+
+
+def case_gn(be, n, c, dhw, groups, slope=0.0, ld=None, seed=3, offset=0.4):
+    """stats + act(GN) backward (incl. addend) against autograd of F.group_norm -> (leaky)relu (double precision truth).
+    offset / 1.7 is the mean/std ratio of the input: large ratios break single-pass E[x^2]-E[x]^2 statistics."""
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dhw
+    x = (torch.randn(n, c, d, h, w, generator=g) * 1.7 + offset).double().requires_grad_(True)
+    gamma = (torch.rand(c, generator=g) + 0.5).double().requires_grad_(True)
+    beta = (torch.randn(c, generator=g) * 0.3).double().requires_grad_(True)
     a = O.norm_act(x, groups, gamma, beta, 1e-5, slope)
     dA = torch.randn(a.shape, generator=g)
     add = torch.randn(a.shape, generator=g)
-    dx_ref, dg_ref, db_ref = torch.autograd.grad(a, (x, gamma, beta), dA)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(a, (x, gamma, beta), dA.double())
     dx_ref = dx_ref + add
+    x, gamma, beta = x.detach().float(), gamma.detach().float(), beta.detach().float()
     xa = to_act(be, x.detach(), ld)
     mr, sc, sh = be.gn_stats(xa, groups, 1e-5, dev(be, gamma.detach()), dev(be, beta.detach()))
     xd = x.detach()
@@ -171,21 +234,33 @@ def case_upsample(be, n, c, lo_dhw, target_dhw, c_skip=8, seed=4):
     return dict(fwd=e_f, bwd=rel_err(from_act(dloa), dlo_ref))
 
 
-def case_proj(be, n, cin, cout, dhw, bias=False, seed=5):
+def case_proj(be, n, cin, cout, dhw, bias=False, seed=5, norm=False):
+    """norm=True: the projection reads LeakyReLU(InstanceNorm(x)) through its prologue (DynUNet output block); dx is then
+    the gradient wrt the activated input."""
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn(n, cin, *dhw, generator=g, requires_grad=True)
+    x0 = torch.randn(n, cin, *dhw, generator=g)
+    pk = {}
+    if norm:
+        gamma = torch.rand(cin, generator=g) + 0.5
+        beta = torch.randn(cin, generator=g) * 0.3
+        x = O.norm_act(x0, cin, gamma, beta, 1e-5, 0.01).detach().requires_grad_(True)
+    else:
+        x = x0.clone().requires_grad_(True)
     w = (torch.randn(cout, cin, 1, 1, 1, generator=g) * 0.2).requires_grad_(True)
     b = torch.randn(cout, generator=g).requires_grad_(True) if bias else None
     y = F.conv3d(x, w, b)
     dy = torch.randn(y.shape, generator=g)
     grads = torch.autograd.grad(y, (x, w) + ((b,) if bias else ()), dy)
-    xa = to_act(be, x.detach())
+    xa = to_act(be, x0)
+    if norm:
+        mr, sc, sh = be.gn_stats(xa, cin, 1e-5, dev(be, gamma), dev(be, beta))
+        pk = dict(scale=sc, shift=sh, slope=0.01)
     logits = torch.empty(n, cout, *dhw, device=be.device)
-    be.proj_fwd(xa, dev(be, w.detach().reshape(cout, cin)), dev(be, b.detach()) if bias else None, logits)
+    be.proj_fwd(xa, dev(be, w.detach().reshape(cout, cin)), dev(be, b.detach()) if bias else None, logits, **pk)
     dxa = to_act(be, torch.zeros_like(x.detach()))
     dw = torch.empty(cout, cin, device=be.device)
     dbias = torch.empty(cout, device=be.device) if bias else None
-    be.proj_bwd(xa, dev(be, w.detach().reshape(cout, cin)), dev(be, dy), dxa, dw, dbias)
+    be.proj_bwd(xa, dev(be, w.detach().reshape(cout, cin)), dev(be, dy), dxa, dw, dbias, **pk)
     out = dict(fwd=rel_err(logits, y), dx=rel_err(from_act(dxa), grads[0]), dw=rel_err(dw, grads[1].reshape(cout, cin)))
     if bias:
         out["dbias"] = rel_err(dbias, grads[2])

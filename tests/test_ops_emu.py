@@ -65,9 +65,28 @@ def test_upsample(emu_backend, lo, tgt):
     assert ok(C.case_upsample(emu_backend, 2, 8, lo, tgt))
 
 
+@pytest.mark.parametrize("ratio", [10.0, 30.0])
+def test_groupnorm_large_mean(emu_backend, ratio):
+    # |mean| >> std (ConvTranspose bias + zero-padded planes produce such groups): shifted-sum statistics and the centred
+    # backward must stay at fp32 roundoff; E[x^2]-E[x]^2 loses every digit at ratio 30
+    r = C.case_gn(emu_backend, 1, 64, (6, 6, 6), 8, offset=1.7 * ratio)
+    assert all(v < 2e-5 for v in r.values()), r
+
+
+@pytest.mark.parametrize("kw", [dict(n=2, cin=32, cout=32, dhw=(3, 4, 5)), dict(n=1, cin=64, cout=36, dhw=(2, 2, 3), norm=False, yld=72)])
+def test_transposed_conv_k2s2(emu_backend, kw):
+    assert ok(C.case_tconv2(emu_backend, **kw))
+
+
+def test_conv_over_concat_with_per_channel_prologue(emu_backend):
+    assert ok(C.case_conv_cat_slope(emu_backend, 1, 32, 32, 32, (5, 6, 7)))
+    assert ok(C.case_conv_cat_slope(emu_backend, 1, 32, 32, 64, (5, 6, 7), stride=2))
+
+
 def test_proj(emu_backend):
     assert ok(C.case_proj(emu_backend, 2, 32, 3, (5, 6, 7)))
     assert ok(C.case_proj(emu_backend, 1, 64, 3, (9, 6, 7), bias=True))
+    assert ok(C.case_proj(emu_backend, 1, 32, 3, (5, 6, 7), bias=True, norm=True))
 
 
 def test_dice(emu_backend):

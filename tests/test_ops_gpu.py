@@ -68,9 +68,29 @@ def test_upsample(hip_backend, lo, tgt):
     assert ok(C.case_upsample(hip_backend, 2, 32, lo, tgt))
 
 
+@pytest.mark.parametrize("ratio", [10.0, 30.0])
+def test_groupnorm_large_mean(hip_backend, ratio):
+    # |mean| >> std (ConvTranspose bias + zero-padded planes produce such groups): shifted-sum statistics and the centred
+    # backward must stay at fp32 roundoff; E[x^2]-E[x]^2 loses every digit at ratio 30
+    r = C.case_gn(hip_backend, 1, 64, (16, 16, 16), 8, offset=1.7 * ratio)
+    assert all(v < 2e-5 for v in r.values()), r
+
+
+@pytest.mark.parametrize("kw", [dict(n=2, cin=96, cout=64, dhw=(8, 8, 8)), dict(n=1, cin=384, cout=256, dhw=(2, 2, 2)), dict(n=1, cin=32, cout=32, dhw=(5, 6, 7), norm=False, yld=64),
+    dict(n=1, cin=128, cout=96, dhw=(16, 16, 16))])
+def test_transposed_conv_k2s2(hip_backend, kw):
+    assert ok(C.case_tconv2(hip_backend, **kw))
+
+
+def test_conv_over_concat_with_per_channel_prologue(hip_backend):
+    assert ok(C.case_conv_cat_slope(hip_backend, 2, 64, 64, 64, (16, 16, 16)))
+    assert ok(C.case_conv_cat_slope(hip_backend, 1, 32, 32, 64, (9, 8, 11), stride=2))
+
+
 def test_proj(hip_backend):
     assert ok(C.case_proj(hip_backend, 2, 32, 3, (32, 32, 32)))
     assert ok(C.case_proj(hip_backend, 1, 64, 3, (19, 16, 17), bias=True))
+    assert ok(C.case_proj(hip_backend, 2, 64, 3, (16, 16, 16), bias=True, norm=True))
 
 
 def test_dice(hip_backend):

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): GPU test suite, bench line, rocprofv3 kernel trace + HBM-traffic PMC passes.
+# Usage: tools/gpu_profile.sh <tag> [what...]   what in: tests bench trace pmc   (default: all)
+tag=${1:-r1}; shift
+what=${*:-tests bench trace pmc}
+out=gpurun_out/$tag; mkdir -p $out
+export TMPDIR=/tmp
+root=$(pwd)
+for w in $what; do
+case $w in
+tests) timeout 1500 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $out/pytest_gpu.log; tail -3 $out/pytest_gpu.log;;
+bench) timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 600 $out/bench.json;;
+trace) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $root/$out/trace -o bench -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $root/$out/trace.log 2>&1); ls $out/trace | head;;
+pmc)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $root/$out/pmc_fetch -o bench -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events > $root/$out/pmc_fetch.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $root/$out/pmc_write -o bench -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events > $root/$out/pmc_write.log 2>&1)
+  ls $out/pmc_fetch $out/pmc_write | head;;
+esac
+done
+# keep the merge-back small: drop anything above 20 MB
+find $out -size +20M -delete
+du -sh $out
