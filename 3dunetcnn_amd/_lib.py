@@ -25,11 +25,13 @@ class MiConvDesc(Structure):
                 ("out_chscale", c_void_p),
                 ("off_z", c_int32), ("off_y", c_int32), ("off_x", c_int32),
                 ("out_d", c_int32), ("out_h", c_int32), ("out_w", c_int32),
-                ("in_slope", c_void_p), ("out_mode", c_int32)]
+                ("in_slope", c_void_p), ("out_mode", c_int32), ("precision", c_int32)]
 
 
 IN_PLAIN, IN_AFFINE_ACT, IN_ZERO_INSERT, IN_S2D = 0, 1, 2, 3
 OUT_PLAIN, OUT_D2S = 0, 1
+PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_BF16 = 0, 1, 2, 3
+PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "bf16": PREC_BF16}
 
 STATUS = {0: "ok", -1: "invalid argument (shape/alignment/null)", -2: "unsupported combination",
           -3: "kernel launch failed", -4: "workspace too small"}
@@ -38,6 +40,9 @@ STATUS = {0: "ok", -1: "invalid argument (shape/alignment/null)", -2: "unsupport
 SIGNATURES = {
     "mi355_packed_weight_elems": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "mi355_pack_conv_weight": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "mi355_packed_weight_bytes_bf16": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "mi355_pack_conv_weight_bf16": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "mi355_conv3d_uses_bf16": (ctypes.c_int, [POINTER(MiConvDesc)]),
     "mi355_conv3d_fwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, POINTER(MiAct), POINTER(MiConvDesc), c_void_p]),
     "mi355_conv3d_fwd_config": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), POINTER(MiConvDesc), c_char_p, c_size_t]),
     "mi355_conv3d_wgrad_workspace": (c_size_t, [POINTER(MiAct), POINTER(MiAct), POINTER(MiConvDesc)]),

@@ -1,0 +1,356 @@
+// 3x3x3 stride-1 conv3d forward / dgrad on gfx950 bf16 MFMA (v_mfma_f32_32x32x16_bf16) with SPLIT fp32 operands.
+//
+// Same op and same fusions as conv3d_fwd.hip (reference: unet3d/models/pytorch/classification/resnet.py:12-22 called from
+// myronenko.py:17-21; GroupNorm-apply + ReLU prologue, residual / Dropout3d / concat-slice epilogue), but the MACs run on the
+// bf16 matrix pipe, which is 16x the rate of the f32 MFMA (MI355X_MICROARCH.md: 2.5 PFLOP/s vs 157 TFLOP/s):
+//
+//   NS = 2  (MI355_PREC_BF16X3): every fp32 operand x is split as x = hi + lo, hi = bf16(x), lo = bf16(x - hi), and
+//           a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi (3 MFMAs, each product exact, fp32 accumulate). The dropped a_lo*b_lo
+//           term and the residual of the split are <= ~2^-16 relative: fp32 in / fp32 out at ~1e-5 relative accuracy.
+//   NS = 3  (MI355_PREC_BF16X6): three planes (hi, mid, lo = 24 mantissa bits) and the 6 products of order <= 2:
+//           fp32-class accuracy (~2^-23) at 6 MFMAs per k-step.
+//   NS = 1  (MI355_PREC_BF16):   operands rounded to bf16, one product -- autocast-style mixed precision.
+//
+// The split costs nothing per MAC: activations are split once while the haloed tile is staged into LDS (each staged element
+// is then read by 27 taps x Cout), weights are split once per optimizer step by the pack kernel.
+//
+// Implicit GEMM, no im2col: M = 32 output voxels per MFMA tile (2 x-rows of 16), N = 32 output channels, K = 16 input
+// channels of one tap per MFMA. LDS holds the haloed input tile [halo voxel][plane][KC channels] (bf16), 16*VSQ bytes per
+// voxel with VSQ odd; the lane -> voxel map of an M tile sends the two ds_read_b128 lane groups ({0-3,12-15,20-27} and
+// {4-11,16-19,28-31}) to the two x-rows of the tile, so every 16-lane group reads 16 distinct 16-byte slots: conflict-free.
+// Weights are pre-packed [tap][ci/8][plane][co][8] (bf16) so a lane fetches its B fragment with one 16-byte global load
+// (L2/L1 resident), software-prefetched one k-step ahead.
+#include "hipcompat.h"
+#include "../../include/mi355_unet3d.h"
+
+struct ConvBArgs {
+  const float* x; int xld;
+  const uint4* wp;
+  float* y; int yld;
+  const float* res; int resld;
+  const float* in_scale; const float* in_shift; float slope; const float* in_slope;
+  const float* out_chscale; const float* bias;
+  int N, Di, Hi, Wi, Cin, CinP;       // CinP = roundup(Cin, 16)
+  int Do, Ho, Wo, Cout, CoutP;
+  int yD, yH, yW, offz, offy, offx;
+  int pad;
+  int tilesZ, tilesY, tilesX, coTiles, spatialTiles;
+};
+
+// lane (0..31) of an M tile -> (x-row 0/1, x position 0..15): row = which ds_read_b128 lane group the lane belongs to
+__device__ __forceinline__ void mtile_lane(int li, int& row, int& tx) {
+  const int q = li >> 2;                    // quad index 0..7: quads {0,3,5,6} are group 0, {1,2,4,7} group 1
+  const int g1 = (0x96 >> q) & 1;           // 0b10010110
+  row = g1;
+  const int rank = g1 ? ((q == 1) ? 0 : (q == 2) ? 1 : (q == 4) ? 2 : 3) : ((q == 0) ? 0 : (q == 3) ? 1 : (q == 5) ? 2 : 3);
+  tx = rank * 4 + (li & 3);
+}
+
+template <int NS> struct Products;
+template <> struct Products<1> { static constexpr int P = 1; static constexpr int pa[1] = {0}; static constexpr int pb[1] = {0}; };
+template <> struct Products<2> { static constexpr int P = 3; static constexpr int pa[3] = {1, 0, 0}; static constexpr int pb[3] = {0, 1, 0}; };
+// smallest terms first
+template <> struct Products<3> { static constexpr int P = 6; static constexpr int pa[6] = {2, 1, 0, 1, 0, 0}; static constexpr int pb[6] = {0, 1, 2, 0, 1, 0}; };
+
+// split 8 floats into NS bf16 planes, each plane one uint4 (8 packed bf16)
+template <int NS>
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[NS]) {
+  float r[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = v[e];
+#pragma unroll
+  for (int p = 0; p < NS; ++p) {
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      w[e] = pack_bf16x2(r[2 * e], r[2 * e + 1]);
+      if (p + 1 < NS) { r[2 * e] -= bf16lo_to_f32(w[e]); r[2 * e + 1] -= bf16hi_to_f32(w[e]); }
+    }
+    out[p] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT, int INMODE>
+__global__ __launch_bounds__(256) void conv3d_k3_bf16(ConvBArgs a) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(TZ * TY / 2 == WM * MT, "M tiles (2 x-rows of 16 voxels) must equal WM*MT");
+  constexpr int TX = 16;
+  constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+  constexpr int HV = HZ * HY * HX;
+  constexpr int KC = 16 * J;                 // input channels per LDS chunk
+  constexpr int OCT = KC / 8;                // channel octets per chunk
+  constexpr int VSQ = NS * OCT + 1;          // voxel stride in 16-byte units (odd)
+  constexpr int P = Products<NS>::P;
+  DYN_LDS(lds_f);
+  uint4* lds = reinterpret_cast<uint4*>(lds_f);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, li = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); give each XCD a contiguous range of
+  // spatial tiles so that neighbouring tiles (which share halo voxels) hit the same L2.
+  int b = blockIdx.x;
+  const int cot = b % a.coTiles; b /= a.coTiles;
+  {
+    const int nsp = a.spatialTiles, per = nsp / 8;
+    if (b < per * 8) b = (b & 7) * per + (b >> 3);
+  }
+  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+  const int tz0 = (b % a.tilesZ) * TZ; b /= a.tilesZ;
+  const int n = b;
+  const int co_base = cot * (32 * WN * NT) + wn * (32 * NT);
+
+  int lrow, ltx;
+  mtile_lane(li, lrow, ltx);
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = wm * MT + mt;
+    const int mz = m / (TY / 2), my = (m % (TY / 2)) * 2 + lrow;
+    abase[mt] = ((mz * HY + my) * HX + ltx) * VSQ + half;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const int CQ8 = a.CinP / 8;
+  const int so = tid % OCT, sv0 = tid / OCT;
+
+  for (int c0 = 0; c0 < a.CinP; c0 += KC) {
+    // ---- stage the haloed input tile for channels [c0, c0+KC): normalise/activate, split into bf16 planes ----
+    __syncthreads();
+    {
+      const int c = c0 + 8 * so;
+      const bool v0ok = c < a.Cin, v1ok = c + 4 < a.Cin;
+      float sc[8], sh[8], sl[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; sl[e] = a.slope; }
+      if (INMODE == MI355_IN_AFFINE_ACT) {
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+          if (hq ? v1ok : v0ok) {
+            const float4 s4 = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c + 4 * hq);
+            const float4 h4 = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c + 4 * hq);
+            sc[4 * hq] = s4.x; sc[4 * hq + 1] = s4.y; sc[4 * hq + 2] = s4.z; sc[4 * hq + 3] = s4.w;
+            sh[4 * hq] = h4.x; sh[4 * hq + 1] = h4.y; sh[4 * hq + 2] = h4.z; sh[4 * hq + 3] = h4.w;
+            if (a.in_slope) {
+              const float4 l4 = *reinterpret_cast<const float4*>(a.in_slope + c + 4 * hq);
+              sl[4 * hq] = l4.x; sl[4 * hq + 1] = l4.y; sl[4 * hq + 2] = l4.z; sl[4 * hq + 3] = l4.w;
+            }
+          }
+        }
+      }
+      for (int hv = sv0; hv < HV; hv += 256 / OCT) {
+        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+        const int iz = tz0 - a.pad + hz, iy = ty0 - a.pad + hy, ix = tx0 - a.pad + hx;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi) {
+          const float* src = a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + c;
+          if (v0ok) { const float4 t = *reinterpret_cast<const float4*>(src); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+          if (v1ok) { const float4 t = *reinterpret_cast<const float4*>(src + 4); v[4] = t.x; v[5] = t.y; v[6] = t.z; v[7] = t.w; }
+          if (INMODE == MI355_IN_AFFINE_ACT) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float u = v[e] * sc[e] + sh[e];
+              v[e] = u > 0.f ? u : u * sl[e];
+            }
+            if (!v0ok) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+            if (!v1ok) { v[4] = v[5] = v[6] = v[7] = 0.f; }
+          }
+        }
+        uint4 pl[NS];
+        split8<NS>(v, pl);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) lds[hv * VSQ + p * OCT + so] = pl[p];
+      }
+    }
+    __syncthreads();
+
+    // ---- 27 taps x J k-steps; B fragments prefetched one step ahead ----
+    const int jn = (a.CinP - c0) / 16 < J ? (a.CinP - c0) / 16 : J;   // wave-uniform
+    const int cq0 = c0 / 8 + half;
+    const int nsteps = 27 * jn;
+    uint4 bcur[NS][NT], bnext[NS][NT];
+#pragma unroll
+    for (int p = 0; p < NS; ++p)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        bcur[p][nt] = a.wp[((size_t)(0 * CQ8 + cq0) * NS + p) * a.CoutP + co_base + nt * 32 + li];
+    int tap = 0, j = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      int jnx = j + 1, tapn = tap;
+      if (jnx == jn) { jnx = 0; tapn = tap + 1; }
+      const int tl = tapn < 27 ? tapn : 26;       // the last step prefetches a valid (unused) address
+#pragma unroll
+      for (int p = 0; p < NS; ++p)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bnext[p][nt] = a.wp[((size_t)(tl * CQ8 + cq0 + 2 * jnx) * NS + p) * a.CoutP + co_base + nt * 32 + li];
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      const int toff = ((dz * HY + dy) * HX + dx) * VSQ + 2 * j;
+      uint4 af[MT][NS];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) af[mt][p] = lds[abase[mt] + toff + p * OCT];
+#pragma unroll
+      for (int q = 0; q < P; ++q)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = MFMA_32x32x16_BF16(af[mt][Products<NS>::pa[q]], bcur[Products<NS>::pb[q]][nt], acc[mt][nt]);
+#pragma unroll
+      for (int p = 0; p < NS; ++p)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bcur[p][nt] = bnext[p][nt];
+      tap = tapn; j = jnx;
+    }
+  }
+
+  // ---- epilogue: bias, residual, dropout scale, windowed store (channel-contiguous across lanes) ----
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = wm * MT + mt;
+    const int mz = m / (TY / 2), my0 = (m % (TY / 2)) * 2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;     // MFMA row = A-operand lane index
+      int rr, rtx;
+      mtile_lane(row, rr, rtx);
+      const int oz = tz0 + mz, oy = ty0 + my0 + rr, ox = tx0 + rtx;
+      if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
+      const int sz = oz + a.offz, sy = oy + a.offy, sx = ox + a.offx;
+      if (sz < 0 || sy < 0 || sx < 0 || sz >= a.yD || sy >= a.yH || sx >= a.yW) continue;
+      const size_t ovox = (((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+      const size_t svox = (((size_t)n * a.yD + sz) * a.yH + sy) * a.yW + sx;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = co_base + nt * 32 + li;
+        if (co >= a.Cout) continue;
+        float v = acc[mt][nt][r];
+        if (a.bias) v += a.bias[co];
+        if (a.res) v += a.res[ovox * a.resld + co];
+        if (a.out_chscale) v *= a.out_chscale[(size_t)n * a.Cout + co];
+        a.y[svox * a.yld + co] = v;
+      }
+    }
+  }
+}
+
+// ---- weight packing: OIDHW fp32 -> [tap][ciP/8][plane][coP][8] bf16 planes ------------------------------------------
+// mode 0: forward pack of a Conv3d weight; mode 1: dgrad pack (taps flipped, roles of ci/co swapped); cout/cin are the
+// PACKED roles as in mi355_pack_conv_weight.
+__global__ void pack_weight_bf16_kernel(const float* w, unsigned short* wp, int cout, int cin, int T, int coutP, int cinP, int mode, int NS) {
+  const size_t total = (size_t)T * (cinP / 8) * coutP * 8;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int e = idx & 7;
+    size_t r = idx >> 3;
+    const int o = r % coutP; r /= coutP;
+    const int i8 = r % (cinP / 8); r /= (cinP / 8);
+    const int t = (int)r;
+    const int i = i8 * 8 + e;
+    float v = 0.f;
+    if (o < cout && i < cin) {
+      const int tf = T - 1 - t;
+      if (mode == 0) v = w[((size_t)o * cin + i) * T + t];
+      else v = w[((size_t)i * cout + o) * T + tf];
+    }
+    for (int p = 0; p < NS; ++p) {
+      const unsigned pk = pack_bf16x2(v, 0.f);
+      wp[((((size_t)t * (cinP / 8) + i8) * NS + p) * coutP + o) * 8 + e] = (unsigned short)(pk & 0xffffu);
+      v -= bf16lo_to_f32(pk);
+    }
+  }
+}
+
+static int nsplit_of(int precision) {
+  switch (precision) {
+    case MI355_PREC_BF16X3: return 2;
+    case MI355_PREC_BF16X6: return 3;
+    case MI355_PREC_BF16: return 1;
+    default: return 0;
+  }
+}
+
+extern "C" size_t mi355_packed_weight_bytes_bf16(int32_t cout, int32_t cin, int32_t kd, int32_t precision) {
+  const int ns = nsplit_of(precision);
+  if (!ns) return 0;
+  const int coutP = (cout + 31) / 32 * 32, cinP = (cin + 15) / 16 * 16;
+  return (size_t)kd * kd * kd * cinP * coutP * ns * 2;
+}
+
+extern "C" int mi355_pack_conv_weight_bf16(const float* w, void* wp, int32_t cout, int32_t cin, int32_t kd, int32_t mode,
+                                           int32_t precision, void* stream) {
+  const int ns = nsplit_of(precision);
+  if (!w || !wp || cout <= 0 || cin <= 0 || kd != 3 || mode < 0 || mode > 1 || !ns) return MI355_EINVAL;
+  const int coutP = (cout + 31) / 32 * 32, cinP = (cin + 15) / 16 * 16;
+  const size_t total = (size_t)27 * cinP * coutP;
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  LAUNCH(pack_weight_bf16_kernel, dim3(grid), dim3(256), 0, stream, w, (unsigned short*)wp, cout, cin, 27, coutP, cinP, mode, ns);
+  return LAUNCH_CHECK();
+}
+
+// ---- dispatch -------------------------------------------------------------------------------------------------------
+template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT>
+static int launch_b(ConvBArgs& a, int in_mode, void* stream) {
+  constexpr int HV = (TZ + 2) * (TY + 2) * 18;
+  constexpr int VSQ = NS * 2 * J + 1;
+  constexpr size_t lds = (size_t)HV * VSQ * 16;
+  static_assert(lds <= 64 * 1024, "LDS tile must fit the default 64 KiB dynamic window");
+  a.tilesZ = ceil_div(a.Do, TZ); a.tilesY = ceil_div(a.Ho, TY); a.tilesX = ceil_div(a.Wo, 16);
+  a.coTiles = ceil_div(a.Cout, 32 * WN * NT);
+  a.spatialTiles = a.N * a.tilesZ * a.tilesY * a.tilesX;
+  const long long blocks = (long long)a.spatialTiles * a.coTiles;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
+  if (in_mode == MI355_IN_PLAIN)
+    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  else
+    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  return LAUNCH_CHECK();
+}
+
+template <int NS>
+static int dispatch_ns(ConvBArgs& a, int in_mode, long long vox, void* stream) {
+  // big volumes: 4x4x16 tiles (256 voxels), 4 waves along M; small: 2x4x16 tiles (128 voxels) so the grid still fills the chip
+  constexpr int J = NS == 1 ? 2 : 1;
+  if constexpr (NS < 3) {     // the 3-plane tile of the big configuration would exceed the 64 KiB LDS window
+    if (vox >= 256LL * 512) {
+      if (a.Cout > 32) return launch_b<4, 4, J, NS, 4, 1, 2, 2>(a, in_mode, stream);
+      return launch_b<4, 4, J, NS, 4, 1, 2, 1>(a, in_mode, stream);
+    }
+  }
+  if (a.Cout > 32) return launch_b<2, 4, J, NS, 2, 2, 2, 1>(a, in_mode, stream);
+  return launch_b<2, 4, J, NS, 4, 1, 1, 1>(a, in_mode, stream);
+}
+
+// called by mi355_conv3d_fwd (conv3d_fwd.hip) when desc->precision selects a bf16 path and the problem qualifies
+int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
+  const int ns = nsplit_of(d->precision);
+  if (!ns || d->kd != 3 || d->stride != 1) return MI355_EUNSUPPORTED;
+  if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
+  ConvBArgs a;
+  a.x = (const float*)x->p; a.xld = x->ld; a.wp = (const uint4*)wp; a.y = (float*)y->p; a.yld = y->ld;
+  a.res = d->residual; a.resld = d->residual_ld;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope;
+  a.out_chscale = d->out_chscale; a.bias = d->bias;
+  a.N = x->n; a.Di = x->d; a.Hi = x->h; a.Wi = x->w; a.Cin = x->c; a.CinP = (x->c + 15) / 16 * 16;
+  a.Do = d->out_d; a.Ho = d->out_h; a.Wo = d->out_w; a.Cout = y->c; a.CoutP = (y->c + 31) / 32 * 32;
+  a.yD = y->d; a.yH = y->h; a.yW = y->w; a.offz = d->off_z; a.offy = d->off_y; a.offx = d->off_x;
+  a.pad = d->pad;
+  if (a.res && a.resld < a.Cout) return MI355_EINVAL;
+  const long long vox = (long long)a.Do * a.Ho * a.Wo * a.N;
+  if (ns == 1) return dispatch_ns<1>(a, d->in_mode, vox, stream);
+  if (ns == 2) return dispatch_ns<2>(a, d->in_mode, vox, stream);
+  return dispatch_ns<3>(a, d->in_mode, vox, stream);
+}

@@ -68,13 +68,16 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
     abase[mt] = (((tz * STRIDE) * HY + ty * STRIDE) * HX + tx * STRIDE) * VS + half * 4;
   }
 
-  f32x16 acc[MT][NT];
+  // Two-level accumulation: the MFMAs of one channel chunk (27*KC products) chain into `accc`, which is folded into `acc`
+  // at the end of the chunk. Keeps the sequential fp32 chain at <= 864 terms instead of 27*Cin (6912 at Cin = 256), which
+  // brings the roundoff of the deep layers down to the level of a blocked CPU convolution.
+  f32x16 acc[MT][NT], accc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; accc[mt][nt][r] = 0.f; }
 
   const int CQ = a.CinP / 4;
   const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
@@ -169,10 +172,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            acc[mt][nt] = MFMA_32x32x2(af[mt].x, bcur[j][nt].x, acc[mt][nt]);
-            acc[mt][nt] = MFMA_32x32x2(af[mt].y, bcur[j][nt].y, acc[mt][nt]);
-            acc[mt][nt] = MFMA_32x32x2(af[mt].z, bcur[j][nt].z, acc[mt][nt]);
-            acc[mt][nt] = MFMA_32x32x2(af[mt].w, bcur[j][nt].w, acc[mt][nt]);
+            accc[mt][nt] = MFMA_32x32x2(af[mt].x, bcur[j][nt].x, accc[mt][nt]);
+            accc[mt][nt] = MFMA_32x32x2(af[mt].y, bcur[j][nt].y, accc[mt][nt]);
+            accc[mt][nt] = MFMA_32x32x2(af[mt].z, bcur[j][nt].z, accc[mt][nt]);
+            accc[mt][nt] = MFMA_32x32x2(af[mt].w, bcur[j][nt].w, accc[mt][nt]);
           }
       }
 #pragma unroll
@@ -180,6 +183,12 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bcur[j][nt] = bnext[j][nt];
     }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[mt][nt][r] += accc[mt][nt][r]; accc[mt][nt][r] = 0.f; }
   }
 
   // ---- epilogue: bias, residual, dropout scale, windowed store ----
@@ -308,6 +317,13 @@ static int select_cfg(int kd, int stride, long long vox, int cout) {
   return cout > 32 ? 6 : 7;
 }
 
+int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream);
+
+extern "C" int mi355_conv3d_uses_bf16(const mi355_conv_desc* d) {
+  return d && d->precision != MI355_PREC_F32 && d->kd == 3 && d->stride == 1 &&
+         (d->in_mode == MI355_IN_PLAIN || d->in_mode == MI355_IN_AFFINE_ACT);
+}
+
 extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
   if (!x || !y || !wp || !d || !x->p || !y->p) return MI355_EINVAL;
   if ((d->kd != 1 && d->kd != 3) || (d->stride != 1 && d->stride != 2)) return MI355_EUNSUPPORTED;
@@ -318,6 +334,11 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
   if ((d->in_mode == MI355_IN_S2D || d->out_mode == MI355_OUT_D2S) && d->kd != 1) return MI355_EUNSUPPORTED;
   if (d->in_mode == MI355_IN_S2D && d->out_mode == MI355_OUT_D2S) return MI355_EUNSUPPORTED;
   if (d->out_mode != MI355_OUT_PLAIN && d->out_mode != MI355_OUT_D2S) return MI355_EINVAL;
+  if (d->precision < MI355_PREC_F32 || d->precision > MI355_PREC_BF16) return MI355_EINVAL;
+  if (mi355_conv3d_uses_bf16(d)) {
+    if (d->out_d <= 0 || d->out_h <= 0 || d->out_w <= 0) return MI355_EINVAL;
+    return mi355_conv3d_fwd_bf16_impl(x, wp, y, d, stream);
+  }
   if (d->in_mode == MI355_IN_ZERO_INSERT && d->stride != 1) return MI355_EINVAL;
   ConvArgs a;
   a.x = (const float*)x->p; a.xld = x->ld; a.wp = wp; a.y = (float*)y->p; a.yld = y->ld;

@@ -19,6 +19,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // lane holds D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] for r in [0,16).
 #define MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) float name[]
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+0..7] and B[k=8*(l>>5)+0..7][j=l&31] as 8 packed bf16
+// (16 bytes, carried here as uint4); same C/D map as the f32 form. 32 cycles per SIMD = 16x the f32 MFMA rate.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define MFMA_32x32x16_BF16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+// two floats -> two bf16 (round to nearest even) packed in one dword (first argument in the low half): v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
 #define LAUNCH(kernel, grid, block, lds, stream, ...) \
   hipLaunchKernelGGL(kernel, (grid), (block), (lds), (hipStream_t)(stream), __VA_ARGS__)
 #define LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? 0 : -3)
@@ -31,3 +43,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MI355_EWORKSPACE (-4)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// value of the bf16 stored in the low / high half of a packed dword
+__device__ __forceinline__ float bf16lo_to_f32(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(unsigned p) { return __uint_as_float(p & 0xffff0000u); }

@@ -88,7 +88,7 @@ class HipNetBase(nn.Module):
             self._packed[id(p)] = ent
         if mode not in ent[1]:
             w = p.data if transform is None else transform(p.data).contiguous()
-            ent[1][mode] = self._be.pack_weight(w, mode)
+            ent[1][mode] = self._be.pack_weight(w, mode)      # lazily packed per format (ops.PackedWeight)
         return ent[1][mode]
 
     # ---- forward / backward bridge -------------------------------------------------------------------------------

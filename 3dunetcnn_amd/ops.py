@@ -13,7 +13,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import IN_AFFINE_ACT, IN_PLAIN, IN_S2D, IN_ZERO_INSERT, OUT_D2S, OUT_PLAIN, MiAct, MiConvDesc, check  # noqa: F401
+from ._lib import (IN_AFFINE_ACT, IN_PLAIN, IN_S2D, IN_ZERO_INSERT, OUT_D2S, OUT_PLAIN, PREC_F32, PRECISIONS,  # noqa: F401
+                   MiAct, MiConvDesc, check)
 
 
 class Act:
@@ -57,6 +58,51 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+class PackedWeight:
+    """Kernel-layout copies of one conv weight, packed on first use per format: the fp32 MFMA layout and, when the backend
+    runs its 3x3x3 stride-1 convolutions on the split-bf16 matrix path, the bf16-plane layout of that precision. Which one a
+    conv call consumes is decided by the library (mi355_conv3d_uses_bf16)."""
+
+    def __init__(self, be, w, mode):
+        assert w.is_contiguous() and w.dtype == torch.float32
+        self.be, self.w, self.mode = be, w, mode
+        kd = w.shape[2]
+        if mode in (0, 3):
+            self.cout, self.cin = w.shape[0], w.shape[1]
+        else:
+            self.cout, self.cin = w.shape[1], w.shape[0]
+        self.kd = kd
+        self._f32 = None
+        self._bf16 = {}
+
+    def f32(self):
+        if self._f32 is None:
+            be = self.be
+            n = be.lib.mi355_packed_weight_elems(self.cout, self.cin, self.kd, self.mode)
+            out = torch.empty(n, dtype=torch.float32, device=self.w.device)
+            check(be.lib.mi355_pack_conv_weight(self.w.data_ptr(), out.data_ptr(), self.cout, self.cin, self.kd, self.mode, be.stream()),
+                  "pack_conv_weight")
+            self._f32 = out
+        return self._f32
+
+    def bf16(self, precision):
+        if precision not in self._bf16:
+            be = self.be
+            nb = be.lib.mi355_packed_weight_bytes_bf16(self.cout, self.cin, self.kd, precision)
+            if nb == 0 or self.mode not in (0, 1):
+                raise RuntimeError("no bf16 pack for this weight / precision")
+            out = torch.empty((nb + 3) // 4, dtype=torch.int32, device=self.w.device)
+            check(be.lib.mi355_pack_conv_weight_bf16(self.w.data_ptr(), out.data_ptr(), self.cout, self.cin, self.kd, self.mode, precision,
+                                                     be.stream()), "pack_conv_weight_bf16")
+            self._bf16[precision] = out
+        return self._bf16[precision]
+
+    def ptr_for(self, desc):
+        if self.be.lib.mi355_conv3d_uses_bf16(ctypes.byref(desc)):
+            return self.bf16(desc.precision).data_ptr()
+        return self.f32().data_ptr()
+
+
 class Backend:
     def __init__(self, lib=None, device=None):
         self.lib = lib if lib is not None else _lib.load_library()
@@ -66,7 +112,12 @@ class Backend:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
         self._ws = None
+        self.precision = PREC_F32   # arithmetic of the 3x3x3 stride-1 convs: see set_precision()
         self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
+
+    def set_precision(self, name):
+        """"fp32" (exact f32 MFMA, default) | "bf16x3" | "bf16x6" (split-bf16 fp32 emulation) | "bf16" (mixed precision)."""
+        self.precision = PRECISIONS[name] if isinstance(name, str) else int(name)
 
     # -- plumbing ------------------------------------------------------------------------------------------------
     def stream(self):
@@ -87,30 +138,15 @@ class Backend:
         return Act(torch.zeros(n, d, h, w, ld or c, dtype=torch.float32, device=self.device), 0, c)
 
     # -- weights -------------------------------------------------------------------------------------------------
-    def pack_weight(self, w, mode, out=None):
+    def pack_weight(self, w, mode):
         """w: Conv3d weight [O, I, k, k, k] (modes 0, 1) or ConvTranspose3d weight [I, O, k, k, k] (modes 2, 3)."""
-        assert w.is_contiguous() and w.dtype == torch.float32
-        kd = w.shape[2]
-        if mode == 0:
-            cout, cin = w.shape[0], w.shape[1]
-        elif mode == 1:
-            cout, cin = w.shape[1], w.shape[0]
-        elif mode == 2:
-            cout, cin = w.shape[1], w.shape[0]
-        else:
-            cout, cin = w.shape[0], w.shape[1]
-        n = self.lib.mi355_packed_weight_elems(cout, cin, kd, mode)
-        if out is None:
-            out = torch.empty(n, dtype=torch.float32, device=w.device)
-        assert out.numel() >= n
-        check(self.lib.mi355_pack_conv_weight(w.data_ptr(), out.data_ptr(), cout, cin, kd, mode, self.stream()), "pack_conv_weight")
-        return out
+        return PackedWeight(self, w, mode)
 
     # -- conv ----------------------------------------------------------------------------------------------------
     def _desc(self, kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep, in_slope=None,
               out_mode=OUT_PLAIN):
         d = MiConvDesc()
-        d.in_slope, d.out_mode = _p(in_slope), out_mode
+        d.in_slope, d.out_mode, d.precision = _p(in_slope), out_mode, self.precision
         keep.append(in_slope)
         d.kd, d.stride, d.pad, d.in_mode, d.act_slope = kd, stride, pad, in_mode, slope
         d.in_scale, d.in_shift, d.bias = _p(scale), _p(shift), _p(bias)
@@ -131,11 +167,13 @@ class Backend:
         d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep, in_slope, out_mode)
         xd, yd = x.desc(), y.desc()
         if self.prof is None:
-            check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wp.data_ptr(), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
+            check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wp.ptr_for(d), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
             return
         # profiling: HIP events on the launch stream around this one kernel, keyed by the kernel's trace name
         name = ctypes.create_string_buffer(96)
         self.lib.mi355_conv3d_fwd_config(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d), name, 96)
+        if self.lib.mi355_conv3d_uses_bf16(ctypes.byref(d)):
+            name.value = b"conv3d_k3_bf16<...>"
         nvox = x.shape[0] * out_dhw[0] * out_dhw[1] * out_dhw[2]
         flops = 2.0 * nvox * x.c * y.c * kd ** 3 * (8 if (in_mode == IN_S2D or out_mode == OUT_D2S) else 1)
         if in_mode == IN_ZERO_INSERT:
@@ -143,7 +181,7 @@ class Backend:
         byts = 4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * x.c + nvox * y.c + kd ** 3 * x.c * y.c)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wp.data_ptr(), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
+        check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wp.ptr_for(d), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
         e1.record()
         self.prof.append((name.value.decode(), flops, byts, e0, e1))
 

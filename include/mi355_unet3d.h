@@ -47,6 +47,14 @@ typedef struct mi355_act {
                                   (d,h,w,8c), logical channel p*c + k with p = 4a+2b+e  <->  x[2z+a,2y+b,2x+e,k].
                                   dgrad of ConvTranspose3d(k2,s2) (MONAI DynUNet up block). x->d/h/w are the FINE extents. */
 
+/* Arithmetic of the 3x3x3 stride-1 conv kernels (forward, dgrad and wgrad). Inputs, outputs and accumulation are fp32 in every
+ * mode; the modes differ in how the fp32 x fp32 products are formed on the matrix pipe. */
+#define MI355_PREC_F32 0     /* v_mfma_f32_32x32x2_f32: exact fp32 products (bitwise a k-ordered fmaf chain). 157 TFLOP/s peak. */
+#define MI355_PREC_BF16X3 1  /* each operand split into 2 bf16 planes (hi + lo), 3 bf16-MFMA products hi*hi + hi*lo + lo*hi:
+                                product error <= ~2^-16 relative ("3xBF16 fp32 emulation"). 2.5 PFLOP/s / 3 peak. */
+#define MI355_PREC_BF16X6 2  /* 3 planes, the 6 products of order <= 2: ~2^-23, fp32-class. 2.5 PFLOP/s / 6 peak. */
+#define MI355_PREC_BF16 3    /* operands rounded to bf16, one product: autocast-style mixed precision. 2.5 PFLOP/s peak. */
+
 /* Output-side layout of the conv kernels. */
 #define MI355_OUT_PLAIN 0
 #define MI355_OUT_D2S 1        /* kd == 1 only: y is a FINE tensor (2d,2h,2w,c); logical output channel p*c + k of coarse voxel
@@ -75,6 +83,7 @@ typedef struct mi355_conv_desc {
                             whose first channels are a raw tensor (slope 1, scale 1, shift 0 = identity) and whose last channels
                             are a normalised+LeakyReLU'd skip (MONAI UnetUpBlock: cat((up, skip), 1) -> conv) needs this. */
   int32_t out_mode;      /* MI355_OUT_* */
+  int32_t precision;     /* MI355_PREC_*: arithmetic of the 3x3x3 stride-1 convolutions (everything else is always F32) */
 } mi355_conv_desc;
 
 /* ---- weight packing -------------------------------------------------------------------------- */
@@ -85,6 +94,13 @@ typedef struct mi355_conv_desc {
  * mode 3: dgrad pack of a ConvTranspose3d weight (= plain stride-2 correlation of dy). */
 size_t mi355_packed_weight_elems(int32_t cout, int32_t cin, int32_t kd, int32_t mode);
 int mi355_pack_conv_weight(const float* w, float* wp, int32_t cout, int32_t cin, int32_t kd, int32_t mode, void* stream);
+
+/* Packed layouts of the bf16 paths: [tap][cinP/8][plane][coutP][8] bf16, cinP = roundup(cin,16), planes per `precision`.
+ * Same `mode` / role conventions as mi355_pack_conv_weight (modes 0 and 1, kd == 3). mi355_conv3d_uses_bf16 tells the caller
+ * which pack a given conv call consumes (1: the bf16 pack of desc->precision, 0: the fp32 pack). */
+size_t mi355_packed_weight_bytes_bf16(int32_t cout, int32_t cin, int32_t kd, int32_t precision);
+int mi355_pack_conv_weight_bf16(const float* w, void* wp, int32_t cout, int32_t cin, int32_t kd, int32_t mode, int32_t precision, void* stream);
+int mi355_conv3d_uses_bf16(const mi355_conv_desc* desc);
 
 /* ---- convolution ------------------------------------------------------------------------------ */
 /* Replaces torch.nn.Conv3d.forward (F.conv3d) for k in {1,3}, stride in {1,2}, bias-free or biased, with the

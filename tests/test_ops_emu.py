@@ -101,3 +101,31 @@ def test_adam(emu_backend):
 
 def test_layout(emu_backend):
     assert C.case_layout(emu_backend, 2, 4, (5, 6, 7)) == 0.0
+
+
+# ---- split-bf16 matrix path of the 3x3x3 stride-1 convs (csrc/conv3d_bf16.hip): fp32 in/out, products on bf16 MFMA ----
+BF16_TOL = {"bf16x3": 1e-4, "bf16x6": 5e-6, "bf16": 3e-2}
+
+
+@pytest.fixture(params=["bf16x3", "bf16x6", "bf16"])
+def prec_backend(emu_backend, request):
+    emu_backend.set_precision(request.param)
+    yield emu_backend, BF16_TOL[request.param]
+    emu_backend.set_precision("fp32")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=32, cout=32, dhw=(3, 5, 19), norm=True, residual=True, chscale=True),
+    dict(n=1, cin=8, cout=64, dhw=(4, 4, 16), norm=True, yld=128, yc0=32),
+    dict(n=1, cin=4, cout=32, dhw=(3, 4, 17), bias=True),
+    dict(n=1, cin=48, cout=40, dhw=(2, 6, 9), norm=True, slope=0.01),
+])
+def test_conv_fwd_bf16_paths(prec_backend, kw):
+    be, tol = prec_backend
+    assert C.case_conv_fwd(be, **kw) < tol
+
+
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=64, dhw=(3, 4, 18)), dict(n=2, cin=64, cout=32, dhw=(4, 4, 16))])
+def test_conv_dgrad_bf16_paths(prec_backend, kw):
+    be, tol = prec_backend
+    assert C.case_conv_dgrad(be, **kw) < tol

@@ -105,3 +105,33 @@ def test_adam(hip_backend):
 
 def test_layout(hip_backend):
     assert C.case_layout(hip_backend, 2, 4, (33, 32, 31)) == 0.0
+
+
+# ---- split-bf16 matrix path of the 3x3x3 stride-1 convs (csrc/conv3d_bf16.hip): fp32 in/out, products on bf16 MFMA ----
+BF16_TOL = {"bf16x3": 1e-4, "bf16x6": 5e-6, "bf16": 3e-2}
+
+
+@pytest.fixture(params=["bf16x3", "bf16x6", "bf16"])
+def prec_backend(hip_backend, request):
+    hip_backend.set_precision(request.param)
+    yield hip_backend, BF16_TOL[request.param]
+    hip_backend.set_precision("fp32")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=32, cout=32, dhw=(9, 10, 37), norm=True, residual=True, chscale=True),
+    dict(n=2, cin=64, cout=96, dhw=(16, 16, 32), norm=True, yld=128, yc0=32),
+    dict(n=1, cin=4, cout=32, dhw=(32, 32, 32), norm=True),
+    dict(n=2, cin=32, cout=32, dhw=(48, 64, 64), norm=True, residual=True),          # big-tile configuration
+    dict(n=1, cin=128, cout=128, dhw=(16, 16, 16)),
+    dict(n=1, cin=24, cout=40, dhw=(7, 9, 20), norm=True, slope=0.01, bias=True),
+])
+def test_conv_fwd_bf16_paths(prec_backend, kw):
+    be, tol = prec_backend
+    assert C.case_conv_fwd(be, **kw) < tol
+
+
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=64, dhw=(16, 17, 18)), dict(n=2, cin=64, cout=32, dhw=(32, 32, 32))])
+def test_conv_dgrad_bf16_paths(prec_backend, kw):
+    be, tol = prec_backend
+    assert C.case_conv_dgrad(be, **kw) < tol

@@ -48,14 +48,17 @@ def unpack(wp, cout, cin, kd):
 
 orig_conv, orig_wgrad, orig_gnb = be.conv_fwd, be.conv_wgrad, be.gn_act_bwd
 count = [0]
+in_bwd = [False]
 
 
 def conv_fwd(x, wp, y, kd, stride=1, pad=None, in_mode=0, slope=0.0, scale=None, shift=None, bias=None, residual=None, chscale=None,
              off=(0, 0, 0), out_dhw=None, **kw):
     orig_conv(x, wp, y, kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, **kw)
+    if not in_bwd[0]:
+        return
     pad_ = kd // 2 if pad is None else pad
     t = act_in(x, in_mode, slope, scale, shift)
-    w = unpack(wp, y.c, x.c, kd)
+    w = unpack(wp.f32(), y.c, x.c, kd)
     if in_mode == ops.IN_ZERO_INSERT:
         z = torch.zeros(t.shape[0], t.shape[1], *[2 * s - 1 for s in t.shape[2:]], dtype=torch.float64)
         z[:, :, ::2, ::2, ::2] = t
@@ -87,6 +90,7 @@ def conv_fwd(x, wp, y, kd, stride=1, pad=None, in_mode=0, slope=0.0, scale=None,
     print(f"#{count[0]:3d} conv_fwd  k{kd} s{stride} mode{in_mode} {x.c:3d}->{y.c:3d} @{tuple(y.shape[1:4])} res={residual is not None} err {e:.2e}{flag}", flush=True)
 
 
+@torch.enable_grad()
 def conv_wgrad(x, dy, dw, kd, stride=1, pad=None, in_mode=0, slope=0.0, scale=None, shift=None, **kw):
     orig_wgrad(x, dy, dw, kd, stride, pad, in_mode, slope, scale, shift, **kw)
     pad_ = kd // 2 if pad is None else pad
@@ -100,6 +104,7 @@ def conv_wgrad(x, dy, dw, kd, stride=1, pad=None, in_mode=0, slope=0.0, scale=No
     print(f"#{count[0]:3d} conv_wgrad k{kd} s{stride} mode{in_mode} {x.c:3d}->{dy.c:3d} @{tuple(dy.shape[1:4])} err {e:.2e}{flag}", flush=True)
 
 
+@torch.enable_grad()
 def gn_act_bwd(x, dA, dx, groups, slope, gamma, mean_rstd, scale, shift, dgamma, dbeta, addend=None):
     xin = nc(x).requires_grad_(True)
     g = gamma.detach().cpu().double().requires_grad_(True)
@@ -133,4 +138,5 @@ crit = losses.HipDiceLoss(sigmoid=True); crit._be = be
 dev = "cuda" if args.gpu else "cpu"
 out = m(x.to(dev)); loss = crit(out, y.to(dev))
 print("---- backward ----", flush=True)
+in_bwd[0] = True
 loss.backward()

@@ -39,6 +39,10 @@ typedef void* hipStream_t;
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x,y,z,w}; }
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x,y,z,w}; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float2 make_float2(float x, float y) { return float2{x,y}; }
 typedef float f32x16 __attribute__((vector_size(64)));
 typedef float f32x4  __attribute__((vector_size(16)));
@@ -63,6 +67,7 @@ struct BlockState {
   // exchange scratch
   double xchg[2048];
   float  mfma_a[2048]; float mfma_b[2048];
+  uint4  mfma_a4[1024]; uint4 mfma_b4[1024];
   std::function<void()> body;
   char* dyn_lds = nullptr;
 };
@@ -185,6 +190,42 @@ static inline f32x16 emu_mfma_32x32x2(float a, float b, f32x16 c) {
   return c;
 }
 #define MFMA_32x32x2(a, b, c) emu_mfma_32x32x2(a, b, c)
+
+// bf16 helpers (round to nearest even, as v_cvt_pk_bf16_f32)
+static inline unsigned emu_f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7f800000u) == 0x7f800000u && (u & 0x007fffffu)) return (u >> 16) | 0x40u;   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+static inline unsigned pack_bf16x2(float lo, float hi) { return emu_f2bf(lo) | (emu_f2bf(hi) << 16); }
+// D = A(32x16) * B(16x32) + C, bf16 inputs: lane l supplies A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31], e in [0,8).
+// Products of bf16 are exact in f32; the 16-term sum is formed in double and rounded once with C (the hardware's internal
+// order is unspecified; this is test infrastructure for index logic, not a bitwise model of the bf16 MFMA).
+static inline f32x16 emu_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
+  emu::BlockState* bs = emu::g_bs;
+  int t = emu::flat_tid();
+  int wbase = (t / 64) * 64, l = t % 64;
+  bs->mfma_a4[t] = a; bs->mfma_b4[t] = b;
+  emu::wave_barrier();
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    double acc = (double)c[r];
+    for (int h = 0; h < 2; ++h) {
+      const unsigned* pa = &bs->mfma_a4[wbase + 32 * h + row].x;
+      const unsigned* pb = &bs->mfma_b4[wbase + 32 * h + col].x;
+      for (int e = 0; e < 4; ++e) {
+        acc += (double)__uint_as_float(pa[e] << 16) * (double)__uint_as_float(pb[e] << 16);
+        acc += (double)__uint_as_float(pa[e] & 0xffff0000u) * (double)__uint_as_float(pb[e] & 0xffff0000u);
+      }
+    }
+    c[r] = (float)acc;
+  }
+  emu::wave_barrier();
+  return c;
+}
+#define MFMA_32x32x16_BF16(a, b, c) emu_mfma_32x32x16_bf16(a, b, c)
 
 static inline float atomicAdd(float* p, float v) {
   std::atomic_ref<float> r(*p); float old = r.load();
