@@ -33,7 +33,7 @@ struct ConvArgs {
   int cD, cH, cW, fC;      // IN_S2D / OUT_D2S (1x1x1 only): coarse grid extents and the fine tensor's channel count
 };
 
-template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT, int INMODE>
+template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT, int INMODE, bool TL = false>
 __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TZ * TY * TX == 32 * WM * MT, "tile voxels must equal 32*WM*MT");
@@ -68,16 +68,17 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
     abase[mt] = (((tz * STRIDE) * HY + ty * STRIDE) * HX + tx * STRIDE) * VS + half * 4;
   }
 
-  // Two-level accumulation: the MFMAs of one channel chunk (27*KC products) chain into `accc`, which is folded into `acc`
-  // at the end of the chunk. Keeps the sequential fp32 chain at <= 864 terms instead of 27*Cin (6912 at Cin = 256), which
-  // brings the roundoff of the deep layers down to the level of a blocked CPU convolution.
-  f32x16 acc[MT][NT], accc[MT][NT];
+  // Two-level accumulation (TL, selected for Cin >= 4 chunks): the MFMAs of one channel chunk (27*KC products) chain into
+  // `accc`, which is folded into `acc` at the end of the chunk. Keeps the sequential fp32 chain at <= 864 terms instead of
+  // 27*Cin (6912 at Cin = 256), which brings the roundoff of the deep layers down to that of a blocked CPU convolution.
+  // Without TL both names are the same accumulator (single chain).
+  f32x16 acc[MT][NT], accc[TL ? MT : 1][TL ? NT : 1];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; accc[mt][nt][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; if (TL) accc[mt][nt][r] = 0.f; }
 
   const int CQ = a.CinP / 4;
   const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
@@ -172,10 +173,11 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            accc[mt][nt] = MFMA_32x32x2(af[mt].x, bcur[j][nt].x, accc[mt][nt]);
-            accc[mt][nt] = MFMA_32x32x2(af[mt].y, bcur[j][nt].y, accc[mt][nt]);
-            accc[mt][nt] = MFMA_32x32x2(af[mt].z, bcur[j][nt].z, accc[mt][nt]);
-            accc[mt][nt] = MFMA_32x32x2(af[mt].w, bcur[j][nt].w, accc[mt][nt]);
+            f32x16& ac = TL ? accc[TL ? mt : 0][TL ? nt : 0] : acc[mt][nt];
+            ac = MFMA_32x32x2(af[mt].x, bcur[j][nt].x, ac);
+            ac = MFMA_32x32x2(af[mt].y, bcur[j][nt].y, ac);
+            ac = MFMA_32x32x2(af[mt].z, bcur[j][nt].z, ac);
+            ac = MFMA_32x32x2(af[mt].w, bcur[j][nt].w, ac);
           }
       }
 #pragma unroll
@@ -183,12 +185,14 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bcur[j][nt] = bnext[j][nt];
     }
+    if (TL) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[mt][nt][r] += accc[mt][nt][r]; accc[mt][nt][r] = 0.f; }
+          for (int r = 0; r < 16; ++r) { acc[mt][nt][r] += accc[TL ? mt : 0][TL ? nt : 0][r]; accc[TL ? mt : 0][TL ? nt : 0][r] = 0.f; }
+    }
   }
 
   // ---- epilogue: bias, residual, dropout scale, windowed store ----
@@ -288,10 +292,13 @@ static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
   a.coTiles = ceil_div(a.Cout, 32 * WN * NT);
   const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
+  const bool tl = KD == 3 && a.CinP >= 4 * KC;
   if (in_mode == MI355_IN_PLAIN) {
-    LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_PLAIN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    if (tl) LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_PLAIN, KD == 3>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    else LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_PLAIN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   } else if (in_mode == MI355_IN_AFFINE_ACT) {
-    LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_AFFINE_ACT>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    if (tl) LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_AFFINE_ACT, KD == 3>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    else LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_AFFINE_ACT>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   } else if (in_mode == MI355_IN_S2D) {
     if constexpr (KD == 1) {
       LAUNCH((conv3d_mfma<1, 1, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_S2D>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
@@ -400,7 +407,10 @@ extern "C" int mi355_conv3d_fwd_config(const mi355_act* x, const mi355_act* y, c
                                       "4, 4, 8, 8, 0, 4, 1, 1, 2", "4, 4, 8, 8, 0, 4, 1, 1, 1",
                                       "3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 2", "3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 1",
                                       "3, 1, 2, 4, 8, 32, 4, 2, 2, 1, 1", "3, 1, 4, 4, 8, 32, 4, 4, 1, 1, 1"};
-  if (cfg == 2 || cfg == 3) snprintf(out, n, "conv3d_mfma<3, %d, %s, %d>", stride_t, tags[cfg], d->in_mode);
-  else snprintf(out, n, "conv3d_mfma<%s, %d>", tags[cfg], d->in_mode);
+  static const int kcs[8] = {32, 32, 8, 8, 16, 16, 32, 32};
+  const int cinP = (x->c + 7) / 8 * 8;
+  const char* tl = (d->kd == 3 && cinP >= 4 * kcs[cfg]) ? "true" : "false";
+  if (cfg == 2 || cfg == 3) snprintf(out, n, "conv3d_mfma<3, %d, %s, %d, %s>", stride_t, tags[cfg], d->in_mode, tl);
+  else snprintf(out, n, "conv3d_mfma<%s, %d, %s>", tags[cfg], d->in_mode, tl);
   return 0;
 }

@@ -175,6 +175,21 @@ __global__ void wgrad_reduce_kernel(const float* ws, float* dw, int Cout, int Ci
   }
 }
 
+int mi355_wgrad_reduce_launch(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles, void* stream) {
+  const size_t total = (size_t)T * Cout * Cin;
+  int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
+  LAUNCH(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, stream, ws, dw, Cout, Cin, T, SL, ciTiles);
+  return LAUNCH_CHECK();
+}
+
+size_t mi355_conv3d_wgrad_bf16_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d);
+int mi355_conv3d_wgrad_bf16_impl(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d,
+                                 void* ws, size_t ws_bytes, void* stream);
+static int wgrad_uses_bf16(const mi355_conv_desc* d) {
+  return d->precision != MI355_PREC_F32 && d->kd == 3 && d->stride == 1 && d->pad == 1 && d->out_mode == MI355_OUT_PLAIN &&
+         (d->in_mode == MI355_IN_PLAIN || d->in_mode == MI355_IN_AFFINE_ACT);
+}
+
 struct WgradPlan { int tz, ty, tx, ntiles, tilesZ, tilesY, tilesX, splits, ciTiles, coTiles, wv, coutL; size_t ws_bytes; int ok; };
 
 static WgradPlan plan_wgrad(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
@@ -213,6 +228,7 @@ static WgradPlan plan_wgrad(const mi355_act* x, const mi355_act* dy, const mi355
 }
 
 extern "C" size_t mi355_conv3d_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  if (d && wgrad_uses_bf16(d)) return mi355_conv3d_wgrad_bf16_workspace(x, dy, d);
   WgradPlan p = plan_wgrad(x, dy, d);
   return p.ok ? p.ws_bytes : 0;
 }
@@ -237,6 +253,8 @@ extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float
   if (((uintptr_t)x->p & 15) || ((uintptr_t)dy->p & 15)) return MI355_EINVAL;
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
   if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift)) return MI355_EINVAL;
+  if (d->precision < MI355_PREC_F32 || d->precision > MI355_PREC_BF16) return MI355_EINVAL;
+  if (wgrad_uses_bf16(d)) return mi355_conv3d_wgrad_bf16_impl(x, dy, dw, d, ws, ws_bytes, stream);
   WgradPlan p = plan_wgrad(x, dy, d);
   if (!p.ok) return MI355_EUNSUPPORTED;
   if (ws_bytes < p.ws_bytes) return MI355_EWORKSPACE;
@@ -263,8 +281,5 @@ extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float
   }
   if (rc) return rc;
   const int T = d->kd * d->kd * d->kd;
-  const size_t total = (size_t)T * a.Cout * a.Cin;
-  int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
-  LAUNCH(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, stream, (const float*)ws, dw, a.Cout, a.Cin, T, p.splits * p.wv, p.ciTiles);
-  return LAUNCH_CHECK();
+  return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, T, p.splits * p.wv, p.ciTiles, stream);
 }

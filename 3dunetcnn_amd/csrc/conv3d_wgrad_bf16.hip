@@ -1,0 +1,307 @@
+// 3x3x3 stride-1 conv3d weight gradient on gfx950 bf16 MFMA (v_mfma_f32_32x32x16_bf16) with split fp32 operands.
+//
+//   dw[co][ci][tap] = sum_{n,v} dy[n,v,co] * in(x)[n, v + tap - 1, ci]        (autograd of F.conv3d wrt the weight;
+//   reference layers: unet3d/models/pytorch/classification/resnet.py:12-22, input transform myronenko.py:18-19)
+//
+// Same precision modes as conv3d_bf16.hip (NS bf16 planes per operand, Products<NS> MFMA products, fp32 accumulate).
+// GEMM view per tap: D[co][ci] (32x32) += A[co][voxel] * B[voxel][ci], K = 16 consecutive x-voxels per MFMA. Both operands
+// need 8 consecutive VOXELS per lane, so the tiles are transposed to channel-major while they are staged (each thread loads
+// 8 voxels x 4 channels as float4s, applies the fused norm + activation, splits into bf16 planes and writes one 16-byte
+// run per channel). LDS (16-byte units, odd channel strides -> conflict-free ds_read_b128):
+//   dy tile  [plane][32*MT co][4 y-rows][2 x-octets]
+//   x  tile  [plane][32 ci][3 z-planes (ring)][6 y-rows][3 x-octets]   (halo: x0-1 .. x0+16)
+// A workgroup = 9 waves = the 9 (dz,dy) tap rows; a wave owns the 3 dx taps of its row (3*MT accumulators) and forms the
+// dx-shifted B fragments from two aligned octets with funnel shifts (v_alignbit) -- no unaligned LDS access, no copies.
+// It walks a contiguous range of output tiles (1 x 4 x 16 voxels) with z fastest and keeps a rolling window of three input
+// z-planes in LDS, so each step stages one new plane (x halo re-read factor 1.7 instead of 5). Partial sums go to the same
+// workspace slabs as the f32 kernel and are reduced by the same deterministic second pass.
+#include "hipcompat.h"
+#include "../../include/mi355_unet3d.h"
+
+int mi355_wgrad_reduce_launch(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles, void* stream);
+
+struct WgradBArgs {
+  const float* x; int xld;
+  const float* dy; int dyld;
+  float* ws;
+  const float* in_scale; const float* in_shift; float slope; const float* in_slope;
+  int N, D, H, W, Cin, Cout;
+  int tilesY, tilesX, ntiles;      // tile index = ((n*tilesY + ty)*tilesX + tx)*D + z   (z fastest)
+  int splits, ciTiles, coTiles32;
+};
+
+template <int NS> struct WProducts;
+template <> struct WProducts<1> { static constexpr int P = 1; static constexpr int pa[1] = {0}; static constexpr int pb[1] = {0}; };
+template <> struct WProducts<2> { static constexpr int P = 3; static constexpr int pa[3] = {1, 0, 0}; static constexpr int pb[3] = {0, 1, 0}; };
+template <> struct WProducts<3> { static constexpr int P = 6; static constexpr int pa[6] = {2, 1, 0, 1, 0, 0}; static constexpr int pb[6] = {0, 1, 2, 0, 1, 0}; };
+
+// column c of an 8-voxel x 4-channel register block -> NS planes of 8 packed bf16
+template <int NS>
+__device__ __forceinline__ void split_col(const float (&v)[8][4], int c, uint4 (&out)[NS]) {
+  float r[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = v[e][c];
+#pragma unroll
+  for (int p = 0; p < NS; ++p) {
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      w[e] = pack_bf16x2(r[2 * e], r[2 * e + 1]);
+      if (p + 1 < NS) { r[2 * e] -= bf16lo_to_f32(w[e]); r[2 * e + 1] -= bf16hi_to_f32(w[e]); }
+    }
+    out[p] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// 8 bf16 starting `dx` elements into the 16-element run {b0, b1}
+template <int DX>
+__device__ __forceinline__ uint4 shift_run(const uint4& b0, const uint4& b1) {
+  if (DX == 0) return b0;
+  if (DX == 1) return make_uint4((b0.x >> 16) | (b0.y << 16), (b0.y >> 16) | (b0.z << 16), (b0.z >> 16) | (b0.w << 16), (b0.w >> 16) | (b1.x << 16));
+  return make_uint4(b0.y, b0.z, b0.w, b1.x);
+}
+
+template <int NS, int MT, int INMODE>
+__global__ __launch_bounds__(576) void conv3d_wgrad_k3_bf16(WgradBArgs a) {
+  constexpr int TY = 4, ROWS = 4, HY = 6, XO = 3;
+  constexpr int COT = 32 * MT;
+  constexpr int CSA = ROWS * 2 + 1;            // 9
+  constexpr int CSB = 3 * HY * XO + 1;         // 55
+  constexpr int P = WProducts<NS>::P;
+  DYN_LDS(lds_f);
+  uint4* ldsA = reinterpret_cast<uint4*>(lds_f);       // [NS][COT][CSA]
+  uint4* ldsB = ldsA + NS * COT * CSA;                 // [NS][32][CSB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;          // 9 waves
+  const int half = lane >> 5, li = lane & 31;
+  const int wdz = wave / 3, wdy = wave % 3;
+  const int split = blockIdx.x, cit = blockIdx.y, cot = blockIdx.z;
+  const int ci0 = cit * 32, co0 = cot * COT;
+
+  f32x16 acc[3][MT];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[dx][mt][r] = 0.f;
+
+  const int per = (a.ntiles + a.splits - 1) / a.splits;
+  const int t_begin = split * per;
+  const int t_end = t_begin + per < a.ntiles ? t_begin + per : a.ntiles;
+  const int q = tid & 7;                               // this thread's channel quad (staging)
+
+  // per-thread prologue constants for the x staging (channel quad fixed)
+  float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, sl[4] = {a.slope, a.slope, a.slope, a.slope};
+  const int cx = ci0 + 4 * q;
+  const bool cxok = cx < a.Cin;
+  int last_col = -1, last_z = -100, last_n = -1;
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int z = tile % a.D;
+    const int col = tile / a.D;
+    const int tx0 = (col % a.tilesX) * 16;
+    const int ty0 = ((col / a.tilesX) % a.tilesY) * TY;
+    const int n = col / (a.tilesX * a.tilesY);
+    const bool cont = (col == last_col && z == last_z + 1);     // rolling window: planes z-1 and z are already staged
+    if (INMODE == MI355_IN_AFFINE_ACT && n != last_n && cxok) {
+      const float4 s4 = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + cx);
+      const float4 h4 = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + cx);
+      sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
+      sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
+      if (a.in_slope) { const float4 l4 = *reinterpret_cast<const float4*>(a.in_slope + cx); sl[0] = l4.x; sl[1] = l4.y; sl[2] = l4.z; sl[3] = l4.w; }
+    }
+    last_col = col; last_z = z; last_n = n;
+    __syncthreads();
+    // ---- stage the dy tile (plane z, rows ty0..ty0+3, 16 x): units = (row, octet, channel quad) ----
+    for (int u = tid; u < ROWS * 2 * 8 * MT; u += 576) {
+      const int qq = u % (8 * MT), ro = u / (8 * MT);
+      const int row = ro >> 1, oct = ro & 1;
+      const int co = co0 + 4 * qq;
+      const int y = ty0 + row, x0 = tx0 + 8 * oct;
+      float v[8][4];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co < a.Cout && y < a.H && x0 + e < a.W)
+          t = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.D + z) * a.H + y) * a.W + x0 + e) * a.dyld + co);
+        v[e][0] = t.x; v[e][1] = t.y; v[e][2] = t.z; v[e][3] = t.w;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint4 pl[NS];
+        split_col<NS>(v, c, pl);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) ldsA[(p * COT + 4 * qq + c) * CSA + row * 2 + oct] = pl[p];
+      }
+    }
+    // ---- stage input planes: all three (new column) or only z+1 (continuing along z) into ring slot (plane % 3) ----
+    {
+      const int hz_lo = cont ? 2 : 0;
+      const int nunits = (3 - hz_lo) * HY * XO * 8;
+      for (int u = tid; u < nunits; u += 576) {
+        const int ro = u >> 3;                              // (hz, hy, oct); u & 7 == q because 576 % 8 == 0
+        const int oct = ro % XO, hy = (ro / XO) % HY, hz = hz_lo + ro / (XO * HY);
+        const int iz = z - 1 + hz, iy = ty0 - 1 + hy, ix0 = tx0 - 1 + 8 * oct;
+        const int slot = (iz + 3) % 3;
+        const bool rowok = cxok && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H;
+        float v[8][4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ix = ix0 + e;
+          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+          const bool ok = rowok && ix >= 0 && ix < a.W && 8 * oct + e < 18;
+          if (ok) {
+            t = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + cx);
+            if (INMODE == MI355_IN_AFFINE_ACT) {
+              t.x = t.x * sc[0] + sh[0]; t.y = t.y * sc[1] + sh[1]; t.z = t.z * sc[2] + sh[2]; t.w = t.w * sc[3] + sh[3];
+              t.x = t.x > 0.f ? t.x : t.x * sl[0]; t.y = t.y > 0.f ? t.y : t.y * sl[1];
+              t.z = t.z > 0.f ? t.z : t.z * sl[2]; t.w = t.w > 0.f ? t.w : t.w * sl[3];
+            }
+          }
+          v[e][0] = t.x; v[e][1] = t.y; v[e][2] = t.z; v[e][3] = t.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          uint4 pl[NS];
+          split_col<NS>(v, c, pl);
+#pragma unroll
+          for (int p = 0; p < NS; ++p) ldsB[(p * 32 + 4 * q + c) * CSB + (slot * HY + hy) * XO + oct] = pl[p];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 4 k-steps (y-rows of 16 voxels); this wave: tap row (wdz, wdy), dx = 0..2 ----
+    const int bslot = (z - 1 + wdz + 3) % 3;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      uint4 af[MT][NS], b0[NS], b1[NS];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) af[mt][p] = ldsA[(p * COT + mt * 32 + li) * CSA + r * 2 + half];
+      const int hrow = bslot * HY + r + wdy;
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+        b0[p] = ldsB[(p * 32 + li) * CSB + hrow * XO + half];
+        b1[p] = ldsB[(p * 32 + li) * CSB + hrow * XO + half + 1];
+      }
+      uint4 bf[NS];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) bf[p] = shift_run<0>(b0[p], b1[p]);
+#pragma unroll
+      for (int qq = 0; qq < P; ++qq)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[0][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[WProducts<NS>::pb[qq]], acc[0][mt]);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) bf[p] = shift_run<1>(b0[p], b1[p]);
+#pragma unroll
+      for (int qq = 0; qq < P; ++qq)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[1][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[WProducts<NS>::pb[qq]], acc[1][mt]);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) bf[p] = shift_run<2>(b0[p], b1[p]);
+#pragma unroll
+      for (int qq = 0; qq < P; ++qq)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[2][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[WProducts<NS>::pb[qq]], acc[2][mt]);
+    }
+  }
+
+  // ---- write the partial tiles: ws[pair][slab][tap][32 co][32 ci] (same layout as the f32 kernel) ----
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int cot32 = cot * MT + mt;
+    if (cot32 >= a.coTiles32) continue;
+    const size_t pair = (size_t)cot32 * a.ciTiles + cit;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int tap = (wdz * 3 + wdy) * 3 + dx;
+      float* dst = a.ws + (((pair * a.splits + split) * 27 + tap) * 1024);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        dst[row * 32 + li] = acc[dx][mt][r];
+      }
+    }
+  }
+}
+
+static int nsplit_of_w(int precision) {
+  switch (precision) {
+    case MI355_PREC_BF16X3: return 2;
+    case MI355_PREC_BF16X6: return 3;
+    case MI355_PREC_BF16: return 1;
+    default: return 0;
+  }
+}
+
+struct WBPlan { int tilesY, tilesX, ntiles, splits, ciTiles, coTiles32, coTilesWG, mt; size_t ws_bytes; int ok; };
+
+static WBPlan plan_wb(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  WBPlan p; memset(&p, 0, sizeof(p));
+  if (!x || !dy || !d || !nsplit_of_w(d->precision)) return p;
+  if (d->kd != 3 || d->stride != 1 || d->pad != 1) return p;
+  if (x->d != dy->d || x->h != dy->h || x->w != dy->w) return p;
+  p.tilesY = ceil_div(dy->h, 4); p.tilesX = ceil_div(dy->w, 16);
+  const long long nt = (long long)dy->n * p.tilesY * p.tilesX * dy->d;
+  if (nt <= 0 || nt > 0x7fffffffLL) return p;
+  p.ntiles = (int)nt;
+  p.ciTiles = ceil_div(x->c, 32); p.coTiles32 = ceil_div(dy->c, 32);
+  p.mt = dy->c > 32 ? 2 : 1;
+  p.coTilesWG = ceil_div(p.coTiles32, p.mt);
+  const int wgs = p.ciTiles * p.coTilesWG;
+  int splits = ceil_div(512, wgs);
+  const int max_splits = p.ntiles >= 8 ? p.ntiles / 8 : 1;      // >= 8 tiles per workgroup: amortise the ring fill and the slab write
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int per = ceil_div(p.ntiles, splits);
+  p.splits = ceil_div(p.ntiles, per);
+  p.ws_bytes = (size_t)p.ciTiles * p.coTiles32 * p.splits * 27 * 1024 * sizeof(float);
+  p.ok = 1;
+  return p;
+}
+
+size_t mi355_conv3d_wgrad_bf16_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  WBPlan p = plan_wb(x, dy, d);
+  return p.ok ? p.ws_bytes : 0;
+}
+
+template <int NS, int MT>
+static int launch_wb(WgradBArgs& a, const WBPlan& p, int in_mode, void* stream) {
+  constexpr size_t lds = ((size_t)NS * 32 * MT * 9 + (size_t)NS * 32 * 55) * 16;
+  static_assert(lds <= 160 * 1024, "LDS");
+  dim3 grid(p.splits, p.ciTiles, p.coTilesWG);
+  if (in_mode == MI355_IN_PLAIN) {
+    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_PLAIN>), lds);
+    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_PLAIN>), grid, dim3(576), lds, stream, a);
+  } else {
+    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_AFFINE_ACT>), lds);
+    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_AFFINE_ACT>), grid, dim3(576), lds, stream, a);
+  }
+  return LAUNCH_CHECK();
+}
+
+// called by mi355_conv3d_wgrad (conv3d_wgrad.hip) when desc->precision selects a bf16 path and the problem qualifies
+int mi355_conv3d_wgrad_bf16_impl(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d,
+                                 void* ws, size_t ws_bytes, void* stream) {
+  WBPlan p = plan_wb(x, dy, d);
+  if (!p.ok) return MI355_EUNSUPPORTED;
+  if (ws_bytes < p.ws_bytes) return MI355_EWORKSPACE;
+  WgradBArgs a;
+  a.x = (const float*)x->p; a.xld = x->ld; a.dy = (const float*)dy->p; a.dyld = dy->ld; a.ws = (float*)ws;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope;
+  a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Cout = dy->c;
+  a.tilesY = p.tilesY; a.tilesX = p.tilesX; a.ntiles = p.ntiles;
+  a.splits = p.splits; a.ciTiles = p.ciTiles; a.coTiles32 = p.coTiles32;
+  const int ns = nsplit_of_w(d->precision);
+  int rc;
+  if (p.mt == 2) rc = ns == 1 ? launch_wb<1, 2>(a, p, d->in_mode, stream) : ns == 2 ? launch_wb<2, 2>(a, p, d->in_mode, stream) : launch_wb<3, 2>(a, p, d->in_mode, stream);
+  else rc = ns == 1 ? launch_wb<1, 1>(a, p, d->in_mode, stream) : ns == 2 ? launch_wb<2, 1>(a, p, d->in_mode, stream) : launch_wb<3, 1>(a, p, d->in_mode, stream);
+  if (rc) return rc;
+  return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, p.splits, p.ciTiles, stream);
+}

@@ -135,3 +135,15 @@ def test_conv_fwd_bf16_paths(prec_backend, kw):
 def test_conv_dgrad_bf16_paths(prec_backend, kw):
     be, tol = prec_backend
     assert C.case_conv_dgrad(be, **kw) < tol
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=2, cin=32, cout=32, dhw=(16, 32, 32), norm=True),
+    dict(n=1, cin=4, cout=32, dhw=(32, 32, 32), norm=True),
+    dict(n=1, cin=64, cout=96, dhw=(15, 15, 19), norm=True, slope=0.01),
+    dict(n=2, cin=128, cout=64, dhw=(8, 8, 16)),
+    dict(n=1, cin=32, cout=64, dhw=(64, 64, 64), norm=True),
+])
+def test_conv_wgrad_bf16_paths(prec_backend, kw):
+    be, tol = prec_backend
+    assert C.case_conv_wgrad(be, **kw) < tol

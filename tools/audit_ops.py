@@ -15,8 +15,9 @@ from oracle import unet3d_ref as R
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--gpu", action="store_true"); ap.add_argument("--bw", type=int, default=32)
-ap.add_argument("--size", type=int, default=32); ap.add_argument("--tc", action="store_true")
+ap.add_argument("--size", type=int, default=32); ap.add_argument("--tc", action="store_true"); ap.add_argument("--fwd", action="store_true")
 ap.add_argument("--thresh", type=float, default=2e-6)
+ap.add_argument("--model", default="unet3d"); ap.add_argument("--filters", default="32,64,96"); ap.add_argument("--dhw", default="")
 args = ap.parse_args()
 unet = importlib.import_module("3dunetcnn_amd.unet"); losses = importlib.import_module("3dunetcnn_amd.losses")
 lib_mod = importlib.import_module("3dunetcnn_amd._lib"); ops = importlib.import_module("3dunetcnn_amd.ops")
@@ -54,10 +55,19 @@ in_bwd = [False]
 def conv_fwd(x, wp, y, kd, stride=1, pad=None, in_mode=0, slope=0.0, scale=None, shift=None, bias=None, residual=None, chscale=None,
              off=(0, 0, 0), out_dhw=None, **kw):
     orig_conv(x, wp, y, kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, **kw)
-    if not in_bwd[0]:
+    if not in_bwd[0] and not args.fwd:
         return
+    if kw.get("out_mode", 0) or in_mode == 3:
+        print(f"#     conv_fwd k{kd} (d2s/s2d GEMM) not audited", flush=True)
+        return
+    if kw.get("in_slope") is not None:
+        sl = kw["in_slope"].cpu().double()[None, :, None, None, None]
+        t0 = nc(x); u = t0 * scale.cpu().double()[:, :, None, None, None] + shift.cpu().double()[:, :, None, None, None]
+        t_override = torch.where(u > 0, u, u * sl)
+    else:
+        t_override = None
     pad_ = kd // 2 if pad is None else pad
-    t = act_in(x, in_mode, slope, scale, shift)
+    t = t_override if t_override is not None else act_in(x, in_mode, slope, scale, shift)
     w = unpack(wp.f32(), y.c, x.c, kd)
     if in_mode == ops.IN_ZERO_INSERT:
         z = torch.zeros(t.shape[0], t.shape[1], *[2 * s - 1 for s in t.shape[2:]], dtype=torch.float64)
@@ -93,8 +103,16 @@ def conv_fwd(x, wp, y, kd, stride=1, pad=None, in_mode=0, slope=0.0, scale=None,
 @torch.enable_grad()
 def conv_wgrad(x, dy, dw, kd, stride=1, pad=None, in_mode=0, slope=0.0, scale=None, shift=None, **kw):
     orig_wgrad(x, dy, dw, kd, stride, pad, in_mode, slope, scale, shift, **kw)
+    if kw.get("out_mode", 0):
+        print("#     conv_wgrad (d2s GEMM) not audited", flush=True)
+        return
     pad_ = kd // 2 if pad is None else pad
-    t = act_in(x, in_mode, slope, scale, shift).requires_grad_(False)
+    if kw.get("in_slope") is not None:
+        sl = kw["in_slope"].cpu().double()[None, :, None, None, None]
+        t0 = nc(x); u = t0 * scale.cpu().double()[:, :, None, None, None] + shift.cpu().double()[:, :, None, None, None]
+        t = torch.where(u > 0, u, u * sl)
+    else:
+        t = act_in(x, in_mode, slope, scale, shift).requires_grad_(False)
     w = torch.zeros(dy.c, x.c, kd, kd, kd, dtype=torch.float64, requires_grad=True)
     yy = F.conv3d(t, w, None, stride=stride, padding=pad_)
     (ref,) = torch.autograd.grad(yy, w, nc(dy))
@@ -128,15 +146,42 @@ def gn_act_bwd(x, dA, dx, groups, slope, gamma, mean_rstd, scale, shift, dgamma,
 
 be.conv_fwd, be.conv_wgrad, be.gn_act_bwd = conv_fwd, conv_wgrad, gn_act_bwd
 torch.manual_seed(1234)
-kw = dict(n_features=4, n_outputs=3, base_width=args.bw, use_transposed_convolutions=args.tc)
-m = unet.HipUNet3D(**kw).eval()
+if args.model == "dynunet":
+    dyn = importlib.import_module("3dunetcnn_amd.dynunet")
+    fl = [int(v) for v in args.filters.split(",")]
+    L = len(fl)
+    m = dyn.HipDynUNet(spatial_dims=3, in_channels=4, out_channels=3, kernel_size=[3] * L, strides=[1] + [2] * (L - 1),
+                       upsample_kernel_size=[2] * (L - 1), filters=fl).eval()
+else:
+    kw = dict(n_features=4, n_outputs=3, base_width=args.bw, use_transposed_convolutions=args.tc)
+    m = unet.HipUNet3D(**kw).eval()
 if args.gpu:
     m = m.cuda()
 m._be = be
-x, y = R.synthetic_case(1, 4, (args.size,) * 3, 3)
+dhw = tuple(int(v) for v in args.dhw.split(",")) if args.dhw else (args.size,) * 3
+x, y = R.synthetic_case(1, 4, dhw, 3)
 crit = losses.HipDiceLoss(sigmoid=True); crit._be = be
 dev = "cuda" if args.gpu else "cpu"
 out = m(x.to(dev)); loss = crit(out, y.to(dev))
 print("---- backward ----", flush=True)
 in_bwd[0] = True
 loss.backward()
+# end-to-end: parameter gradients vs the fp64 oracle graph
+from oracle import torch_ops as O
+sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in m.state_dict().items()}
+if args.model == "dynunet":
+    from oracle import dynunet_ref as DR
+    ref = DR.dynunet_forward(sd, x.double(), len(m.filters))
+else:
+    ref = R.unet3d_forward(sd, x.double(), (1, 2, 2, 4), None, args.tc)
+O.dice_loss(ref, y).backward()
+sd32 = {k: v.detach().cpu().float().requires_grad_(True) for k, v in m.state_dict().items()}
+if args.model == "dynunet":
+    ref32 = DR.dynunet_forward(sd32, x, len(m.filters))
+else:
+    ref32 = R.unet3d_forward(sd32, x, (1, 2, 2, 4), None, args.tc)
+O.dice_loss(ref32, y).backward()
+rows = sorted(((C.rel_err(p.grad, sd[k].grad), C.rel_err(sd32[k].grad, sd[k].grad), C.rel_err(p.grad, sd32[k].grad), k) for k, p in m.named_parameters()), reverse=True)
+print("logits: kernels vs fp64", C.rel_err(out, ref.detach()), " cpu fp32 oracle vs fp64", C.rel_err(ref32.detach(), ref.detach()), "threads", torch.get_num_threads())
+for e, e32, ex, k in rows[:10]:
+    print(f"grad: kernels-vs-fp64 {e:.2e}  cpu32-vs-fp64 {e32:.2e}  kernels-vs-cpu32 {ex:.2e}  {k}")

@@ -26,6 +26,15 @@ def timeit(fn, iters=5, warm=2):
 def main():
     be = ops.default_backend()
     n = int(os.environ.get("N", "2"))
+    precs = sys.argv[1:] or ["fp32"]
+    for prec in precs:
+        be.set_precision(prec)
+        print(f"==== precision {prec} ====")
+        run(be, n, only_k3s1=(prec != "fp32"))
+    be.set_precision("fp32")
+
+
+def run(be, n, only_k3s1=False):
     layers = [  # (cin, cout, size, kd, stride)
         (4, 32, 128, 3, 1), (32, 32, 128, 3, 1), (64, 32, 128, 3, 1), (32, 32, 128, 3, 2),
         (32, 64, 64, 3, 1), (64, 64, 64, 3, 1), (128, 128, 64, 3, 1), (64, 64, 64, 3, 2),
@@ -35,6 +44,8 @@ def main():
     ]
     print(f"{'layer':34s} {'fwd ms':>8s} {'TF/s':>7s} {'GB/s':>7s} | {'dgrad ms':>8s} {'TF/s':>7s} | {'wgrad ms':>8s} {'TF/s':>7s}")
     for cin, cout, s, kd, st in layers:
+        if only_k3s1 and (kd != 3 or st != 1):
+            continue
         so = s // st
         x = be.empty_act(n, s, s, s, cin); x.buf.normal_()
         y = be.empty_act(n, so, so, so, cout)

@@ -242,3 +242,4 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetc
 #define LAUNCH(kernel, grid, block, lds, stream, ...) \
   emu::launch((grid), (block), (lds), [=]() { kernel(__VA_ARGS__); })
 #define LAUNCH_CHECK() 0
+#define SET_MAX_DYN_LDS(kernel, bytes) do {} while (0)
