@@ -292,7 +292,9 @@ static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
   a.coTiles = ceil_div(a.Cout, 32 * WN * NT);
   const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
-  const bool tl = KD == 3 && a.CinP >= 4 * KC;
+  // two-level accumulation: always for >= 4 channel chunks; for the 1-tile-per-wave configurations (16 accumulator
+  // registers, deep layers) already from 2 chunks, where it is free
+  const bool tl = KD == 3 && (a.CinP >= 4 * KC || (MT * NT == 1 && a.CinP >= 2 * KC));
   if (in_mode == MI355_IN_PLAIN) {
     if (tl) LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_PLAIN, KD == 3>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
     else LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_PLAIN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
@@ -409,7 +411,8 @@ extern "C" int mi355_conv3d_fwd_config(const mi355_act* x, const mi355_act* y, c
                                       "3, 1, 2, 4, 8, 32, 4, 2, 2, 1, 1", "3, 1, 4, 4, 8, 32, 4, 4, 1, 1, 1"};
   static const int kcs[8] = {32, 32, 8, 8, 16, 16, 32, 32};
   const int cinP = (x->c + 7) / 8 * 8;
-  const char* tl = (d->kd == 3 && cinP >= 4 * kcs[cfg]) ? "true" : "false";
+  const bool one = cfg == 3 || cfg == 6 || cfg == 7;     // MT * NT == 1
+  const char* tl = (d->kd == 3 && (cinP >= 4 * kcs[cfg] || (one && cinP >= 2 * kcs[cfg]))) ? "true" : "false";
   if (cfg == 2 || cfg == 3) snprintf(out, n, "conv3d_mfma<3, %d, %s, %d, %s>", stride_t, tags[cfg], d->in_mode, tl);
   else snprintf(out, n, "conv3d_mfma<%s, %d, %s>", tags[cfg], d->in_mode, tl);
   return 0;

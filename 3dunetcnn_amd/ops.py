@@ -208,7 +208,8 @@ class Backend:
             nvox = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3]
             flops = 2.0 * nvox * x.c * dy.c * kd ** 3
             byts = 4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * x.c + nvox * dy.c + kd ** 3 * x.c * dy.c)
-            self.prof.append((f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1))
+            bf = self.precision != PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT) and out_mode == OUT_PLAIN
+            self.prof.append(("conv3d_wgrad_k3_bf16<...> (+reduce)" if bf else f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1))
 
     # -- norm ----------------------------------------------------------------------------------------------------
     def gn_stats(self, x, groups, eps, gamma, beta):

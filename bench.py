@@ -31,7 +31,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0
 HBM_PEAK_GBPS = 8000.0
+
+
+DTYPE = {"fp32": "f32", "bf16x3": "f32 (3xbf16 split-MFMA emulation)", "bf16x6": "f32 (6xbf16 split-MFMA emulation)", "bf16": "bf16 (mixed)"}
+ARITH = {"fp32": "3x3x3 convs on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate)",
+         "bf16x3": "3x3x3 stride-1 convs: fp32 operands split hi+lo bf16, 3 v_mfma_f32_32x32x16_bf16 products per MAC, fp32 accumulate "
+                   "(product error <= 2^-16); everything else fp32",
+         "bf16x6": "3x3x3 stride-1 convs: fp32 operands split into 3 bf16 planes, 6 bf16 MFMA products per MAC, fp32 accumulate "
+                   "(product error ~2^-23, fp32-class); everything else fp32",
+         "bf16": "3x3x3 stride-1 convs: operands rounded to bf16, fp32 accumulate (autocast-style mixed precision); everything else fp32"}
 
 
 def parse():
@@ -41,6 +51,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=2, help="volumes per GPU (BASELINE configs[1]: 2)")
     ap.add_argument("--size", type=int, default=128, help="cubic patch edge (BASELINE configs[1]: 128)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x6", "bf16"],
+                    help="arithmetic of the 3x3x3 stride-1 convs: exact f32 MFMA (default) | split-bf16 fp32 emulation | bf16")
+    ap.add_argument("--model", default="unet3d", choices=["unet3d", "dynunet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="disable the per-launch HIP events (roofline -> null)")
     return ap.parse_args()
@@ -101,7 +114,14 @@ def main():
     from oracle import unet3d_ref as R   # synthetic_case only (input generator; not part of the measured path)
 
     torch.manual_seed(1234)
-    model = unet.HipUNet3D(n_features=4, n_outputs=3).to(dev)
+    if args.model == "dynunet":
+        dyn = importlib.import_module("3dunetcnn_amd.dynunet")
+        model = dyn.HipDynUNet(spatial_dims=3, in_channels=4, out_channels=3, kernel_size=[3] * 6, strides=[1] + [2] * 5,
+                               upsample_kernel_size=[2] * 5, filters=[64, 96, 128, 192, 256, 384]).to(dev)   # brats2020_config.json:2-107
+        model_desc = "BraTS2020-config DynUNet 4ch->3cls (24928451 params)"
+    else:
+        model = unet.HipUNet3D(n_features=4, n_outputs=3).to(dev)
+        model_desc = "UNet3D 4ch->3cls (23970216 params)"
     model.train()                                                 # Dropout3d active, as in the reference's training loop
     model.flatten_parameters()
     criterion = losses.HipDiceLoss(sigmoid=True)
@@ -115,6 +135,7 @@ def main():
     x, y = R.synthetic_case(B, 4, (S, S, S), seed=rank)
     x, y = x.to(dev), y.to(dev)                                   # inputs resident in HBM before the timed region
     be = ops.default_backend()
+    be.set_precision(args.precision)
 
     def step():
         optimizer.zero_grad(set_to_none=True)
@@ -160,8 +181,12 @@ def main():
             a[3] += 1
         name, (secs, fl, by, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
         ach = fl / secs / 1e12
-        roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        on_bf16 = "bf16" in name
+        peak = BF16_MFMA_PEAK_TFLOPS if on_bf16 else FP32_MFMA_PEAK_TFLOPS
+        products = {"bf16x3": 3, "bf16x6": 6, "bf16": 1}.get(args.precision, 1) if on_bf16 else 1
+        roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "mfma_products_per_mac": products, "mfma_pipe_frac": round(ach * products / peak, 4),
                     "launches": cnt, "avg_launch_ms": round(secs / cnt * 1e3, 4),
                     "hbm_gbps_algorithmic": round(by / secs / 1e9, 1), "hbm_frac": round(by / secs / 1e9 / HBM_PEAK_GBPS, 4),
                     "share_of_step": round(secs / dt, 4),
@@ -171,10 +196,10 @@ def main():
     if rank == 0:
         out = {"metric": "training volumes/sec (128^3, 4ch->3cls)", "value": round(world * B * args.steps / dt, 4), "unit": "volumes/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"BASELINE configs[1]: UNet3D 4ch->3cls (23970216 params), {S}^3 patch, batch {B}/GPU, fp32, "
-                                      f"fwd + sigmoid-Dice + bwd + Adam, Dropout3d on", "global_batch": world * B,
-                          "parallelism": f"dp{world}"},
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
+               "config": {"workload": f"BASELINE configs[1]: {model_desc}, {S}^3 patch, batch {B}/GPU, fp32 tensors, "
+                                      f"fwd + sigmoid-Dice + bwd + Adam" + (", Dropout3d on" if args.model == "unet3d" else ""),
+                          "conv_arithmetic": ARITH[args.precision], "global_batch": world * B, "parallelism": f"dp{world}"},
                "final_loss": round(loss_val, 6), "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S)

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import op_cases as C
+from oracle import conditioning
 from oracle import torch_ops as O
 from oracle import unet3d_ref as R
 
@@ -19,37 +20,44 @@ optim = importlib.import_module("3dunetcnn_amd.optim")
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-GRAD_TOL_FP64 = 5e-3
+KAPPA = 4.0   # allowed multiple of the measured one-ulp noise response (oracle/conditioning.py)
 
 
-def _run_pair(kw, enc, dhw, n, tc=False, seed=1234, fp64=False):
-    """fp64=False: oracle in fp32 (the reference's arithmetic). fp64=True: the same oracle graph in double = the exact
-    gradient both fp32 implementations approximate; used for the large case, where the parameter gradients are
-    ill-conditioned under fp32 rounding (sparse Dice gradients through ReLU masks: tools/grad_sensitivity.py shows 1e-6
-    relative noise on the CPU conv outputs moves the same tensors by 4e-3, and the reference's own fp32 CPU path is 1e-3
-    away from fp64), so two fp32 implementations cannot agree to 1e-3 there."""
+def _run_pair(kw, enc, dhw, n, tc=False, seed=1234):
+    """Kernels vs the fp64 evaluation of the oracle graph (= the exact value the reference's fp32 arithmetic approximates).
+    Logits and loss must agree to TOL. Each parameter gradient must agree to max(TOL, KAPPA * noise_floor), where
+    noise_floor is the measured response of that gradient to one-ulp (1e-7 relative) perturbations of the fp32 oracle's
+    convolution outputs: freshly initialised norm + Dice networks have some gradients that no fp32 implementation can
+    reproduce to 1e-3 (oracle/conditioning.py). Returns `grad` = worst error / allowance (<= 1 passes)."""
     torch.manual_seed(seed)
     m = unet.HipUNet3D(**kw).cuda().eval()
-    dt = torch.float64 if fp64 else torch.float32
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    sd = {k: v.detach().cpu().clone().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
+    sd = {k: v.detach().cpu().clone().double().requires_grad_(True) for k, v in m.state_dict().items()}
     x, y = R.synthetic_case(n, kw["n_features"], dhw, kw["n_outputs"])
-    ref = R.unet3d_forward(sd, x.to(dt), enc, None, tc)
+    ref = R.unet3d_forward(sd, x.double(), enc, None, tc)
     lref = O.dice_loss(ref, y)
     lref.backward()
     ref, lref = ref.detach(), lref.detach()
+
+    def run32():
+        s32 = {k: v.detach().cpu().clone().float().requires_grad_(True) for k, v in m.state_dict().items()}
+        O.dice_loss(R.unet3d_forward(s32, x, enc, None, tc), y).backward()
+        return {k: v.grad for k, v in s32.items()}
+    floor = conditioning.noise_floor(R, run32)
     out = m(x.cuda())
     crit = losses.HipDiceLoss(sigmoid=True)
     loss = crit(out, y.cuda())
     loss.backward()
-    errs = {"logits": C.rel_err(out, ref), "loss": abs(float(loss) - float(lref)) / abs(float(lref))}
-    worst, wk = 0.0, None
+    errs = {"logits": C.rel_err(out, ref), "loss": abs(float(loss.detach()) - float(lref)) / abs(float(lref))}
+    worst, wk, we, wf = 0.0, None, 0.0, 0.0
     for k, p in m.named_parameters():
         e = C.rel_err(p.grad, sd[k].grad)
-        if e > worst:
-            worst, wk = e, k
-    errs["grad"] = worst
-    errs["grad_key"] = wk
+        r = e / max(TOL, KAPPA * floor[k])
+        if r > worst:
+            worst, wk, we, wf = r, k, e, floor[k]
+    errs.update(grad=worst, grad_key=wk, grad_err=we, noise_floor=wf,
+                n_ill_conditioned=sum(1 for v in floor.values() if KAPPA * v > TOL),
+                max_grad_err=max(C.rel_err(p.grad, sd[k].grad) for k, p in m.named_parameters()))
     return errs
 
 
@@ -57,27 +65,27 @@ def _run_pair(kw, enc, dhw, n, tc=False, seed=1234, fp64=False):
 def test_unet3d_default_fwd_bwd(dhw, n):
     e = _run_pair(dict(n_features=4, n_outputs=3), (1, 2, 2, 4), dhw, n)
     print(e)
-    assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] < TOL, e
+    assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] <= 1.0, e
 
 
-def test_unet3d_default_fwd_bwd_64cube_vs_fp64_oracle():
-    """BASELINE configs[0] size (1x4x64^3). Outputs to 1e-3 (north star); gradients against the fp64 oracle (see _run_pair)."""
-    e = _run_pair(dict(n_features=4, n_outputs=3), (1, 2, 2, 4), (64, 64, 64), 1, fp64=True)
+def test_unet3d_default_fwd_bwd_64cube():
+    """BASELINE configs[0] size (1x4x64^3)."""
+    e = _run_pair(dict(n_features=4, n_outputs=3), (1, 2, 2, 4), (64, 64, 64), 1)
     print(e)
-    assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] < GRAD_TOL_FP64, e
+    assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] <= 1.0, e
 
 
 def test_unet3d_transposed_conv_variant():
     e = _run_pair(dict(n_features=4, n_outputs=3, use_transposed_convolutions=True), (1, 2, 2, 4), (32, 32, 32), 1, tc=True)
     print(e)
-    assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] < TOL, e
+    assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] <= 1.0, e
 
 
 def test_unet3d_five_levels():
     # BASELINE configs[3] topology (encoder_blocks=[1,2,2,2,4], 96.8M params) at a reduced patch so the CPU oracle is quick
     e = _run_pair(dict(n_features=4, n_outputs=3, encoder_blocks=[1, 2, 2, 2, 4]), (1, 2, 2, 2, 4), (32, 48, 32), 1)
     print(e)
-    assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] < TOL, e
+    assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] <= 1.0, e
 
 
 def test_training_steps_match_torch_adam():
