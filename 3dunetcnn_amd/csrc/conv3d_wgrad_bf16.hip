@@ -9,11 +9,12 @@
 // 8 voxels x 4 channels as float4s, applies the fused norm + activation, splits into bf16 planes and writes one 16-byte
 // run per channel). LDS (16-byte units, odd channel strides -> conflict-free ds_read_b128):
 //   dy tile  [plane][32*MT co][4 y-rows][2 x-octets]
-//   x  tile  [plane][32 ci][3 z-planes (ring)][6 y-rows][3 x-octets]   (halo: x0-1 .. x0+16)
-// A workgroup = 9 waves = the 9 (dz,dy) tap rows; a wave owns the 3 dx taps of its row (3*MT accumulators) and forms the
-// dx-shifted B fragments from two aligned octets with funnel shifts (v_alignbit) -- no unaligned LDS access, no copies.
-// It walks a contiguous range of output tiles (1 x 4 x 16 voxels) with z fastest and keeps a rolling window of three input
-// z-planes in LDS, so each step stages one new plane (x halo re-read factor 1.7 instead of 5). Partial sums go to the same
+//   x  tile  [plane][32 ci][4 z-planes (ring)][6 y-rows][3 x-octets]   (halo: x0-1 .. x0+16)
+// A workgroup = 9 consumer waves = the 9 (dz,dy) tap rows + 3 producer waves. A consumer owns the 3 dx taps of its row
+// (3*MT accumulators) and forms the dx-shifted B fragments from two aligned octets with funnel shifts (v_alignbit) -- no
+// unaligned LDS access, no copies. The workgroup walks a contiguous range of output tiles (1 x 4 x 16 voxels) with z fastest
+// and keeps a ring of four input z-planes in LDS, so each step stages ONE new plane (x halo re-read factor 1.7 instead of 5)
+// while the consumers compute on the other three. Partial sums go to the same
 // workspace slabs as the f32 kernel and are reduced by the same deterministic second pass.
 #include "hipcompat.h"
 #include "../../include/mi355_unet3d.h"
@@ -61,21 +62,27 @@ __device__ __forceinline__ uint4 shift_run(const uint4& b0, const uint4& b1) {
   return make_uint4(b0.y, b0.z, b0.w, b1.x);
 }
 
+// Producer / consumer workgroup: waves 0..8 are the 9 (dz,dy) tap rows and only read LDS + issue MFMAs; waves 9..11 only
+// stage: while the consumers work on tile t they load tile t+1 (its dy tile and the one new input plane) from global memory,
+// transform/split/transpose it and write it to the other dy buffer / the free slot of a 4-plane ring. One barrier per tile;
+// global-memory latency is never on the consumers' path.
 template <int NS, int MT, int INMODE>
-__global__ __launch_bounds__(576) void conv3d_wgrad_k3_bf16(WgradBArgs a) {
-  constexpr int TY = 4, ROWS = 4, HY = 6, XO = 3;
+__global__ __launch_bounds__(768) void conv3d_wgrad_k3_bf16(WgradBArgs a) {
+  constexpr int TY = 4, ROWS = 4, HY = 6, XO = 3, RING = 4;
   constexpr int COT = 32 * MT;
   constexpr int CSA = ROWS * 2 + 1;            // 9
-  constexpr int CSB = 3 * HY * XO + 1;         // 55
+  constexpr int CSB = RING * HY * XO + 1;      // 73
   constexpr int P = WProducts<NS>::P;
+  constexpr int NCONS = 576, NLOAD = 192;
   DYN_LDS(lds_f);
-  uint4* ldsA = reinterpret_cast<uint4*>(lds_f);       // [NS][COT][CSA]
-  uint4* ldsB = ldsA + NS * COT * CSA;                 // [NS][32][CSB]
+  uint4* ldsA = reinterpret_cast<uint4*>(lds_f);       // [2 buffers][NS][COT][CSA]
+  uint4* ldsB = ldsA + 2 * NS * COT * CSA;             // [NS][32][CSB]
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;          // 9 waves
+  const int lane = tid & 63, wave = tid >> 6;          // 12 waves
+  const bool loader = wave >= 9;
   const int half = lane >> 5, li = lane & 31;
-  const int wdz = wave / 3, wdy = wave % 3;
+  const int wdz = wave / 3, wdy = wave % 3;            // consumers only
   const int split = blockIdx.x, cit = blockIdx.y, cot = blockIdx.z;
   const int ci0 = cit * 32, co0 = cot * COT;
 
@@ -90,32 +97,16 @@ __global__ __launch_bounds__(576) void conv3d_wgrad_k3_bf16(WgradBArgs a) {
   const int per = (a.ntiles + a.splits - 1) / a.splits;
   const int t_begin = split * per;
   const int t_end = t_begin + per < a.ntiles ? t_begin + per : a.ntiles;
-  const int q = tid & 7;                               // this thread's channel quad (staging)
-
-  // per-thread prologue constants for the x staging (channel quad fixed)
-  float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, sl[4] = {a.slope, a.slope, a.slope, a.slope};
+  const int ltid = tid - NCONS;                        // loader thread index 0..191
+  const int q = ltid & 7;                              // loader: channel quad of the x staging (192 % 8 == 0)
   const int cx = ci0 + 4 * q;
   const bool cxok = cx < a.Cin;
-  int last_col = -1, last_z = -100, last_n = -1;
 
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    const int z = tile % a.D;
-    const int col = tile / a.D;
-    const int tx0 = (col % a.tilesX) * 16;
-    const int ty0 = ((col / a.tilesX) % a.tilesY) * TY;
-    const int n = col / (a.tilesX * a.tilesY);
-    const bool cont = (col == last_col && z == last_z + 1);     // rolling window: planes z-1 and z are already staged
-    if (INMODE == MI355_IN_AFFINE_ACT && n != last_n && cxok) {
-      const float4 s4 = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + cx);
-      const float4 h4 = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + cx);
-      sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
-      sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
-      if (a.in_slope) { const float4 l4 = *reinterpret_cast<const float4*>(a.in_slope + cx); sl[0] = l4.x; sl[1] = l4.y; sl[2] = l4.z; sl[3] = l4.w; }
-    }
-    last_col = col; last_z = z; last_n = n;
-    __syncthreads();
-    // ---- stage the dy tile (plane z, rows ty0..ty0+3, 16 x): units = (row, octet, channel quad) ----
-    for (int u = tid; u < ROWS * 2 * 8 * MT; u += 576) {
+  // stage the dy tile of `tile` into buffer `buf` (loader threads)
+  auto stage_dy = [&](int tile, int buf) {
+    const int z = tile % a.D, col = tile / a.D;
+    const int tx0 = (col % a.tilesX) * 16, ty0 = ((col / a.tilesX) % a.tilesY) * TY, n = col / (a.tilesX * a.tilesY);
+    for (int u = ltid; u < ROWS * 2 * 8 * MT; u += NLOAD) {
       const int qq = u % (8 * MT), ro = u / (8 * MT);
       const int row = ro >> 1, oct = ro & 1;
       const int co = co0 + 4 * qq;
@@ -133,99 +124,139 @@ __global__ __launch_bounds__(576) void conv3d_wgrad_k3_bf16(WgradBArgs a) {
         uint4 pl[NS];
         split_col<NS>(v, c, pl);
 #pragma unroll
-        for (int p = 0; p < NS; ++p) ldsA[(p * COT + 4 * qq + c) * CSA + row * 2 + oct] = pl[p];
+        for (int p = 0; p < NS; ++p) ldsA[((buf * NS + p) * COT + 4 * qq + c) * CSA + row * 2 + oct] = pl[p];
       }
     }
-    // ---- stage input planes: all three (new column) or only z+1 (continuing along z) into ring slot (plane % 3) ----
-    {
-      const int hz_lo = cont ? 2 : 0;
-      const int nunits = (3 - hz_lo) * HY * XO * 8;
-      for (int u = tid; u < nunits; u += 576) {
-        const int ro = u >> 3;                              // (hz, hy, oct); u & 7 == q because 576 % 8 == 0
-        const int oct = ro % XO, hy = (ro / XO) % HY, hz = hz_lo + ro / (XO * HY);
-        const int iz = z - 1 + hz, iy = ty0 - 1 + hy, ix0 = tx0 - 1 + 8 * oct;
-        const int slot = (iz + 3) % 3;
-        const bool rowok = cxok && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H;
-        float v[8][4];
+  };
+  // stage input planes iz = z_lo .. z_hi (inclusive) of the column of `tile` into ring slots iz & 3 (loader threads)
+  auto stage_x = [&](int tile, int z_lo, int z_hi) {
+    const int col = tile / a.D;
+    const int tx0 = (col % a.tilesX) * 16, ty0 = ((col / a.tilesX) % a.tilesY) * TY, n = col / (a.tilesX * a.tilesY);
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, sl[4] = {a.slope, a.slope, a.slope, a.slope};
+    if (INMODE == MI355_IN_AFFINE_ACT && cxok) {
+      const float4 s4 = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + cx);
+      const float4 h4 = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + cx);
+      sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
+      sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
+      if (a.in_slope) { const float4 l4 = *reinterpret_cast<const float4*>(a.in_slope + cx); sl[0] = l4.x; sl[1] = l4.y; sl[2] = l4.z; sl[3] = l4.w; }
+    }
+    const int nunits = (z_hi - z_lo + 1) * HY * XO * 8;
+    for (int u = ltid; u < nunits; u += NLOAD) {
+      const int ro = u >> 3;                              // (plane, hy, oct); u & 7 == q
+      const int oct = ro % XO, hy = (ro / XO) % HY, iz = z_lo + ro / (XO * HY);
+      const int iy = ty0 - 1 + hy, ix0 = tx0 - 1 + 8 * oct;
+      const int slot = iz & 3;                            // iz >= -1: (-1 & 3) == 3
+      const bool rowok = cxok && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H;
+      float v[8][4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int ix = ix0 + e;
-          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-          const bool ok = rowok && ix >= 0 && ix < a.W && 8 * oct + e < 18;
-          if (ok) {
-            t = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + cx);
-            if (INMODE == MI355_IN_AFFINE_ACT) {
-              t.x = t.x * sc[0] + sh[0]; t.y = t.y * sc[1] + sh[1]; t.z = t.z * sc[2] + sh[2]; t.w = t.w * sc[3] + sh[3];
-              t.x = t.x > 0.f ? t.x : t.x * sl[0]; t.y = t.y > 0.f ? t.y : t.y * sl[1];
-              t.z = t.z > 0.f ? t.z : t.z * sl[2]; t.w = t.w > 0.f ? t.w : t.w * sl[3];
-            }
+      for (int e = 0; e < 8; ++e) {
+        const int ix = ix0 + e;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rowok && ix >= 0 && ix < a.W && 8 * oct + e < 18) {
+          t = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + cx);
+          if (INMODE == MI355_IN_AFFINE_ACT) {
+            t.x = t.x * sc[0] + sh[0]; t.y = t.y * sc[1] + sh[1]; t.z = t.z * sc[2] + sh[2]; t.w = t.w * sc[3] + sh[3];
+            t.x = t.x > 0.f ? t.x : t.x * sl[0]; t.y = t.y > 0.f ? t.y : t.y * sl[1];
+            t.z = t.z > 0.f ? t.z : t.z * sl[2]; t.w = t.w > 0.f ? t.w : t.w * sl[3];
           }
-          v[e][0] = t.x; v[e][1] = t.y; v[e][2] = t.z; v[e][3] = t.w;
         }
+        v[e][0] = t.x; v[e][1] = t.y; v[e][2] = t.z; v[e][3] = t.w;
+      }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          uint4 pl[NS];
-          split_col<NS>(v, c, pl);
+      for (int c = 0; c < 4; ++c) {
+        uint4 pl[NS];
+        split_col<NS>(v, c, pl);
 #pragma unroll
-          for (int p = 0; p < NS; ++p) ldsB[(p * 32 + 4 * q + c) * CSB + (slot * HY + hy) * XO + oct] = pl[p];
+        for (int p = 0; p < NS; ++p) ldsB[(p * 32 + 4 * q + c) * CSB + (slot * HY + hy) * XO + oct] = pl[p];
+      }
+    }
+  };
+
+  // ---- prologue: everything tile t_begin needs ----
+  if (t_begin < t_end && loader) {
+    const int z = t_begin % a.D;
+    stage_dy(t_begin, 0);
+    stage_x(t_begin, z - 1, z + 1);
+  }
+  __syncthreads();
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int z = tile % a.D;
+    const int buf = (tile - t_begin) & 1;
+    const bool has_next = tile + 1 < t_end;
+    const bool next_same_col = has_next && z + 1 < a.D;     // z fastest: the next tile continues this column iff z+1 < D
+    if (loader) {
+      if (next_same_col) {
+        stage_dy(tile + 1, buf ^ 1);
+        stage_x(tile + 1, z + 2, z + 2);                     // the one new plane goes to the slot the consumers do not read now
+      }
+    } else {
+      // ---- consumers: 4 k-steps (y-rows of 16 voxels); this wave: tap row (wdz, wdy), dx = 0..2 ----
+      const int bslot = (z - 1 + wdz) & 3;
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        uint4 af[MT][NS], b0[NS], b1[NS];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int p = 0; p < NS; ++p) af[mt][p] = ldsA[((buf * NS + p) * COT + mt * 32 + li) * CSA + r * 2 + half];
+        const int hrow = bslot * HY + r + wdy;
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+          b0[p] = ldsB[(p * 32 + li) * CSB + hrow * XO + half];
+          b1[p] = ldsB[(p * 32 + li) * CSB + hrow * XO + half + 1];
         }
+        uint4 bf[NS];
+#pragma unroll
+        for (int p = 0; p < NS; ++p) bf[p] = shift_run<0>(b0[p], b1[p]);
+#pragma unroll
+        for (int qq = 0; qq < P; ++qq)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[0][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[WProducts<NS>::pb[qq]], acc[0][mt]);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) bf[p] = shift_run<1>(b0[p], b1[p]);
+#pragma unroll
+        for (int qq = 0; qq < P; ++qq)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[1][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[WProducts<NS>::pb[qq]], acc[1][mt]);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) bf[p] = shift_run<2>(b0[p], b1[p]);
+#pragma unroll
+        for (int qq = 0; qq < P; ++qq)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[2][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[WProducts<NS>::pb[qq]], acc[2][mt]);
       }
     }
     __syncthreads();
-    // ---- 4 k-steps (y-rows of 16 voxels); this wave: tap row (wdz, wdy), dx = 0..2 ----
-    const int bslot = (z - 1 + wdz + 3) % 3;
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      uint4 af[MT][NS], b0[NS], b1[NS];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int p = 0; p < NS; ++p) af[mt][p] = ldsA[(p * COT + mt * 32 + li) * CSA + r * 2 + half];
-      const int hrow = bslot * HY + r + wdy;
-#pragma unroll
-      for (int p = 0; p < NS; ++p) {
-        b0[p] = ldsB[(p * 32 + li) * CSB + hrow * XO + half];
-        b1[p] = ldsB[(p * 32 + li) * CSB + hrow * XO + half + 1];
+    if (has_next && !next_same_col) {
+      // new column: the ring is refilled while the consumers wait (once per D tiles)
+      if (loader) {
+        stage_dy(tile + 1, buf ^ 1);
+        stage_x(tile + 1, -1, 1);
       }
-      uint4 bf[NS];
-#pragma unroll
-      for (int p = 0; p < NS; ++p) bf[p] = shift_run<0>(b0[p], b1[p]);
-#pragma unroll
-      for (int qq = 0; qq < P; ++qq)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[0][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[WProducts<NS>::pb[qq]], acc[0][mt]);
-#pragma unroll
-      for (int p = 0; p < NS; ++p) bf[p] = shift_run<1>(b0[p], b1[p]);
-#pragma unroll
-      for (int qq = 0; qq < P; ++qq)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[1][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[WProducts<NS>::pb[qq]], acc[1][mt]);
-#pragma unroll
-      for (int p = 0; p < NS; ++p) bf[p] = shift_run<2>(b0[p], b1[p]);
-#pragma unroll
-      for (int qq = 0; qq < P; ++qq)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[2][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[WProducts<NS>::pb[qq]], acc[2][mt]);
+      __syncthreads();
     }
   }
 
   // ---- write the partial tiles: ws[pair][slab][tap][32 co][32 ci] (same layout as the f32 kernel) ----
+  if (!loader) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int cot32 = cot * MT + mt;
-    if (cot32 >= a.coTiles32) continue;
-    const size_t pair = (size_t)cot32 * a.ciTiles + cit;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int cot32 = cot * MT + mt;
+      if (cot32 >= a.coTiles32) continue;
+      const size_t pair = (size_t)cot32 * a.ciTiles + cit;
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int tap = (wdz * 3 + wdy) * 3 + dx;
-      float* dst = a.ws + (((pair * a.splits + split) * 27 + tap) * 1024);
+      for (int dx = 0; dx < 3; ++dx) {
+        const int tap = (wdz * 3 + wdy) * 3 + dx;
+        float* dst = a.ws + (((pair * a.splits + split) * 27 + tap) * 1024);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        dst[row * 32 + li] = acc[dx][mt][r];
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          dst[row * 32 + li] = acc[dx][mt][r];
+        }
       }
     }
   }
@@ -252,7 +283,7 @@ static WBPlan plan_wb(const mi355_act* x, const mi355_act* dy, const mi355_conv_
   if (nt <= 0 || nt > 0x7fffffffLL) return p;
   p.ntiles = (int)nt;
   p.ciTiles = ceil_div(x->c, 32); p.coTiles32 = ceil_div(dy->c, 32);
-  p.mt = dy->c > 32 ? 2 : 1;
+  p.mt = (dy->c > 32 && nsplit_of_w(d->precision) < 3) ? 2 : 1;     // 3 planes x 64 co would not fit the 160 KiB LDS
   p.coTilesWG = ceil_div(p.coTiles32, p.mt);
   const int wgs = p.ciTiles * p.coTilesWG;
   int splits = ceil_div(512, wgs);
@@ -273,15 +304,15 @@ size_t mi355_conv3d_wgrad_bf16_workspace(const mi355_act* x, const mi355_act* dy
 
 template <int NS, int MT>
 static int launch_wb(WgradBArgs& a, const WBPlan& p, int in_mode, void* stream) {
-  constexpr size_t lds = ((size_t)NS * 32 * MT * 9 + (size_t)NS * 32 * 55) * 16;
+  constexpr size_t lds = ((size_t)2 * NS * 32 * MT * 9 + (size_t)NS * 32 * 73) * 16;
   static_assert(lds <= 160 * 1024, "LDS");
   dim3 grid(p.splits, p.ciTiles, p.coTilesWG);
   if (in_mode == MI355_IN_PLAIN) {
     SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_PLAIN>), lds);
-    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_PLAIN>), grid, dim3(576), lds, stream, a);
+    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_PLAIN>), grid, dim3(768), lds, stream, a);
   } else {
     SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_AFFINE_ACT>), lds);
-    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_AFFINE_ACT>), grid, dim3(576), lds, stream, a);
+    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_AFFINE_ACT>), grid, dim3(768), lds, stream, a);
   }
   return LAUNCH_CHECK();
 }
@@ -300,7 +331,7 @@ int mi355_conv3d_wgrad_bf16_impl(const mi355_act* x, const mi355_act* dy, float*
   a.splits = p.splits; a.ciTiles = p.ciTiles; a.coTiles32 = p.coTiles32;
   const int ns = nsplit_of_w(d->precision);
   int rc;
-  if (p.mt == 2) rc = ns == 1 ? launch_wb<1, 2>(a, p, d->in_mode, stream) : ns == 2 ? launch_wb<2, 2>(a, p, d->in_mode, stream) : launch_wb<3, 2>(a, p, d->in_mode, stream);
+  if (p.mt == 2) rc = ns == 1 ? launch_wb<1, 2>(a, p, d->in_mode, stream) : launch_wb<2, 2>(a, p, d->in_mode, stream);
   else rc = ns == 1 ? launch_wb<1, 1>(a, p, d->in_mode, stream) : ns == 2 ? launch_wb<2, 1>(a, p, d->in_mode, stream) : launch_wb<3, 1>(a, p, d->in_mode, stream);
   if (rc) return rc;
   return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, p.splits, p.ciTiles, stream);

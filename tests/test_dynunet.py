@@ -27,25 +27,21 @@ def _kw(filters):
                 upsample_kernel_size=[2] * (L - 1), filters=filters)
 
 
-KAPPA = 4.0   # allowed multiple of the measured one-ulp noise response (oracle/conditioning.py)
-
-
 def _pair(m, be, dhw, n, dev):
-    """Kernels vs the fp64 evaluation of the oracle graph. Returns logits/loss errors and, per parameter, the gradient error
-    divided by its allowance max(TOL, KAPPA * noise_floor): `grad` <= 1 passes."""
+    """Kernels vs the CPU oracle graph: logits/loss to TOL against the fp32 oracle, gradients by op_cases.grad_parity."""
     L = len(m.filters)
-    sd = {k: v.detach().cpu().clone().double().requires_grad_(True) for k, v in m.state_dict().items()}
     x, y = R.synthetic_case(n, 4, dhw, 3)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    ref = D.dynunet_forward(sd, x.double(), L)
-    lref = O.dice_loss(ref, y)
-    lref.backward()
 
-    def run32():
-        s32 = {k: v.detach().cpu().clone().float().requires_grad_(True) for k, v in m.state_dict().items()}
-        O.dice_loss(D.dynunet_forward(s32, x, L), y).backward()
-        return {k: v.grad for k, v in s32.items()}
-    floor = conditioning.noise_floor(D, run32)
+    def run(dt):
+        sd = {k: v.detach().cpu().clone().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
+        ref = D.dynunet_forward(sd, x.to(dt), L)
+        l = O.dice_loss(ref, y)
+        l.backward()
+        return ref.detach(), l.detach(), {k: v.grad for k, v in sd.items()}
+    ref, lref, g32 = run(torch.float32)
+    _, _, g64 = run(torch.float64)
+    floor = conditioning.noise_floor(D, lambda: run(torch.float32)[2])
     crit = losses.HipDiceLoss(sigmoid=True)
     if be is not None:
         m._be = be
@@ -53,15 +49,10 @@ def _pair(m, be, dhw, n, dev):
     out = m(x.to(dev))
     loss = crit(out, y.to(dev))
     loss.backward()
-    errs = {"logits": C.rel_err(out, ref.detach()), "loss": abs(float(loss.detach()) - float(lref.detach())) / abs(float(lref.detach()))}
-    worst, wk = 0.0, None
-    for k, p in m.named_parameters():
-        e = C.rel_err(p.grad, sd[k].grad)
-        r = e / max(TOL, KAPPA * floor[k])
-        if r > worst:
-            worst, wk, we, wf = r, k, e, floor[k]
-    errs["grad"], errs["grad_key"], errs["grad_err"], errs["noise_floor"] = worst, wk, we, wf
-    errs["n_ill_conditioned"] = sum(1 for v in floor.values() if KAPPA * v > TOL)
+    errs = {"logits": C.rel_err(out, ref), "loss": abs(float(loss.detach()) - float(lref)) / abs(float(lref))}
+    w = C.grad_parity({k: p.grad for k, p in m.named_parameters()}, g32, g64, floor, TOL)
+    errs["grad"] = w.pop("ratio")
+    errs.update(w)
     return errs
 
 

@@ -135,6 +135,7 @@ def test_conv_dgrad_bf16_paths(prec_backend, kw):
     dict(n=2, cin=32, cout=32, dhw=(3, 5, 18), norm=True),
     dict(n=1, cin=4, cout=64, dhw=(4, 4, 16)),
     dict(n=1, cin=40, cout=96, dhw=(5, 3, 7), norm=True, slope=0.01),
+    dict(n=2, cin=32, cout=32, dhw=(5, 8, 32), norm=True),      # 40 tiles in 5 splits: workgroups start mid-column and cross columns
 ])
 def test_conv_wgrad_bf16_paths(prec_backend, kw):
     be, tol = prec_backend
