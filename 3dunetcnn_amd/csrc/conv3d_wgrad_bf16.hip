@@ -17,6 +17,7 @@
 // while the consumers compute on the other three. Partial sums go to the same
 // workspace slabs as the f32 kernel and are reduced by the same deterministic second pass.
 #include "hipcompat.h"
+#include <cstdlib>
 #include "../../include/mi355_unet3d.h"
 
 int mi355_wgrad_reduce_launch(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles, void* stream);
@@ -29,6 +30,7 @@ struct WgradBArgs {
   int N, D, H, W, Cin, Cout;
   int tilesY, tilesX, ntiles;      // tile index = ((n*tilesY + ty)*tilesX + tx)*D + z   (z fastest)
   int splits, ciTiles, coTiles32;
+  int dbg;   // developer switch (MI355_WGRAD_DBG): 1 = producers idle, 2 = consumers idle (timing experiments only)
 };
 
 template <int NS> struct WProducts;
@@ -62,30 +64,146 @@ __device__ __forceinline__ uint4 shift_run(const uint4& b0, const uint4& b1) {
   return make_uint4(b0.y, b0.z, b0.w, b1.x);
 }
 
-// Producer / consumer workgroup: waves 0..8 are the 9 (dz,dy) tap rows and only read LDS + issue MFMAs; waves 9..11 only
-// stage: while the consumers work on tile t they load tile t+1 (its dy tile and the one new input plane) from global memory,
-// transform/split/transpose it and write it to the other dy buffer / the free slot of a 4-plane ring. One barrier per tile;
-// global-memory latency is never on the consumers' path.
-template <int NS, int MT, int INMODE>
-__global__ __launch_bounds__(768) void conv3d_wgrad_k3_bf16(WgradBArgs a) {
+// Producer / consumer workgroup: waves 0..8 are the 9 (dz,dy) tap rows and only read LDS + issue MFMAs; the NLW producer
+// waves only stage: while the consumers work on tile t they load tile t+1 (its dy tile and the one new input plane) from
+// global memory -- every load of the tile issued before the first use, from clamped always-valid addresses (a branch around a
+// load would serialise the round trips) --, transform/split/transpose it and write it to the other dy buffer / the free slot
+// of a 4-plane ring. One barrier per tile; global-memory latency is never on the consumers' path.
+template <int NS, int MT, int NLW, int INMODE>
+__global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArgs a) {
   constexpr int TY = 4, ROWS = 4, HY = 6, XO = 3, RING = 4;
   constexpr int COT = 32 * MT;
   constexpr int CSA = ROWS * 2 + 1;            // 9
   constexpr int CSB = RING * HY * XO + 1;      // 73
   constexpr int P = WProducts<NS>::P;
-  constexpr int NCONS = 576, NLOAD = 192;
+  constexpr int NCONS = 576, NLOAD = 64 * NLW;
+  constexpr int NXU = HY * XO * 8;             // staging units (8 voxels x 4 channels) of one input plane: 144
+  constexpr int NDYU = ROWS * 2 * 8 * MT;      // of one dy tile: 64 * MT
+  constexpr int UPT = (NXU + NDYU + NLOAD - 1) / NLOAD;   // units per producer thread and tile
   DYN_LDS(lds_f);
   uint4* ldsA = reinterpret_cast<uint4*>(lds_f);       // [2 buffers][NS][COT][CSA]
   uint4* ldsB = ldsA + 2 * NS * COT * CSA;             // [NS][32][CSB]
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;          // 12 waves
+  const int lane = tid & 63, wave = tid >> 6;
   const bool loader = wave >= 9;
-  const int half = lane >> 5, li = lane & 31;
-  const int wdz = wave / 3, wdy = wave % 3;            // consumers only
   const int split = blockIdx.x, cit = blockIdx.y, cot = blockIdx.z;
   const int ci0 = cit * 32, co0 = cot * COT;
+  const int per = (a.ntiles + a.splits - 1) / a.splits;
+  const int t_begin = split * per;
+  const int t_end = t_begin + per < a.ntiles ? t_begin + per : a.ntiles;
 
+  if (loader) {
+    // ================================ producers ================================
+    const int ltid = tid - NCONS;
+    // unit u of a tile: u < nx -> input-plane unit (plane index u / NXU relative to z_lo), else dy unit u - nx
+    auto stage = [&](int tile, int buf, int z_lo, int nplanes, bool with_dy) {
+      const int z = tile % a.D, col = tile / a.D;
+      const int tx0 = (col % a.tilesX) * 16, ty0 = ((col / a.tilesX) % a.tilesY) * TY, n = col / (a.tilesX * a.tilesY);
+      const int nx = nplanes * NXU, total = nx + (with_dy ? NDYU : 0);
+      for (int u0 = ltid; u0 < total; u0 += NLOAD * UPT) {
+        float4 t8[UPT][8];
+        // ---- issue every load of this round ----
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+          const int u = u0 + k * NLOAD;
+          const bool isx = u < nx;
+          int c, iz, iy, ix0, ld; const float* base;
+          if (isx) {
+            const int ro = u >> 3, oct = ro % XO, hy = (ro / XO) % HY;
+            c = ci0 + 4 * (u & 7); if (c >= a.Cin) c = 0;
+            iz = z_lo + ro / (XO * HY); iy = ty0 - 1 + hy; ix0 = tx0 - 1 + 8 * oct; ld = a.xld; base = a.x;
+          } else {
+            const int v = u - nx, qq = v % (8 * MT), ro = v / (8 * MT);
+            c = co0 + 4 * qq; if (c >= a.Cout) c = 0;
+            iz = z; iy = ty0 + (ro >> 1); ix0 = tx0 + 8 * (ro & 1); ld = a.dyld; base = a.dy;
+          }
+          const int izc = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1), iyc = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1);
+          const float* rowp = base + (((size_t)n * a.D + izc) * a.H + iyc) * (size_t)a.W * ld + c;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int ix = ix0 + e;
+            const int ixc = ix < 0 ? 0 : (ix < a.W ? ix : a.W - 1);
+            t8[k][e] = *reinterpret_cast<const float4*>(rowp + (size_t)ixc * ld);
+          }
+        }
+        // ---- transform, split, transpose, write ----
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+          const int u = u0 + k * NLOAD;
+          if (u >= total) continue;
+          float v[8][4];
+          if (u < nx) {
+            const int ro = u >> 3, oct = ro % XO, hy = (ro / XO) % HY, q = u & 7;
+            const int c = ci0 + 4 * q;
+            const int iz = z_lo + ro / (XO * HY), iy = ty0 - 1 + hy, ix0 = tx0 - 1 + 8 * oct;
+            const bool rowok = c < a.Cin && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H;
+            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, sl[4] = {a.slope, a.slope, a.slope, a.slope};
+            if (INMODE == MI355_IN_AFFINE_ACT && c < a.Cin) {
+              const float4 s4 = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
+              const float4 h4 = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
+              sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
+              sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
+              if (a.in_slope) { const float4 l4 = *reinterpret_cast<const float4*>(a.in_slope + c); sl[0] = l4.x; sl[1] = l4.y; sl[2] = l4.z; sl[3] = l4.w; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int ix = ix0 + e;
+              float4 t = t8[k][e];
+              if (INMODE == MI355_IN_AFFINE_ACT) {
+                t.x = t.x * sc[0] + sh[0]; t.y = t.y * sc[1] + sh[1]; t.z = t.z * sc[2] + sh[2]; t.w = t.w * sc[3] + sh[3];
+                t.x = t.x > 0.f ? t.x : t.x * sl[0]; t.y = t.y > 0.f ? t.y : t.y * sl[1];
+                t.z = t.z > 0.f ? t.z : t.z * sl[2]; t.w = t.w > 0.f ? t.w : t.w * sl[3];
+              }
+              const bool ok = rowok && ix >= 0 && ix < a.W && 8 * oct + e < 18;
+              v[e][0] = ok ? t.x : 0.f; v[e][1] = ok ? t.y : 0.f; v[e][2] = ok ? t.z : 0.f; v[e][3] = ok ? t.w : 0.f;
+            }
+            const int slot = iz & 3;                          // iz >= -1: (-1 & 3) == 3
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              uint4 pl[NS];
+              split_col<NS>(v, cc, pl);
+#pragma unroll
+              for (int p = 0; p < NS; ++p) ldsB[(p * 32 + 4 * q + cc) * CSB + (slot * HY + hy) * XO + oct] = pl[p];
+            }
+          } else {
+            const int w = u - nx, qq = w % (8 * MT), ro = w / (8 * MT), row = ro >> 1, oct = ro & 1;
+            const int co = co0 + 4 * qq, y = ty0 + row, x0 = tx0 + 8 * oct;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const bool ok = co < a.Cout && y < a.H && x0 + e < a.W;
+              v[e][0] = ok ? t8[k][e].x : 0.f; v[e][1] = ok ? t8[k][e].y : 0.f; v[e][2] = ok ? t8[k][e].z : 0.f; v[e][3] = ok ? t8[k][e].w : 0.f;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              uint4 pl[NS];
+              split_col<NS>(v, cc, pl);
+#pragma unroll
+              for (int p = 0; p < NS; ++p) ldsA[((buf * NS + p) * COT + 4 * qq + cc) * CSA + row * 2 + oct] = pl[p];
+            }
+          }
+        }
+      }
+    };
+    if (t_begin < t_end) stage(t_begin, 0, t_begin % a.D - 1, 3, true);       // prologue: everything tile t_begin needs
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int z = tile % a.D, buf = (tile - t_begin) & 1;
+      const bool has_next = tile + 1 < t_end;
+      const bool next_same_col = has_next && z + 1 < a.D;   // z fastest: the next tile continues this column iff z+1 < D
+      if (next_same_col && a.dbg != 1) stage(tile + 1, buf ^ 1, z + 2, 1, true);   // the one new plane -> the slot not read now
+      __syncthreads();
+      if (has_next && !next_same_col) {                      // new column: refill the ring while the consumers wait
+        stage(tile + 1, buf ^ 1, -1, 3, true);
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  // ================================ consumers ================================
+  const int half = lane >> 5, li = lane & 31;
+  const int wdz = wave / 3, wdy = wave % 3;
   f32x16 acc[3][MT];
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx)
@@ -93,105 +211,13 @@ __global__ __launch_bounds__(768) void conv3d_wgrad_k3_bf16(WgradBArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[dx][mt][r] = 0.f;
-
-  const int per = (a.ntiles + a.splits - 1) / a.splits;
-  const int t_begin = split * per;
-  const int t_end = t_begin + per < a.ntiles ? t_begin + per : a.ntiles;
-  const int ltid = tid - NCONS;                        // loader thread index 0..191
-  const int q = ltid & 7;                              // loader: channel quad of the x staging (192 % 8 == 0)
-  const int cx = ci0 + 4 * q;
-  const bool cxok = cx < a.Cin;
-
-  // stage the dy tile of `tile` into buffer `buf` (loader threads)
-  auto stage_dy = [&](int tile, int buf) {
-    const int z = tile % a.D, col = tile / a.D;
-    const int tx0 = (col % a.tilesX) * 16, ty0 = ((col / a.tilesX) % a.tilesY) * TY, n = col / (a.tilesX * a.tilesY);
-    for (int u = ltid; u < ROWS * 2 * 8 * MT; u += NLOAD) {
-      const int qq = u % (8 * MT), ro = u / (8 * MT);
-      const int row = ro >> 1, oct = ro & 1;
-      const int co = co0 + 4 * qq;
-      const int y = ty0 + row, x0 = tx0 + 8 * oct;
-      float v[8][4];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (co < a.Cout && y < a.H && x0 + e < a.W)
-          t = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.D + z) * a.H + y) * a.W + x0 + e) * a.dyld + co);
-        v[e][0] = t.x; v[e][1] = t.y; v[e][2] = t.z; v[e][3] = t.w;
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        uint4 pl[NS];
-        split_col<NS>(v, c, pl);
-#pragma unroll
-        for (int p = 0; p < NS; ++p) ldsA[((buf * NS + p) * COT + 4 * qq + c) * CSA + row * 2 + oct] = pl[p];
-      }
-    }
-  };
-  // stage input planes iz = z_lo .. z_hi (inclusive) of the column of `tile` into ring slots iz & 3 (loader threads)
-  auto stage_x = [&](int tile, int z_lo, int z_hi) {
-    const int col = tile / a.D;
-    const int tx0 = (col % a.tilesX) * 16, ty0 = ((col / a.tilesX) % a.tilesY) * TY, n = col / (a.tilesX * a.tilesY);
-    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, sl[4] = {a.slope, a.slope, a.slope, a.slope};
-    if (INMODE == MI355_IN_AFFINE_ACT && cxok) {
-      const float4 s4 = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + cx);
-      const float4 h4 = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + cx);
-      sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
-      sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
-      if (a.in_slope) { const float4 l4 = *reinterpret_cast<const float4*>(a.in_slope + cx); sl[0] = l4.x; sl[1] = l4.y; sl[2] = l4.z; sl[3] = l4.w; }
-    }
-    const int nunits = (z_hi - z_lo + 1) * HY * XO * 8;
-    for (int u = ltid; u < nunits; u += NLOAD) {
-      const int ro = u >> 3;                              // (plane, hy, oct); u & 7 == q
-      const int oct = ro % XO, hy = (ro / XO) % HY, iz = z_lo + ro / (XO * HY);
-      const int iy = ty0 - 1 + hy, ix0 = tx0 - 1 + 8 * oct;
-      const int slot = iz & 3;                            // iz >= -1: (-1 & 3) == 3
-      const bool rowok = cxok && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H;
-      float v[8][4];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int ix = ix0 + e;
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rowok && ix >= 0 && ix < a.W && 8 * oct + e < 18) {
-          t = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + cx);
-          if (INMODE == MI355_IN_AFFINE_ACT) {
-            t.x = t.x * sc[0] + sh[0]; t.y = t.y * sc[1] + sh[1]; t.z = t.z * sc[2] + sh[2]; t.w = t.w * sc[3] + sh[3];
-            t.x = t.x > 0.f ? t.x : t.x * sl[0]; t.y = t.y > 0.f ? t.y : t.y * sl[1];
-            t.z = t.z > 0.f ? t.z : t.z * sl[2]; t.w = t.w > 0.f ? t.w : t.w * sl[3];
-          }
-        }
-        v[e][0] = t.x; v[e][1] = t.y; v[e][2] = t.z; v[e][3] = t.w;
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        uint4 pl[NS];
-        split_col<NS>(v, c, pl);
-#pragma unroll
-        for (int p = 0; p < NS; ++p) ldsB[(p * 32 + 4 * q + c) * CSB + (slot * HY + hy) * XO + oct] = pl[p];
-      }
-    }
-  };
-
-  // ---- prologue: everything tile t_begin needs ----
-  if (t_begin < t_end && loader) {
-    const int z = t_begin % a.D;
-    stage_dy(t_begin, 0);
-    stage_x(t_begin, z - 1, z + 1);
-  }
-  __syncthreads();
-
+  __syncthreads();                                           // prologue
   for (int tile = t_begin; tile < t_end; ++tile) {
-    const int z = tile % a.D;
-    const int buf = (tile - t_begin) & 1;
+    const int z = tile % a.D, buf = (tile - t_begin) & 1;
     const bool has_next = tile + 1 < t_end;
-    const bool next_same_col = has_next && z + 1 < a.D;     // z fastest: the next tile continues this column iff z+1 < D
-    if (loader) {
-      if (next_same_col) {
-        stage_dy(tile + 1, buf ^ 1);
-        stage_x(tile + 1, z + 2, z + 2);                     // the one new plane goes to the slot the consumers do not read now
-      }
-    } else {
-      // ---- consumers: 4 k-steps (y-rows of 16 voxels); this wave: tap row (wdz, wdy), dx = 0..2 ----
+    const bool next_same_col = has_next && z + 1 < a.D;
+    if (a.dbg != 2) {
+      // 4 k-steps (y-rows of 16 voxels); this wave: tap row (wdz, wdy), dx = 0..2
       const int bslot = (z - 1 + wdz) & 3;
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
@@ -206,57 +232,37 @@ __global__ __launch_bounds__(768) void conv3d_wgrad_k3_bf16(WgradBArgs a) {
           b0[p] = ldsB[(p * 32 + li) * CSB + hrow * XO + half];
           b1[p] = ldsB[(p * 32 + li) * CSB + hrow * XO + half + 1];
         }
-        uint4 bf[NS];
+        uint4 bf[3][NS];
 #pragma unroll
-        for (int p = 0; p < NS; ++p) bf[p] = shift_run<0>(b0[p], b1[p]);
-#pragma unroll
-        for (int qq = 0; qq < P; ++qq)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[0][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[WProducts<NS>::pb[qq]], acc[0][mt]);
-#pragma unroll
-        for (int p = 0; p < NS; ++p) bf[p] = shift_run<1>(b0[p], b1[p]);
+        for (int p = 0; p < NS; ++p) { bf[0][p] = shift_run<0>(b0[p], b1[p]); bf[1][p] = shift_run<1>(b0[p], b1[p]); bf[2][p] = shift_run<2>(b0[p], b1[p]); }
+        // products outermost: consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
 #pragma unroll
         for (int qq = 0; qq < P; ++qq)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[1][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[WProducts<NS>::pb[qq]], acc[1][mt]);
+          for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int p = 0; p < NS; ++p) bf[p] = shift_run<2>(b0[p], b1[p]);
-#pragma unroll
-        for (int qq = 0; qq < P; ++qq)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[2][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[WProducts<NS>::pb[qq]], acc[2][mt]);
+            for (int mt = 0; mt < MT; ++mt)
+              acc[dx][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[dx][WProducts<NS>::pb[qq]], acc[dx][mt]);
       }
     }
     __syncthreads();
-    if (has_next && !next_same_col) {
-      // new column: the ring is refilled while the consumers wait (once per D tiles)
-      if (loader) {
-        stage_dy(tile + 1, buf ^ 1);
-        stage_x(tile + 1, -1, 1);
-      }
-      __syncthreads();
-    }
+    if (has_next && !next_same_col) __syncthreads();
   }
 
   // ---- write the partial tiles: ws[pair][slab][tap][32 co][32 ci] (same layout as the f32 kernel) ----
-  if (!loader) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int cot32 = cot * MT + mt;
-      if (cot32 >= a.coTiles32) continue;
-      const size_t pair = (size_t)cot32 * a.ciTiles + cit;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int cot32 = cot * MT + mt;
+    if (cot32 >= a.coTiles32) continue;
+    const size_t pair = (size_t)cot32 * a.ciTiles + cit;
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int tap = (wdz * 3 + wdy) * 3 + dx;
-        float* dst = a.ws + (((pair * a.splits + split) * 27 + tap) * 1024);
+    for (int dx = 0; dx < 3; ++dx) {
+      const int tap = (wdz * 3 + wdy) * 3 + dx;
+      float* dst = a.ws + (((pair * a.splits + split) * 27 + tap) * 1024);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          dst[row * 32 + li] = acc[dx][mt][r];
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        dst[row * 32 + li] = acc[dx][mt][r];
       }
     }
   }
@@ -304,15 +310,16 @@ size_t mi355_conv3d_wgrad_bf16_workspace(const mi355_act* x, const mi355_act* dy
 
 template <int NS, int MT>
 static int launch_wb(WgradBArgs& a, const WBPlan& p, int in_mode, void* stream) {
+  constexpr int NLW = MT == 1 ? 4 : 3;     // producer waves: 4 cover a tile's 208 staging units in one round; MT = 2 is VGPR-limited to 12 waves
   constexpr size_t lds = ((size_t)2 * NS * 32 * MT * 9 + (size_t)NS * 32 * 73) * 16;
   static_assert(lds <= 160 * 1024, "LDS");
   dim3 grid(p.splits, p.ciTiles, p.coTilesWG);
   if (in_mode == MI355_IN_PLAIN) {
-    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_PLAIN>), lds);
-    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_PLAIN>), grid, dim3(768), lds, stream, a);
+    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_PLAIN>), lds);
+    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_PLAIN>), grid, dim3(576 + 64 * NLW), lds, stream, a);
   } else {
-    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_AFFINE_ACT>), lds);
-    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, MI355_IN_AFFINE_ACT>), grid, dim3(768), lds, stream, a);
+    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_AFFINE_ACT>), lds);
+    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_AFFINE_ACT>), grid, dim3(576 + 64 * NLW), lds, stream, a);
   }
   return LAUNCH_CHECK();
 }
@@ -329,6 +336,7 @@ int mi355_conv3d_wgrad_bf16_impl(const mi355_act* x, const mi355_act* dy, float*
   a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Cout = dy->c;
   a.tilesY = p.tilesY; a.tilesX = p.tilesX; a.ntiles = p.ntiles;
   a.splits = p.splits; a.ciTiles = p.ciTiles; a.coTiles32 = p.coTiles32;
+  { const char* e = getenv("MI355_WGRAD_DBG"); a.dbg = e ? atoi(e) : 0; }
   const int ns = nsplit_of_w(d->precision);
   int rc;
   if (p.mt == 2) rc = ns == 1 ? launch_wb<1, 2>(a, p, d->in_mode, stream) : launch_wb<2, 2>(a, p, d->in_mode, stream);
