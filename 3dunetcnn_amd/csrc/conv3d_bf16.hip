@@ -148,26 +148,42 @@ __global__ __launch_bounds__(256) void conv3d_k3_bf16(ConvBArgs a) {
           }
         }
       }
-      for (int hv = sv0; hv < HV; hv += 256 / OCT) {
+      // Two phases: (1) every global load of this thread's staging units is issued from a clamped, always-valid address
+      // -- no branch around a load, so all of them are in flight together instead of one dependent round trip per unit --
+      // (2) mask / normalise / split / write to LDS.
+      constexpr int UP = (HV * OCT + 255) / 256;       // staging units (one halo voxel x 8 channels) per thread
+      const int c0q = v0ok ? c : 0, c1q = v1ok ? c + 4 : c0q;
+      float4 ld0[UP], ld1[UP];
+#pragma unroll
+      for (int k = 0; k < UP; ++k) {
+        int hv = sv0 + k * (256 / OCT);
+        if (hv >= HV) hv = HV - 1;
+        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+        int iz = tz0 - a.pad + hz, iy = ty0 - a.pad + hy, ix = tx0 - a.pad + hx;
+        iz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
+        iy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
+        ix = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
+        const float* src = a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld;
+        ld0[k] = *reinterpret_cast<const float4*>(src + c0q);
+        ld1[k] = *reinterpret_cast<const float4*>(src + c1q);
+      }
+#pragma unroll
+      for (int k = 0; k < UP; ++k) {
+        const int hv = sv0 + k * (256 / OCT);
+        if (hv >= HV) continue;
         const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
         const int iz = tz0 - a.pad + hz, iy = ty0 - a.pad + hy, ix = tx0 - a.pad + hx;
-        float v[8];
+        const bool inb = iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi;
+        float v[8] = {ld0[k].x, ld0[k].y, ld0[k].z, ld0[k].w, ld1[k].x, ld1[k].y, ld1[k].z, ld1[k].w};
+        if (INMODE == MI355_IN_AFFINE_ACT) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        if (iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi) {
-          const float* src = a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + c;
-          if (v0ok) { const float4 t = *reinterpret_cast<const float4*>(src); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-          if (v1ok) { const float4 t = *reinterpret_cast<const float4*>(src + 4); v[4] = t.x; v[5] = t.y; v[6] = t.z; v[7] = t.w; }
-          if (INMODE == MI355_IN_AFFINE_ACT) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float u = v[e] * sc[e] + sh[e];
-              v[e] = u > 0.f ? u : u * sl[e];
-            }
-            if (!v0ok) { v[0] = v[1] = v[2] = v[3] = 0.f; }
-            if (!v1ok) { v[4] = v[5] = v[6] = v[7] = 0.f; }
+          for (int e = 0; e < 8; ++e) {
+            const float u = v[e] * sc[e] + sh[e];
+            v[e] = u > 0.f ? u : u * sl[e];
           }
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { if (!(inb && v0ok)) v[e] = 0.f; if (!(inb && v1ok)) v[4 + e] = 0.f; }
         uint4 pl[NS];
         split8<NS>(v, pl);
 #pragma unroll

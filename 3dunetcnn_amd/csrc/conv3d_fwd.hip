@@ -112,28 +112,52 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
           }
           *reinterpret_cast<float4*>(lds + hv * VS + 4 * sq) = val;
         }
-      } else
-      for (int hv = sv0; hv < HV; hv += 256 / Q) {
-        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
-        int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
-        bool ok = cvalid;
-        if (INMODE == MI355_IN_ZERO_INSERT) {
-          ok = ok && iz >= 0 && iy >= 0 && ix >= 0 && ((iz | iy | ix) & 1) == 0;
-          iz >>= 1; iy >>= 1; ix >>= 1;
-          ok = ok && iz < a.Di && iy < a.Hi && ix < a.Wi;
-        } else {
-          ok = ok && iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi;
-        }
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
-          v = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + c);
-          if (INMODE == MI355_IN_AFFINE_ACT) {
-            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-            v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
-            v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+      } else {
+        // Batches of UB staging units: all loads of a batch are issued from clamped, always-valid addresses before the first
+        // use (no branch around a load, so they are in flight together instead of one dependent round trip each), then
+        // masked / normalised and written to LDS.
+        constexpr int UP = (HV * Q + 255) / 256, UB = 4;
+#pragma unroll
+        for (int k0 = 0; k0 < UP; k0 += UB) {
+          float4 ld[UB];
+#pragma unroll
+          for (int kk = 0; kk < UB; ++kk) {
+            if (k0 + kk >= UP) continue;
+            int hv = sv0 + (k0 + kk) * (256 / Q);
+            if (hv >= HV) hv = HV - 1;
+            const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+            int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
+            if (INMODE == MI355_IN_ZERO_INSERT) { iz >>= 1; iy >>= 1; ix >>= 1; }
+            iz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
+            iy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
+            ix = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
+            ld[kk] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (cvalid ? c : 0));
+          }
+#pragma unroll
+          for (int kk = 0; kk < UB; ++kk) {
+            if (k0 + kk >= UP) continue;
+            const int hv = sv0 + (k0 + kk) * (256 / Q);
+            if (hv >= HV) continue;
+            const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+            int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
+            bool ok = cvalid;
+            if (INMODE == MI355_IN_ZERO_INSERT) {
+              ok = ok && iz >= 0 && iy >= 0 && ix >= 0 && ((iz | iy | ix) & 1) == 0;
+              iz >>= 1; iy >>= 1; ix >>= 1;
+              ok = ok && iz < a.Di && iy < a.Hi && ix < a.Wi;
+            } else {
+              ok = ok && iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi;
+            }
+            float4 v = ld[kk];
+            if (INMODE == MI355_IN_AFFINE_ACT) {
+              v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+              v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
+              v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+            }
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(lds + hv * VS + 4 * sq) = v;
           }
         }
-        *reinterpret_cast<float4*>(lds + hv * VS + 4 * sq) = v;
       }
     }
     __syncthreads();

@@ -93,12 +93,30 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
           *reinterpret_cast<float4*>(lds_dy + v * 32 + 4 * sq) = val;
         }
       } else
-      for (int v = sv0; v < TV; v += 32) {
-        const int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cvalid && oz < a.Do && oy < a.Ho && ox < a.Wo)
-          val = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.dyld + c);
-        *reinterpret_cast<float4*>(lds_dy + v * 32 + 4 * sq) = val;
+      {
+        // batches of 4 loads from clamped, always-valid addresses (all in flight together), masked afterwards
+        constexpr int UPD = (TV + 31) / 32;
+#pragma unroll
+        for (int k0 = 0; k0 < UPD; k0 += 4) {
+          float4 ld[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            if (k0 + kk >= UPD) continue;
+            int v = sv0 + (k0 + kk) * 32; if (v >= TV) v = TV - 1;
+            int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
+            oz = oz < a.Do ? oz : a.Do - 1; oy = oy < a.Ho ? oy : a.Ho - 1; ox = ox < a.Wo ? ox : a.Wo - 1;
+            ld[kk] = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.dyld + (cvalid ? c : 0));
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            if (k0 + kk >= UPD) continue;
+            const int v = sv0 + (k0 + kk) * 32;
+            if (v >= TV) continue;
+            const int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
+            const bool ok = cvalid && oz < a.Do && oy < a.Ho && ox < a.Wo;
+            *reinterpret_cast<float4*>(lds_dy + v * 32 + 4 * sq) = ok ? ld[kk] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
       }
     }
     // ---- stage haloed x tile with the fused input transform ----
@@ -112,19 +130,38 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
         sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
         if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + c);
       }
-      for (int hv = sv0; hv < HV; hv += 32) {
-        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
-        const int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cvalid && iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi) {
-          v = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + c);
+      constexpr int UPX = (HV + 31) / 32;
+#pragma unroll
+      for (int k0 = 0; k0 < UPX; k0 += 4) {
+        float4 ld[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          if (k0 + kk >= UPX) continue;
+          int hv = sv0 + (k0 + kk) * 32; if (hv >= HV) hv = HV - 1;
+          const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+          int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
+          iz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
+          iy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
+          ix = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
+          ld[kk] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (cvalid ? c : 0));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          if (k0 + kk >= UPX) continue;
+          const int hv = sv0 + (k0 + kk) * 32;
+          if (hv >= HV) continue;
+          const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+          const int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
+          const bool ok = cvalid && iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi;
+          float4 v = ld[kk];
           if (INMODE == MI355_IN_AFFINE_ACT) {
             v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
             v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
             v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
           }
+          if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(lds_x + hv * 32 + 4 * sq) = v;
         }
-        *reinterpret_cast<float4*>(lds_x + hv * 32 + 4 * sq) = v;
       }
     }
     __syncthreads();
