@@ -33,7 +33,10 @@ struct ConvArgs {
   int cD, cH, cW, fC;      // IN_S2D / OUT_D2S (1x1x1 only): coarse grid extents and the fine tensor's channel count
 };
 
-template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT, int INMODE, bool TL = false>
+// FULLJ: CinP is a multiple of KC, so every chunk has all KC/8 k-groups and the tap loop contains no data-dependent branch
+// (with a runtime k-group count the compiler keeps the accumulators in VGPRs across the branches and copies all of them to
+// and from AGPRs around every group of MFMAs).
+template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT, int INMODE, bool TL = false, bool FULLJ = false>
 __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TZ * TY * TX == 32 * WM * MT, "tile voxels must equal 32*WM*MT");
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
     // ---- 27 taps x KC/8 k-groups, B fragments prefetched one tap ahead ----
     const int cq0 = c0 / 4 + half;
     // k-groups of this chunk that exist (CinP is a multiple of 8 but not necessarily of KC); wave-uniform
-    const int jn = (a.CinP - c0) / 8 < J ? (a.CinP - c0) / 8 : J;
+    const int jn = FULLJ ? J : ((a.CinP - c0) / 8 < J ? (a.CinP - c0) / 8 : J);
     float4 bcur[J][NT], bnext[J][NT];
 #pragma unroll
     for (int j = 0; j < J; ++j)
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
         if (j < jn) bcur[j][nt] = wp4[((size_t)(0 * CQ + cq0 + 2 * j)) * a.CoutP + co_base + nt * 32 + li];
       }
 
+#pragma unroll 1
     for (int tap = 0; tap < T; ++tap) {
       const int tn = tap + 1 < T ? tap + 1 : tap;
 #pragma unroll
@@ -318,23 +322,31 @@ static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
   // two-level accumulation: always for >= 4 channel chunks; for the 1-tile-per-wave configurations (16 accumulator
   // registers, deep layers) already from 2 chunks, where it is free
-  const bool tl = KD == 3 && (a.CinP >= 4 * KC || (MT * NT == 1 && a.CinP >= 2 * KC));
+  // (not for the 4-tile configuration: 64 more live registers would cost a wave of occupancy per SIMD)
+  const bool tl = KD == 3 && MT * NT <= 2 && (a.CinP >= 4 * KC || (MT * NT == 1 && a.CinP >= 2 * KC));
+  const bool fullj = a.CinP % KC == 0;
+#define MI355_LAUNCH_CONV(SS, IM)                                                                                              \
+  do {                                                                                                                         \
+    if (tl && fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, true>), dim3((unsigned)blocks), dim3(256), lds, stream, a);  \
+    else if (tl) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, false>), dim3((unsigned)blocks), dim3(256), lds, stream, a);      \
+    else if (fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, true>), dim3((unsigned)blocks), dim3(256), lds, stream, a);       \
+    else LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, false>), dim3((unsigned)blocks), dim3(256), lds, stream, a);                 \
+  } while (0)
   if (in_mode == MI355_IN_PLAIN) {
-    if (tl) LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_PLAIN, KD == 3>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
-    else LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_PLAIN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    MI355_LAUNCH_CONV(STRIDE, MI355_IN_PLAIN);
   } else if (in_mode == MI355_IN_AFFINE_ACT) {
-    if (tl) LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_AFFINE_ACT, KD == 3>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
-    else LAUNCH((conv3d_mfma<KD, STRIDE, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_AFFINE_ACT>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    MI355_LAUNCH_CONV(STRIDE, MI355_IN_AFFINE_ACT);
   } else if (in_mode == MI355_IN_S2D) {
     if constexpr (KD == 1) {
-      LAUNCH((conv3d_mfma<1, 1, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_S2D>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+      MI355_LAUNCH_CONV(1, MI355_IN_S2D);
     } else return MI355_EUNSUPPORTED;
   } else {
     if constexpr (KD == 3) {
       if (STRIDE != 1) return MI355_EUNSUPPORTED;
-      LAUNCH((conv3d_mfma<3, 1, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, MI355_IN_ZERO_INSERT>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+      MI355_LAUNCH_CONV(1, MI355_IN_ZERO_INSERT);
     } else return MI355_EUNSUPPORTED;
   }
+#undef MI355_LAUNCH_CONV
   return LAUNCH_CHECK();
 }
 
@@ -436,8 +448,12 @@ extern "C" int mi355_conv3d_fwd_config(const mi355_act* x, const mi355_act* y, c
   static const int kcs[8] = {32, 32, 8, 8, 16, 16, 32, 32};
   const int cinP = (x->c + 7) / 8 * 8;
   const bool one = cfg == 3 || cfg == 6 || cfg == 7;     // MT * NT == 1
-  const char* tl = (d->kd == 3 && (cinP >= 4 * kcs[cfg] || (one && cinP >= 2 * kcs[cfg]))) ? "true" : "false";
-  if (cfg == 2 || cfg == 3) snprintf(out, n, "conv3d_mfma<3, %d, %s, %d, %s>", stride_t, tags[cfg], d->in_mode, tl);
-  else snprintf(out, n, "conv3d_mfma<%s, %d, %s>", tags[cfg], d->in_mode, tl);
+  const bool four = cfg == 2 || cfg == 4;                 // MT * NT == 4 (cfg 2: NT = 2, MT = 1 -> 2 tiles, allowed)
+  const char* tl = (d->kd == 3 && cfg != 4 && (cinP >= 4 * kcs[cfg] || (one && cinP >= 2 * kcs[cfg]))) ? "true" : "false";
+  (void)four;
+  const int cinL = d->in_mode == MI355_IN_S2D ? 8 * x->c : x->c;
+  const char* fj = (((cinL + 7) / 8 * 8) % kcs[cfg] == 0) ? "true" : "false";
+  if (cfg == 2 || cfg == 3) snprintf(out, n, "conv3d_mfma<3, %d, %s, %d, %s, %s>", stride_t, tags[cfg], d->in_mode, tl, fj);
+  else snprintf(out, n, "conv3d_mfma<%s, %d, %s, %s>", tags[cfg], d->in_mode, tl, fj);
   return 0;
 }

@@ -9,6 +9,7 @@ on the current CUDA(=HIP) device; it raises if the library is missing. (tests/ m
 emulator build of the same sources -- test infrastructure only, never used by the modules of this package.)
 """
 import ctypes
+import os
 
 import torch
 
@@ -305,4 +306,7 @@ def default_backend():
     dev = torch.cuda.current_device()
     if dev not in _default:
         _default[dev] = Backend()
+        env = os.environ.get("MI355_PRECISION")        # fp32 (default) | bf16x6 | bf16x3 | bf16
+        if env:
+            _default[dev].set_precision(env)
     return _default[dev]

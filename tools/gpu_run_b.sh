@@ -1,14 +1,11 @@
 #!/bin/bash
-out=gpurun_out/r1e; mkdir -p $out
-timeout 1500 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $out/pytest_gpu.log; tail -8 $out/pytest_gpu.log
-for p in fp32 bf16x6 bf16x3 bf16; do
-  timeout 600 python bench.py --precision $p --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_$p.json 2> $out/bench_$p.err
-  python -c "
-import json,sys
-d=json.load(open('$out/bench_$p.json')); r=d['roofline']
-print('$p', d['value'], 'vol/s', d['ms_per_step'], 'ms loss', d['final_loss'], '|', r['kernel'], r['achieved'], 'TF/s share', r['share_of_step'])
-for k,v in list(r['all_kernels'].items())[:6]: print('    ', k, v)
-"
+out=$(pwd)/gpurun_out/r1g; mkdir -p $out; root=$(pwd)
+cd /tmp; export TMPDIR=/tmp
+A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"
+B="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"
+for cfg in "fp32 32 32 128 fwd" "fp32 64 64 64 fwd" "bf16x3 32 32 128 fwd" "bf16x3 128 128 64 fwd" "fp32 32 32 128 wgrad" "bf16x3 32 32 128 wgrad"; do
+  tag=$(echo $cfg | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc $A -f csv -d $out/$tag.a -o p -- python $root/tools/one_conv.py $cfg > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $B -f csv -d $out/$tag.b -o p -- python $root/tools/one_conv.py $cfg > /dev/null 2>&1
+  echo "=== $cfg"; python $root/tools/pmc_kernel.py $out/$tag.a/p_counter_collection.csv conv3d; python $root/tools/pmc_kernel.py $out/$tag.b/p_counter_collection.csv conv3d | grep -v avg_us
 done
-timeout 600 python bench.py --model dynunet --batch 1 --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_dyn_fp32.json 2> $out/bench_dyn.err; cut -c1-400 $out/bench_dyn_fp32.json
-timeout 600 python bench.py --model dynunet --batch 1 --steps 3 --warmup 1 --no-cpu-baseline --precision bf16x3 > $out/bench_dyn_bf16x3.json 2>> $out/bench_dyn.err; cut -c1-400 $out/bench_dyn_bf16x3.json

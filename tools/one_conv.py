@@ -1,0 +1,25 @@
+"""Developer tool (GPU): launch one conv layer a few times (for rocprofv3 --pmc runs).
+    python tools/one_conv.py <precision> <cin> <cout> <size> [fwd|wgrad] [iters]"""
+import importlib, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ops = importlib.import_module("3dunetcnn_amd.ops")
+be = ops.default_backend()
+prec, cin, cout, s = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+what = sys.argv[5] if len(sys.argv) > 5 else "fwd"
+iters = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+be.set_precision(prec)
+n = 2
+x = be.empty_act(n, s, s, s, cin); x.buf.normal_()
+y = be.empty_act(n, s, s, s, cout); y.buf.normal_()
+w = torch.randn(cout, cin, 3, 3, 3, device=be.device) * 0.05
+wp = be.pack_weight(w, 0)
+dw = torch.empty_like(w)
+sc = torch.ones(n, cin, device=be.device); sh = torch.zeros(n, cin, device=be.device)
+for _ in range(iters):
+    if what == "fwd":
+        be.conv_fwd(x, wp, y, 3, 1, in_mode=ops.IN_AFFINE_ACT, scale=sc, shift=sh)
+    else:
+        be.conv_wgrad(x, y, dw, 3, 1, in_mode=ops.IN_AFFINE_ACT, scale=sc, shift=sh)
+torch.cuda.synchronize()
