@@ -59,6 +59,25 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel_name, precision):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md 'HBM'). PMC collection needs rocprofv3 around the process, so bench.py reads the summary."""
+    path = os.path.join(ROOT, "profiles", "r1_bench_fp32_hbm_traffic_pmc.csv")
+    if precision != "fp32" or not os.path.exists(path):
+        return None, None
+    import csv
+    key = kernel_name.split(" (")[0].split("<")[0]
+    best = None
+    for r in csv.DictReader(open(path)):
+        if key in r["Kernel"] and (best is None or int(r["Calls"]) > int(best["Calls"])):
+            best = r
+    if best is None:
+        return None, None
+    mib = float(best["fetch_x2_MiB_per_launch"]) + float(best["WRITE_SIZE_MiB_per_launch"])
+    return round(mib * 1048576), "profiles/r1_bench_fp32_hbm_traffic_pmc.csv (FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
+
+
 def cpu_baseline(size):
     """One training step of the oracle graph on the host CPU (bounded sample: N=1, same patch size)."""
     from oracle import torch_ops as O
@@ -184,8 +203,10 @@ def main():
         on_bf16 = "bf16" in name
         peak = BF16_MFMA_PEAK_TFLOPS if on_bf16 else FP32_MFMA_PEAK_TFLOPS
         products = {"bf16x3": 3, "bf16x6": 6, "bf16": 1}.get(args.precision, 1) if on_bf16 else 1
+        traffic, traffic_src = pmc_traffic(name, args.precision)
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(by / cnt),
                     "mfma_products_per_mac": products, "mfma_pipe_frac": round(ach * products / peak, 4),
                     "launches": cnt, "avg_launch_ms": round(secs / cnt * 1e3, 4),
                     "hbm_gbps_algorithmic": round(by / secs / 1e9, 1), "hbm_frac": round(by / secs / 1e9 / HBM_PEAK_GBPS, 4),
