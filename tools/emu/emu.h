@@ -243,3 +243,4 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetc
   emu::launch((grid), (block), (lds), [=]() { kernel(__VA_ARGS__); })
 #define LAUNCH_CHECK() 0
 #define SET_MAX_DYN_LDS(kernel, bytes) do {} while (0)
+#define SCHED_BARRIER() do {} while (0)
