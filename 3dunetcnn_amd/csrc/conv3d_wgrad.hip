@@ -14,6 +14,7 @@
 // tap accumulators distributed over its 4 waves (7/7/7/6). Partial tiles go to a workspace slab; a second
 // kernel reduces the slabs in a fixed order (deterministic, no atomics) and writes OIDHW.
 #include "hipcompat.h"
+#include <cstdlib>
 #include "../../include/mi355_unet3d.h"
 
 struct WgradArgs {
@@ -68,103 +69,169 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
   const int t_begin = split * per;
   const int t_end = t_begin + per < a.ntiles ? t_begin + per : a.ntiles;
   const int sq = tid & 7, sv0 = tid >> 3;   // staging: 8 quads per 32-channel row
+  constexpr int UPD = (TV + 31) / 32;       // dy staging units (one voxel x 4 channels) per thread and tile
+  constexpr int UPX = (HV + 31) / 32;       // x  staging units per thread and tile
+  const int cdy = co0 + 4 * sq, cx = ci0 + 4 * sq;
+  const bool dyvalid = cdy < a.Cout, xvalid = cx < a.Cin;   // Cout % 4 == 0 and Cin % 4 == 0 are required
+  const bool d2s = KD == 1 && a.dymode == MI355_OUT_D2S;
+  const int d2s_p = (d2s && dyvalid) ? cdy / a.fC : 0, d2s_k = cdy - d2s_p * a.fC;
 
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // Software pipeline over the tiles of this workgroup: the global loads of tile t+1 are issued (into registers, from
+  // clamped always-valid addresses, all in flight together) BEFORE the MFMA loop of tile t and written to LDS after it,
+  // so HBM/L2 latency overlaps the matrix work instead of alternating with it.
+  float4 pdy[UPD], px[UPX];
+  auto decode = [&](int tile, int& n, int& tz0, int& ty0, int& tx0) {
     int b = tile;
-    const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
-    const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
-    const int tz0 = (b % a.tilesZ) * TZ; b /= a.tilesZ;
-    const int n = b;
-    __syncthreads();
-    // ---- stage dy tile ----
-    {
-      const int c = co0 + 4 * sq;
-      const bool cvalid = c < a.Cout;   // Cout % 4 == 0 is required
-      if (KD == 1 && a.dymode == MI355_OUT_D2S) {
-        const int p = cvalid ? c / a.fC : 0, k = c - p * a.fC;
-        for (int v = sv0; v < TV; v += 32) {
-          const int ox = tx0 + v;
-          float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (cvalid && ox < a.Wo) {
-            const int xx = ox % a.cW, yy = (ox / a.cW) % a.cH, zz = ox / (a.cW * a.cH);
-            const size_t fv = (((size_t)n * (2 * a.cD) + 2 * zz + (p >> 2)) * (2 * a.cH) + 2 * yy + ((p >> 1) & 1)) * (2 * a.cW) + 2 * xx + (p & 1);
-            val = *reinterpret_cast<const float4*>(a.dy + fv * a.dyld + k);
-          }
-          *reinterpret_cast<float4*>(lds_dy + v * 32 + 4 * sq) = val;
-        }
-      } else
-      {
-        // batches of 4 loads from clamped, always-valid addresses (all in flight together), masked afterwards
-        constexpr int UPD = (TV + 31) / 32;
+    tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+    ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+    tz0 = (b % a.tilesZ) * TZ; b /= a.tilesZ;
+    n = b;
+  };
+  auto prefetch = [&](int tile) {
+    int n, tz0, ty0, tx0;
+    decode(tile, n, tz0, ty0, tx0);
 #pragma unroll
-        for (int k0 = 0; k0 < UPD; k0 += 4) {
-          float4 ld[4];
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            if (k0 + kk >= UPD) continue;
-            int v = sv0 + (k0 + kk) * 32; if (v >= TV) v = TV - 1;
-            int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
-            oz = oz < a.Do ? oz : a.Do - 1; oy = oy < a.Ho ? oy : a.Ho - 1; ox = ox < a.Wo ? ox : a.Wo - 1;
-            ld[kk] = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.dyld + (cvalid ? c : 0));
-          }
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            if (k0 + kk >= UPD) continue;
-            const int v = sv0 + (k0 + kk) * 32;
-            if (v >= TV) continue;
-            const int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
-            const bool ok = cvalid && oz < a.Do && oy < a.Ho && ox < a.Wo;
-            *reinterpret_cast<float4*>(lds_dy + v * 32 + 4 * sq) = ok ? ld[kk] : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-        }
+    for (int k = 0; k < UPD; ++k) {
+      int v = sv0 + k * 32; if (v >= TV) v = TV - 1;
+      if (d2s) {
+        int ox = tx0 + v; if (ox >= a.Wo) ox = a.Wo - 1;
+        const int xx = ox % a.cW, yy = (ox / a.cW) % a.cH, zz = ox / (a.cW * a.cH);
+        const size_t fv = (((size_t)n * (2 * a.cD) + 2 * zz + (d2s_p >> 2)) * (2 * a.cH) + 2 * yy + ((d2s_p >> 1) & 1)) * (2 * a.cW) + 2 * xx + (d2s_p & 1);
+        pdy[k] = *reinterpret_cast<const float4*>(a.dy + fv * a.dyld + (dyvalid ? d2s_k : 0));
+      } else {
+        int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
+        oz = oz < a.Do ? oz : a.Do - 1; oy = oy < a.Ho ? oy : a.Ho - 1; ox = ox < a.Wo ? ox : a.Wo - 1;
+        pdy[k] = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.dyld + (dyvalid ? cdy : 0));
       }
     }
-    // ---- stage haloed x tile with the fused input transform ----
-    {
-      const int c = ci0 + 4 * sq;
-      const bool cvalid = c < a.Cin;
-      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
-      if (INMODE == MI355_IN_AFFINE_ACT && cvalid) {
-        sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
-        sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
-        if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + c);
+#pragma unroll
+    for (int k = 0; k < UPX; ++k) {
+      int hv = sv0 + k * 32; if (hv >= HV) hv = HV - 1;
+      const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+      int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
+      iz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
+      iy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
+      ix = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
+      px[k] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (xvalid ? cx : 0));
+    }
+  };
+  // mask / transform the prefetched registers of `tile` and write them to LDS
+  auto commit = [&](int tile) {
+    int n, tz0, ty0, tx0;
+    decode(tile, n, tz0, ty0, tx0);
+#pragma unroll
+    for (int k = 0; k < UPD; ++k) {
+      const int v = sv0 + k * 32;
+      if (v >= TV) continue;
+      bool ok;
+      if (d2s) ok = dyvalid && tx0 + v < a.Wo;
+      else {
+        const int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
+        ok = dyvalid && oz < a.Do && oy < a.Ho && ox < a.Wo;
       }
-      constexpr int UPX = (HV + 31) / 32;
+      *reinterpret_cast<float4*>(lds_dy + v * 32 + 4 * sq) = ok ? pdy[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
+    if (INMODE == MI355_IN_AFFINE_ACT && xvalid) {
+      sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + cx);
+      sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + cx);
+      if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + cx);
+    }
 #pragma unroll
-      for (int k0 = 0; k0 < UPX; k0 += 4) {
-        float4 ld[4];
+    for (int k = 0; k < UPX; ++k) {
+      const int hv = sv0 + k * 32;
+      if (hv >= HV) continue;
+      const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+      const int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
+      const bool ok = xvalid && iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi;
+      float4 v = px[k];
+      if (INMODE == MI355_IN_AFFINE_ACT) {
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
+        v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+      }
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(lds_x + hv * 32 + 4 * sq) = v;
+    }
+  };
+
+  // PIPE: keep tile t+1 in registers across the MFMA loop of tile t. It pays where the MFMA loop is short relative to the
+  // staging (1x1x1, stride 2); for 3x3x3 stride 1 the 64 extra live registers would halve the occupancy (7 accumulator tiles =
+  // 112 AGPRs), so there the tile is loaded (all loads in flight at once) and committed back to back.
+  constexpr bool PIPE = (KD == 1) || (STRIDE == 2);
+  // non-pipelined staging: batches of 4 units (loads of a batch in flight together), small live register set
+  auto stage_direct = [&](int tile) {
+    int n, tz0, ty0, tx0;
+    decode(tile, n, tz0, ty0, tx0);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          if (k0 + kk >= UPX) continue;
-          int hv = sv0 + (k0 + kk) * 32; if (hv >= HV) hv = HV - 1;
-          const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
-          int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
-          iz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
-          iy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
-          ix = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
-          ld[kk] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (cvalid ? c : 0));
-        }
+    for (int k0 = 0; k0 < UPD; k0 += 4) {
+      float4 ld[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          if (k0 + kk >= UPX) continue;
-          const int hv = sv0 + (k0 + kk) * 32;
-          if (hv >= HV) continue;
-          const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
-          const int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
-          const bool ok = cvalid && iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi;
-          float4 v = ld[kk];
-          if (INMODE == MI355_IN_AFFINE_ACT) {
-            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-            v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
-            v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
-          }
-          if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(lds_x + hv * 32 + 4 * sq) = v;
-        }
+      for (int kk = 0; kk < 4; ++kk) {
+        if (k0 + kk >= UPD) continue;
+        int v = sv0 + (k0 + kk) * 32; if (v >= TV) v = TV - 1;
+        int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
+        oz = oz < a.Do ? oz : a.Do - 1; oy = oy < a.Ho ? oy : a.Ho - 1; ox = ox < a.Wo ? ox : a.Wo - 1;
+        ld[kk] = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.dyld + (dyvalid ? cdy : 0));
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (k0 + kk >= UPD) continue;
+        const int v = sv0 + (k0 + kk) * 32;
+        if (v >= TV) continue;
+        const int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
+        const bool ok = dyvalid && oz < a.Do && oy < a.Ho && ox < a.Wo;
+        *reinterpret_cast<float4*>(lds_dy + v * 32 + 4 * sq) = ok ? ld[kk] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
+    if (INMODE == MI355_IN_AFFINE_ACT && xvalid) {
+      sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + cx);
+      sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + cx);
+      if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + cx);
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < UPX; k0 += 4) {
+      float4 ld[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (k0 + kk >= UPX) continue;
+        int hv = sv0 + (k0 + kk) * 32; if (hv >= HV) hv = HV - 1;
+        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+        int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
+        iz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
+        iy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
+        ix = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
+        ld[kk] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (xvalid ? cx : 0));
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (k0 + kk >= UPX) continue;
+        const int hv = sv0 + (k0 + kk) * 32;
+        if (hv >= HV) continue;
+        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+        const int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
+        const bool ok = xvalid && iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi;
+        float4 v = ld[kk];
+        if (INMODE == MI355_IN_AFFINE_ACT) {
+          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+          v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
+          v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+        }
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(lds_x + hv * 32 + 4 * sq) = v;
+      }
+    }
+  };
+  if (PIPE && t_begin < t_end) prefetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();                 // every wave is done reading the previous tile
+    if (PIPE) commit(tile); else stage_direct(tile);
     __syncthreads();
+    if (PIPE && tile + 1 < t_end) prefetch(tile + 1);
+    SCHED_BARRIER();                 // keep the prefetch loads above the MFMA loop
     // ---- K loop over voxel pairs ----
     constexpr int KSTEPS = TV / 2 / WV;
     const int ks0 = (T == 1) ? wave * KSTEPS : 0;

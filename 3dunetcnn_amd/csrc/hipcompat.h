@@ -36,6 +36,8 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 #define LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? 0 : -3)
 // pins the instruction order across this point (keeps software-prefetch loads ahead of the MFMA block they overlap with)
 #define SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// s_sleep: n * 64 clocks (n <= 127)
+#define SLEEP_64CLK(n) __builtin_amdgcn_s_sleep(n)
 // kernels that need more than the default 64 KiB dynamic LDS window (gfx950 has 160 KiB per CU)
 #define SET_MAX_DYN_LDS(kernel, bytes) \
   do { if ((bytes) > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); } while (0)
