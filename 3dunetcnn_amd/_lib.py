@@ -61,6 +61,9 @@ SIGNATURES = {
     "mi355_proj_workspace": (c_size_t, [POINTER(MiAct), c_int32]),
     "mi355_proj_bwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p, c_float, c_void_p, c_void_p, POINTER(MiAct), c_void_p, c_void_p, c_int32,
                                       c_void_p, c_size_t, c_void_p]),
+    "mi355_sw_accumulate": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                           c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "mi355_sw_normalize": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
     "mi355_dice_workspace": (c_size_t, [c_int32, c_int32, c_int64]),
     "mi355_dice_fwd_bwd": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32,
                                           c_float, c_float, c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),

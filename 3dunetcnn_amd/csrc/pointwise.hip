@@ -353,3 +353,37 @@ extern "C" int mi355_proj_bwd(const mi355_act* x, const float* in_scale, const f
   LAUNCH(proj_reduce_kernel, dim3(ceil_div(npairs, 128)), dim3(128), 0, stream, (const float*)ws, nb, npairs, cout * x->c, dw, dbias);
   return LAUNCH_CHECK();
 }
+
+// ---- sliding-window accumulation (MONAI SlidingWindowInferer; script_utils.py:290-293, training_utils.py:106-107) ----
+__global__ void sw_accumulate_kernel(const float* pred, const float* w, float* out, float* cnt, int C, int rd, int rh, int rw,
+                                     int D, int H, int W, int z0, int y0, int x0) {
+  const long long rv = (long long)rd * rh * rw;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < rv; idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % rw), y = (int)((idx / rw) % rh), z = (int)(idx / ((long long)rw * rh));
+    const int oz = z0 + z, oy = y0 + y, ox = x0 + x;
+    if (oz < 0 || oy < 0 || ox < 0 || oz >= D || oy >= H || ox >= W) continue;
+    const float wv = w[idx];
+    const size_t o = ((size_t)oz * H + oy) * W + ox;
+    cnt[o] += wv;
+    for (int c = 0; c < C; ++c) out[(size_t)c * D * H * W + o] += wv * pred[(size_t)c * rv + idx];
+  }
+}
+__global__ void sw_normalize_kernel(float* out, const float* cnt, int C, long long V) {
+  const long long total = (long long)C * V;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x)
+    out[idx] = out[idx] / cnt[idx % V];
+}
+
+extern "C" int mi355_sw_accumulate(const float* pred, const float* importance, float* out, float* count, int32_t c,
+                                   int32_t rd, int32_t rh, int32_t rw, int32_t D, int32_t H, int32_t W,
+                                   int32_t z0, int32_t y0, int32_t x0, void* stream) {
+  if (!pred || !importance || !out || !count || c <= 0 || rd <= 0 || rh <= 0 || rw <= 0 || D <= 0 || H <= 0 || W <= 0) return MI355_EINVAL;
+  LAUNCH(sw_accumulate_kernel, dim3(grid_for((long long)rd * rh * rw)), dim3(256), 0, stream, pred, importance, out, count, c, rd, rh, rw,
+         D, H, W, z0, y0, x0);
+  return LAUNCH_CHECK();
+}
+extern "C" int mi355_sw_normalize(float* out, const float* count, int32_t c, int64_t voxels, void* stream) {
+  if (!out || !count || c <= 0 || voxels <= 0) return MI355_EINVAL;
+  LAUNCH(sw_normalize_kernel, dim3(grid_for((long long)c * voxels)), dim3(256), 0, stream, out, count, c, (long long)voxels);
+  return LAUNCH_CHECK();
+}

@@ -276,6 +276,17 @@ class Backend:
                                       ctypes.byref(dxd) if dxd is not None else None, dw.data_ptr(), _p(dbias), cout, ws.data_ptr(),
                                       ws.numel() * 4, self.stream()), "proj_bwd")
 
+    # -- sliding-window inference ---------------------------------------------------------------------------------
+    def sw_accumulate(self, pred, importance, out, count, start):
+        """pred [C, rd, rh, rw], importance [rd, rh, rw], out [C, D, H, W], count [D, H, W] (fp32, contiguous)."""
+        c, rd, rh, rw = pred.shape
+        _, D, H, W = out.shape
+        check(self.lib.mi355_sw_accumulate(pred.data_ptr(), importance.data_ptr(), out.data_ptr(), count.data_ptr(), c, rd, rh, rw,
+                                           D, H, W, int(start[0]), int(start[1]), int(start[2]), self.stream()), "sw_accumulate")
+
+    def sw_normalize(self, out, count):
+        check(self.lib.mi355_sw_normalize(out.data_ptr(), count.data_ptr(), out.shape[0], count.numel(), self.stream()), "sw_normalize")
+
     # -- loss / optimizer ----------------------------------------------------------------------------------------
     def dice(self, logits, target, sigmoid=True, batch=False, squared_pred=False, smooth_nr=1e-5, smooth_dr=1e-5,
              want_grad=True, grad_scale=1.0):

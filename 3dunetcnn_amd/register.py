@@ -3,6 +3,7 @@
   * models:     getattr(unet3d.models.pytorch, model_name)(**kwargs)   (unet3d/models/build.py:9-13)
   * criteria:   getattr(unet3d.losses, name) first                     (unet3d/scripts/script_utils.py:61-77)
   * optimizers: getattr(torch.optim, name)                             (unet3d/scripts/script_utils.py:80-81)
+  * inferers:   getattr(monai.inferers, name)                          (unet3d/scripts/script_utils.py:290-293)
 
 so a config with {"model": {"name": "HipUNet3D", ...}, "loss": {"name": "HipDiceLoss", ...},
 "optimizer": {"name": "HipAdam", ...}} trains through unet3d.train.run_training as is. With replace=True the
@@ -41,4 +42,14 @@ def register(replace=False):
         done["losses"] = []
     torch.optim.HipAdam = HipAdam
     done["optim"] = ["HipAdam"]
+    try:
+        from .inferer import HipSlidingWindowInferer
+        inferers = importlib.import_module("monai.inferers")
+        inferers.HipSlidingWindowInferer = HipSlidingWindowInferer
+        done["inferers"] = ["HipSlidingWindowInferer"]
+        if replace:
+            inferers.SlidingWindowInferer = HipSlidingWindowInferer
+            done["inferers"].append("SlidingWindowInferer")
+    except ImportError:
+        done["inferers"] = []
     return done

@@ -170,6 +170,19 @@ int mi355_proj_bwd(const mi355_act* x, const float* in_scale, const float* in_sh
                    const float* dlogits_ncdhw, const mi355_act* dx, float* dw, float* dbias, int32_t cout,
                    void* ws, size_t ws_bytes, void* stream);
 
+/* ---- sliding-window inference ------------------------------------------------------------------ */
+/* Accumulation step of MONAI's SlidingWindowInferer, which the reference builds from config["inference"]
+ * (unet3d/scripts/script_utils.py:290-293) and calls as inferer(images, model) at unet3d/train/training_utils.py:106-107 and
+ * unet3d/predict/volumetric.py:147-148: for one window with origin (z0,y0,x0)
+ *   out[c, z0+z, y0+y, x0+x] += w[z,y,x] * pred[c,z,y,x] ;  count[z0+z, y0+y, x0+x] += w[z,y,x]
+ * pred: NCDHW window prediction [c][rd][rh][rw]; w: importance map [rd][rh][rw] (constant or Gaussian); out: [c][D][H][W];
+ * count: [D][H][W]. Windows are accumulated one launch at a time on the stream (deterministic, no atomics). */
+int mi355_sw_accumulate(const float* pred, const float* importance, float* out, float* count, int32_t c,
+                        int32_t rd, int32_t rh, int32_t rw, int32_t D, int32_t H, int32_t W,
+                        int32_t z0, int32_t y0, int32_t x0, void* stream);
+/* out[c][v] /= count[v] (final normalisation by the accumulated importance). */
+int mi355_sw_normalize(float* out, const float* count, int32_t c, int64_t voxels, void* stream);
+
 /* ---- Dice loss -------------------------------------------------------------------------------- */
 /* monai.losses.DiceLoss as configured by examples/brats2020/brats2020_config.json:112-116 (sigmoid=True,
  * include_background=True, smooth_nr=smooth_dr=1e-5, reduction="mean"), plus `batch` and `squared_pred`.
