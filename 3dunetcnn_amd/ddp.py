@@ -17,12 +17,13 @@ import torch.distributed as dist
 
 
 class GradientBucketReducer:
-    def __init__(self, model, bucket_bytes=25 << 20, process_group=None, average=True):
+    def __init__(self, model, bucket_bytes=25 << 20, process_group=None, average=True, reduce_single_rank=False):
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
         self.bucket_bytes = bucket_bytes
+        self.reduce_single_rank = reduce_single_rank     # issue the collectives even with one rank (exercises the RCCL path)
         self._works = []
         self._built_for = None
         model.grad_ready_callback = self._on_ready
@@ -76,7 +77,7 @@ class GradientBucketReducer:
         self._works = []
 
     def _on_ready(self, params):
-        if self.world == 1:
+        if self.world == 1 and not self.reduce_single_rank:
             return
         for p in params:
             bi = self.bucket_of[id(p)]

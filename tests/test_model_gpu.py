@@ -144,3 +144,39 @@ def test_cpu_input_fails_loudly():
     m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1])
     with pytest.raises(RuntimeError):
         m(torch.randn(1, 4, 8, 8, 8))
+
+
+def test_bucketed_allreduce_over_rccl_single_rank():
+    """The RCCL leg of the data-parallel path on the one GPU a test box has: a 1-rank `nccl` (= RCCL) process group, bucketed
+    asynchronous all-reduces launched from inside the explicit backward, optimizer waiting on them. (World size 2 is covered on
+    CPU over gloo in test_ddp_gloo.py; the 8-GPU run is the driver's.)"""
+    import socket
+    import torch.distributed as dist
+    ddp = importlib.import_module("3dunetcnn_amd.ddp")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        torch.manual_seed(9)
+        kw = dict(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1, 2])
+        m = unet.HipUNet3D(**kw).cuda().eval()
+        m.flatten_parameters()
+        red = ddp.GradientBucketReducer(m, bucket_bytes=64 << 10, reduce_single_rank=True)
+        red.broadcast_parameters(0)
+        x, y = R.synthetic_case(2, 4, (32, 32, 32), 3)
+        crit = losses.HipDiceLoss(sigmoid=True)
+        opt = optim.HipAdam(m.parameters(), lr=1e-3)
+        sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+        opt.zero_grad(set_to_none=True)
+        loss = crit(m(x.cuda()), y.cuda())
+        loss.backward()
+        assert len(red._works) == len(red.buckets) >= 3          # every bucket was reduced, launched during backward
+        red.wait()
+        lref = O.dice_loss(R.unet3d_forward(sd, x, (1, 1, 2)), y)
+        lref.backward()
+        for k, p in m.named_parameters():
+            assert C.rel_err(p.grad, sd[k].grad) < TOL, k        # average over 1 rank == the gradient
+        opt.step()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
