@@ -161,14 +161,15 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
   // 112 AGPRs), so there the tile is loaded (all loads in flight at once) and committed back to back.
   constexpr bool PIPE = (KD == 1) || (STRIDE == 2);
   // non-pipelined staging: batches of 4 units (loads of a batch in flight together), small live register set
+  constexpr int SB = 6;   // staging batch: 6 loads in flight per thread (8 would cost a wave of occupancy)
   auto stage_direct = [&](int tile) {
     int n, tz0, ty0, tx0;
     decode(tile, n, tz0, ty0, tx0);
 #pragma unroll
-    for (int k0 = 0; k0 < UPD; k0 += 4) {
-      float4 ld[4];
+    for (int k0 = 0; k0 < UPD; k0 += SB) {
+      float4 ld[SB];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int kk = 0; kk < SB; ++kk) {
         if (k0 + kk >= UPD) continue;
         int v = sv0 + (k0 + kk) * 32; if (v >= TV) v = TV - 1;
         int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
         ld[kk] = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.dyld + (dyvalid ? cdy : 0));
       }
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int kk = 0; kk < SB; ++kk) {
         if (k0 + kk >= UPD) continue;
         const int v = sv0 + (k0 + kk) * 32;
         if (v >= TV) continue;
@@ -193,10 +194,10 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
       if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + cx);
     }
 #pragma unroll
-    for (int k0 = 0; k0 < UPX; k0 += 4) {
-      float4 ld[4];
+    for (int k0 = 0; k0 < UPX; k0 += SB) {
+      float4 ld[SB];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int kk = 0; kk < SB; ++kk) {
         if (k0 + kk >= UPX) continue;
         int hv = sv0 + (k0 + kk) * 32; if (hv >= HV) hv = HV - 1;
         const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
         ld[kk] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (xvalid ? cx : 0));
       }
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int kk = 0; kk < SB; ++kk) {
         if (k0 + kk >= UPX) continue;
         const int hv = sv0 + (k0 + kk) * 32;
         if (hv >= HV) continue;
