@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--model", default="unet3d", choices=["unet3d", "dynunet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="disable the per-launch HIP events (roofline -> null)")
+    ap.add_argument("--no-precision-modes", action="store_true",
+                    help="skip the short extra runs of the opt-in conv arithmetic modes (reported under precision_modes, N=1 only)")
     return ap.parse_args()
 
 
@@ -118,6 +120,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.set_num_threads(max(1, (os.cpu_count() or 1) // max(world, 1)))      # host-side torch ops: no oversubscription across ranks
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -222,6 +225,23 @@ def main():
                                       f"fwd + sigmoid-Dice + bwd + Adam" + (", Dropout3d on" if args.model == "unet3d" else ""),
                           "conv_arithmetic": ARITH[args.precision], "global_batch": world * B, "parallelism": f"dp{world}"},
                "final_loss": round(loss_val, 6), "roofline": roofline}
+        if world == 1 and args.precision == "fp32" and not args.no_precision_modes:
+            # informational: the same step with the opt-in arithmetic modes of the 3x3x3 stride-1 convs;
+            # `value` above is the exact-fp32 number
+            modes = {}
+            for pm in ("bf16x6", "bf16x3", "bf16"):
+                be.set_precision(pm)
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                dtm = (time.perf_counter() - t1) / 3
+                modes[pm] = {"volumes_per_s": round(B / dtm, 3), "ms_per_step": round(dtm * 1e3, 2), "conv_arithmetic": ARITH[pm]}
+            be.set_precision("fp32")
+            out["precision_modes"] = modes
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S)
         print(json.dumps(out), flush=True)
