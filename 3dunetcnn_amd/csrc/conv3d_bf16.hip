@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_bf16(ConvBArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           bnext[p][nt] = a.wp[((size_t)(tl * CQ8 + cq0 + 2 * jnx) * NS + p) * a.CoutP + co_base + nt * 32 + li];
+      SCHED_BARRIER();     // the B loads of the NEXT step stay above this step's MFMAs (the scheduler otherwise sinks them to their use)
       const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
       const int toff = ((dz * HY + dy) * HX + dx) * VSQ + 2 * j;
       uint4 af[MT][NS];
