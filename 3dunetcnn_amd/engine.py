@@ -34,6 +34,7 @@ class HipNetBase(nn.Module):
 
     def _init_engine(self):
         self._be = None
+        self.conv_precision = None   # None: the backend's setting; "fp32" | "bf16x6" | "bf16x3" | "bf16": per-module override
         self._flat = None          # flat parameter buffer (views are the nn.Parameters)
         self._flat_grad = None
         self._packed = {}          # id(param) -> [version, {mode: packed tensor}, data_ptr]
@@ -107,11 +108,15 @@ class HipNetBase(nn.Module):
     def _begin_forward(self):
         be = self._be = self._be or _ops.default_backend()
         self._packs_dirty_local = self._packs_dirty
+        self._saved_precision = be.precision
+        if self.conv_precision is not None:
+            be.set_precision(self.conv_precision)
         return be
 
     def _end_forward(self):
         self._packs_dirty = False
         self._packs_dirty_local = False
+        self._be.precision = self._saved_precision
 
     def _gslice(self, p):
         o = self._goff[id(p)]
@@ -141,7 +146,13 @@ class HipNetBase(nn.Module):
             self.backward_start_callback(gbuf)
         self._goff = {id(p): o for p, o in zip(ps, self._offsets)}
         self._packs_dirty_local = False
-        dx_t = self._backward_impl_body(be, saved, dlogits, need_dx)
+        saved_precision = be.precision
+        if self.conv_precision is not None:
+            be.set_precision(self.conv_precision)
+        try:
+            dx_t = self._backward_impl_body(be, saved, dlogits, need_dx)
+        finally:
+            be.precision = saved_precision
         self._flush_ready()
         grads = []
         for p, o in zip(ps, self._offsets):

@@ -18,17 +18,21 @@ def register(replace=False):
     from .dynunet import HipDynUNet
     from .losses import HipDiceLoss
     from .optim import HipAdam
-    from .unet import HipUNet3D
+    from .unet import HipAutocastUNet, HipAutoImplantUNet, HipUNet3D
     done = {}
     try:
         models = importlib.import_module("unet3d.models.pytorch")
         models.HipUNet3D = HipUNet3D
         models.HipDynUNet = HipDynUNet
-        done["models"] = ["HipUNet3D", "HipDynUNet"]
+        models.HipAutocastUNet = HipAutocastUNet
+        models.HipAutoImplantUNet = HipAutoImplantUNet
+        done["models"] = ["HipUNet3D", "HipDynUNet", "HipAutocastUNet", "HipAutoImplantUNet"]
         if replace:
             models.UNet3D = HipUNet3D
             models.DynUNet = HipDynUNet
-            done["models"] += ["UNet3D", "DynUNet"]
+            models.AutocastUNet = HipAutocastUNet
+            models.AutoImplantUNet = HipAutoImplantUNet
+            done["models"] += ["UNet3D", "DynUNet", "AutocastUNet", "AutoImplantUNet"]
     except ImportError:
         done["models"] = []
     try:

@@ -384,3 +384,25 @@ class HipUNet3D(HipNetBase):
                            max(-off[2], 0):max(-off[2], 0) + sub.shape[3], :]
         dst.copy_(sub)
         return out, win
+
+
+class HipAutocastUNet(HipUNet3D):
+    """Drop-in for the reference's AutocastUNet (unet3d/models/pytorch/segmentation/unet.py:53-58), which runs UNet3D.forward
+    under torch.cuda.amp.autocast (fp16 convolutions with fp32 accumulate, norms in fp32). MI355X equivalent: the 3x3x3
+    convolutions take the bf16 matrix path (operands rounded to bf16 while staged, fp32 accumulate; bf16 has fp32's exponent
+    range, so no GradScaler is needed), everything else stays fp32 -- BASELINE configs[2]'s "bf16 mixed precision"."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.conv_precision = "bf16"
+
+
+class HipAutoImplantUNet(HipUNet3D):
+    """Drop-in for the reference's AutoImplantUNet (unet.py:61-70): forward returns y - x, `.test(x)` the plain network output
+    (unet3d/predict/utils.py:46-47 prefers `.test` when present)."""
+
+    def forward(self, x):
+        return super().forward(x) - x
+
+    def test(self, x):
+        return super().forward(x)

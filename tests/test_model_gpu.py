@@ -180,3 +180,41 @@ def test_bucketed_allreduce_over_rccl_single_rank():
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
+
+
+def test_autocast_unet_bf16_mixed_precision():
+    """HipAutocastUNet (reference AutocastUNet, unet.py:53-58; BASELINE configs[2] 'bf16 mixed precision'): 3x3x3 convs on the
+    bf16 matrix path, fp32 everywhere else. Tolerance is bf16's (8 mantissa bits): logits 3e-2, loss 1e-2 vs the fp32 oracle;
+    a few optimizer steps must reduce the loss like the fp32 run does."""
+    torch.manual_seed(11)
+    kw = dict(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1, 2])
+    m = unet.HipAutocastUNet(**kw).cuda().eval()
+    assert m.conv_precision == "bf16"
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x, y = R.synthetic_case(2, 4, (32, 32, 32), 3)
+    ref = R.unet3d_forward(sd, x, (1, 1, 2))
+    lref = O.dice_loss(ref, y)
+    crit = losses.HipDiceLoss(sigmoid=True)
+    out = m(x.cuda())
+    loss = crit(out, y.cuda())
+    assert 1e-5 < C.rel_err(out, ref.detach()) < 3e-2          # really the bf16 path (not bit-close), within bf16 tolerance
+    assert abs(float(loss) - float(lref)) / float(lref) < 1e-2
+    be = importlib.import_module("3dunetcnn_amd.ops").default_backend()
+    assert be.precision == 0                                    # the per-module override does not leak into the backend
+    opt = optim.HipAdam(m.parameters(), lr=1e-3)
+    first = None
+    for _ in range(8):
+        opt.zero_grad()
+        l = crit(m(x.cuda()), y.cuda())
+        l.backward()
+        opt.step()
+        first = float(l) if first is None else first
+    assert float(l) < first
+
+
+def test_auto_implant_unet_contract():
+    torch.manual_seed(2)
+    m = unet.HipAutoImplantUNet(n_features=4, n_outputs=4, base_width=8, encoder_blocks=[1, 1]).cuda().eval()
+    x = torch.randn(1, 4, 16, 16, 16).cuda()
+    with torch.no_grad():
+        assert torch.allclose(m(x), m.test(x) - x)

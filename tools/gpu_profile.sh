@@ -10,10 +10,10 @@ for w in $what; do
 case $w in
 tests) timeout 1500 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $out/pytest_gpu.log; tail -3 $out/pytest_gpu.log;;
 bench) timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 600 $out/bench.json;;
-trace) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $root/$out/trace -o bench -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $root/$out/trace.log 2>&1); ls $out/trace | head;;
+trace) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $root/$out/trace -o bench -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-precision-modes > $root/$out/trace.log 2>&1); ls $out/trace | head;;
 pmc)
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $root/$out/pmc_fetch -o bench -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events > $root/$out/pmc_fetch.log 2>&1)
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $root/$out/pmc_write -o bench -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events > $root/$out/pmc_write.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $root/$out/pmc_fetch -o bench -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-precision-modes --no-kernel-events > $root/$out/pmc_fetch.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $root/$out/pmc_write -o bench -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-precision-modes --no-kernel-events > $root/$out/pmc_write.log 2>&1)
   ls $out/pmc_fetch $out/pmc_write | head;;
 esac
 done
