@@ -287,6 +287,41 @@ class Backend:
     def sw_normalize(self, out, count):
         check(self.lib.mi355_sw_normalize(out.data_ptr(), count.data_ptr(), out.shape[0], count.numel(), self.stream()), "sw_normalize")
 
+    # -- steps either side of the network ---------------------------------------------------------------------------
+    def postprocess(self, logits, activation, threshold, labels, hierarchy, sum_then_threshold=False, want_probs=True, want_labels=True):
+        """logits [C, D, H, W] fp32 (one sample). Returns (probs or None, int16 label map or None)."""
+        assert logits.is_contiguous() and logits.dtype == torch.float32 and logits.dim() == 4
+        c, vox = logits.shape[0], logits[0].numel()
+        probs = torch.empty_like(logits) if want_probs else None
+        lm = torch.empty(logits.shape[1:], dtype=torch.int16, device=logits.device) if want_labels else None
+        lab = torch.as_tensor(list(labels), dtype=torch.int16, device=logits.device) if want_labels else None
+        act = {None: 0, "none": 0, "sigmoid": 1, "softmax": 2}[activation]
+        check(self.lib.mi355_postprocess(logits.data_ptr(), c, vox, act, float(threshold), _p(lab), int(bool(hierarchy)),
+                                         int(bool(sum_then_threshold)), _p(probs), _p(lm), self.stream()), "postprocess")
+        return probs, lm
+
+    def one_hot(self, label_map, groups):
+        """label_map [D, H, W] fp32; groups: list of lists of label values. Returns uint8 [len(groups), D, H, W]."""
+        assert label_map.is_contiguous() and label_map.dtype == torch.float32
+        vals = torch.tensor([float(v) for g in groups for v in g], dtype=torch.float32, device=label_map.device)
+        offs, o = [0], 0
+        for g in groups:
+            o += len(g)
+            offs.append(o)
+        offs = torch.tensor(offs, dtype=torch.int32, device=label_map.device)
+        out = torch.empty(len(groups), *label_map.shape, dtype=torch.uint8, device=label_map.device)
+        check(self.lib.mi355_one_hot(label_map.data_ptr(), label_map.numel(), vals.data_ptr(), offs.data_ptr(), len(groups), out.data_ptr(),
+                                     self.stream()), "one_hot")
+        return out
+
+    def zscore(self, x):
+        """x [C, D, H, W] fp32 -> per-channel (x - mean) / std."""
+        assert x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 4
+        y = torch.empty_like(x)
+        ws = self.ws(self.lib.mi355_zscore_workspace(x.shape[0]))
+        check(self.lib.mi355_zscore(x.data_ptr(), y.data_ptr(), x.shape[0], x[0].numel(), ws.data_ptr(), ws.numel() * 4, self.stream()), "zscore")
+        return y
+
     # -- loss / optimizer ----------------------------------------------------------------------------------------
     def dice(self, logits, target, sigmoid=True, batch=False, squared_pred=False, smooth_nr=1e-5, smooth_dr=1e-5,
              want_grad=True, grad_scale=1.0):

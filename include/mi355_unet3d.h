@@ -183,6 +183,24 @@ int mi355_sw_accumulate(const float* pred, const float* importance, float* out, 
 /* out[c][v] /= count[v] (final normalisation by the accumulated importance). */
 int mi355_sw_normalize(float* out, const float* count, int32_t c, int64_t voxels, void* stream);
 
+/* ---- steps either side of the network, on the device ---------------------- */
+/* After the network: activation of unet3d/predict/volumetric.py:151-156 (activation 0 none | 1 sigmoid | 2 softmax over c) and the
+ * label-map decode of unet3d/utils/one_hot.py:44-118 in one pass over the logits [c][voxels] (one sample, NCDHW):
+ * hierarchy != 0 -> convert_one_hot_to_label_map_using_hierarchy (:101-118); else threshold mask (any > thr, or sum > thr when
+ * sum_then_threshold) + argmax (:68-92). probs ([c][voxels]) and label_map (int16 [voxels]) are optional outputs; labels: device
+ * int16[c]. c <= 16. */
+int mi355_postprocess(const float* logits, int32_t c, int64_t voxels, int32_t activation, float threshold, const int16_t* labels,
+                      int32_t hierarchy, int32_t sum_then_threshold, float* probs, int16_t* label_map, void* stream);
+/* Before the network: compile_one_hot_encoding (unet3d/utils/one_hot.py:7-37, used by transforms/one_hot.py:7-16): channel g of
+ * out (uint8 [c][voxels]) is 1 where round(label_map) is close (atol 1e-8, rtol 1e-5) to any of the values
+ * label_values[group_offsets[g] .. group_offsets[g+1]) (device arrays). */
+int mi355_one_hot(const float* label_map, int64_t voxels, const float* label_values, const int32_t* group_offsets, int32_t c,
+                  uint8_t* out, void* stream);
+/* MONAI NormalizeIntensityD(channel_wise=True, nonzero=False) (unet3d/datasets/segmentation.py:77-86; brats2020_config.json:140-144):
+ * y[c][v] = (x[c][v] - mean_c) / std_c with the population std, std 0 -> 1. x, y: [c][voxels] (one sample). */
+size_t mi355_zscore_workspace(int32_t c);
+int mi355_zscore(const float* x, float* y, int32_t c, int64_t voxels, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- Dice loss -------------------------------------------------------------------------------- */
 /* monai.losses.DiceLoss as configured by examples/brats2020/brats2020_config.json:112-116 (sigmoid=True,
  * include_background=True, smooth_nr=smooth_dr=1e-5, reduction="mean"), plus `batch` and `squared_pred`.
