@@ -39,12 +39,14 @@ class HipAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
             be = self._be or _ops.default_backend()
-            st = self.state.setdefault("_group%d" % id(group), {})
+            # state of the fused path lives under a string key (kept verbatim by Optimizer.state_dict / load_state_dict), indexed
+            # by the group's position so that a checkpoint restores into a freshly built optimizer
+            st = self.state.setdefault("_flat_group%d" % gi, {})
             st["step"] = st.get("step", 0) + 1
             b1, b2 = group["betas"]
             args = (float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], st["step"], self.grad_scale)
@@ -52,6 +54,8 @@ class HipAdam(torch.optim.Optimizer):
             grun = _contiguous_run([p.grad for p in ps]) if prun else None
             if prun and grun and prun[1] == grun[1]:
                 n = prun[1]
+                if "flat_m" in st and st["flat_m"].device != ps[0].device:
+                    st["flat_m"], st["flat_v"] = st["flat_m"].to(ps[0].device), st["flat_v"].to(ps[0].device)
                 if "flat_m" not in st or st["flat_m"].numel() != n:
                     st["flat_m"] = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
                     st["flat_v"] = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
