@@ -25,11 +25,12 @@ class MiConvDesc(Structure):
                 ("out_chscale", c_void_p),
                 ("off_z", c_int32), ("off_y", c_int32), ("off_x", c_int32),
                 ("out_d", c_int32), ("out_h", c_int32), ("out_w", c_int32),
-                ("in_slope", c_void_p), ("out_mode", c_int32), ("precision", c_int32)]
+                ("in_slope", c_void_p), ("out_mode", c_int32), ("precision", c_int32), ("wformat", c_int32)]
 
 
 IN_PLAIN, IN_AFFINE_ACT, IN_ZERO_INSERT, IN_S2D = 0, 1, 2, 3
 OUT_PLAIN, OUT_D2S = 0, 1
+W_PACKED, W_OIDHW4 = 0, 1
 PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_BF16 = 0, 1, 2, 3
 PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "bf16": PREC_BF16}
 

@@ -1,0 +1,283 @@
+// First-layer kernels: 3x3x3 stride-1 Conv3d with FOUR input channels (the 4 MRI modalities of BASELINE.json's
+// "128^3 x 4ch" layer: UNet3D encoder block 0 conv1, unet3d/models/pytorch/classification/myronenko.py:17-21 via resnet.py:12-17;
+// DynUNet input_block.conv1), forward and weight gradient, exact fp32 MFMA.
+//
+// The generic kernels pad the input channels to 8 (forward) / 32 (wgrad) per tap, i.e. run 2x / 8x the useful MFMAs on the
+// layer whose algorithmic intensity is lowest (48 flop/B). Here the GEMM K (forward) / N (wgrad) index is the fused (tap, ci)
+// pair: 27*4 = 108 values, so
+//   forward: 54 v_mfma_f32_32x32x2_f32 per 32-voxel x 32-channel tile instead of 108;
+//   wgrad:   4 MFMAs per voxel pair (one (tap,ci) tile of 32 per wave) instead of 27.
+// Both stage the haloed 4-channel input tile in LDS as one float4 per voxel (normalised + activated on the way in); an MFMA
+// operand is ONE float per lane, so the per-lane (tap, ci) gather is a plain ds_read_b32 whose tap offset is an instruction
+// immediate (forward) or a per-lane constant (wgrad) -- no address arithmetic in the inner loops.
+// The forward reads the UNPACKED OIDHW weight (3456 floats per 32 output channels, staged to LDS in [(tap,ci)][co] order).
+#include "hipcompat.h"
+#include "../../include/mi355_unet3d.h"
+
+struct C4Args {
+  const float* x; int xld;
+  const float* w;                  // forward: OIDHW [Cout][4][27]
+  float* y; int yld;
+  const float* res; int resld;
+  const float* in_scale; const float* in_shift; float slope; const float* in_slope;
+  const float* out_chscale; const float* bias;
+  const float* dy; int dyld; float* ws;      // wgrad
+  int N, D, H, W, Cout;
+  int yD, yH, yW, offz, offy, offx;
+  int tilesZ, tilesY, tilesX, coTiles, ntiles, splits;
+};
+
+__device__ __forceinline__ float4 c4_prologue(float4 v, const float4& sc, const float4& sh, const float4& sl) {
+  v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+  v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
+  v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+  return v;
+}
+
+// stage the haloed tile (HZ x HY x HX voxels x 4 channels) of sample n at origin (z0-1, y0-1, x0-1) into lds_x[hv] (float4)
+template <int HZ, int HY, int HX, int INMODE, int NTHREADS>
+__device__ __forceinline__ void c4_stage_x(const C4Args& a, float4* lds_x, int n, int z0, int y0, int x0, int tid) {
+  constexpr int HV = HZ * HY * HX;
+  constexpr int UP = (HV + NTHREADS - 1) / NTHREADS;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f), sl = make_float4(a.slope, a.slope, a.slope, a.slope);
+  if (INMODE == MI355_IN_AFFINE_ACT) {
+    sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * 4);
+    sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * 4);
+    if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope);
+  }
+  float4 ld[UP];
+#pragma unroll
+  for (int k = 0; k < UP; ++k) {          // all loads first, from clamped always-valid addresses
+    int hv = tid + k * NTHREADS; if (hv >= HV) hv = HV - 1;
+    int iz = z0 - 1 + hv / (HY * HX), iy = y0 - 1 + (hv / HX) % HY, ix = x0 - 1 + hv % HX;
+    iz = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1);
+    iy = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1);
+    ix = ix < 0 ? 0 : (ix < a.W ? ix : a.W - 1);
+    ld[k] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld);
+  }
+#pragma unroll
+  for (int k = 0; k < UP; ++k) {
+    const int hv = tid + k * NTHREADS;
+    if (hv >= HV) continue;
+    const int iz = z0 - 1 + hv / (HY * HX), iy = y0 - 1 + (hv / HX) % HY, ix = x0 - 1 + hv % HX;
+    const bool ok = iz >= 0 && iy >= 0 && ix >= 0 && iz < a.D && iy < a.H && ix < a.W;
+    float4 v = ld[k];
+    if (INMODE == MI355_IN_AFFINE_ACT) v = c4_prologue(v, sc, sh, sl);
+    lds_x[hv] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// ---- forward: 4x8x8 output voxels x 32 output channels per workgroup; 4 waves x 2 M tiles ----
+template <int INMODE>
+__global__ __launch_bounds__(256) void conv3d_c4_fwd(C4Args a) {
+  constexpr int TZ = 4, TY = 8, TX = 8, HZ = 6, HY = 10, HX = 10, HV = HZ * HY * HX, MT = 2;
+  __shared__ float4 lds_x[HV];            // 9600 B
+  __shared__ float lds_w[108 * 33];       // [(tap*4+ci)][co], row stride 33: the k-fast staging writes are conflict-free
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+  int b = blockIdx.x;
+  const int cot = b % a.coTiles; b /= a.coTiles;
+  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+  const int tz0 = (b % a.tilesZ) * TZ; b /= a.tilesZ;
+  const int n = b;
+  const int co0 = cot * 32;
+  for (int i = tid; i < 108 * 32; i += 256) {
+    const int co = i / 108, k = i % 108;           // consecutive threads walk k (contiguous in OIDHW: [co][ci][tap])
+    const int ci = k / 27, tap = k % 27;
+    lds_w[(tap * 4 + ci) * 33 + co] = (co0 + co < a.Cout) ? a.w[((size_t)(co0 + co) * 4 + ci) * 27 + tap] : 0.f;
+  }
+  c4_stage_x<HZ, HY, HX, INMODE, 256>(a, lds_x, n, tz0, ty0, tx0, tid);
+  __syncthreads();
+  const float* xs = reinterpret_cast<const float*>(lds_x);
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int tv = (wave * MT + mt) * 32 + li;
+    abase[mt] = ((tv / (TY * TX)) * HY * HX + ((tv / TX) % TY) * HX + tv % TX) * 4 + half;     // + channel (k parity) via half
+  }
+  const int bbase = half * 33 + li;
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+  // k = 2s + half = tap*4 + ci  ->  tap = s >> 1 (same for both halves), ci = 2*(s & 1) + half: every offset below is an immediate
+#pragma unroll
+  for (int s = 0; s < 54; ++s) {
+    const int tap = s >> 1;
+    const int toff = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 4 + 2 * (s & 1);
+    const float bv = lds_w[bbase + s * 66];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA_32x32x2(xs[abase[mt] + toff], bv, acc[mt]);
+  }
+  const int co = co0 + li;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int tv = (wave * MT + mt) * 32 + row;
+      const int oz = tz0 + tv / (TY * TX), oy = ty0 + (tv / TX) % TY, ox = tx0 + tv % TX;
+      if (oz >= a.D || oy >= a.H || ox >= a.W || co >= a.Cout) continue;
+      const int sz = oz + a.offz, sy = oy + a.offy, sx = ox + a.offx;
+      if (sz < 0 || sy < 0 || sx < 0 || sz >= a.yD || sy >= a.yH || sx >= a.yW) continue;
+      const size_t ovox = (((size_t)n * a.D + oz) * a.H + oy) * a.W + ox;
+      const size_t svox = (((size_t)n * a.yD + sz) * a.yH + sy) * a.yW + sx;
+      float v = acc[mt][r];
+      if (a.bias) v += a.bias[co];
+      if (a.res) v += a.res[ovox * a.resld + co];
+      if (a.out_chscale) v *= a.out_chscale[(size_t)n * a.Cout + co];
+      a.y[svox * a.yld + co] = v;
+    }
+  }
+}
+
+// ---- wgrad: one 32-output-channel tile per workgroup column; wave w owns (tap, ci) columns 32w .. 32w+31 ----
+template <int INMODE>
+__global__ __launch_bounds__(256) void conv3d_c4_wgrad(C4Args a) {
+  constexpr int TZ = 4, TY = 4, TX = 8, TV = TZ * TY * TX, HZ = 6, HY = 6, HX = 10, HV = HZ * HY * HX;
+  __shared__ float4 lds_x[HV];            // 5760 B
+  __shared__ float lds_dy[TV * 32];       // 16384 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+  const int split = blockIdx.x, cot = blockIdx.y, co0 = cot * 32;
+  const int jcol = wave * 32 + li;                      // (tap, ci) column of this lane
+  const int tap = jcol >> 2 < 27 ? jcol >> 2 : 26, ci = jcol & 3;
+  const int boff = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 4 + ci;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int per = (a.ntiles + a.splits - 1) / a.splits;
+  const int t_begin = split * per, t_end = t_begin + per < a.ntiles ? t_begin + per : a.ntiles;
+  const int sq = tid & 7, sv0 = tid >> 3;
+  const int cdy = co0 + 4 * sq;
+  const bool dyvalid = cdy < a.Cout;
+  const float* xs = reinterpret_cast<const float*>(lds_x);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int b = tile;
+    const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+    const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+    const int tz0 = (b % a.tilesZ) * TZ; b /= a.tilesZ;
+    const int n = b;
+    __syncthreads();
+    {
+      float4 ld[TV / 32];
+#pragma unroll
+      for (int k = 0; k < TV / 32; ++k) {
+        const int v = sv0 + k * 32;
+        int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
+        oz = oz < a.D ? oz : a.D - 1; oy = oy < a.H ? oy : a.H - 1; ox = ox < a.W ? ox : a.W - 1;
+        ld[k] = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.D + oz) * a.H + oy) * a.W + ox) * a.dyld + (dyvalid ? cdy : 0));
+      }
+#pragma unroll
+      for (int k = 0; k < TV / 32; ++k) {
+        const int v = sv0 + k * 32;
+        const int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
+        const bool ok = dyvalid && oz < a.D && oy < a.H && ox < a.W;
+        *reinterpret_cast<float4*>(lds_dy + v * 32 + 4 * sq) = ok ? ld[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    c4_stage_x<HZ, HY, HX, INMODE, 256>(a, lds_x, n, tz0, ty0, tx0, tid);
+    __syncthreads();
+#pragma unroll 8
+    for (int ks = 0; ks < TV / 2; ++ks) {
+      const int v = 2 * ks + half;
+      const int xb = ((v / (TY * TX)) * HY * HX + ((v / TX) % TY) * HX + v % TX) * 4;
+      acc = MFMA_32x32x2(lds_dy[v * 32 + li], xs[xb + boff], acc);
+    }
+  }
+  // partial tile -> ws[cot][split][32 co][128 (tap,ci) columns] (coalesced: the 32 lanes of a half write 128 contiguous bytes)
+  float* dst = a.ws + ((size_t)cot * a.splits + split) * 4096;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    dst[row * 128 + jcol] = acc[r];
+  }
+}
+
+// deterministic split reduction: dw[co][ci][tap] = sum over splits. One workgroup per 32 consecutive (co, column) elements:
+// 8 split-groups x 32 elements, 4 independent partial sums per thread, groups combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void conv3d_c4_wgrad_reduce(const float* ws, float* dw, int Cout, int splits) {
+  __shared__ float part[8][32];
+  const int cot = blockIdx.x >> 7;
+  const int e = (blockIdx.x & 127) * 32 + (threadIdx.x & 31);
+  const int grp = threadIdx.x >> 5;
+  const float* src = ws + (size_t)cot * splits * 4096 + e;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int k = grp;
+  for (; k + 24 < splits; k += 32) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] += src[(size_t)(k + 8 * u) * 4096];
+  }
+  for (int u = 0; k < splits; k += 8, ++u) acc[u & 3] += src[(size_t)k * 4096];
+  part[grp][threadIdx.x & 31] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float s = part[0][threadIdx.x];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) s += part[g][threadIdx.x];
+    const int col = e & 127, co = cot * 32 + (e >> 7);
+    if (col < 108 && co < Cout) dw[((size_t)co * 4 + (col & 3)) * 27 + (col >> 2)] = s;
+  }
+}
+
+static void c4_fill(C4Args& a, const mi355_act* x, const mi355_conv_desc* d) {
+  memset(&a, 0, sizeof(a));
+  a.x = (const float*)x->p; a.xld = x->ld;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope;
+  a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w;
+}
+
+int mi355_conv3d_c4_ok(const mi355_act* x, const mi355_conv_desc* d) {
+  return x && d && x->c == 4 && d->kd == 3 && d->stride == 1 && d->pad == 1 && d->out_mode == MI355_OUT_PLAIN &&
+         (d->in_mode == MI355_IN_PLAIN || d->in_mode == MI355_IN_AFFINE_ACT);
+}
+
+// wp = the UNPACKED OIDHW weight
+int mi355_conv3d_c4_fwd_impl(const mi355_act* x, const float* w, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
+  if (!mi355_conv3d_c4_ok(x, d) || d->out_d != x->d || d->out_h != x->h || d->out_w != x->w) return MI355_EUNSUPPORTED;
+  C4Args a; c4_fill(a, x, d);
+  a.w = w; a.y = (float*)y->p; a.yld = y->ld; a.res = d->residual; a.resld = d->residual_ld;
+  a.out_chscale = d->out_chscale; a.bias = d->bias; a.Cout = y->c;
+  a.yD = y->d; a.yH = y->h; a.yW = y->w; a.offz = d->off_z; a.offy = d->off_y; a.offx = d->off_x;
+  if (a.res && a.resld < a.Cout) return MI355_EINVAL;
+  a.tilesZ = ceil_div(a.D, 4); a.tilesY = ceil_div(a.H, 8); a.tilesX = ceil_div(a.W, 8); a.coTiles = ceil_div(a.Cout, 32);
+  const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
+  if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_c4_fwd<MI355_IN_PLAIN>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  else LAUNCH((conv3d_c4_fwd<MI355_IN_AFFINE_ACT>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  return LAUNCH_CHECK();
+}
+
+static int c4_wgrad_plan(const mi355_act* x, const mi355_act* dy, C4Args& a) {
+  a.tilesZ = ceil_div(x->d, 4); a.tilesY = ceil_div(x->h, 4); a.tilesX = ceil_div(x->w, 8); a.coTiles = ceil_div(dy->c, 32);
+  const long long nt = (long long)x->n * a.tilesZ * a.tilesY * a.tilesX;
+  if (nt <= 0 || nt > 0x7fffffffLL) return 0;
+  a.ntiles = (int)nt;
+  int splits = ceil_div(1024, a.coTiles);
+  const int max_splits = a.ntiles >= 8 ? a.ntiles / 8 : 1;
+  if (splits > max_splits) splits = max_splits;
+  const int per = ceil_div(a.ntiles, splits);
+  a.splits = ceil_div(a.ntiles, per);
+  return 1;
+}
+
+size_t mi355_conv3d_c4_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  C4Args a; memset(&a, 0, sizeof(a));
+  if (!mi355_conv3d_c4_ok(x, d) || !c4_wgrad_plan(x, dy, a)) return 0;
+  return (size_t)a.coTiles * a.splits * 4096 * sizeof(float);
+}
+
+int mi355_conv3d_c4_wgrad_impl(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d,
+                               void* ws, size_t ws_bytes, void* stream) {
+  if (!mi355_conv3d_c4_ok(x, d) || x->d != dy->d || x->h != dy->h || x->w != dy->w) return MI355_EUNSUPPORTED;
+  C4Args a; c4_fill(a, x, d);
+  if (!c4_wgrad_plan(x, dy, a)) return MI355_EINVAL;
+  if (ws_bytes < (size_t)a.coTiles * a.splits * 4096 * sizeof(float)) return MI355_EWORKSPACE;
+  a.dy = (const float*)dy->p; a.dyld = dy->ld; a.ws = (float*)ws; a.Cout = dy->c;
+  dim3 grid(a.splits, a.coTiles);
+  if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_c4_wgrad<MI355_IN_PLAIN>), grid, dim3(256), 0, stream, a);
+  else LAUNCH((conv3d_c4_wgrad<MI355_IN_AFFINE_ACT>), grid, dim3(256), 0, stream, a);
+  int rc = LAUNCH_CHECK(); if (rc) return rc;
+  LAUNCH(conv3d_c4_wgrad_reduce, dim3(a.coTiles * 128), dim3(256), 0, stream, (const float*)ws, dw, a.Cout, a.splits);
+  return LAUNCH_CHECK();
+}

@@ -381,6 +381,7 @@ static int select_cfg(int kd, int stride, long long vox, int cout) {
 }
 
 int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream);
+int mi355_conv3d_c4_fwd_impl(const mi355_act* x, const float* w, const mi355_act* y, const mi355_conv_desc* d, void* stream);
 
 extern "C" int mi355_conv3d_uses_bf16(const mi355_conv_desc* d) {
   return d && d->precision != MI355_PREC_F32 && d->kd == 3 && d->stride == 1 &&
@@ -398,6 +399,8 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
   if (d->in_mode == MI355_IN_S2D && d->out_mode == MI355_OUT_D2S) return MI355_EUNSUPPORTED;
   if (d->out_mode != MI355_OUT_PLAIN && d->out_mode != MI355_OUT_D2S) return MI355_EINVAL;
   if (d->precision < MI355_PREC_F32 || d->precision > MI355_PREC_BF16) return MI355_EINVAL;
+  if (d->wformat == MI355_W_OIDHW4) return mi355_conv3d_c4_fwd_impl(x, wp, y, d, stream);
+  if (d->wformat != MI355_W_PACKED) return MI355_EINVAL;
   if (mi355_conv3d_uses_bf16(d)) {
     if (d->out_d <= 0 || d->out_h <= 0 || d->out_w <= 0) return MI355_EINVAL;
     return mi355_conv3d_fwd_bf16_impl(x, wp, y, d, stream);

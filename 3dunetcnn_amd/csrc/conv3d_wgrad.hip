@@ -331,6 +331,10 @@ int mi355_wgrad_reduce_launch(const float* ws, float* dw, int Cout, int Cin, int
 size_t mi355_conv3d_wgrad_bf16_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d);
 int mi355_conv3d_wgrad_bf16_impl(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d,
                                  void* ws, size_t ws_bytes, void* stream);
+int mi355_conv3d_c4_ok(const mi355_act* x, const mi355_conv_desc* d);
+size_t mi355_conv3d_c4_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d);
+int mi355_conv3d_c4_wgrad_impl(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d,
+                               void* ws, size_t ws_bytes, void* stream);
 static int wgrad_uses_bf16(const mi355_conv_desc* d) {
   return d->precision != MI355_PREC_F32 && d->kd == 3 && d->stride == 1 && d->pad == 1 && d->out_mode == MI355_OUT_PLAIN &&
          (d->in_mode == MI355_IN_PLAIN || d->in_mode == MI355_IN_AFFINE_ACT);
@@ -374,6 +378,7 @@ static WgradPlan plan_wgrad(const mi355_act* x, const mi355_act* dy, const mi355
 }
 
 extern "C" size_t mi355_conv3d_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  if (mi355_conv3d_c4_ok(x, d)) return mi355_conv3d_c4_wgrad_workspace(x, dy, d);
   if (d && wgrad_uses_bf16(d)) return mi355_conv3d_wgrad_bf16_workspace(x, dy, d);
   WgradPlan p = plan_wgrad(x, dy, d);
   return p.ok ? p.ws_bytes : 0;
@@ -400,6 +405,7 @@ extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
   if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift)) return MI355_EINVAL;
   if (d->precision < MI355_PREC_F32 || d->precision > MI355_PREC_BF16) return MI355_EINVAL;
+  if (mi355_conv3d_c4_ok(x, d)) return mi355_conv3d_c4_wgrad_impl(x, dy, dw, d, ws, ws_bytes, stream);
   if (wgrad_uses_bf16(d)) return mi355_conv3d_wgrad_bf16_impl(x, dy, dw, d, ws, ws_bytes, stream);
   WgradPlan p = plan_wgrad(x, dy, d);
   if (!p.ok) return MI355_EUNSUPPORTED;

@@ -14,7 +14,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (IN_AFFINE_ACT, IN_PLAIN, IN_S2D, IN_ZERO_INSERT, OUT_D2S, OUT_PLAIN, PREC_F32, PRECISIONS,  # noqa: F401
+from ._lib import (IN_AFFINE_ACT, IN_PLAIN, IN_S2D, IN_ZERO_INSERT, OUT_D2S, OUT_PLAIN, PREC_F32, PRECISIONS, W_OIDHW4,  # noqa: F401
                    MiAct, MiConvDesc, check)
 
 
@@ -99,6 +99,10 @@ class PackedWeight:
         return self._bf16[precision]
 
     def ptr_for(self, desc):
+        if (self.mode == 0 and self.cin == 4 and self.kd == 3 and desc.stride == 1 and desc.pad == 1 and desc.out_mode == OUT_PLAIN
+                and desc.in_mode in (IN_PLAIN, IN_AFFINE_ACT)):
+            desc.wformat = W_OIDHW4        # first layer: dedicated (tap, ci)-fused kernel reads the unpacked weight
+            return self.w.data_ptr()
         if self.be.lib.mi355_conv3d_uses_bf16(ctypes.byref(desc)):
             return self.bf16(desc.precision).data_ptr()
         return self.f32().data_ptr()
@@ -175,6 +179,8 @@ class Backend:
         self.lib.mi355_conv3d_fwd_config(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d), name, 96)
         if self.lib.mi355_conv3d_uses_bf16(ctypes.byref(d)):
             name.value = b"conv3d_k3_bf16<...>"
+        if wp.ptr_for(d) and d.wformat == W_OIDHW4:
+            name.value = b"conv3d_c4_fwd"
         nvox = x.shape[0] * out_dhw[0] * out_dhw[1] * out_dhw[2]
         flops = 2.0 * nvox * x.c * y.c * kd ** 3 * (8 if (in_mode == IN_S2D or out_mode == OUT_D2S) else 1)
         if in_mode == IN_ZERO_INSERT:
@@ -210,7 +216,9 @@ class Backend:
             flops = 2.0 * nvox * x.c * dy.c * kd ** 3
             byts = 4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * x.c + nvox * dy.c + kd ** 3 * x.c * dy.c)
             bf = self.precision != PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT) and out_mode == OUT_PLAIN
-            self.prof.append(("conv3d_wgrad_k3_bf16<...> (+reduce)" if bf else f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1))
+            c4 = x.c == 4 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT) and out_mode == OUT_PLAIN
+            self.prof.append(("conv3d_c4_wgrad (+reduce)" if c4 else "conv3d_wgrad_k3_bf16<...> (+reduce)" if bf
+                              else f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1))
 
     # -- norm ----------------------------------------------------------------------------------------------------
     def gn_stats(self, x, groups, eps, gamma, beta):

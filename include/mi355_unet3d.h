@@ -84,7 +84,14 @@ typedef struct mi355_conv_desc {
                             are a normalised+LeakyReLU'd skip (MONAI UnetUpBlock: cat((up, skip), 1) -> conv) needs this. */
   int32_t out_mode;      /* MI355_OUT_* */
   int32_t precision;     /* MI355_PREC_*: arithmetic of the 3x3x3 stride-1 convolutions (everything else is always F32) */
+  int32_t wformat;       /* MI355_W_*: what the `wp` argument of mi355_conv3d_fwd points at */
 } mi355_conv_desc;
+
+#define MI355_W_PACKED 0   /* a pack made by mi355_pack_conv_weight / mi355_pack_conv_weight_bf16 (see mi355_conv3d_uses_bf16) */
+#define MI355_W_OIDHW4 1   /* the UNPACKED Conv3d weight [cout][4][3][3][3] of a 4-input-channel 3x3x3 stride-1 pad-1 conv
+                              (x->c == 4, IN_PLAIN / IN_AFFINE_ACT, OUT_PLAIN): the network's first layer runs on a dedicated
+                              exact-fp32 kernel whose GEMM K index is the fused (tap, ci) pair (csrc/conv3d_c4.hip), whatever
+                              `precision` says. mi355_conv3d_wgrad takes that path by itself whenever x->c == 4. */
 
 /* ---- weight packing -------------------------------------------------------------------------- */
 /* Packed layout consumed by mi355_conv3d_fwd: wp[tap][cinP/4][coutP][4], cinP = roundup(cin,8),

@@ -53,6 +53,26 @@ def test_conv_wgrad(hip_backend, kw):
     assert C.case_conv_wgrad(hip_backend, **kw) < TOL
 
 
+# first-layer (4 input channels) kernels, csrc/conv3d_c4.hip: ragged extents, wide/odd output channel counts, concat slices
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=4, cout=32, dhw=(5, 9, 11)),
+    dict(n=2, cin=4, cout=48, dhw=(4, 8, 8), norm=True, slope=0.01, bias=True),
+    dict(n=1, cin=4, cout=32, dhw=(7, 6, 10), norm=True, xld=8, yld=64, yc0=32, residual=True, chscale=True),
+    dict(n=1, cin=4, cout=8, dhw=(3, 3, 3)),
+])
+def test_conv_fwd_first_layer(hip_backend, kw):
+    assert C.case_conv_fwd(hip_backend, **kw) < TOL
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=4, cout=32, dhw=(5, 9, 11)),
+    dict(n=2, cin=4, cout=48, dhw=(8, 8, 16), norm=True, slope=0.01),
+    dict(n=1, cin=4, cout=8, dhw=(3, 3, 3)),
+])
+def test_conv_wgrad_first_layer(hip_backend, kw):
+    assert C.case_conv_wgrad(hip_backend, **kw) < TOL
+
+
 @pytest.mark.parametrize("kw", [
     dict(n=2, c=32, dhw=(64, 64, 64), groups=8),
     dict(n=2, c=4, dhw=(64, 64, 64), groups=4),
