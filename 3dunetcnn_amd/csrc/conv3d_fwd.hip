@@ -13,6 +13,7 @@
 // K ordering inside an 8-channel group: lanes 0-31 own channels 0..3, lanes 32-63 channels 4..7, k-step s uses
 // (s, 4+s); A and B use the same permutation so the sum is unchanged.
 #include "hipcompat.h"
+#include <cstdlib>
 #include "../../include/mi355_unet3d.h"
 
 struct ConvArgs {
@@ -53,6 +54,14 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, li = lane & 31;
   const int wm = wave / WN, wn = wave % WN;
+  // Zero-insert mode (dgrad of a stride-2 conv / ConvTranspose3d(k3,s2,p1)): 7 of 8 positions of the up-sampled input are
+  // zeros, and WHICH taps see a non-zero depends only on the output voxel's parity per axis: an even coordinate uses tap 1,
+  // an odd one taps 0 and 2. With ZIP the 8 M tiles of the 4x8x8 output tile are the 8 parity classes (32 same-parity voxels
+  // each), so a tile issues MFMAs for its own 1/2/4/8 taps only instead of all 27 (27/8 taps per voxel on average). A wave
+  // owns the two classes that differ in x; the (z, y) class is rotated with the workgroup index because the classes carry
+  // 3/6/6/12 taps and would otherwise load the 4 SIMDs unevenly.
+  constexpr bool ZIP = INMODE == MI355_IN_ZERO_INSERT && KD == 3 && STRIDE == 1 && TZ == 4 && TY == 8 && TX == 8 && WM == 4 && MT == 2;
+  const int zcls = ZIP ? ((wm + (int)blockIdx.x) & 3) : 0;     // (az, ay) = (zcls >> 1, zcls & 1)
 
   int b = blockIdx.x;
   const int cot = b % a.coTiles; b /= a.coTiles;
@@ -67,7 +76,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int tv = (wm * MT + mt) * 32 + li;
-    const int tz = tv / (TY * TX), ty = (tv / TX) % TY, tx = tv % TX;
+    int tz = tv / (TY * TX), ty = (tv / TX) % TY, tx = tv % TX;
+    if (ZIP) { tz = 2 * (li >> 4) + (zcls >> 1); ty = 2 * ((li >> 2) & 3) + (zcls & 1); tx = 2 * (li & 3) + mt; }
     abase[mt] = (((tz * STRIDE) * HY + ty * STRIDE) * HX + tx * STRIDE) * VS + half * 4;
   }
 
@@ -169,6 +179,42 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
     const int cq0 = c0 / 4 + half;
     // k-groups of this chunk that exist (CinP is a multiple of 8 but not necessarily of KC); wave-uniform
     const int jn = FULLJ ? J : ((a.CinP - c0) / 8 < J ? (a.CinP - c0) / 8 : J);
+    if constexpr (ZIP) {
+      const int az = zcls >> 1, ay = zcls & 1;
+      const int ny = ay ? 2 : 1, ncomb = (az ? 2 : 1) * ny;
+#pragma unroll 1
+      for (int cb = 0; cb < ncomb; ++cb) {
+        const int dz = az ? 2 * (cb / ny) : 1, dy = ay ? 2 * (cb % ny) : 1;
+        float4 b3[3][J][NT];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              b3[dx][j][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (j < jn) b3[dx][j][nt] = wp4[((size_t)(((dz * 3 + dy) * 3 + dx) * CQ + cq0 + 2 * j)) * a.CoutP + co_base + nt * 32 + li];
+            }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int mt = (dx & 1) ? 0 : 1;          // even x (class ax = 0 = M tile 0) uses tap 1, odd x taps 0 and 2
+          const int toff = ((dz * HY + dy) * HX + dx) * VS;
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            if (j >= jn) continue;
+            const float4 af = *reinterpret_cast<const float4*>(lds + abase[mt] + toff + j * 8);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              f32x16& ac = TL ? accc[TL ? mt : 0][TL ? nt : 0] : acc[mt][nt];
+              ac = MFMA_32x32x2(af.x, b3[dx][j][nt].x, ac);
+              ac = MFMA_32x32x2(af.y, b3[dx][j][nt].y, ac);
+              ac = MFMA_32x32x2(af.z, b3[dx][j][nt].z, ac);
+              ac = MFMA_32x32x2(af.w, b3[dx][j][nt].w, ac);
+            }
+          }
+        }
+      }
+    } else {
     float4 bcur[J][NT], bnext[J][NT];
 #pragma unroll
     for (int j = 0; j < J; ++j)
@@ -231,6 +277,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bcur[j][nt] = bnext[j][nt];
     }
+    }
     if (TL) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -248,7 +295,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
       const int tv = (wm * MT + mt) * 32 + row;
-      const int oz = tz0 + tv / (TY * TX), oy = ty0 + (tv / TX) % TY, ox = tx0 + tv % TX;
+      int oz = tz0 + tv / (TY * TX), oy = ty0 + (tv / TX) % TY, ox = tx0 + tv % TX;
+      if (ZIP) { oz = tz0 + 2 * (row >> 4) + (zcls >> 1); oy = ty0 + 2 * ((row >> 2) & 3) + (zcls & 1); ox = tx0 + 2 * (row & 3) + mt; }
       if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
       if (KD == 1 && a.outmode == MI355_OUT_D2S) {
         // ConvTranspose3d(k2,s2): logical channel p*fC + k of coarse voxel ox (flat) -> fine voxel (2z+a, 2y+b, 2x+e), channel k
@@ -373,10 +421,10 @@ static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
 //  2/3: 3x3x3 stride 2 (also the zero-insert form with stride template 1), 4x4x8 tiles, KC=8
 //  4/5: 3x3x3 stride 1, 4x8x8 tiles, KC=16 (large volumes: >= 131072 output voxels in the batch)
 //  6/7: 3x3x3 stride 1, 2x4x8 / 4x4x8 tiles, KC=32 (small volumes, so the grid still covers 256 CUs)
-static int select_cfg(int kd, int stride, long long vox, int cout) {
+static int select_cfg(int kd, int stride, long long vox, int cout, int in_mode = MI355_IN_PLAIN) {
   if (kd == 1) return cout > 32 ? 0 : 1;
   if (stride == 2) return cout > 32 ? 2 : 3;
-  if (vox >= 256LL * 512) return cout > 32 ? 4 : 5;
+  if (vox >= 256LL * 512 || in_mode == MI355_IN_ZERO_INSERT) return cout > 32 ? 4 : 5;   // zero-insert: parity-class tiles need 4x8x8
   return cout > 32 ? 6 : 7;
 }
 
@@ -405,7 +453,7 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
     if (d->out_d <= 0 || d->out_h <= 0 || d->out_w <= 0) return MI355_EINVAL;
     return mi355_conv3d_fwd_bf16_impl(x, wp, y, d, stream);
   }
-  if (d->in_mode == MI355_IN_ZERO_INSERT && d->stride != 1) return MI355_EINVAL;
+  if (d->in_mode == MI355_IN_ZERO_INSERT && (d->stride != 1 || d->kd != 3 || d->pad != 1)) return MI355_EINVAL;
   ConvArgs a;
   a.x = (const float*)x->p; a.xld = x->ld; a.wp = wp; a.y = (float*)y->p; a.yld = y->ld;
   a.res = d->residual; a.resld = d->residual_ld;
@@ -419,7 +467,7 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
   if (a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0) return MI355_EINVAL;
   if (a.res && a.resld < a.Cout) return MI355_EINVAL;
   const int im = d->in_mode;
-  const int cfg = select_cfg(d->kd, d->stride, (long long)a.Do * a.Ho * a.Wo * a.N, a.Cout);
+  const int cfg = select_cfg(d->kd, d->stride, (long long)a.Do * a.Ho * a.Wo * a.N, a.Cout, im);
   if (d->kd == 1) {
     if (d->stride != 1 || im == MI355_IN_ZERO_INSERT) return MI355_EUNSUPPORTED;
     const int cfg1 = select_cfg(1, 1, 0, d->out_mode == MI355_OUT_D2S ? 8 * y->c : y->c);
@@ -460,7 +508,7 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
 extern "C" int mi355_conv3d_fwd_config(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d, char* out, size_t n) {
   if (!x || !y || !d || !out || n < 8) return MI355_EINVAL;
   const int cfg = select_cfg(d->kd, d->stride, (long long)d->out_d * d->out_h * d->out_w * x->n,
-                             (d->kd == 1 && d->out_mode == MI355_OUT_D2S) ? 8 * y->c : y->c);
+                             (d->kd == 1 && d->out_mode == MI355_OUT_D2S) ? 8 * y->c : y->c, d->in_mode);
   const int stride_t = d->in_mode == MI355_IN_ZERO_INSERT ? 1 : d->stride;
   static const char* const tags[8] = {"1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 2", "1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 1",
                                       "4, 4, 8, 8, 0, 4, 1, 1, 2", "4, 4, 8, 8, 0, 4, 1, 1, 1",

@@ -271,18 +271,19 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
 // = 4 ci per thread, 64 float4 per slab), every thread keeps 8 independent running sums so 8 loads are in flight, and the 4
 // slab-groups are combined through LDS in a fixed order. (A thread that walks all slabs with one dependent load at a time is
 // latency-bound: 5 % of the training step at 512 slabs.)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles, int parts) {
   __shared__ float4 part[4][256];
-  const int tap = blockIdx.x % T;
-  const int pair = blockIdx.x / T;
+  // parts = 4: four workgroups share one tile (64 float4 each) -- launches with few (pair, tap) tiles are otherwise latency-bound
+  const int tile = blockIdx.x / parts, sub0 = (blockIdx.x % parts) * (4 / parts), sub1 = sub0 + 4 / parts;
+  const int tap = tile % T;
+  const int pair = tile / T;
   const int cot = pair / ciTiles, cit = pair % ciTiles;
   const int tid = threadIdx.x;
   const int e4 = tid & 63 /* which float4 of ... */, grp = tid >> 6;
   // 1024 floats per slab tile = 256 float4: thread (grp, e4) handles float4 indices e4, e4+64, e4+128, e4+192 of slabs k = grp, grp+4, ...
   const float4* base = reinterpret_cast<const float4*>(ws + (((size_t)pair * SL) * T + tap) * 1024);
   const size_t slab_stride = (size_t)T * 256;       // in float4
-#pragma unroll
-  for (int sub = 0; sub < 4; ++sub) {
+  for (int sub = sub0; sub < sub1; ++sub) {
     const int f4 = e4 + 64 * sub;
     float4 acc[8];
 #pragma unroll
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
   }
   __syncthreads();
   // final: thread t combines the 4 groups for float4 index t (row = co in tile, 8 float4 per row of 32 ci)
-  {
+  if ((tid >> 6) >= sub0 && (tid >> 6) < sub1) {
     const int f4 = tid;
     float4 s = part[0][f4];
 #pragma unroll
@@ -323,8 +324,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
 
 int mi355_wgrad_reduce_launch(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles, void* stream) {
   const int coTiles = ceil_div(Cout, 32);
-  const long long grid = (long long)coTiles * ciTiles * T;
-  LAUNCH(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, ws, dw, Cout, Cin, T, SL, ciTiles);
+  const long long tiles = (long long)coTiles * ciTiles * T;
+  const int parts = tiles < 256 ? 4 : 1;
+  LAUNCH(wgrad_reduce_kernel, dim3((unsigned)(tiles * parts)), dim3(256), 0, stream, ws, dw, Cout, Cin, T, SL, ciTiles, parts);
   return LAUNCH_CHECK();
 }
 

@@ -8,6 +8,7 @@
 //
 // Algorithmic traffic: stats = 1 read of x; backward = reads of (x, dA) twice + 1 write of dx.
 #include "hipcompat.h"
+#include <cstdlib>
 #include "../../include/mi355_unet3d.h"
 
 #define GN_MAX_BLOCKS_PER_SAMPLE 256
@@ -164,21 +165,36 @@ __global__ void gn_stats_finalize_kernel(const float* ws, const float* x, int xl
 __global__ void gn_bwd_finalize_kernel(const float* ws, int B, int C, int G, long long V, const float* gamma,
                                        const float* mean_rstd, float* coef, float* nc_sums) {
   __shared__ double red[256];
+  __shared__ double p1[256], p2[256];
   const int g = blockIdx.x, n = blockIdx.y;
   const int cpg = C / G;
+  const int tid = threadIdx.x;
   double m1 = 0.0, m2 = 0.0;
-  // per-channel sums first (deterministic order: each thread owns whole channels)
-  for (int i = threadIdx.x; i < cpg; i += blockDim.x) {
-    const int c = g * cpg + i;
-    double s1 = 0.0, s2 = 0.0;
-    for (int blk = 0; blk < B; ++blk) {
-      const float* p = ws + (((size_t)n * B + blk) * C + c) * 2;
-      s1 += (double)p[0]; s2 += (double)p[1];
+  // per-channel sums first: the 256 threads cover (channel, slice of the block range); slices are combined in a fixed order
+  for (int c0 = 0; c0 < cpg; c0 += 256) {
+    const int nch = cpg - c0 < 256 ? cpg - c0 : 256;
+    const int S = 256 / nch;
+    const int i = tid % nch, sl = tid / nch;
+    double a1 = 0.0, a2 = 0.0;
+    if (sl < S) {
+      const int c = g * cpg + c0 + i;
+      for (int blk = sl; blk < B; blk += S) {
+        const float* p = ws + (((size_t)n * B + blk) * C + c) * 2;
+        a1 += (double)p[0]; a2 += (double)p[1];
+      }
     }
-    nc_sums[((size_t)n * C + c) * 2] = (float)s1;
-    nc_sums[((size_t)n * C + c) * 2 + 1] = (float)s2;
-    const double ga = gamma ? (double)gamma[c] : 1.0;
-    m1 += ga * s1; m2 += ga * s2;
+    p1[tid] = a1; p2[tid] = a2;
+    __syncthreads();
+    if (tid < nch) {
+      const int c = g * cpg + c0 + tid;
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < S; ++k) { s1 += p1[k * nch + tid]; s2 += p2[k * nch + tid]; }
+      nc_sums[((size_t)n * C + c) * 2] = (float)s1;
+      nc_sums[((size_t)n * C + c) * 2 + 1] = (float)s2;
+      const double ga = gamma ? (double)gamma[c] : 1.0;
+      m1 += ga * s1; m2 += ga * s2;
+    }
+    __syncthreads();
   }
   m1 = block_sum_double(m1, red);
   m2 = block_sum_double(m2, red);
@@ -238,7 +254,7 @@ __global__ void gn_bwd_apply_kernel(const float* x, int xld, const float* dA, in
 }
 
 static int gn_blocks_per_sample(long long V) {
-  long long b = V / 2048;
+  long long b = V / 16;   // >= 16 voxels per block: the deep 8^3 / 16^3 levels still get hundreds of blocks (V/2048 left them latency-bound)   // >= 16 voxels per block; small deep levels still get hundreds of blocks (they were latency-bound at V/2048)
   if (b < 1) b = 1;
   if (b > GN_MAX_BLOCKS_PER_SAMPLE) b = GN_MAX_BLOCKS_PER_SAMPLE;
   return (int)b;

@@ -301,13 +301,22 @@ __global__ void proj_bwd_kernel(const float* x, int xld, const float* sc, const 
   }
 }
 
-__global__ void proj_reduce_kernel(const float* ws, int nblocks, int npairs, int ndw, float* dw, float* dbias) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= npairs) return;
+// 8 output elements per workgroup x 32 lanes striding the per-block partials; lanes combined through LDS in a fixed order
+__global__ __launch_bounds__(256) void proj_reduce_kernel(const float* ws, int nblocks, int npairs, int ndw, float* dw, float* dbias) {
+  __shared__ double part[8][32];
+  const int l = threadIdx.x & 31, k = threadIdx.x >> 5;
+  const int e = blockIdx.x * 8 + k;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += (double)ws[(size_t)b * npairs + e];
-  if (e < ndw) dw[e] = (float)s;
-  else if (dbias) dbias[e - ndw] = (float)s;
+  if (e < npairs)
+    for (int b = l; b < nblocks; b += 32) s += (double)ws[(size_t)b * npairs + e];
+  part[k][l] = s;
+  __syncthreads();
+  if (l == 0 && e < npairs) {
+    double t = 0.0;
+    for (int i = 0; i < 32; ++i) t += part[k][i];
+    if (e < ndw) dw[e] = (float)t;
+    else if (dbias) dbias[e - ndw] = (float)t;
+  }
 }
 
 static int proj_blocks(const mi355_act* x) {
@@ -350,7 +359,7 @@ extern "C" int mi355_proj_bwd(const mi355_act* x, const float* in_scale, const f
   LAUNCH(proj_bwd_kernel, dim3(nb), dim3(256), lds, stream, (const float*)x->p, x->ld, in_scale, in_shift, act_slope, w, dlogits, dx ? (float*)dx->p : (float*)nullptr,
          dx ? dx->ld : 0, (float*)ws, x->n, V, x->c, cout);
   int rc = LAUNCH_CHECK(); if (rc) return rc;
-  LAUNCH(proj_reduce_kernel, dim3(ceil_div(npairs, 128)), dim3(128), 0, stream, (const float*)ws, nb, npairs, cout * x->c, dw, dbias);
+  LAUNCH(proj_reduce_kernel, dim3(ceil_div(npairs, 8)), dim3(256), 0, stream, (const float*)ws, nb, npairs, cout * x->c, dw, dbias);
   return LAUNCH_CHECK();
 }
 

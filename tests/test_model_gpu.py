@@ -37,13 +37,13 @@ def _run_pair(kw, enc, dhw, n, tc=False, seed=1234):
         return ref.detach(), l.detach(), {k: v.grad for k, v in sd.items()}
     ref, lref, g32 = run(torch.float32)
     _, _, g64 = run(torch.float64)
-    floor = conditioning.noise_floor(R, lambda: run(torch.float32)[2])
+    floor, perturbed = conditioning.noise_floor(R, lambda: run(torch.float32)[2], return_evals=True)
     out = m(x.cuda())
     crit = losses.HipDiceLoss(sigmoid=True)
     loss = crit(out, y.cuda())
     loss.backward()
     errs = {"logits": C.rel_err(out, ref), "loss": abs(float(loss.detach()) - float(lref)) / abs(float(lref))}
-    w = C.grad_parity({k: p.grad for k, p in m.named_parameters()}, g32, g64, floor, TOL)
+    w = C.grad_parity({k: p.grad for k, p in m.named_parameters()}, g32, g64, floor, TOL, perturbed=perturbed)
     errs["grad"] = w.pop("ratio")
     errs.update(w)
     return errs

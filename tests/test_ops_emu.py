@@ -35,6 +35,7 @@ def test_conv_fwd_big_tile(emu_backend):
     dict(n=1, cin=32, cout=64, dhw=(6, 7, 8)),
     dict(n=1, cin=32, cout=32, dhw=(8, 8, 8), stride=2),
     dict(n=1, cin=8, cout=32, dhw=(7, 9, 8), stride=2),
+    dict(n=1, cin=64, cout=32, dhw=(6, 8, 10), stride=2),     # 64 dx channels: the NT = 2 parity-class configuration
 ])
 def test_conv_dgrad(emu_backend, kw):
     assert C.case_conv_dgrad(emu_backend, **kw) < TOL

@@ -1,9 +1,15 @@
 #!/bin/bash
-out=$(pwd)/gpurun_out/r1i; mkdir -p $out; root=$(pwd)
-cd /tmp; export TMPDIR=/tmp
-A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
-for cfg in "fp32 32 32 128 fwd" "fp32 128 128 64 fwd" "fp32 256 256 32 fwd" "fp32 128 128 64 wgrad"; do
-  tag=$(echo $cfg | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $A -f csv -d $out/$tag.a -o p -- python $root/tools/one_conv.py $cfg > /dev/null 2>&1
-  echo "=== $cfg"; python $root/tools/pmc_kernel.py $out/$tag.a/p_counter_collection.csv conv3d
+# scratch: seeds sweep of the transposed-conv variant gradient parity
+cd /root/repo
+cat > /tmp/sweep.py <<'PY'
+import sys
+sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo")
+import test_model_gpu as T
+for seed in (1234, 1, 2, 3, 4, 5):
+    e = T._run_pair(dict(n_features=4, n_outputs=3, use_transposed_convolutions=True), (1, 2, 2, 4), (32, 32, 32), 1, tc=True, seed=seed)
+    print(seed, {k: (round(v, 6) if isinstance(v, float) else v) for k, v in e.items()}, flush=True)
+PY
+for env in "X=1" "MI355_GN_VPB=2048"; do
+  echo "=== $env"
+  env $env timeout 900 python /tmp/sweep.py 2>&1 | tail -8 | cut -c1-330
 done
