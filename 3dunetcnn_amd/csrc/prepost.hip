@@ -135,3 +135,66 @@ extern "C" int mi355_zscore(const float* x, float* y, int32_t c, int64_t voxels,
   LAUNCH(zscore_apply_kernel, dim3(pp_grid((long long)c * voxels)), dim3(256), 0, stream, x, y, (long long)voxels, c, (const float*)stats);
   return LAUNCH_CHECK();
 }
+
+// ---- affine resampling (ResizeD / ResampleToMatch) ----
+struct ResampleM { float m[12]; };
+
+__global__ void resample_affine_kernel(const float* src, float* dst, int C, int sd, int sh, int sw, int dd, int dh, int dw, ResampleM M,
+                                       int mode, int padding) {
+  const long long DV = (long long)dd * dh * dw, SV = (long long)sd * sh * sw;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < DV; v += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(v % dw), y = (int)((v / dw) % dh), z = (int)(v / ((long long)dw * dh));
+    float cz = M.m[0] * z + M.m[1] * y + M.m[2] * x + M.m[3];
+    float cy = M.m[4] * z + M.m[5] * y + M.m[6] * x + M.m[7];
+    float cx = M.m[8] * z + M.m[9] * y + M.m[10] * x + M.m[11];
+    if (mode != MI355_RESAMPLE_TRILINEAR) {
+      const float rz = mode == MI355_RESAMPLE_NEAREST ? rintf(cz) : floorf(cz);
+      const float ry = mode == MI355_RESAMPLE_NEAREST ? rintf(cy) : floorf(cy);
+      const float rx = mode == MI355_RESAMPLE_NEAREST ? rintf(cx) : floorf(cx);
+      int iz = (int)rz, iy = (int)ry, ix = (int)rx;
+      const bool inside = iz >= 0 && iy >= 0 && ix >= 0 && iz < sd && iy < sh && ix < sw;
+      iz = iz < 0 ? 0 : (iz < sd ? iz : sd - 1); iy = iy < 0 ? 0 : (iy < sh ? iy : sh - 1); ix = ix < 0 ? 0 : (ix < sw ? ix : sw - 1);
+      const size_t o = ((size_t)iz * sh + iy) * sw + ix;
+      for (int c = 0; c < C; ++c) dst[(size_t)c * DV + v] = (padding == 1 && !inside) ? 0.f : src[(size_t)c * SV + o];
+      continue;
+    }
+    if (padding == 0) {
+      cz = cz < 0.f ? 0.f : (cz > (float)(sd - 1) ? (float)(sd - 1) : cz);
+      cy = cy < 0.f ? 0.f : (cy > (float)(sh - 1) ? (float)(sh - 1) : cy);
+      cx = cx < 0.f ? 0.f : (cx > (float)(sw - 1) ? (float)(sw - 1) : cx);
+    }
+    const float fz = floorf(cz), fy = floorf(cy), fx = floorf(cx);
+    const float lz = cz - fz, ly = cy - fy, lx = cx - fx;
+    const int z0 = (int)fz, y0 = (int)fy, x0 = (int)fx;
+    float wgt[8]; size_t off[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int a = k >> 2, b = (k >> 1) & 1, e = k & 1;
+      int iz = z0 + a, iy = y0 + b, ix = x0 + e;
+      float w = (a ? lz : 1.f - lz) * (b ? ly : 1.f - ly) * (e ? lx : 1.f - lx);
+      const bool inside = iz >= 0 && iy >= 0 && ix >= 0 && iz < sd && iy < sh && ix < sw;
+      if (!inside) {
+        if (padding == 1) w = 0.f;               // zeros outside; with border padding the clamp above leaves only weight-0 corners outside
+        iz = iz < 0 ? 0 : (iz < sd ? iz : sd - 1); iy = iy < 0 ? 0 : (iy < sh ? iy : sh - 1); ix = ix < 0 ? 0 : (ix < sw ? ix : sw - 1);
+      }
+      wgt[k] = w; off[k] = ((size_t)iz * sh + iy) * sw + ix;
+    }
+    for (int c = 0; c < C; ++c) {
+      const float* sc = src + (size_t)c * SV;
+      // x pairs first, then y, then z
+      const float v00 = wgt[0] * sc[off[0]] + wgt[1] * sc[off[1]], v01 = wgt[2] * sc[off[2]] + wgt[3] * sc[off[3]];
+      const float v10 = wgt[4] * sc[off[4]] + wgt[5] * sc[off[5]], v11 = wgt[6] * sc[off[6]] + wgt[7] * sc[off[7]];
+      dst[(size_t)c * DV + v] = (v00 + v01) + (v10 + v11);
+    }
+  }
+}
+
+extern "C" int mi355_resample_affine(const float* src, float* dst, int32_t c, int32_t sd, int32_t sh, int32_t sw, int32_t dd, int32_t dh,
+                                     int32_t dw, const float* m, int32_t mode, int32_t padding, void* stream) {
+  if (!src || !dst || !m || c < 1 || sd < 1 || sh < 1 || sw < 1 || dd < 1 || dh < 1 || dw < 1) return MI355_EINVAL;
+  if (mode < MI355_RESAMPLE_TRILINEAR || mode > MI355_RESAMPLE_NEAREST_FLOOR || padding < 0 || padding > 1) return MI355_EINVAL;
+  ResampleM M;
+  for (int i = 0; i < 12; ++i) M.m[i] = m[i];
+  LAUNCH(resample_affine_kernel, dim3(pp_grid((long long)dd * dh * dw)), dim3(256), 0, stream, src, dst, c, sd, sh, sw, dd, dh, dw, M, mode, padding);
+  return LAUNCH_CHECK();
+}

@@ -330,6 +330,17 @@ class Backend:
         check(self.lib.mi355_zscore(x.data_ptr(), y.data_ptr(), x.shape[0], x[0].numel(), ws.data_ptr(), ws.numel() * 4, self.stream()), "zscore")
         return y
 
+    def resample_affine(self, src, out_shape, matrix, mode="trilinear", padding="border"):
+        """src [C, D, H, W] fp32; matrix: 12 floats (3x4 row-major, dst voxel -> src voxel, (z, y, x) order). Returns [C, *out_shape]."""
+        assert src.is_contiguous() and src.dtype == torch.float32 and src.dim() == 4
+        m = (ctypes.c_float * 12)(*[float(v) for v in matrix])
+        dst = torch.empty(src.shape[0], *out_shape, dtype=torch.float32, device=src.device)
+        md = {"trilinear": 0, "bilinear": 0, "nearest": 1, "nearest_floor": 2}[mode]
+        pd = {"border": 0, "zeros": 1}[padding]
+        check(self.lib.mi355_resample_affine(src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], src.shape[2], src.shape[3],
+                                             out_shape[0], out_shape[1], out_shape[2], m, md, pd, self.stream()), "resample_affine")
+        return dst
+
     # -- loss / optimizer ----------------------------------------------------------------------------------------
     def dice(self, logits, target, sigmoid=True, batch=False, squared_pred=False, smooth_nr=1e-5, smooth_dr=1e-5,
              want_grad=True, grad_scale=1.0):

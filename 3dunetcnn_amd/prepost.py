@@ -5,6 +5,11 @@
   activate_and_decode           unet3d/predict/volumetric.py:151-156 + the decode above, one pass over the logits
   normalize_intensity           MONAI NormalizeIntensityD(channel_wise=True, nonzero=False), datasets/segmentation.py:77-86
 
+  resize                        MONAI ResizeD(spatial_size, mode=("trilinear", "nearest")) = F.interpolate(size=...,
+                                align_corners=False), datasets/segmentation.py:63-68
+  resample_to_match             MONAI ResampleToMatch(mode) of a prediction onto the source image grid,
+                                predict/volumetric.py:135-136, 168-170 (voxel map inv(A_src) @ A_dst; parity unpinned: MONAI absent)
+
 Inputs and outputs live on the GPU; there is no CPU fallback.
 """
 import torch
@@ -72,3 +77,29 @@ def normalize_intensity(image, channel_wise=True, nonzero=False, _backend=None):
     if image.dim() == 5:
         return torch.stack([be.zscore(image[n].float().contiguous()) for n in range(image.shape[0])])
     return be.zscore(image.float().contiguous())
+
+
+def resize(img, spatial_size, mode="trilinear", _backend=None):
+    """img [C, D, H, W] -> [C, *spatial_size]. "trilinear": F.interpolate(size=spatial_size, mode="trilinear",
+    align_corners=False); "nearest": F.interpolate(mode="nearest") (source index floor(dst * in/out))."""
+    be = _be(img, _backend)
+    if mode not in ("trilinear", "nearest"):
+        raise NotImplementedError(f"resize mode {mode!r}")
+    x = img.float().contiguous()
+    m = [0.0] * 12
+    for i in range(3):
+        sc = x.shape[1 + i] / float(spatial_size[i])
+        m[4 * i + i] = sc
+        m[4 * i + 3] = 0.5 * sc - 0.5 if mode == "trilinear" else 0.0
+    return be.resample_affine(x, tuple(int(v) for v in spatial_size), m, "trilinear" if mode == "trilinear" else "nearest_floor", "border")
+
+
+def resample_to_match(img, src_affine, dst_affine, dst_shape, mode="trilinear", padding_mode="border", _backend=None):
+    """img [C, D, H, W] with voxel->world affine src_affine (4x4) resampled onto the grid (dst_shape, dst_affine):
+    dst[c, v] = interp(img[c], inv(src_affine) @ dst_affine @ v). mode "trilinear"/"bilinear"/"nearest"; padding_mode
+    "border"/"zeros"."""
+    be = _be(img, _backend)
+    a_src = torch.as_tensor(src_affine, dtype=torch.float64).cpu()
+    a_dst = torch.as_tensor(dst_affine, dtype=torch.float64).cpu()
+    m = (torch.linalg.inv(a_src) @ a_dst)[:3, :].reshape(-1).tolist()
+    return be.resample_affine(img.float().contiguous(), tuple(int(v) for v in dst_shape), m, mode, padding_mode)

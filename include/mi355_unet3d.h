@@ -207,6 +207,18 @@ int mi355_one_hot(const float* label_map, int64_t voxels, const float* label_val
  * y[c][v] = (x[c][v] - mean_c) / std_c with the population std, std 0 -> 1. x, y: [c][voxels] (one sample). */
 size_t mi355_zscore_workspace(int32_t c);
 int mi355_zscore(const float* x, float* y, int32_t c, int64_t voxels, void* ws, size_t ws_bytes, void* stream);
+/* Resampling of one channel-first sample through an affine voxel map:
+ *   dst[c][z][y][x] = interp(src[c], M * (z, y, x, 1)),  M = 3x4 row-major HOST array, rows = source (z, y, x) coordinate.
+ * Replaces MONAI ResizeD(spatial_size, mode=("trilinear","nearest")) = F.interpolate(size=..., align_corners=False)
+ * (unet3d/datasets/segmentation.py:63-68: M = diag(in/out) with offset 0.5*in/out - 0.5 for trilinear, offset 0 + FLOOR for
+ * torch's "nearest") and the ResampleToMatch of the predictions back onto the source grid (unet3d/predict/volumetric.py:135-136,
+ * 168-170: M = inv(A_src) * A_dst in voxel coordinates). mode: MI355_RESAMPLE_*. padding 0: border (coordinates clamped to the
+ * volume, what F.interpolate does), 1: zeros outside. */
+#define MI355_RESAMPLE_TRILINEAR 0
+#define MI355_RESAMPLE_NEAREST 1        /* round half to even (grid_sample nearest) */
+#define MI355_RESAMPLE_NEAREST_FLOOR 2  /* floor (F.interpolate nearest) */
+int mi355_resample_affine(const float* src, float* dst, int32_t c, int32_t sd, int32_t sh, int32_t sw, int32_t dd, int32_t dh,
+                          int32_t dw, const float* m, int32_t mode, int32_t padding, void* stream);
 
 /* ---- Dice loss -------------------------------------------------------------------------------- */
 /* monai.losses.DiceLoss as configured by examples/brats2020/brats2020_config.json:112-116 (sigmoid=True,

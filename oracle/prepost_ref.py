@@ -63,3 +63,30 @@ def normalize_intensity(x):
         m, s = x[c].float().mean(), x[c].float().std(unbiased=False)
         out[c] = (x[c].float() - m) / (s if float(s) != 0.0 else 1.0)
     return out
+
+
+def resize_ref(img, spatial_size, mode="trilinear"):
+    """MONAI Resize (datasets/segmentation.py:63-68) = torch F.interpolate on the channel-first sample; align_corners=False."""
+    import torch.nn.functional as F
+    if mode == "trilinear":
+        return F.interpolate(img[None].float(), size=tuple(spatial_size), mode="trilinear", align_corners=False)[0]
+    return F.interpolate(img[None].float(), size=tuple(spatial_size), mode="nearest")[0]
+
+
+def resample_to_match_ref(img, src_affine, dst_affine, dst_shape, mode="trilinear", padding_mode="border"):
+    """ResampleToMatch (predict/volumetric.py:135-136, 168-170) restated as torch F.grid_sample(align_corners=True) over the voxel
+    map inv(A_src) @ A_dst (float64 coordinates -> normalised grid). PARITY UNPINNED: MONAI is not importable here; the voxel
+    map is the affine contract of the two NIfTI grids, MONAI's own sub-voxel conventions are not checked."""
+    import torch
+    import torch.nn.functional as F
+    a = torch.linalg.inv(torch.as_tensor(src_affine, dtype=torch.float64)) @ torch.as_tensor(dst_affine, dtype=torch.float64)
+    dd, dh, dw = dst_shape
+    zz, yy, xx = torch.meshgrid(torch.arange(dd, dtype=torch.float64), torch.arange(dh, dtype=torch.float64),
+                                torch.arange(dw, dtype=torch.float64), indexing="ij")
+    v = torch.stack([zz, yy, xx, torch.ones_like(zz)], dim=-1) @ a.T          # (..., 4): source (z, y, x, 1)
+    sd, sh, sw = img.shape[1:]
+    def norm(c, n):
+        return 2.0 * c / max(n - 1, 1) - 1.0
+    grid = torch.stack([norm(v[..., 2], sw), norm(v[..., 1], sh), norm(v[..., 0], sd)], dim=-1)[None]
+    gm = {"trilinear": "bilinear", "bilinear": "bilinear", "nearest": "nearest"}[mode]
+    return F.grid_sample(img[None].double(), grid, mode=gm, padding_mode=padding_mode, align_corners=True)[0].float()

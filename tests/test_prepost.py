@@ -95,8 +95,40 @@ def _cases(dev, be, dhw):
     assert torch.allclose(got.cpu(), P.normalize_intensity(x), atol=2e-5)
 
 
+def _resample_cases(dev, be, dhw):
+    """ResizeD / ResampleToMatch on device vs torch F.interpolate / F.grid_sample. Tolerance 1e-4 absolute on N(0,1) data: the
+    source coordinate is an fp32 number of magnitude <= 150 (ulp 1.5e-5 at 128..256), so two correct evaluations differ by
+    ulp(coordinate) x |neighbour difference|; nearest modes are bit-exact away from exact .5 / integer-boundary coordinates."""
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(3, *dhw, generator=g)
+    lab = torch.randint(0, 5, (1, *dhw), generator=g).float()
+    for size in ((dhw[0] * 2, dhw[1] * 2, dhw[2] * 2), (dhw[0] + 3, dhw[1] - 2, dhw[2] * 3 - 1), (5, 4, 3), dhw):
+        got = prepost.resize(img.to(dev), size, "trilinear", _backend=be)
+        assert got.shape == (3, *size)
+        err = float((got.cpu() - P.resize_ref(img, size, "trilinear")).abs().max())
+        assert err < 1e-4, (size, err)
+        gotl = prepost.resize(lab.to(dev), size, "nearest", _backend=be)
+        assert torch.equal(gotl.cpu(), P.resize_ref(lab, size, "nearest")), size
+    # prediction grid (2 mm, shifted origin, one flipped axis) -> source grid (1 mm)
+    a_src = torch.tensor([[2.0, 0, 0, -10.0], [0, -2.0, 0, 31.0], [0, 0, 2.0, 4.0], [0, 0, 0, 1.0]])
+    a_dst = torch.tensor([[1.0, 0, 0, -11.3], [0, 1.0, 0, 1.5], [0, 0, 1.0, 3.25], [0, 0, 0, 1.0]])
+    dst_shape = (2 * dhw[0] + 3, 2 * dhw[1] + 1, 2 * dhw[2] + 2)
+    for mode, pad, tol in (("trilinear", "border", 1e-4), ("trilinear", "zeros", 1e-4), ("nearest", "border", 0.0)):
+        src = img if mode == "trilinear" else lab
+        got = prepost.resample_to_match(src.to(dev), a_src, a_dst, dst_shape, mode, pad, _backend=be)
+        want = P.resample_to_match_ref(src, a_src, a_dst, dst_shape, mode, pad)
+        if tol:
+            assert float((got.cpu() - want).abs().max()) < tol, (mode, pad, float((got.cpu() - want).abs().max()))
+        else:
+            assert float((got.cpu() != want).float().mean()) < 1e-3, mode  # ties at exact .5 coordinates may round either way
+    # identity map reproduces the input exactly
+    eye = torch.eye(4)
+    assert torch.equal(prepost.resample_to_match(img.to(dev), eye, eye, dhw, _backend=be).cpu(), img), "identity"
+
+
 def test_prepost_on_emulator(emu_backend):
     _cases("cpu", emu_backend, (6, 7, 9))
+    _resample_cases("cpu", emu_backend, (6, 7, 9))
 
 
 def test_prepost_refuses_cpu():
@@ -107,6 +139,7 @@ def test_prepost_refuses_cpu():
 @pytest.mark.gpu
 def test_prepost_gpu(hip_backend):
     _cases("cuda", None, (40, 33, 50))
+    _resample_cases("cuda", None, (40, 33, 50))
     # the reference's own known answer at its full 100^3 size
     data = _label_volume()
     got = prepost.compile_one_hot_encoding(data.cuda(), 2, labels=[5, 22])
