@@ -218,6 +218,7 @@ class Backend:
             bf = self.precision != PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT) and out_mode == OUT_PLAIN
             c4 = x.c == 4 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT) and out_mode == OUT_PLAIN
             self.prof.append(("conv3d_c4_wgrad (+reduce)" if c4 else "conv3d_wgrad_k3_bf16<...> (+reduce)" if bf
+                              else "conv3d_wgrad_ring (+reduce)" if (kd == 3 and stride == 1 and pad == 1 and out_mode == OUT_PLAIN)
                               else f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1))
 
     # -- norm ----------------------------------------------------------------------------------------------------

@@ -53,6 +53,16 @@ def test_conv_wgrad(hip_backend, kw):
     assert C.case_conv_wgrad(hip_backend, **kw) < TOL
 
 
+def test_conv_wgrad_ring_z_chunks(hip_backend):
+    # tall thin volume: the plane-ring wgrad cuts each 4x8 column into two z chunks (9 + 8 planes) with ragged y/x tiles
+    assert C.case_conv_wgrad(hip_backend, n=1, cin=32, cout=64, dhw=(17, 5, 9), norm=True) < TOL
+
+
+def test_conv_wgrad_ring_many_columns(hip_backend):
+    # more 4x8 columns than workgroups per (co, ci) pair: every workgroup walks several columns into the same accumulators
+    assert C.case_conv_wgrad(hip_backend, n=1, cin=32, cout=32, dhw=(8, 96, 190), norm=True) < TOL
+
+
 # first-layer (4 input channels) kernels, csrc/conv3d_c4.hip: ragged extents, wide/odd output channel counts, concat slices
 @pytest.mark.parametrize("kw", [
     dict(n=1, cin=4, cout=32, dhw=(5, 9, 11)),
