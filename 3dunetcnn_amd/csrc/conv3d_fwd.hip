@@ -235,9 +235,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
           if (j < jn) bnext[j][nt] = wp4[((size_t)(tn * CQ + cq0 + 2 * j)) * a.CoutP + co_base + nt * 32 + li];
         }
 
-#if !defined(MI355_EXP_NO_SCHED_BARRIER)
       SCHED_BARRIER();      // the B loads of the NEXT tap stay above this tap's MFMAs (the scheduler otherwise sinks them to their use)
-#endif
       const int dz = tap / (KD * KD), dy = (tap / KD) % KD, dx = tap % KD;
       const int toff = ((dz * HY + dy) * HX + dx) * VS;
 #pragma unroll
@@ -246,20 +244,6 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
         float4 af[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const float4*>(lds + abase[mt] + toff + j * 8);
-#if defined(MI355_EXP_MFMA_ORDER)
-        // k-element outermost: consecutive MFMAs go to different accumulators
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              f32x16& ac = TL ? accc[TL ? mt : 0][TL ? nt : 0] : acc[mt][nt];
-              const float av = e == 0 ? af[mt].x : e == 1 ? af[mt].y : e == 2 ? af[mt].z : af[mt].w;
-              const float bv = e == 0 ? bcur[j][nt].x : e == 1 ? bcur[j][nt].y : e == 2 ? bcur[j][nt].z : bcur[j][nt].w;
-              ac = MFMA_32x32x2(av, bv, ac);
-            }
-#else
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -270,7 +254,6 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
             ac = MFMA_32x32x2(af[mt].z, bcur[j][nt].z, ac);
             ac = MFMA_32x32x2(af[mt].w, bcur[j][nt].w, ac);
           }
-#endif
       }
 #pragma unroll
       for (int j = 0; j < J; ++j)

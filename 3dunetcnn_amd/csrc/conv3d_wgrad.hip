@@ -499,7 +499,7 @@ static WgradPlan plan_wgrad(const mi355_act* x, const mi355_act* dy, const mi355
     Do = x->d; Ho = x->h; Wo = x->w; coutL = 8 * dy->c;
   }
   if (d->kd == 1) { p.tz = 1; p.ty = 1; p.tx = 256; long long v = (long long)Do * Ho * Wo; if (v > 0x7fffffffLL) return p; Do = 1; Ho = 1; Wo = (int)v; p.wv = 4; }
-  else if (d->stride == 1) { p.tz = 4; p.ty = 4; p.tx = 8; p.wv = 1; }
+  else if (d->stride == 1) return p;   // 3x3x3 stride 1: plane-ring kernel (plan_wgrad_ring)
   else { p.tz = 2; p.ty = 2; p.tx = 8; p.wv = 1; }
   p.tilesZ = ceil_div(Do, p.tz); p.tilesY = ceil_div(Ho, p.ty); p.tilesX = ceil_div(Wo, p.tx);
   const long long nt = (long long)dy->n * p.tilesZ * p.tilesY * p.tilesX;
@@ -616,10 +616,10 @@ extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float
     if (vi != vo) return MI355_EINVAL;
     a.Di = a.Hi = 1; a.Wi = (int)vi; a.Do = a.Ho = 1; a.Wo = (int)vo; a.pad = 0;
     rc = launch_wgrad<1, 1, 1, 1, 256>(a, d->in_mode, stream);
-  } else if (d->stride == 1) {
-    rc = launch_wgrad<3, 1, 4, 4, 8>(a, d->in_mode, stream);
-  } else {
+  } else if (d->stride == 2) {
     rc = launch_wgrad<3, 2, 2, 2, 8>(a, d->in_mode, stream);
+  } else {
+    return MI355_EUNSUPPORTED;       // 3x3x3 stride 1 with pad != 1 (pad 1 runs on conv3d_wgrad_ring above)
   }
   if (rc) return rc;
   const int T = d->kd * d->kd * d->kd;
