@@ -18,6 +18,7 @@ ConvTranspose3d(k2, s2) is ONE 1x1x1 GEMM with 8*co logical output channels whos
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ._lib import IN_AFFINE_ACT, IN_PLAIN, IN_S2D, IN_ZERO_INSERT, OUT_D2S
 from .engine import HipNetBase
@@ -112,8 +113,6 @@ class HipDynUNet(HipNetBase):
         an = act_name[0] if isinstance(act_name, (tuple, list)) else act_name
         if str(an).lower() != "leakyrelu" or (isinstance(act_name, (tuple, list)) and act_name[1].get("negative_slope", 0.01) != 0.01):
             bad.append("activation other than LeakyReLU(0.01)")
-        if in_channels % 4:
-            bad.append("in_channels not a multiple of 4 (NDHWC float4 rows)")
         if bad:
             raise NotImplementedError("HipDynUNet implements the configuration the reference ships (brats2020_config.json); "
                                       "unsupported: " + ", ".join(bad))
@@ -156,12 +155,19 @@ class HipDynUNet(HipNetBase):
     def _blocks(self):
         return [self.input_block] + list(self.downsamples) + [self.bottleneck]
 
+    @staticmethod
+    def _ci_pad(blk, cin):
+        """Weight transform for a block whose input Act carries more channels than conv1 has (the network input, zero-padded to a
+        multiple of 4 channels because NDHWC rows are float4 multiples): zero input-channel columns."""
+        pad = cin - blk.conv1.conv.in_channels
+        return None if pad == 0 else (lambda w: F.pad(w, (0, 0, 0, 0, 0, 0, 0, pad)))
+
     def _block_fwd(self, be, blk, xin, dst, keep):
         n = xin.act.shape[0]
         cout = blk.norm1.num_features
         d, h, w = dst.shape[1:4]
         r1 = be.empty_act(n, d, h, w, cout)
-        be.conv_fwd(xin.act, self._packed_weight(blk.conv1.conv.weight, 0), r1, 3, blk.stride, **xin.kw())
+        be.conv_fwd(xin.act, self._packed_weight(blk.conv1.conv.weight, 0, self._ci_pad(blk, xin.act.c)), r1, 3, blk.stride, **xin.kw())
         st1 = be.gn_stats(r1, cout, IN_EPS, blk.norm1.weight.data, blk.norm1.bias.data)
         be.conv_fwd(r1, self._packed_weight(blk.conv2.conv.weight, 0), dst, 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2],
                     slope=SLOPE)
@@ -178,8 +184,13 @@ class HipDynUNet(HipNetBase):
                 raise ValueError(f"HipDynUNet: spatial size {tuple(x.shape[2:])} must be divisible by {2 ** (L - 1)} "
                                  "(ConvTranspose3d(k2,s2) output must match the skip, as in MONAI DynUNet)")
             sizes.append(tuple(s // 2 for s in sizes[-1]))
-        xa = be.empty_act(n, D, H, W, self.in_channels)
-        be.ncdhw_to_ndhwc(x, xa)
+        cpad = (self.in_channels + 3) // 4 * 4
+        if cpad == self.in_channels:
+            xa = be.empty_act(n, D, H, W, self.in_channels)
+            be.ncdhw_to_ndhwc(x, xa)
+        else:
+            xa = be.zeros_act(n, D, H, W, cpad)
+            be.ncdhw_to_ndhwc(x, xa.slice(0, self.in_channels))
         cats = [be.empty_act(n, *sizes[i], 2 * f[i]) for i in range(L - 1)]
         enc = []
         cur = _In(xa)
@@ -230,13 +241,19 @@ class HipDynUNet(HipNetBase):
         be.gn_act_bwd(r1, dA1, dA1, cout, SLOPE, blk.norm1.weight.data, st1[0], st1[1], st1[2],
                       self._gslice(blk.norm1.weight), self._gslice(blk.norm1.bias))
         d_r1 = dA1
-        be.conv_wgrad(xin.act, d_r1, self._gslice(blk.conv1.conv.weight), 3, blk.stride, **xin.kw())
+        w1 = blk.conv1.conv.weight
+        if xin.act.c == w1.shape[1]:
+            be.conv_wgrad(xin.act, d_r1, self._gslice(w1), 3, blk.stride, **xin.kw())
+        else:                                  # zero-padded network input: wgrad over the padded channels, sliced back
+            tw = torch.empty(w1.shape[0], xin.act.c, 3, 3, 3, dtype=torch.float32, device=w1.device)
+            be.conv_wgrad(xin.act, d_r1, tw, 3, blk.stride, **xin.kw())
+            self._gslice(w1).copy_(tw[:, :w1.shape[1]])
         self._flush_ready()
         if not need_dx:
             return None
         n, d, h, w, cin = xin.act.shape
         dAin = be.empty_act(n, d, h, w, cin)
-        wp = self._packed_weight(blk.conv1.conv.weight, 1)
+        wp = self._packed_weight(blk.conv1.conv.weight, 1, self._ci_pad(blk, cin))
         if blk.stride == 1:
             be.conv_fwd(d_r1, wp, dAin, 3, 1, residual=dx_residual)
         else:
@@ -279,5 +296,5 @@ class HipDynUNet(HipNetBase):
         if need_dx and dx is not None:
             sizes = saved["sizes"]
             dx_t = torch.empty(n, self.in_channels, *sizes[0], dtype=torch.float32, device=dlogits.device)
-            be.ndhwc_to_ncdhw(dx, dx_t)
+            be.ndhwc_to_ncdhw(dx.slice(0, self.in_channels), dx_t)
         return dx_t

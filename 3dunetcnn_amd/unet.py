@@ -20,6 +20,7 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .engine import HipNetBase
 from ._lib import IN_AFFINE_ACT, IN_PLAIN, IN_ZERO_INSERT
@@ -126,8 +127,9 @@ class HipUNet3D(HipNetBase):
             raise NotImplementedError("HipUNet3D implements the reference default downsampling_stride=2")
         if interpolation_mode != "trilinear" and not use_transposed_convolutions:
             raise NotImplementedError("only trilinear interpolation (reference default) or transposed convolutions")
-        if n_features % 4 != 0:
-            raise NotImplementedError("n_features must be a multiple of 4 (NDHWC float4 rows)")
+        # NDHWC rows are float4 multiples: an input with 1..3 (5..7, ...) channels is carried with zero channels up to the next
+        # multiple of 4; the first block's weights / norm parameters are zero-padded copies and their gradients are sliced back
+        self._cin_pad = (n_features + 3) // 4 * 4
         self.input_shape = input_shape
         self.base_width = base_width
         self.n_features = n_features
@@ -169,13 +171,14 @@ class HipUNet3D(HipNetBase):
         n, d, h, w, cin = x.shape
         cout = blk.conv1.conv.out_channels
         c1, c2 = blk.conv1, blk.conv2
-        st1 = be.gn_stats(x, c1.norm1.num_groups, GN_EPS, c1.norm1.weight.data, c1.norm1.bias.data)
+        g1, b1, groups1, padw = self._in_pad(c1, cin)
+        st1 = be.gn_stats(x, groups1, GN_EPS, g1, b1)
         h1 = be.empty_act(n, d, h, w, cout)
-        be.conv_fwd(x, self._packed_weight(c1.conv.weight, 0), h1, 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2])
+        be.conv_fwd(x, self._packed_weight(c1.conv.weight, 0, padw), h1, 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2])
         st2 = be.gn_stats(h1, c2.norm1.num_groups, GN_EPS, c2.norm1.weight.data, c2.norm1.bias.data)
         if blk.sample is not None:
             idn = be.empty_act(n, d, h, w, cout)
-            be.conv_fwd(x, self._packed_weight(blk.sample.weight, 0), idn, 1)
+            be.conv_fwd(x, self._packed_weight(blk.sample.weight, 0, padw), idn, 1)
         else:
             idn = x
         be.conv_fwd(h1, self._packed_weight(c2.conv.weight, 0), out, 3, 1, in_mode=IN_AFFINE_ACT, scale=st2[1], shift=st2[2],
@@ -185,6 +188,29 @@ class HipUNet3D(HipNetBase):
             s.x, s.h1, s.st1, s.st2, s.out, s.chscale = x, h1, st1, st2, out, chscale
             return s
         return None
+
+    def _in_pad(self, c1, cin):
+        """(gamma, beta, groups, weight transform) of a block whose input Act carries `cin` >= conv.in_channels channels (the
+        zero-padded network input). Padding only happens for channel counts that are not multiples of 4, where the reference's
+        GroupNorm is per-channel (groups = C whenever C < 8 or C % 8 != 0, myronenko.py:23-31): groups = cin keeps it so, and
+        the zero gamma / beta / weight columns make the pad channels contribute nothing."""
+        cm = c1.conv.in_channels
+        if cin == cm:
+            return c1.norm1.weight.data, c1.norm1.bias.data, c1.norm1.num_groups, None
+        pad = cin - cm
+        return (F.pad(c1.norm1.weight.data, (0, pad)), F.pad(c1.norm1.bias.data, (0, pad)), cin,
+                lambda w: F.pad(w, (0, 0, 0, 0, 0, 0, 0, pad)))
+
+    def _wgrad_target(self, p, cin):
+        """Destination of a weight gradient whose kernel sees `cin` input channels: the parameter's slice of the flat gradient
+        buffer, or (padded input) a scratch tensor that `_wgrad_commit` slices back into it."""
+        if p.shape[1] == cin:
+            return self._gslice(p)
+        return torch.empty(p.shape[0], cin, *p.shape[2:], dtype=torch.float32, device=p.device)
+
+    def _wgrad_commit(self, p, t):
+        if t.shape != p.shape:
+            self._gslice(p).copy_(t[:, :p.shape[1]])
 
     def _layer_fwd(self, be, layer, x, out_last, keep):
         """All blocks of a layer; the last block writes into out_last. Returns list of saved blocks."""
@@ -213,8 +239,12 @@ class HipUNet3D(HipNetBase):
         sizes = [(D, H, W)]
         for _ in range(L - 1):
             sizes.append(tuple((s - 1) // 2 + 1 for s in sizes[-1]))
-        xa = be.empty_act(n, D, H, W, self.n_features)
-        be.ncdhw_to_ndhwc(x, xa)
+        if self._cin_pad == self.n_features:
+            xa = be.empty_act(n, D, H, W, self.n_features)
+            be.ncdhw_to_ndhwc(x, xa)
+        else:
+            xa = be.zeros_act(n, D, H, W, self._cin_pad)
+            be.ncdhw_to_ndhwc(x, xa.slice(0, self.n_features))
         # concat buffers for decoder levels: level i (resolution of encoder level i, i < L-1) holds [up | skip]
         cats = []
         for i in range(L - 1):
@@ -289,22 +319,35 @@ class HipUNet3D(HipNetBase):
         be.gn_act_bwd(s.h1, dA2, dA2, c2.norm1.num_groups, 0.0, c2.norm1.weight.data, st2[0], st2[1], st2[2],
                       self._gslice(c2.norm1.weight), self._gslice(c2.norm1.bias))
         dh1 = dA2
-        be.conv_wgrad(s.x, dh1, self._gslice(c1.conv.weight), 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2])
+        g1, _, groups1, padw = self._in_pad(c1, cin)
+        tw = self._wgrad_target(c1.conv.weight, cin)
+        be.conv_wgrad(s.x, dh1, tw, 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2])
+        self._wgrad_commit(c1.conv.weight, tw)
         dA1 = be.empty_act(n, d, h, w, cin)
-        be.conv_fwd(dh1, self._packed_weight(c1.conv.weight, 1), dA1, 3, 1)
+        be.conv_fwd(dh1, self._packed_weight(c1.conv.weight, 1, padw), dA1, 3, 1)
         if blk.sample is not None:
-            be.conv_wgrad(s.x, d_out, self._gslice(blk.sample.weight), 1)
+            ts = self._wgrad_target(blk.sample.weight, cin)
+            be.conv_wgrad(s.x, d_out, ts, 1)
+            self._wgrad_commit(blk.sample.weight, ts)
             d_id = None
             if need_dx:
                 d_id = be.empty_act(n, d, h, w, cin)
-                be.conv_fwd(d_out, self._packed_weight(blk.sample.weight, 1), d_id, 1)
+                be.conv_fwd(d_out, self._packed_weight(blk.sample.weight, 1, padw), d_id, 1)
         else:
             d_id = d_out
         dx = None
         if need_dx:
             dx = dx_out if dx_out is not None else dA1
-        be.gn_act_bwd(s.x, dA1, dx if dx is not None else dA1, c1.norm1.num_groups, 0.0, c1.norm1.weight.data, st1[0], st1[1], st1[2],
-                      self._gslice(c1.norm1.weight), self._gslice(c1.norm1.bias), addend=d_id if need_dx else None)
+        if padw is None:
+            dg, db = self._gslice(c1.norm1.weight), self._gslice(c1.norm1.bias)
+        else:
+            dg, db = torch.empty(cin, dtype=torch.float32, device=be.device), torch.empty(cin, dtype=torch.float32, device=be.device)
+        be.gn_act_bwd(s.x, dA1, dx if dx is not None else dA1, groups1, 0.0, g1, st1[0], st1[1], st1[2], dg, db,
+                      addend=d_id if need_dx else None)
+        if padw is not None:
+            cm = c1.conv.in_channels
+            self._gslice(c1.norm1.weight).copy_(dg[:cm])
+            self._gslice(c1.norm1.bias).copy_(db[:cm])
         self._flush_ready()
         return dx
 
@@ -367,7 +410,7 @@ class HipUNet3D(HipNetBase):
         dx_t = None
         if need_dx and dx is not None:
             dx_t = torch.empty(n, self.n_features, *sizes[0], dtype=torch.float32, device=dlogits.device)
-            be.ndhwc_to_ncdhw(dx, dx_t)
+            be.ndhwc_to_ncdhw(dx.slice(0, self.n_features), dx_t)
         return dx_t
 
     def _window(self, be, d_up, off, win):

@@ -1,0 +1,78 @@
+"""Inputs whose channel count is not a multiple of 4 (the reference's default is n_features=1): the network input is carried
+zero-padded to a float4 multiple, the first block's parameters as zero-padded copies; logits, loss, every parameter gradient
+and the input gradient must match the CPU oracle graph (1e-3 relative, BASELINE north star)."""
+import importlib
+
+import pytest
+import torch
+
+import op_cases as C
+from oracle import dynunet_ref as D
+from oracle import torch_ops as O
+from oracle import unet3d_ref as R
+
+unet = importlib.import_module("3dunetcnn_amd.unet")
+dyn = importlib.import_module("3dunetcnn_amd.dynunet")
+losses = importlib.import_module("3dunetcnn_amd.losses")
+TOL = 1e-3
+
+
+def _check(m, be, dev, fwd_ref, cin, dhw):
+    x, y = R.synthetic_case(1, cin, dhw, 2)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    ref = fwd_ref(sd, xr)
+    lref = O.dice_loss(ref, y)
+    lref.backward()
+    crit = losses.HipDiceLoss(sigmoid=True)
+    if be is not None:
+        m._be = be
+        crit._be = be
+    xg = x.to(dev).requires_grad_(True)
+    out = m(xg)
+    loss = crit(out, y.to(dev))
+    loss.backward()
+    assert out.shape == ref.shape
+    assert C.rel_err(out, ref) < TOL
+    assert abs(float(loss.detach()) - float(lref)) / abs(float(lref)) < TOL
+    gmax = max(float(v.grad.abs().max()) for v in sd.values())
+    for k, p in m.named_parameters():
+        # relative to the tensor's own scale, floored at 1e-3 of the largest gradient (a single-channel norm weight has a
+        # gradient that is zero up to roundoff: 3e-7 against 1e-1 elsewhere)
+        scale = max(float(sd[k].grad.abs().max()), 1e-3 * gmax)
+        assert p.grad.shape == sd[k].grad.shape and float((p.grad.cpu() - sd[k].grad).abs().max()) / scale < TOL, k
+    assert C.rel_err(xg.grad, xr.grad) < TOL
+
+
+def _unet(cin):
+    torch.manual_seed(3)
+    kw = dict(n_features=cin, n_outputs=2, base_width=8, encoder_blocks=[1, 1])
+    return unet.HipUNet3D(**kw).eval(), (lambda sd, x: R.unet3d_forward(sd, x, (1, 1)))
+
+
+def _dyn(cin):
+    torch.manual_seed(4)
+    m = dyn.HipDynUNet(spatial_dims=3, in_channels=cin, out_channels=2, kernel_size=[3, 3], strides=[1, 2], upsample_kernel_size=[2],
+                       filters=[8, 12]).eval()
+    return m, (lambda sd, x: D.dynunet_forward(sd, x, 2))
+
+
+@pytest.mark.parametrize("cin", [1, 3, 6])
+def test_unet3d_odd_input_channels_on_emulator(emu_backend, cin):
+    m, ref = _unet(cin)
+    _check(m, emu_backend, "cpu", ref, cin, (8, 8, 8))
+
+
+@pytest.mark.parametrize("cin", [1, 3])
+def test_dynunet_odd_input_channels_on_emulator(emu_backend, cin):
+    m, ref = _dyn(cin)
+    _check(m, emu_backend, "cpu", ref, cin, (8, 8, 8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin", [1, 3])
+def test_odd_input_channels_gpu(cin):
+    m, ref = _unet(cin)
+    _check(m.cuda(), None, "cuda", ref, cin, (16, 20, 24))
+    m, ref = _dyn(cin)
+    _check(m.cuda(), None, "cuda", ref, cin, (16, 16, 24))
