@@ -1,5 +1,5 @@
 """Developer tool (GPU): launch one conv layer a few times (for rocprofv3 --pmc runs).
-    python tools/one_conv.py <precision> <cin> <cout> <size> [fwd|wgrad] [iters]"""
+    python tools/one_conv.py <precision> <cin> <cout> <size> [fwd|fwdplain|wgrad] [iters]"""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,9 +17,18 @@ w = torch.randn(cout, cin, 3, 3, 3, device=be.device) * 0.05
 wp = be.pack_weight(w, 0)
 dw = torch.empty_like(w)
 sc = torch.ones(n, cin, device=be.device); sh = torch.zeros(n, cin, device=be.device)
-for _ in range(iters):
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for it in range(iters):
+    if it == 1:
+        e0.record()
     if what == "fwd":
         be.conv_fwd(x, wp, y, 3, 1, in_mode=ops.IN_AFFINE_ACT, scale=sc, shift=sh)
+    elif what == "fwdplain":
+        be.conv_fwd(x, wp, y, 3, 1)
     else:
         be.conv_wgrad(x, y, dw, 3, 1, in_mode=ops.IN_AFFINE_ACT, scale=sc, shift=sh)
+e1.record()
 torch.cuda.synchronize()
+if iters > 1:
+    ms = e0.elapsed_time(e1) / (iters - 1)
+    print(f"{' '.join(sys.argv[1:6])}: {ms:.3f} ms/launch, {2.0 * n * s ** 3 * cin * cout * 27 / ms / 1e9:.1f} TFLOP/s")
