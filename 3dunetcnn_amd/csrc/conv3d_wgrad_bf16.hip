@@ -30,7 +30,6 @@ struct WgradBArgs {
   int N, D, H, W, Cin, Cout;
   int tilesY, tilesX, ntiles;      // tile index = ((n*tilesY + ty)*tilesX + tx)*D + z   (z fastest)
   int splits, ciTiles, coTiles32;
-  int dbg;   // developer switch (MI355_WGRAD_DBG): 1 = producers idle, 2 = consumers idle (timing experiments only)
 };
 
 template <int NS> struct WProducts;
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArg
       const int z = tile % a.D, buf = (tile - t_begin) & 1;
       const bool has_next = tile + 1 < t_end;
       const bool next_same_col = has_next && z + 1 < a.D;   // z fastest: the next tile continues this column iff z+1 < D
-      if (next_same_col && a.dbg != 1) stage(tile + 1, buf ^ 1, z + 2, 1, true);   // the one new plane -> the slot not read now
+      if (next_same_col) stage(tile + 1, buf ^ 1, z + 2, 1, true);   // the one new plane -> the slot not read now
       __syncthreads();
       if (has_next && !next_same_col) {                      // new column: refill the ring while the consumers wait
         stage(tile + 1, buf ^ 1, -1, 3, true);
@@ -216,7 +215,7 @@ __global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArg
     const int z = tile % a.D, buf = (tile - t_begin) & 1;
     const bool has_next = tile + 1 < t_end;
     const bool next_same_col = has_next && z + 1 < a.D;
-    if (a.dbg != 2) {
+    {
       // 4 k-steps (y-rows of 16 voxels); this wave: tap row (wdz, wdy), dx = 0..2
       const int bslot = (z - 1 + wdz) & 3;
 #pragma unroll
@@ -336,7 +335,6 @@ int mi355_conv3d_wgrad_bf16_impl(const mi355_act* x, const mi355_act* dy, float*
   a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Cout = dy->c;
   a.tilesY = p.tilesY; a.tilesX = p.tilesX; a.ntiles = p.ntiles;
   a.splits = p.splits; a.ciTiles = p.ciTiles; a.coTiles32 = p.coTiles32;
-  { const char* e = getenv("MI355_WGRAD_DBG"); a.dbg = e ? atoi(e) : 0; }
   const int ns = nsplit_of_w(d->precision);
   int rc;
   if (p.mt == 2) rc = ns == 1 ? launch_wb<1, 2>(a, p, d->in_mode, stream) : launch_wb<2, 2>(a, p, d->in_mode, stream);
