@@ -94,6 +94,93 @@ __global__ void dice_grad_kernel(const float* logits, const void* target, int ta
 
 static int dice_blocks(long long V) { long long b = V / 4096; if (b < 1) b = 1; if (b > DICE_MAX_BLOCKS) b = DICE_MAX_BLOCKS; return (int)b; }
 
+
+// ---- cross-entropy (softmax-CE with probability targets / BCE-with-logits), value + gradient in one pass ----
+#define CE_BLOCKS 1024
+#define CE_MAX_C 16
+template <typename TT>
+__global__ void ce_kernel(const float* z, const TT* y, int N, int C, long long V, int mode, float gscale, float* dz, int accumulate,
+                          float* part) {
+  __shared__ float red[256];
+  float local = 0.f;
+  const long long NV = (long long)N * V;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < NV; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / V, v = i - n * V;
+    const size_t base = (size_t)n * C * V + v;
+    float zc[CE_MAX_C], yc[CE_MAX_C];
+    for (int c = 0; c < C; ++c) { zc[c] = z[base + (size_t)c * V]; yc[c] = (float)y[base + (size_t)c * V]; }
+    if (mode == MI355_CE_SOFTMAX) {
+      float mx = zc[0];
+      for (int c = 1; c < C; ++c) mx = zc[c] > mx ? zc[c] : mx;
+      float se = 0.f, sy = 0.f;
+      for (int c = 0; c < C; ++c) { se += expf(zc[c] - mx); sy += yc[c]; }
+      const float lse = mx + logf(se);
+      for (int c = 0; c < C; ++c) {
+        local += yc[c] * (lse - zc[c]);
+        if (dz) {
+          const float g = (expf(zc[c] - lse) * sy - yc[c]) * gscale;
+          dz[base + (size_t)c * V] = accumulate ? dz[base + (size_t)c * V] + g : g;
+        }
+      }
+    } else {
+      for (int c = 0; c < C; ++c) {
+        const float a = fabsf(zc[c]);
+        local += (zc[c] > 0.f ? zc[c] : 0.f) - zc[c] * yc[c] + log1pf(expf(-a));
+        if (dz) {
+          const float p = 1.f / (1.f + expf(-zc[c]));
+          const float g = (p - yc[c]) * gscale;
+          dz[base + (size_t)c * V] = accumulate ? dz[base + (size_t)c * V] + g : g;
+        }
+      }
+    }
+  }
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void ce_finalize_kernel(const float* part, int B, double inv_count, float weight, float* loss, int accumulate) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) s += (double)part[b];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float v = (float)(red[0] * inv_count) * weight;
+    loss[0] = accumulate ? loss[0] + v : v;
+  }
+}
+
+extern "C" size_t mi355_ce_workspace(int64_t voxels) { (void)voxels; return CE_BLOCKS * sizeof(float); }
+
+extern "C" int mi355_ce_fwd_bwd(const float* logits, const void* target, int32_t target_is_u8, int32_t n, int32_t c, int64_t voxels,
+                                int32_t mode, float weight, float* loss, int32_t accumulate_loss, float* dlogits, int32_t accumulate_grad,
+                                float grad_scale, void* ws, size_t ws_bytes, void* stream) {
+  if (!logits || !target || !loss || !ws || n < 1 || c < 1 || c > CE_MAX_C || voxels <= 0) return MI355_EINVAL;
+  if (mode != MI355_CE_SOFTMAX && mode != MI355_CE_BCE) return MI355_EINVAL;
+  if (ws_bytes < mi355_ce_workspace(voxels)) return MI355_EWORKSPACE;
+  const long long NV = (long long)n * voxels;
+  const double count = mode == MI355_CE_SOFTMAX ? (double)NV : (double)NV * c;
+  long long g = (NV + 255) / 256; if (g > CE_BLOCKS) g = CE_BLOCKS;
+  const float gs = (float)((double)weight * (double)grad_scale / count);
+  if (target_is_u8)
+    LAUNCH((ce_kernel<unsigned char>), dim3((unsigned)g), dim3(256), 0, stream, logits, (const unsigned char*)target, n, c, (long long)voxels, mode,
+           gs, dlogits, accumulate_grad, (float*)ws);
+  else
+    LAUNCH((ce_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, logits, (const float*)target, n, c, (long long)voxels, mode, gs, dlogits,
+           accumulate_grad, (float*)ws);
+  int rc = LAUNCH_CHECK(); if (rc) return rc;
+  LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, (int)g, 1.0 / count, weight, loss, accumulate_loss);
+  return LAUNCH_CHECK();
+}
+
 // ws (floats): partials [NC][B][3] | stats [NC][3] | coef [NC][2]
 extern "C" size_t mi355_dice_workspace(int32_t n, int32_t c, int64_t voxels) {
   const size_t NC = (size_t)n * c;

@@ -357,6 +357,24 @@ class Backend:
                                           _p(dlogits), grad_scale, ws.data_ptr(), ws.numel() * 4, self.stream()), "dice_fwd_bwd")
         return loss, dlogits
 
+    def cross_entropy(self, logits, target, mode="softmax", weight=1.0, loss=None, dlogits=None, want_grad=True, grad_scale=1.0):
+        """mode "softmax": CrossEntropyLoss(mean) with probability targets; "bce": BCEWithLogitsLoss(mean). `loss` / `dlogits`
+        given: the weighted CE value / gradient is ADDED to them (fusing with a Dice term); else fresh tensors are returned."""
+        assert logits.is_contiguous() and target.is_contiguous() and logits.dtype == torch.float32
+        assert target.dtype in (torch.uint8, torch.float32) and target.shape == logits.shape
+        n, c = logits.shape[0], logits.shape[1]
+        vox = logits[0, 0].numel()
+        acc_l, acc_g = loss is not None, dlogits is not None
+        if loss is None:
+            loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        if dlogits is None and want_grad:
+            dlogits = torch.empty_like(logits)
+        ws = self.ws(self.lib.mi355_ce_workspace(vox))
+        check(self.lib.mi355_ce_fwd_bwd(logits.data_ptr(), target.data_ptr(), 1 if target.dtype == torch.uint8 else 0, n, c, vox,
+                                        {"softmax": 0, "bce": 1}[mode], float(weight), loss.data_ptr(), int(acc_l), _p(dlogits), int(acc_g),
+                                        float(grad_scale), ws.data_ptr(), ws.numel() * 4, self.stream()), "ce_fwd_bwd")
+        return loss, dlogits
+
     def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
         check(self.lib.mi355_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
                                        weight_decay, step, grad_scale, self.stream()), "adam_step")

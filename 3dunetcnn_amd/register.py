@@ -16,7 +16,7 @@ import torch
 
 def register(replace=False):
     from .dynunet import HipDynUNet
-    from .losses import HipDiceLoss
+    from .losses import HipBCEWithLogitsLoss, HipCrossEntropyLoss, HipDiceCELoss, HipDiceLoss
     from .optim import HipAdam
     from .unet import HipAutocastUNet, HipAutoImplantUNet, HipUNet3D
     done = {}
@@ -37,11 +37,16 @@ def register(replace=False):
         done["models"] = []
     try:
         losses = importlib.import_module("unet3d.losses")
-        losses.HipDiceLoss = HipDiceLoss
-        done["losses"] = ["HipDiceLoss"]
+        hip_losses = {"HipDiceLoss": HipDiceLoss, "HipDiceCELoss": HipDiceCELoss, "HipBCEWithLogitsLoss": HipBCEWithLogitsLoss,
+                      "HipCrossEntropyLoss": HipCrossEntropyLoss}
+        for name, cls in hip_losses.items():
+            setattr(losses, name, cls)
+        done["losses"] = list(hip_losses)
         if replace:
-            losses.DiceLoss = HipDiceLoss
-            done["losses"].append("DiceLoss")
+            # unet3d.losses is searched before torch.nn and monai.losses (script_utils.py:61-77), so these shadow them
+            for name, cls in hip_losses.items():
+                setattr(losses, name[3:], cls)
+                done["losses"].append(name[3:])
     except ImportError:
         done["losses"] = []
     torch.optim.HipAdam = HipAdam

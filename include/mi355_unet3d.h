@@ -230,6 +230,23 @@ int mi355_dice_fwd_bwd(const float* logits, const void* target, int32_t target_i
                        int32_t sigmoid, int32_t batch, int32_t squared_pred, float smooth_nr, float smooth_dr,
                        float* loss, float* dlogits, float grad_scale, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- cross-entropy --------------------------------------------------------------------------- */
+/* The cross-entropy leg of the reference's loss look-up (scripts/script_utils.py:61-77: torch.nn.BCEWithLogitsLoss /
+ * CrossEntropyLoss via the torch fallback, monai.losses.DiceCELoss), fused into one pass over the logits: loss value and
+ * d(loss)/d(logits) together.
+ *   mode MI355_CE_SOFTMAX: torch.nn.CrossEntropyLoss(reduction="mean") with PROBABILITY targets (what DiceCELoss passes for a
+ *        one-hot target): loss = -1/(n*voxels) * sum_{n,v} sum_c y_c * log_softmax(z)_c.
+ *   mode MI355_CE_BCE:     torch.nn.BCEWithLogitsLoss(reduction="mean"): mean over n*c*voxels of softplus(z) - y*z.
+ * logits fp32 NCDHW, target uint8 or fp32 NCDHW. loss[0] = weight * CE (or += when accumulate_loss != 0, e.g. after
+ * mi355_dice_fwd_bwd); dlogits (optional) receives weight * grad_scale * dCE/dlogits, ADDED to its contents when
+ * accumulate_grad != 0. c <= 16. */
+#define MI355_CE_SOFTMAX 0
+#define MI355_CE_BCE 1
+size_t mi355_ce_workspace(int64_t voxels);
+int mi355_ce_fwd_bwd(const float* logits, const void* target, int32_t target_is_u8, int32_t n, int32_t c, int64_t voxels, int32_t mode,
+                     float weight, float* loss, int32_t accumulate_loss, float* dlogits, int32_t accumulate_grad, float grad_scale,
+                     void* ws, size_t ws_bytes, void* stream);
+
 /* ---- optimizer -------------------------------------------------------------------------------- */
 /* torch.optim.Adam(lr, betas, eps, weight_decay=0, amsgrad=False).step() (script_utils.py:80-81) over one flat
  * parameter buffer; grad is multiplied by grad_scale first (1/world_size after the RCCL sum). step is 1-based. */

@@ -324,6 +324,25 @@ def case_dice(be, n, c, dhw, batch=False, squared=False, u8=True, seed=6):
     return dict(loss=abs(float(loss.cpu()) - float(ref.detach())) / abs(float(ref.detach())), grad=rel_err(dz, dz_ref))
 
 
+def case_ce(be, n, c, dhw, mode="softmax", u8=True, with_dice=False, seed=11):
+    """mi355_ce_fwd_bwd vs torch: CrossEntropyLoss(mean) on probability targets / BCEWithLogitsLoss(mean); with_dice: the value
+    and gradient accumulate onto a Dice term (0.7 * Dice + 0.4 * CE), as HipDiceCELoss runs it."""
+    g = torch.Generator().manual_seed(seed)
+    z = (torch.randn(n, c, *dhw, generator=g) * 3).requires_grad_(True)
+    t = nested_masks(n, dhw, seed)[:, :c] if c <= 3 else (torch.rand(n, c, *dhw, generator=g) > 0.7).to(torch.uint8)
+    tt = t if u8 else t.float()
+    ce = F.cross_entropy(z, t.float()) if mode == "softmax" else F.binary_cross_entropy_with_logits(z, t.float())
+    ref = 0.4 * ce + (0.7 * O.dice_loss(z, t, True) if with_dice else 0.0)
+    (dz_ref,) = torch.autograd.grad(ref, z)
+    zd, td = dev(be, z.detach()), dev(be, tt)
+    loss = dz = None
+    if with_dice:
+        loss, dz = be.dice(zd, td, True, grad_scale=0.7)
+        loss.mul_(0.7)
+    loss, dz = be.cross_entropy(zd, td, mode=mode, weight=0.4, loss=loss, dlogits=dz)
+    return dict(loss=abs(float(loss.cpu()) - float(ref.detach())) / abs(float(ref.detach())), grad=rel_err(dz, dz_ref))
+
+
 def case_adam(be, count, steps=3, wd=0.0, seed=7):
     g = torch.Generator().manual_seed(seed)
     p = torch.randn(count, generator=g)

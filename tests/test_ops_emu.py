@@ -62,6 +62,14 @@ def test_conv_wgrad_ring_many_columns(emu_backend):
     assert C.case_conv_wgrad(emu_backend, n=1, cin=64, cout=64, dhw=(2, 40, 104), norm=True) < TOL
 
 
+@pytest.mark.parametrize("kw", [
+    dict(mode="softmax"), dict(mode="bce"), dict(mode="softmax", u8=False, with_dice=True), dict(mode="bce", with_dice=True),
+])
+def test_cross_entropy(emu_backend, kw):
+    assert ok(C.case_ce(emu_backend, 2, 3, (12, 12, 12), **kw))
+    assert ok(C.case_ce(emu_backend, 1, 5, (6, 7, 9), **kw))
+
+
 # first-layer (4 input channels) kernels, csrc/conv3d_c4.hip: ragged extents, wide/odd output channel counts, concat slices
 @pytest.mark.parametrize("kw", [
     dict(n=1, cin=4, cout=32, dhw=(5, 9, 11)),
