@@ -46,9 +46,14 @@ __global__ void dice_partial_kernel(const float* logits, const void* target, int
   }
 }
 
-// single block: sums -> loss and per-(n,c) gradient coefficients (a, b): dL/dp = -a*y + b*(1 or 2p)
+// single block: sums -> loss and per-(n,c) gradient coefficients (a, b): dL/dp = -a*y + b*(1 or 2p).
+// variant 0: DiceLoss, mean over (n, c) [or c with batch] of 1 - (2I + snr)/(P + G + sdr).
+// variant 1: monai GeneralizedDiceLoss (w_type "square"): per sample n [or once with batch] w_c = 1/G_c^2, an infinite weight (empty
+//            class) is replaced by the largest finite weight of that sample; f = 1 - (2 sum_c w_c I_c + snr)/(sum_c w_c (G_c + P_c) + sdr);
+//            loss = mean over samples.
+// c0 = 1 when include_background=False: channel 0 is left out of the loss (zero gradient).
 __global__ void dice_finalize_kernel(const float* ws, int B, int N, int C, int batch, float snr, float sdr, float grad_scale,
-                                     float* stats, float* coef, float* loss) {
+                                     int variant, int c0, float* stats, float* coef, float* loss) {
   __shared__ double sums[3 * 1024];
   __shared__ double fsum[256];
   const int NC = N * C;
@@ -60,22 +65,50 @@ __global__ void dice_finalize_kernel(const float* ws, int B, int N, int C, int b
   }
   __syncthreads();
   double f = 0.0;
-  const int K = batch ? C : NC;     // number of terms in the mean
-  for (int i = threadIdx.x; i < NC; i += blockDim.x) {
-    double I, D;
-    if (batch) {
-      const int c = i % C; I = 0.0; D = 0.0;
-      for (int n = 0; n < N; ++n) { I += sums[3 * (n * C + c)]; D += sums[3 * (n * C + c) + 1] + sums[3 * (n * C + c) + 2]; }
-    } else { I = sums[3 * i]; D = sums[3 * i + 1] + sums[3 * i + 2]; }
-    const double den = D + (double)sdr;
-    coef[2 * i] = (float)((double)grad_scale * 2.0 / (K * den));
-    coef[2 * i + 1] = (float)((double)grad_scale * (2.0 * I + (double)snr) / (K * den * den));
-    if (!batch || i < C) f += 1.0 - (2.0 * I + (double)snr) / den;
+  const int Ce = C - c0;                                  // channels that count
+  if (variant == 0) {
+    const int K = batch ? Ce : N * Ce;                    // number of terms in the mean
+    for (int i = threadIdx.x; i < NC; i += blockDim.x) {
+      const int c = i % C;
+      if (c < c0) { coef[2 * i] = 0.f; coef[2 * i + 1] = 0.f; continue; }
+      double I, D;
+      if (batch) {
+        I = 0.0; D = 0.0;
+        for (int n = 0; n < N; ++n) { I += sums[3 * (n * C + c)]; D += sums[3 * (n * C + c) + 1] + sums[3 * (n * C + c) + 2]; }
+      } else { I = sums[3 * i]; D = sums[3 * i + 1] + sums[3 * i + 2]; }
+      const double den = D + (double)sdr;
+      coef[2 * i] = (float)((double)grad_scale * 2.0 / (K * den));
+      coef[2 * i + 1] = (float)((double)grad_scale * (2.0 * I + (double)snr) / (K * den * den));
+      if (!batch || i < C) f += (1.0 - (2.0 * I + (double)snr) / den) / K;
+    }
+  } else {
+    const int K = batch ? 1 : N;
+    for (int i = threadIdx.x; i < NC; i += blockDim.x) {
+      const int c = i % C, n = i / C;
+      if (c < c0) { coef[2 * i] = 0.f; coef[2 * i + 1] = 0.f; continue; }
+      // class sums of this sample (or of the whole batch) and the weights
+      double wmax = 0.0, numer = (double)snr, denom = (double)sdr, wme = 0.0;
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int cc = c0; cc < C; ++cc) {
+          double I = 0.0, P = 0.0, G = 0.0;
+          const int n0 = batch ? 0 : n, n1 = batch ? N : n + 1;
+          for (int nn = n0; nn < n1; ++nn) { I += sums[3 * (nn * C + cc)]; P += sums[3 * (nn * C + cc) + 1]; G += sums[3 * (nn * C + cc) + 2]; }
+          const bool empty = G == 0.0;
+          if (pass == 0) { if (!empty) { const double w = 1.0 / (G * G); wmax = w > wmax ? w : wmax; } continue; }
+          const double w = empty ? wmax : 1.0 / (G * G);
+          numer += 2.0 * w * I; denom += w * (G + P);
+          if (cc == c) wme = w;
+        }
+      }
+      coef[2 * i] = (float)((double)grad_scale * 2.0 * wme / (K * denom));
+      coef[2 * i + 1] = (float)((double)grad_scale * numer * wme / (K * denom * denom));
+      if (c == c0 && (!batch || n == 0)) f += (1.0 - numer / denom) / K;
+    }
   }
   fsum[threadIdx.x] = f;
   __syncthreads();
   for (int s = blockDim.x / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) fsum[threadIdx.x] += fsum[threadIdx.x + s]; __syncthreads(); }
-  if (threadIdx.x == 0) loss[0] = (float)(fsum[0] / K);
+  if (threadIdx.x == 0) loss[0] = (float)fsum[0];
 }
 
 __global__ void dice_grad_kernel(const float* logits, const void* target, int target_u8, long long V, int NC, int sigmoid, int squared,
@@ -188,16 +221,20 @@ extern "C" size_t mi355_dice_workspace(int32_t n, int32_t c, int64_t voxels) {
 }
 
 extern "C" int mi355_dice_fwd_bwd(const float* logits, const void* target, int32_t target_is_u8, int32_t n, int32_t c, int64_t voxels,
-                                  int32_t sigmoid, int32_t batch, int32_t squared_pred, float smooth_nr, float smooth_dr,
-                                  float* loss, float* dlogits, float grad_scale, void* ws, size_t ws_bytes, void* stream) {
+                                  int32_t sigmoid, int32_t batch, int32_t squared_pred, int32_t variant, int32_t include_background,
+                                  float smooth_nr, float smooth_dr, float* loss, float* dlogits, float grad_scale, void* ws,
+                                  size_t ws_bytes, void* stream) {
   if (!logits || !target || !loss || !ws || n <= 0 || c <= 0 || voxels <= 0) return MI355_EINVAL;
+  if (variant < MI355_DICE_PLAIN || variant > MI355_DICE_GENERALIZED || (variant == MI355_DICE_GENERALIZED && squared_pred)) return MI355_EINVAL;
+  if (!include_background && c < 2) return MI355_EINVAL;
   if ((size_t)n * c > 1024) return MI355_EUNSUPPORTED;
   if (ws_bytes < mi355_dice_workspace(n, c, voxels)) return MI355_EWORKSPACE;
   const int NC = n * c, B = dice_blocks(voxels);
   float* part = (float*)ws; float* stats = part + (size_t)NC * B * 3; float* coef = stats + (size_t)NC * 3;
   LAUNCH(dice_partial_kernel, dim3(B, NC), dim3(256), 0, stream, logits, target, target_is_u8, (long long)voxels, sigmoid, squared_pred, part);
   int rc = LAUNCH_CHECK(); if (rc) return rc;
-  LAUNCH(dice_finalize_kernel, dim3(1), dim3(256), 0, stream, (const float*)part, B, n, c, batch, smooth_nr, smooth_dr, grad_scale, stats, coef, loss);
+  LAUNCH(dice_finalize_kernel, dim3(1), dim3(256), 0, stream, (const float*)part, B, n, c, batch, smooth_nr, smooth_dr, grad_scale, variant,
+         include_background ? 0 : 1, stats, coef, loss);
   rc = LAUNCH_CHECK(); if (rc) return rc;
   if (dlogits) {
     const long long total = (long long)NC * voxels;

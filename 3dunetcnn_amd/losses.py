@@ -23,7 +23,8 @@ class _DiceFunction(torch.autograd.Function):
         be = mod._be or _ops.default_backend()
         want = ctx.needs_input_grad[0]
         loss, dlogits = be.dice(logits.contiguous(), target.contiguous(), sigmoid=mod.sigmoid, batch=mod.batch,
-                                squared_pred=mod.squared_pred, smooth_nr=mod.smooth_nr, smooth_dr=mod.smooth_dr, want_grad=want)
+                                squared_pred=mod.squared_pred, smooth_nr=mod.smooth_nr, smooth_dr=mod.smooth_dr, want_grad=want,
+                                generalized=mod.generalized, include_background=mod.include_background)
         ctx.dlogits = dlogits
         return loss.reshape(())
 
@@ -39,8 +40,6 @@ class HipDiceLoss(nn.Module):
                  squared_pred=False, jaccard=False, reduction="mean", smooth_nr=1e-5, smooth_dr=1e-5, batch=False, weight=None):
         super().__init__()
         unsupported = []
-        if not include_background:
-            unsupported.append("include_background=False")
         if to_onehot_y:
             unsupported.append("to_onehot_y=True")
         if softmax:
@@ -60,11 +59,16 @@ class HipDiceLoss(nn.Module):
         self.batch = bool(batch)
         self.smooth_nr = float(smooth_nr)
         self.smooth_dr = float(smooth_dr)
+        self.include_background = bool(include_background)
         self._be = None
+
+    generalized = False
 
     def forward(self, input, target):
         if input.device.type != "cuda" and self._be is None:
-            raise RuntimeError("HipDiceLoss runs on an MI355X only (no CPU fallback)")
+            raise RuntimeError(f"{type(self).__name__} runs on an MI355X only (no CPU fallback)")
+        if not self.include_background and input.shape[1] == 1:
+            raise ValueError("single channel prediction, `include_background=False` ignored is not supported: pass include_background=True")
         if target.shape != input.shape:
             raise AssertionError(f"ground truth has different shape ({tuple(target.shape)}) from input ({tuple(input.shape)})")
         if target.dtype not in (torch.uint8, torch.float32):
@@ -82,7 +86,8 @@ class _CEFunction(torch.autograd.Function):
         loss = dlogits = None
         if mod.lambda_dice != 0.0:
             loss, dlogits = be.dice(logits, target, sigmoid=mod.sigmoid, batch=mod.batch, squared_pred=mod.squared_pred,
-                                    smooth_nr=mod.smooth_nr, smooth_dr=mod.smooth_dr, want_grad=want, grad_scale=mod.lambda_dice)
+                                    smooth_nr=mod.smooth_nr, smooth_dr=mod.smooth_dr, want_grad=want, grad_scale=mod.lambda_dice,
+                                    include_background=mod.include_background)
             loss.mul_(mod.lambda_dice)
         if mod.lambda_ce != 0.0:
             loss, dlogits = be.cross_entropy(logits, target, mode=mod.ce_mode, weight=mod.lambda_ce, loss=loss,
@@ -97,7 +102,21 @@ class _CEFunction(torch.autograd.Function):
         return d * g, None, None
 
 
+class HipGeneralizedDiceLoss(HipDiceLoss):
+    """monai.losses.GeneralizedDiceLoss(w_type="square") -- the loss doc/Configuration.md:41 of the reference configures
+    ({"name": "GeneralizedDiceLoss", "include_background": false, "sigmoid": true})."""
+    generalized = True
+
+    def __init__(self, include_background=True, to_onehot_y=False, sigmoid=False, softmax=False, other_act=None, w_type="square",
+                 reduction="mean", smooth_nr=1e-5, smooth_dr=1e-5, batch=False):
+        if str(getattr(w_type, "value", w_type)).lower() != "square":
+            raise NotImplementedError("HipGeneralizedDiceLoss implements w_type='square' (the MONAI default)")
+        super().__init__(include_background=include_background, to_onehot_y=to_onehot_y, sigmoid=sigmoid, softmax=softmax,
+                         other_act=other_act, reduction=reduction, smooth_nr=smooth_nr, smooth_dr=smooth_dr, batch=batch)
+
+
 class _CEBase(nn.Module):
+    include_background = True
     sigmoid = True
     squared_pred = batch = False
     smooth_nr = smooth_dr = 1e-5
@@ -122,7 +141,7 @@ class HipDiceCELoss(_CEBase):
                  jaccard=False, reduction="mean", smooth_nr=1e-5, smooth_dr=1e-5, batch=False, weight=None, lambda_dice=1.0,
                  lambda_ce=1.0, label_smoothing=0.0):
         super().__init__()
-        bad = [k for k, v in dict(include_background=not include_background, to_onehot_y=to_onehot_y, softmax=softmax,
+        bad = [k for k, v in dict(to_onehot_y=to_onehot_y, softmax=softmax,
                                   other_act=other_act is not None, jaccard=jaccard, reduction=reduction != "mean",
                                   weight=weight is not None, label_smoothing=label_smoothing != 0.0).items() if v]
         if bad:
@@ -130,6 +149,7 @@ class HipDiceCELoss(_CEBase):
         self.sigmoid, self.squared_pred, self.batch = bool(sigmoid), bool(squared_pred), bool(batch)
         self.smooth_nr, self.smooth_dr = float(smooth_nr), float(smooth_dr)
         self.lambda_dice, self.lambda_ce = float(lambda_dice), float(lambda_ce)
+        self.include_background = bool(include_background)      # Dice term only (MONAI: the CE term always sees every channel)
         self._be = None
 
     def forward(self, input, target):

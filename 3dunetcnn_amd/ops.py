@@ -344,7 +344,7 @@ class Backend:
 
     # -- loss / optimizer ----------------------------------------------------------------------------------------
     def dice(self, logits, target, sigmoid=True, batch=False, squared_pred=False, smooth_nr=1e-5, smooth_dr=1e-5,
-             want_grad=True, grad_scale=1.0):
+             want_grad=True, grad_scale=1.0, generalized=False, include_background=True):
         assert logits.is_contiguous() and target.is_contiguous() and logits.dtype == torch.float32
         assert target.dtype in (torch.uint8, torch.float32) and target.shape == logits.shape
         n, c = logits.shape[0], logits.shape[1]
@@ -353,7 +353,8 @@ class Backend:
         dlogits = torch.empty_like(logits) if want_grad else None
         ws = self.ws(self.lib.mi355_dice_workspace(n, c, vox))
         check(self.lib.mi355_dice_fwd_bwd(logits.data_ptr(), target.data_ptr(), 1 if target.dtype == torch.uint8 else 0, n, c, vox,
-                                          int(sigmoid), int(batch), int(squared_pred), smooth_nr, smooth_dr, loss.data_ptr(),
+                                          int(sigmoid), int(batch), int(squared_pred), int(generalized), int(include_background), smooth_nr,
+                                          smooth_dr, loss.data_ptr(),
                                           _p(dlogits), grad_scale, ws.data_ptr(), ws.numel() * 4, self.stream()), "dice_fwd_bwd")
         return loss, dlogits
 

@@ -16,7 +16,7 @@ import torch
 
 def register(replace=False):
     from .dynunet import HipDynUNet
-    from .losses import HipBCEWithLogitsLoss, HipCrossEntropyLoss, HipDiceCELoss, HipDiceLoss
+    from .losses import HipBCEWithLogitsLoss, HipCrossEntropyLoss, HipDiceCELoss, HipDiceLoss, HipGeneralizedDiceLoss
     from .optim import HipAdam
     from .unet import HipAutocastUNet, HipAutoImplantUNet, HipUNet3D
     done = {}
@@ -37,7 +37,8 @@ def register(replace=False):
         done["models"] = []
     try:
         losses = importlib.import_module("unet3d.losses")
-        hip_losses = {"HipDiceLoss": HipDiceLoss, "HipDiceCELoss": HipDiceCELoss, "HipBCEWithLogitsLoss": HipBCEWithLogitsLoss,
+        hip_losses = {"HipDiceLoss": HipDiceLoss, "HipDiceCELoss": HipDiceCELoss, "HipGeneralizedDiceLoss": HipGeneralizedDiceLoss,
+                      "HipBCEWithLogitsLoss": HipBCEWithLogitsLoss,
                       "HipCrossEntropyLoss": HipCrossEntropyLoss}
         for name, cls in hip_losses.items():
             setattr(losses, name, cls)

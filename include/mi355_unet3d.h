@@ -224,11 +224,16 @@ int mi355_resample_affine(const float* src, float* dst, int32_t c, int32_t sd, i
 /* monai.losses.DiceLoss as configured by examples/brats2020/brats2020_config.json:112-116 (sigmoid=True,
  * include_background=True, smooth_nr=smooth_dr=1e-5, reduction="mean"), plus `batch` and `squared_pred`.
  * logits fp32 NCDHW, target uint8 or fp32 NCDHW (target_is_u8). Writes loss[0] and, if dlogits != NULL,
- * dloss/dlogits (scaled by grad_scale). stats: [n*c*3] floats scratch kept for inspection (I, sum p, sum y). */
+ * dloss/dlogits (scaled by grad_scale). stats: [n*c*3] floats scratch kept for inspection (I, sum p, sum y).
+ * variant MI355_DICE_GENERALIZED: monai.losses.GeneralizedDiceLoss (w_type "square"; the loss doc/Configuration.md:41 configures);
+ * include_background == 0 leaves channel 0 out (both variants). */
+#define MI355_DICE_PLAIN 0
+#define MI355_DICE_GENERALIZED 1
 size_t mi355_dice_workspace(int32_t n, int32_t c, int64_t voxels);
 int mi355_dice_fwd_bwd(const float* logits, const void* target, int32_t target_is_u8, int32_t n, int32_t c, int64_t voxels,
-                       int32_t sigmoid, int32_t batch, int32_t squared_pred, float smooth_nr, float smooth_dr,
-                       float* loss, float* dlogits, float grad_scale, void* ws, size_t ws_bytes, void* stream);
+                       int32_t sigmoid, int32_t batch, int32_t squared_pred, int32_t variant, int32_t include_background,
+                       float smooth_nr, float smooth_dr, float* loss, float* dlogits, float grad_scale, void* ws, size_t ws_bytes,
+                       void* stream);
 
 /* ---- cross-entropy --------------------------------------------------------------------------- */
 /* The cross-entropy leg of the reference's loss look-up (scripts/script_utils.py:61-77: torch.nn.BCEWithLogitsLoss /

@@ -48,11 +48,14 @@ def conv_transpose_pad(x, w, bias, target_dhw):
     return F.pad(y, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2, dz // 2, dz - dz // 2])
 
 
-def dice_loss(logits, target, sigmoid=True, batch=False, squared_pred=False, smooth_nr=1e-5, smooth_dr=1e-5):
-    """monai.losses.DiceLoss(include_background=True, reduction="mean") restated (MONAI >= 1.2 is un-vendored and
-    unpinned: requirements.txt:4). Call site unet3d/scripts/script_utils.py:72; config brats2020_config.json:112-116."""
+def dice_loss(logits, target, sigmoid=True, batch=False, squared_pred=False, smooth_nr=1e-5, smooth_dr=1e-5, include_background=True):
+    """monai.losses.DiceLoss(reduction="mean") restated (MONAI >= 1.2 is un-vendored and unpinned: requirements.txt:4).
+    Call site unet3d/scripts/script_utils.py:72; config brats2020_config.json:112-116. include_background=False drops
+    channel 0 of both tensors first."""
     p = torch.sigmoid(logits) if sigmoid else logits
     y = target.to(p.dtype)
+    if not include_background:
+        p, y = p[:, 1:], y[:, 1:]
     axes = list(range(2, p.dim()))
     if batch:
         axes = [0] + axes
@@ -63,6 +66,34 @@ def dice_loss(logits, target, sigmoid=True, batch=False, squared_pred=False, smo
         g, q = torch.sum(y, dim=axes), torch.sum(p, dim=axes)
     f = 1.0 - (2.0 * inter + smooth_nr) / (g + q + smooth_dr)
     return torch.mean(f)
+
+
+def generalized_dice_loss(logits, target, sigmoid=True, batch=False, smooth_nr=1e-5, smooth_dr=1e-5, include_background=True):
+    """monai.losses.GeneralizedDiceLoss(w_type="square", reduction="mean") restated -- the loss doc/Configuration.md:41 configures
+    (include_background=False, sigmoid=True). PARITY UNPINNED: MONAI is not importable here; formula as published
+    (Sudre et al. 2017) with MONAI's handling of empty classes: an infinite weight is replaced by the largest finite weight of
+    the same sample (of the batch with batch=True)."""
+    p = torch.sigmoid(logits) if sigmoid else logits
+    y = target.to(p.dtype)
+    if not include_background:
+        p, y = p[:, 1:], y[:, 1:]
+    axes = list(range(2, p.dim()))
+    if batch:
+        axes = [0] + axes
+    inter = torch.sum(y * p, dim=axes)
+    g, q = torch.sum(y, dim=axes), torch.sum(p, dim=axes)
+    w = 1.0 / (g * g)
+    infs = torch.isinf(w)
+    w = torch.where(infs, torch.zeros_like(w), w)
+    if batch:
+        w = w + infs * torch.max(w)
+        dim = 0
+    else:
+        w = w + infs * torch.max(w, dim=1, keepdim=True)[0]
+        dim = 1
+    numer = 2.0 * (inter * w).sum(dim) + smooth_nr
+    denom = ((g + q) * w).sum(dim) + smooth_dr
+    return torch.mean(1.0 - numer / denom)
 
 
 def adam_step(p, g, m, v, lr, b1, b2, eps, wd, step):

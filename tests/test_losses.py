@@ -21,8 +21,17 @@ def _data(n, c, dhw, seed=0):
     return z, t
 
 
-def _check(crit, ref_fn, be, dev, n, c, dhw):
+def _empty(t):
+    """Second class empty in sample 0 (infinite generalized-Dice weight -> largest finite weight of the sample)."""
+    t = t.clone()
+    t[0, 1] = 0
+    return t
+
+
+def _check(crit, ref_fn, be, dev, n, c, dhw, name=""):
     z, t = _data(n, c, dhw)
+    if "empty" in name:
+        t = _empty(t)
     zr = z.clone().requires_grad_(True)
     ref = ref_fn(zr, t)
     ref.backward()
@@ -41,6 +50,11 @@ CASES = [
     ("dicece_weighted", lambda: losses.HipDiceCELoss(sigmoid=True, lambda_dice=0.3, lambda_ce=2.0, batch=True),
      lambda z, t: 0.3 * O.dice_loss(z, t, True, True) + 2.0 * F.cross_entropy(z, t.float()), 3),
     ("dicece_1ch", lambda: losses.HipDiceCELoss(sigmoid=True), lambda z, t: O.dice_loss(z, t, True) + F.binary_cross_entropy_with_logits(z, t.float()), 1),
+    ("dice_nobg", lambda: losses.HipDiceLoss(sigmoid=True, include_background=False), lambda z, t: O.dice_loss(z, t, True, include_background=False), 3),
+    ("gdl_doc_config", lambda: losses.HipGeneralizedDiceLoss(include_background=False, sigmoid=True),
+     lambda z, t: O.generalized_dice_loss(z, t, True, include_background=False), 4),
+    ("gdl_batch", lambda: losses.HipGeneralizedDiceLoss(sigmoid=True, batch=True), lambda z, t: O.generalized_dice_loss(z, t, True, batch=True), 3),
+    ("gdl_empty_class", lambda: losses.HipGeneralizedDiceLoss(sigmoid=True), lambda z, t: O.generalized_dice_loss(z, _empty(t), True), 3),
     ("bce", lambda: losses.HipBCEWithLogitsLoss(), lambda z, t: F.binary_cross_entropy_with_logits(z, t.float()), 3),
     ("ce", lambda: losses.HipCrossEntropyLoss(), lambda z, t: F.cross_entropy(z, t.float()), 4),
 ]
@@ -48,13 +62,13 @@ CASES = [
 
 @pytest.mark.parametrize("name,mk,ref,c", CASES, ids=[c[0] for c in CASES])
 def test_losses_on_emulator(emu_backend, name, mk, ref, c):
-    _check(mk(), ref, emu_backend, "cpu", 2, c, (9, 8, 10))
+    _check(mk(), ref, emu_backend, "cpu", 2, c, (9, 8, 10), name)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,mk,ref,c", CASES, ids=[c[0] for c in CASES])
 def test_losses_gpu(name, mk, ref, c):
-    _check(mk(), ref, None, "cuda", 2, c, (40, 48, 36))
+    _check(mk(), ref, None, "cuda", 2, c, (40, 48, 36), name)
 
 
 def test_unsupported_options_raise():
