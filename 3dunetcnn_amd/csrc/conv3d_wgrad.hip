@@ -7,14 +7,15 @@
 // (myronenko.py:18-19), recomputed from x and the saved per-(n,c) scale/shift instead of storing the
 // activated tensor.
 //
-// GEMM view per tap: D[co][ci] (32x32 MFMA tile) += A[co][voxel] * B[voxel][ci], K = voxels (2 per MFMA).
-// A workgroup owns one (32 co) x (32 ci) pair, walks a contiguous range of output-voxel tiles (split-K),
-// stages dy[tile][32co] and the haloed x tile [halo][32ci] in LDS in their natural voxel-major layout (so both
-// MFMA operands are conflict-free ds_read_b32: 32 consecutive channels per half-wave), and keeps the 27
-// tap accumulators distributed over its 4 waves (7/7/7/6). Partial tiles go to a workspace slab; a second
-// kernel reduces the slabs in a fixed order (deterministic, no atomics) and writes OIDHW.
+// GEMM view per tap: D[co][ci] (32x32 MFMA tile) += A[co][voxel] * B[voxel][ci], K = voxels (2 per MFMA). Both operands sit in LDS
+// in their natural voxel-major layout, so every MFMA operand is a conflict-free ds_read_b32 (32 consecutive channels per
+// half-wave), and the 27 tap accumulators are distributed over the 4 waves of a workgroup (7/7/7/6). Partial tiles go to a
+// workspace slab; a second kernel reduces the slabs in a fixed order (deterministic, no atomics) and writes OIDHW.
+//   conv3d_wgrad_ring : 3x3x3 stride 1 (the dominant kernel of the training step): 4x8 columns marched along z through an LDS ring
+//                       of input planes, global loads overlapped with the MFMA loop (below).
+//   conv3d_wgrad_mfma : 3x3x3 stride 2 and 1x1x1 (incl. the depth-to-space transposed-conv form): split-K over voxel tiles staged
+//                       whole in LDS, register-prefetch software pipeline.
 #include "hipcompat.h"
-#include <cstdlib>
 #include "../../include/mi355_unet3d.h"
 
 struct WgradArgs {
@@ -156,82 +157,12 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
     }
   };
 
-  // PIPE: keep tile t+1 in registers across the MFMA loop of tile t. It pays where the MFMA loop is short relative to the
-  // staging (1x1x1, stride 2); for 3x3x3 stride 1 the 64 extra live registers would halve the occupancy (7 accumulator tiles =
-  // 112 AGPRs), so there the tile is loaded (all loads in flight at once) and committed back to back.
-  constexpr bool PIPE = (KD == 1) || (STRIDE == 2);
-  // non-pipelined staging: batches of 4 units (loads of a batch in flight together), small live register set
-  constexpr int SB = 6;   // staging batch: 6 loads in flight per thread (8 would cost a wave of occupancy)
-  auto stage_direct = [&](int tile) {
-    int n, tz0, ty0, tx0;
-    decode(tile, n, tz0, ty0, tx0);
-#pragma unroll
-    for (int k0 = 0; k0 < UPD; k0 += SB) {
-      float4 ld[SB];
-#pragma unroll
-      for (int kk = 0; kk < SB; ++kk) {
-        if (k0 + kk >= UPD) continue;
-        int v = sv0 + (k0 + kk) * 32; if (v >= TV) v = TV - 1;
-        int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
-        oz = oz < a.Do ? oz : a.Do - 1; oy = oy < a.Ho ? oy : a.Ho - 1; ox = ox < a.Wo ? ox : a.Wo - 1;
-        ld[kk] = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.dyld + (dyvalid ? cdy : 0));
-      }
-#pragma unroll
-      for (int kk = 0; kk < SB; ++kk) {
-        if (k0 + kk >= UPD) continue;
-        const int v = sv0 + (k0 + kk) * 32;
-        if (v >= TV) continue;
-        const int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
-        const bool ok = dyvalid && oz < a.Do && oy < a.Ho && ox < a.Wo;
-        *reinterpret_cast<float4*>(lds_dy + v * 32 + 4 * sq) = ok ? ld[kk] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
-    if (INMODE == MI355_IN_AFFINE_ACT && xvalid) {
-      sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + cx);
-      sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + cx);
-      if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + cx);
-    }
-#pragma unroll
-    for (int k0 = 0; k0 < UPX; k0 += SB) {
-      float4 ld[SB];
-#pragma unroll
-      for (int kk = 0; kk < SB; ++kk) {
-        if (k0 + kk >= UPX) continue;
-        int hv = sv0 + (k0 + kk) * 32; if (hv >= HV) hv = HV - 1;
-        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
-        int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
-        iz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
-        iy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
-        ix = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
-        ld[kk] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (xvalid ? cx : 0));
-      }
-#pragma unroll
-      for (int kk = 0; kk < SB; ++kk) {
-        if (k0 + kk >= UPX) continue;
-        const int hv = sv0 + (k0 + kk) * 32;
-        if (hv >= HV) continue;
-        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
-        const int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy, ix = tx0 * STRIDE - a.pad + hx;
-        const bool ok = xvalid && iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi;
-        float4 v = ld[kk];
-        if (INMODE == MI355_IN_AFFINE_ACT) {
-          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-          v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
-          v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
-        }
-        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(lds_x + hv * 32 + 4 * sq) = v;
-      }
-    }
-  };
-  if (PIPE && t_begin < t_end) prefetch(t_begin);
+  if (t_begin < t_end) prefetch(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();                 // every wave is done reading the previous tile
-    if (PIPE) commit(tile); else stage_direct(tile);
+    commit(tile);
     __syncthreads();
-    if (PIPE && tile + 1 < t_end) prefetch(tile + 1);
+    if (tile + 1 < t_end) prefetch(tile + 1);
     SCHED_BARRIER();                 // keep the prefetch loads above the MFMA loop
     // ---- K loop over voxel pairs ----
     constexpr int KSTEPS = TV / 2 / WV;
