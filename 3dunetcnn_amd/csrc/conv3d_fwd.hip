@@ -13,7 +13,6 @@
 // K ordering inside an 8-channel group: lanes 0-31 own channels 0..3, lanes 32-63 channels 4..7, k-step s uses
 // (s, 4+s); A and B use the same permutation so the sum is unchanged.
 #include "hipcompat.h"
-#include <cstdlib>
 #include "../../include/mi355_unet3d.h"
 
 struct ConvArgs {
@@ -404,10 +403,13 @@ static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
 //  2/3: 3x3x3 stride 2 (also the zero-insert form with stride template 1), 4x4x8 tiles, KC=8
 //  4/5: 3x3x3 stride 1, 4x8x8 tiles, KC=16 (large volumes: >= 131072 output voxels in the batch)
 //  6/7: 3x3x3 stride 1, 2x4x8 / 4x4x8 tiles, KC=32 (small volumes, so the grid still covers 256 CUs)
+//  8:   3x3x3 stride 1, 4x4x8 tiles x 64 output channels, KC=16, 2 M tiles per wave (32768 .. 131071 output voxels, > 32 output
+//       channels: each B fragment feeds two MFMA tiles; +10 % over configuration 6 on the 32^3-level layers)
 static int select_cfg(int kd, int stride, long long vox, int cout, int in_mode = MI355_IN_PLAIN) {
   if (kd == 1) return cout > 32 ? 0 : 1;
   if (stride == 2) return cout > 32 ? 2 : 3;
   if (vox >= 256LL * 512 || in_mode == MI355_IN_ZERO_INSERT) return cout > 32 ? 4 : 5;   // zero-insert: parity-class tiles need 4x8x8
+  if (cout > 32 && vox >= 64LL * 512) return 8;
   return cout > 32 ? 6 : 7;
 }
 
@@ -482,6 +484,7 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
     case 4: return launch_cfg<3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 2>(a, im, stream);
     case 5: return launch_cfg<3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 1>(a, im, stream);
     case 6: return launch_cfg<3, 1, 2, 4, 8, 32, 4, 2, 2, 1, 1>(a, im, stream);
+    case 8: return launch_cfg<3, 1, 4, 4, 8, 16, 4, 2, 2, 2, 1>(a, im, stream);
     default: return launch_cfg<3, 1, 4, 4, 8, 32, 4, 4, 1, 1, 1>(a, im, stream);
   }
 }
@@ -493,11 +496,12 @@ extern "C" int mi355_conv3d_fwd_config(const mi355_act* x, const mi355_act* y, c
   const int cfg = select_cfg(d->kd, d->stride, (long long)d->out_d * d->out_h * d->out_w * x->n,
                              (d->kd == 1 && d->out_mode == MI355_OUT_D2S) ? 8 * y->c : y->c, d->in_mode);
   const int stride_t = d->in_mode == MI355_IN_ZERO_INSERT ? 1 : d->stride;
-  static const char* const tags[8] = {"1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 2", "1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 1",
+  static const char* const tags[9] = {"1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 2", "1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 1",
                                       "4, 4, 8, 8, 0, 4, 1, 1, 2", "4, 4, 8, 8, 0, 4, 1, 1, 1",
                                       "3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 2", "3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 1",
-                                      "3, 1, 2, 4, 8, 32, 4, 2, 2, 1, 1", "3, 1, 4, 4, 8, 32, 4, 4, 1, 1, 1"};
-  static const int kcs[8] = {32, 32, 8, 8, 16, 16, 32, 32};
+                                      "3, 1, 2, 4, 8, 32, 4, 2, 2, 1, 1", "3, 1, 4, 4, 8, 32, 4, 4, 1, 1, 1",
+                                      "3, 1, 4, 4, 8, 16, 4, 2, 2, 2, 1"};
+  static const int kcs[9] = {32, 32, 8, 8, 16, 16, 32, 32, 16};
   const int cinP = (x->c + 7) / 8 * 8;
   const bool one = cfg == 3 || cfg == 6 || cfg == 7;     // MT * NT == 1
   const bool four = cfg == 2 || cfg == 4;                 // MT * NT == 4 (cfg 2: NT = 2, MT = 1 -> 2 tiles, allowed)

@@ -26,6 +26,13 @@ def test_conv_fwd(emu_backend, kw):
     assert C.case_conv_fwd(emu_backend, **kw) < TOL
 
 
+def test_conv_fwd_mid_tile(emu_backend):
+    # 32768 .. 131071 output voxels with > 32 output channels: 4x4x8 tiles, two M tiles per wave (configuration 8)
+    assert C.case_conv_fwd(emu_backend, 1, 8, 64, (8, 16, 256), norm=True, residual=True) < TOL
+    assert C.case_conv_fwd(emu_backend, 1, 24, 40, (9, 15, 250)) < TOL      # ragged tiles, a partial last channel chunk (24 = 16 + 8)
+    assert C.case_conv_dgrad(emu_backend, 1, 64, 8, (8, 16, 256)) < TOL
+
+
 def test_conv_fwd_big_tile(emu_backend):
     # >= 131072 voxels selects the 4x8x8 / KC=16 configuration used at 128^3
     assert C.case_conv_fwd(emu_backend, 1, 8, 64, (8, 16, 128 * 8), residual=True) < TOL

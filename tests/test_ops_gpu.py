@@ -71,6 +71,14 @@ def test_cross_entropy(hip_backend, kw):
     assert ok(C.case_ce(hip_backend, 1, 5, (6, 7, 9), **kw))
 
 
+def test_conv_fwd_mid_tile(hip_backend):
+    # 32768 .. 131071 output voxels, > 32 output channels: configuration 8 (4x4x8 tiles, two M tiles per wave), deep K with the
+    # two-level accumulation, ragged extents; and the dgrad that runs through the same configuration
+    assert C.case_conv_fwd(hip_backend, 2, 128, 128, (32, 32, 32), norm=True, residual=True) < TOL
+    assert C.case_conv_fwd(hip_backend, 1, 40, 96, (31, 33, 38)) < TOL
+    assert C.case_conv_dgrad(hip_backend, 1, 64, 32, (32, 32, 40)) < TOL
+
+
 # first-layer (4 input channels) kernels, csrc/conv3d_c4.hip: ragged extents, wide/odd output channel counts, concat slices
 @pytest.mark.parametrize("kw", [
     dict(n=1, cin=4, cout=32, dhw=(5, 9, 11)),
