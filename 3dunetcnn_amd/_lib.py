@@ -30,7 +30,7 @@ class MiConvDesc(Structure):
 
 IN_PLAIN, IN_AFFINE_ACT, IN_ZERO_INSERT, IN_S2D = 0, 1, 2, 3
 OUT_PLAIN, OUT_D2S = 0, 1
-W_PACKED, W_OIDHW4 = 0, 1
+W_PACKED, W_OIDHW4, W_PACKED_F32_NARROW = 0, 1, 2
 PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_BF16 = 0, 1, 2, 3
 PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "bf16": PREC_BF16}
 

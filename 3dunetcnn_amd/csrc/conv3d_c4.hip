@@ -220,6 +220,99 @@ __global__ __launch_bounds__(256) void conv3d_c4_wgrad_reduce(const float* ws, f
   }
 }
 
+// ---- dgrad of the first layer: 3x3x3 stride-1 conv with <= 4 OUTPUT channels on the vector ALU ----
+// The gradient wrt the activated first-layer input (needed for the gamma/beta gradients of the network's first norm) is a
+// conv Cout -> 4. On the 32-wide MFMA N tile 7/8 of the matrix work would be padding (measured: 2.0 ms at 128^3, batch 2 --
+// as long as a 32 -> 32 layer). Here one thread owns one output voxel and its <= 4 output channels: the haloed input tile
+// (6x10x10 voxels x 32 channels = 76.8 KB, XOR-swizzled by (x + y) so the ds_read_b128 of 8 x-neighbours and of two y rows
+// are bank-conflict free without padding) is staged once per 32-channel chunk; per (tap, 4-channel group) a thread issues one
+// ds_read_b128 and 8 packed FMAs whose weight operands are wave-uniform (scalar loads straight from the packed
+// [tap][ci/4][32][4] buffer, only the first 4 of the 32 padded output columns are touched). fp32 FMA chains: exact products.
+struct NarrowArgs {
+  const float* x; int xld;
+  const float* wp;                 // fp32 pack [27][CinQ][32][4]
+  float* y; int yld;
+  int N, D, H, W, Cq, CinQ, Cout;   // Cq = input channels / 4 (real quads), CinQ = quads of the pack (cinP / 4)
+  int tilesZ, tilesY, tilesX, spatialTiles;
+};
+
+__global__ __launch_bounds__(256) void conv3d_c4_dgrad(NarrowArgs a) {
+  constexpr int TZ = 4, TY = 8, TX = 8, HZ = 6, HY = 10, HX = 10, HV = HZ * HY * HX;
+  DYN_LDS(lds_f);                           // float4 [HV][8], quad q of haloed voxel (hz,hy,hx) at slot q ^ ((hx + hy) & 7)
+  float4* lds = reinterpret_cast<float4*>(lds_f);
+  const int tid = threadIdx.x, lz = tid >> 6, ly = (tid >> 3) & 7, lx = tid & 7;
+  int b = blockIdx.x;
+  {                                         // XCD-aware order: each XCD (workgroup id % 8) walks a contiguous range of tiles
+    const int per = a.spatialTiles / 8;
+    if (b < per * 8) b = (b & 7) * per + (b >> 3);
+  }
+  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+  const int tz0 = (b % a.tilesZ) * TZ; b /= a.tilesZ;
+  const int n = b;
+  pkf2 acc[4][2];                           // per output channel: partial sums over input channels 4q + {0,1} and 4q + {2,3}
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[o][0] = acc[o][1] = make_pkf2(0.f, 0.f);
+  constexpr int UNITS = HV * 8, UP = (UNITS + 255) / 256;
+  for (int c0 = 0; c0 < a.Cq; c0 += 8) {
+    const int nq = a.Cq - c0 < 8 ? a.Cq - c0 : 8;
+    __syncthreads();
+    {
+      float4 ld[UP];
+#pragma unroll
+      for (int k = 0; k < UP; ++k) {        // all loads first, from clamped always-valid addresses
+        int u = tid + k * 256; if (u >= UNITS) u = UNITS - 1;
+        const int hv = u >> 3; int q = u & 7; if (q >= nq) q = nq - 1;
+        int iz = tz0 - 1 + hv / (HY * HX), iy = ty0 - 1 + (hv / HX) % HY, ix = tx0 - 1 + hv % HX;
+        iz = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1);
+        iy = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1);
+        ix = ix < 0 ? 0 : (ix < a.W ? ix : a.W - 1);
+        ld[k] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + 4 * (c0 + q));
+      }
+#pragma unroll
+      for (int k = 0; k < UP; ++k) {
+        const int u = tid + k * 256;
+        if (u >= UNITS) continue;
+        const int hv = u >> 3, q = u & 7;
+        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+        const int iz = tz0 - 1 + hz, iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+        const bool ok = q < nq && iz >= 0 && iy >= 0 && ix >= 0 && iz < a.D && iy < a.H && ix < a.W;
+        lds[hv * 8 + (q ^ ((hx + hy) & 7))] = ok ? ld[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    __syncthreads();
+    for (int tap = 0; tap < 27; ++tap) {
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      const int hy = ly + dy, hx = lx + dx;
+      const int hv = ((lz + dz) * HY + hy) * HX + hx, sw = (hx + hy) & 7;
+      const float* wt = a.wp + (size_t)tap * a.CinQ * 128;              // [CinQ][32 output columns][4]: columns 0..3 used
+      float4 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = lds[hv * 8 + (q ^ sw)];        // all eight reads in flight before the first FMA
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        // branch-free over the chunk: quads past the input's last one hold zeros in LDS; their weight address is clamped
+        // into the pack (0 * w contributes nothing)
+        const int qq = c0 + q < a.CinQ ? c0 + q : a.CinQ - 1;
+        const float* wq = wt + qq * 128;
+        const pkf2 vlo = make_pkf2(v[q].x, v[q].y), vhi = make_pkf2(v[q].z, v[q].w);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          acc[o][0] = pk_fma(vlo, make_pkf2(wq[o * 4 + 0], wq[o * 4 + 1]), acc[o][0]);
+          acc[o][1] = pk_fma(vhi, make_pkf2(wq[o * 4 + 2], wq[o * 4 + 3]), acc[o][1]);
+        }
+      }
+    }
+  }
+  const int oz = tz0 + lz, oy = ty0 + ly, ox = tx0 + lx;
+  if (oz < a.D && oy < a.H && ox < a.W) {
+    float* dst = a.y + ((((size_t)n * a.D + oz) * a.H + oy) * a.W + ox) * a.yld;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      if (o < a.Cout) dst[o] = (acc[o][0].x + acc[o][0].y) + (acc[o][1].x + acc[o][1].y);
+  }
+}
+
 static void c4_fill(C4Args& a, const mi355_act* x, const mi355_conv_desc* d) {
   memset(&a, 0, sizeof(a));
   a.x = (const float*)x->p; a.xld = x->ld;
@@ -279,5 +372,28 @@ int mi355_conv3d_c4_wgrad_impl(const mi355_act* x, const mi355_act* dy, float* d
   else LAUNCH((conv3d_c4_wgrad<MI355_IN_AFFINE_ACT>), grid, dim3(256), 0, stream, a);
   int rc = LAUNCH_CHECK(); if (rc) return rc;
   LAUNCH(conv3d_c4_wgrad_reduce, dim3(a.coTiles * 128), dim3(256), 0, stream, (const float*)ws, dw, a.Cout, a.splits);
+  return LAUNCH_CHECK();
+}
+
+// 3x3x3 stride-1 pad-1 conv with <= 4 output channels from the fp32 pack (any mode of mi355_pack_conv_weight), no epilogue fusion
+int mi355_conv3d_narrow_ok(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d) {
+  return x && y && d && y->c >= 1 && y->c <= 4 && x->c % 4 == 0 && d->kd == 3 && d->stride == 1 && d->pad == 1 &&
+         d->in_mode == MI355_IN_PLAIN && d->out_mode == MI355_OUT_PLAIN && !d->bias && !d->residual && !d->out_chscale &&
+         d->off_z == 0 && d->off_y == 0 && d->off_x == 0 && d->out_d == x->d && d->out_h == x->h && d->out_w == x->w &&
+         y->d == x->d && y->h == x->h && y->w == x->w;
+}
+
+int mi355_conv3d_narrow_impl(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
+  if (!mi355_conv3d_narrow_ok(x, y, d)) return MI355_EUNSUPPORTED;
+  NarrowArgs a; memset(&a, 0, sizeof(a));
+  a.x = (const float*)x->p; a.xld = x->ld; a.wp = wp; a.y = (float*)y->p; a.yld = y->ld;
+  a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cq = x->c / 4; a.CinQ = (x->c + 7) / 8 * 2; a.Cout = y->c;
+  a.tilesZ = ceil_div(a.D, 4); a.tilesY = ceil_div(a.H, 8); a.tilesX = ceil_div(a.W, 8);
+  const long long sp = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX;
+  if (sp <= 0 || sp > 0x7fffffffLL) return MI355_EINVAL;
+  a.spatialTiles = (int)sp;
+  constexpr size_t lds = (size_t)6 * 10 * 10 * 8 * 16;      // 76800 B: two workgroups per CU
+  SET_MAX_DYN_LDS(conv3d_c4_dgrad, lds);
+  LAUNCH(conv3d_c4_dgrad, dim3((unsigned)sp), dim3(256), lds, stream, a);
   return LAUNCH_CHECK();
 }

@@ -31,6 +31,10 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   f32x2_t v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+// two fp32 lanes per VGPR pair: v_pk_fma_f32 (the vector ALU's full fp32 rate needs the packed form)
+typedef f32x2_t pkf2;
+__device__ __forceinline__ pkf2 make_pkf2(float x, float y) { pkf2 v = {x, y}; return v; }
+__device__ __forceinline__ pkf2 pk_fma(pkf2 a, pkf2 b, pkf2 c) { return __builtin_elementwise_fma(a, b, c); }
 #define LAUNCH(kernel, grid, block, lds, stream, ...) \
   hipLaunchKernelGGL(kernel, (grid), (block), (lds), (hipStream_t)(stream), __VA_ARGS__)
 #define LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? 0 : -3)

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (IN_AFFINE_ACT, IN_PLAIN, IN_S2D, IN_ZERO_INSERT, OUT_D2S, OUT_PLAIN, PREC_F32, PRECISIONS, W_OIDHW4,  # noqa: F401
-                   MiAct, MiConvDesc, check)
+                   W_PACKED, W_PACKED_F32_NARROW, MiAct, MiConvDesc, check)
 
 
 class Act:
@@ -103,6 +103,11 @@ class PackedWeight:
                 and desc.in_mode in (IN_PLAIN, IN_AFFINE_ACT)):
             desc.wformat = W_OIDHW4        # first layer: dedicated (tap, ci)-fused kernel reads the unpacked weight
             return self.w.data_ptr()
+        if (self.cout <= 4 and self.kd == 3 and desc.stride == 1 and desc.pad == 1 and desc.in_mode == IN_PLAIN
+                and desc.out_mode == OUT_PLAIN and not (desc.bias or desc.residual or desc.out_chscale)
+                and desc.off_z == desc.off_y == desc.off_x == 0):
+            desc.wformat = W_PACKED_F32_NARROW   # <= 4 output channels (first-layer dgrad): exact-fp32 vector-ALU kernel, fp32 pack
+            return self.f32().data_ptr()
         if self.be.lib.mi355_conv3d_uses_bf16(ctypes.byref(desc)):
             return self.bf16(desc.precision).data_ptr()
         return self.f32().data_ptr()
@@ -176,11 +181,12 @@ class Backend:
             return
         # profiling: HIP events on the launch stream around this one kernel, keyed by the kernel's trace name
         name = ctypes.create_string_buffer(96)
+        wptr = wp.ptr_for(d)                          # also settles d.wformat
         self.lib.mi355_conv3d_fwd_config(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d), name, 96)
-        if self.lib.mi355_conv3d_uses_bf16(ctypes.byref(d)):
-            name.value = b"conv3d_k3_bf16<...>"
-        if wp.ptr_for(d) and d.wformat == W_OIDHW4:
+        if d.wformat == W_OIDHW4:
             name.value = b"conv3d_c4_fwd"
+        elif d.wformat == W_PACKED and self.lib.mi355_conv3d_uses_bf16(ctypes.byref(d)):
+            name.value = b"conv3d_k3_bf16<...>"
         nvox = x.shape[0] * out_dhw[0] * out_dhw[1] * out_dhw[2]
         flops = 2.0 * nvox * x.c * y.c * kd ** 3 * (8 if (in_mode == IN_S2D or out_mode == OUT_D2S) else 1)
         if in_mode == IN_ZERO_INSERT:
@@ -188,7 +194,7 @@ class Backend:
         byts = 4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * x.c + nvox * y.c + kd ** 3 * x.c * y.c)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wp.ptr_for(d), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
+        check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wptr, ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
         e1.record()
         self.prof.append((name.value.decode(), flops, byts, e0, e1))
 

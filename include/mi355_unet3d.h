@@ -92,6 +92,12 @@ typedef struct mi355_conv_desc {
                               (x->c == 4, IN_PLAIN / IN_AFFINE_ACT, OUT_PLAIN): the network's first layer runs on a dedicated
                               exact-fp32 kernel whose GEMM K index is the fused (tap, ci) pair (csrc/conv3d_c4.hip), whatever
                               `precision` says. mi355_conv3d_wgrad takes that path by itself whenever x->c == 4. */
+#define MI355_W_PACKED_F32_NARROW 2 /* the fp32 pack of mi355_pack_conv_weight, consumed by the narrow-output kernel whatever
+                              `precision` says: 3x3x3 stride-1 pad-1 conv with y->c <= 4 output channels, IN_PLAIN, OUT_PLAIN, no
+                              bias / residual / channel scale / window (the dgrad of the 4-channel first layer, which feeds the
+                              gamma/beta gradients of the network's first norm, myronenko.py:17-21). One thread per output voxel
+                              on the vector ALU (exact fp32 FMA chains) instead of a 32-wide MFMA N tile that would be 7/8
+                              padding. With MI355_W_PACKED and MI355_PREC_F32 such a call takes this kernel by itself. */
 
 /* ---- weight packing -------------------------------------------------------------------------- */
 /* Packed layout consumed by mi355_conv3d_fwd: wp[tap][cinP/4][coutP][4], cinP = roundup(cin,8),

@@ -49,6 +49,30 @@ def test_conv_dgrad(emu_backend, kw):
 
 
 @pytest.mark.parametrize("kw", [
+    dict(n=2, cin=4, cout=32, dhw=(5, 9, 11)),               # first-layer dgrad: <= 4 output channels -> vector-ALU kernel, ragged tiles
+    dict(n=1, cin=4, cout=64, dhw=(4, 8, 8)),                 # two 32-channel chunks (DynUNet input block width)
+    dict(n=1, cin=3, cout=40, dhw=(3, 5, 6)),                 # 3 dx channels; 40 dy channels = one full + one partial chunk
+    dict(n=1, cin=4, cout=12, dhw=(6, 3, 9)),                 # odd quad count (cinP has a zero-weight pad quad that is never read)
+])
+def test_conv_dgrad_first_layer(emu_backend, kw):
+    assert C.case_conv_dgrad(emu_backend, **kw) < TOL
+
+
+def test_conv_narrow_config_name(emu_backend):
+    import ctypes
+    be = emu_backend
+    xa, ya = be.empty_act(1, 4, 8, 8, 32), be.empty_act(1, 4, 8, 8, 4)
+    d = be._desc(3, 1, 1, C.ops.IN_PLAIN, 0.0, None, None, None, None, None, (0, 0, 0), (4, 8, 8), [])
+    xd, yd = xa.desc(), ya.desc()
+    name = ctypes.create_string_buffer(96)
+    be.lib.mi355_conv3d_fwd_config(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d), name, 96)
+    assert name.value == b"conv3d_c4_dgrad"
+    ya8 = be.empty_act(1, 4, 8, 8, 8).desc()
+    be.lib.mi355_conv3d_fwd_config(ctypes.byref(xd), ctypes.byref(ya8), ctypes.byref(d), name, 96)
+    assert name.value.startswith(b"conv3d_mfma<")
+
+
+@pytest.mark.parametrize("kw", [
     dict(n=2, cin=32, cout=32, dhw=(6, 7, 8)),
     dict(n=1, cin=4, cout=32, dhw=(8, 8, 8), norm=True),
     dict(n=1, cin=64, cout=96, dhw=(5, 5, 9), norm=True, slope=0.01),

@@ -42,6 +42,26 @@ def test_conv_dgrad(hip_backend, kw):
 
 
 @pytest.mark.parametrize("kw", [
+    dict(n=2, cin=4, cout=32, dhw=(33, 40, 47)),      # first-layer dgrad (<= 4 output channels): vector-ALU kernel, ragged tiles
+    dict(n=1, cin=4, cout=64, dhw=(16, 24, 32)),      # two 32-channel chunks (DynUNet input-block width)
+    dict(n=1, cin=3, cout=40, dhw=(9, 11, 13)),       # 3 output channels, partial second chunk
+    dict(n=1, cin=1, cout=12, dhw=(6, 7, 9)),         # odd quad count
+])
+def test_conv_dgrad_first_layer(hip_backend, kw):
+    assert C.case_conv_dgrad(hip_backend, **kw) < TOL
+
+
+def test_conv_dgrad_first_layer_every_precision_mode(hip_backend):
+    # the narrow-output kernel is exact fp32 whatever the backend's arithmetic mode (the fp32 pack is selected in ops.PackedWeight)
+    for mode in ("bf16x3", "bf16x6", "bf16"):
+        hip_backend.set_precision(mode)
+        try:
+            assert C.case_conv_dgrad(hip_backend, 1, 4, 32, (12, 16, 20)) < TOL
+        finally:
+            hip_backend.set_precision("fp32")
+
+
+@pytest.mark.parametrize("kw", [
     dict(n=2, cin=32, cout=32, dhw=(32, 32, 32), norm=True),
     dict(n=1, cin=4, cout=32, dhw=(32, 32, 32), norm=True),
     dict(n=1, cin=64, cout=96, dhw=(15, 15, 19), norm=True, slope=0.01),

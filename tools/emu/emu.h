@@ -191,6 +191,11 @@ static inline f32x16 emu_mfma_32x32x2(float a, float b, f32x16 c) {
 }
 #define MFMA_32x32x2(a, b, c) emu_mfma_32x32x2(a, b, c)
 
+// v_pk_fma_f32: two independent fmaf per lane
+struct pkf2 { float x, y; };
+static inline pkf2 make_pkf2(float x, float y) { return pkf2{x, y}; }
+static inline pkf2 pk_fma(pkf2 a, pkf2 b, pkf2 c) { return pkf2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+
 // bf16 helpers (round to nearest even, as v_cvt_pk_bf16_f32)
 static inline unsigned emu_f2bf(float f) {
   unsigned u = __float_as_uint(f);
