@@ -8,7 +8,8 @@ Dice need no cross-rank statistics.
 HipUNet3D writes parameter gradients into one flat buffer and reports each parameter as soon as its wgrad is enqueued
 (`model.grad_ready_callback`). Buckets are contiguous ranges of that buffer (default ~25 MB: with xGMI's
 point-to-point links a ring all-reduce is per-link bound at ~153 GB/s, so a 25 MB bucket costs ~0.3 ms while the
-backward producing it takes several ms); when the last parameter of a bucket is ready its all-reduce is launched with
+backward producing it takes several ms; the bucket holding the first encoder levels -- the last one backward completes,
+hence the only exposed one -- is cut to ~3 MB); when the last parameter of a bucket is ready its all-reduce is launched with
 async_op=True -- torch.distributed runs it on the communicator's own HIP stream after an event on the compute stream --
 and `wait()` (before optimizer.step) makes the compute stream wait for all of them.
 """
@@ -43,10 +44,13 @@ class GradientBucketReducer:
         offs = m._offsets
         total = m._flat.numel()
         # bucket boundaries over the flat layout
+        # The flat layout follows parameter order (encoder first) while backward produces gradients in reverse, so the bucket at
+        # the lowest offsets completes last and its all-reduce is the only one nothing overlaps with: keep that one small
+        # (1/8 of a regular bucket: the first encoder levels), the rest regular.
         per = max(1, self.bucket_bytes // 4)
         bounds, start = [], 0
         while start < total:
-            end = min(total, start + per)
+            end = min(total, start + (max(1, per // 8) if start == 0 else per))
             bounds.append([start, end])
             start = end
         # snap boundaries to parameter starts so that no parameter straddles two buckets

@@ -103,13 +103,23 @@ def cpu_baseline(size):
         return time.perf_counter() - t0
 
     step((32, 32, 32))                                           # warm-up (thread pools, oneDNN primitives)
-    # bounded sample: one step on a half-edge patch (1/8 of the voxels, same network and channel widths), scaled by
-    # the voxel ratio to the metric's unit -- every op on the path is linear in the voxel count.
+    # bounded sample (10-30 s of CPU work): one step on a half-edge patch first (1/8 of the voxels, same network and channel
+    # widths); if that predicts <= 30 s for the full patch, time one full-size step and report it directly, otherwise scale the
+    # half-edge step by the voxel ratio (every op on the path is linear in the voxel count).
     s = max(32, size // 2)
     dt = step((s, s, s))
     scale = (size / s) ** 3
+    what = "fwd + sigmoid-Dice + bwd + Adam"
+    if scale > 1 and dt * scale <= 30.0:
+        try:
+            dt_full = step((size, size, size))
+            return {"value": round(1.0 / dt_full, 5), "unit": "volumes/s", "cores": cores, "kind": "port",
+                    "sample": f"1 training step ({what}) of the CPU oracle graph (oracle/unet3d_ref.py), N=1, full {size}^3 patch, fp32, "
+                              f"{cores} threads: {dt_full:.1f} s measured (the {s}^3 step before it: {dt:.2f} s)"}
+        except (MemoryError, RuntimeError):
+            pass                                                 # host RAM too small for the full patch: report the scaled sample
     return {"value": round(1.0 / (dt * scale), 5), "unit": "volumes/s", "cores": cores, "kind": "port",
-            "sample": f"1 training step (fwd + sigmoid-Dice + bwd + Adam) of the CPU oracle graph (oracle/unet3d_ref.py), N=1, "
+            "sample": f"1 training step ({what}) of the CPU oracle graph (oracle/unet3d_ref.py), N=1, "
                       f"{s}^3 patch = 1/{scale:.0f} of a {size}^3 volume, fp32, {cores} threads: {dt:.2f} s measured, x{scale:.0f} "
                       f"voxel scaling -> {dt * scale:.1f} s per {size}^3 volume"}
 

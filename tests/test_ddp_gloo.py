@@ -54,3 +54,25 @@ def test_two_rank_bucketed_allreduce_matches_oracle(tmp_path, emu_backend):
     for k in recs[0]["sd2"]:
         assert torch.equal(recs[0]["sd2"][k], recs[1]["sd2"][k]), k
         assert not torch.equal(recs[0]["sd2"][k], recs[0]["sd0"][k]) or recs[0]["sd0"][k].numel() == 0, k
+
+
+def test_bucket_layout_default_model():
+    """Bucket plan over the flat gradient buffer of the default UNet3D (23 970 216 params): contiguous cover, cut only at
+    parameter starts, and a small FIRST bucket -- the first encoder levels are the last gradients backward produces, so that
+    bucket's all-reduce is the one nothing can overlap with."""
+    import importlib
+    unet = importlib.import_module("3dunetcnn_amd.unet")
+    ddp = importlib.import_module("3dunetcnn_amd.ddp")
+    m = unet.HipUNet3D(n_features=4, n_outputs=3)
+    m.flatten_parameters()
+    red = ddp.GradientBucketReducer(m)                   # no process group: world 1, plan only
+    red._build()
+    starts = set(m._offsets)
+    assert red.buckets[0][0] == 0 and red.buckets[-1][1] == m._flat.numel()
+    for (a, b), (c, d) in zip(red.buckets, red.buckets[1:]):
+        assert b == c and a < b
+    assert all(a in starts for a, _ in red.buckets)
+    sizes = [4 * (b - a) for a, b in red.buckets]
+    assert sizes[0] <= 6 << 20 and sizes[0] == min(sizes[:-1])
+    assert max(sizes) <= 40 << 20 and len(sizes) >= 4
+    assert sum(red.pending_init) == len(list(m.parameters()))
