@@ -15,7 +15,8 @@ Extra objects on the JSON line (tier contract):
                   fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md), since the 3x3x3 convs are compute-bound in fp32
                   (SURVEY.md 7.3 #1); `hbm_gbps` gives the same launches' algorithmic bytes / time for reference.
   cpu_baseline -- the oracle (CPU restatement of the reference graph, oracle/unet3d_ref.py) timed on this host for one
-                  training step at N=1, same volume size (rank 0, N=1 runs only).
+                  training step at N=1: the full 128^3 patch when a half-edge step predicts <= 30 s, else the half-edge step
+                  scaled by the voxel ratio (rank 0, N=1 runs only).
 """
 import argparse
 import importlib
