@@ -1,8 +1,11 @@
-"""Worker for tests/test_ddp_gloo.py: one rank of a world_size-2 data-parallel step on CPU.
+"""Worker for tests/test_ddp_gloo.py: one rank of a world_size-2 data-parallel step.
 
-The gradient exchange (3dunetcnn_amd/ddp.py) is exercised over gloo; the kernels are run by the CPU emulator build of the
-same sources (tools/emu -- test infrastructure). Each rank trains on its own synthetic batch; rank r saves its averaged
-gradients, updated flat parameters and loss to <out>/rank<r>.pt.
+The gradient exchange (3dunetcnn_amd/ddp.py) is exercised over gloo. Device "cpu" (default): the kernels are run by the CPU
+emulator build of the same sources (tools/emu -- test infrastructure). Device "cuda" (the -m gpu variant): both ranks share
+cuda:0 and run the real HIP library through the product modules (RCCL refuses two ranks on one device, gloo reduces device
+tensors through the host; the reducer, its callbacks from the explicit backward and the flat device gradient buffer are the
+product code either way). Each rank trains on its own synthetic batch; rank r saves its averaged gradients, updated flat
+parameters and loss to <out>/rank<r>.pt.
 """
 import ctypes
 import importlib
@@ -17,32 +20,41 @@ sys.path.insert(0, ROOT)
 from oracle import unet3d_ref as R  # noqa: E402  (synthetic inputs only)
 
 
-def main(out_dir):
+def main(out_dir, device="cpu"):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
+    on_gpu = device == "cuda"
     unet = importlib.import_module("3dunetcnn_amd.unet")
     losses = importlib.import_module("3dunetcnn_amd.losses")
     optim = importlib.import_module("3dunetcnn_amd.optim")
     ddp = importlib.import_module("3dunetcnn_amd.ddp")
     lib_mod = importlib.import_module("3dunetcnn_amd._lib")
     ops = importlib.import_module("3dunetcnn_amd.ops")
-    be = ops.Backend(lib=lib_mod.bind(ctypes.CDLL(os.path.join(ROOT, "tools", "emu", "libmi355unet3d_emu.so"))), device="cpu")
+    if on_gpu:
+        torch.cuda.set_device(0)
+        be = ops.default_backend()                    # the HIP library (raises if it is missing)
+    else:
+        be = ops.Backend(lib=lib_mod.bind(ctypes.CDLL(os.path.join(ROOT, "tools", "emu", "libmi355unet3d_emu.so"))), device="cpu")
 
     torch.manual_seed(100 + rank)                  # ranks start from DIFFERENT weights: broadcast must fix that
     kw = dict(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1, 1])
     m = unet.HipUNet3D(**kw).eval()
+    if on_gpu:
+        m = m.cuda()
     m._be = be
     m.flatten_parameters()
     # small buckets so that the step uses several all-reduces launched from inside backward
     red = ddp.GradientBucketReducer(m, bucket_bytes=16 << 10)
     red.broadcast_parameters(0)
-    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     crit = losses.HipDiceLoss(sigmoid=True)
     crit._be = be
     opt = optim.HipAdam(m.parameters(), lr=1e-3)
     opt._be = be
     x, y = R.synthetic_case(1, 4, (16, 16, 16), 3, seed=rank)
+    if on_gpu:
+        x, y = x.cuda(), y.cuda()
     rec = {"sd0": sd0, "losses": [], "n_buckets": None}
     for _ in range(2):
         opt.zero_grad(set_to_none=True)
@@ -50,15 +62,15 @@ def main(out_dir):
         loss.backward()
         red.wait()
         if "grads" not in rec:
-            rec["grads"] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+            rec["grads"] = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
             rec["n_buckets"] = len(red.buckets)
         opt.step()
         m.mark_parameters_updated()
         rec["losses"].append(float(loss))
-    rec["sd2"] = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    rec["sd2"] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     torch.save(rec, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "cpu")
