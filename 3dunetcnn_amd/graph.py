@@ -1,0 +1,66 @@
+"""HipGraphedTrainStep: the inner loop of the reference's training step replayed as ONE HIP graph.
+
+The reference's step (unet3d/train/training_utils.py:59-72: zero_grad -> model(images) -> criterion -> backward -> optimizer.step)
+enqueues ~600 kernels per iteration through this package (26 convolutions forward, their dgrad/wgrad pairs, 52 norm passes ...).
+At the 128^3 training patch the GPU needs ~47 ms per volume for them and the ~20 ms of host-side enqueue work hide behind it; at
+small patches (the 64^3 plumbing configuration, validation crops, deep levels of a sliding-window sweep) the step is
+launch-bound: the GPU finishes before the host has enqueued the next kernels. Everything between the input copy and the
+optimizer is shape-static, sync-free and allocates only from torch's caching allocator, so it is captured once
+(torch.cuda.CUDAGraph = hipGraph on ROCm: hipStreamBeginCapture on the stream the C ABI launches on) and replayed with a single
+hipGraphLaunch per step.
+
+What is inside the graph: weight (re)packing, forward, loss value + d(loss)/d(logits), the explicit backward writing every
+parameter gradient into the model's flat gradient buffer. What stays outside: the copy of the new batch into the static input
+tensors and the optimizer step (one fused Adam launch; kept eager so lr schedulers -- ReduceLROnPlateau in the reference's
+config -- keep working and the bias-correction step count stays a host integer).
+
+Not for the multi-rank path: the bucketed RCCL all-reduce is launched from Python callbacks during backward (ddp.py).
+"""
+import torch
+
+
+class HipGraphedTrainStep:
+    def __init__(self, model, criterion, optimizer, example_x, example_y, warmup=2):
+        if getattr(model, "grad_ready_callback", None) is not None:
+            raise RuntimeError("HipGraphedTrainStep: the model has a GradientBucketReducer attached; graph replay cannot launch its "
+                               "all-reduces -- use the eager step for multi-rank training")
+        if example_x.device.type != "cuda":
+            raise RuntimeError("HipGraphedTrainStep runs on an MI355X only (no CPU fallback)")
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.x = example_x.detach().clone()          # static inputs: every replay reads these addresses
+        self.y = example_y.detach().clone()
+        model.flatten_parameters()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            # warm-up off the default stream: sizes the backend workspace, the flat gradient buffer and the allocator pools.
+            # No optimizer step here -- constructing the graph must not change the weights.
+            for _ in range(max(1, warmup)):
+                optimizer.zero_grad(set_to_none=True)
+                criterion(model(self.x), self.y).backward()
+        torch.cuda.current_stream().wait_stream(side)
+        optimizer.zero_grad(set_to_none=True)        # capture writes the gradients in place (no accumulate branch)
+        model.mark_parameters_updated()              # the pack kernels are part of every replay
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            logits = model(self.x)
+            loss = criterion(logits, self.y)
+            loss.backward()
+        self.logits = logits.detach()                # static outputs, refreshed by every replay
+        self.loss = loss.detach()
+        self._grads = [(p, p.grad) for p in model.parameters() if p.grad is not None]
+
+    def __call__(self, x, y):
+        """One training step on the batch (x, y) (shapes/dtypes of the example batch). Returns the loss (a static 0-dim device
+        tensor: read it with .item() before the next call if the value is needed)."""
+        if x.shape != self.x.shape or y.shape != self.y.shape or y.dtype != self.y.dtype:
+            raise ValueError(f"HipGraphedTrainStep was captured for x {tuple(self.x.shape)}, y {tuple(self.y.shape)} {self.y.dtype}")
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x, non_blocking=True)
+        if y.data_ptr() != self.y.data_ptr():
+            self.y.copy_(y, non_blocking=True)
+        self.graph.replay()
+        for p, g in self._grads:                     # a zero_grad(set_to_none=True) between calls must not hide the gradients
+            p.grad = g
+        self.optimizer.step()
+        return self.loss

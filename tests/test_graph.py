@@ -1,0 +1,85 @@
+"""HipGraphedTrainStep (3dunetcnn_amd/graph.py): the step replayed as one HIP graph must be the eager step, bit for bit."""
+import importlib
+
+import pytest
+import torch
+
+from oracle import unet3d_ref as R          # synthetic inputs only
+
+graph = importlib.import_module("3dunetcnn_amd.graph")
+unet = importlib.import_module("3dunetcnn_amd.unet")
+dynunet = importlib.import_module("3dunetcnn_amd.dynunet")
+losses = importlib.import_module("3dunetcnn_amd.losses")
+optim = importlib.import_module("3dunetcnn_amd.optim")
+
+
+def test_graphed_step_refuses_cpu_tensors():
+    m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1])
+    x, y = R.synthetic_case(1, 4, (16, 16, 16), 3)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        graph.HipGraphedTrainStep(m, losses.HipDiceLoss(sigmoid=True), optim.HipAdam(m.parameters()), x, y)
+
+
+def _build(kind):
+    torch.manual_seed(3)
+    if kind == "unet3d":
+        return unet.HipUNet3D(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 2, 2]).cuda().eval()
+    return dynunet.HipDynUNet(spatial_dims=3, in_channels=4, out_channels=3, kernel_size=[3] * 4, strides=[1, 2, 2, 2],
+                              upsample_kernel_size=[2] * 3, filters=[32, 64, 96, 128]).cuda().eval()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["unet3d", "dynunet"])
+def test_graphed_step_equals_eager_step(hip_backend, kind):
+    batches = [tuple(t.cuda() for t in R.synthetic_case(2, 4, (32, 32, 32), 3, seed=s)) for s in range(3)]
+    # eager reference run (eval(): no Dropout3d mask, so both runs see the same arithmetic)
+    m0 = _build(kind)
+    crit0, opt0 = losses.HipDiceLoss(sigmoid=True), optim.HipAdam(m0.parameters(), lr=1e-3)
+    want = []
+    for x, y in batches:
+        opt0.zero_grad(set_to_none=True)
+        loss = crit0(m0(x), y)
+        loss.backward()
+        opt0.step()
+        want.append(float(loss.detach()))
+    # graphed run from the same initial weights
+    m1 = _build(kind)
+    for (k0, v0), (k1, v1) in zip(m0.state_dict().items(), m1.state_dict().items()):
+        assert k0 == k1
+    crit1, opt1 = losses.HipDiceLoss(sigmoid=True), optim.HipAdam(m1.parameters(), lr=1e-3)
+    before = {k: v.detach().clone() for k, v in m1.state_dict().items()}
+    step = graph.HipGraphedTrainStep(m1, crit1, opt1, *batches[0])
+    for k, v in m1.state_dict().items():
+        assert torch.equal(v, before[k]), f"building the graph changed {k}"
+    got = []
+    for x, y in batches:
+        opt1.zero_grad(set_to_none=True)        # the reference's loop calls it; the graphed step must survive it
+        got.append(float(step(x, y).item()))
+    assert got == want, (got, want)
+    for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+@pytest.mark.gpu
+def test_graphed_step_train_mode_dropout_draws_a_new_mask_per_replay(hip_backend):
+    torch.manual_seed(0)
+    m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1]).cuda().train()
+    x, y = (t.cuda() for t in R.synthetic_case(1, 4, (16, 16, 16), 3))
+    opt = optim.HipAdam(m.parameters(), lr=0.0)              # lr 0: the weights stay put, only the Dropout3d mask varies
+    step = graph.HipGraphedTrainStep(m, losses.HipDiceLoss(sigmoid=True), opt, x, y)
+    outs = []
+    for _ in range(4):
+        step(x, y)
+        outs.append(step.logits.clone())
+    assert any(not torch.equal(outs[0], o) for o in outs[1:]), "every replay reused one Dropout3d mask"
+
+
+@pytest.mark.gpu
+def test_graphed_step_rejects_ddp_model(hip_backend):
+    ddp = importlib.import_module("3dunetcnn_amd.ddp")
+    m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1]).cuda()
+    m.flatten_parameters()
+    ddp.GradientBucketReducer(m)
+    x, y = (t.cuda() for t in R.synthetic_case(1, 4, (16, 16, 16), 3))
+    with pytest.raises(RuntimeError, match="GradientBucketReducer"):
+        graph.HipGraphedTrainStep(m, losses.HipDiceLoss(sigmoid=True), optim.HipAdam(m.parameters()), x, y)

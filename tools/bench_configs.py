@@ -8,10 +8,11 @@ from oracle import unet3d_ref as R   # synthetic inputs only
 unet = importlib.import_module("3dunetcnn_amd.unet"); dyn = importlib.import_module("3dunetcnn_amd.dynunet")
 losses = importlib.import_module("3dunetcnn_amd.losses"); optim = importlib.import_module("3dunetcnn_amd.optim")
 inferer = importlib.import_module("3dunetcnn_amd.inferer"); ops = importlib.import_module("3dunetcnn_amd.ops")
+graph = importlib.import_module("3dunetcnn_amd.graph")
 be = ops.default_backend()
 
 
-def train_rate(model, batch, dhw, steps=4, warm=2, precision=None):
+def train_rate(model, batch, dhw, steps=4, warm=2, precision=None, graphed=False):
     model = model.cuda().train()
     model.conv_precision = precision
     crit = losses.HipDiceLoss(sigmoid=True); opt = optim.HipAdam(model.parameters(), lr=1e-3)
@@ -20,6 +21,9 @@ def train_rate(model, batch, dhw, steps=4, warm=2, precision=None):
     def step():
         opt.zero_grad(set_to_none=True)
         l = crit(model(x), y); l.backward(); opt.step()
+    if graphed:      # the same step replayed as one HIP graph (3dunetcnn_amd/graph.py)
+        gstep = graph.HipGraphedTrainStep(model, crit, opt, x, y)
+        step = lambda: gstep(x, y)
     for _ in range(warm): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): step()
@@ -34,6 +38,9 @@ brats = dict(spatial_dims=3, in_channels=4, out_channels=3, kernel_size=[3] * 6,
 rows = [
     ("C1 DynUNet (BraTS config) 1x4x64^3 fp32 train", lambda: train_rate(dyn.HipDynUNet(**brats), 1, (64, 64, 64))),
     ("C1 UNet3D 1x4x64^3 fp32 train", lambda: train_rate(unet.HipUNet3D(n_features=4, n_outputs=3), 1, (64, 64, 64))),
+    ("C1 DynUNet (BraTS config) 1x4x64^3 fp32 train, HIP-graph step", lambda: train_rate(dyn.HipDynUNet(**brats), 1, (64, 64, 64), steps=8, graphed=True)),
+    ("C1 UNet3D 1x4x64^3 fp32 train, HIP-graph step", lambda: train_rate(unet.HipUNet3D(n_features=4, n_outputs=3), 1, (64, 64, 64), steps=8, graphed=True)),
+    ("C2 UNet3D 128^3 batch 2 fp32 train, HIP-graph step", lambda: train_rate(unet.HipUNet3D(n_features=4, n_outputs=3), 2, (128, 128, 128), graphed=True)),
     ("C2' DynUNet (BraTS config) 128^3 batch 2 fp32 train", lambda: train_rate(dyn.HipDynUNet(**brats), 2, (128, 128, 128))),
     ("C3 UNet3D 128^3 batch 4 bf16 mixed (HipAutocastUNet) train, 1 GPU", lambda: train_rate(unet.HipAutocastUNet(n_features=4, n_outputs=3), 4, (128, 128, 128), precision="bf16")),
     ("C4 UNet3D 5 levels (96.8M params) 160x192x128 batch 1 fp32 train", lambda: train_rate(unet.HipUNet3D(n_features=4, n_outputs=3, encoder_blocks=[1, 2, 2, 2, 4]), 1, (160, 192, 128))),
