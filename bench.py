@@ -25,7 +25,10 @@ import os
 import sys
 import time
 
-import torch
+# dmabuf IPC for RCCL between the per-GPU processes (the host driver has no legacy IPC); must be set before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -144,7 +147,7 @@ def main():
     optim = importlib.import_module("3dunetcnn_amd.optim")
     ddp = importlib.import_module("3dunetcnn_amd.ddp")
     ops = importlib.import_module("3dunetcnn_amd.ops")
-    from oracle import unet3d_ref as R   # synthetic_case only (input generator; not part of the measured path)
+    synthetic = importlib.import_module("3dunetcnn_amd.synthetic")
 
     torch.manual_seed(1234)
     if args.model == "dynunet":
@@ -165,7 +168,7 @@ def main():
         reducer.broadcast_parameters(0)
 
     S, B = args.size, args.batch
-    x, y = R.synthetic_case(B, 4, (S, S, S), seed=rank)
+    x, y = synthetic.synthetic_case(B, 4, (S, S, S), seed=rank)
     x, y = x.to(dev), y.to(dev)                                   # inputs resident in HBM before the timed region
     be = ops.default_backend()
     be.set_precision(args.precision)

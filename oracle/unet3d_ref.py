@@ -13,6 +13,8 @@ Follows:
   unet3d/models/pytorch/classification/decoder.py:99-106 (ConvTranspose3d k3 s2 p1 | 1x1x1 + trilinear x2)
   unet3d/models/pytorch/autoencoder/variational.py:81-87 (encoder -> decoder -> final 1x1x1 -> activation)
 """
+import importlib
+
 import torch
 import torch.nn.functional as F
 
@@ -82,18 +84,6 @@ def unet3d_forward(sd, x, encoder_blocks=(1, 2, 2, 4), decoder_blocks=None, use_
     return x
 
 
-def synthetic_case(n, n_features, dhw, n_outputs=3, seed=0):
-    """Synthetic inputs of SURVEY.md 8(d): randn image (z-scored MRI stand-in) + nested ellipsoid uint8 masks."""
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn(n, n_features, *dhw, generator=g)
-    d, h, w = dhw
-    zz, yy, xx = torch.meshgrid(torch.arange(d), torch.arange(h), torch.arange(w), indexing="ij")
-    y = torch.zeros(n, n_outputs, d, h, w, dtype=torch.uint8)
-    fr = (0.30, 0.20, 0.10, 0.05, 0.03, 0.02, 0.01, 0.005)
-    for i in range(n):
-        c = [s / 2 + float(torch.rand(1, generator=g) * 2 - 1) * min(8.0, s / 8) for s in dhw]
-        for k in range(n_outputs):
-            f = fr[k]
-            r = ((zz - c[0]) / (f * d)) ** 2 + ((yy - c[1]) / (f * h)) ** 2 + ((xx - c[2]) / (f * w)) ** 2
-            y[i, k] = (r <= 1.0).to(torch.uint8)
-    return x, y
+# the synthetic batch generator of SURVEY.md 8(d) lives in the package (bench.py's measured path must not import oracle/);
+# re-exported here for the tests
+synthetic_case = importlib.import_module("3dunetcnn_amd.synthetic").synthetic_case

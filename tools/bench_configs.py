@@ -4,7 +4,7 @@ import importlib, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import unet3d_ref as R   # synthetic inputs only
+R = importlib.import_module("3dunetcnn_amd.synthetic")   # synthetic inputs
 unet = importlib.import_module("3dunetcnn_amd.unet"); dyn = importlib.import_module("3dunetcnn_amd.dynunet")
 losses = importlib.import_module("3dunetcnn_amd.losses"); optim = importlib.import_module("3dunetcnn_amd.optim")
 inferer = importlib.import_module("3dunetcnn_amd.inferer"); ops = importlib.import_module("3dunetcnn_amd.ops")

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 unet = importlib.import_module("3dunetcnn_amd.unet")
 losses = importlib.import_module("3dunetcnn_amd.losses")
 optim = importlib.import_module("3dunetcnn_amd.optim")
-from oracle import unet3d_ref as R        # synthetic inputs only
+R = importlib.import_module("3dunetcnn_amd.synthetic")   # synthetic inputs
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 5
