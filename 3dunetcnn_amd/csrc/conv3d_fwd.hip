@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
   // owns the two classes that differ in x; the (z, y) class is rotated with the workgroup index because the classes carry
   // 3/6/6/12 taps and would otherwise load the 4 SIMDs unevenly.
   constexpr bool ZIP = INMODE == MI355_IN_ZERO_INSERT && KD == 3 && STRIDE == 1 && TZ == 4 && TY == 8 && TX == 8 && WM == 4 && MT == 2;
+  constexpr int ZCZ = TZ / 2 + 1, ZCY = TY / 2 + 1, ZCX = TX / 2 + 1, ZHV = ZCZ * ZCY * ZCX;   // coarse tile of the ZIP form
   const int zcls = ZIP ? ((wm + (int)blockIdx.x) & 3) : 0;     // (az, ay) = (zcls >> 1, zcls & 1)
 
   int b = blockIdx.x;
@@ -76,8 +77,11 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
   for (int mt = 0; mt < MT; ++mt) {
     const int tv = (wm * MT + mt) * 32 + li;
     int tz = tv / (TY * TX), ty = (tv / TX) % TY, tx = tv % TX;
-    if (ZIP) { tz = 2 * (li >> 4) + (zcls >> 1); ty = 2 * ((li >> 2) & 3) + (zcls & 1); tx = 2 * (li & 3) + mt; }
     abase[mt] = (((tz * STRIDE) * HY + ty * STRIDE) * HX + tx * STRIDE) * VS + half * 4;
+    // ZIP: LDS holds only the COARSE voxels the tile can see (CZ x CY x CX = 3 x 5 x 5 instead of the 6 x 10 x 10 zero-inserted
+    // halo, 7/8 of which would be zeros). Lane li of a parity-class tile is output voxel (2*(li>>4)+az, 2*((li>>2)&3)+ay,
+    // 2*(li&3)+ax); a tap d it uses reads coarse voxel (li>>4) + (d>>1) along each axis, whatever the class.
+    if (ZIP) abase[mt] = ((((li >> 4) * ZCY) + ((li >> 2) & 3)) * ZCX + (li & 3)) * VS + half * 4;
   }
 
   // Two-level accumulation (TL, selected for Cin >= 4 chunks): the MFMAs of one channel chunk (27*KC products) chain into
@@ -123,6 +127,26 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
             val = *reinterpret_cast<const float4*>(a.x + fv * a.xld + k);
           }
           *reinterpret_cast<float4*>(lds + hv * VS + 4 * sq) = val;
+        }
+      } else if constexpr (ZIP) {
+        // coarse voxel (cz, cy, cx) of the tile = input voxel (tz0/2 + cz, ty0/2 + cy, tx0/2 + cx) (tile origins are even, pad is 1)
+        constexpr int UP = (ZHV * Q + 255) / 256;
+        float4 ld[UP];
+#pragma unroll
+        for (int k = 0; k < UP; ++k) {
+          int hv = sv0 + k * (256 / Q);
+          if (hv >= ZHV) hv = ZHV - 1;
+          int iz = tz0 / 2 + hv / (ZCY * ZCX), iy = ty0 / 2 + (hv / ZCX) % ZCY, ix = tx0 / 2 + hv % ZCX;
+          iz = iz < a.Di ? iz : a.Di - 1; iy = iy < a.Hi ? iy : a.Hi - 1; ix = ix < a.Wi ? ix : a.Wi - 1;
+          ld[k] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (cvalid ? c : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < UP; ++k) {
+          const int hv = sv0 + k * (256 / Q);
+          if (hv >= ZHV) continue;
+          const int iz = tz0 / 2 + hv / (ZCY * ZCX), iy = ty0 / 2 + (hv / ZCX) % ZCY, ix = tx0 / 2 + hv % ZCX;
+          const bool ok = cvalid && iz < a.Di && iy < a.Hi && ix < a.Wi;
+          *reinterpret_cast<float4*>(lds + hv * VS + 4 * sq) = ok ? ld[k] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       } else {
         // Batches of UB staging units: all loads of a batch are issued from clamped, always-valid addresses before the first
@@ -197,7 +221,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
           const int mt = (dx & 1) ? 0 : 1;          // even x (class ax = 0 = M tile 0) uses tap 1, odd x taps 0 and 2
-          const int toff = ((dz * HY + dy) * HX + dx) * VS;
+          const int toff = (((dz >> 1) * ZCY + (dy >> 1)) * ZCX + (dx >> 1)) * VS;
 #pragma unroll
           for (int j = 0; j < J; ++j) {
             if (j >= jn) continue;
@@ -373,25 +397,28 @@ static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
   // (not for the 4-tile configuration: 64 more live registers would cost a wave of occupancy per SIMD)
   const bool tl = KD == 3 && MT * NT <= 2 && (a.CinP >= 4 * KC || (MT * NT == 1 && a.CinP >= 2 * KC));
   const bool fullj = a.CinP % KC == 0;
-#define MI355_LAUNCH_CONV(SS, IM)                                                                                              \
+#define MI355_LAUNCH_CONV(SS, IM, LDSB)                                                                                              \
   do {                                                                                                                         \
-    if (tl && fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, true>), dim3((unsigned)blocks), dim3(256), lds, stream, a);  \
-    else if (tl) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, false>), dim3((unsigned)blocks), dim3(256), lds, stream, a);      \
-    else if (fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, true>), dim3((unsigned)blocks), dim3(256), lds, stream, a);       \
-    else LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, false>), dim3((unsigned)blocks), dim3(256), lds, stream, a);                 \
+    if (tl && fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, true>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);  \
+    else if (tl) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, false>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);      \
+    else if (fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, true>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);       \
+    else LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, false>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);                 \
   } while (0)
   if (in_mode == MI355_IN_PLAIN) {
-    MI355_LAUNCH_CONV(STRIDE, MI355_IN_PLAIN);
+    MI355_LAUNCH_CONV(STRIDE, MI355_IN_PLAIN, lds);
   } else if (in_mode == MI355_IN_AFFINE_ACT) {
-    MI355_LAUNCH_CONV(STRIDE, MI355_IN_AFFINE_ACT);
+    MI355_LAUNCH_CONV(STRIDE, MI355_IN_AFFINE_ACT, lds);
   } else if (in_mode == MI355_IN_S2D) {
     if constexpr (KD == 1) {
-      MI355_LAUNCH_CONV(1, MI355_IN_S2D);
+      MI355_LAUNCH_CONV(1, MI355_IN_S2D, lds);
     } else return MI355_EUNSUPPORTED;
   } else {
     if constexpr (KD == 3) {
       if (STRIDE != 1) return MI355_EUNSUPPORTED;
-      MI355_LAUNCH_CONV(1, MI355_IN_ZERO_INSERT);
+      // parity-class form (4x8x8 tiles, 2 M tiles per wave): LDS holds the 3x5x5 coarse voxels only
+      constexpr bool zip = TZ == 4 && TY == 8 && TX == 8 && WM == 4 && MT == 2;
+      constexpr size_t lds_zi = zip ? (size_t)(TZ / 2 + 1) * (TY / 2 + 1) * (TX / 2 + 1) * (KC + PADV) * sizeof(float) : lds;
+      MI355_LAUNCH_CONV(1, MI355_IN_ZERO_INSERT, lds_zi);
     } else return MI355_EUNSUPPORTED;
   }
 #undef MI355_LAUNCH_CONV

@@ -133,6 +133,26 @@ def case_conv_dgrad(be, n, cin, cout, dhw, stride=1, seed=1):
     return rel_err(from_act(dxa), dx_ref)
 
 
+def case_tconv3(be, n, cin, cout, dhw, pad_to=None, seed=12):
+    """ConvTranspose3d(k3, s2, p1, bias) forward (decoder.py:99-102) = zero-insert conv with the mode-2 pack; `pad_to`: the
+    F.pad window of unet.py:34-40 (output written at offset diff//2 of a pre-zeroed larger tensor)."""
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dhw
+    x = torch.randn(n, cin, d, h, w, generator=g)
+    wt = torch.randn(cin, cout, 3, 3, 3, generator=g) * (1.0 / (cin * 27 / 8) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv_transpose3d(x, wt, b, stride=2, padding=1)
+    od = tuple(2 * s - 1 for s in dhw)
+    tgt = pad_to or od
+    off = tuple((t - o) // 2 for t, o in zip(tgt, od))
+    if pad_to:
+        ref = F.pad(ref, [v for t, o, f in reversed(list(zip(tgt, od, off))) for v in (f, t - o - f)])
+    xa = to_act(be, x)
+    ya = to_act(be, torch.zeros(n, cout, *tgt))
+    be.conv_fwd(xa, be.pack_weight(dev(be, wt), 2), ya, 3, 1, pad=1, in_mode=ops.IN_ZERO_INSERT, bias=dev(be, b), off=off, out_dhw=od)
+    return rel_err(from_act(ya), ref)
+
+
 def case_conv_wgrad(be, n, cin, cout, dhw, kd=3, stride=1, norm=False, slope=0.0, seed=2):
     g = torch.Generator().manual_seed(seed)
     d, h, w = dhw

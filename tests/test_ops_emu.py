@@ -73,6 +73,15 @@ def test_conv_narrow_config_name(emu_backend):
 
 
 @pytest.mark.parametrize("kw", [
+    dict(n=1, cin=32, cout=32, dhw=(4, 5, 6)),                        # output 7x9x11: ragged parity-class tiles
+    dict(n=2, cin=16, cout=64, dhw=(3, 4, 4), pad_to=(6, 8, 8)),      # NT = 2 configuration, F.pad window (one zero plane at the back)
+    dict(n=1, cin=40, cout=24, dhw=(2, 6, 5)),                        # partial last channel chunk
+])
+def test_transposed_conv_k3s2(emu_backend, kw):
+    assert C.case_tconv3(emu_backend, **kw) < TOL
+
+
+@pytest.mark.parametrize("kw", [
     dict(n=2, cin=32, cout=32, dhw=(6, 7, 8)),
     dict(n=1, cin=4, cout=32, dhw=(8, 8, 8), norm=True),
     dict(n=1, cin=64, cout=96, dhw=(5, 5, 9), norm=True, slope=0.01),

@@ -42,6 +42,15 @@ def test_conv_dgrad(hip_backend, kw):
 
 
 @pytest.mark.parametrize("kw", [
+    dict(n=2, cin=32, cout=32, dhw=(16, 17, 20)),
+    dict(n=1, cin=128, cout=64, dhw=(8, 8, 8), pad_to=(16, 16, 16)),
+    dict(n=1, cin=40, cout=24, dhw=(5, 6, 7)),
+])
+def test_transposed_conv_k3s2(hip_backend, kw):
+    assert C.case_tconv3(hip_backend, **kw) < TOL
+
+
+@pytest.mark.parametrize("kw", [
     dict(n=2, cin=4, cout=32, dhw=(33, 40, 47)),      # first-layer dgrad (<= 4 output channels): vector-ALU kernel, ragged tiles
     dict(n=1, cin=4, cout=64, dhw=(16, 24, 32)),      # two 32-channel chunks (DynUNet input-block width)
     dict(n=1, cin=3, cout=40, dhw=(9, 11, 13)),       # 3 output channels, partial second chunk
