@@ -102,6 +102,11 @@ class HipNetBase(nn.Module):
 
     def _run(self, x):
         self._check_input(x)
+        if x.shape[0] == 0:
+            # empty batch (torch's Conv3d / GroupNorm return empty tensors for it): nothing to launch; the zero-size sum keeps
+            # the autograd link, so loss.backward() yields zero-valued parameter gradients as it does for the reference
+            n_out = getattr(self, "n_outputs", None) or getattr(self, "out_channels")
+            return x.new_zeros((0, n_out) + tuple(x.shape[2:])) + sum(p.sum() * 0 for p in self._params())
         self.flatten_parameters()
         return _NetFunction.apply(self, x.contiguous().float(), *self._params())
 
