@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256) void conv3d_c4_wgrad_reduce(const float* ws, f
 // The gradient wrt the activated first-layer input (needed for the gamma/beta gradients of the network's first norm) is a
 // conv Cout -> 4. On the 32-wide MFMA N tile 7/8 of the matrix work would be padding (measured: 2.0 ms at 128^3, batch 2 --
 // as long as a 32 -> 32 layer). Here one thread owns one output voxel and its <= 4 output channels: the haloed input tile
-// (6x10x10 voxels x 32 channels = 76.8 KB, XOR-swizzled by (x + y) so the ds_read_b128 of 8 x-neighbours and of two y rows
-// are bank-conflict free without padding) is staged once per 32-channel chunk; per (tap, 4-channel group) a thread issues one
+// (6x10x10 voxels x CQ*4 = 16 channels = 38.4 KB, XOR-swizzled by (x + y) to spread the ds_read_b128 of x-neighbours and adjacent
+// y rows over the banks without padding) is staged once per 16-channel chunk; per (tap, 4-channel group) a thread issues one
 // ds_read_b128 and 8 packed FMAs whose weight operands are wave-uniform (scalar loads straight from the packed
 // [tap][ci/4][32][4] buffer, only the first 4 of the 32 padded output columns are touched). fp32 FMA chains: exact products.
 struct NarrowArgs {
@@ -236,9 +236,10 @@ struct NarrowArgs {
   int tilesZ, tilesY, tilesX, spatialTiles;
 };
 
+template <int CQ>
 __global__ __launch_bounds__(256) void conv3d_c4_dgrad(NarrowArgs a) {
   constexpr int TZ = 4, TY = 8, TX = 8, HZ = 6, HY = 10, HX = 10, HV = HZ * HY * HX;
-  DYN_LDS(lds_f);                           // float4 [HV][8], quad q of haloed voxel (hz,hy,hx) at slot q ^ ((hx + hy) & 7)
+  DYN_LDS(lds_f);                           // float4 [HV][CQ], quad q of haloed voxel (hz,hy,hx) at slot q ^ ((hx + hy) & (CQ - 1))
   float4* lds = reinterpret_cast<float4*>(lds_f);
   const int tid = threadIdx.x, lz = tid >> 6, ly = (tid >> 3) & 7, lx = tid & 7;
   int b = blockIdx.x;
@@ -253,16 +254,16 @@ __global__ __launch_bounds__(256) void conv3d_c4_dgrad(NarrowArgs a) {
   pkf2 acc[4][2];                           // per output channel: partial sums over input channels 4q + {0,1} and 4q + {2,3}
 #pragma unroll
   for (int o = 0; o < 4; ++o) acc[o][0] = acc[o][1] = make_pkf2(0.f, 0.f);
-  constexpr int UNITS = HV * 8, UP = (UNITS + 255) / 256;
-  for (int c0 = 0; c0 < a.Cq; c0 += 8) {
-    const int nq = a.Cq - c0 < 8 ? a.Cq - c0 : 8;
+  constexpr int UNITS = HV * CQ, UP = (UNITS + 255) / 256;
+  for (int c0 = 0; c0 < a.Cq; c0 += CQ) {
+    const int nq = a.Cq - c0 < CQ ? a.Cq - c0 : CQ;
     __syncthreads();
     {
       float4 ld[UP];
 #pragma unroll
       for (int k = 0; k < UP; ++k) {        // all loads first, from clamped always-valid addresses
         int u = tid + k * 256; if (u >= UNITS) u = UNITS - 1;
-        const int hv = u >> 3; int q = u & 7; if (q >= nq) q = nq - 1;
+        const int hv = u / CQ; int q = u % CQ; if (q >= nq) q = nq - 1;
         int iz = tz0 - 1 + hv / (HY * HX), iy = ty0 - 1 + (hv / HX) % HY, ix = tx0 - 1 + hv % HX;
         iz = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1);
         iy = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1);
@@ -273,24 +274,24 @@ __global__ __launch_bounds__(256) void conv3d_c4_dgrad(NarrowArgs a) {
       for (int k = 0; k < UP; ++k) {
         const int u = tid + k * 256;
         if (u >= UNITS) continue;
-        const int hv = u >> 3, q = u & 7;
+        const int hv = u / CQ, q = u % CQ;
         const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
         const int iz = tz0 - 1 + hz, iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
         const bool ok = q < nq && iz >= 0 && iy >= 0 && ix >= 0 && iz < a.D && iy < a.H && ix < a.W;
-        lds[hv * 8 + (q ^ ((hx + hy) & 7))] = ok ? ld[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        lds[hv * CQ + (q ^ ((hx + hy) & (CQ - 1)))] = ok ? ld[k] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
     __syncthreads();
     for (int tap = 0; tap < 27; ++tap) {
       const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
       const int hy = ly + dy, hx = lx + dx;
-      const int hv = ((lz + dz) * HY + hy) * HX + hx, sw = (hx + hy) & 7;
+      const int hv = ((lz + dz) * HY + hy) * HX + hx, sw = (hx + hy) & (CQ - 1);
       const float* wt = a.wp + (size_t)tap * a.CinQ * 128;              // [CinQ][32 output columns][4]: columns 0..3 used
-      float4 v[8];
+      float4 v[CQ];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = lds[hv * 8 + (q ^ sw)];        // all eight reads in flight before the first FMA
+      for (int q = 0; q < CQ; ++q) v[q] = lds[hv * CQ + (q ^ sw)];      // all reads in flight before the first FMA
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < CQ; ++q) {
         // branch-free over the chunk: quads past the input's last one hold zeros in LDS; their weight address is clamped
         // into the pack (0 * w contributes nothing)
         const int qq = c0 + q < a.CinQ ? c0 + q : a.CinQ - 1;
@@ -392,8 +393,9 @@ int mi355_conv3d_narrow_impl(const mi355_act* x, const float* wp, const mi355_ac
   const long long sp = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX;
   if (sp <= 0 || sp > 0x7fffffffLL) return MI355_EINVAL;
   a.spatialTiles = (int)sp;
-  constexpr size_t lds = (size_t)6 * 10 * 10 * 8 * 16;      // 76800 B: two workgroups per CU
-  SET_MAX_DYN_LDS(conv3d_c4_dgrad, lds);
-  LAUNCH(conv3d_c4_dgrad, dim3((unsigned)sp), dim3(256), lds, stream, a);
+  // 16 input channels per LDS chunk: 38.4 KB and 103 VGPRs -> four workgroups per CU (measured on the 128^3 batch-2 layer: 0.53 ms;
+  // 32-channel chunks, two workgroups per CU: 0.67 ms; 8-channel chunks: 0.96 ms)
+  constexpr size_t lds = (size_t)6 * 10 * 10 * 4 * 16;
+  LAUNCH(conv3d_c4_dgrad<4>, dim3((unsigned)sp), dim3(256), lds, stream, a);
   return LAUNCH_CHECK();
 }
