@@ -1,0 +1,69 @@
+"""bench.py's driver contract, checked without a GPU: flag defaults, the cpu_baseline leg, the PMC traffic look-up and the
+shape of the committed bench line (profiles/r1_bench_fp32.json, produced by `python bench.py` on an MI355X)."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_flag_defaults(monkeypatch):
+    b = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = b.parse()
+    assert (a.gpus, a.batch, a.size, a.precision, a.model) == (1, 2, 128, "fp32", "unet3d")      # BASELINE configs[1]
+    assert a.steps >= 1 and a.warmup >= 1
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "7", "--warmup", "2"])
+    a = b.parse()
+    assert (a.gpus, a.steps, a.warmup) == (8, 7, 2)
+
+
+def test_cpu_baseline_leg_reports_the_contract_fields():
+    r = _bench().cpu_baseline(32)          # 16^3 half-edge step, then the full 32^3 step: a second of CPU work
+    assert set(r) == {"value", "unit", "cores", "kind", "sample"}
+    assert r["kind"] == "port" and r["unit"] == "volumes/s" and r["value"] > 0 and r["cores"] >= 1
+    assert "32^3" in r["sample"]
+
+
+def test_pmc_traffic_lookup_reads_the_committed_profile():
+    b = _bench()
+    traffic, src = b.pmc_traffic("conv3d_wgrad_ring (+reduce)", "fp32")
+    assert isinstance(traffic, int) and traffic > 100 << 20 and "profiles/" in src
+    assert b.pmc_traffic("conv3d_wgrad_ring (+reduce)", "bf16") == (None, None)
+
+
+def test_committed_bench_line_has_the_contract_shape():
+    line = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_fp32.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["unit"] == "volumes/s" and line["dtype"] == "f32" and line["data"] == "synthetic"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - line["config"]["global_batch"] * 1e3 / line["ms_per_step"]) / line["value"] < 1e-3
+    roof = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in roof, k
+    assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["traffic"] is None or roof["traffic"] >= roof["algorithmic_bytes_per_launch"]
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0
+
+
+def test_bench_needs_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1"], capture_output=True, text=True)
+    assert p.returncode != 0 and "MI355X" in p.stderr
