@@ -13,7 +13,6 @@ hence the only exposed one -- is cut to ~3 MB); when the last parameter of a buc
 async_op=True -- torch.distributed runs it on the communicator's own HIP stream after an event on the compute stream --
 and `wait()` (before optimizer.step) makes the compute stream wait for all of them.
 """
-import torch
 import torch.distributed as dist
 
 

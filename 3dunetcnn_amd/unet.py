@@ -16,14 +16,12 @@ Forward graph (reference lines in brackets), all activations NDHWC:
 Backward is explicit (no autograd graph inside): wgrad / dgrad (same MFMA conv kernel on flipped packs) /
 GroupNorm+ReLU backward / transposed upsample, parameter gradients written into one flat buffer.
 """
-import math
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .engine import HipNetBase
-from ._lib import IN_AFFINE_ACT, IN_PLAIN, IN_ZERO_INSERT
+from ._lib import IN_AFFINE_ACT, IN_ZERO_INSERT
 
 GN_EPS = 1e-5
 

@@ -10,7 +10,6 @@ import os
 import pytest
 import torch
 
-import op_cases as C
 from oracle import reference_shim, torch_ops as O, unet3d_ref as R
 
 pytestmark = pytest.mark.skipif(not reference_shim.available(), reason="/root/reference only exists in the build container")

@@ -1,7 +1,7 @@
 """Developer tool: checks each gn_act_bwd / dgrad call inside a real backward against fp64 torch math (needs an MI355X)."""
 import importlib, os, sys
 import torch
-import torch.nn.functional as F
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import op_cases as C

@@ -4,7 +4,7 @@ Runs the CPU oracle graph in fp64 (truth) and in fp32 with relative Gaussian noi
 Noise of 1e-6 (the size of a k-ordered fp32 accumulation over K~3.5k terms) already moves some encoder gradients by
 4e-3 -- the same tensors, by the same amount, as the MI355X path (profiles/ and DESIGN.md, 'Gradient conditioning').
 """
-import sys, time, importlib
+import sys, importlib
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
