@@ -58,6 +58,15 @@ def test_conv_dgrad_first_layer(emu_backend, kw):
     assert C.case_conv_dgrad(emu_backend, **kw) < TOL
 
 
+def test_conv_fwd_narrow_output_forward_pack(emu_backend):
+    # the <= 4-output-channel kernel is a plain correlation over any fp32 pack: a forward conv to 3 / 4 channels takes it too
+    # (also into a channel slice of a wider buffer); with a prologue or a bias the same problem stays on the generic kernel
+    assert C.case_conv_fwd(emu_backend, 1, 16, 3, (5, 6, 7)) < TOL
+    assert C.case_conv_fwd(emu_backend, 2, 8, 4, (4, 9, 8), yld=8, yc0=4) < TOL
+    assert C.case_conv_fwd(emu_backend, 1, 16, 3, (5, 6, 7), norm=True) < TOL
+    assert C.case_conv_fwd(emu_backend, 1, 16, 3, (5, 6, 7), bias=True) < TOL
+
+
 def test_conv_narrow_config_name(emu_backend):
     import ctypes
     be = emu_backend
