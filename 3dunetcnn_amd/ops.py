@@ -227,6 +227,24 @@ class Backend:
                               else "conv3d_wgrad_ring (+reduce)" if (kd == 3 and stride == 1 and pad == 1 and out_mode == OUT_PLAIN)
                               else f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1))
 
+    def conv_wgrad_ring_exp(self, x, dy, dw, variant, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, in_slope=None):
+        """DEVELOPER hook (not used by any module of this package): the experimental variants of the plane-ring 3x3x3 stride-1
+        weight-gradient kernel in csrc/conv3d_wgrad_exp.hip. variant bit 0: 16x16x4 MFMA tiles (27 per wave), bit 1: 8x8 columns."""
+        fn = self.lib.mi355_conv3d_wgrad_ring_exp
+        fn.restype, fn.argtypes = ctypes.c_int, [ctypes.POINTER(MiAct), ctypes.POINTER(MiAct), ctypes.c_void_p, ctypes.POINTER(MiConvDesc),
+                                                 ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_void_p]
+        wsf = self.lib.mi355_conv3d_wgrad_ring_exp_workspace
+        wsf.restype, wsf.argtypes = ctypes.c_size_t, [ctypes.POINTER(MiAct), ctypes.POINTER(MiAct), ctypes.c_int32]
+        keep = []
+        d = self._desc(3, 1, 1, in_mode, slope, scale, shift, None, None, None, (0, 0, 0), dy.shape[1:4], keep, in_slope, OUT_PLAIN)
+        xd, dyd = x.desc(), dy.desc()
+        nbytes = wsf(ctypes.byref(xd), ctypes.byref(dyd), variant)
+        if nbytes == 0:
+            raise RuntimeError("conv_wgrad_ring_exp: unsupported configuration")
+        ws = self.ws(nbytes)
+        check(fn(ctypes.byref(xd), ctypes.byref(dyd), dw.data_ptr(), ctypes.byref(d), ws.data_ptr(), ws.numel() * 4, variant, self.stream()),
+              "conv3d_wgrad_ring_exp")
+
     # -- norm ----------------------------------------------------------------------------------------------------
     def gn_stats(self, x, groups, eps, gamma, beta):
         n, c = x.shape[0], x.c

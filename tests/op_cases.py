@@ -133,6 +133,32 @@ def case_conv_dgrad(be, n, cin, cout, dhw, stride=1, seed=1):
     return rel_err(from_act(dxa), dx_ref)
 
 
+def case_conv_wgrad_exp(be, variant, n, cin, cout, dhw, norm=False, slope=0.0, seed=2):
+    """Experimental ring-wgrad variants (csrc/conv3d_wgrad_exp.hip) against the same oracle as case_conv_wgrad."""
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dhw
+    x = torch.randn(n, cin, d, h, w, generator=g)
+    wt = (torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    normspec = None
+    gamma = beta = None
+    if norm:
+        groups = 8 if cin >= 8 and cin % 8 == 0 else cin
+        gamma = torch.rand(cin, generator=g) + 0.5
+        beta = torch.randn(cin, generator=g) * 0.3
+        normspec = (groups, gamma, beta, 1e-5, slope)
+    y = O.conv_block(x, wt, 1, 1, normspec)
+    dy = torch.randn(y.shape, generator=g)
+    (dw_ref,) = torch.autograd.grad(y, wt, dy)
+    xa, dya = to_act(be, x), to_act(be, dy)
+    kw = {}
+    if norm:
+        mr, sc, sh = be.gn_stats(xa, groups, 1e-5, dev(be, gamma), dev(be, beta))
+        kw = dict(in_mode=ops.IN_AFFINE_ACT, slope=slope, scale=sc, shift=sh)
+    dw = torch.zeros(cout, cin, 3, 3, 3).to(be.device)
+    be.conv_wgrad_ring_exp(xa, dya, dw, variant, **kw)
+    return rel_err(dw.cpu(), dw_ref)
+
+
 def case_tconv3(be, n, cin, cout, dhw, pad_to=None, seed=12):
     """ConvTranspose3d(k3, s2, p1, bias) forward (decoder.py:99-102) = zero-insert conv with the mode-2 pack; `pad_to`: the
     F.pad window of unet.py:34-40 (output written at offset diff//2 of a pre-zeroed larger tensor)."""

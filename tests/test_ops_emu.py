@@ -228,3 +228,16 @@ def test_conv_dgrad_bf16_paths(prec_backend, kw):
 def test_conv_wgrad_bf16_paths(prec_backend, kw):
     be, tol = prec_backend
     assert C.case_conv_wgrad(be, **kw) < tol
+
+
+# ---- experimental ring-wgrad variants (csrc/conv3d_wgrad_exp.hip; not dispatched by the product path): index logic on the emulator ----
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("kw", [
+    dict(n=2, cin=32, cout=32, dhw=(5, 6, 9), norm=True),            # ragged columns in y and x, two samples
+    dict(n=1, cin=64, cout=96, dhw=(4, 9, 8), norm=True, slope=0.01),  # 2 x 3 (ci, co) pairs
+    dict(n=1, cin=40, cout=24, dhw=(3, 4, 17)),                       # partial channel tiles, plain input
+    dict(n=1, cin=32, cout=32, dhw=(32, 4, 8), norm=True),            # one column cut into two z chunks
+    dict(n=1, cin=32, cout=32, dhw=(3, 12, 24)),                      # several columns per workgroup? no: 512 slabs > columns; many idle workgroups
+])
+def test_conv_wgrad_ring_experimental_variants(emu_backend, variant, kw):
+    assert C.case_conv_wgrad_exp(emu_backend, variant, **kw) < TOL
