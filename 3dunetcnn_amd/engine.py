@@ -5,6 +5,8 @@ views into ONE flat device buffer; its gradients are written by the HIP kernels 
 fused Adam and the RCCL bucket all-reduce operate on). Subclasses implement `_forward_impl(x, keep)` and
 `_backward_impl_body(be, saved, dlogits, need_dx)` with explicit forward/backward over the C ABI (no autograd graph inside).
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -43,6 +45,12 @@ class HipNetBase(nn.Module):
         self.grad_ready_callback = None        # set by ddp.GradientBucketReducer
         self.backward_start_callback = None
         self._written = []
+        # EXPERIMENTAL (off by default, not yet measured): enqueue the weight-gradient kernels on a second HIP stream so that the
+        # matrix-bound wgrads overlap the HBM-bound norm-backward passes of the dgrad chain (see _wgrad_stream)
+        self.backward_side_stream = False
+        self._s2 = None
+        self._s2_active = None
+        self._ws2 = None
 
     # ---- flat parameter storage --------------------------------------------------------------------------------
     def _params(self):
@@ -128,6 +136,29 @@ class HipNetBase(nn.Module):
         self._written.append(p)
         return self._gbuf[o:o + p.numel()].view(p.shape)
 
+    @contextlib.contextmanager
+    def _wgrad_stream(self, be, *used):
+        """Context for a weight-gradient launch. Default: nothing (the launch goes to the current stream, in program order).
+        With `backward_side_stream` the launch is forked onto the side stream after everything enqueued so far (its inputs are
+        complete), with its own workspace; `used` (Acts / tensors the kernel reads) are marked as in use by that stream so that the
+        caching allocator does not hand their memory out again before the kernel has run. _backward_impl joins the streams."""
+        s2 = self._s2_active
+        if s2 is None:
+            yield
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        s2.wait_event(ev)
+        for t in used:
+            if t is not None:
+                (t.buf if hasattr(t, "buf") else t).record_stream(s2)
+        main_ws, be._ws = be._ws, self._ws2
+        try:
+            with torch.cuda.stream(s2):
+                yield
+        finally:
+            self._ws2, be._ws = be._ws, main_ws
+
     def _flush_ready(self):
         """Report parameters whose gradient kernels have been enqueued (DDP launches the bucket all-reduce from here)."""
         if self._written and self.grad_ready_callback is not None:
@@ -154,10 +185,18 @@ class HipNetBase(nn.Module):
         saved_precision = be.precision
         if self.conv_precision is not None:
             be.set_precision(self.conv_precision)
+        self._s2_active = None
+        if self.backward_side_stream and self.grad_ready_callback is None and dlogits.device.type == "cuda":
+            if self._s2 is None:
+                self._s2 = torch.cuda.Stream(device=dlogits.device)
+            self._s2_active = self._s2
         try:
             dx_t = self._backward_impl_body(be, saved, dlogits, need_dx)
         finally:
             be.precision = saved_precision
+            if self._s2_active is not None:
+                torch.cuda.current_stream().wait_stream(self._s2_active)     # join: the optimizer reads every gradient
+                self._s2_active = None
         self._flush_ready()
         grads = []
         for p, o in zip(ps, self._offsets):

@@ -311,22 +311,25 @@ class HipUNet3D(HipNetBase):
         if s.chscale is not None:
             be.chscale(d_out, s.chscale, d_out)
         st1, st2 = s.st1, s.st2
-        be.conv_wgrad(s.h1, d_out, self._gslice(c2.conv.weight), 3, 1, in_mode=IN_AFFINE_ACT, scale=st2[1], shift=st2[2])
+        with self._wgrad_stream(be, s.h1, d_out, st2[1], st2[2]):
+            be.conv_wgrad(s.h1, d_out, self._gslice(c2.conv.weight), 3, 1, in_mode=IN_AFFINE_ACT, scale=st2[1], shift=st2[2])
         dA2 = be.empty_act(n, d, h, w, cout)
         be.conv_fwd(d_out, self._packed_weight(c2.conv.weight, 1), dA2, 3, 1)
         be.gn_act_bwd(s.h1, dA2, dA2, c2.norm1.num_groups, 0.0, c2.norm1.weight.data, st2[0], st2[1], st2[2],
                       self._gslice(c2.norm1.weight), self._gslice(c2.norm1.bias))
         dh1 = dA2
         g1, _, groups1, padw = self._in_pad(c1, cin)
-        tw = self._wgrad_target(c1.conv.weight, cin)
-        be.conv_wgrad(s.x, dh1, tw, 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2])
-        self._wgrad_commit(c1.conv.weight, tw)
+        with self._wgrad_stream(be, s.x, dh1, st1[1], st1[2]):
+            tw = self._wgrad_target(c1.conv.weight, cin)
+            be.conv_wgrad(s.x, dh1, tw, 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2])
+            self._wgrad_commit(c1.conv.weight, tw)
         dA1 = be.empty_act(n, d, h, w, cin)
         be.conv_fwd(dh1, self._packed_weight(c1.conv.weight, 1, padw), dA1, 3, 1)
         if blk.sample is not None:
-            ts = self._wgrad_target(blk.sample.weight, cin)
-            be.conv_wgrad(s.x, d_out, ts, 1)
-            self._wgrad_commit(blk.sample.weight, ts)
+            with self._wgrad_stream(be, s.x, d_out):
+                ts = self._wgrad_target(blk.sample.weight, cin)
+                be.conv_wgrad(s.x, d_out, ts, 1)
+                self._wgrad_commit(blk.sample.weight, ts)
             d_id = None
             if need_dx:
                 d_id = be.empty_act(n, d, h, w, cin)
@@ -386,7 +389,8 @@ class HipUNet3D(HipNetBase):
                 pre = dec.pre_upsampling_blocks[k]
                 d_pre = be.empty_act(lay_out.shape[0], lay_out.shape[1], lay_out.shape[2], lay_out.shape[3], out_w)
                 be.upsample2x_bwd(d_cat.slice(0, up_c), d_pre, off)
-                be.conv_wgrad(lay_out, d_pre, self._gslice(pre.weight), 1)
+                with self._wgrad_stream(be, lay_out, d_pre):
+                    be.conv_wgrad(lay_out, d_pre, self._gslice(pre.weight), 1)
                 be.conv_fwd(d_pre, self._packed_weight(pre.weight, 1), d_lay, 1)
             d_cur = self._layer_bwd(be, dec.layers[k], sv, d_lay, True)
         # encoder, deep -> shallow; d_cur is the gradient wrt the deepest encoder output
@@ -398,7 +402,8 @@ class HipUNet3D(HipNetBase):
                 # gradient wrt encoder level i-1 output = dgrad of the stride-2 conv (+ the skip gradient from the concat)
                 dw = enc.downsampling_convolutions[i - 1].weight
                 out_prev = saved["enc"][i - 1][-1].out
-                be.conv_wgrad(out_prev, d_in, self._gslice(dw), 3, 2)
+                with self._wgrad_stream(be, out_prev, d_in):
+                    be.conv_wgrad(out_prev, d_in, self._gslice(dw), 3, 2)
                 dprev = be.empty_act(n, *sizes[i - 1], enc.widths[i - 1])
                 be.conv_fwd(d_in, self._packed_weight(dw, 1), dprev, 3, 1, pad=1, in_mode=IN_ZERO_INSERT,
                             residual=d_skips[i - 1], out_dhw=sizes[i - 1])
