@@ -162,7 +162,19 @@ class HipNetBase(nn.Module):
     def _flush_ready(self):
         """Report parameters whose gradient kernels have been enqueued (DDP launches the bucket all-reduce from here)."""
         if self._written and self.grad_ready_callback is not None:
-            self.grad_ready_callback(self._written)
+            s2 = self._s2_active
+            if s2 is None:
+                self.grad_ready_callback(self._written)
+            else:
+                # side-stream form: the reported gradients were written partly on the current stream (norm gamma/beta) and partly on
+                # the side stream (wgrads). Let the SIDE stream wait for the current one and launch the bucket all-reduces from it
+                # (torch.distributed orders a collective after the stream that is current at the call), so the dgrad chain on the
+                # current stream never waits for a weight gradient.
+                ev = torch.cuda.Event()
+                ev.record()
+                s2.wait_event(ev)
+                with torch.cuda.stream(s2):
+                    self.grad_ready_callback(self._written)
         self._written = []
 
     def _backward_impl(self, saved, dlogits, need_dx):
@@ -186,18 +198,18 @@ class HipNetBase(nn.Module):
         if self.conv_precision is not None:
             be.set_precision(self.conv_precision)
         self._s2_active = None
-        if self.backward_side_stream and self.grad_ready_callback is None and dlogits.device.type == "cuda":
+        if self.backward_side_stream and dlogits.device.type == "cuda":
             if self._s2 is None:
                 self._s2 = torch.cuda.Stream(device=dlogits.device)
             self._s2_active = self._s2
         try:
             dx_t = self._backward_impl_body(be, saved, dlogits, need_dx)
+            self._flush_ready()
         finally:
             be.precision = saved_precision
             if self._s2_active is not None:
                 torch.cuda.current_stream().wait_stream(self._s2_active)     # join: the optimizer reads every gradient
                 self._s2_active = None
-        self._flush_ready()
         grads = []
         for p, o in zip(ps, self._offsets):
             g = gbuf[o:o + p.numel()].view(p.shape)
