@@ -235,19 +235,21 @@ class HipDynUNet(HipNetBase):
         be.gn_act_bwd(r2, dA2, dA2, cout, SLOPE, blk.norm2.weight.data, st2[0], st2[1], st2[2],
                       self._gslice(blk.norm2.weight), self._gslice(blk.norm2.bias))
         d_r2 = dA2
-        be.conv_wgrad(r1, d_r2, self._gslice(blk.conv2.conv.weight), 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2], slope=SLOPE)
+        with self._wgrad_stream(be, r1, d_r2, st1[1], st1[2]):
+            be.conv_wgrad(r1, d_r2, self._gslice(blk.conv2.conv.weight), 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2], slope=SLOPE)
         dA1 = be.empty_act(*r1.shape)
         be.conv_fwd(d_r2, self._packed_weight(blk.conv2.conv.weight, 1), dA1, 3, 1)
         be.gn_act_bwd(r1, dA1, dA1, cout, SLOPE, blk.norm1.weight.data, st1[0], st1[1], st1[2],
                       self._gslice(blk.norm1.weight), self._gslice(blk.norm1.bias))
         d_r1 = dA1
         w1 = blk.conv1.conv.weight
-        if xin.act.c == w1.shape[1]:
-            be.conv_wgrad(xin.act, d_r1, self._gslice(w1), 3, blk.stride, **xin.kw())
-        else:                                  # zero-padded network input: wgrad over the padded channels, sliced back
-            tw = torch.empty(w1.shape[0], xin.act.c, 3, 3, 3, dtype=torch.float32, device=w1.device)
-            be.conv_wgrad(xin.act, d_r1, tw, 3, blk.stride, **xin.kw())
-            self._gslice(w1).copy_(tw[:, :w1.shape[1]])
+        with self._wgrad_stream(be, xin.act, d_r1, xin.scale, xin.shift, xin.slope_vec):
+            if xin.act.c == w1.shape[1]:
+                be.conv_wgrad(xin.act, d_r1, self._gslice(w1), 3, blk.stride, **xin.kw())
+            else:                                  # zero-padded network input: wgrad over the padded channels, sliced back
+                tw = torch.empty(w1.shape[0], xin.act.c, 3, 3, 3, dtype=torch.float32, device=w1.device)
+                be.conv_wgrad(xin.act, d_r1, tw, 3, blk.stride, **xin.kw())
+                self._gslice(w1).copy_(tw[:, :w1.shape[1]])
         self._flush_ready()
         if not need_dx:
             return None
@@ -279,9 +281,10 @@ class HipDynUNet(HipNetBase):
             tin = s["tin"]                                  # activated input of the transposed conv (raw + prologue)
             w = up.transp_conv.conv.weight
             cin = w.shape[0]
-            dw1 = torch.empty(8 * co, cin, dtype=torch.float32, device=be.device)
-            be.conv_wgrad(tin.act, d_up, dw1, 1, out_mode=OUT_D2S, **tin.kw())
-            self._gslice(w).copy_(dw1.view(2, 2, 2, co, cin).permute(4, 3, 0, 1, 2))
+            with self._wgrad_stream(be, tin.act, d_up, tin.scale, tin.shift, tin.slope_vec):
+                dw1 = torch.empty(8 * co, cin, dtype=torch.float32, device=be.device)
+                be.conv_wgrad(tin.act, d_up, dw1, 1, out_mode=OUT_D2S, **tin.kw())
+                self._gslice(w).copy_(dw1.view(2, 2, 2, co, cin).permute(4, 3, 0, 1, 2))
             dA = be.empty_act(*tin.act.shape)
             be.conv_fwd(d_up, self._packed_weight(w, 1, _tw_fwd), dA, 1, in_mode=IN_S2D)
             self._flush_ready()
