@@ -241,6 +241,63 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ring_x(RingXArgs a) {
   }
 }
 
+// ---- slab reduction with more bytes in flight (variant bit 2) ----
+// The shipped reduction gives a (pair, tap) tile to 1 or 4 workgroups, 8 loads in flight per thread: with one pair (the 32 -> 32
+// layers: 512 slabs, 56.6 MB) that is 108 workgroups x 256 threads x 8 x 16 B = 3.5 MB in flight, a third of what the HBM latency
+// needs (measured 39 us per launch on average, 1.4 ms per step, for ~12 us of traffic). Here every tile is always split over 4
+// workgroups (one 64-float4 column group each) and a thread keeps 16 running sums = 16 loads in flight; same fixed summation tree
+// per element on every run (deterministic), different from the shipped kernel's in the last bits.
+__global__ __launch_bounds__(256) void wgrad_reduce_x_kernel(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles) {
+  __shared__ float4 part[4][64];
+  const int tile = blockIdx.x >> 2, sub = blockIdx.x & 3;
+  const int tap = tile % T, pair = tile / T;
+  const int cot = pair / ciTiles, cit = pair % ciTiles;
+  const int tid = threadIdx.x, e4 = tid & 63, grp = tid >> 6;
+  const int f4 = e4 + 64 * sub;                                  // float4 index inside the 32x32 tile: row co = f4 / 8, 4 ci
+  const float4* base = reinterpret_cast<const float4*>(ws + (((size_t)pair * SL) * T + tap) * 1024) + f4;
+  const size_t slab_stride = (size_t)T * 256;                   // in float4
+  float4 acc[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k = grp;
+  for (; k + 60 < SL; k += 64) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float4 v = base[(size_t)(k + 4 * u) * slab_stride];
+      acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+    }
+  }
+  for (int u = 0; k < SL; k += 4, ++u) {
+    const float4 v = base[(size_t)k * slab_stride];
+    acc[u & 15].x += v.x; acc[u & 15].y += v.y; acc[u & 15].z += v.z; acc[u & 15].w += v.w;
+  }
+#pragma unroll
+  for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+    for (int u = 0; u < w; ++u) { acc[u].x += acc[u + w].x; acc[u].y += acc[u + w].y; acc[u].z += acc[u + w].z; acc[u].w += acc[u + w].w; }
+  part[grp][e4] = acc[0];
+  __syncthreads();
+  if (grp == 0) {
+    float4 s4 = part[0][e4];
+#pragma unroll
+    for (int g = 1; g < 4; ++g) { s4.x += part[g][e4].x; s4.y += part[g][e4].y; s4.z += part[g][e4].z; s4.w += part[g][e4].w; }
+    const int co = cot * 32 + f4 / 8, ci = cit * 32 + (f4 % 8) * 4;
+    if (co < Cout) {
+      const float v[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (ci + e < Cin) dw[((size_t)co * Cin + ci + e) * T + tap] = v[e];
+    }
+  }
+}
+
+static int wgrad_reduce_x_launch(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles, void* stream) {
+  const long long tiles = (long long)ceil_div(Cout, 32) * ciTiles * T;
+  if (tiles <= 0 || tiles * 4 > 0x7fffffffLL) return MI355_EINVAL;
+  LAUNCH(wgrad_reduce_x_kernel, dim3((unsigned)(tiles * 4)), dim3(256), 0, stream, ws, dw, Cout, Cin, T, SL, ciTiles);
+  return LAUNCH_CHECK();
+}
+
 // plan of the shipped ring kernel (conv3d_wgrad.hip: plan_wgrad_ring) with the column height as a parameter
 struct RingXPlan { int tilesY, tilesX, zchunks, planes, chunks, splits, ciTiles, coTiles; size_t ws_bytes; int ok; };
 static RingXPlan plan_ring_x(const mi355_act* x, const mi355_act* dy, int ty) {
@@ -265,7 +322,7 @@ static RingXPlan plan_ring_x(const mi355_act* x, const mi355_act* dy, int ty) {
   return p;
 }
 
-// variant: bit 0 = M16 (16x16x4 MFMA tiles, 27 per wave), bit 1 = TY8 (8x8-voxel columns)
+// variant: bit 0 = M16 (16x16x4 MFMA tiles, 27 per wave), bit 1 = TY8 (8x8-voxel columns), bit 2 = the 16-in-flight slab reduction
 extern "C" size_t mi355_conv3d_wgrad_ring_exp_workspace(const mi355_act* x, const mi355_act* dy, int32_t variant) {
   RingXPlan p = plan_ring_x(x, dy, (variant & 2) ? 8 : 4);
   return p.ok ? p.ws_bytes : 0;
@@ -293,7 +350,7 @@ extern "C" int mi355_conv3d_wgrad_ring_exp(const mi355_act* x, const mi355_act* 
   if (d->kd != 3 || d->stride != 1 || d->pad != 1 || d->out_mode != MI355_OUT_PLAIN) return MI355_EUNSUPPORTED;
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
   if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift)) return MI355_EINVAL;
-  if (variant < 0 || variant > 3) return MI355_EINVAL;
+  if (variant < 0 || variant > 7) return MI355_EINVAL;
   RingXPlan r = plan_ring_x(x, dy, (variant & 2) ? 8 : 4);
   if (!r.ok) return MI355_EUNSUPPORTED;
   if (ws_bytes < r.ws_bytes) return MI355_EWORKSPACE;
@@ -305,12 +362,13 @@ extern "C" int mi355_conv3d_wgrad_ring_exp(const mi355_act* x, const mi355_act* 
   a.zchunks = r.zchunks; a.planes = r.planes; a.tilesY = r.tilesY; a.tilesX = r.tilesX; a.chunks = r.chunks; a.splits = r.splits;
   a.ciTiles = r.ciTiles; a.coTiles = r.coTiles;
   int rc;
-  switch (variant) {
+  switch (variant & 3) {
     case 0: rc = launch_ring_x<4, false>(a, d->in_mode, stream); break;
     case 1: rc = launch_ring_x<4, true>(a, d->in_mode, stream); break;
     case 2: rc = launch_ring_x<8, false>(a, d->in_mode, stream); break;
     default: rc = launch_ring_x<8, true>(a, d->in_mode, stream); break;
   }
   if (rc) return rc;
+  if (variant & 4) return wgrad_reduce_x_launch((const float*)ws, dw, a.Cout, a.Cin, 27, r.splits, r.ciTiles, stream);
   return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, r.splits, r.ciTiles, stream);
 }

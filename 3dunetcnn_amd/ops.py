@@ -229,7 +229,8 @@ class Backend:
 
     def conv_wgrad_ring_exp(self, x, dy, dw, variant, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, in_slope=None):
         """DEVELOPER hook (not used by any module of this package): the experimental variants of the plane-ring 3x3x3 stride-1
-        weight-gradient kernel in csrc/conv3d_wgrad_exp.hip. variant bit 0: 16x16x4 MFMA tiles (27 per wave), bit 1: 8x8 columns."""
+        weight-gradient kernel in csrc/conv3d_wgrad_exp.hip. variant bit 0: 16x16x4 MFMA tiles (27 per wave), bit 1: 8x8 columns,
+        bit 2: slab reduction with 16 loads in flight per thread."""
         fn = self.lib.mi355_conv3d_wgrad_ring_exp
         fn.restype, fn.argtypes = ctypes.c_int, [ctypes.POINTER(MiAct), ctypes.POINTER(MiAct), ctypes.c_void_p, ctypes.POINTER(MiConvDesc),
                                                  ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_void_p]

@@ -231,7 +231,7 @@ def test_conv_wgrad_bf16_paths(prec_backend, kw):
 
 
 # ---- experimental ring-wgrad variants (csrc/conv3d_wgrad_exp.hip; not dispatched by the product path): index logic on the emulator ----
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])       # bit 0: 16x16x4 tiles, bit 1: 8x8 columns, bit 2: 16-in-flight slab reduction
 @pytest.mark.parametrize("kw", [
     dict(n=2, cin=32, cout=32, dhw=(5, 6, 9), norm=True),            # ragged columns in y and x, two samples
     dict(n=1, cin=64, cout=96, dhw=(4, 9, 8), norm=True, slope=0.01),  # 2 x 3 (ci, co) pairs
@@ -241,3 +241,8 @@ def test_conv_wgrad_bf16_paths(prec_backend, kw):
 ])
 def test_conv_wgrad_ring_experimental_variants(emu_backend, variant, kw):
     assert C.case_conv_wgrad_exp(emu_backend, variant, **kw) < TOL
+
+
+def test_conv_wgrad_experimental_reduction_512_slabs(emu_backend):
+    # one (co, ci) pair and 512 columns -> 512 partial slabs: the 64-slab main loop of the 16-in-flight reduction plus its tail
+    assert C.case_conv_wgrad_exp(emu_backend, 4, 4, 32, 32, (2, 64, 64), norm=True) < TOL

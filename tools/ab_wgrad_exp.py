@@ -1,7 +1,7 @@
 """Developer tool (GPU): A/B of the experimental ring-wgrad variants (csrc/conv3d_wgrad_exp.hip) against the shipped kernel.
     python tools/ab_wgrad_exp.py
 variant 0 = the shipped algorithm rebuilt in the experimental file (control), 1 = 16x16x4 MFMA tiles (27 per wave),
-2 = 8x8-voxel columns, 3 = both. Times include the slab reduction, as bench.py's roofline figure does."""
+2 = 8x8-voxel columns, 3 = both; +4 = the 16-in-flight slab reduction (4 = shipped ring kernel + new reduction). Times include the slab reduction, as bench.py's roofline figure does."""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,7 @@ for cin, cout, s in ((32, 32, 128), (64, 32, 128), (128, 128, 64), (256, 256, 32
     sc = torch.rand(n, cin, device=be.device) + 0.5; sh = torch.randn(n, cin, device=be.device) * 0.1
     kw = dict(in_mode=ops.IN_AFFINE_ACT, scale=sc, shift=sh)
     runs = {"shipped": lambda dw: be.conv_wgrad(x, dy, dw, 3, 1, **kw)}
-    for v in range(4):
+    for v in (0, 1, 2, 3, 4, 5):
         runs[f"exp{v}"] = (lambda dw, v=v: be.conv_wgrad_ring_exp(x, dy, dw, v, **kw))
     outs, best = {}, {k: 1e9 for k in runs}
     for rnd in range(3):
