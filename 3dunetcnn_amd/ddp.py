@@ -11,7 +11,12 @@ point-to-point links a ring all-reduce is per-link bound at ~153 GB/s, so a 25 M
 backward producing it takes several ms; the bucket holding the first encoder levels -- the last one backward completes,
 hence the only exposed one -- is cut to ~3 MB); when the last parameter of a bucket is ready its all-reduce is launched with
 async_op=True -- torch.distributed runs it on the communicator's own HIP stream after an event on the compute stream --
-and `wait()` (before optimizer.step) makes the compute stream wait for all of them.
+and `wait()` makes the compute stream wait for all of them. The engine calls `wait()` itself at the end of the explicit backward
+(`model.grad_sync_callback`), so the reference's unmodified loop (`loss.backward(); optimizer.step()`,
+unet3d/train/training_utils.py:71-72) steps on reduced gradients; calling it again is a no-op.
+
+Averaging happens exactly once, here (ReduceOp.AVG on RCCL, SUM followed by 1/world on other backends): leave
+`HipAdam.grad_scale` at 1.0 when a reducer is attached.
 """
 import torch.distributed as dist
 
@@ -28,6 +33,7 @@ class GradientBucketReducer:
         self._built_for = None
         model.grad_ready_callback = self._on_ready
         model.backward_start_callback = self._on_backward_start
+        model.grad_sync_callback = self.wait        # the engine joins the exchange at the end of every backward
 
     # -- setup ---------------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src=0):

@@ -44,6 +44,7 @@ class HipNetBase(nn.Module):
         self._packs_dirty_local = False
         self.grad_ready_callback = None        # set by ddp.GradientBucketReducer
         self.backward_start_callback = None
+        self.grad_sync_callback = None         # set by ddp.GradientBucketReducer: joins the bucket all-reduces at the end of backward
         self._written = []
         # EXPERIMENTAL (off by default, not yet measured): enqueue the weight-gradient kernels on a second HIP stream so that the
         # matrix-bound wgrads overlap the HBM-bound norm-backward passes of the dgrad chain (see _wgrad_stream)
@@ -210,6 +211,11 @@ class HipNetBase(nn.Module):
             if self._s2_active is not None:
                 torch.cuda.current_stream().wait_stream(self._s2_active)     # join: the optimizer reads every gradient
                 self._s2_active = None
+        if self.grad_sync_callback is not None:
+            # every bucket all-reduce has been launched by now: order the launch stream behind them (a stream-level wait on RCCL,
+            # the host does not stall), so that ANY caller's `loss.backward(); optimizer.step()` -- the reference's epoch_training
+            # loop, unet3d/train/training_utils.py:71-72 -- steps on fully reduced, averaged gradients without calling the reducer
+            self.grad_sync_callback()
         grads = []
         for p, o in zip(ps, self._offsets):
             g = gbuf[o:o + p.numel()].view(p.shape)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- training volumes/sec of the MI355X-native 3D U-Net hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: bench.py spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one optimizer step of the reference's inner loop (unet3d/train/training_utils.py:59-72:
@@ -62,7 +62,48 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="disable the per-launch HIP events (roofline -> null)")
     ap.add_argument("--no-precision-modes", action="store_true",
                     help="skip the short extra runs of the opt-in conv arithmetic modes (reported under precision_modes, N=1 only)")
+    # TEST INFRASTRUCTURE (tests/test_bench_contract.py): run the launch / rank / reduce plumbing of this script on the CPU emulator
+    # build of the kernel sources over gloo. Never a measurement: the line it prints says so in "data".
+    ap.add_argument("--emulator-plumbing-test", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, the same command line, rendezvous
+    on 127.0.0.1:<free port>) and wait for them. Rank 0 inherits stdout and prints the JSON line; a failing rank takes the job
+    down (the others are terminated by PID). The reference turns multi-GPU on with one call (unet3d/models/build.py:18-20);
+    this is the one command that does it here."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def pmc_traffic(kernel_name, precision):
@@ -130,17 +171,29 @@ def cpu_baseline(size):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))                          # no launcher: this process only starts and reaps the ranks
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; reporting n_gpus={world}", file=sys.stderr)
+    emu = args.emulator_plumbing_test
     torch.set_num_threads(max(1, (os.cpu_count() or 1) // max(world, 1)))      # host-side torch ops: no oversubscription across ranks
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if emu:
+        dev = torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+        assert local_rank < torch.cuda.device_count(), f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     unet = importlib.import_module("3dunetcnn_amd.unet")
     losses = importlib.import_module("3dunetcnn_amd.losses")
@@ -155,6 +208,9 @@ def main():
         model = dyn.HipDynUNet(spatial_dims=3, in_channels=4, out_channels=3, kernel_size=[3] * 6, strides=[1] + [2] * 5,
                                upsample_kernel_size=[2] * 5, filters=[64, 96, 128, 192, 256, 384]).to(dev)   # brats2020_config.json:2-107
         model_desc = "BraTS2020-config DynUNet 4ch->3cls (24928451 params)"
+    elif emu:
+        model = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1, 1])   # the emulator runs ~1e4x slower
+        model_desc = "REDUCED UNet3D (base_width 8, 3 levels) for the emulator plumbing test"
     else:
         model = unet.HipUNet3D(n_features=4, n_outputs=3).to(dev)
         model_desc = "UNet3D 4ch->3cls (23970216 params)"
@@ -162,6 +218,14 @@ def main():
     model.flatten_parameters()
     criterion = losses.HipDiceLoss(sigmoid=True)
     optimizer = optim.HipAdam(model.parameters(), lr=1e-3)
+    if emu:
+        import ctypes
+        lib_mod = importlib.import_module("3dunetcnn_amd._lib")
+        be = ops.Backend(lib=lib_mod.bind(ctypes.CDLL(os.path.join(ROOT, "tools", "emu", "libmi355unet3d_emu.so"))), device="cpu")
+        model._be = criterion._be = optimizer._be = be
+        args.no_kernel_events = args.no_cpu_baseline = args.no_precision_modes = True
+    else:
+        be = ops.default_backend()
     reducer = None
     if world > 1:
         reducer = ddp.GradientBucketReducer(model)
@@ -170,23 +234,21 @@ def main():
     S, B = args.size, args.batch
     x, y = synthetic.synthetic_case(B, 4, (S, S, S), seed=rank)
     x, y = x.to(dev), y.to(dev)                                   # inputs resident in HBM before the timed region
-    be = ops.default_backend()
     be.set_precision(args.precision)
 
     def step():
         optimizer.zero_grad(set_to_none=True)
         out = model(x)
         loss = criterion(out, y)
-        loss.backward()
-        if reducer is not None:
-            reducer.wait()
-        optimizer.step()
+        loss.backward()                                           # the reducer's bucket all-reduces are launched from inside backward
+        optimizer.step()                                          # and joined at its end (engine.py: grad_sync_callback)
         return loss
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -201,10 +263,13 @@ def main():
     prof, be.prof = be.prof, None
     loss_val = float(loss.item())
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    per_rank = [dt]
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
+    dt = max(per_rank)                                            # the job is as slow as its slowest rank
 
     roofline = None
     if prof:
@@ -234,7 +299,9 @@ def main():
     if rank == 0:
         out = {"metric": "training volumes/sec (128^3, 4ch->3cls)", "value": round(world * B * args.steps / dt, 4), "unit": "volumes/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
+               "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision],
+               "data": "synthetic" if not emu else "synthetic -- CPU-EMULATOR PLUMBING TEST, NOT A MEASUREMENT",
                "config": {"workload": f"BASELINE configs[1]: {model_desc}, {S}^3 patch, batch {B}/GPU, fp32 tensors, "
                                       f"fwd + sigmoid-Dice + bwd + Adam" + (", Dropout3d on" if args.model == "unet3d" else ""),
                           "conv_arithmetic": ARITH[args.precision], "global_batch": world * B, "parallelism": f"dp{world}"},

@@ -59,8 +59,7 @@ def main(out_dir, device="cpu"):
     for _ in range(2):
         opt.zero_grad(set_to_none=True)
         loss = crit(m(x), y)
-        loss.backward()
-        red.wait()
+        loss.backward()            # no reducer.wait(): the reference's loop (training_utils.py:71-72) never calls one -- the engine joins
         if "grads" not in rec:
             rec["grads"] = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
             rec["n_buckets"] = len(red.buckets)

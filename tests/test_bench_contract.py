@@ -67,3 +67,30 @@ def test_bench_needs_a_gpu():
         pytest.skip("GPU present")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1"], capture_output=True, text=True)
     assert p.returncode != 0 and "MI355X" in p.stderr
+
+
+def test_gpus_flag_launches_that_many_ranks(emu_backend):
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself and report n_gpus 2 (round 1 parsed the
+    flag and ignored it). Runs the script's launch / rendezvous / reduce / timing plumbing on the CPU emulator over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "8", "--batch", "1", "--steps", "2",
+                        "--warmup", "1", "--emulator-plumbing-test"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout                       # rank 0 prints ONE line for the whole job
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 2
+    assert len(line["per_rank_ms_per_step"]) == 2 and line["ms_per_step"] == max(line["per_rank_ms_per_step"])
+    assert abs(line["value"] - 2 * 1e3 / line["ms_per_step"]) / line["value"] < 1e-2
+    assert "NOT A MEASUREMENT" in line["data"]
+
+
+def test_launcher_environment_wins_over_self_launch(emu_backend):
+    """Under a launcher (WORLD_SIZE set, the driver's torch.distributed.run form) bench.py must NOT spawn again: one rank given
+    WORLD_SIZE=1 and --gpus 1 prints n_gpus 1."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--size", "8", "--batch", "1", "--steps", "1",
+                        "--warmup", "1", "--emulator-plumbing-test"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["per_rank_ms_per_step"] == [line["ms_per_step"]]
