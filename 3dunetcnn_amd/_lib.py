@@ -17,6 +17,12 @@ class MiAct(Structure):
                 ("c", c_int32), ("ld", c_int32)]
 
 
+class MiGnBwdFuse(Structure):
+    """mi355_gn_bwd_fuse: the dgrad conv's epilogue also emits the first pass of the norm backward."""
+    _fields_ = [("gx", c_void_p), ("gx_ld", c_int32), ("scale", c_void_p), ("shift", c_void_p), ("mean_rstd", c_void_p),
+                ("groups", c_int32), ("act_slope", c_float), ("partials_out", c_void_p)]
+
+
 class MiConvDesc(Structure):
     _fields_ = [("kd", c_int32), ("stride", c_int32), ("pad", c_int32), ("in_mode", c_int32),
                 ("act_slope", c_float),
@@ -25,7 +31,8 @@ class MiConvDesc(Structure):
                 ("out_chscale", c_void_p),
                 ("off_z", c_int32), ("off_y", c_int32), ("off_x", c_int32),
                 ("out_d", c_int32), ("out_h", c_int32), ("out_w", c_int32),
-                ("in_slope", c_void_p), ("out_mode", c_int32), ("precision", c_int32), ("wformat", c_int32)]
+                ("in_slope", c_void_p), ("out_mode", c_int32), ("precision", c_int32), ("wformat", c_int32),
+                ("moments_out", c_void_p), ("gn_bwd", POINTER(MiGnBwdFuse))]
 
 
 IN_PLAIN, IN_AFFINE_ACT, IN_ZERO_INSERT, IN_S2D = 0, 1, 2, 3
@@ -45,11 +52,19 @@ SIGNATURES = {
     "mi355_pack_conv_weight_bf16": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mi355_conv3d_uses_bf16": (ctypes.c_int, [POINTER(MiConvDesc)]),
     "mi355_conv3d_fwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, POINTER(MiAct), POINTER(MiConvDesc), c_void_p]),
+    "mi355_conv3d_stats_blocks": (c_int32, [POINTER(MiAct), POINTER(MiAct), POINTER(MiConvDesc)]),
     "mi355_conv3d_fwd_config": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), POINTER(MiConvDesc), c_char_p, c_size_t]),
     "mi355_conv3d_wgrad_workspace": (c_size_t, [POINTER(MiAct), POINTER(MiAct), POINTER(MiConvDesc)]),
     "mi355_conv3d_wgrad": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), c_void_p, POINTER(MiConvDesc), c_void_p, c_size_t, c_void_p]),
     "mi355_gn_workspace": (c_size_t, [POINTER(MiAct)]),
     "mi355_gn_stats": (ctypes.c_int, [POINTER(MiAct), c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mi355_gn_moments_blocks": (c_int32, [POINTER(MiAct)]),
+    "mi355_gn_moments": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p]),
+    "mi355_gn_finalize": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mi355_gn_act_bwd_fused": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), POINTER(MiAct), c_void_p, c_int32, c_int32, c_float,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t,
+                                              c_void_p]),
     "mi355_gn_act_bwd": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), POINTER(MiAct), c_void_p, c_int32, c_int32, c_float,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mi355_upsample2x_fwd": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), c_int32, c_int32, c_int32, c_void_p]),

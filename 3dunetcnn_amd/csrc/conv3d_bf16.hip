@@ -356,6 +356,7 @@ int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_a
   const int ns = nsplit_of(d->precision);
   if (!ns || d->kd != 3 || d->stride != 1) return MI355_EUNSUPPORTED;
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
+  if (d->moments_out || d->gn_bwd) return MI355_EUNSUPPORTED;        // see mi355_conv3d_bf16_stats_blocks
   ConvBArgs a;
   a.x = (const float*)x->p; a.xld = x->ld; a.wp = (const uint4*)wp; a.y = (float*)y->p; a.yld = y->ld;
   a.res = d->residual; a.resld = d->residual_ld;
@@ -370,4 +371,11 @@ int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_a
   if (ns == 1) return dispatch_ns<1>(a, d->in_mode, vox, stream);
   if (ns == 2) return dispatch_ns<2>(a, d->in_mode, vox, stream);
   return dispatch_ns<3>(a, d->in_mode, vox, stream);
+}
+
+// norm statistics fused into the epilogue (gn_fuse.h): not in the bf16-pipe kernels yet -- 0 tells the caller to run the
+// standalone statistics pass for outputs of these kernels
+int32_t mi355_conv3d_bf16_stats_blocks(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d) {
+  (void)x; (void)y; (void)d;
+  return 0;
 }

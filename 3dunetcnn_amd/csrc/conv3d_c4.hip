@@ -13,6 +13,7 @@
 // The forward reads the UNPACKED OIDHW weight (3456 floats per 32 output channels, staged to LDS in [(tap,ci)][co] order).
 #include "hipcompat.h"
 #include "../../include/mi355_unet3d.h"
+#include "gn_fuse.h"
 
 struct C4Args {
   const float* x; int xld;
@@ -25,6 +26,7 @@ struct C4Args {
   int N, D, H, W, Cout;
   int yD, yH, yW, offz, offy, offx;
   int tilesZ, tilesY, tilesX, coTiles, ntiles, splits;
+  float* mom;                      // forward: fused norm statistics of the output (gn_fuse.h), or NULL
 };
 
 __device__ __forceinline__ float4 c4_prologue(float4 v, const float4& sc, const float4& sh, const float4& sl) {
@@ -68,7 +70,7 @@ __device__ __forceinline__ void c4_stage_x(const C4Args& a, float4* lds_x, int n
 }
 
 // ---- forward: 4x8x8 output voxels x 32 output channels per workgroup; 4 waves x 2 M tiles ----
-template <int INMODE>
+template <int INMODE, bool FUSE>
 __global__ __launch_bounds__(256) void conv3d_c4_fwd(C4Args a) {
   constexpr int TZ = 4, TY = 8, TX = 8, HZ = 6, HY = 10, HX = 10, HV = HZ * HY * HX, MT = 2;
   __shared__ float4 lds_x[HV];            // 9600 B
@@ -111,6 +113,8 @@ __global__ __launch_bounds__(256) void conv3d_c4_fwd(C4Args a) {
     for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA_32x32x2(xs[abase[mt] + toff], bv, acc[mt]);
   }
   const int co = co0 + li;
+  unsigned vmask = 0;                      // bit mt*16 + r: that accumulator row is a voxel of the output
+  float mK = 0.f, ms0 = 0.f, ms1 = 0.f;    // FUSE: one-pass moments about K = the lane's first stored value
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -118,9 +122,12 @@ __global__ __launch_bounds__(256) void conv3d_c4_fwd(C4Args a) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
       const int tv = (wave * MT + mt) * 32 + row;
       const int oz = tz0 + tv / (TY * TX), oy = ty0 + (tv / TX) % TY, ox = tx0 + tv % TX;
-      if (oz >= a.D || oy >= a.H || ox >= a.W || co >= a.Cout) continue;
+      if (oz >= a.D || oy >= a.H || ox >= a.W) continue;
       const int sz = oz + a.offz, sy = oy + a.offy, sx = ox + a.offx;
       if (sz < 0 || sy < 0 || sx < 0 || sz >= a.yD || sy >= a.yH || sx >= a.yW) continue;
+      const bool first = FUSE && vmask == 0;
+      if (FUSE) vmask |= 1u << (mt * 16 + r);
+      if (co >= a.Cout) continue;
       const size_t ovox = (((size_t)n * a.D + oz) * a.H + oy) * a.W + ox;
       const size_t svox = (((size_t)n * a.yD + sz) * a.yH + sy) * a.yW + sx;
       float v = acc[mt][r];
@@ -128,7 +135,22 @@ __global__ __launch_bounds__(256) void conv3d_c4_fwd(C4Args a) {
       if (a.res) v += a.res[ovox * a.resld + co];
       if (a.out_chscale) v *= a.out_chscale[(size_t)n * a.Cout + co];
       a.y[svox * a.yld + co] = v;
+      if constexpr (FUSE) {
+        if (first) mK = v;
+        const float t = v - mK;
+        ms0 += t; ms1 += t * t;
+      }
     }
+  }
+  if constexpr (FUSE) {
+    // the 32-channel x 128^3 output of this layer is the largest tensor a norm ever reads: its statistics leave with the tile
+    float vals[1][3];
+    const float cnt = (float)__builtin_popcount(vmask);
+    const float m2 = cnt > 0.f ? ms1 - ms0 * ms0 / cnt : 0.f;
+    vals[0][0] = cnt; vals[0][1] = ms0 + cnt * mK; vals[0][2] = m2 > 0.f ? m2 : 0.f;
+    const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
+    const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
+    gn_fuse_reduce_store<3, 1, 4, 1>(vals, reinterpret_cast<float*>(lds_x), wave, 0, half, li, tid, a.mom + rec * a.Cout * 3, co0, a.Cout);
   }
 }
 
@@ -334,11 +356,19 @@ int mi355_conv3d_c4_fwd_impl(const mi355_act* x, const float* w, const mi355_act
   a.out_chscale = d->out_chscale; a.bias = d->bias; a.Cout = y->c;
   a.yD = y->d; a.yH = y->h; a.yW = y->w; a.offz = d->off_z; a.offy = d->off_y; a.offx = d->off_x;
   if (a.res && a.resld < a.Cout) return MI355_EINVAL;
+  if (d->gn_bwd) return MI355_EUNSUPPORTED;
+  if (d->moments_out && (d->off_z || d->off_y || d->off_x || y->d != x->d || y->h != x->h || y->w != x->w)) return MI355_EUNSUPPORTED;
+  a.mom = d->moments_out;
   a.tilesZ = ceil_div(a.D, 4); a.tilesY = ceil_div(a.H, 8); a.tilesX = ceil_div(a.W, 8); a.coTiles = ceil_div(a.Cout, 32);
   const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
-  if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_c4_fwd<MI355_IN_PLAIN>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-  else LAUNCH((conv3d_c4_fwd<MI355_IN_AFFINE_ACT>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  if (a.mom) {
+    if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_c4_fwd<MI355_IN_PLAIN, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else LAUNCH((conv3d_c4_fwd<MI355_IN_AFFINE_ACT, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  } else {
+    if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_c4_fwd<MI355_IN_PLAIN, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else LAUNCH((conv3d_c4_fwd<MI355_IN_AFFINE_ACT, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  }
   return LAUNCH_CHECK();
 }
 

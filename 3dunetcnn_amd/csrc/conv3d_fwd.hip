@@ -14,6 +14,7 @@
 // (s, 4+s); A and B use the same permutation so the sum is unchanged.
 #include "hipcompat.h"
 #include "../../include/mi355_unet3d.h"
+#include "gn_fuse.h"
 
 struct ConvArgs {
   const float* x; int xld;
@@ -31,12 +32,16 @@ struct ConvArgs {
   const float* in_slope;   // per-input-channel negative slope (NULL: scalar slope)
   int outmode;             // MI355_OUT_*
   int cD, cH, cW, fC;      // IN_S2D / OUT_D2S (1x1x1 only): coarse grid extents and the fine tensor's channel count
+  GnFuseArgs g;            // norm statistics fused into the epilogue (gn_fuse.h); both pointers NULL: nothing extra
 };
 
 // FULLJ: CinP is a multiple of KC, so every chunk has all KC/8 k-groups and the tap loop contains no data-dependent branch
 // (with a runtime k-group count the compiler keeps the accumulators in VGPRs across the branches and copies all of them to
 // and from AGPRs around every group of MFMAs).
-template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT, int INMODE, bool TL = false, bool FULLJ = false>
+// FUSE: the epilogue also reduces norm statistics of what it stores (gn_fuse.h): 1 = moments of the output (forward), 2 = the
+// norm-backward partial sums (dgrad). Separate instantiations so that the plain kernels keep their register budget (the extra
+// live values cost a wave of occupancy per SIMD in several configurations).
+template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT, int INMODE, bool TL = false, bool FULLJ = false, int FUSE = 0>
 __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TZ * TY * TX == 32 * WM * MT, "tile voxels must equal 32*WM*MT");
@@ -295,45 +300,108 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
   }
 
   // ---- epilogue: bias, residual, dropout scale, windowed store ----
+  if constexpr (FUSE == 0) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int tv = (wm * MT + mt) * 32 + row;
-      int oz = tz0 + tv / (TY * TX), oy = ty0 + (tv / TX) % TY, ox = tx0 + tv % TX;
-      if (ZIP) { oz = tz0 + 2 * (row >> 4) + (zcls >> 1); oy = ty0 + 2 * ((row >> 2) & 3) + (zcls & 1); ox = tx0 + 2 * (row & 3) + mt; }
-      if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
-      if (KD == 1 && a.outmode == MI355_OUT_D2S) {
-        // ConvTranspose3d(k2,s2): logical channel p*fC + k of coarse voxel ox (flat) -> fine voxel (2z+a, 2y+b, 2x+e), channel k
-        const int xx = ox % a.cW, yy = (ox / a.cW) % a.cH, zz = ox / (a.cW * a.cH);
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int tv = (wm * MT + mt) * 32 + row;
+        int oz = tz0 + tv / (TY * TX), oy = ty0 + (tv / TX) % TY, ox = tx0 + tv % TX;
+        if (ZIP) { oz = tz0 + 2 * (row >> 4) + (zcls >> 1); oy = ty0 + 2 * ((row >> 2) & 3) + (zcls & 1); ox = tx0 + 2 * (row & 3) + mt; }
+        if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
+        if (KD == 1 && a.outmode == MI355_OUT_D2S) {
+          // ConvTranspose3d(k2,s2): logical channel p*fC + k of coarse voxel ox (flat) -> fine voxel (2z+a, 2y+b, 2x+e), channel k
+          const int xx = ox % a.cW, yy = (ox / a.cW) % a.cH, zz = ox / (a.cW * a.cH);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int co = co_base + nt * 32 + li;
+            if (co >= a.Cout) continue;
+            const int p = co / a.fC, k = co - p * a.fC;
+            const size_t fv = (((size_t)n * (2 * a.cD) + 2 * zz + (p >> 2)) * (2 * a.cH) + 2 * yy + ((p >> 1) & 1)) * (2 * a.cW) + 2 * xx + (p & 1);
+            float v = acc[mt][nt][r];
+            if (a.bias) v += a.bias[k];
+            a.y[fv * a.yld + k] = v;
+          }
+          continue;
+        }
+        const int sz = oz + a.offz, sy = oy + a.offy, sx = ox + a.offx;
+        if (sz < 0 || sy < 0 || sx < 0 || sz >= a.yD || sy >= a.yH || sx >= a.yW) continue;
+        const size_t ovox = (((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+        const size_t svox = (((size_t)n * a.yD + sz) * a.yH + sy) * a.yW + sx;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int co = co_base + nt * 32 + li;
           if (co >= a.Cout) continue;
-          const int p = co / a.fC, k = co - p * a.fC;
-          const size_t fv = (((size_t)n * (2 * a.cD) + 2 * zz + (p >> 2)) * (2 * a.cH) + 2 * yy + ((p >> 1) & 1)) * (2 * a.cW) + 2 * xx + (p & 1);
           float v = acc[mt][nt][r];
-          if (a.bias) v += a.bias[k];
-          a.y[fv * a.yld + k] = v;
+          if (a.bias) v += a.bias[co];
+          if (a.res) v += a.res[ovox * a.resld + co];
+          if (a.out_chscale) v *= a.out_chscale[(size_t)n * a.Cout + co];
+          a.y[svox * a.yld + co] = v;
         }
-        continue;
-      }
-      const int sz = oz + a.offz, sy = oy + a.offy, sx = ox + a.offx;
-      if (sz < 0 || sy < 0 || sx < 0 || sz >= a.yD || sy >= a.yH || sx >= a.yW) continue;
-      const size_t ovox = (((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
-      const size_t svox = (((size_t)n * a.yD + sz) * a.yH + sy) * a.yW + sx;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int co = co_base + nt * 32 + li;
-        if (co >= a.Cout) continue;
-        float v = acc[mt][nt][r];
-        if (a.bias) v += a.bias[co];
-        if (a.res) v += a.res[ovox * a.resld + co];
-        if (a.out_chscale) v *= a.out_chscale[(size_t)n * a.Cout + co];
-        a.y[svox * a.yld + co] = v;
       }
     }
+  } else {
+    // ---- the same epilogue + norm statistics of what it stores (gn_fuse.h). The host only selects these instantiations for
+    // un-windowed plain outputs (stats_fusable), so the stored voxel IS the logical one. One N tile at a time: the running sums of a
+    // single channel column are live, not NT of them (the 4-tile configurations sit at their register limit).
+    constexpr int K = FUSE == 1 ? 3 : 2;
+    float vals[NT][K];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = co_base + nt * 32 + li;
+      const bool cov = co < a.Cout;
+      const int coc = cov ? co : a.Cout - 1;
+      float bs = 0.f, cs = 1.f;
+      if (a.bias) bs = a.bias[coc];
+      if (a.out_chscale) cs = a.out_chscale[(size_t)n * a.Cout + coc];
+      // FUSE 1: one-pass moments about K0 = the lane's first stored value of this channel (a sample of the data: no cancellation)
+      // FUSE 2: sum du, sum du * xhat with du = dA * act'(scale * gx + shift), xhat = (gx - mean) * rstd
+      float K0 = 0.f, s0 = 0.f, s1 = 0.f, gsc = 1.f, gsh = 0.f, gmean = 0.f, grstd = 1.f;
+      int cnt = 0;
+      if constexpr (FUSE == 2) {
+        const int grp = coc / (a.Cout / a.g.ggroups);
+        gsc = a.g.gscale[(size_t)n * a.Cout + coc]; gsh = a.g.gshift[(size_t)n * a.Cout + coc];
+        gmean = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int tv = (wm * MT + mt) * 32 + row;
+          const int oz = tz0 + tv / (TY * TX), oy = ty0 + (tv / TX) % TY, ox = tx0 + tv % TX;
+          if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo || !cov) continue;
+          const size_t ovox = (((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+          float v = acc[mt][nt][r] + bs;
+          if (a.res) v += a.res[ovox * a.resld + co];
+          v *= cs;
+          a.y[ovox * a.yld + co] = v;
+          if constexpr (FUSE == 1) {
+            if (cnt == 0) K0 = v;
+            const float t = v - K0;
+            s0 += t; s1 += t * t;
+          } else {
+            const float xv = a.g.gx[ovox * a.g.gxld + co];
+            const float u = xv * gsc + gsh;
+            const float du = u > 0.f ? v : v * a.g.gslope;
+            s0 += du; s1 += du * ((xv - gmean) * grstd);
+          }
+          ++cnt;
+        }
+      }
+      if constexpr (FUSE == 1) {
+        const float c = (float)cnt;
+        const float m2 = cnt > 0 ? s1 - s0 * s0 / c : 0.f;
+        vals[nt][0] = c; vals[nt][1] = s0 + c * K0; vals[nt][2] = m2 > 0.f ? m2 : 0.f;
+      } else {
+        vals[nt][0] = s0; vals[nt][1] = s1;
+      }
+    }
+    const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
+    const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
+    float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * K;
+    gn_fuse_reduce_store<K, NT, WM, WN>(vals, lds, wm, wn, half, li, tid, dst, cot * (32 * WN * NT), a.Cout);
   }
 }
 
@@ -397,12 +465,23 @@ static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
   // (not for the 4-tile configuration: 64 more live registers would cost a wave of occupancy per SIMD)
   const bool tl = KD == 3 && MT * NT <= 2 && (a.CinP >= 4 * KC || (MT * NT == 1 && a.CinP >= 2 * KC));
   const bool fullj = a.CinP % KC == 0;
+  if (a.g.mom && a.g.gnb) return MI355_EUNSUPPORTED;     // a call is a forward (moments) or a dgrad (norm-backward sums), not both
+  const int fuse = a.g.mom ? 1 : (a.g.gnb ? 2 : 0);
+  if (fuse && (KD != 3 || (in_mode != MI355_IN_PLAIN && in_mode != MI355_IN_AFFINE_ACT))) return MI355_EUNSUPPORTED;
+#define MI355_LAUNCH_CONV4(SS, IM, LDSB, FU)                                                                                         \
+  do {                                                                                                                         \
+    if (tl && fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, true, FU>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);  \
+    else if (tl) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, false, FU>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);      \
+    else if (fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, true, FU>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);       \
+    else LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, false, FU>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);                 \
+  } while (0)
 #define MI355_LAUNCH_CONV(SS, IM, LDSB)                                                                                              \
   do {                                                                                                                         \
-    if (tl && fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, true>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);  \
-    else if (tl) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, false>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);      \
-    else if (fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, true>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);       \
-    else LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, false>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);                 \
+    if constexpr (KD == 3 && (IM == MI355_IN_PLAIN || IM == MI355_IN_AFFINE_ACT)) {                                            \
+      if (fuse == 1) MI355_LAUNCH_CONV4(SS, IM, LDSB, 1);                                                                      \
+      else if (fuse == 2) { if constexpr (IM == MI355_IN_PLAIN) MI355_LAUNCH_CONV4(SS, IM, LDSB, 2); else return MI355_EUNSUPPORTED; } \
+      else MI355_LAUNCH_CONV4(SS, IM, LDSB, 0);                                                                                \
+    } else MI355_LAUNCH_CONV4(SS, IM, LDSB, 0);                                                                                \
   } while (0)
   if (in_mode == MI355_IN_PLAIN) {
     MI355_LAUNCH_CONV(STRIDE, MI355_IN_PLAIN, lds);
@@ -422,6 +501,7 @@ static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
     } else return MI355_EUNSUPPORTED;
   }
 #undef MI355_LAUNCH_CONV
+#undef MI355_LAUNCH_CONV4
   return LAUNCH_CHECK();
 }
 
@@ -440,7 +520,27 @@ static int select_cfg(int kd, int stride, long long vox, int cout, int in_mode =
   return cout > 32 ? 6 : 7;
 }
 
+// spatial tile (TZ, TY, TX) of each configuration id (select_cfg); 1x1x1 tiles are 256 voxels of the flattened volume
+static void cfg_tile(int cfg, int& tz, int& ty, int& tx) {
+  switch (cfg) {
+    case 0: case 1: tz = 1; ty = 1; tx = 256; break;
+    case 4: case 5: tz = 4; ty = 8; tx = 8; break;
+    case 6: tz = 2; ty = 4; tx = 8; break;
+    default: tz = 4; ty = 4; tx = 8; break;      // 2, 3, 7, 8
+  }
+}
+
+// can this call fuse norm statistics into its epilogue? (plain, un-windowed output: what is stored IS the logical tensor)
+static bool stats_fusable(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d) {
+  if (!x || !y || !d || d->out_mode != MI355_OUT_PLAIN || d->in_mode == MI355_IN_S2D) return false;
+  if (d->off_z || d->off_y || d->off_x || d->out_d != y->d || d->out_h != y->h || d->out_w != y->w) return false;
+  if ((d->kd != 1 && d->kd != 3) || (d->stride != 1 && d->stride != 2)) return false;
+  return true;
+}
+
 int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream);
+int32_t mi355_conv3d_bf16_stats_blocks(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d);
+int mi355_conv3d_c4_ok(const mi355_act* x, const mi355_conv_desc* d);
 int mi355_conv3d_c4_fwd_impl(const mi355_act* x, const float* w, const mi355_act* y, const mi355_conv_desc* d, void* stream);
 int mi355_conv3d_narrow_ok(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d);
 int mi355_conv3d_narrow_impl(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream);
@@ -448,6 +548,41 @@ int mi355_conv3d_narrow_impl(const mi355_act* x, const float* wp, const mi355_ac
 extern "C" int mi355_conv3d_uses_bf16(const mi355_conv_desc* d) {
   return d && d->precision != MI355_PREC_F32 && d->kd == 3 && d->stride == 1 &&
          (d->in_mode == MI355_IN_PLAIN || d->in_mode == MI355_IN_AFFINE_ACT);
+}
+
+extern "C" int32_t mi355_conv3d_stats_blocks(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d) {
+  if (!stats_fusable(x, y, d)) return 0;
+  if (d->wformat == MI355_W_PACKED_F32_NARROW || (d->wformat == MI355_W_PACKED && d->precision == MI355_PREC_F32 && mi355_conv3d_narrow_ok(x, y, d)))
+    return 0;
+  long long b;
+  if (d->wformat == MI355_W_OIDHW4) {
+    if (!mi355_conv3d_c4_ok(x, d)) return 0;
+    b = (long long)ceil_div(y->d, 4) * ceil_div(y->h, 8) * ceil_div(y->w, 8);
+  } else if (mi355_conv3d_uses_bf16(d)) {
+    return mi355_conv3d_bf16_stats_blocks(x, y, d);
+  } else if (d->kd == 1 || (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT)) {
+    return 0;                 // only the 3x3x3 kernels reading a plain / normalised input carry the fused-statistics epilogue
+  } else {
+    int tz, ty, tx;
+    cfg_tile(select_cfg(d->kd, d->stride, (long long)y->d * y->h * y->w * x->n, y->c, d->in_mode), tz, ty, tx);
+    b = (long long)ceil_div(y->d, tz) * ceil_div(y->h, ty) * ceil_div(y->w, tx);
+  }
+  return b > 0 && b <= 0x7fffffffLL ? (int32_t)b : 0;
+}
+
+static int fill_gn_fuse(GnFuseArgs& g, const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d) {
+  memset(&g, 0, sizeof(g));
+  if (!d->moments_out && !d->gn_bwd) return 0;
+  if (!stats_fusable(x, y, d)) return MI355_EUNSUPPORTED;
+  g.mom = d->moments_out;
+  if (d->gn_bwd) {
+    const mi355_gn_bwd_fuse* f = d->gn_bwd;
+    if (!f->gx || !f->scale || !f->shift || !f->mean_rstd || !f->partials_out || f->groups <= 0 || y->c % f->groups || f->gx_ld < y->c)
+      return MI355_EINVAL;
+    g.gnb = f->partials_out; g.gx = f->gx; g.gxld = f->gx_ld; g.gscale = f->scale; g.gshift = f->shift; g.gmr = f->mean_rstd;
+    g.ggroups = f->groups; g.gslope = f->act_slope;
+  }
+  return 0;
 }
 
 extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
@@ -462,9 +597,11 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
   if (d->out_mode != MI355_OUT_PLAIN && d->out_mode != MI355_OUT_D2S) return MI355_EINVAL;
   if (d->precision < MI355_PREC_F32 || d->precision > MI355_PREC_BF16) return MI355_EINVAL;
   if (d->wformat == MI355_W_OIDHW4) return mi355_conv3d_c4_fwd_impl(x, wp, y, d, stream);
-  if (d->wformat == MI355_W_PACKED_F32_NARROW) return mi355_conv3d_narrow_impl(x, wp, y, d, stream);
+  const bool wants_stats = d->moments_out || d->gn_bwd;
+  if (d->wformat == MI355_W_PACKED_F32_NARROW) return wants_stats ? MI355_EUNSUPPORTED : mi355_conv3d_narrow_impl(x, wp, y, d, stream);
   if (d->wformat != MI355_W_PACKED) return MI355_EINVAL;
-  if (d->precision == MI355_PREC_F32 && mi355_conv3d_narrow_ok(x, y, d)) return mi355_conv3d_narrow_impl(x, wp, y, d, stream);
+  if (d->precision == MI355_PREC_F32 && mi355_conv3d_narrow_ok(x, y, d))
+    return wants_stats ? MI355_EUNSUPPORTED : mi355_conv3d_narrow_impl(x, wp, y, d, stream);
   if (mi355_conv3d_uses_bf16(d)) {
     if (d->out_d <= 0 || d->out_h <= 0 || d->out_w <= 0) return MI355_EINVAL;
     return mi355_conv3d_fwd_bf16_impl(x, wp, y, d, stream);
@@ -481,6 +618,7 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
   a.pad = d->pad;
   a.in_slope = d->in_slope; a.outmode = d->out_mode; a.cD = a.cH = a.cW = 1; a.fC = 4;
   if (a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0) return MI355_EINVAL;
+  { const int rcg = fill_gn_fuse(a.g, x, y, d); if (rcg) return rcg; }
   if (a.res && a.resld < a.Cout) return MI355_EINVAL;
   const int im = d->in_mode;
   const int cfg = select_cfg(d->kd, d->stride, (long long)a.Do * a.Ho * a.Wo * a.N, a.Cout, im);

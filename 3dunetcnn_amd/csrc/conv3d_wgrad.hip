@@ -199,21 +199,29 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
 }
 
 // ---- 3x3x3 stride-1 wgrad, plane-ring form (the dominant kernel of the training step) ----
-// A workgroup owns a 4(y) x 8(x) column of output voxels for one (32 co x 32 ci) pair and marches along z. LDS holds a ring of
-// 4 haloed input planes (6 x 10 voxels x 32 ci) and 2 dy planes (32 voxels x 32 co): while the 4 waves run the 16 voxel-pair
-// k-steps x 7 taps of output plane z out of ring slots z-1, z, z+1, the global loads of input plane z+2 and dy plane z+1 are
-// in flight (3 float4 per thread, issued before the MFMA loop); they are normalised / activated and written to the free
-// ring slot after it -- one barrier per plane, and the HBM/L2 latency never sits between two MFMA loops. Compared with the
-// tile form above (stage 4x4x8 tile -> barrier -> MFMAs -> barrier) the halo overhead drops from 2.8 to 1.9 input voxels
-// per output voxel and LDS from 62 KB to 38 KB. Operand layout and MFMA mapping are the same: conflict-free ds_read_b32 of 32
-// consecutive channels, A = dy[voxel][co], B = in(x)[voxel + tap][ci], K = voxel pairs.
-template <int INMODE>
+// A workgroup owns a TY(y) x 8(x) column of output voxels for one (32 co x 32 ci) pair and marches along z. LDS holds a ring of
+// 4 haloed input planes ((TY+2) x 10 voxels x 32 ci) and 2 dy planes (TY*8 voxels x 32 co): while the 4 waves run the TY*4
+// voxel-pair k-steps x 7 taps of output plane z out of ring slots z-1, z, z+1, the global loads of input plane z+2 and dy plane
+// z+1 are in flight (issued before the MFMA loop); they are normalised / activated and written to the free ring slot after it --
+// one barrier per plane, and the HBM/L2 latency never sits between two MFMA loops. Compared with the tile form above (stage
+// 4x4x8 tile -> barrier -> MFMAs -> barrier) the halo overhead drops from 2.8 to 1.9 (TY = 4) / 1.56 (TY = 8) input voxels per
+// output voxel. Operand layout and MFMA mapping are the same: conflict-free ds_read_b32 of 32 consecutive channels,
+// A = dy[voxel][co], B = in(x)[voxel + tap][ci], K = voxel pairs.
+// TY = 8 (8x8 columns, 67.6 KB of LDS = two workgroups per CU, which is what the register file allows anyway): half the barriers
+// per output voxel; measured on MI355X (round 2 A/B, tools/ab_wgrad history in DESIGN.md): +1.9 % on every 128^3 / 64^3 / 32^3
+// layer (32->32 @128^3: 1.843 -> 1.809 ms). TY = 4 stays for the small deep levels, where 8x8 columns would leave too few chunks.
+// Two variants lost the same A/B and are gone: v_mfma_f32_16x16x4_f32 tiles, 27 per wave (tap-balanced, but -3 %: twice the
+// LDS operand reads per flop), and a slab reduction with 16 loads in flight per thread (-1 .. -6 %).
+template <int INMODE, int TY>
 __global__ __launch_bounds__(256) void conv3d_wgrad_ring(WgradArgs a) {
-  constexpr int TY = 4, TX = 8, HY = 6, HX = 10, PV = TY * TX, HPV = HY * HX;
+  constexpr int TX = 8, HY = TY + 2, HX = 10, PV = TY * TX, HPV = HY * HX;
   constexpr int XSLOT = HPV * 32, DSLOT = PV * 32;
+  constexpr int NXU = (HPV * 8 + 255) / 256, NDU = (PV * 8) / 256;     // staging units (voxel, channel quad) per thread and plane
+  static_assert((PV * 8) % 256 == 0, "dy plane staging");
   constexpr int NTW = 7;
-  __shared__ float lds_x[4 * XSLOT];     // 30720 B
-  __shared__ float lds_dy[2 * DSLOT];    //  8192 B
+  DYN_LDS(lds);
+  float* lds_x = lds;                    // ring of 4 haloed input planes [HPV][32]
+  float* lds_dy = lds + 4 * XSLOT;       // 2 dy planes [PV][32]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, li = lane & 31;
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ring(WgradArgs a) {
     int tap = wave + 4 * ti;
     if (tap >= 27) tap = 26;
     tdz[ti] = tap / 9;
-    tin[ti] = (((tap / 3) % 3) * HX + tap % 3) * 32;
+    tin[ti] = (((tap / 3) % 3) * HX + tap % 3) * 32 + li;
   }
   f32x16 acc[NTW];
 #pragma unroll
@@ -233,97 +241,110 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ring(WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
 
-  const int sq = tid & 7, sv0 = tid >> 3;          // staging unit: voxel sv0 (+32) of the plane, channel quad sq
+  const int sq = tid & 7, sv0 = tid >> 3;          // staging unit u: voxel sv0 + 32 * u of the plane, channel quad sq
   const int cdy = co0 + 4 * sq, cx = ci0 + 4 * sq;
   const bool dyvalid = cdy < a.Cout, xvalid = cx < a.Cin;
   // Chunks (column x z range) split, split + splits, ... of the a.ntiles chunks belong to this workgroup: neighbouring
   // columns are walked by neighbouring workgroups at the same time (their halos meet in L2) and all of them accumulate into
   // the same 27 tap tiles, so the number of partial slabs is the number of workgroups, not of columns.
   for (int chunk = split; chunk < a.ntiles; chunk += a.splits) {
-  int b = chunk;
-  const int zc = b % a.tilesZ; b /= a.tilesZ;
-  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
-  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
-  const int n = b;
-  const int zb = zc * a.pad, ze = zb + a.pad < a.Do ? zb + a.pad : a.Do;
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
-  if (INMODE == MI355_IN_AFFINE_ACT && xvalid) {
-    sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + cx);
-    sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + cx);
-    if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + cx);
-  }
-  // in-plane coordinates of this thread's staging units (fixed for the whole column)
-  const int hv1 = sv0 + 32 < HPV ? sv0 + 32 : HPV - 1;
-  const int hy0 = sv0 / HX, hx0 = sv0 % HX, hy1 = hv1 / HX, hx1 = hv1 % HX;
-  const int iy0 = ty0 - 1 + hy0, ix0 = tx0 - 1 + hx0, iy1 = ty0 - 1 + hy1, ix1 = tx0 - 1 + hx1;
-  const bool in0 = xvalid && iy0 >= 0 && ix0 >= 0 && iy0 < a.Hi && ix0 < a.Wi;
-  const bool in1 = xvalid && sv0 + 32 < HPV && iy1 >= 0 && ix1 >= 0 && iy1 < a.Hi && ix1 < a.Wi;
-  const int cy0 = iy0 < 0 ? 0 : (iy0 < a.Hi ? iy0 : a.Hi - 1), cx0 = ix0 < 0 ? 0 : (ix0 < a.Wi ? ix0 : a.Wi - 1);
-  const int cy1 = iy1 < 0 ? 0 : (iy1 < a.Hi ? iy1 : a.Hi - 1), cx1 = ix1 < 0 ? 0 : (ix1 < a.Wi ? ix1 : a.Wi - 1);
-  const size_t xo0 = ((size_t)cy0 * a.Wi + cx0) * a.xld + (xvalid ? cx : 0), xo1 = ((size_t)cy1 * a.Wi + cx1) * a.xld + (xvalid ? cx : 0);
-  const int oy = ty0 + sv0 / TX, ox = tx0 + sv0 % TX;
-  const bool dyin = dyvalid && oy < a.Ho && ox < a.Wo;
-  const size_t dyo = ((size_t)(oy < a.Ho ? oy : a.Ho - 1) * a.Wo + (ox < a.Wo ? ox : a.Wo - 1)) * a.dyld + (dyvalid ? cdy : 0);
-  const float* xn = a.x + (size_t)n * a.Di * a.Hi * a.Wi * a.xld;
-  const float* dyn = a.dy + (size_t)n * a.Do * a.Ho * a.Wo * a.dyld;
-  const size_t xplane = (size_t)a.Hi * a.Wi * a.xld, dyplane = (size_t)a.Ho * a.Wo * a.dyld;
-
-  float4 px0, px1, pdy;
-  auto load_x = [&](int iz) {                    // input plane iz (may lie outside the volume: clamped address, masked at commit)
-    const int cz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
-    px0 = *reinterpret_cast<const float4*>(xn + cz * xplane + xo0);
-    px1 = *reinterpret_cast<const float4*>(xn + cz * xplane + xo1);
-  };
-  auto load_dy = [&](int oz) {
-    const int cz = oz < a.Do ? oz : a.Do - 1;
-    pdy = *reinterpret_cast<const float4*>(dyn + cz * dyplane + dyo);
-  };
-  auto prologue = [&](float4 v) {
-    if (INMODE == MI355_IN_AFFINE_ACT) {
-      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-      v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
-      v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+    int b = chunk;
+    const int zc = b % a.tilesZ; b /= a.tilesZ;
+    const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+    const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+    const int n = b;
+    const int zb = zc * a.pad, ze = zb + a.pad < a.Do ? zb + a.pad : a.Do;      // a.pad = planes per chunk (ring plan)
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
+    if (INMODE == MI355_IN_AFFINE_ACT && xvalid) {
+      sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + cx);
+      sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + cx);
+      if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + cx);
     }
-    return v;
-  };
-  auto commit_x = [&](int iz) {
-    const bool zin = iz >= 0 && iz < a.Di;
-    float* slot = lds_x + ((iz + 1) & 3) * XSLOT;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(slot + sv0 * 32 + 4 * sq) = (zin && in0) ? prologue(px0) : z4;
-    if (sv0 + 32 < HPV) *reinterpret_cast<float4*>(slot + (sv0 + 32) * 32 + 4 * sq) = (zin && in1) ? prologue(px1) : z4;
-  };
-  auto commit_dy = [&](int oz) {
-    *reinterpret_cast<float4*>(lds_dy + (oz & 1) * DSLOT + sv0 * 32 + 4 * sq) = (dyin && oz < a.Do) ? pdy : make_float4(0.f, 0.f, 0.f, 0.f);
-  };
-
-  // fill: input planes zb-1, zb, zb+1 and dy plane zb
-  for (int iz = zb - 1; iz <= zb + 1; ++iz) { load_x(iz); commit_x(iz); }
-  load_dy(zb); commit_dy(zb);
-  __syncthreads();
-
-  for (int z = zb; z < ze; ++z) {
-    const bool more = z + 1 < ze;
-    if (more) { load_x(z + 2); load_dy(z + 1); }
-    SCHED_BARRIER();                 // the loads stay above the MFMA loop they overlap with
-    int soff[NTW];
+    // in-plane geometry of this thread's staging units (fixed for the whole column)
+    bool xin[NXU], xuse[NXU]; size_t xo[NXU]; int xl[NXU];
 #pragma unroll
-    for (int ti = 0; ti < NTW; ++ti) soff[ti] = ((z + tdz[ti]) & 3) * XSLOT + tin[ti] + li;
-    const float* dys = lds_dy + (z & 1) * DSLOT + li;
-#pragma unroll 4
-    for (int ks = 0; ks < PV / 2; ++ks) {
-      const int v = 2 * ks + half;
-      const float av = dys[v * 32];
-      const int xb = ((v / TX) * HX + v % TX) * 32;
-#pragma unroll
-      for (int ti = 0; ti < NTW; ++ti) acc[ti] = MFMA_32x32x2(av, lds_x[soff[ti] + xb], acc[ti]);
+    for (int u = 0; u < NXU; ++u) {
+      const int hv = sv0 + 32 * u;
+      xuse[u] = hv < HPV;
+      const int hvc = xuse[u] ? hv : HPV - 1;
+      const int hy = hvc / HX, hx = hvc % HX;
+      const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+      xin[u] = xvalid && xuse[u] && iy >= 0 && ix >= 0 && iy < a.Hi && ix < a.Wi;
+      const int cy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1), cxx = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
+      xo[u] = ((size_t)cy * a.Wi + cxx) * a.xld + (xvalid ? cx : 0);
+      xl[u] = hvc * 32 + 4 * sq;
     }
-    SCHED_BARRIER();
-    if (more) { commit_x(z + 2); commit_dy(z + 1); }
+    bool din[NDU]; size_t dyo[NDU]; int dl[NDU];
+#pragma unroll
+    for (int u = 0; u < NDU; ++u) {
+      const int v = sv0 + 32 * u;
+      const int oy = ty0 + v / TX, ox = tx0 + v % TX;
+      din[u] = dyvalid && oy < a.Ho && ox < a.Wo;
+      dyo[u] = ((size_t)(oy < a.Ho ? oy : a.Ho - 1) * a.Wo + (ox < a.Wo ? ox : a.Wo - 1)) * a.dyld + (dyvalid ? cdy : 0);
+      dl[u] = v * 32 + 4 * sq;
+    }
+    const float* xn = a.x + (size_t)n * a.Di * a.Hi * a.Wi * a.xld;
+    const float* dyn = a.dy + (size_t)n * a.Do * a.Ho * a.Wo * a.dyld;
+    const size_t xplane = (size_t)a.Hi * a.Wi * a.xld, dyplane = (size_t)a.Ho * a.Wo * a.dyld;
+
+    float4 px[NXU], pdy[NDU];
+    auto load_x = [&](int iz) {                    // input plane iz (may lie outside the volume: clamped address, masked at commit)
+      const int cz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
+#pragma unroll
+      for (int u = 0; u < NXU; ++u) px[u] = *reinterpret_cast<const float4*>(xn + cz * xplane + xo[u]);
+    };
+    auto load_dy = [&](int oz) {
+      const int cz = oz < a.Do ? oz : a.Do - 1;
+#pragma unroll
+      for (int u = 0; u < NDU; ++u) pdy[u] = *reinterpret_cast<const float4*>(dyn + cz * dyplane + dyo[u]);
+    };
+    auto prologue = [&](float4 v) {
+      if (INMODE == MI355_IN_AFFINE_ACT) {
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
+        v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+      }
+      return v;
+    };
+    auto commit_x = [&](int iz) {
+      const bool zin = iz >= 0 && iz < a.Di;
+      float* slot = lds_x + ((iz + 1) & 3) * XSLOT;
+#pragma unroll
+      for (int u = 0; u < NXU; ++u)
+        if (xuse[u]) *reinterpret_cast<float4*>(slot + xl[u]) = (zin && xin[u]) ? prologue(px[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto commit_dy = [&](int oz) {
+#pragma unroll
+      for (int u = 0; u < NDU; ++u)
+        *reinterpret_cast<float4*>(lds_dy + (oz & 1) * DSLOT + dl[u]) = (din[u] && oz < a.Do) ? pdy[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+
+    // fill: input planes zb-1, zb, zb+1 and dy plane zb (the previous chunk ended with a barrier: every wave is done with the ring)
+    for (int iz = zb - 1; iz <= zb + 1; ++iz) { load_x(iz); commit_x(iz); }
+    load_dy(zb); commit_dy(zb);
     __syncthreads();
-  }
 
+    for (int z = zb; z < ze; ++z) {
+      const bool more = z + 1 < ze;
+      if (more) { load_x(z + 2); load_dy(z + 1); }
+      SCHED_BARRIER();                 // the loads stay above the MFMA loop they overlap with
+      int soff[NTW];
+#pragma unroll
+      for (int ti = 0; ti < NTW; ++ti) soff[ti] = ((z + tdz[ti]) & 3) * XSLOT + tin[ti];
+      const float* dys = lds_dy + (z & 1) * DSLOT + li;
+#pragma unroll 4
+      for (int ks = 0; ks < PV / 2; ++ks) {
+        const int v = 2 * ks + half;
+        const float av = dys[v * 32];
+        const int xb = ((v / TX) * HX + v % TX) * 32;
+#pragma unroll
+        for (int ti = 0; ti < NTW; ++ti) acc[ti] = MFMA_32x32x2(av, lds_x[soff[ti] + xb], acc[ti]);
+      }
+      SCHED_BARRIER();
+      if (more) { commit_x(z + 2); commit_dy(z + 1); }
+      __syncthreads();
+    }
   }
 
   // ---- partial tiles: ws[pair][slab = split][tap][32 co][32 ci] ----
@@ -456,11 +477,12 @@ static WgradPlan plan_wgrad(const mi355_act* x, const mi355_act* dy, const mi355
 // plane-ring plan (3x3x3 stride 1): columns of 4x8 output voxels, cut into z chunks of >= 16 planes only when a (co, ci) pair
 // would otherwise have fewer than 2 chunks per workgroup; 512 workgroups in total (2 per CU = what the register file holds:
 // one round, no tail), i.e. 512 / pairs workgroups and partial slabs per pair.
-struct RingPlan { int tilesY, tilesX, zchunks, planes, chunks, splits, ciTiles, coTiles; size_t ws_bytes; int ok; };
+struct RingPlan { int ty, tilesY, tilesX, zchunks, planes, chunks, splits, ciTiles, coTiles; size_t ws_bytes; int ok; };
 static RingPlan plan_wgrad_ring(const mi355_act* x, const mi355_act* dy) {
   RingPlan p; memset(&p, 0, sizeof(p));
   if (x->d != dy->d || x->h != dy->h || x->w != dy->w) return p;
-  p.tilesY = ceil_div(dy->h, 4); p.tilesX = ceil_div(dy->w, 8);
+  p.ty = dy->h >= 32 ? 8 : 4;            // 8x8 columns where the plane is large enough (measured win at 32^3 .. 128^3)
+  p.tilesY = ceil_div(dy->h, p.ty); p.tilesX = ceil_div(dy->w, 8);
   p.ciTiles = ceil_div(x->c, 32); p.coTiles = ceil_div(dy->c, 32);
   const long long cols = (long long)dy->n * p.tilesY * p.tilesX;
   const long long pairs = (long long)p.ciTiles * p.coTiles;
@@ -523,8 +545,15 @@ extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float
     a.tilesZ = r.zchunks; a.pad = r.planes;          // ring kernel: z chunks per column / planes per chunk
     a.tilesY = r.tilesY; a.tilesX = r.tilesX; a.splits = r.splits; a.ntiles = r.chunks; a.ciTiles = r.ciTiles; a.coTiles = r.coTiles;
     dim3 grid(r.splits, r.ciTiles, r.coTiles);
-    if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wgrad_ring<MI355_IN_PLAIN>), grid, dim3(256), 0, stream, a);
-    else LAUNCH((conv3d_wgrad_ring<MI355_IN_AFFINE_ACT>), grid, dim3(256), 0, stream, a);
+#define MI355_LAUNCH_RING(IM, TYV)                                                                              \
+    do {                                                                                                        \
+      constexpr size_t ldsb = (size_t)(4 * ((TYV) + 2) * 10 * 32 + 2 * (TYV) * 8 * 32) * sizeof(float);         \
+      SET_MAX_DYN_LDS((conv3d_wgrad_ring<IM, TYV>), ldsb);                                                      \
+      LAUNCH((conv3d_wgrad_ring<IM, TYV>), grid, dim3(256), ldsb, stream, a);                                   \
+    } while (0)
+    if (r.ty == 8) { if (d->in_mode == MI355_IN_PLAIN) MI355_LAUNCH_RING(MI355_IN_PLAIN, 8); else MI355_LAUNCH_RING(MI355_IN_AFFINE_ACT, 8); }
+    else { if (d->in_mode == MI355_IN_PLAIN) MI355_LAUNCH_RING(MI355_IN_PLAIN, 4); else MI355_LAUNCH_RING(MI355_IN_AFFINE_ACT, 4); }
+#undef MI355_LAUNCH_RING
     int rc = LAUNCH_CHECK(); if (rc) return rc;
     return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, r.splits, r.ciTiles, stream);
   }

@@ -18,9 +18,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
 // lane holds D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] for r in [0,16).
 #define MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-// v_mfma_f32_16x16x4_f32: 16x16 tile, K = 4, 32 cycles per SIMD (same 64 flop/clk as the 32x32x2 form).
-// lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15]; lane holds D[row=4*(l>>4)+r][col=l&15] for r in [0,4).
-#define MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) float name[]
 // v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+0..7] and B[k=8*(l>>5)+0..7][j=l&31] as 8 packed bf16
 // (16 bytes, carried here as uint4); same C/D map as the f32 form. 32 cycles per SIMD = 16x the f32 MFMA rate.

@@ -6,21 +6,20 @@
 // folded into a per-(n,c) scale/shift pair that the consuming conv applies while staging its LDS tile
 // (conv3d_fwd.hip / conv3d_wgrad.hip), so the normalised tensor never exists in HBM.
 //
-// Algorithmic traffic: stats = 1 read of x; backward = reads of (x, dA) twice + 1 write of dx.
+// Algorithmic traffic: stats = 1 read of x; backward = reads of (x, dA) twice + 1 write of dx. When the tensor (forward) or its
+// gradient (backward) leaves a conv, that conv's epilogue emits the per-tile partial records instead (gn_fuse.h) and the first
+// read disappears: 0 extra bytes for the forward statistics, 1 pass fewer in the backward.
 #include "hipcompat.h"
 #include <cstdlib>
 #include "../../include/mi355_unet3d.h"
 
 #define GN_MAX_BLOCKS_PER_SAMPLE 256
 
-// per-(n, block, c) partial sums of v0 and v1 where
-//  MODE 0 (stats):    v0 = x - K_c,  v1 = (x - K_c)^2 with the per-(n,c) shift K_c = x[n, voxel 0, c] (a sample of the
-//                     channel, so the sums do not cancel catastrophically when |mean| >> std; finalize undoes the shift)
-//  MODE 1 (backward): v0 = du, v1 = du*xhat, du = dA * act'(scale*x+shift), xhat = (x-mean)*rstd
-template <int MODE>
-__global__ void gn_partial_kernel(const float* x, int xld, const float* dA, int dald, long long V, int C, int Q, int R,
-                                  int G, float slope, const float* mean_rstd, const float* scale, const float* shift,
-                                  float* ws) {
+// per-(n, block, c) partial sums (sum du, sum du*xhat), du = dA * act'(scale*x+shift), xhat = (x-mean)*rstd: the first pass of the
+// backward when the dgrad conv that produced dA could not emit them from its epilogue (gn_fuse.h)
+__global__ void gn_bwd_partial_kernel(const float* x, int xld, const float* dA, int dald, long long V, int C, int Q, int R,
+                                      int G, float slope, const float* mean_rstd, const float* scale, const float* shift,
+                                      float* ws) {
   DYN_LDS(lds);  // [R][Q][8]
   const int tid = threadIdx.x;
   const int q = tid % Q, r = tid / Q;
@@ -30,40 +29,28 @@ __global__ void gn_partial_kernel(const float* x, int xld, const float* dA, int 
   const long long ve = vb + per < V ? vb + per : V;
   float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
   float mean[4], rstd[4], sc[4], sh[4];
-  if (MODE == 1) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = 4 * q + e;
-      const int g = c / (C / G);
-      mean[e] = mean_rstd[((size_t)n * G + g) * 2];
-      rstd[e] = mean_rstd[((size_t)n * G + g) * 2 + 1];
-      sc[e] = scale[(size_t)n * C + c];
-      sh[e] = shift[(size_t)n * C + c];
-    }
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * q + e;
+    const int g = c / (C / G);
+    mean[e] = mean_rstd[((size_t)n * G + g) * 2];
+    rstd[e] = mean_rstd[((size_t)n * G + g) * 2 + 1];
+    sc[e] = scale[(size_t)n * C + c];
+    sh[e] = shift[(size_t)n * C + c];
   }
   const float* xn = x + (size_t)n * V * xld + 4 * q;
-  const float* dn = (MODE == 1) ? dA + (size_t)n * V * dald + 4 * q : nullptr;
-  float kc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (MODE == 0) {
-    const float4 k4 = *reinterpret_cast<const float4*>(xn);
-    kc[0] = k4.x; kc[1] = k4.y; kc[2] = k4.z; kc[3] = k4.w;
-  }
+  const float* dn = dA + (size_t)n * V * dald + 4 * q;
   for (long long v = vb + r; v < ve; v += R) {
     const float4 xv = *reinterpret_cast<const float4*>(xn + (size_t)v * xld);
     const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
-    if (MODE == 0) {
+    const float4 dv = *reinterpret_cast<const float4*>(dn + (size_t)v * dald);
+    const float de[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float t = xe[e] - kc[e]; s0[e] += t; s1[e] += t * t; }
-    } else {
-      const float4 dv = *reinterpret_cast<const float4*>(dn + (size_t)v * dald);
-      const float de[4] = {dv.x, dv.y, dv.z, dv.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float u = xe[e] * sc[e] + sh[e];
-        const float du = u > 0.f ? de[e] : de[e] * slope;
-        const float xh = (xe[e] - mean[e]) * rstd[e];
-        s0[e] += du; s1[e] += du * xh;
-      }
+    for (int e = 0; e < 4; ++e) {
+      const float u = xe[e] * sc[e] + sh[e];
+      const float du = u > 0.f ? de[e] : de[e] * slope;
+      const float xh = (xe[e] - mean[e]) * rstd[e];
+      s0[e] += du; s1[e] += du * xh;
     }
   }
   float* my = lds + (size_t)tid * 8;
@@ -96,68 +83,6 @@ __device__ __forceinline__ double block_sum_double(double v, double* red) {
   const double r = red[0];
   __syncthreads();
   return r;
-}
-
-// one block per (n, g). Per channel c of the group (shift K_c = x[n,0,c]): S1 = sum(x-K), S2 = sum((x-K)^2) over all
-// partial blocks -> channel mean m_c = K + S1/V and centred second moment M2_c = S2 - S1^2/V; the group statistics are
-// combined from those in double (parallel-variance formula), in a fixed order (deterministic).
-__global__ void gn_stats_finalize_kernel(const float* ws, const float* x, int xld, int B, int C, int G, long long V, float eps,
-                                         const float* gamma, const float* beta, float* mean_rstd, float* scale, float* shift) {
-  __shared__ double red[256];
-  __shared__ double p1[256], p2[256];
-  const int g = blockIdx.x, n = blockIdx.y;
-  const int cpg = C / G;
-  const int tid = threadIdx.x;
-  double msum = 0.0, m2sum = 0.0;     // this thread's channels: sum of m_c, and of M2_c + V*m_c^2-style terms (second pass below)
-  double mc_local[4]; double m2_local[4];   // cpg <= 1024 -> at most 4 channel rounds of 256
-  int rounds = 0;
-  for (int c0 = 0; c0 < cpg; c0 += 256, ++rounds) {
-    const int nch = cpg - c0 < 256 ? cpg - c0 : 256;
-    const int S = 256 / nch;                       // slices of the block range per channel
-    const int i = tid % nch, sl = tid / nch;
-    double a1 = 0.0, a2 = 0.0;
-    if (sl < S) {
-      const int c = g * cpg + c0 + i;
-      for (int blk = sl; blk < B; blk += S) {
-        const float* p = ws + (((size_t)n * B + blk) * C + c) * 2;
-        a1 += (double)p[0]; a2 += (double)p[1];
-      }
-    }
-    p1[tid] = a1; p2[tid] = a2;
-    __syncthreads();
-    double mc = 0.0, m2 = 0.0;
-    if (tid < nch) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int k = 0; k < S; ++k) { s1 += p1[k * nch + tid]; s2 += p2[k * nch + tid]; }
-      const double K = (double)x[(size_t)n * V * xld + g * cpg + c0 + tid];
-      mc = K + s1 / (double)V;
-      m2 = s2 - s1 * s1 / (double)V;
-      if (m2 < 0.0) m2 = 0.0;
-      msum += mc;
-    }
-    mc_local[rounds] = mc; m2_local[rounds] = m2;
-    __syncthreads();
-  }
-  const double mean = block_sum_double(msum, red) / (double)cpg;
-  rounds = 0;
-  for (int c0 = 0; c0 < cpg; c0 += 256, ++rounds) {
-    const int nch = cpg - c0 < 256 ? cpg - c0 : 256;
-    if (tid < nch) { const double d = mc_local[rounds] - mean; m2sum += m2_local[rounds] + (double)V * d * d; }
-  }
-  const double M = (double)V * cpg;
-  double var = block_sum_double(m2sum, red) / M;
-  if (var < 0.0) var = 0.0;
-  const double rstd = 1.0 / sqrt(var + (double)eps);
-  if (tid == 0) {
-    mean_rstd[((size_t)n * G + g) * 2] = (float)mean;
-    mean_rstd[((size_t)n * G + g) * 2 + 1] = (float)rstd;
-  }
-  for (int i = tid; i < cpg; i += blockDim.x) {
-    const int c = g * cpg + i;
-    const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
-    scale[(size_t)n * C + c] = (float)(ga * rstd);
-    shift[(size_t)n * C + c] = (float)(be - mean * ga * rstd);
-  }
 }
 
 // one block per (n, g): per-channel sums -> coefficients (k0, c0, k2, mean) with dx = k0*du + c0 + k2*(x - mean), and the
@@ -253,6 +178,130 @@ __global__ void gn_bwd_apply_kernel(const float* x, int xld, const float* dA, in
   }
 }
 
+// ---- statistics from partial moments (gn_fuse.h record format: (count, sum, M2) per (sample, block, channel)) ----
+// Standalone producer of the records: one streaming read of x. Inside a block the sums are taken about K_c = the block's first
+// voxel of that channel (a sample of the data, so they do not cancel when |mean| >> std) and converted to (count, sum, M2) once.
+__global__ void gn_moments_kernel(const float* x, int xld, long long V, int C, int Q, int R, float* out) {
+  DYN_LDS(lds);  // [R][Q][8]
+  const int tid = threadIdx.x;
+  const int q = tid % Q, r = tid / Q;
+  const int n = blockIdx.y, blk = blockIdx.x, B = gridDim.x;
+  const long long per = (V + B - 1) / B;
+  const long long vb = (long long)blk * per;
+  const long long ve = vb + per < V ? vb + per : V;
+  const float* xn = x + (size_t)n * V * xld + 4 * q;
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  float kc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (vb < ve) {
+    const float4 k4 = *reinterpret_cast<const float4*>(xn + (size_t)vb * xld);
+    kc[0] = k4.x; kc[1] = k4.y; kc[2] = k4.z; kc[3] = k4.w;
+  }
+  for (long long v = vb + r; v < ve; v += R) {
+    const float4 xv = *reinterpret_cast<const float4*>(xn + (size_t)v * xld);
+    const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float t = xe[e] - kc[e]; s0[e] += t; s1[e] += t * t; }
+  }
+  float* my = lds + (size_t)tid * 8;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { my[e] = s0[e]; my[4 + e] = s1[e]; }
+  __syncthreads();
+  if (r == 0) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = 0.f;
+    for (int rr = 0; rr < R; ++rr) {
+      const float* o = lds + (size_t)(rr * Q + q) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] += o[e];
+    }
+    const float cnt = (float)(ve > vb ? ve - vb : 0);
+    float* dst = out + (((size_t)n * B + blk) * C + 4 * q) * 3;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float m2 = cnt > 0.f ? t[4 + e] - t[e] * t[e] / cnt : 0.f;
+      dst[3 * e] = cnt; dst[3 * e + 1] = t[e] + cnt * kc[e]; dst[3 * e + 2] = m2 > 0.f ? m2 : 0.f;
+    }
+  }
+}
+
+struct MomSrc { const float* p; int B, C, c0; };   // channels [c0, c0 + C) of the normalised tensor: records p[n][B][C][3]
+
+// one block per (n, g). Per channel: the block records are merged in double about the reference K = the mean of the channel's first
+// record (total count, total sum, M2 about K -> centred M2); the group statistics are then combined from the channels by the
+// parallel-variance formula, all in a fixed order (deterministic).
+__global__ void gn_moments_finalize_kernel(MomSrc sa, MomSrc sb, int C, int G, float eps, const float* gamma, const float* beta,
+                                           float* mean_rstd, float* scale, float* shift) {
+  __shared__ double red[256];
+  __shared__ double p0[256], p1[256], p2[256];
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int cpg = C / G;
+  const int tid = threadIdx.x;
+  double wsum = 0.0, cntsum = 0.0;            // this thread's channels: sum of cnt_c * mean_c, sum of cnt_c
+  double mc_local[4], m2_local[4], cn_local[4];   // cpg <= 1024 -> at most 4 channel rounds of 256
+  int rounds = 0;
+  for (int c0 = 0; c0 < cpg; c0 += 256, ++rounds) {
+    const int nch = cpg - c0 < 256 ? cpg - c0 : 256;
+    const int S = 256 / nch;                       // slices of the record range per channel
+    const int i = tid % nch, sl = tid / nch;
+    double cn = 0.0, sm = 0.0, qq = 0.0;
+    if (sl < S) {
+      const int c = g * cpg + c0 + i;
+      const MomSrc src = (sb.p != nullptr && c >= sb.c0) ? sb : sa;
+      const float* base = src.p + ((size_t)n * src.B * src.C + (c - src.c0)) * 3;
+      const size_t stride = (size_t)src.C * 3;
+      const double K = base[0] > 0.f ? (double)base[1] / (double)base[0] : 0.0;
+      for (int blk = sl; blk < src.B; blk += S) {
+        const float* r = base + (size_t)blk * stride;
+        const double bc = (double)r[0];
+        if (bc > 0.0) {
+          const double bs = (double)r[1], d = bs / bc - K;
+          cn += bc; sm += bs; qq += (double)r[2] + bc * d * d;
+        }
+      }
+    }
+    p0[tid] = cn; p1[tid] = sm; p2[tid] = qq;
+    __syncthreads();
+    double mc = 0.0, m2 = 0.0, cc = 0.0;
+    if (tid < nch) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      for (int k = 0; k < S; ++k) { a0 += p0[k * nch + tid]; a1 += p1[k * nch + tid]; a2 += p2[k * nch + tid]; }
+      const int c = g * cpg + c0 + tid;
+      const MomSrc src = (sb.p != nullptr && c >= sb.c0) ? sb : sa;
+      const float* base = src.p + ((size_t)n * src.B * src.C + (c - src.c0)) * 3;
+      const double K = base[0] > 0.f ? (double)base[1] / (double)base[0] : 0.0;
+      cc = a0;
+      mc = a0 > 0.0 ? a1 / a0 : 0.0;
+      m2 = a2 - a0 * (mc - K) * (mc - K);
+      if (m2 < 0.0) m2 = 0.0;
+      wsum += a0 * mc; cntsum += a0;
+    }
+    mc_local[rounds] = mc; m2_local[rounds] = m2; cn_local[rounds] = cc;
+    __syncthreads();
+  }
+  const double M = block_sum_double(cntsum, red);
+  const double mean = M > 0.0 ? block_sum_double(wsum, red) / M : 0.0;
+  double m2sum = 0.0;
+  rounds = 0;
+  for (int c0 = 0; c0 < cpg; c0 += 256, ++rounds) {
+    const int nch = cpg - c0 < 256 ? cpg - c0 : 256;
+    if (tid < nch) { const double d = mc_local[rounds] - mean; m2sum += m2_local[rounds] + cn_local[rounds] * d * d; }
+  }
+  double var = M > 0.0 ? block_sum_double(m2sum, red) / M : 0.0;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  if (tid == 0) {
+    mean_rstd[((size_t)n * G + g) * 2] = (float)mean;
+    mean_rstd[((size_t)n * G + g) * 2 + 1] = (float)rstd;
+  }
+  for (int i = tid; i < cpg; i += blockDim.x) {
+    const int c = g * cpg + i;
+    const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+    scale[(size_t)n * C + c] = (float)(ga * rstd);
+    shift[(size_t)n * C + c] = (float)(be - mean * ga * rstd);
+  }
+}
+
 static int gn_blocks_per_sample(long long V) {
   long long b = V / 16;   // >= 16 voxels per block: the deep 8^3 / 16^3 levels still get hundreds of blocks (V/2048 left them latency-bound)   // >= 16 voxels per block; small deep levels still get hundreds of blocks (they were latency-bound at V/2048)
   if (b < 1) b = 1;
@@ -260,12 +309,13 @@ static int gn_blocks_per_sample(long long V) {
   return (int)b;
 }
 
-// workspace layout (floats): partials [N][B][C][2] | coef [N][C][4] | nc_sums [N][C][2]
+// workspace layout (floats): forward: moment records [N][B][C][3]; backward: partials [N][B][C][2] | coef [N][C][4] | nc_sums [N][C][2]
+// (sized for the larger of the two)
 extern "C" size_t mi355_gn_workspace(const mi355_act* x) {
   if (!x) return 0;
   const long long V = (long long)x->d * x->h * x->w;
   const int B = gn_blocks_per_sample(V);
-  return ((size_t)x->n * B * x->c * 2 + (size_t)x->n * x->c * 6) * sizeof(float);
+  return ((size_t)x->n * B * x->c * 3 + (size_t)x->n * x->c * 6) * sizeof(float);
 }
 
 static int gn_check(const mi355_act* x, int groups) {
@@ -275,42 +325,73 @@ static int gn_check(const mi355_act* x, int groups) {
   return 0;
 }
 
+extern "C" int32_t mi355_gn_moments_blocks(const mi355_act* x) {
+  if (!x) return 0;
+  return gn_blocks_per_sample((long long)x->d * x->h * x->w);
+}
+
+extern "C" int mi355_gn_moments(const mi355_act* x, float* out, void* stream) {
+  int rc = gn_check(x, 1);
+  if (rc) return rc;
+  if (!out) return MI355_EINVAL;
+  const long long V = (long long)x->d * x->h * x->w;
+  const int B = gn_blocks_per_sample(V), C = x->c, Q = C / 4, R = 256 / Q > 0 ? 256 / Q : 1;
+  LAUNCH(gn_moments_kernel, dim3(B, x->n), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream, (const float*)x->p, x->ld, V, C, Q, R, out);
+  return LAUNCH_CHECK();
+}
+
+extern "C" int mi355_gn_finalize(const float* part_a, int32_t blocks_a, int32_t c_a, const float* part_b, int32_t blocks_b, int32_t c_b,
+                                 int32_t n, int32_t groups, float eps, const float* gamma, const float* beta,
+                                 float* mean_rstd, float* scale, float* shift, void* stream) {
+  if (!part_a || blocks_a <= 0 || c_a <= 0 || n <= 0 || groups <= 0 || !mean_rstd || !scale || !shift) return MI355_EINVAL;
+  if (part_b && (blocks_b <= 0 || c_b <= 0)) return MI355_EINVAL;
+  const int C = c_a + (part_b ? c_b : 0);
+  if (C % groups) return MI355_EINVAL;
+  if (C / groups > 1024) return MI355_EUNSUPPORTED;
+  MomSrc sa = {part_a, blocks_a, c_a, 0}, sb = {part_b, part_b ? blocks_b : 0, part_b ? c_b : 0, c_a};
+  LAUNCH(gn_moments_finalize_kernel, dim3(groups, n), dim3(256), 0, stream, sa, sb, C, groups, eps, gamma, beta, mean_rstd, scale, shift);
+  return LAUNCH_CHECK();
+}
+
+// standalone statistics = the standalone record producer + the same finalisation the fused epilogues feed
 extern "C" int mi355_gn_stats(const mi355_act* x, int32_t groups, float eps, const float* gamma, const float* beta,
                               float* mean_rstd, float* scale, float* shift, void* ws, size_t ws_bytes, void* stream) {
   int rc = gn_check(x, groups);
   if (rc) return rc;
   if (!mean_rstd || !scale || !shift || !ws) return MI355_EINVAL;
   if (ws_bytes < mi355_gn_workspace(x)) return MI355_EWORKSPACE;
-  const long long V = (long long)x->d * x->h * x->w;
-  const int B = gn_blocks_per_sample(V), C = x->c, Q = C / 4, R = 256 / Q > 0 ? 256 / Q : 1;
-  LAUNCH((gn_partial_kernel<0>), dim3(B, x->n), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream,
-         (const float*)x->p, x->ld, (const float*)nullptr, 0, V, C, Q, R, groups, 0.f, (const float*)nullptr,
-         (const float*)nullptr, (const float*)nullptr, (float*)ws);
-  rc = LAUNCH_CHECK(); if (rc) return rc;
-  LAUNCH(gn_stats_finalize_kernel, dim3(groups, x->n), dim3(256), 0, stream, (const float*)ws, (const float*)x->p, x->ld, B, C, groups,
-         V, eps, gamma, beta, mean_rstd, scale, shift);
-  return LAUNCH_CHECK();
+  rc = mi355_gn_moments(x, (float*)ws, stream);
+  if (rc) return rc;
+  return mi355_gn_finalize((const float*)ws, mi355_gn_moments_blocks(x), x->c, nullptr, 0, 0, x->n, groups, eps, gamma, beta,
+                           mean_rstd, scale, shift, stream);
 }
 
-extern "C" int mi355_gn_act_bwd(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const float* addend, int32_t addend_ld,
-                                int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
-                                const float* scale, const float* shift, float* dgamma, float* dbeta,
-                                void* ws, size_t ws_bytes, void* stream) {
+static int gn_act_bwd_impl(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const float* addend, int32_t addend_ld,
+                           int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
+                           const float* scale, const float* shift, float* dgamma, float* dbeta,
+                           const float* partials, int32_t blocks, void* ws, size_t ws_bytes, void* stream) {
   int rc = gn_check(x, groups);
   if (rc) return rc;
   if (!dA || !dx || !dA->p || !dx->p || !mean_rstd || !scale || !shift || !ws) return MI355_EINVAL;
   if (dA->c != x->c || dx->c != x->c || dA->ld % 4 || dx->ld % 4 || ((uintptr_t)dA->p & 15) || ((uintptr_t)dx->p & 15)) return MI355_EINVAL;
   if (addend && (addend_ld % 4 || ((uintptr_t)addend & 15))) return MI355_EINVAL;
   if (ws_bytes < mi355_gn_workspace(x)) return MI355_EWORKSPACE;
+  if (partials && blocks <= 0) return MI355_EINVAL;
   const long long V = (long long)x->d * x->h * x->w;
-  const int B = gn_blocks_per_sample(V), C = x->c, N = x->n, Q = C / 4, R = 256 / Q > 0 ? 256 / Q : 1;
+  const int C = x->c, N = x->n, Q = C / 4, R = 256 / Q > 0 ? 256 / Q : 1;
+  int B = gn_blocks_per_sample(V);
   float* part = (float*)ws;
   float* coef = part + (size_t)N * B * C * 2;
   float* ncs = coef + (size_t)N * C * 4;
-  LAUNCH((gn_partial_kernel<1>), dim3(B, N), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream,
-         (const float*)x->p, x->ld, (const float*)dA->p, dA->ld, V, C, Q, R, groups, act_slope, mean_rstd, scale, shift, part);
-  rc = LAUNCH_CHECK(); if (rc) return rc;
-  LAUNCH(gn_bwd_finalize_kernel, dim3(groups, N), dim3(256), 0, stream, (const float*)part, B, C, groups, V, gamma, mean_rstd, coef, ncs);
+  if (partials) {
+    B = blocks;                                   // first pass already done by the dgrad conv's epilogue (gn_fuse.h)
+  } else {
+    LAUNCH(gn_bwd_partial_kernel, dim3(B, N), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream,
+           (const float*)x->p, x->ld, (const float*)dA->p, dA->ld, V, C, Q, R, groups, act_slope, mean_rstd, scale, shift, part);
+    rc = LAUNCH_CHECK(); if (rc) return rc;
+    partials = part;
+  }
+  LAUNCH(gn_bwd_finalize_kernel, dim3(groups, N), dim3(256), 0, stream, partials, B, C, groups, V, gamma, mean_rstd, coef, ncs);
   rc = LAUNCH_CHECK(); if (rc) return rc;
   if (dgamma || dbeta) {
     LAUNCH(gn_bwd_param_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, (const float*)ncs, N, C, dgamma, dbeta);
@@ -321,4 +402,21 @@ extern "C" int mi355_gn_act_bwd(const mi355_act* x, const mi355_act* dA, const m
   LAUNCH(gn_bwd_apply_kernel, dim3((unsigned)grid), dim3(256), 0, stream, (const float*)x->p, x->ld, (const float*)dA->p, dA->ld,
          (float*)dx->p, dx->ld, addend, addend_ld, V, C, N, act_slope, scale, shift, (const float*)coef);
   return LAUNCH_CHECK();
+}
+
+extern "C" int mi355_gn_act_bwd(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const float* addend, int32_t addend_ld,
+                                int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
+                                const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                void* ws, size_t ws_bytes, void* stream) {
+  return gn_act_bwd_impl(x, dA, dx, addend, addend_ld, groups, act_slope, gamma, mean_rstd, scale, shift, dgamma, dbeta, nullptr, 0,
+                         ws, ws_bytes, stream);
+}
+
+extern "C" int mi355_gn_act_bwd_fused(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const float* addend, int32_t addend_ld,
+                                      int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
+                                      const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                      const float* partials, int32_t blocks, void* ws, size_t ws_bytes, void* stream) {
+  if (!partials) return MI355_EINVAL;
+  return gn_act_bwd_impl(x, dA, dx, addend, addend_ld, groups, act_slope, gamma, mean_rstd, scale, shift, dgamma, dbeta, partials, blocks,
+                         ws, ws_bytes, stream);
 }

@@ -167,11 +167,16 @@ class HipDynUNet(HipNetBase):
         cout = blk.norm1.num_features
         d, h, w = dst.shape[1:4]
         r1 = be.empty_act(n, d, h, w, cout)
-        be.conv_fwd(xin.act, self._packed_weight(blk.conv1.conv.weight, 0, self._ci_pad(blk, xin.act.c)), r1, 3, blk.stride, **xin.kw())
+        # InstanceNorm statistics are not passes over r1 / dst: each conv's epilogue leaves the moment records of what it wrote
+        # (csrc/gn_fuse.h) and gn_stats finalises those
+        be.conv_fwd(xin.act, self._packed_weight(blk.conv1.conv.weight, 0, self._ci_pad(blk, xin.act.c)), r1, 3, blk.stride, moments=True,
+                    **xin.kw())
         st1 = be.gn_stats(r1, cout, IN_EPS, blk.norm1.weight.data, blk.norm1.bias.data)
+        r1.mom = None
         be.conv_fwd(r1, self._packed_weight(blk.conv2.conv.weight, 0), dst, 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2],
-                    slope=SLOPE)
+                    slope=SLOPE, moments=True)
         st2 = be.gn_stats(dst, cout, IN_EPS, blk.norm2.weight.data, blk.norm2.bias.data)
+        dst.mom = None
         return dict(xin=xin, r1=r1, st1=st1, r2=dst, st2=st2) if keep else dict(r2=dst, st2=st2)
 
     def _forward_impl(self, x, keep):
@@ -238,9 +243,10 @@ class HipDynUNet(HipNetBase):
         with self._wgrad_stream(be, r1, d_r2, st1[1], st1[2]):
             be.conv_wgrad(r1, d_r2, self._gslice(blk.conv2.conv.weight), 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2], slope=SLOPE)
         dA1 = be.empty_act(*r1.shape)
-        be.conv_fwd(d_r2, self._packed_weight(blk.conv2.conv.weight, 1), dA1, 3, 1)
+        # the dgrad's epilogue also leaves the first pass of the norm backward (sum du, sum du*xhat per tile)
+        p1 = be.conv_fwd(d_r2, self._packed_weight(blk.conv2.conv.weight, 1), dA1, 3, 1, gnb=(r1, st1, cout, SLOPE))
         be.gn_act_bwd(r1, dA1, dA1, cout, SLOPE, blk.norm1.weight.data, st1[0], st1[1], st1[2],
-                      self._gslice(blk.norm1.weight), self._gslice(blk.norm1.bias))
+                      self._gslice(blk.norm1.weight), self._gslice(blk.norm1.bias), partials=p1)
         d_r1 = dA1
         w1 = blk.conv1.conv.weight
         with self._wgrad_stream(be, xin.act, d_r1, xin.scale, xin.shift, xin.slope_vec):

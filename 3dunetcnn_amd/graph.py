@@ -27,6 +27,7 @@ class HipGraphedTrainStep:
         if example_x.device.type != "cuda":
             raise RuntimeError("HipGraphedTrainStep runs on an MI355X only (no CPU fallback)")
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        model.backward_side_stream = False           # one captured stream: the graph already removes the launch gaps the fork hides
         self.x = example_x.detach().clone()          # static inputs: every replay reads these addresses
         self.y = example_y.detach().clone()
         model.flatten_parameters()
@@ -41,11 +42,22 @@ class HipGraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         optimizer.zero_grad(set_to_none=True)        # capture writes the gradients in place (no accumulate branch)
         model.mark_parameters_updated()              # the pack kernels are part of every replay
+        be = model._be
+        ws_before = None if be is None or be._ws is None else be._ws.data_ptr()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             logits = model(self.x)
             loss = criterion(logits, self.y)
             loss.backward()
+        # The captured kernels have the ADDRESS of the backend workspace baked in. Keep that tensor alive for the life of the graph:
+        # a later eager op that needs a larger workspace makes Backend.ws() allocate a new one and drop its own reference, and
+        # without this reference the caching allocator (the reference loop calls empty_cache() every iteration,
+        # unet3d/train/training_utils.py:66) could hand the old block to another tensor that replay() would then scribble over.
+        be = model._be
+        self._ws_ref = None if be is None else be._ws
+        if ws_before is not None and self._ws_ref is not None and self._ws_ref.data_ptr() != ws_before:
+            raise RuntimeError("HipGraphedTrainStep: the backend workspace was reallocated DURING capture (warm-up did not size it); "
+                               "raise `warmup` or run one eager step first")
         self.logits = logits.detach()                # static outputs, refreshed by every replay
         self.loss = loss.detach()
         self._grads = [(p, p.grad) for p in model.parameters() if p.grad is not None]

@@ -15,17 +15,21 @@ import torch
 
 from . import _lib
 from ._lib import (IN_AFFINE_ACT, IN_PLAIN, IN_S2D, IN_ZERO_INSERT, OUT_D2S, OUT_PLAIN, PREC_F32, PRECISIONS, W_OIDHW4,  # noqa: F401
-                   W_PACKED, W_PACKED_F32_NARROW, MiAct, MiConvDesc, check)
+                   W_PACKED, W_PACKED_F32_NARROW, MiAct, MiConvDesc, MiGnBwdFuse, check)
 
 
 class Act:
-    __slots__ = ("buf", "c0", "c")
+    """`mom`: None, or the partial-moment records of this view's channels as a list of (records [N, B, c, 3], B, c) sources in
+    channel order -- written by the epilogue of the conv that produced the tensor (Backend.conv_fwd(moments=True)) or by
+    Backend.moments(); Backend.gn_stats finalises them instead of reading the tensor again."""
+    __slots__ = ("buf", "c0", "c", "mom")
 
     def __init__(self, buf, c0=0, c=None):
         assert buf.dim() == 5 and buf.is_contiguous() and buf.dtype == torch.float32
         self.buf = buf
         self.c0 = c0
         self.c = buf.shape[-1] - c0 if c is None else c
+        self.mom = None
         assert self.c0 % 4 == 0 and self.c0 + self.c <= buf.shape[-1]
 
     @property
@@ -124,6 +128,9 @@ class Backend:
         self._ws = None
         self.precision = PREC_F32   # arithmetic of the 3x3x3 stride-1 convs: see set_precision()
         self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
+        # norm statistics leave with the producing conv's epilogue (csrc/gn_fuse.h). False: every statistic is a standalone pass
+        # over the tensor again (the round-1 form; kept as the cross-check of the fused path, tests/test_ops_gpu.py)
+        self.fused_stats = True
 
     def set_precision(self, name):
         """"fp32" (exact f32 MFMA, default) | "bf16x3" | "bf16x6" (split-bf16 fp32 emulation) | "bf16" (mixed precision)."""
@@ -169,19 +176,39 @@ class Backend:
         return d
 
     def conv_fwd(self, x, wp, y, kd, stride=1, pad=None, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, bias=None,
-                 residual=None, chscale=None, off=(0, 0, 0), out_dhw=None, in_slope=None, out_mode=OUT_PLAIN):
+                 residual=None, chscale=None, off=(0, 0, 0), out_dhw=None, in_slope=None, out_mode=OUT_PLAIN, moments=False, gnb=None):
+        """moments=True: y will be normalised next -- have the epilogue emit its partial moments (y.mom) when this call can.
+        gnb=(gx, stats, groups, slope): this call is a dgrad whose output is the gradient wrt act(norm(gx)) with stats =
+        (mean_rstd, scale, shift) of gx: have the epilogue emit the first pass of gn_act_bwd. Returns None, or (records, B) to
+        hand to gn_act_bwd(partials=...)."""
         pad = kd // 2 if pad is None else pad
         if out_dhw is None:
             out_dhw = x.shape[1:4] if out_mode == OUT_D2S else y.shape[1:4]
         keep = []
         d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep, in_slope, out_mode)
         xd, yd = x.desc(), y.desc()
+        wptr = wp.ptr_for(d)                          # also settles d.wformat
+        y.mom = None
+        gparts = None
+        if self.fused_stats and (moments or gnb is not None):
+            nb = self.lib.mi355_conv3d_stats_blocks(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d))
+            if nb > 0 and moments:
+                rec = torch.empty(x.shape[0], nb, y.c, 3, dtype=torch.float32, device=self.device)
+                d.moments_out = rec.data_ptr()
+                y.mom = [(rec, nb, y.c)]
+            elif nb > 0 and in_mode == IN_PLAIN and d.wformat == W_PACKED:
+                gx, st, groups, gslope = gnb
+                assert gx.shape == y.shape
+                rec = torch.empty(x.shape[0], nb, y.c, 2, dtype=torch.float32, device=self.device)
+                fuse = MiGnBwdFuse(gx.ptr(), gx.ld, st[1].data_ptr(), st[2].data_ptr(), st[0].data_ptr(), groups, gslope, rec.data_ptr())
+                d.gn_bwd = ctypes.pointer(fuse)
+                keep.extend([fuse, gx, st])
+                gparts = (rec, nb)
         if self.prof is None:
-            check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wp.ptr_for(d), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
-            return
+            check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wptr, ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
+            return gparts
         # profiling: HIP events on the launch stream around this one kernel, keyed by the kernel's trace name
         name = ctypes.create_string_buffer(96)
-        wptr = wp.ptr_for(d)                          # also settles d.wformat
         self.lib.mi355_conv3d_fwd_config(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d), name, 96)
         if d.wformat == W_OIDHW4:
             name.value = b"conv3d_c4_fwd"
@@ -197,6 +224,7 @@ class Backend:
         check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wptr, ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
         e1.record()
         self.prof.append((name.value.decode(), flops, byts, e0, e1))
+        return gparts
 
     def conv_wgrad(self, x, dy, dw, kd, stride=1, pad=None, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, in_slope=None,
                    out_mode=OUT_PLAIN):
@@ -227,44 +255,49 @@ class Backend:
                               else "conv3d_wgrad_ring (+reduce)" if (kd == 3 and stride == 1 and pad == 1 and out_mode == OUT_PLAIN)
                               else f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1))
 
-    def conv_wgrad_ring_exp(self, x, dy, dw, variant, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, in_slope=None):
-        """DEVELOPER hook (not used by any module of this package): the experimental variants of the plane-ring 3x3x3 stride-1
-        weight-gradient kernel in csrc/conv3d_wgrad_exp.hip. variant bit 0: 16x16x4 MFMA tiles (27 per wave), bit 1: 8x8 columns,
-        bit 2: slab reduction with 16 loads in flight per thread."""
-        fn = self.lib.mi355_conv3d_wgrad_ring_exp
-        fn.restype, fn.argtypes = ctypes.c_int, [ctypes.POINTER(MiAct), ctypes.POINTER(MiAct), ctypes.c_void_p, ctypes.POINTER(MiConvDesc),
-                                                 ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_void_p]
-        wsf = self.lib.mi355_conv3d_wgrad_ring_exp_workspace
-        wsf.restype, wsf.argtypes = ctypes.c_size_t, [ctypes.POINTER(MiAct), ctypes.POINTER(MiAct), ctypes.c_int32]
-        keep = []
-        d = self._desc(3, 1, 1, in_mode, slope, scale, shift, None, None, None, (0, 0, 0), dy.shape[1:4], keep, in_slope, OUT_PLAIN)
-        xd, dyd = x.desc(), dy.desc()
-        nbytes = wsf(ctypes.byref(xd), ctypes.byref(dyd), variant)
-        if nbytes == 0:
-            raise RuntimeError("conv_wgrad_ring_exp: unsupported configuration")
-        ws = self.ws(nbytes)
-        check(fn(ctypes.byref(xd), ctypes.byref(dyd), dw.data_ptr(), ctypes.byref(d), ws.data_ptr(), ws.numel() * 4, variant, self.stream()),
-              "conv3d_wgrad_ring_exp")
-
     # -- norm ----------------------------------------------------------------------------------------------------
+    def moments(self, x):
+        """Standalone producer of x.mom (one streaming read of x) for tensors no conv epilogue wrote: the trilinear-upsampled
+        half of a concat buffer, the network input."""
+        xd = x.desc()
+        nb = self.lib.mi355_gn_moments_blocks(ctypes.byref(xd))
+        rec = torch.empty(x.shape[0], nb, x.c, 3, dtype=torch.float32, device=self.device)
+        check(self.lib.mi355_gn_moments(ctypes.byref(xd), rec.data_ptr(), self.stream()), "gn_moments")
+        x.mom = [(rec, nb, x.c)]
+        return x.mom
+
     def gn_stats(self, x, groups, eps, gamma, beta):
+        """(mean_rstd [n, G, 2], scale [n, c], shift [n, c]) of GroupNorm(groups) over x: from the moment records the producer(s)
+        of x left behind (x.mom, at most two sources: a concat buffer has two producers) or, without them, one standalone pass."""
         n, c = x.shape[0], x.c
         mean_rstd = torch.empty(n, groups, 2, dtype=torch.float32, device=self.device)
         scale = torch.empty(n, c, dtype=torch.float32, device=self.device)
         shift = torch.empty(n, c, dtype=torch.float32, device=self.device)
+        mom = x.mom if self.fused_stats else None
+        if mom is not None and 1 <= len(mom) <= 2 and sum(m[2] for m in mom) == c:
+            a = mom[0]
+            b = mom[1] if len(mom) == 2 else (None, 0, 0)
+            check(self.lib.mi355_gn_finalize(a[0].data_ptr(), a[1], a[2], _p(b[0]), b[1], b[2], n, groups, eps, _p(gamma), _p(beta),
+                                             mean_rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), self.stream()), "gn_finalize")
+            return mean_rstd, scale, shift
         xd = x.desc()
         ws = self.ws(self.lib.mi355_gn_workspace(ctypes.byref(xd)))
         check(self.lib.mi355_gn_stats(ctypes.byref(xd), groups, eps, _p(gamma), _p(beta), mean_rstd.data_ptr(), scale.data_ptr(),
                                       shift.data_ptr(), ws.data_ptr(), ws.numel() * 4, self.stream()), "gn_stats")
         return mean_rstd, scale, shift
 
-    def gn_act_bwd(self, x, dA, dx, groups, slope, gamma, mean_rstd, scale, shift, dgamma, dbeta, addend=None):
+    def gn_act_bwd(self, x, dA, dx, groups, slope, gamma, mean_rstd, scale, shift, dgamma, dbeta, addend=None, partials=None):
+        """partials: None, or what conv_fwd(gnb=...) returned for the dgrad that produced dA (its epilogue did the first pass)."""
         xd, dad, dxd = x.desc(), dA.desc(), dx.desc()
         ws = self.ws(self.lib.mi355_gn_workspace(ctypes.byref(xd)))
-        check(self.lib.mi355_gn_act_bwd(ctypes.byref(xd), ctypes.byref(dad), ctypes.byref(dxd),
-                                        None if addend is None else addend.ptr(), 0 if addend is None else addend.ld,
-                                        groups, slope, _p(gamma), mean_rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                        _p(dgamma), _p(dbeta), ws.data_ptr(), ws.numel() * 4, self.stream()), "gn_act_bwd")
+        common = (ctypes.byref(xd), ctypes.byref(dad), ctypes.byref(dxd),
+                  None if addend is None else addend.ptr(), 0 if addend is None else addend.ld,
+                  groups, slope, _p(gamma), mean_rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _p(dgamma), _p(dbeta))
+        if partials is not None:
+            check(self.lib.mi355_gn_act_bwd_fused(*common, partials[0].data_ptr(), partials[1], ws.data_ptr(), ws.numel() * 4, self.stream()),
+                  "gn_act_bwd_fused")
+        else:
+            check(self.lib.mi355_gn_act_bwd(*common, ws.data_ptr(), ws.numel() * 4, self.stream()), "gn_act_bwd")
 
     # -- resample / layout / pointwise ---------------------------------------------------------------------------
     def upsample2x_fwd(self, lo, cat, off):

@@ -164,23 +164,27 @@ class HipUNet3D(HipNetBase):
             y = self.activation(y)
         return y
 
-    def _block_fwd(self, be, blk, x, out, chscale, keep):
-        """One residual block. x: Act input; out: Act destination (maybe a concat slice)."""
+    def _block_fwd(self, be, blk, x, out, chscale, keep, out_moments=True):
+        """One residual block. x: Act input; out: Act destination (maybe a concat slice). Norm statistics are not passes over the
+        tensors: each conv's epilogue leaves the moment records of what it wrote (x.mom / h1.mom, csrc/gn_fuse.h) and gn_stats
+        finalises those; `out_moments`: whether `out` is normalised by whoever consumes it."""
         n, d, h, w, cin = x.shape
         cout = blk.conv1.conv.out_channels
         c1, c2 = blk.conv1, blk.conv2
         g1, b1, groups1, padw = self._in_pad(c1, cin)
         st1 = be.gn_stats(x, groups1, GN_EPS, g1, b1)
         h1 = be.empty_act(n, d, h, w, cout)
-        be.conv_fwd(x, self._packed_weight(c1.conv.weight, 0, padw), h1, 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2])
+        be.conv_fwd(x, self._packed_weight(c1.conv.weight, 0, padw), h1, 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2],
+                    moments=True)
         st2 = be.gn_stats(h1, c2.norm1.num_groups, GN_EPS, c2.norm1.weight.data, c2.norm1.bias.data)
+        h1.mom = None
         if blk.sample is not None:
             idn = be.empty_act(n, d, h, w, cout)
             be.conv_fwd(x, self._packed_weight(blk.sample.weight, 0, padw), idn, 1)
         else:
             idn = x
         be.conv_fwd(h1, self._packed_weight(c2.conv.weight, 0), out, 3, 1, in_mode=IN_AFFINE_ACT, scale=st2[1], shift=st2[2],
-                    residual=idn, chscale=chscale)
+                    residual=idn, chscale=chscale, moments=out_moments)
         if keep:
             s = _Saved()
             s.x, s.h1, s.st1, s.st2, s.out, s.chscale = x, h1, st1, st2, out, chscale
@@ -210,8 +214,8 @@ class HipUNet3D(HipNetBase):
         if t.shape != p.shape:
             self._gslice(p).copy_(t[:, :p.shape[1]])
 
-    def _layer_fwd(self, be, layer, x, out_last, keep):
-        """All blocks of a layer; the last block writes into out_last. Returns list of saved blocks."""
+    def _layer_fwd(self, be, layer, x, out_last, keep, out_moments=True):
+        """All blocks of a layer; the last block writes into out_last (`out_moments`: a norm reads it next). Returns list of saved blocks."""
         saved = []
         nb = len(layer.blocks)
         n, d, h, w, _ = x.shape
@@ -224,7 +228,7 @@ class HipUNet3D(HipNetBase):
                 p = layer.dropout_p
                 keepmask = torch.rand(n, cout, device=be.device, generator=self.dropout_generator) >= p
                 chscale = keepmask.float() / (1.0 - p)
-            saved.append(self._block_fwd(be, blk, x, out, chscale, keep))
+            saved.append(self._block_fwd(be, blk, x, out, chscale, keep, out_moments or j < nb - 1))
             x = out
         return saved
 
@@ -265,7 +269,7 @@ class HipUNet3D(HipNetBase):
             if i < L - 1:
                 dn = sizes[i + 1]
                 nxt = be.empty_act(n, dn[0], dn[1], dn[2], enc.widths[i])
-                be.conv_fwd(out, self._packed_weight(enc.downsampling_convolutions[i].weight, 0), nxt, 3, 2)
+                be.conv_fwd(out, self._packed_weight(enc.downsampling_convolutions[i].weight, 0), nxt, 3, 2, moments=True)
                 cur = nxt
         # decoder
         cur = enc_out[-1]
@@ -275,7 +279,7 @@ class HipUNet3D(HipNetBase):
             in_w, out_w = dec.level_widths[k]
             d_, h_, w_ = sizes[lvl + 1]
             lay_out = be.empty_act(n, d_, h_, w_, in_w)
-            sv = self._layer_fwd(be, layer, cur, lay_out, keep)
+            sv = self._layer_fwd(be, layer, cur, lay_out, keep, out_moments=False)     # feeds the 1x1x1 / transposed conv, not a norm
             cat, up_c, skip_c = cats[lvl]
             tgt = sizes[lvl]
             off = tuple((t - 2 * s) // 2 for t, s in zip(tgt, (d_, h_, w_)))
@@ -290,11 +294,17 @@ class HipUNet3D(HipNetBase):
                 pre_out = be.empty_act(n, d_, h_, w_, out_w)
                 be.conv_fwd(lay_out, self._packed_weight(dec.pre_upsampling_blocks[k].weight, 0), pre_out, 1)
                 be.upsample2x_fwd(pre_out, cat.slice(0, up_c), off)
+            # statistics of the concat buffer: the skip half's records were left by the encoder conv that wrote it, the up-sampled
+            # half (no conv epilogue produced it) gets one read of that half only
+            skip_mom = enc_out[lvl].mom
+            if be.fused_stats and skip_mom is not None:
+                upsl = cat.slice(0, up_c)
+                cat.mom = be.moments(upsl) + skip_mom
             saved["dec"].append((sv, lay_out, off))
             cur = cat
         d_, h_, w_ = sizes[0]
         last_out = be.empty_act(n, d_, h_, w_, dec.level_widths[-1][1])
-        saved["last"] = self._layer_fwd(be, dec.layers[-1], cur, last_out, keep)
+        saved["last"] = self._layer_fwd(be, dec.layers[-1], cur, last_out, keep, out_moments=False)
         saved["last_out"] = last_out
         logits = torch.empty(n, self.n_outputs, D, H, W, dtype=torch.float32, device=x.device)
         wf = self.final_convolution.weight
@@ -314,9 +324,10 @@ class HipUNet3D(HipNetBase):
         with self._wgrad_stream(be, s.h1, d_out, st2[1], st2[2]):
             be.conv_wgrad(s.h1, d_out, self._gslice(c2.conv.weight), 3, 1, in_mode=IN_AFFINE_ACT, scale=st2[1], shift=st2[2])
         dA2 = be.empty_act(n, d, h, w, cout)
-        be.conv_fwd(d_out, self._packed_weight(c2.conv.weight, 1), dA2, 3, 1)
+        # the dgrad's epilogue also leaves the first pass of the norm backward (sum du, sum du*xhat per tile): dA2 is in registers there
+        p2 = be.conv_fwd(d_out, self._packed_weight(c2.conv.weight, 1), dA2, 3, 1, gnb=(s.h1, st2, c2.norm1.num_groups, 0.0))
         be.gn_act_bwd(s.h1, dA2, dA2, c2.norm1.num_groups, 0.0, c2.norm1.weight.data, st2[0], st2[1], st2[2],
-                      self._gslice(c2.norm1.weight), self._gslice(c2.norm1.bias))
+                      self._gslice(c2.norm1.weight), self._gslice(c2.norm1.bias), partials=p2)
         dh1 = dA2
         g1, _, groups1, padw = self._in_pad(c1, cin)
         with self._wgrad_stream(be, s.x, dh1, st1[1], st1[2]):
@@ -324,7 +335,7 @@ class HipUNet3D(HipNetBase):
             be.conv_wgrad(s.x, dh1, tw, 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2])
             self._wgrad_commit(c1.conv.weight, tw)
         dA1 = be.empty_act(n, d, h, w, cin)
-        be.conv_fwd(dh1, self._packed_weight(c1.conv.weight, 1, padw), dA1, 3, 1)
+        p1 = be.conv_fwd(dh1, self._packed_weight(c1.conv.weight, 1, padw), dA1, 3, 1, gnb=(s.x, st1, groups1, 0.0))
         if blk.sample is not None:
             with self._wgrad_stream(be, s.x, d_out):
                 ts = self._wgrad_target(blk.sample.weight, cin)
@@ -344,7 +355,7 @@ class HipUNet3D(HipNetBase):
         else:
             dg, db = torch.empty(cin, dtype=torch.float32, device=be.device), torch.empty(cin, dtype=torch.float32, device=be.device)
         be.gn_act_bwd(s.x, dA1, dx if dx is not None else dA1, groups1, 0.0, g1, st1[0], st1[1], st1[2], dg, db,
-                      addend=d_id if need_dx else None)
+                      addend=d_id if need_dx else None, partials=p1)
         if padw is not None:
             cm = c1.conv.in_channels
             self._gslice(c1.norm1.weight).copy_(dg[:cm])

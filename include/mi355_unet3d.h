@@ -85,7 +85,24 @@ typedef struct mi355_conv_desc {
   int32_t out_mode;      /* MI355_OUT_* */
   int32_t precision;     /* MI355_PREC_*: arithmetic of the 3x3x3 stride-1 convolutions (everything else is always F32) */
   int32_t wformat;       /* MI355_W_*: what the `wp` argument of mi355_conv3d_fwd points at */
+  /* ---- norm statistics fused into the epilogue (myronenko.py:17-21: the conv's output is the next block's GroupNorm input) ---- */
+  float* moments_out;    /* NULL or [n][B][cout][3]: per-(sample, spatial tile, channel) partial moments (count, sum, M2 about
+                            sum/count) of the values this call stores, B = mi355_conv3d_stats_blocks(x, y, desc). mi355_gn_finalize
+                            turns them into the next conv's scale/shift: the statistics pass over the tensor disappears. */
+  const struct mi355_gn_bwd_fuse* gn_bwd; /* NULL or: this call is a dgrad whose output dA is the gradient wrt act(GroupNorm(gx)); the
+                            epilogue also emits the partial sums of mi355_gn_act_bwd (see mi355_gn_bwd_fuse) */
 } mi355_conv_desc;
+
+/* Backward-side fusion: y = dA (gradient wrt the activated, normalised tensor). With u = scale*gx + shift, du = dA*act'(u),
+ * xhat = (gx - mean)*rstd the epilogue writes partials_out[n][B][c][2] = (sum du, sum du*xhat) over each spatial tile -- the
+ * first of the two passes of mi355_gn_act_bwd, with dA still in registers. gx has the logical shape of y. */
+typedef struct mi355_gn_bwd_fuse {
+  const float* gx; int32_t gx_ld;
+  const float* scale; const float* shift; /* [n][c] (mi355_gn_stats / mi355_gn_finalize) */
+  const float* mean_rstd;                 /* [n][groups][2] */
+  int32_t groups; float act_slope;
+  float* partials_out;                    /* [n][B][c][2], B = mi355_conv3d_stats_blocks */
+} mi355_gn_bwd_fuse;
 
 #define MI355_W_PACKED 0   /* a pack made by mi355_pack_conv_weight / mi355_pack_conv_weight_bf16 (see mi355_conv3d_uses_bf16) */
 #define MI355_W_OIDHW4 1   /* the UNPACKED Conv3d weight [cout][4][3][3][3] of a 4-input-channel 3x3x3 stride-1 pad-1 conv
@@ -122,6 +139,11 @@ int mi355_conv3d_uses_bf16(const mi355_conv_desc* desc);
  * v_mfma_f32_32x32x2_f32 (exact fp32). */
 int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* desc, void* stream);
 
+/* Number of spatial tiles per sample (B) that mi355_conv3d_fwd will write partial statistics for (desc->moments_out /
+ * desc->gn_bwd->partials_out), or 0 when this call cannot fuse them (windowed / depth-to-space outputs, the narrow kernel):
+ * the caller then runs mi355_gn_stats / the unfused mi355_gn_act_bwd instead. */
+int32_t mi355_conv3d_stats_blocks(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* desc);
+
 /* Writes the (demangled) name of the kernel instantiation mi355_conv3d_fwd launches for this problem, e.g.
  * "conv3d_mfma<3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 1, 1>", so HIP-event timings can be matched to a rocprofv3 trace. */
 int mi355_conv3d_fwd_config(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* desc, char* out, size_t n);
@@ -142,6 +164,17 @@ size_t mi355_gn_workspace(const mi355_act* x);
 int mi355_gn_stats(const mi355_act* x, int32_t groups, float eps, const float* gamma, const float* beta,
                    float* mean_rstd, float* scale, float* shift, void* ws, size_t ws_bytes, void* stream);
 
+/* Partial moments of x in the format of mi355_conv_desc.moments_out: out[n][B][c][3], B = mi355_gn_moments_blocks(x). One streaming
+ * read; for tensors no conv epilogue produced (the network input, the trilinear-upsampled half of a concat buffer). */
+int32_t mi355_gn_moments_blocks(const mi355_act* x);
+int mi355_gn_moments(const mi355_act* x, float* out, void* stream);
+/* Statistics from partial moments: the channels [0, c_a) of the normalised tensor come from part_a[n][blocks_a][c_a][3] and, when
+ * part_b != NULL, the channels [c_a, c_a + c_b) from part_b[n][blocks_b][c_b][3] (a concat buffer whose halves were written by two
+ * producers, unet.py:42). Combined in double in a fixed order (deterministic). Outputs as mi355_gn_stats. */
+int mi355_gn_finalize(const float* part_a, int32_t blocks_a, int32_t c_a, const float* part_b, int32_t blocks_b, int32_t c_b,
+                      int32_t n, int32_t groups, float eps, const float* gamma, const float* beta,
+                      float* mean_rstd, float* scale, float* shift, void* stream);
+
 /* Backward of act(GroupNorm(x)) given dA = dLoss/d(act output):
  *   du = dA * act'(u), dgamma[c] = sum du*xhat, dbeta[c] = sum du,
  *   dx = rstd*(gamma*du - mean_g(gamma*du) - xhat*mean_g(gamma*du*xhat)) (+ addend if not NULL)
@@ -150,6 +183,11 @@ int mi355_gn_act_bwd(const mi355_act* x, const mi355_act* dA, const mi355_act* d
                      int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
                      const float* scale, const float* shift, float* dgamma, float* dbeta,
                      void* ws, size_t ws_bytes, void* stream);
+/* The same with the first pass already done by the dgrad conv that produced dA (mi355_gn_bwd_fuse): partials[n][blocks][c][2]. */
+int mi355_gn_act_bwd_fused(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const float* addend, int32_t addend_ld,
+                           int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
+                           const float* scale, const float* shift, float* dgamma, float* dbeta,
+                           const float* partials, int32_t blocks, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- upsample + pad + concat ------------------------------------------------------------------ */
 /* F.interpolate(scale_factor=2, mode="trilinear", align_corners=False) (decoder.py:105-106) followed by

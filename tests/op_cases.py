@@ -133,32 +133,6 @@ def case_conv_dgrad(be, n, cin, cout, dhw, stride=1, seed=1):
     return rel_err(from_act(dxa), dx_ref)
 
 
-def case_conv_wgrad_exp(be, variant, n, cin, cout, dhw, norm=False, slope=0.0, seed=2):
-    """Experimental ring-wgrad variants (csrc/conv3d_wgrad_exp.hip) against the same oracle as case_conv_wgrad."""
-    g = torch.Generator().manual_seed(seed)
-    d, h, w = dhw
-    x = torch.randn(n, cin, d, h, w, generator=g)
-    wt = (torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.1).requires_grad_(True)
-    normspec = None
-    gamma = beta = None
-    if norm:
-        groups = 8 if cin >= 8 and cin % 8 == 0 else cin
-        gamma = torch.rand(cin, generator=g) + 0.5
-        beta = torch.randn(cin, generator=g) * 0.3
-        normspec = (groups, gamma, beta, 1e-5, slope)
-    y = O.conv_block(x, wt, 1, 1, normspec)
-    dy = torch.randn(y.shape, generator=g)
-    (dw_ref,) = torch.autograd.grad(y, wt, dy)
-    xa, dya = to_act(be, x), to_act(be, dy)
-    kw = {}
-    if norm:
-        mr, sc, sh = be.gn_stats(xa, groups, 1e-5, dev(be, gamma), dev(be, beta))
-        kw = dict(in_mode=ops.IN_AFFINE_ACT, slope=slope, scale=sc, shift=sh)
-    dw = torch.zeros(cout, cin, 3, 3, 3).to(be.device)
-    be.conv_wgrad_ring_exp(xa, dya, dw, variant, **kw)
-    return rel_err(dw.cpu(), dw_ref)
-
-
 def case_tconv3(be, n, cin, cout, dhw, pad_to=None, seed=12):
     """ConvTranspose3d(k3, s2, p1, bias) forward (decoder.py:99-102) = zero-insert conv with the mode-2 pack; `pad_to`: the
     F.pad window of unet.py:34-40 (output written at offset diff//2 of a pre-zeroed larger tensor)."""
@@ -293,6 +267,100 @@ def case_gn(be, n, c, dhw, groups, slope=0.0, ld=None, seed=3, offset=0.4):
     dbet = torch.empty(c, device=be.device)
     be.gn_act_bwd(xa, dAa, dxa, groups, slope, dev(be, gamma.detach()), mr, sc, sh, dgam, dbet, addend=to_act(be, add))
     return dict(stats=e_stats, dx=rel_err(from_act(dxa), dx_ref), dgamma=rel_err(dgam, dg_ref), dbeta=rel_err(dbet, db_ref))
+
+
+def case_conv_moments(be, n, cin, cout, dhw, stride=1, norm=True, residual=False, chscale=False, groups_out=None, yld=None, yc0=0,
+                      expect_fused=True, seed=13):
+    """Norm statistics of a conv OUTPUT taken from the moment records its epilogue wrote (csrc/gn_fuse.h; myronenko.py:17-21:
+    every conv output is the next block's GroupNorm input) against the statistics of the oracle's conv output, and against the
+    standalone statistics pass over the same device tensor. Returns the worst relative error of (mean, rstd, scale, shift)."""
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dhw
+    x = torch.randn(n, cin, d, h, w, generator=g) * 1.3 + 0.2
+    wt = torch.randn(cout, cin, 3, 3, 3, generator=g) * (1.0 / (cin * 27) ** 0.5)
+    normspec = None
+    kw = {}
+    xa = to_act(be, x)
+    if norm:
+        gi = 8 if cin >= 8 and cin % 8 == 0 else cin
+        gamma = torch.rand(cin, generator=g) + 0.5
+        beta = torch.randn(cin, generator=g) * 0.3
+        normspec = (gi, gamma, beta, 1e-5, 0.0)
+        mr, sc, sh = be.gn_stats(xa, gi, 1e-5, dev(be, gamma), dev(be, beta))
+        kw = dict(in_mode=ops.IN_AFFINE_ACT, scale=sc, shift=sh)
+    od, oh, ow = [(s + 2 - 3) // stride + 1 for s in dhw]
+    res = torch.randn(n, cout, od, oh, ow, generator=g) + 3.0 if residual else None      # |mean| >> std of the conv term
+    cs = (torch.rand(n, cout, generator=g) > 0.3).float() * 1.25 if chscale else None
+    ref = O.conv_block(x, wt, stride, 1, normspec, None, res, cs)
+    ya = to_act(be, torch.zeros(n, cout, od, oh, ow), yld, yc0)
+    be.conv_fwd(xa, be.pack_weight(dev(be, wt), 0), ya, 3, stride, 1, residual=to_act(be, res) if residual else None, chscale=dev(be, cs),
+                moments=True, **kw)
+    assert rel_err(from_act(ya), ref) < TOL
+    assert (ya.mom is not None) == expect_fused, "fused statistics expected" if expect_fused else "fallback expected"
+    go = groups_out or (8 if cout >= 8 and cout % 8 == 0 else cout)
+    g2 = torch.rand(cout, generator=g) + 0.5
+    b2 = torch.randn(cout, generator=g) * 0.3
+    mr, sc, sh = be.gn_stats(ya, go, 1e-5, dev(be, g2), dev(be, b2))
+    rg = ref.double().reshape(n, go, -1)
+    mean_ref, rstd_ref = rg.mean(-1), (rg.var(-1, unbiased=False) + 1e-5).rsqrt()
+    cpg = cout // go
+    sc_ref = g2.double()[None] * rstd_ref.repeat_interleave(cpg, 1)
+    sh_ref = b2.double()[None] - mean_ref.repeat_interleave(cpg, 1) * sc_ref
+    e = max(rel_err(mr[..., 0], mean_ref), rel_err(mr[..., 1], rstd_ref), rel_err(sc, sc_ref), rel_err(sh, sh_ref))
+    # cross-check: the standalone pass over the same device tensor
+    saved, ya.mom = ya.mom, None
+    mr2, sc2, sh2 = be.gn_stats(ya, go, 1e-5, dev(be, g2), dev(be, b2))
+    ya.mom = saved
+    e = max(e, rel_err(mr[..., 1], mr2[..., 1].cpu()), rel_err(sh, sh2.cpu()))
+    return e
+
+
+def case_cat_moments(be, n, c_up, c_skip, dhw, seed=14):
+    """Statistics of a concat buffer whose two halves have different producers (segmentation/unet.py:42): the skip half's records come
+    from a conv epilogue, the up half's from the standalone record producer (Backend.moments); groups straddle nothing or both."""
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dhw
+    up = torch.randn(n, c_up, d, h, w, generator=g) * 0.7 - 1.0
+    x = torch.randn(n, 8, d, h, w, generator=g)
+    wt = torch.randn(c_skip, 8, 3, 3, 3, generator=g) * 0.1
+    skip = F.conv3d(x, wt, None, padding=1)
+    cat = to_act(be, torch.zeros(n, c_up + c_skip, d, h, w))
+    cat.tensor()[..., :c_up] = up.permute(0, 2, 3, 4, 1).to(be.device)
+    sl_up, sl_skip = cat.slice(0, c_up), cat.slice(c_up, c_skip)
+    be.conv_fwd(to_act(be, x), be.pack_weight(dev(be, wt), 0), sl_skip, 3, 1, 1, moments=True)
+    assert sl_skip.mom is not None
+    be.moments(sl_up)
+    cat.mom = sl_up.mom + sl_skip.mom
+    c = c_up + c_skip
+    groups = 8 if c % 8 == 0 else c
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    mr, sc, sh = be.gn_stats(cat, groups, 1e-5, dev(be, gamma), dev(be, beta))
+    ref = torch.cat((up, skip), 1).double().reshape(n, groups, -1)
+    mean_ref, rstd_ref = ref.mean(-1), (ref.var(-1, unbiased=False) + 1e-5).rsqrt()
+    return max(rel_err(mr[..., 0], mean_ref), rel_err(mr[..., 1], rstd_ref))
+
+
+def case_gn_bwd_fused(be, n, cin, cout, dhw, groups=None, slope=0.0, expect_fused=True, seed=15):
+    """act(GroupNorm) backward where the first pass (sum du, sum du*xhat) leaves with the epilogue of the dgrad conv that produces
+    dA (csrc/gn_fuse.h): dx / dgamma / dbeta against double-precision autograd of conv(act(norm(x)))."""
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dhw
+    groups = groups or (8 if cin >= 8 and cin % 8 == 0 else cin)
+    x = (torch.randn(n, cin, d, h, w, generator=g) * 1.7 + 0.4).double().requires_grad_(True)
+    gamma = (torch.rand(cin, generator=g) + 0.5).double().requires_grad_(True)
+    beta = (torch.randn(cin, generator=g) * 0.3).double().requires_grad_(True)
+    wt = (torch.randn(cout, cin, 3, 3, 3, generator=g) * (1.0 / (cin * 27) ** 0.5)).double()
+    y = F.conv3d(O.norm_act(x, groups, gamma, beta, 1e-5, slope), wt, None, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(y, (x, gamma, beta), dy.double())
+    xa = to_act(be, x.detach().float())
+    st = be.gn_stats(xa, groups, 1e-5, dev(be, gamma.detach().float()), dev(be, beta.detach().float()))
+    dA = to_act(be, torch.zeros(n, cin, d, h, w))
+    parts = be.conv_fwd(to_act(be, dy), be.pack_weight(dev(be, wt.float()), 1), dA, 3, 1, 1, gnb=(xa, st, groups, slope))
+    assert (parts is not None) == expect_fused
+    dgam, dbet = torch.empty(cin, device=be.device), torch.empty(cin, device=be.device)
+    be.gn_act_bwd(xa, dA, dA, groups, slope, dev(be, gamma.detach().float()), st[0], st[1], st[2], dgam, dbet, partials=parts)
+    return dict(dx=rel_err(from_act(dA), dx_ref), dgamma=rel_err(dgam, dg_ref), dbeta=rel_err(dbet, db_ref))
 
 
 def case_upsample(be, n, c, lo_dhw, target_dhw, c_skip=8, seed=4):

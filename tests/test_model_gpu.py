@@ -218,3 +218,27 @@ def test_auto_implant_unet_contract():
     x = torch.randn(1, 4, 16, 16, 16).cuda()
     with torch.no_grad():
         assert torch.allclose(m(x), m.test(x) - x)
+
+
+def test_side_stream_weight_gradients_are_bit_identical():
+    """The default backward enqueues the weight-gradient kernels on a second HIP stream (engine.py: backward_side_stream) so they
+    overlap the HBM-bound norm-backward passes. Same kernels, same inputs, same workspace discipline: the flat gradient must be
+    BITWISE the single-stream one, run to run."""
+    x, y = R.synthetic_case(2, 4, (48, 40, 32), 3)
+    x, y = x.cuda(), y.cuda()
+    flat = {}
+    for side in (False, True, True):
+        torch.manual_seed(5)
+        m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=16).cuda().eval()
+        assert m.backward_side_stream is True                     # the shipped default
+        m.backward_side_stream = side
+        crit = losses.HipDiceLoss(sigmoid=True)
+        for _ in range(2):                                        # second pass: allocator blocks are being reused across streams
+            m.zero_grad(set_to_none=True)
+            crit(m(x), y).backward()
+        torch.cuda.synchronize()
+        g = m.flat_grad().clone()
+        if side in flat:
+            assert torch.equal(flat[side], g)
+        flat[side] = g
+    assert torch.equal(flat[False], flat[True])

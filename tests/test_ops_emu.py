@@ -148,6 +148,51 @@ def test_groupnorm(emu_backend, kw):
     assert ok(C.case_gn(emu_backend, **kw))
 
 
+# ---- norm statistics fused into conv epilogues (csrc/gn_fuse.h): index logic of every tile configuration on the emulator ----
+@pytest.mark.parametrize("kw", [
+    dict(n=2, cin=8, cout=32, dhw=(5, 6, 9)),                                   # ragged tiles, 2 samples (cfg 7: 4x4x8 tiles)
+    dict(n=1, cin=16, cout=64, dhw=(3, 5, 8), residual=True, chscale=True),     # 2x2 wave grid, residual with |mean| >> std, dropout scale
+    dict(n=1, cin=8, cout=40, dhw=(4, 4, 8), groups_out=40),                    # partial channel tile, InstanceNorm-style groups
+    dict(n=1, cin=4, cout=32, dhw=(5, 9, 9)),                                   # first-layer kernel (conv3d_c4_fwd)
+    dict(n=1, cin=32, cout=32, dhw=(9, 8, 8), stride=2, norm=False),            # stride-2 down-sampling conv
+    dict(n=1, cin=8, cout=32, dhw=(4, 4, 8), yld=64, yc0=32),                   # output written into a concat slice
+])
+def test_conv_epilogue_moments(emu_backend, kw):
+    assert C.case_conv_moments(emu_backend, **kw) < 2e-5
+
+
+def test_conv_epilogue_moments_large_tiles(emu_backend):
+    # >= 131072 output voxels: the 4x8x8 two-M-tile configurations (cfg 4 / 5) of the 128^3 layers
+    assert C.case_conv_moments(emu_backend, 1, 8, 64, (32, 64, 64), norm=False) < 2e-5
+
+
+def test_concat_statistics_from_two_producers(emu_backend):
+    assert C.case_cat_moments(emu_backend, 2, 8, 24, (3, 5, 8)) < 2e-5
+    assert C.case_cat_moments(emu_backend, 1, 4, 8, (4, 4, 4)) < 2e-5          # 12 channels: per-channel groups
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=2, cin=32, cout=32, dhw=(5, 6, 9)),
+    dict(n=1, cin=64, cout=16, dhw=(3, 5, 8), slope=0.01),                      # 2 N tiles per wave, LeakyReLU
+    dict(n=1, cin=40, cout=8, dhw=(4, 4, 8), groups=40),                        # partial channel tile, InstanceNorm
+])
+def test_norm_backward_sums_from_dgrad_epilogue(emu_backend, kw):
+    r = C.case_gn_bwd_fused(emu_backend, **kw)
+    assert all(v < 2e-5 for v in r.values()), r
+
+
+def test_fused_statistics_switch_off(emu_backend):
+    """Backend.fused_stats = False is the round-1 form (every statistic a standalone pass): same numbers, no records."""
+    be = emu_backend
+    be.fused_stats = False
+    try:
+        assert C.case_conv_moments(be, 1, 8, 32, (4, 4, 8), expect_fused=False) < 2e-5
+        r = C.case_gn_bwd_fused(be, 1, 32, 32, (4, 4, 8), expect_fused=False)
+        assert all(v < 2e-5 for v in r.values()), r
+    finally:
+        be.fused_stats = True
+
+
 @pytest.mark.parametrize("lo,tgt", [((3, 4, 5), (6, 8, 10)), ((4, 3, 5), (7, 5, 9)), ((2, 2, 2), (5, 4, 4))])
 def test_upsample(emu_backend, lo, tgt):
     assert ok(C.case_upsample(emu_backend, 2, 8, lo, tgt))
@@ -230,19 +275,14 @@ def test_conv_wgrad_bf16_paths(prec_backend, kw):
     assert C.case_conv_wgrad(be, **kw) < tol
 
 
-# ---- experimental ring-wgrad variants (csrc/conv3d_wgrad_exp.hip; not dispatched by the product path): index logic on the emulator ----
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])       # bit 0: 16x16x4 tiles, bit 1: 8x8 columns, bit 2: 16-in-flight slab reduction
+# ---- the 8x8-column form of the plane-ring wgrad (taken when the plane has >= 32 rows): index logic on the emulator ----
 @pytest.mark.parametrize("kw", [
-    dict(n=2, cin=32, cout=32, dhw=(5, 6, 9), norm=True),            # ragged columns in y and x, two samples
-    dict(n=1, cin=64, cout=96, dhw=(4, 9, 8), norm=True, slope=0.01),  # 2 x 3 (ci, co) pairs
-    dict(n=1, cin=40, cout=24, dhw=(3, 4, 17)),                       # partial channel tiles, plain input
-    dict(n=1, cin=32, cout=32, dhw=(32, 4, 8), norm=True),            # one column cut into two z chunks
-    dict(n=1, cin=32, cout=32, dhw=(3, 12, 24)),                      # several columns per workgroup? no: 512 slabs > columns; many idle workgroups
+    dict(n=2, cin=32, cout=32, dhw=(3, 34, 9), norm=True),            # ragged columns in y (34 = 4 x 8 + 2) and x, two samples
+    dict(n=1, cin=64, cout=96, dhw=(2, 32, 8), norm=True, slope=0.01),  # 2 x 3 (ci, co) pairs
+    dict(n=1, cin=40, cout=24, dhw=(2, 33, 17)),                      # partial channel tiles, plain input
+    dict(n=1, cin=32, cout=32, dhw=(32, 32, 8), norm=True),           # columns cut into z chunks
 ])
-def test_conv_wgrad_ring_experimental_variants(emu_backend, variant, kw):
-    assert C.case_conv_wgrad_exp(emu_backend, variant, **kw) < TOL
+def test_conv_wgrad_ring_8x8_columns(emu_backend, kw):
+    assert C.case_conv_wgrad(emu_backend, **kw) < TOL
 
 
-def test_conv_wgrad_experimental_reduction_512_slabs(emu_backend):
-    # one (co, ci) pair and 512 columns -> 512 partial slabs: the 64-slab main loop of the 16-in-flight reduction plus its tail
-    assert C.case_conv_wgrad_exp(emu_backend, 4, 4, 32, 32, (2, 64, 64), norm=True) < TOL

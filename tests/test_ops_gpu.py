@@ -138,6 +138,50 @@ def test_groupnorm(hip_backend, kw):
     assert ok(C.case_gn(hip_backend, **kw))
 
 
+# ---- norm statistics fused into the conv epilogues (csrc/gn_fuse.h): every tile configuration the networks use ----
+@pytest.mark.parametrize("kw", [
+    dict(n=2, cin=32, cout=32, dhw=(64, 64, 64), residual=True, chscale=True),      # 4x8x8 x 32 channels: the 128^3-level kernel
+    dict(n=2, cin=32, cout=64, dhw=(64, 64, 64)),                                   # 4x8x8 x 64 channels (4 MFMA tiles per wave)
+    dict(n=1, cin=64, cout=128, dhw=(32, 32, 32)),                                  # 4x4x8 x 64, 2x2 wave grid
+    dict(n=2, cin=128, cout=256, dhw=(16, 16, 16), residual=True),                  # 2x4x8 tiles, two-level accumulation
+    dict(n=2, cin=4, cout=32, dhw=(64, 64, 64)),                                    # first layer (conv3d_c4_fwd)
+    dict(n=1, cin=4, cout=64, dhw=(33, 30, 36), groups_out=64),                     # DynUNet input block: ragged, InstanceNorm
+    dict(n=2, cin=32, cout=32, dhw=(64, 64, 64), stride=2, norm=False),             # stride-2 down-sampling conv
+    dict(n=1, cin=96, cout=96, dhw=(31, 33, 17), stride=2, groups_out=96),
+    dict(n=1, cin=32, cout=32, dhw=(32, 32, 32), yld=64, yc0=32),                   # written into a concat slice
+])
+def test_conv_epilogue_moments(hip_backend, kw):
+    assert C.case_conv_moments(hip_backend, **kw) < 2e-5
+
+
+def test_concat_statistics_from_two_producers(hip_backend):
+    assert C.case_cat_moments(hip_backend, 2, 32, 32, (64, 64, 64)) < 2e-5
+    assert C.case_cat_moments(hip_backend, 1, 4, 8, (9, 10, 11)) < 2e-5
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=2, cin=32, cout=32, dhw=(64, 64, 64)),
+    dict(n=2, cin=64, cout=32, dhw=(64, 64, 64)),                                   # 4 MFMA tiles per wave
+    dict(n=1, cin=128, cout=128, dhw=(32, 32, 32)),
+    dict(n=2, cin=256, cout=256, dhw=(16, 16, 16)),
+    dict(n=1, cin=96, cout=64, dhw=(17, 19, 23), groups=96, slope=0.01),            # InstanceNorm + LeakyReLU, ragged
+])
+def test_norm_backward_sums_from_dgrad_epilogue(hip_backend, kw):
+    r = C.case_gn_bwd_fused(hip_backend, **kw)
+    assert all(v < 2e-5 for v in r.values()), r
+
+
+def test_fused_statistics_switch_off(hip_backend):
+    be = hip_backend
+    be.fused_stats = False
+    try:
+        assert C.case_conv_moments(be, 1, 32, 32, (16, 16, 16), expect_fused=False) < 2e-5
+        r = C.case_gn_bwd_fused(be, 1, 32, 32, (16, 16, 16), expect_fused=False)
+        assert all(v < 2e-5 for v in r.values()), r
+    finally:
+        be.fused_stats = True
+
+
 @pytest.mark.parametrize("lo,tgt", [((16, 16, 16), (32, 32, 32)), ((8, 7, 9), (15, 13, 17)), ((4, 4, 4), (9, 8, 8))])
 def test_upsample(hip_backend, lo, tgt):
     assert ok(C.case_upsample(hip_backend, 2, 32, lo, tgt))

@@ -191,25 +191,6 @@ static inline f32x16 emu_mfma_32x32x2(float a, float b, f32x16 c) {
 }
 #define MFMA_32x32x2(a, b, c) emu_mfma_32x32x2(a, b, c)
 
-// D = A(16x4) * B(4x16) + C ; lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; lane holds C[row=4*(l>>4)+r][col=l&15], r in [0,4).
-static inline f32x4 emu_mfma_16x16x4(float a, float b, f32x4 c) {
-  emu::BlockState* bs = emu::g_bs;
-  int t = emu::flat_tid();
-  int wbase = (t / 64) * 64, l = t % 64;
-  bs->mfma_a[t] = a; bs->mfma_b[t] = b;
-  emu::wave_barrier();
-  int col = l & 15;
-  for (int r = 0; r < 4; ++r) {
-    int row = 4 * (l >> 4) + r;
-    float acc = c[r];
-    for (int k = 0; k < 4; ++k) acc = fmaf(bs->mfma_a[wbase + 16 * k + row], bs->mfma_b[wbase + 16 * k + col], acc);
-    c[r] = acc;
-  }
-  emu::wave_barrier();
-  return c;
-}
-#define MFMA_16x16x4(a, b, c) emu_mfma_16x16x4(a, b, c)
-
 // v_pk_fma_f32: two independent fmaf per lane
 struct pkf2 { float x, y; };
 static inline pkf2 make_pkf2(float x, float y) { return pkf2{x, y}; }
