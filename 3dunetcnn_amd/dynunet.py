@@ -142,8 +142,38 @@ class HipDynUNet(HipNetBase):
         self.n_in_channels = in_channels
         self._init_engine()
 
-    # MONAI registers the same blocks a second time under `skip_layers.*` (DynUNetSkipLayer chain): those keys are
-    # aliases of the ones above. Accept checkpoints that contain them; never emit them.
+    # MONAI registers the same blocks a second time under `skip_layers.*`: DynUNet.__init__ ends with
+    #   self.skip_layers = create_skips(0, [input_block] + downsamples, upsamples[::-1], bottleneck)
+    # a chain of DynUNetSkipLayer(downsample, next_layer, upsample) modules (attributes registered in that order) whose innermost
+    # `next_layer` is the bottleneck block itself. nn.Module.state_dict() does not de-duplicate shared modules, so a MONAI checkpoint
+    # carries every encoder / decoder tensor twice: under its own name and under the alias. Emitting the aliases (same tensors, MONAI's
+    # order: after output_block) makes a HipDynUNet checkpoint load into MONAI's DynUNet with strict=True; loading accepts and ignores
+    # them. [MONAI-memory: the class is not importable here; the key names follow SURVEY.md 8a-b5 / MONAI's dynunet.py.]
+    def _skip_layer_aliases(self):
+        L = len(self.filters)
+        downs = [("input_block", self.input_block)] + [(f"downsamples.{i}", m) for i, m in enumerate(self.downsamples)]
+        ups = [(f"upsamples.{k}", m) for k, m in enumerate(self.upsamples)][::-1]
+        out = []
+
+        def walk(prefix, depth):
+            if depth == L - 1:
+                out.append((prefix, "bottleneck"))
+                return
+            out.append((prefix + ".downsample", downs[depth][0]))
+            walk(prefix + ".next_layer", depth + 1)
+            out.append((prefix + ".upsample", ups[depth][0]))
+        walk("skip_layers", 0)
+        return out                                   # [(alias prefix, canonical prefix)]
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        own = [k for k in sd.keys() if k.startswith(prefix)]
+        for alias, canon in self._skip_layer_aliases():
+            for k in own:
+                if k.startswith(prefix + canon + "."):
+                    sd[prefix + alias + k[len(prefix + canon):]] = sd[k]
+        return sd
+
     def load_state_dict(self, state_dict, strict=True, **kw):
         sd = {k: v for k, v in state_dict.items() if not k.startswith("skip_layers.")}
         return super().load_state_dict(sd, strict=strict, **kw)

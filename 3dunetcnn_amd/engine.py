@@ -26,6 +26,10 @@ class _NetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         model = ctx.model
+        if ctx.saved is None:
+            # the saved activations are released by the first backward (12 GB at 128^3, batch 2): there is no retain_graph form
+            raise RuntimeError(f"{type(model).__name__}: backward called a second time through the same forward (or after a no-grad "
+                               "forward): the saved activations are freed by the first backward; run the forward again")
         grads, dx = model._backward_impl(ctx.saved, dlogits.contiguous(), ctx.x_requires_grad)
         ctx.saved = None
         return (None, dx) + (None,) * len(grads)   # parameter .grad is set by _backward_impl (zero-copy views of the flat buffer)
@@ -117,11 +121,31 @@ class HipNetBase(nn.Module):
             # the autograd link, so loss.backward() yields zero-valued parameter gradients as it does for the reference
             n_out = getattr(self, "n_outputs", None) or getattr(self, "out_channels")
             return x.new_zeros((0, n_out) + tuple(x.shape[2:])) + sum(p.sum() * 0 for p in self._params())
+        if getattr(self, "_is_replica", False):
+            # torch.nn.DataParallel (what the reference wraps the model in for n_gpus > 1, unet3d/models/build.py:18-20) re-creates the
+            # module per GPU every forward with its parameters as broadcast views: the flat parameter / gradient buffers, packed
+            # weights and the explicit backward of this engine cannot live in such a replica
+            raise RuntimeError(f"{type(self).__name__} does not run under torch.nn.DataParallel (n_gpus > 1 in the reference's "
+                               "build_or_load_model): use one process per GPU -- `python bench.py --gpus N`, or "
+                               "3dunetcnn_amd.ddp.GradientBucketReducer under torch.distributed (INTEGRATION.md, multi-GPU)")
         self.flatten_parameters()
-        return _NetFunction.apply(self, x.contiguous().float(), *self._params())
+        if self._be is not None and x.device.type == "cuda" and self._be.device.type == "cuda" and x.device != self._be.device:
+            raise RuntimeError(f"{type(self).__name__}: input on {x.device} but the module lives on {self._be.device}")
+        with self._device_guard(x):
+            return _NetFunction.apply(self, x.contiguous().float(), *self._params())
+
+    @staticmethod
+    def _device_guard(x):
+        """Make the input's device current for the forward (torch.empty / current_stream follow the current device)."""
+        return torch.cuda.device(x.device) if x.device.type == "cuda" else contextlib.nullcontext()
 
     def _begin_forward(self):
-        be = self._be = self._be or _ops.default_backend()
+        # the backend (library handle, workspace, launch stream) of the device the PARAMETERS live on -- not of whatever device
+        # happens to be current: a model on cuda:1 must not allocate and launch on cuda:0
+        if self._be is None:
+            dev = self._flat.device if self._flat is not None else None
+            self._be = _ops.default_backend(dev.index if dev is not None and dev.type == "cuda" else None)
+        be = self._be
         self._packs_dirty_local = self._packs_dirty
         self._saved_precision = be.precision
         if self.conv_precision is not None:
@@ -220,10 +244,12 @@ class HipNetBase(nn.Module):
         grads = []
         for p, o in zip(ps, self._offsets):
             g = gbuf[o:o + p.numel()].view(p.shape)
+            grads.append(g)
+            if not p.requires_grad:
+                continue           # frozen parameter: as with autograd, no .grad appears (an optimizer holding it must not move it)
             if p.grad is None:
                 p.grad = g
             else:
                 p.grad.add_(g)
-            grads.append(g)
         self._gbuf = None
         return grads, dx_t

@@ -85,7 +85,7 @@ class HipSlidingWindowInferer:
     def __call__(self, inputs, network, *args, **kwargs):
         if inputs.device.type != "cuda" and self._be is None:
             raise RuntimeError("HipSlidingWindowInferer runs on an MI355X only (no CPU fallback)")
-        be = self._be or _ops.default_backend()
+        be = self._be or _ops.default_backend(inputs.device)
         if inputs.dim() != 5:
             raise ValueError("expected inputs [N, C, D, H, W]")
         inputs = inputs.float()

@@ -20,7 +20,7 @@ from . import ops as _ops
 class _DiceFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, mod):
-        be = mod._be or _ops.default_backend()
+        be = mod._be or _ops.default_backend(logits.device)
         want = ctx.needs_input_grad[0]
         loss, dlogits = be.dice(logits.contiguous(), target.contiguous(), sigmoid=mod.sigmoid, batch=mod.batch,
                                 squared_pred=mod.squared_pred, smooth_nr=mod.smooth_nr, smooth_dr=mod.smooth_dr, want_grad=want,
@@ -30,9 +30,16 @@ class _DiceFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        d = ctx.dlogits
-        ctx.dlogits = None
-        return d * g, None, None
+        return _scaled(ctx, g), None, None
+
+
+def _scaled(ctx, g):
+    """d(loss)/d(logits) computed by the forward pass, times the incoming scalar gradient -- in place (no second logits-sized tensor)."""
+    d = ctx.dlogits
+    if d is None:
+        raise RuntimeError("loss backward called a second time: d(loss)/d(logits) is released by the first backward")
+    ctx.dlogits = None
+    return d.mul_(g)
 
 
 class HipDiceLoss(nn.Module):
@@ -80,7 +87,7 @@ class _CEFunction(torch.autograd.Function):
     """loss = lambda_dice * Dice + lambda_ce * CE (either weight may be 0), value and d/dlogits from the fused HIP passes."""
     @staticmethod
     def forward(ctx, logits, target, mod):
-        be = mod._be or _ops.default_backend()
+        be = mod._be or _ops.default_backend(logits.device)
         want = ctx.needs_input_grad[0]
         logits, target = logits.contiguous(), target.contiguous()
         loss = dlogits = None
@@ -97,9 +104,7 @@ class _CEFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        d = ctx.dlogits
-        ctx.dlogits = None
-        return d * g, None, None
+        return _scaled(ctx, g), None, None
 
 
 class HipGeneralizedDiceLoss(HipDiceLoss):
@@ -149,6 +154,10 @@ class HipDiceCELoss(_CEBase):
         self.sigmoid, self.squared_pred, self.batch = bool(sigmoid), bool(squared_pred), bool(batch)
         self.smooth_nr, self.smooth_dr = float(smooth_nr), float(smooth_dr)
         self.lambda_dice, self.lambda_ce = float(lambda_dice), float(lambda_ce)
+        if self.lambda_dice < 0.0 or self.lambda_ce < 0.0:
+            raise ValueError("lambda_dice and lambda_ce should be no less than 0.0.")      # MONAI's check, same message
+        if self.lambda_dice == 0.0 and self.lambda_ce == 0.0:
+            raise ValueError("HipDiceCELoss: lambda_dice and lambda_ce are both 0 -- the loss would be identically zero")
         self.include_background = bool(include_background)      # Dice term only (MONAI: the CE term always sees every channel)
         self._be = None
 

@@ -442,13 +442,16 @@ class Backend:
 _default = {}
 
 
-def default_backend():
-    """HIP backend for the current device (created on first use; raises without library or GPU)."""
+def default_backend(device=None):
+    """HIP backend of `device` (an index, a torch.device or a tensor's .device; None: the current device). Created on first use;
+    raises without library or GPU."""
     if not torch.cuda.is_available():
         raise RuntimeError("3dunetcnn_amd needs an MI355X (no HIP device visible); there is no CPU fallback")
-    dev = torch.cuda.current_device()
+    if isinstance(device, torch.device):
+        device = device.index
+    dev = torch.cuda.current_device() if device is None else int(device)
     if dev not in _default:
-        _default[dev] = Backend()
+        _default[dev] = Backend(device=torch.device("cuda", dev))
         env = os.environ.get("MI355_PRECISION")        # fp32 (default) | bf16x6 | bf16x3 | bf16
         if env:
             _default[dev].set_precision(env)

@@ -43,7 +43,7 @@ class HipAdam(torch.optim.Optimizer):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
-            be = self._be or _ops.default_backend()
+            be = self._be or _ops.default_backend(ps[0].device)
             # state of the fused path lives under a string key (kept verbatim by Optimizer.state_dict / load_state_dict), indexed
             # by the group's position so that a checkpoint restores into a freshly built optimizer
             st = self.state.setdefault("_flat_group%d" % gi, {})

@@ -22,7 +22,7 @@ def _be(t, be=None):
         return be
     if t.device.type != "cuda":
         raise RuntimeError("3dunetcnn_amd.prepost runs on an MI355X only (no CPU fallback)")
-    return _ops.default_backend()
+    return _ops.default_backend(t.device)
 
 
 def compile_one_hot_encoding(data, n_labels, labels=None, dtype=torch.uint8, return_4d=True, round=True, _backend=None):

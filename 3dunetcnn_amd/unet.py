@@ -120,11 +120,17 @@ class HipUNet3D(HipNetBase):
             # unusable in the reference as well (IndexError at decoder.py:112-114)
             raise ValueError("layer_widths is not supported (the reference UNet3D raises IndexError for it)")
         if kernel_size != 3:
+            # the reference forwards kernel_size to every conv3x3x3 and to ConvTranspose3d (myronenko.py:15, decoder.py:96-102); the HIP
+            # kernels exist for the 3x3x3 form every shipped configuration uses ("constructor surface")
             raise NotImplementedError("HipUNet3D implements the reference default kernel_size=3")
         if downsampling_stride != 2:
+            # the reference uses it as conv stride AND as the decoder's up-sampling scale (variational.py:47-52)
             raise NotImplementedError("HipUNet3D implements the reference default downsampling_stride=2")
-        if interpolation_mode != "trilinear" and not use_transposed_convolutions:
-            raise NotImplementedError("only trilinear interpolation (reference default) or transposed convolutions")
+        # interpolation_mode: the reference accepts any string at construction and hands it to F.interpolate together with
+        # align_corners=False (decoder.py:105-106); torch then raises at the first forward for everything but "trilinear"
+        # ("nearest" / "area": ValueError, align_corners cannot be set; "linear" / "bilinear" / "bicubic": NotImplementedError for
+        # 5-D input). Same here: accepted now, the same exception from the first forward (see forward()).
+        self.interpolation_mode = interpolation_mode
         # NDHWC rows are float4 multiples: an input with 1..3 (5..7, ...) channels is carried with zero channels up to the next
         # multiple of 4; the first block's weights / norm parameters are zero-padded copies and their gradients are sliced back
         self._cin_pad = (n_features + 3) // 4 * 4
@@ -159,6 +165,10 @@ class HipUNet3D(HipNetBase):
 
     # ---- forward -----------------------------------------------------------------------------------------------
     def forward(self, x):
+        if self.interpolation_mode != "trilinear" and not self.use_transposed_convolutions:
+            # let torch raise exactly what the reference's F.interpolate call raises for this mode (decoder.py:105-106)
+            F.interpolate(torch.zeros(1, 1, 1, 1, 1), scale_factor=2, mode=self.interpolation_mode, align_corners=False)
+            raise NotImplementedError(f"interpolation_mode={self.interpolation_mode!r}: only 'trilinear' has a HIP kernel")
         y = self._run(x)
         if self.activation is not None:
             y = self.activation(y)

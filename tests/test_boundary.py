@@ -1,0 +1,139 @@
+"""The drop-in boundary's edges (SURVEY.md 8b "object protocol"): what the reference's builder / loader / training loop may do with
+the module besides calling it -- DataParallel wrap, tolerant checkpoint loading, frozen parameters, odd constructor kwargs -- and
+that each case either works like the reference or fails loudly, never silently.
+Kernels run on the CPU emulator (test infrastructure); /root/reference is imported where the reference's own code is the caller."""
+import importlib
+
+import pytest
+import torch
+
+from oracle import reference_shim, torch_ops as O, unet3d_ref as R
+
+unet = importlib.import_module("3dunetcnn_amd.unet")
+losses = importlib.import_module("3dunetcnn_amd.losses")
+optim = importlib.import_module("3dunetcnn_amd.optim")
+KW = dict(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1, 1])
+
+
+def _model(be, **kw):
+    m = unet.HipUNet3D(**{**KW, **kw}).eval()
+    m._be = be
+    return m
+
+
+def test_data_parallel_replicas_are_refused_loudly(emu_backend):
+    """unet3d/models/build.py:18-20 wraps the model in torch.nn.DataParallel for n_gpus > 1. Its replicas (re-created every forward,
+    parameters = broadcast views, torch marks them `_is_replica`) cannot carry the flat parameter / gradient buffers of this engine:
+    a replica's forward must raise and name the supported route, not compute garbage."""
+    m = _model(emu_backend)
+    x, _ = R.synthetic_case(1, 4, (8, 8, 8), 3)
+    m(x)                                             # the module itself runs
+    rep = m._replicate_for_data_parallel()           # what torch.nn.parallel.replicate creates per device
+    assert rep._is_replica
+    with pytest.raises(RuntimeError, match="DataParallel.*one process per GPU"):
+        rep(x)
+
+
+@pytest.mark.gpu
+def test_data_parallel_wrap_on_one_gpu_runs_the_module_itself(hip_backend):
+    """DataParallel over a single device calls the wrapped module directly (no replica): the reference's n_gpus=2 path on a
+    one-GPU box, and the unwrap in its loader (build.py:37-41), keep working."""
+    m = unet.HipUNet3D(**KW).cuda().eval()
+    dp = torch.nn.DataParallel(m, device_ids=[0])
+    x, _ = R.synthetic_case(1, 4, (16, 16, 16), 3)
+    with torch.no_grad():
+        assert torch.equal(dp(x.cuda()), m(x.cuda()))
+    dp.module.load_state_dict(m.state_dict(), strict=True)
+    if torch.cuda.device_count() == 1:
+        with pytest.raises(RuntimeError, match="DataParallel"):
+            torch.nn.parallel.replicate(m, [0, 0])[1](x.cuda())
+
+
+@pytest.mark.skipif(not reference_shim.available(), reason="/root/reference only exists in the build container")
+def test_reference_loader_tiles_a_narrower_checkpoint(emu_backend, tmp_path):
+    """unet3d/models/build.py:47-64 (match_state_dict_shapes / match_tensor_sizes): with strict=False a checkpoint whose tensors are
+    narrower is tiled (torch.cat of copies) and cropped to the model's shapes before load_state_dict. The module must take that
+    state_dict like an nn.Module made of torch layers does: same keys, OIDHW shapes, and the flat buffer must follow the loaded values."""
+    reference_shim.import_reference_unet()
+    importlib.import_module("3dunetcnn_amd.register").register()
+    build = importlib.import_module("unet3d.models.build")
+    torch.manual_seed(3)
+    narrow = unet.HipUNet3D(**{**KW, "n_features": 2, "base_width": 4})         # half the input modalities and half the widths
+    path = str(tmp_path / "narrow.pth")
+    torch.save(narrow.state_dict(), path)
+    model = build.build_or_load_model("HipUNet3D", path, n_gpus=0, strict=False, **KW)
+    want = build.match_state_dict_shapes(unet.HipUNet3D(**KW).state_dict(), torch.load(path))
+    for k, v in model.state_dict().items():
+        assert v.shape == want[k].shape and torch.equal(v, want[k]), k
+    w = model.state_dict()["encoder.layers.0.blocks.0.conv1.conv.weight"]       # (8, 4, 3, 3, 3) tiled from (4, 2, 3, 3, 3)
+    assert torch.equal(w[:4, :2], w[4:, 2:]) and torch.equal(w[:4, :2], narrow.state_dict()["encoder.layers.0.blocks.0.conv1.conv.weight"])
+    # the loaded weights are what the kernels use: forward == oracle on the loaded state_dict
+    model.eval()
+    model._be = emu_backend
+    x, _ = R.synthetic_case(1, 4, (8, 8, 8), 3)
+    ref = R.unet3d_forward({k: v.clone() for k, v in model.state_dict().items()}, x, (1, 1, 1))
+    out = model(x)
+    assert float((out - ref).abs().max() / ref.abs().max()) < 1e-3
+
+
+def test_non_trilinear_interpolation_fails_like_the_reference(emu_backend):
+    """The reference accepts any interpolation_mode at construction and passes it to F.interpolate with align_corners=False
+    (classification/decoder.py:105-106); torch rejects that at the first forward for every mode but "trilinear". Same here."""
+    x, _ = R.synthetic_case(1, 4, (8, 8, 8), 3)
+    for mode, exc in (("nearest", ValueError), ("area", ValueError), ("bilinear", NotImplementedError)):
+        m = _model(emu_backend, interpolation_mode=mode)                        # construction succeeds, as in the reference
+        with pytest.raises(exc) as ei:
+            m(x)
+        with pytest.raises(exc) as ref:
+            torch.nn.functional.interpolate(torch.zeros(1, 1, 2, 2, 2), scale_factor=2, mode=mode, align_corners=False)
+        assert str(ei.value) == str(ref.value)
+    _model(emu_backend, interpolation_mode="nearest", use_transposed_convolutions=True)(x)      # mode unused with transposed convs
+    for kw in (dict(kernel_size=5), dict(downsampling_stride=1), dict(layer_widths=[8, 16, 32])):
+        with pytest.raises((NotImplementedError, ValueError)):
+            unet.HipUNet3D(**{**KW, **kw})
+
+
+def test_frozen_parameters_get_no_gradient_and_do_not_move(emu_backend):
+    """requires_grad=False (fine-tuning a decoder on a frozen encoder): as with autograd, frozen parameters get no .grad, so an
+    optimizer that holds them leaves them alone; the others match the oracle."""
+    torch.manual_seed(4)
+    m = _model(emu_backend)
+    for p in m.encoder.parameters():
+        p.requires_grad_(False)
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x, y = R.synthetic_case(1, 4, (8, 8, 8), 3)
+    crit = losses.HipDiceLoss(sigmoid=True)
+    crit._be = emu_backend
+    opt = optim.HipAdam(m.parameters(), lr=1e-2)
+    opt._be = emu_backend
+    loss = crit(m(x), y)
+    loss.backward()
+    sd = {k: v.clone().requires_grad_(not k.startswith("encoder.")) for k, v in before.items()}
+    O.dice_loss(R.unet3d_forward(sd, x, (1, 1, 1)), y).backward()
+    for k, p in m.named_parameters():
+        if k.startswith("encoder."):
+            assert p.grad is None, k
+        else:
+            assert float((p.grad - sd[k].grad).abs().max() / sd[k].grad.abs().max().clamp_min(1e-30)) < 1e-3, k
+    opt.step()
+    after = m.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before if k.startswith("encoder."))
+    assert any(not torch.equal(before[k], after[k]) for k in before if k.startswith("decoder."))
+
+
+def test_second_backward_raises_a_clear_error(emu_backend):
+    m = _model(emu_backend)
+    x, y = R.synthetic_case(1, 4, (8, 8, 8), 3)
+    crit = losses.HipDiceLoss(sigmoid=True)
+    crit._be = emu_backend
+    loss = crit(m(x), y)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time|released"):
+        loss.backward()
+
+
+def test_dice_ce_rejects_degenerate_weights():
+    with pytest.raises(ValueError):
+        losses.HipDiceCELoss(sigmoid=True, lambda_dice=0.0, lambda_ce=0.0)
+    with pytest.raises(ValueError):
+        losses.HipDiceCELoss(sigmoid=True, lambda_dice=-1.0)

