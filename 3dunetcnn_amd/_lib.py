@@ -60,6 +60,7 @@ SIGNATURES = {
     "mi355_gn_stats": (ctypes.c_int, [POINTER(MiAct), c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mi355_gn_moments_blocks": (c_int32, [POINTER(MiAct)]),
     "mi355_gn_moments": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p]),
+    "mi355_gn_records_reduce": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "mi355_gn_finalize": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     "mi355_gn_act_bwd_fused": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), POINTER(MiAct), c_void_p, c_int32, c_int32, c_float,

@@ -207,11 +207,12 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
 // 4x4x8 tile -> barrier -> MFMAs -> barrier) the halo overhead drops from 2.8 to 1.9 (TY = 4) / 1.56 (TY = 8) input voxels per
 // output voxel. Operand layout and MFMA mapping are the same: conflict-free ds_read_b32 of 32 consecutive channels,
 // A = dy[voxel][co], B = in(x)[voxel + tap][ci], K = voxel pairs.
-// TY = 8 (8x8 columns, 67.6 KB of LDS = two workgroups per CU, which is what the register file allows anyway): half the barriers
-// per output voxel; measured on MI355X (round 2 A/B, tools/ab_wgrad history in DESIGN.md): +1.9 % on every 128^3 / 64^3 / 32^3
-// layer (32->32 @128^3: 1.843 -> 1.809 ms). TY = 4 stays for the small deep levels, where 8x8 columns would leave too few chunks.
-// Two variants lost the same A/B and are gone: v_mfma_f32_16x16x4_f32 tiles, 27 per wave (tap-balanced, but -3 %: twice the
-// LDS operand reads per flop), and a slab reduction with 16 loads in flight per thread (-1 .. -6 %).
+// Round-2 A/B on MI355X of three prepared variants: all lost and are gone.
+//   * TY = 8 (8x8 columns, 67.6 KB of LDS, half the barriers per output voxel): +1.9 % in the isolated micro-benchmark
+//     (32->32 @128^3: 1.843 -> 1.809 ms) but -8 % INSIDE the training step (rocprofv3 trace of bench.py: the 15 launches of the
+//     128^3 .. 32^3 layers 23.2 -> 25.1 ms per step) -- the step is what counts; the TY parameter stays in the template.
+//   * v_mfma_f32_16x16x4_f32 tiles, 27 per wave (tap-balanced): -3 % (twice the LDS operand reads per flop).
+//   * a slab reduction with 16 loads in flight per thread: -1 .. -6 %.
 template <int INMODE, int TY>
 __global__ __launch_bounds__(256) void conv3d_wgrad_ring(WgradArgs a) {
   constexpr int TX = 8, HY = TY + 2, HX = 10, PV = TY * TX, HPV = HY * HX;
@@ -481,7 +482,7 @@ struct RingPlan { int ty, tilesY, tilesX, zchunks, planes, chunks, splits, ciTil
 static RingPlan plan_wgrad_ring(const mi355_act* x, const mi355_act* dy) {
   RingPlan p; memset(&p, 0, sizeof(p));
   if (x->d != dy->d || x->h != dy->h || x->w != dy->w) return p;
-  p.ty = dy->h >= 32 ? 8 : 4;            // 8x8 columns where the plane is large enough (measured win at 32^3 .. 128^3)
+  p.ty = 4;                              // 4x8 columns (8x8 lost inside the step, see conv3d_wgrad_ring)
   p.tilesY = ceil_div(dy->h, p.ty); p.tilesX = ceil_div(dy->w, 8);
   p.ciTiles = ceil_div(x->c, 32); p.coTiles = ceil_div(dy->c, 32);
   const long long cols = (long long)dy->n * p.tilesY * p.tilesX;
@@ -551,8 +552,7 @@ extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float
       SET_MAX_DYN_LDS((conv3d_wgrad_ring<IM, TYV>), ldsb);                                                      \
       LAUNCH((conv3d_wgrad_ring<IM, TYV>), grid, dim3(256), ldsb, stream, a);                                   \
     } while (0)
-    if (r.ty == 8) { if (d->in_mode == MI355_IN_PLAIN) MI355_LAUNCH_RING(MI355_IN_PLAIN, 8); else MI355_LAUNCH_RING(MI355_IN_AFFINE_ACT, 8); }
-    else { if (d->in_mode == MI355_IN_PLAIN) MI355_LAUNCH_RING(MI355_IN_PLAIN, 4); else MI355_LAUNCH_RING(MI355_IN_AFFINE_ACT, 4); }
+    if (d->in_mode == MI355_IN_PLAIN) MI355_LAUNCH_RING(MI355_IN_PLAIN, 4); else MI355_LAUNCH_RING(MI355_IN_AFFINE_ACT, 4);
 #undef MI355_LAUNCH_RING
     int rc = LAUNCH_CHECK(); if (rc) return rc;
     return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, r.splits, r.ciTiles, stream);

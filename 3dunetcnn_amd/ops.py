@@ -130,7 +130,7 @@ class Backend:
         self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
         # norm statistics leave with the producing conv's epilogue (csrc/gn_fuse.h). False: every statistic is a standalone pass
         # over the tensor again (the round-1 form; kept as the cross-check of the fused path, tests/test_ops_gpu.py)
-        self.fused_stats = True
+        self.fused_stats = os.environ.get("MI355_FUSED_STATS", "1") != "0"
 
     def set_precision(self, name):
         """"fp32" (exact f32 MFMA, default) | "bf16x3" | "bf16x6" (split-bf16 fp32 emulation) | "bf16" (mixed precision)."""
@@ -195,7 +195,7 @@ class Backend:
             if nb > 0 and moments:
                 rec = torch.empty(x.shape[0], nb, y.c, 3, dtype=torch.float32, device=self.device)
                 d.moments_out = rec.data_ptr()
-                y.mom = [(rec, nb, y.c)]
+                y.mom = [(rec, nb, y.c)]                      # folded after the launch (see below)
             elif nb > 0 and in_mode == IN_PLAIN and d.wformat == W_PACKED:
                 gx, st, groups, gslope = gnb
                 assert gx.shape == y.shape
@@ -206,7 +206,7 @@ class Backend:
                 gparts = (rec, nb)
         if self.prof is None:
             check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wptr, ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
-            return gparts
+            return self._fold_after(y, gparts)
         # profiling: HIP events on the launch stream around this one kernel, keyed by the kernel's trace name
         name = ctypes.create_string_buffer(96)
         self.lib.mi355_conv3d_fwd_config(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d), name, 96)
@@ -224,6 +224,15 @@ class Backend:
         check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wptr, ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
         e1.record()
         self.prof.append((name.value.decode(), flops, byts, e0, e1))
+        return self._fold_after(y, gparts)
+
+    def _fold_after(self, y, gparts):
+        if y.mom is not None:
+            rec, nb, c = y.mom[0]
+            rec, nb = self._fold_records(rec, nb, c, 3)
+            y.mom = [(rec, nb, c)]
+        if gparts is not None:
+            gparts = self._fold_records(gparts[0], gparts[1], y.c, 2)
         return gparts
 
     def conv_wgrad(self, x, dy, dw, kd, stride=1, pad=None, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, in_slope=None,
@@ -256,6 +265,19 @@ class Backend:
                               else f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1))
 
     # -- norm ----------------------------------------------------------------------------------------------------
+    RECORDS_MAX = 256        # more epilogue records than this per (sample, channel) are folded to RECORDS_FOLD before finalisation
+    RECORDS_FOLD = 64
+
+    def _fold_records(self, rec, nb, c, k):
+        """(records, blocks) with at most RECORDS_MAX blocks: large layers leave thousands of per-tile records, which one workgroup
+        per (sample, group) cannot walk quickly; one extra small launch folds them in parallel (mi355_gn_records_reduce)."""
+        if nb <= self.RECORDS_MAX:
+            return rec, nb
+        out = torch.empty(rec.shape[0], self.RECORDS_FOLD, c, k, dtype=torch.float32, device=self.device)
+        check(self.lib.mi355_gn_records_reduce(rec.data_ptr(), rec.shape[0], nb, c, k, out.data_ptr(), self.RECORDS_FOLD, self.stream()),
+              "gn_records_reduce")
+        return out, self.RECORDS_FOLD
+
     def moments(self, x):
         """Standalone producer of x.mom (one streaming read of x) for tensors no conv epilogue wrote: the trilinear-upsampled
         half of a concat buffer, the network input."""

@@ -168,6 +168,10 @@ int mi355_gn_stats(const mi355_act* x, int32_t groups, float eps, const float* g
  * read; for tensors no conv epilogue produced (the network input, the trilinear-upsampled half of a concat buffer). */
 int32_t mi355_gn_moments_blocks(const mi355_act* x);
 int mi355_gn_moments(const mi355_act* x, float* out, void* stream);
+/* Folds epilogue records in[n][blocks][c][k] (k = 3: moment records, k = 2: the norm-backward sums) into out[n][out_blocks][c][k],
+ * each output record the in-order merge of a contiguous run of input records (same format, deterministic): a 128^3 layer leaves 8192
+ * records per channel, too many for the one-workgroup-per-(sample, group) finalisation kernels to walk. out_blocks <= blocks. */
+int mi355_gn_records_reduce(const float* in, int32_t n, int32_t blocks, int32_t c, int32_t k, float* out, int32_t out_blocks, void* stream);
 /* Statistics from partial moments: the channels [0, c_a) of the normalised tensor come from part_a[n][blocks_a][c_a][3] and, when
  * part_b != NULL, the channels [c_a, c_a + c_b) from part_b[n][blocks_b][c_b][3] (a concat buffer whose halves were written by two
  * producers, unet.py:42). Combined in double in a fixed order (deterministic). Outputs as mi355_gn_stats. */

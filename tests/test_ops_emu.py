@@ -275,14 +275,13 @@ def test_conv_wgrad_bf16_paths(prec_backend, kw):
     assert C.case_conv_wgrad(be, **kw) < tol
 
 
-# ---- the 8x8-column form of the plane-ring wgrad (taken when the plane has >= 32 rows): index logic on the emulator ----
+# ---- plane-ring wgrad on tall planes (>= 32 rows: many columns per workgroup, z chunks) ----
 @pytest.mark.parametrize("kw", [
-    dict(n=2, cin=32, cout=32, dhw=(3, 34, 9), norm=True),            # ragged columns in y (34 = 4 x 8 + 2) and x, two samples
-    dict(n=1, cin=64, cout=96, dhw=(2, 32, 8), norm=True, slope=0.01),  # 2 x 3 (ci, co) pairs
+    dict(n=2, cin=32, cout=32, dhw=(3, 34, 9), norm=True),            # ragged columns in y (34 = 8 x 4 + 2) and x, two samples
     dict(n=1, cin=40, cout=24, dhw=(2, 33, 17)),                      # partial channel tiles, plain input
     dict(n=1, cin=32, cout=32, dhw=(32, 32, 8), norm=True),           # columns cut into z chunks
 ])
-def test_conv_wgrad_ring_8x8_columns(emu_backend, kw):
+def test_conv_wgrad_ring_tall_planes(emu_backend, kw):
     assert C.case_conv_wgrad(emu_backend, **kw) < TOL
 
 
