@@ -80,6 +80,10 @@ SIGNATURES = {
                                       c_void_p, c_size_t, c_void_p]),
     "mi355_sw_accumulate": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                            c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "mi355_sw_gather": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                       c_void_p, c_void_p]),
+    "mi355_sw_accumulate_batch": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                                 c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "mi355_sw_normalize": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
     "mi355_postprocess": (ctypes.c_int, [c_void_p, c_int32, c_int64, c_int32, c_float, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "mi355_one_hot": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),

@@ -22,6 +22,7 @@
 // (L2/L1 resident), software-prefetched one k-step ahead.
 #include "hipcompat.h"
 #include "../../include/mi355_unet3d.h"
+#include "gn_fuse.h"
 
 struct ConvBArgs {
   const float* x; int xld;
@@ -35,6 +36,7 @@ struct ConvBArgs {
   int yD, yH, yW, offz, offy, offx;
   int pad;
   int tilesZ, tilesY, tilesX, coTiles, spatialTiles;
+  GnFuseArgs g;            // norm statistics fused into the epilogue (gn_fuse.h)
 };
 
 // lane (0..31) of an M tile -> (x-row 0/1, x position 0..15): row = which ds_read_b128 lane group the lane belongs to
@@ -70,7 +72,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[NS]) {
   }
 }
 
-template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT, int INMODE>
+// FUSE: 0 plain epilogue, 1 + moment records of the output, 2 + norm-backward sums (dgrad): as conv3d_fwd.hip
+template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT, int INMODE, int FUSE = 0>
 __global__ __launch_bounds__(256) void conv3d_k3_bf16(ConvBArgs a) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TZ * TY / 2 == WM * MT, "M tiles (2 x-rows of 16 voxels) must equal WM*MT");
@@ -236,32 +239,94 @@ __global__ __launch_bounds__(256) void conv3d_k3_bf16(ConvBArgs a) {
   }
 
   // ---- epilogue: bias, residual, dropout scale, windowed store (channel-contiguous across lanes) ----
+  if constexpr (FUSE == 0) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = wm * MT + mt;
-    const int mz = m / (TY / 2), my0 = (m % (TY / 2)) * 2;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = wm * MT + mt;
+      const int mz = m / (TY / 2), my0 = (m % (TY / 2)) * 2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;     // MFMA row = A-operand lane index
-      int rr, rtx;
-      mtile_lane(row, rr, rtx);
-      const int oz = tz0 + mz, oy = ty0 + my0 + rr, ox = tx0 + rtx;
-      if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
-      const int sz = oz + a.offz, sy = oy + a.offy, sx = ox + a.offx;
-      if (sz < 0 || sy < 0 || sx < 0 || sz >= a.yD || sy >= a.yH || sx >= a.yW) continue;
-      const size_t ovox = (((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
-      const size_t svox = (((size_t)n * a.yD + sz) * a.yH + sy) * a.yW + sx;
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;     // MFMA row = A-operand lane index
+        int rr, rtx;
+        mtile_lane(row, rr, rtx);
+        const int oz = tz0 + mz, oy = ty0 + my0 + rr, ox = tx0 + rtx;
+        if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
+        const int sz = oz + a.offz, sy = oy + a.offy, sx = ox + a.offx;
+        if (sz < 0 || sy < 0 || sx < 0 || sz >= a.yD || sy >= a.yH || sx >= a.yW) continue;
+        const size_t ovox = (((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+        const size_t svox = (((size_t)n * a.yD + sz) * a.yH + sy) * a.yW + sx;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int co = co_base + nt * 32 + li;
-        if (co >= a.Cout) continue;
-        float v = acc[mt][nt][r];
-        if (a.bias) v += a.bias[co];
-        if (a.res) v += a.res[ovox * a.resld + co];
-        if (a.out_chscale) v *= a.out_chscale[(size_t)n * a.Cout + co];
-        a.y[svox * a.yld + co] = v;
+        for (int nt = 0; nt < NT; ++nt) {
+          const int co = co_base + nt * 32 + li;
+          if (co >= a.Cout) continue;
+          float v = acc[mt][nt][r];
+          if (a.bias) v += a.bias[co];
+          if (a.res) v += a.res[ovox * a.resld + co];
+          if (a.out_chscale) v *= a.out_chscale[(size_t)n * a.Cout + co];
+          a.y[svox * a.yld + co] = v;
+        }
       }
     }
+  } else {
+    // the same epilogue + norm statistics of what it stores (gn_fuse.h; host side: un-windowed plain outputs only), one N tile at a time
+    constexpr int K = FUSE == 1 ? 3 : 2;
+    float vals[NT][K];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = co_base + nt * 32 + li;
+      const bool cov = co < a.Cout;
+      const int coc = cov ? co : a.Cout - 1;
+      float bs = 0.f, cs = 1.f;
+      if (a.bias) bs = a.bias[coc];
+      if (a.out_chscale) cs = a.out_chscale[(size_t)n * a.Cout + coc];
+      float K0 = 0.f, s0 = 0.f, s1 = 0.f, gsc = 1.f, gsh = 0.f, gmean = 0.f, grstd = 1.f;
+      int cnt = 0;
+      if constexpr (FUSE == 2) {
+        const int grp = coc / (a.Cout / a.g.ggroups);
+        gsc = a.g.gscale[(size_t)n * a.Cout + coc]; gsh = a.g.gshift[(size_t)n * a.Cout + coc];
+        gmean = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = wm * MT + mt;
+        const int mz = m / (TY / 2), my0 = (m % (TY / 2)) * 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          int rr, rtx;
+          mtile_lane(row, rr, rtx);
+          const int oz = tz0 + mz, oy = ty0 + my0 + rr, ox = tx0 + rtx;
+          if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo || !cov) continue;
+          const size_t ovox = (((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+          float v = acc[mt][nt][r] + bs;
+          if (a.res) v += a.res[ovox * a.resld + co];
+          v *= cs;
+          a.y[ovox * a.yld + co] = v;
+          if constexpr (FUSE == 1) {
+            if (cnt == 0) K0 = v;
+            const float t = v - K0;
+            s0 += t; s1 += t * t;
+          } else {
+            const float xv = a.g.gx[ovox * a.g.gxld + co];
+            const float u = xv * gsc + gsh;
+            const float du = u > 0.f ? v : v * a.g.gslope;
+            s0 += du; s1 += du * ((xv - gmean) * grstd);
+          }
+          ++cnt;
+        }
+      }
+      if constexpr (FUSE == 1) {
+        const float c = (float)cnt;
+        const float m2 = cnt > 0 ? s1 - s0 * s0 / c : 0.f;
+        vals[nt][0] = c; vals[nt][1] = s0 + c * K0; vals[nt][2] = m2 > 0.f ? m2 : 0.f;
+      } else {
+        vals[nt][0] = s0; vals[nt][1] = s1;
+      }
+    }
+    const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
+    const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
+    float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * K;
+    gn_fuse_reduce_store<K, NT, WM, WN>(vals, lds_f, wm, wn, half, li, tid, dst, cot * (32 * WN * NT), a.Cout);
   }
 }
 
@@ -330,7 +395,16 @@ static int launch_b(ConvBArgs& a, int in_mode, void* stream) {
   a.spatialTiles = a.N * a.tilesZ * a.tilesY * a.tilesX;
   const long long blocks = (long long)a.spatialTiles * a.coTiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
-  if (in_mode == MI355_IN_PLAIN)
+  if (a.g.mom && a.g.gnb) return MI355_EUNSUPPORTED;
+  if (a.g.mom) {
+    if (in_mode == MI355_IN_PLAIN)
+      LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    else
+      LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  } else if (a.g.gnb) {
+    if (in_mode != MI355_IN_PLAIN) return MI355_EUNSUPPORTED;
+    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 2>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  } else if (in_mode == MI355_IN_PLAIN)
     LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   else
     LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
@@ -351,13 +425,35 @@ static int dispatch_ns(ConvBArgs& a, int in_mode, long long vox, void* stream) {
   return launch_b<2, 4, J, NS, 4, 1, 1, 1>(a, in_mode, stream);
 }
 
+// spatial tiles (= epilogue records per sample) of the configuration dispatch_ns picks; 0: this call cannot fuse statistics
+int32_t mi355_conv3d_bf16_stats_blocks(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d) {
+  const int ns = nsplit_of(d->precision);
+  if (!ns || d->kd != 3 || d->stride != 1 || d->out_mode != MI355_OUT_PLAIN) return 0;
+  if (d->off_z || d->off_y || d->off_x || d->out_d != y->d || d->out_h != y->h || d->out_w != y->w) return 0;
+  const long long vox = (long long)y->d * y->h * y->w * x->n;
+  const bool big = ns < 3 && vox >= 256LL * 512;
+  const int tz = big ? 4 : 2, ty = 4;
+  const long long b = (long long)ceil_div(y->d, tz) * ceil_div(y->h, ty) * ceil_div(y->w, 16);
+  return b > 0 && b <= 0x7fffffffLL ? (int32_t)b : 0;
+}
+
 // called by mi355_conv3d_fwd (conv3d_fwd.hip) when desc->precision selects a bf16 path and the problem qualifies
 int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
   const int ns = nsplit_of(d->precision);
   if (!ns || d->kd != 3 || d->stride != 1) return MI355_EUNSUPPORTED;
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
-  if (d->moments_out || d->gn_bwd) return MI355_EUNSUPPORTED;        // see mi355_conv3d_bf16_stats_blocks
   ConvBArgs a;
+  memset(&a.g, 0, sizeof(a.g));
+  if (d->moments_out || d->gn_bwd) {
+    if (!mi355_conv3d_bf16_stats_blocks(x, y, d)) return MI355_EUNSUPPORTED;
+    a.g.mom = d->moments_out;
+    if (d->gn_bwd) {
+      const mi355_gn_bwd_fuse* f = d->gn_bwd;
+      if (!f->gx || !f->scale || !f->shift || !f->mean_rstd || !f->partials_out || f->groups <= 0 || y->c % f->groups || f->gx_ld < y->c) return MI355_EINVAL;
+      a.g.gnb = f->partials_out; a.g.gx = f->gx; a.g.gxld = f->gx_ld; a.g.gscale = f->scale; a.g.gshift = f->shift; a.g.gmr = f->mean_rstd;
+      a.g.ggroups = f->groups; a.g.gslope = f->act_slope;
+    }
+  }
   a.x = (const float*)x->p; a.xld = x->ld; a.wp = (const uint4*)wp; a.y = (float*)y->p; a.yld = y->ld;
   a.res = d->residual; a.resld = d->residual_ld;
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope;
@@ -371,11 +467,4 @@ int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_a
   if (ns == 1) return dispatch_ns<1>(a, d->in_mode, vox, stream);
   if (ns == 2) return dispatch_ns<2>(a, d->in_mode, vox, stream);
   return dispatch_ns<3>(a, d->in_mode, vox, stream);
-}
-
-// norm statistics fused into the epilogue (gn_fuse.h): not in the bf16-pipe kernels yet -- 0 tells the caller to run the
-// standalone statistics pass for outputs of these kernels
-int32_t mi355_conv3d_bf16_stats_blocks(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d) {
-  (void)x; (void)y; (void)d;
-  return 0;
 }

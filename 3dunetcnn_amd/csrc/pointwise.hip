@@ -383,6 +383,53 @@ __global__ void sw_normalize_kernel(float* out, const float* cnt, int C, long lo
     out[idx] = out[idx] / cnt[idx % V];
 }
 
+// ---- batched form: one gather launch builds the whole window batch, one accumulate launch folds all its predictions ----
+// starts: device int32 [nw][4] = (sample, z0, y0, x0) of every window of the batch.
+__global__ void sw_gather_kernel(const float* vol, int C, int D, int H, int W, const int* starts, int nw, int rd, int rh, int rw, float* win) {
+  const long long rv = (long long)rd * rh * rw, per = rv * C, total = per * nw;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int wi = (int)(idx / per); long long r = idx - (long long)wi * per;
+    const int c = (int)(r / rv); r -= (long long)c * rv;
+    const int x = (int)(r % rw), y = (int)((r / rw) % rh), z = (int)(r / ((long long)rw * rh));
+    const int* st = starts + 4 * wi;
+    win[idx] = vol[((((size_t)st[0] * C + c) * D + st[1] + z) * H + st[2] + y) * W + st[3] + x];
+  }
+}
+// One thread per OUTPUT voxel of the volume walks the batch's windows in order: overlapping windows of one batch are folded
+// race-free and in a fixed order (w = 0 .. nw-1), so the result is bitwise the one-launch-per-window form's.
+__global__ void sw_accumulate_batch_kernel(const float* pred, const float* w, float* out, float* cnt, int N, int C, int rd, int rh, int rw,
+                                           int D, int H, int W, const int* starts, int nw) {
+  const long long V = (long long)D * H * W, total = V * N, rv = (long long)rd * rh * rw;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(idx / V); const long long v = idx - (long long)n * V;
+    const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / ((long long)W * H));
+    for (int wi = 0; wi < nw; ++wi) {
+      const int* st = starts + 4 * wi;
+      const int lz = z - st[1], ly = y - st[2], lx = x - st[3];
+      if (st[0] != n || lz < 0 || ly < 0 || lx < 0 || lz >= rd || ly >= rh || lx >= rw) continue;
+      const long long l = ((long long)lz * rh + ly) * rw + lx;
+      const float wv = w[l];
+      cnt[idx] += wv;
+      for (int c = 0; c < C; ++c) out[((size_t)n * C + c) * V + v] += wv * pred[((size_t)wi * C + c) * rv + l];
+    }
+  }
+}
+
+extern "C" int mi355_sw_gather(const float* volume, int32_t n, int32_t c, int32_t D, int32_t H, int32_t W, const int32_t* starts, int32_t nw,
+                               int32_t rd, int32_t rh, int32_t rw, float* windows, void* stream) {
+  if (!volume || !starts || !windows || n <= 0 || c <= 0 || nw <= 0 || rd <= 0 || rh <= 0 || rw <= 0 || rd > D || rh > H || rw > W) return MI355_EINVAL;
+  LAUNCH(sw_gather_kernel, dim3(grid_for((long long)nw * c * rd * rh * rw)), dim3(256), 0, stream, volume, c, D, H, W, starts, nw, rd, rh, rw, windows);
+  return LAUNCH_CHECK();
+}
+extern "C" int mi355_sw_accumulate_batch(const float* pred, const float* importance, float* out, float* count, int32_t n, int32_t c,
+                                         int32_t rd, int32_t rh, int32_t rw, int32_t D, int32_t H, int32_t W, const int32_t* starts, int32_t nw,
+                                         void* stream) {
+  if (!pred || !importance || !out || !count || !starts || n <= 0 || c <= 0 || nw <= 0 || rd <= 0 || rh <= 0 || rw <= 0) return MI355_EINVAL;
+  LAUNCH(sw_accumulate_batch_kernel, dim3(grid_for((long long)n * D * H * W)), dim3(256), 0, stream, pred, importance, out, count, n, c, rd, rh, rw,
+         D, H, W, starts, nw);
+  return LAUNCH_CHECK();
+}
+
 extern "C" int mi355_sw_accumulate(const float* pred, const float* importance, float* out, float* count, int32_t c,
                                    int32_t rd, int32_t rh, int32_t rw, int32_t D, int32_t H, int32_t W,
                                    int32_t z0, int32_t y0, int32_t x0, void* stream) {

@@ -84,6 +84,7 @@ class GradientBucketReducer:
         self.gbuf = gbuf
         self.pending = list(self.pending_init)
         self._works = []
+        self.n_launched = 0            # bucket all-reduces launched during this backward (diagnostics / tests)
 
     def _on_ready(self, params):
         if self.world == 1 and not self.reduce_single_rank:
@@ -94,6 +95,7 @@ class GradientBucketReducer:
             if self.pending[bi] == 0:
                 a, b = self.buckets[bi]
                 view = self.gbuf[a:b]
+                self.n_launched += 1
                 backend = dist.get_backend(self.pg)
                 if self.average and backend == "nccl":
                     w = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)

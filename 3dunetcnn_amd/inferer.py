@@ -103,27 +103,30 @@ class HipSlidingWindowInferer:
         starts = _window_starts(psize, roi, _scan_interval(psize, roi, self.overlap))
         if self._w is None or tuple(self._w.shape) != tuple(roi) or self._w.device != inputs.device:
             self._w = importance_map(roi, self.mode, self.sigma_scale, inputs.device)
-        outs = []
+        # MONAI's loop: the (sample, window) pairs of the whole batch in order, `sw_batch_size` of them per network call. Per call:
+        # ONE gather launch builds the window batch from the volume, ONE accumulate launch folds its predictions (one thread per
+        # output voxel walks the windows in order: deterministic, bitwise the per-window result).
+        inputs = inputs.contiguous()
+        plan = [(n, z, y, x) for n in range(N) for (z, y, x) in starts]
+        plan_dev = torch.tensor(plan, dtype=torch.int32).to(inputs.device)       # one small H2D copy per volume batch
+        out = count = None
         with torch.no_grad():
+            for b0 in range(0, len(plan), self.sw_batch_size):
+                st = plan_dev[b0:b0 + self.sw_batch_size].contiguous()
+                win = be.sw_gather(inputs, st, roi)
+                pred = network(win, *args, **kwargs)
+                if isinstance(pred, (tuple, list)):
+                    pred = pred[0]
+                pred = pred.float().contiguous()
+                if tuple(pred.shape[2:]) != tuple(roi):
+                    raise NotImplementedError("networks that change the spatial size are not supported by HipSlidingWindowInferer")
+                if out is None:
+                    out = torch.zeros(N, pred.shape[1], *psize, dtype=torch.float32, device=inputs.device)
+                    count = torch.zeros(N, *psize, dtype=torch.float32, device=inputs.device)
+                be.sw_accumulate_batch(pred, self._w, out, count, st)
             for n in range(N):
-                out = count = None
-                for b0 in range(0, len(starts), self.sw_batch_size):
-                    batch = starts[b0:b0 + self.sw_batch_size]
-                    win = torch.stack([inputs[n, :, z:z + roi[0], y:y + roi[1], x:x + roi[2]] for z, y, x in batch]).contiguous()
-                    pred = network(win, *args, **kwargs)
-                    if isinstance(pred, (tuple, list)):
-                        pred = pred[0]
-                    pred = pred.float().contiguous()
-                    if tuple(pred.shape[2:]) != tuple(roi):
-                        raise NotImplementedError("networks that change the spatial size are not supported by HipSlidingWindowInferer")
-                    if out is None:
-                        out = torch.zeros(pred.shape[1], *psize, dtype=torch.float32, device=inputs.device)
-                        count = torch.zeros(*psize, dtype=torch.float32, device=inputs.device)
-                    for i, st in enumerate(batch):
-                        be.sw_accumulate(pred[i], self._w, out, count, st)
-                be.sw_normalize(out, count)
-                outs.append(out)
-        res = torch.stack(outs)
+                be.sw_normalize(out[n], count[n])
+        res = out
         if any(p[0] or p[1] for p in pads):
             res = res[:, :, pads[0][0]:pads[0][0] + image_size[0], pads[1][0]:pads[1][0] + image_size[1],
                       pads[2][0]:pads[2][0] + image_size[2]].contiguous()

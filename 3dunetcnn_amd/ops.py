@@ -373,6 +373,23 @@ class Backend:
         check(self.lib.mi355_sw_accumulate(pred.data_ptr(), importance.data_ptr(), out.data_ptr(), count.data_ptr(), c, rd, rh, rw,
                                            D, H, W, int(start[0]), int(start[1]), int(start[2]), self.stream()), "sw_accumulate")
 
+    def sw_gather(self, volume, starts, roi):
+        """volume [N, C, D, H, W]; starts: device int32 [nw, 4] = (sample, z0, y0, x0). Returns the window batch [nw, C, *roi]."""
+        assert volume.is_contiguous() and volume.dtype == torch.float32 and starts.dtype == torch.int32 and starts.is_contiguous()
+        n, c, D, H, W = volume.shape
+        nw = starts.shape[0]
+        win = torch.empty(nw, c, *roi, dtype=torch.float32, device=volume.device)
+        check(self.lib.mi355_sw_gather(volume.data_ptr(), n, c, D, H, W, starts.data_ptr(), nw, roi[0], roi[1], roi[2], win.data_ptr(),
+                                       self.stream()), "sw_gather")
+        return win
+
+    def sw_accumulate_batch(self, pred, importance, out, count, starts):
+        """pred [nw, C, *roi], importance [*roi], out [N, C, D, H, W], count [N, D, H, W], starts device int32 [nw, 4]."""
+        nw, c, rd, rh, rw = pred.shape
+        n, _, D, H, W = out.shape
+        check(self.lib.mi355_sw_accumulate_batch(pred.data_ptr(), importance.data_ptr(), out.data_ptr(), count.data_ptr(), n, c, rd, rh, rw,
+                                                 D, H, W, starts.data_ptr(), nw, self.stream()), "sw_accumulate_batch")
+
     def sw_normalize(self, out, count):
         check(self.lib.mi355_sw_normalize(out.data_ptr(), count.data_ptr(), out.shape[0], count.numel(), self.stream()), "sw_normalize")
 

@@ -106,23 +106,39 @@ def self_launch(n):
     return rc
 
 
+PMC_FILE = os.path.join("profiles", "r2_bench_fp32_hbm_traffic_pmc.csv")
+
+
 def pmc_traffic(kernel_name, precision):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md 'HBM'). PMC collection needs rocprofv3 around the process, so bench.py reads the summary."""
-    path = os.path.join(ROOT, "profiles", "r1_bench_fp32_hbm_traffic_pmc.csv")
+    MI355X_MICROARCH.md 'HBM'). PMC collection needs rocprofv3 around the process, so bench.py reads the summary -- but only one
+    collected from THESE kernels: the file's first line records the sha256 of the kernel sources it was measured on
+    (tools/pmc_summary.py), and a file from other sources is refused (traffic -> null, the reason in traffic_source)."""
+    path = os.path.join(ROOT, PMC_FILE)
     if precision != "fp32" or not os.path.exists(path):
         return None, None
     import csv
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_summary import kernel_source_hash
+    lines = open(path).read().splitlines()
+    recorded = None
+    if lines and lines[0].startswith("#"):
+        for tok in lines[0].split():
+            if tok.startswith("kernel_source_sha256="):
+                recorded = tok.split("=", 1)[1]
+        lines = lines[1:]
+    if recorded != kernel_source_hash():
+        return None, f"{PMC_FILE} is stale (collected from kernel sources {str(recorded)[:12]}, tree has {kernel_source_hash()[:12]}): re-run tools/gpu_profile.sh <tag> pmc"
     key = kernel_name.split(" (")[0].split("<")[0]
     best = None
-    for r in csv.DictReader(open(path)):
+    for r in csv.DictReader(lines):
         if key in r["Kernel"] and (best is None or int(r["Calls"]) > int(best["Calls"])):
             best = r
     if best is None:
         return None, None
     mib = float(best["fetch_x2_MiB_per_launch"]) + float(best["WRITE_SIZE_MiB_per_launch"])
-    return round(mib * 1048576), "profiles/r1_bench_fp32_hbm_traffic_pmc.csv (FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
+    return round(mib * 1048576), f"{PMC_FILE} (FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
 
 
 def cpu_baseline(size):
@@ -260,8 +276,31 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    prof, be.prof = be.prof, None
+    prof_timed, be.prof = be.prof, None
     loss_val = float(loss.item())
+    # Roofline pass. The timed region runs the weight-gradient kernels on a second stream (engine.py: backward_side_stream), where a
+    # launch shares the chip with the dgrad chain and its HIP-event duration is not its own. The kernel's rate is therefore measured
+    # on ROOF_STEPS extra steps right after the timed region with that overlap switched off (one stream, every launch alone);
+    # `value` / `ms_per_step` never include these steps. MI355_SIDE_STREAM=0 makes the timed region itself serialized (that is the
+    # command the committed rocprofv3 summary in profiles/ was taken with).
+    prof = prof_timed
+    roof_note = "HIP events over the timed region"
+    ROOF_STEPS = 3
+    if prof_timed is not None and getattr(model, "backward_side_stream", False) and dev.type == "cuda":
+        model.backward_side_stream = False
+        step()
+        barrier()
+        be.prof = []
+        t1 = time.perf_counter()
+        for _ in range(ROOF_STEPS):
+            step()
+        barrier()
+        serial_ms = (time.perf_counter() - t1) / ROOF_STEPS * 1e3
+        prof, be.prof = be.prof, None
+        model.backward_side_stream = True
+        roof_note = (f"HIP events over {ROOF_STEPS} serialized steps run right after the timed region (weight gradients on the launch stream: "
+                     f"{serial_ms:.2f} ms/step; the timed region overlaps them with the dgrad chain on a second stream, where a launch's "
+                     "duration is not its own)")
 
     per_rank = [dt]
     if world > 1:
@@ -286,13 +325,13 @@ def main():
         peak = BF16_MFMA_PEAK_TFLOPS if on_bf16 else FP32_MFMA_PEAK_TFLOPS
         products = {"bf16x3": 3, "bf16x6": 6, "bf16": 1}.get(args.precision, 1) if on_bf16 else 1
         traffic, traffic_src = pmc_traffic(name, args.precision)
-        roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+        roofline = {"bound": "mfma", "kernel": name, "measured": roof_note, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(by / cnt),
                     "mfma_products_per_mac": products, "mfma_pipe_frac": round(ach * products / peak, 4),
                     "launches": cnt, "avg_launch_ms": round(secs / cnt * 1e3, 4),
                     "hbm_gbps_algorithmic": round(by / secs / 1e9, 1), "hbm_frac": round(by / secs / 1e9 / HBM_PEAK_GBPS, 4),
-                    "share_of_step": round(secs / dt, 4),
+                    "share_of_step": round(secs / (ROOF_STEPS if prof is not prof_timed else args.steps) / (dt / args.steps), 4),
                     "all_kernels": {k: {"s": round(v[0], 5), "tflops": round(v[1] / v[0] / 1e12, 2), "launches": v[3]}
                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
 

@@ -235,6 +235,16 @@ int mi355_proj_bwd(const mi355_act* x, const float* in_scale, const float* in_sh
 int mi355_sw_accumulate(const float* pred, const float* importance, float* out, float* count, int32_t c,
                         int32_t rd, int32_t rh, int32_t rw, int32_t D, int32_t H, int32_t W,
                         int32_t z0, int32_t y0, int32_t x0, void* stream);
+/* Batched form (one launch per window BATCH instead of per window): starts = device int32 [nw][4] = (sample, z0, y0, x0).
+ * mi355_sw_gather: windows[w][c][rd][rh][rw] = volume[sample_w][c][z0_w + z][y0_w + y][x0_w + x] (volume: [n][c][D][H][W]) -- the
+ * `sw_batch_size` network inputs of MONAI's loop in one pass. mi355_sw_accumulate_batch: folds the nw predictions pred[w][c][...]
+ * into out [n][c][D][H][W] / count [n][D][H][W]: one thread per output voxel walks the windows in order, so overlapping windows of a
+ * batch are race-free and the sums are bitwise those of nw sequential mi355_sw_accumulate calls. */
+int mi355_sw_gather(const float* volume, int32_t n, int32_t c, int32_t D, int32_t H, int32_t W, const int32_t* starts, int32_t nw,
+                    int32_t rd, int32_t rh, int32_t rw, float* windows, void* stream);
+int mi355_sw_accumulate_batch(const float* pred, const float* importance, float* out, float* count, int32_t n, int32_t c,
+                              int32_t rd, int32_t rh, int32_t rw, int32_t D, int32_t H, int32_t W, const int32_t* starts, int32_t nw,
+                              void* stream);
 /* out[c][v] /= count[v] (final normalisation by the accumulated importance). */
 int mi355_sw_normalize(float* out, const float* count, int32_t c, int64_t voxels, void* stream);
 

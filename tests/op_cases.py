@@ -40,22 +40,32 @@ def grad_parity(grads, g32, g64, floor, tol=TOL, kappa=KAPPA, perturbed=()):
     floor was measured from: agreeing with any of them to `tol` passes too (a single ReLU tie puts the kernel exactly on the
     branch some of those evaluations take). Returns dict(ratio=worst error/allowance (<= 1 passes), ...)."""
     worst = dict(ratio=0.0, key=None)
-    n_ill = 0
+    n_ill = n_loose = 0
     max32 = 0.0
     for k, g in grads.items():
         e32, e64 = rel_err(g, g32[k]), rel_err(g, g64[k])
         allow64 = max(tol, kappa * floor[k])
         max32 = max(max32, e32)
         n_ill += kappa * floor[k] > tol
+        n_loose += e32 > tol              # tensors that do NOT meet the tolerance against the fp32 oracle directly (they need a loose leg)
         r = min(e32 / tol, e64 / allow64)
         for gp in perturbed:
             if r > 1.0:
                 r = min(r, rel_err(g, gp[k]) / tol)
         if r > worst["ratio"]:
             worst = dict(ratio=r, key=k, err_vs_fp32=e32, err_vs_fp64=e64, noise_floor=floor[k])
-    worst["n_ill_conditioned"] = n_ill
+    worst["n_ill_conditioned"] = n_ill      # a property of the problem (oracle-side conditioning), not of the kernels
+    worst["n_loose"] = n_loose
     worst["max_err_vs_fp32"] = max32
     return worst
+
+
+def assert_recorded(e, bounds):
+    """Whole-network parity diagnostics against bounds recorded on MI355X: `grad` (worst error / allowance, <= 1 passes) must keep
+    clear of its limit, the number of tensors that need a loose leg (`n_loose`) and the worst error against the fp32 oracle must not
+    grow -- so a regression that pushes well-conditioned tensors onto the loose legs fails even though every tensor still 'passes'."""
+    for k, b in bounds.items():
+        assert e[k] <= b, (k, e[k], "recorded bound", b, e)
 
 
 def to_act(be, t, ld=None, c0=0):
@@ -270,7 +280,7 @@ def case_gn(be, n, c, dhw, groups, slope=0.0, ld=None, seed=3, offset=0.4):
 
 
 def case_conv_moments(be, n, cin, cout, dhw, stride=1, norm=True, residual=False, chscale=False, groups_out=None, yld=None, yc0=0,
-                      expect_fused=True, seed=13):
+                      expect_fused=True, seed=13, ytol=TOL, strict_vs_oracle=True):
     """Norm statistics of a conv OUTPUT taken from the moment records its epilogue wrote (csrc/gn_fuse.h; myronenko.py:17-21:
     every conv output is the next block's GroupNorm input) against the statistics of the oracle's conv output, and against the
     standalone statistics pass over the same device tensor. Returns the worst relative error of (mean, rstd, scale, shift)."""
@@ -295,7 +305,7 @@ def case_conv_moments(be, n, cin, cout, dhw, stride=1, norm=True, residual=False
     ya = to_act(be, torch.zeros(n, cout, od, oh, ow), yld, yc0)
     be.conv_fwd(xa, be.pack_weight(dev(be, wt), 0), ya, 3, stride, 1, residual=to_act(be, res) if residual else None, chscale=dev(be, cs),
                 moments=True, **kw)
-    assert rel_err(from_act(ya), ref) < TOL
+    assert rel_err(from_act(ya), ref) < ytol
     assert (ya.mom is not None) == expect_fused, "fused statistics expected" if expect_fused else "fallback expected"
     go = groups_out or (8 if cout >= 8 and cout % 8 == 0 else cout)
     g2 = torch.rand(cout, generator=g) + 0.5
@@ -307,6 +317,9 @@ def case_conv_moments(be, n, cin, cout, dhw, stride=1, norm=True, residual=False
     sc_ref = g2.double()[None] * rstd_ref.repeat_interleave(cpg, 1)
     sh_ref = b2.double()[None] - mean_ref.repeat_interleave(cpg, 1) * sc_ref
     e = max(rel_err(mr[..., 0], mean_ref), rel_err(mr[..., 1], rstd_ref), rel_err(sc, sc_ref), rel_err(sh, sh_ref))
+    if not strict_vs_oracle:      # reduced-precision conv arithmetic: the statistics are those of the stored tensor, checked below
+        assert e < 10 * ytol
+        e = 0.0
     # cross-check: the standalone pass over the same device tensor
     saved, ya.mom = ya.mom, None
     mr2, sc2, sh2 = be.gn_stats(ya, go, 1e-5, dev(be, g2), dev(be, b2))
@@ -340,7 +353,7 @@ def case_cat_moments(be, n, c_up, c_skip, dhw, seed=14):
     return max(rel_err(mr[..., 0], mean_ref), rel_err(mr[..., 1], rstd_ref))
 
 
-def case_gn_bwd_fused(be, n, cin, cout, dhw, groups=None, slope=0.0, expect_fused=True, seed=15):
+def case_gn_bwd_fused(be, n, cin, cout, dhw, groups=None, slope=0.0, expect_fused=True, seed=15, compare_unfused=False):
     """act(GroupNorm) backward where the first pass (sum du, sum du*xhat) leaves with the epilogue of the dgrad conv that produces
     dA (csrc/gn_fuse.h): dx / dgamma / dbeta against double-precision autograd of conv(act(norm(x)))."""
     g = torch.Generator().manual_seed(seed)
@@ -359,7 +372,14 @@ def case_gn_bwd_fused(be, n, cin, cout, dhw, groups=None, slope=0.0, expect_fuse
     parts = be.conv_fwd(to_act(be, dy), be.pack_weight(dev(be, wt.float()), 1), dA, 3, 1, 1, gnb=(xa, st, groups, slope))
     assert (parts is not None) == expect_fused
     dgam, dbet = torch.empty(cin, device=be.device), torch.empty(cin, device=be.device)
+    dA_raw = dA.tensor().clone()
     be.gn_act_bwd(xa, dA, dA, groups, slope, dev(be, gamma.detach().float()), st[0], st[1], st[2], dgam, dbet, partials=parts)
+    if compare_unfused:
+        # reduced-precision conv arithmetic: compare with the unfused norm backward applied to the SAME dA (the sums' own accuracy)
+        dA2 = Act(dA_raw.contiguous(), 0, cin)
+        dg2, db2 = torch.empty(cin, device=be.device), torch.empty(cin, device=be.device)
+        be.gn_act_bwd(xa, dA2, dA2, groups, slope, dev(be, gamma.detach().float()), st[0], st[1], st[2], dg2, db2)
+        return dict(dx=rel_err(from_act(dA), from_act(dA2)), dgamma=rel_err(dgam, dg2.cpu()), dbeta=rel_err(dbet, db2.cpu()))
     return dict(dx=rel_err(from_act(dA), dx_ref), dgamma=rel_err(dgam, dg_ref), dbeta=rel_err(dbet, db_ref))
 
 

@@ -36,11 +36,29 @@ def test_cpu_baseline_leg_reports_the_contract_fields():
     assert "32^3" in r["sample"]
 
 
-def test_pmc_traffic_lookup_reads_the_committed_profile():
+def test_pmc_traffic_lookup_checks_provenance(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed rocprofv3 PMC summary -- but only from one collected on THESE kernel sources: the
+    summary's first line records their sha256 (tools/pmc_summary.py) and bench.py refuses a stale file instead of quoting it."""
     b = _bench()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_summary import kernel_source_hash
+    body = ('Kernel,Calls,FETCH_SIZE_MiB_per_launch,WRITE_SIZE_MiB_per_launch,fetch_x2_MiB_per_launch,avg_ms_under_pmc\n'
+            '"void conv3d_wgrad_ring<1, 4>(WgradArgs)",50,172.51,54.00,345.02,1.0628\n')
+    good = tmp_path / "good.csv"
+    good.write_text(f"# provenance: git_sha=abc kernel_source_sha256={kernel_source_hash()}\n" + body)
+    monkeypatch.setattr(b, "PMC_FILE", str(good))
     traffic, src = b.pmc_traffic("conv3d_wgrad_ring (+reduce)", "fp32")
-    assert isinstance(traffic, int) and traffic > 100 << 20 and "profiles/" in src
+    assert traffic == round((345.02 + 54.00) * 1048576) and "FETCH_SIZE x2" in src
     assert b.pmc_traffic("conv3d_wgrad_ring (+reduce)", "bf16") == (None, None)
+    stale = tmp_path / "stale.csv"
+    stale.write_text("# provenance: git_sha=abc kernel_source_sha256=0000\n" + body)
+    monkeypatch.setattr(b, "PMC_FILE", str(stale))
+    traffic, src = b.pmc_traffic("conv3d_wgrad_ring (+reduce)", "fp32")
+    assert traffic is None and "stale" in src
+    old = tmp_path / "old.csv"
+    old.write_text(body)                                  # a round-1 style file without provenance
+    monkeypatch.setattr(b, "PMC_FILE", str(old))
+    assert b.pmc_traffic("conv3d_wgrad_ring (+reduce)", "fp32")[0] is None
 
 
 def test_committed_bench_line_has_the_contract_shape():

@@ -109,14 +109,23 @@ def test_emulated_dynunet_fwd_bwd(emu_backend):
     assert e["max_err_vs_fp32"] < TOL, e         # this small case is well conditioned: plain 1e-3 on every gradient
 
 
+# Recorded on MI355X (round 2; `pytest -s` prints the dictionaries): grad = worst error / allowance (<= 1 passes), max_err_vs_fp32 =
+# worst error against the fp32 oracle over all tensors (the ill-conditioned ones sit at their noise floor: InstanceNorm over 8
+# voxels at the 2^3 bottleneck of the BraTS configuration), n_loose = tensors that need the fp64 / perturbed-oracle legs.
+#   5 levels 32^3: grad 0.084, max_err 6.8e-3 | 3 levels 16x24x32 batch 2: 0.110, 4.1e-3 | BraTS config 64^3: 0.122, 0.166
+RECORDED = {"five": dict(grad=0.5, n_loose=24, max_err_vs_fp32=3e-2, logits=5e-5), "three": dict(grad=0.5, n_loose=12, max_err_vs_fp32=2e-2, logits=5e-5),
+            "brats": dict(grad=0.5, n_loose=36, max_err_vs_fp32=0.5, logits=5e-5)}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("filters,dhw,n", [([64, 96, 128, 192, 256], (32, 32, 32), 1), ([32, 64, 96], (16, 24, 32), 2)])
-def test_dynunet_fwd_bwd_gpu(filters, dhw, n):
+@pytest.mark.parametrize("filters,dhw,n,rec", [([64, 96, 128, 192, 256], (32, 32, 32), 1, "five"), ([32, 64, 96], (16, 24, 32), 2, "three")])
+def test_dynunet_fwd_bwd_gpu(filters, dhw, n, rec):
     torch.manual_seed(1234)
     m = dyn.HipDynUNet(**_kw(filters)).cuda().eval()
     e = _pair(m, None, dhw, n, "cuda")
     print(e)
     assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] <= 1.0, e
+    C.assert_recorded(e, RECORDED[rec])
 
 
 @pytest.mark.gpu
@@ -127,6 +136,7 @@ def test_dynunet_brats_config_64cube():
     e = _pair(m, None, (64, 64, 64), 1, "cuda")
     print(e)
     assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] <= 1.0, e
+    C.assert_recorded(e, RECORDED["brats"])
 
 
 @pytest.mark.gpu

@@ -1,0 +1,159 @@
+"""Hand-worked known answers (tests/golden/handworked.json, derivations in tests/golden/make_handworked.py) for the MONAI-side pieces
+that cannot be pinned against MONAI itself: Dice / GeneralizedDice incl. an empty class, the sliding-window plan + Gaussian
+importance map + a closed-form weighted average, and a two-level DynUNet with integer weights. The numbers come from scalar Python
+arithmetic written from the published definitions, independently of oracle/ and of the kernels; here the ORACLE restatements and the
+HIP kernels (emulator on CPU, the device under -m gpu) are both held to them."""
+import importlib
+import json
+import math
+import os
+
+import pytest
+import torch
+
+from oracle import dynunet_ref as D
+from oracle import sliding_window_ref as S
+from oracle import torch_ops as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FX = json.load(open(os.path.join(HERE, "golden", "handworked.json")))
+losses = importlib.import_module("3dunetcnn_amd.losses")
+inferer = importlib.import_module("3dunetcnn_amd.inferer")
+dyn = importlib.import_module("3dunetcnn_amd.dynunet")
+
+
+def _dice_tensors(two, dtype=torch.float32):
+    d = FX["dice"]
+    lg = torch.tensor(d["logits2" if two else "logits"], dtype=dtype)
+    tg = torch.tensor(d["target2" if two else "target"], dtype=torch.uint8)
+    n = lg.shape[0]
+    return lg.reshape(n, 2, 1, 2, 2), tg.reshape(n, 2, 1, 2, 2)
+
+
+DICE_CASES = [("dice", False, {}), ("dice_squared_pred", False, dict(squared_pred=True)), ("dice_two_samples", True, {}),
+              ("dice_two_samples_batch", True, dict(batch=True))]
+
+
+def test_fixture_matches_its_closed_forms():
+    d = FX["dice"]
+    assert abs(d["dice"] - 0.5 * ((1 - 2.50001 / 4.00001) + (1 - 1e-5 / 1.00001))) < 1e-15
+    assert abs(d["gdl"] - (1 - 0.62501 / 1.25001)) < 1e-15
+    w = FX["window"]
+    assert w["starts"]["20/8/0.25"] == [0, 6, 12] and w["starts"]["240/128/0.5"] == [0, 64, 112] and w["starts"]["155/128/0.5"] == [0, 27]
+    assert all(abs(a - b) < 1e-15 for a, b in zip(w["gauss_roi8"], w["gauss_roi8_closed_form"]))
+    assert abs(w["ramp_inference"]["out_of_z"][7] - (7 + 100 / (1 + math.exp(-3)))) < 1e-12
+
+
+@pytest.mark.parametrize("key,two,kw", DICE_CASES)
+def test_oracle_dice_matches_hand_values(key, two, kw):
+    lg, tg = _dice_tensors(two, torch.float64)
+    assert abs(float(O.dice_loss(lg, tg, **kw)) - FX["dice"][key]) < 1e-12
+
+
+def test_oracle_generalized_dice_matches_hand_values():
+    for key, two in (("gdl", False), ("gdl_two_samples", True)):
+        lg, tg = _dice_tensors(two, torch.float64)
+        assert abs(float(O.generalized_dice_loss(lg, tg)) - FX["dice"][key]) < 1e-12
+
+
+def _hip_losses(be, dev):
+    for key, two, kw in DICE_CASES:
+        lg, tg = _dice_tensors(two)
+        crit = losses.HipDiceLoss(sigmoid=True, **kw)
+        crit._be = be
+        assert abs(float(crit(lg.to(dev), tg.to(dev))) - FX["dice"][key]) < 2e-6, key
+    for key, two in (("gdl", False), ("gdl_two_samples", True)):
+        lg, tg = _dice_tensors(two)
+        crit = losses.HipGeneralizedDiceLoss(sigmoid=True)
+        crit._be = be
+        assert abs(float(crit(lg.to(dev), tg.to(dev))) - FX["dice"][key]) < 2e-6, key
+
+
+def test_hip_losses_match_hand_values_on_emulator(emu_backend):
+    _hip_losses(emu_backend, "cpu")
+
+
+@pytest.mark.gpu
+def test_hip_losses_match_hand_values_on_gpu(hip_backend):
+    _hip_losses(None, "cuda")
+
+
+def test_window_plan_and_importance_map_match_hand_values():
+    w = FX["window"]
+    for key, want in w["starts"].items():
+        size, roi, ov = key.split("/")
+        size, roi, ov = int(size), int(roi), float(ov)
+        got_o = sorted({s[0] for s in S.dense_patch_starts([size, roi, roi], [roi] * 3, S.scan_interval([size, roi, roi], [roi] * 3, ov))})
+        got_h = sorted({s[0] for s in inferer._window_starts([size, roi, roi], [roi] * 3, inferer._scan_interval([size, roi, roi], [roi] * 3, (ov,) * 3))})
+        assert got_o == want and got_h == want, key
+    g = torch.tensor(w["gauss_roi8"], dtype=torch.float64)
+    want3 = g[:, None, None] * g[None, :, None] * g[None, None, :]
+    want3 = torch.clamp(want3 / want3.max(), min=1e-3)
+    assert float((S.gaussian_importance([8, 8, 8]).double() - want3).abs().max()) < 1e-7
+    assert float((inferer.importance_map([8, 8, 8], "gaussian", 0.125, "cpu").double() - want3).abs().max()) < 1e-7
+
+
+def _ramp_inference(be, dev):
+    r = FX["window"]["ramp_inference"]
+    vol = torch.arange(20, dtype=torch.float32)[None, None, :, None, None].expand(1, 1, 20, 8, 8).contiguous()
+    calls = []
+
+    def predictor(win):
+        # the k-th window of the plan gets + 100 k (windows arrive in plan order, sw_batch_size of them per call)
+        k0 = sum(calls)
+        calls.append(win.shape[0])
+        off = torch.arange(k0, k0 + win.shape[0], dtype=win.dtype, device=win.device)[:, None, None, None, None]
+        return win + 100.0 * off
+    inf = inferer.HipSlidingWindowInferer(r["roi"], sw_batch_size=2, overlap=r["overlap"], mode="gaussian")
+    inf._be = be
+    got = inf(vol.to(dev), predictor).cpu()
+    calls.clear()
+    ref = S.sliding_window_inference(vol, r["roi"], 2, predictor, r["overlap"], "gaussian")
+    # in-plane centre (clamp of the importance map inactive: closed form), corner (every weight clamped: plain average), and one
+    # voxel off the centre line (the clamp bites only the window tails) -- fp32 weights, values ~ 100
+    for key, (y, x) in (("out_of_z", (3, 3)), ("out_of_z_corner", (0, 0)), ("out_of_z_y3x5", (3, 5))):
+        want = torch.tensor(r[key], dtype=torch.float64)
+        assert float((got[0, 0, :, y, x].double() - want).abs().max()) < 2e-4, key
+        assert float((ref[0, 0, :, y, x].double() - want).abs().max()) < 2e-4, key
+    assert abs(r["out_of_z_corner"][7] - 57.0) < 1e-12
+
+
+def test_ramp_inference_matches_hand_values_on_emulator(emu_backend):
+    _ramp_inference(emu_backend, "cpu")
+
+
+@pytest.mark.gpu
+def test_ramp_inference_matches_hand_values_on_gpu(hip_backend):
+    _ramp_inference(None, "cuda")
+
+
+def _dynunet_fixture():
+    f = FX["dynunet"]
+    sd = {k: torch.tensor(v, dtype=torch.float32) for k, v in f["state_dict"].items()}
+    return f, sd, torch.tensor(f["x"], dtype=torch.float32), torch.tensor(f["logits"], dtype=torch.float64)
+
+
+def test_oracle_dynunet_matches_hand_values():
+    f, sd, x, want = _dynunet_fixture()
+    got = D.dynunet_forward({k: v.double() for k, v in sd.items()}, x.double(), 2)
+    assert got.shape == want.shape and float((got - want).abs().max() / want.abs().max()) < 1e-10
+
+
+def _hip_dynunet(be, dev):
+    f, sd, x, want = _dynunet_fixture()
+    m = dyn.HipDynUNet(**f["kwargs"]).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev)
+    m._be = be
+    with torch.no_grad():
+        got = m(x.to(dev)).cpu().double()
+    assert got.shape == want.shape and float((got - want).abs().max() / want.abs().max()) < 1e-4
+
+
+def test_hip_dynunet_matches_hand_values_on_emulator(emu_backend):
+    _hip_dynunet(emu_backend, "cpu")
+
+
+@pytest.mark.gpu
+def test_hip_dynunet_matches_hand_values_on_gpu(hip_backend):
+    _hip_dynunet(None, "cuda")

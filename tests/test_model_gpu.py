@@ -49,11 +49,30 @@ def _run_pair(kw, enc, dhw, n, tc=False, seed=1234):
     return errs
 
 
-@pytest.mark.parametrize("dhw,n", [((32, 32, 32), 2), ((30, 31, 29), 1)])
-def test_unet3d_default_fwd_bwd(dhw, n):
+# Recorded on MI355X (round 2, exact-fp32 kernels, fused norm statistics; `pytest -s` prints the dictionaries):
+#   config                 grad (err/allowance)  n_loose  max_err_vs_fp32   logits
+#   32^3 batch 2           0.0014                0        5.2e-5            1.2e-6
+#   30x31x29               0.0014                (>0)     8.6e-3            1.2e-6      one ReLU-tie family, see DESIGN.md section 4
+#   64^3 (configs[0])      0.099                 (>0)     2.4e-3            1.4e-6
+#   transposed convs 32^3  0.0008                0        1.9e-4            1.4e-6
+#   five levels 32x48x32   0.0013                0        4.5e-6            8.0e-7
+# The asserted bounds leave a factor ~3-5 for summation-order changes; `n_loose` is the count of tensors that miss 1e-3 against the
+# fp32 oracle directly and therefore rely on the fp64 / perturbed-oracle legs of op_cases.grad_parity.
+RECORDED = {
+    "32": dict(grad=0.02, n_loose=0, max_err_vs_fp32=3e-4, logits=2e-5),
+    "odd": dict(grad=0.02, n_loose=8, max_err_vs_fp32=3e-2, logits=2e-5),
+    "64": dict(grad=0.5, n_loose=12, max_err_vs_fp32=1e-2, logits=2e-5),
+    "tc": dict(grad=0.02, n_loose=0, max_err_vs_fp32=1e-3, logits=2e-5),
+    "five": dict(grad=0.02, n_loose=0, max_err_vs_fp32=5e-5, logits=2e-5),
+}
+
+
+@pytest.mark.parametrize("dhw,n,rec", [((32, 32, 32), 2, "32"), ((30, 31, 29), 1, "odd")])
+def test_unet3d_default_fwd_bwd(dhw, n, rec):
     e = _run_pair(dict(n_features=4, n_outputs=3), (1, 2, 2, 4), dhw, n)
     print(e)
     assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] <= 1.0, e
+    C.assert_recorded(e, RECORDED[rec])
 
 
 def test_unet3d_default_fwd_bwd_64cube():
@@ -61,12 +80,14 @@ def test_unet3d_default_fwd_bwd_64cube():
     e = _run_pair(dict(n_features=4, n_outputs=3), (1, 2, 2, 4), (64, 64, 64), 1)
     print(e)
     assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] <= 1.0, e
+    C.assert_recorded(e, RECORDED["64"])
 
 
 def test_unet3d_transposed_conv_variant():
     e = _run_pair(dict(n_features=4, n_outputs=3, use_transposed_convolutions=True), (1, 2, 2, 4), (32, 32, 32), 1, tc=True)
     print(e)
     assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] <= 1.0, e
+    C.assert_recorded(e, RECORDED["tc"])
 
 
 def test_unet3d_five_levels():
@@ -74,6 +95,7 @@ def test_unet3d_five_levels():
     e = _run_pair(dict(n_features=4, n_outputs=3, encoder_blocks=[1, 2, 2, 2, 4]), (1, 2, 2, 2, 4), (32, 48, 32), 1)
     print(e)
     assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] <= 1.0, e
+    C.assert_recorded(e, RECORDED["five"])
 
 
 def test_training_steps_match_torch_adam():
@@ -170,8 +192,8 @@ def test_bucketed_allreduce_over_rccl_single_rank():
         opt.zero_grad(set_to_none=True)
         loss = crit(m(x.cuda()), y.cuda())
         loss.backward()
-        assert len(red._works) == len(red.buckets) >= 3          # every bucket was reduced, launched during backward
-        red.wait()
+        assert red.n_launched == len(red.buckets) >= 3           # every bucket was reduced, launched during backward
+        assert red._works == []                                  # ... and joined by the engine at the end of backward (no reducer.wait())
         lref = O.dice_loss(R.unet3d_forward(sd, x, (1, 1, 2)), y)
         lref.backward()
         for k, p in m.named_parameters():

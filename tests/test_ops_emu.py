@@ -275,6 +275,23 @@ def test_conv_wgrad_bf16_paths(prec_backend, kw):
     assert C.case_conv_wgrad(be, **kw) < tol
 
 
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=32, cout=32, dhw=(3, 5, 19), residual=True, chscale=True),     # ragged 2x4x16 tiles
+    dict(n=1, cin=16, cout=64, dhw=(4, 4, 16), yld=128, yc0=32),                 # 2x2 wave grid, concat slice
+    dict(n=2, cin=16, cout=40, dhw=(2, 6, 9), groups_out=40),                    # partial channel tile, InstanceNorm groups
+])
+def test_conv_epilogue_moments_bf16_paths(prec_backend, kw):
+    be, tol = prec_backend
+    assert C.case_conv_moments(be, ytol=tol, strict_vs_oracle=False, **kw) < 2e-5
+
+
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(3, 5, 19)), dict(n=2, cin=64, cout=16, dhw=(4, 4, 16), slope=0.01)])
+def test_norm_backward_sums_from_dgrad_epilogue_bf16_paths(prec_backend, kw):
+    be, tol = prec_backend
+    r = C.case_gn_bwd_fused(be, compare_unfused=True, **kw)
+    assert all(v < 2e-5 for v in r.values()), r
+
+
 # ---- plane-ring wgrad on tall planes (>= 32 rows: many columns per workgroup, z chunks) ----
 @pytest.mark.parametrize("kw", [
     dict(n=2, cin=32, cout=32, dhw=(3, 34, 9), norm=True),            # ragged columns in y (34 = 8 x 4 + 2) and x, two samples

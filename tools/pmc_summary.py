@@ -7,8 +7,24 @@ gfx950 counts 128-B requests as 64 B for wide coalesced reads: the `fetch_x2` co
 uncalibrated and reported as is.
 """
 import csv
+import hashlib
+import os
+import subprocess
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, in name order): bench.py refuses a traffic file collected from other kernels."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "3dunetcnn_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def load(path):
@@ -30,6 +46,11 @@ def main(paths):
     for t in tables.values():
         names |= set(t)
     cols = sorted(tables)
+    try:
+        sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
+    except OSError:
+        sha = "unknown"
+    print(f"# provenance: git_sha={os.environ.get('MI355_GIT_SHA', sha)} kernel_source_sha256={kernel_source_hash()}")
     print("Kernel,Calls," + ",".join(f"{c}_MiB_per_launch" for c in cols) + ",fetch_x2_MiB_per_launch,avg_ms_under_pmc")
     rows = []
     for n in names:
