@@ -69,6 +69,40 @@ __device__ __forceinline__ void c4_stage_x(const C4Args& a, float4* lds_x, int n
   }
 }
 
+// Epilogue of a 4x8x8 x 32-channel tile held as 2 M tiles per wave (wave = z plane, M tile mt = y rows 4mt .. 4mt+3, accumulator row
+// r -> y = 4 mt + (r >> 2), x = (r & 3) + 4 half). INTERIOR tiles with a plain destination take the fast path: one base pointer and
+// two strides, so a store costs two integer operations instead of the ~40 of the general index arithmetic -- in these kernels
+// (54 or 7*P MFMAs per tile) the 32 stores per lane are a visible share of the tile, unlike in the big convolutions.
+// Returns false when the tile needs the general path (ragged edge, window shift, destination of another extent).
+template <int MT>
+__device__ __forceinline__ bool c4_store_fast(const C4Args& a, const f32x16 (&acc)[MT], int n, int tz0, int ty0, int tx0, int wave, int half, int co,
+                                              bool fuse, float& mK, float& ms0, float& ms1) {
+  if (tz0 + 4 > a.D || ty0 + 8 > a.H || tx0 + 8 > a.W || a.offz || a.offy || a.offx || a.yD != a.D || a.yH != a.H || a.yW != a.W) return false;
+  if (co >= a.Cout) return true;
+  const size_t vox0 = (((size_t)n * a.D + tz0 + wave) * a.H + ty0) * a.W + tx0 + 4 * half;
+  float* yp = a.y + vox0 * a.yld + co;
+  const float* rp = a.res ? a.res + vox0 * a.resld + co : nullptr;
+  const size_t yrow = (size_t)a.W * a.yld, rrow = (size_t)a.W * a.resld;
+  const float bs = a.bias ? a.bias[co] : 0.f, cs = a.out_chscale ? a.out_chscale[(size_t)n * a.Cout + co] : 1.f;
+  bool first = true;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int yy = 4 * mt + (r >> 2), xx = r & 3;
+      float v = acc[mt][r] + bs;
+      if (rp) v += rp[yy * rrow + (size_t)xx * a.resld];
+      v *= cs;
+      yp[yy * yrow + (size_t)xx * a.yld] = v;
+      if (fuse) {
+        if (first) { mK = v; first = false; }
+        const float t = v - mK;
+        ms0 += t; ms1 += t * t;
+      }
+    }
+  return true;
+}
+
 // ---- forward: 4x8x8 output voxels x 32 output channels per workgroup; 4 waves x 2 M tiles ----
 template <int INMODE, bool FUSE>
 __global__ __launch_bounds__(256) void conv3d_c4_fwd(C4Args a) {
@@ -115,8 +149,11 @@ __global__ __launch_bounds__(256) void conv3d_c4_fwd(C4Args a) {
   const int co = co0 + li;
   unsigned vmask = 0;                      // bit mt*16 + r: that accumulator row is a voxel of the output
   float mK = 0.f, ms0 = 0.f, ms1 = 0.f;    // FUSE: one-pass moments about K = the lane's first stored value
+  const bool fast = c4_store_fast<MT>(a, acc, n, tz0, ty0, tx0, wave, half, co, FUSE, mK, ms0, ms1);
+  if (fast) vmask = 0xffffffffu;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    if (fast) break;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -151,6 +188,177 @@ __global__ __launch_bounds__(256) void conv3d_c4_fwd(C4Args a) {
     const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
     const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
     gn_fuse_reduce_store<3, 1, 4, 1>(vals, reinterpret_cast<float*>(lds_x), wave, 0, half, li, tid, a.mom + rec * a.Cout * 3, co0, a.Cout);
+  }
+}
+
+// ---- forward on the bf16 matrix pipe with SPLIT fp32 operands (the opt-in precision modes, include/mi355_unet3d.h MI355_PREC_*) ----
+// Same GEMM (K = the fused (tap, ci) index, 108 values padded to 7 k-steps of 16), but on v_mfma_f32_32x32x16_bf16: 7 * P MFMAs of
+// 32 cycles per 32-voxel x 32-channel tile (P = 1 / 3 / 6 products) instead of 54 fp32 MFMAs of 64 cycles -- in exact fp32 this layer
+// is matrix-bound at ~1.7 TB/s algorithmic (22 % of the HBM roofline; <= 41 % is the fp32 ceiling); on the bf16
+// pipe it is the OUTPUT write that bounds it (32 channels x 128^3 fp32). A lane's A operand of a k-step is 8 consecutive k = the 4
+// channels of two consecutive taps = two ds_read_b64 of the haloed tile, kept in LDS as NS bf16 planes of 4 channels per voxel; the
+// B operand (weights, split once per workgroup while they are staged) is one ds_read_b128. A workgroup walks several z tiles of its
+// (y, x) column so that the weight staging is amortised; the next tile's input loads are in flight during the MFMA loop.
+template <int NS> struct C4Prod;
+template <> struct C4Prod<1> { static constexpr int P = 1; static constexpr int pa[1] = {0}; static constexpr int pb[1] = {0}; };
+template <> struct C4Prod<2> { static constexpr int P = 3; static constexpr int pa[3] = {1, 0, 0}; static constexpr int pb[3] = {0, 1, 0}; };
+template <> struct C4Prod<3> { static constexpr int P = 6; static constexpr int pa[6] = {2, 1, 0, 1, 0, 0}; static constexpr int pb[6] = {0, 1, 2, 0, 1, 0}; };   // smallest terms first
+
+template <int NS, int INMODE, bool FUSE>
+__global__ __launch_bounds__(256) void conv3d_c4_fwd_bf16(C4Args a) {
+  constexpr int TZ = 4, TY = 8, TX = 8, HZ = 6, HY = 10, HX = 10, HV = HZ * HY * HX, MT = 2, KS = 7;
+  constexpr int P = C4Prod<NS>::P;
+  __shared__ uint2 lds_x[HV * NS];                 // [halo voxel][plane]: 4 bf16 (the 4 input channels)
+  __shared__ uint4 lds_w[KS * 2 * NS * 32];        // [k-step][half][plane][co]: 8 bf16 = k 8*half .. 8*half+7 of that step
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+  int b = blockIdx.x;
+  const int cot = b % a.coTiles; b /= a.coTiles;
+  const int zc = b % a.splits; b /= a.splits;                  // a.splits = z chunks per column, a.ntiles = z tiles per chunk
+  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+  const int n = b;
+  const int co0 = cot * 32;
+  // ---- weights: OIDHW fp32 -> split bf16 planes in MFMA B-fragment order ----
+  {
+    unsigned short* w16 = reinterpret_cast<unsigned short*>(lds_w);
+    for (int i = tid; i < KS * 16 * 32; i += 256) {
+      const int co = i / (KS * 16), k = i % (KS * 16);
+      const int tap = k >> 2, ci = k & 3;
+      float v = (tap < 27 && co0 + co < a.Cout) ? a.w[((size_t)(co0 + co) * 4 + ci) * 27 + tap] : 0.f;
+      const int ks = k >> 4, hh = (k >> 3) & 1, e = k & 7;
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+        const unsigned pk = pack_bf16x2(v, 0.f);
+        w16[((((ks * 2 + hh) * NS + p) * 32 + co) << 3) + e] = (unsigned short)(pk & 0xffffu);
+        v -= bf16lo_to_f32(pk);
+      }
+    }
+  }
+  // per-lane LDS offsets (in voxels) of the two taps this half supplies in every k-step; tap 27 is padding (zero weights)
+  int o0[KS], o1[KS];
+#pragma unroll
+  for (int s2 = 0; s2 < KS; ++s2) {
+    const int t0 = 4 * s2 + 2 * half, t1 = t0 + 1 < 27 ? t0 + 1 : 26;
+    o0[s2] = ((t0 / 9) * HY + (t0 / 3) % 3) * HX + t0 % 3;
+    o1[s2] = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3;
+  }
+  int hv0[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int tv = (wave * MT + mt) * 32 + li;
+    hv0[mt] = ((tv / (TY * TX)) * HY + (tv / TX) % TY) * HX + tv % TX;
+  }
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f), sl = make_float4(a.slope, a.slope, a.slope, a.slope);
+  if (INMODE == MI355_IN_AFFINE_ACT) {
+    sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * 4);
+    sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * 4);
+    if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope);
+  }
+  constexpr int UP = (HV + 255) / 256;
+  float4 ld[UP];
+  auto load_tile = [&](int tz0) {
+#pragma unroll
+    for (int k = 0; k < UP; ++k) {            // clamped, always-valid addresses: all loads in flight together
+      int hv = tid + k * 256; if (hv >= HV) hv = HV - 1;
+      int iz = tz0 - 1 + hv / (HY * HX), iy = ty0 - 1 + (hv / HX) % HY, ix = tx0 - 1 + hv % HX;
+      iz = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1);
+      iy = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1);
+      ix = ix < 0 ? 0 : (ix < a.W ? ix : a.W - 1);
+      ld[k] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld);
+    }
+  };
+  auto commit_tile = [&](int tz0) {
+#pragma unroll
+    for (int k = 0; k < UP; ++k) {
+      const int hv = tid + k * 256;
+      if (hv >= HV) continue;
+      const int iz = tz0 - 1 + hv / (HY * HX), iy = ty0 - 1 + (hv / HX) % HY, ix = tx0 - 1 + hv % HX;
+      const bool ok = iz >= 0 && iy >= 0 && ix >= 0 && iz < a.D && iy < a.H && ix < a.W;
+      float4 v = ld[k];
+      if (INMODE == MI355_IN_AFFINE_ACT) v = c4_prologue(v, sc, sh, sl);
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+        const unsigned lo = pack_bf16x2(v.x, v.y), hi = pack_bf16x2(v.z, v.w);
+        lds_x[hv * NS + p] = make_uint2(lo, hi);
+        if (p + 1 < NS) { v.x -= bf16lo_to_f32(lo); v.y -= bf16hi_to_f32(lo); v.z -= bf16lo_to_f32(hi); v.w -= bf16hi_to_f32(hi); }
+      }
+    }
+  };
+  const int tz_begin = zc * a.ntiles, tz_end = tz_begin + a.ntiles < a.tilesZ ? tz_begin + a.ntiles : a.tilesZ;
+  if (tz_begin < tz_end) load_tile(tz_begin * TZ);
+  const int co = co0 + li;
+  for (int tzi = tz_begin; tzi < tz_end; ++tzi) {
+    const int tz0 = tzi * TZ;
+    __syncthreads();                          // the previous tile's MFMA loop / statistics scratch is done with lds_x
+    commit_tile(tz0);
+    __syncthreads();                          // (first iteration: also publishes lds_w)
+    if (tzi + 1 < tz_end) load_tile(tz0 + TZ);
+    SCHED_BARRIER();
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      uint4 bf[NS];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) bf[p] = lds_w[((s2 * 2 + half) * NS + p) * 32 + li];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        uint4 af[NS];
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+          const uint2 lo = lds_x[(hv0[mt] + o0[s2]) * NS + p], hi = lds_x[(hv0[mt] + o1[s2]) * NS + p];
+          af[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+#pragma unroll
+        for (int q = 0; q < P; ++q) acc[mt] = MFMA_32x32x16_BF16(af[C4Prod<NS>::pa[q]], bf[C4Prod<NS>::pb[q]], acc[mt]);
+      }
+    }
+    // ---- epilogue (as conv3d_c4_fwd) ----
+    unsigned vmask = 0;
+    float mK = 0.f, ms0 = 0.f, ms1 = 0.f;
+    const bool fast = c4_store_fast<MT>(a, acc, n, tz0, ty0, tx0, wave, half, co, FUSE, mK, ms0, ms1);
+    if (fast) vmask = 0xffffffffu;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (fast) break;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int tv = (wave * MT + mt) * 32 + row;
+        const int oz = tz0 + tv / (TY * TX), oy = ty0 + (tv / TX) % TY, ox = tx0 + tv % TX;
+        if (oz >= a.D || oy >= a.H || ox >= a.W) continue;
+        const int sz = oz + a.offz, sy = oy + a.offy, sx = ox + a.offx;
+        if (sz < 0 || sy < 0 || sx < 0 || sz >= a.yD || sy >= a.yH || sx >= a.yW) continue;
+        const bool first = FUSE && vmask == 0;
+        if (FUSE) vmask |= 1u << (mt * 16 + r);
+        if (co >= a.Cout) continue;
+        const size_t ovox = (((size_t)n * a.D + oz) * a.H + oy) * a.W + ox;
+        const size_t svox = (((size_t)n * a.yD + sz) * a.yH + sy) * a.yW + sx;
+        float v = acc[mt][r];
+        if (a.bias) v += a.bias[co];
+        if (a.res) v += a.res[ovox * a.resld + co];
+        if (a.out_chscale) v *= a.out_chscale[(size_t)n * a.Cout + co];
+        a.y[svox * a.yld + co] = v;
+        if constexpr (FUSE) {
+          if (first) mK = v;
+          const float t = v - mK;
+          ms0 += t; ms1 += t * t;
+        }
+      }
+    }
+    if constexpr (FUSE) {
+      float vals[1][3];
+      const float cnt = (float)__builtin_popcount(vmask);
+      const float m2 = cnt > 0.f ? ms1 - ms0 * ms0 / cnt : 0.f;
+      vals[0][0] = cnt; vals[0][1] = ms0 + cnt * mK; vals[0][2] = m2 > 0.f ? m2 : 0.f;
+      const int tile = (tzi * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
+      const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
+      gn_fuse_reduce_store<3, 1, 4, 1>(vals, reinterpret_cast<float*>(lds_x), wave, 0, half, li, tid, a.mom + rec * a.Cout * 3, co0, a.Cout);
+    }
   }
 }
 
@@ -362,6 +570,25 @@ int mi355_conv3d_c4_fwd_impl(const mi355_act* x, const float* w, const mi355_act
   a.tilesZ = ceil_div(a.D, 4); a.tilesY = ceil_div(a.H, 8); a.tilesX = ceil_div(a.W, 8); a.coTiles = ceil_div(a.Cout, 32);
   const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
+  if (d->precision != MI355_PREC_F32) {
+    // bf16 matrix pipe with split operands: a workgroup walks a.ntiles z tiles of its (y, x) column; enough z chunks for >= ~2048 workgroups
+    const long long cols = (long long)a.N * a.tilesY * a.tilesX * a.coTiles;
+    int zs = (int)((2048 + cols - 1) / cols); if (zs < 1) zs = 1; if (zs > a.tilesZ) zs = a.tilesZ;
+    a.ntiles = ceil_div(a.tilesZ, zs); a.splits = ceil_div(a.tilesZ, a.ntiles);
+    const long long wg = cols * a.splits;
+    if (wg > 0x7fffffffLL) return MI355_EINVAL;
+    const int ns = d->precision == MI355_PREC_BF16X3 ? 2 : (d->precision == MI355_PREC_BF16X6 ? 3 : 1);
+#define MI355_C4B(NSV, IM, FU) LAUNCH((conv3d_c4_fwd_bf16<NSV, IM, FU>), dim3((unsigned)wg), dim3(256), 0, stream, a)
+#define MI355_C4B_NS(NSV)                                                                                  \
+    do {                                                                                                   \
+      if (a.mom) { if (d->in_mode == MI355_IN_PLAIN) MI355_C4B(NSV, MI355_IN_PLAIN, true); else MI355_C4B(NSV, MI355_IN_AFFINE_ACT, true); }   \
+      else { if (d->in_mode == MI355_IN_PLAIN) MI355_C4B(NSV, MI355_IN_PLAIN, false); else MI355_C4B(NSV, MI355_IN_AFFINE_ACT, false); }       \
+    } while (0)
+    if (ns == 1) MI355_C4B_NS(1); else if (ns == 2) MI355_C4B_NS(2); else MI355_C4B_NS(3);
+#undef MI355_C4B_NS
+#undef MI355_C4B
+    return LAUNCH_CHECK();
+  }
   if (a.mom) {
     if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_c4_fwd<MI355_IN_PLAIN, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
     else LAUNCH((conv3d_c4_fwd<MI355_IN_AFFINE_ACT, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);

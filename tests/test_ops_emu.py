@@ -258,6 +258,22 @@ def test_conv_fwd_bf16_paths(prec_backend, kw):
     assert C.case_conv_fwd(be, **kw) < tol
 
 
+# the 4-input-channel first layer on the bf16 pipe (conv3d_c4_fwd_bf16: K = fused (tap, ci) index, split operands, z-walking workgroups)
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=4, cout=32, dhw=(9, 9, 9), norm=True),                                     # ragged tiles in every axis, 3 z tiles per column
+    dict(n=2, cin=4, cout=64, dhw=(5, 6, 17), norm=True, residual=True, chscale=True),       # two co tiles (DynUNet width), two samples
+    dict(n=1, cin=4, cout=48, dhw=(3, 4, 5), bias=True, yld=64, yc0=16),                     # partial co tile, concat slice
+])
+def test_first_layer_fwd_bf16_paths(prec_backend, kw):
+    be, tol = prec_backend
+    assert C.case_conv_fwd(be, **kw) < tol
+
+
+def test_first_layer_moments_bf16_paths(prec_backend):
+    be, tol = prec_backend
+    assert C.case_conv_moments(be, 2, 4, 32, (9, 8, 10), ytol=tol, strict_vs_oracle=False) < 2e-5
+
+
 @pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=64, dhw=(3, 4, 18)), dict(n=2, cin=64, cout=32, dhw=(4, 4, 16))])
 def test_conv_dgrad_bf16_paths(prec_backend, kw):
     be, tol = prec_backend

@@ -250,6 +250,23 @@ def test_conv_fwd_bf16_paths(prec_backend, kw):
     assert C.case_conv_fwd(be, **kw) < tol
 
 
+# the 4-input-channel first layer on the bf16 pipe (conv3d_c4_fwd_bf16)
+@pytest.mark.parametrize("kw", [
+    dict(n=2, cin=4, cout=32, dhw=(64, 64, 64), norm=True),                                   # 16 z tiles per column, split into chunks
+    dict(n=1, cin=4, cout=32, dhw=(33, 30, 37), norm=True, residual=True, chscale=True),      # ragged in every axis
+    dict(n=2, cin=4, cout=64, dhw=(16, 24, 32), norm=True, slope=0.01),                       # two co tiles (DynUNet input block)
+    dict(n=1, cin=4, cout=48, dhw=(7, 6, 10), bias=True, yld=64, yc0=16),
+])
+def test_first_layer_fwd_bf16_paths(prec_backend, kw):
+    be, tol = prec_backend
+    assert C.case_conv_fwd(be, **kw) < tol
+
+
+def test_first_layer_moments_bf16_paths(prec_backend):
+    be, tol = prec_backend
+    assert C.case_conv_moments(be, 2, 4, 32, (32, 40, 48), ytol=tol, strict_vs_oracle=False) < 2e-5
+
+
 @pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=64, dhw=(16, 17, 18)), dict(n=2, cin=64, cout=32, dhw=(32, 32, 32))])
 def test_conv_dgrad_bf16_paths(prec_backend, kw):
     be, tol = prec_backend

@@ -39,6 +39,8 @@ typedef void* hipStream_t;
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x,y,z,w}; }
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 struct uint4 { unsigned x, y, z, w; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x,y,z,w}; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
