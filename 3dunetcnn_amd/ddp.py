@@ -18,6 +18,8 @@ unet3d/train/training_utils.py:71-72) steps on reduced gradients; calling it aga
 Averaging happens exactly once, here (ReduceOp.AVG on RCCL, SUM followed by 1/world on other backends): leave
 `HipAdam.grad_scale` at 1.0 when a reducer is attached.
 """
+import contextlib
+
 import torch.distributed as dist
 
 
@@ -34,6 +36,8 @@ class GradientBucketReducer:
         model.grad_ready_callback = self._on_ready
         model.backward_start_callback = self._on_backward_start
         model.grad_sync_callback = self.wait        # the engine joins the exchange at the end of every backward
+        model.grad_accumulated_callback = self._on_accumulated
+        self._sync = True
 
     # -- setup ---------------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src=0):
@@ -77,6 +81,30 @@ class GradientBucketReducer:
                     break
         self._built_for = m._flat.data_ptr()
 
+    # -- gradient accumulation ---------------------------------------------------------------------------------------
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Micro-batches whose gradients only accumulate locally (torch DDP's no_sync): inside this context a backward launches no
+        all-reduce. The first backward OUTSIDE the context that accumulates onto them reduces the accumulated buffer (averaged over
+        ranks), so optimizer.step() sees mean-over-ranks of sum-over-micro-batches, as with torch.nn.parallel.DistributedDataParallel."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
+    def _on_accumulated(self, flat_grad):
+        """A backward has ADDED its gradients onto existing ones (engine.py): reduce the accumulated flat buffer in one piece -- the
+        per-bucket overlap is not available here, the micro-batch backward could not know it was the last."""
+        if not self._sync or (self.world == 1 and not self.reduce_single_rank):
+            return
+        if self.average and dist.get_backend(self.pg) == "nccl":
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, group=self.pg)
+        else:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+            if self.average:
+                flat_grad.mul_(1.0 / self.world)
+
     # -- per-backward ----------------------------------------------------------------------------------------------
     def _on_backward_start(self, gbuf):
         if self._built_for != self.model._flat.data_ptr():
@@ -87,7 +115,7 @@ class GradientBucketReducer:
         self.n_launched = 0            # bucket all-reduces launched during this backward (diagnostics / tests)
 
     def _on_ready(self, params):
-        if self.world == 1 and not self.reduce_single_rank:
+        if not self._sync or (self.world == 1 and not self.reduce_single_rank):
             return
         for p in params:
             bi = self.bucket_of[id(p)]

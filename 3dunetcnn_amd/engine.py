@@ -50,6 +50,7 @@ class HipNetBase(nn.Module):
         self.grad_ready_callback = None        # set by ddp.GradientBucketReducer
         self.backward_start_callback = None
         self.grad_sync_callback = None         # set by ddp.GradientBucketReducer: joins the bucket all-reduces at the end of backward
+        self.grad_accumulated_callback = None  # set by ddp.GradientBucketReducer: a backward that ACCUMULATED into existing .grad
         self._written = []
         # Weight-gradient kernels are enqueued on a second HIP stream so that the matrix-bound wgrads overlap the HBM-bound
         # norm-backward / upsample-backward passes of the dgrad chain (see _wgrad_stream). Measured on MI355X (round 2 A/B,
@@ -209,12 +210,13 @@ class HipNetBase(nn.Module):
         ps = self._params()
         gbuf = self.flat_grad()
         accumulate = any(p.grad is not None for p in ps)
+        reducer_cb = (self.grad_ready_callback, self.backward_start_callback, self.grad_sync_callback)
         if accumulate:
-            # existing .grad tensors (which may alias the flat buffer) must be ADDED to: compute into scratch
-            if self.grad_ready_callback is not None:
-                raise RuntimeError("gradient accumulation with the DDP reducer is not supported: call "
-                                   "optimizer.zero_grad(set_to_none=True) before every backward")
+            # existing .grad tensors (which may alias the flat buffer) must be ADDED to: compute into scratch. With a DDP reducer attached
+            # the per-bucket all-reduces cannot be launched from inside this backward (they would reduce the micro-batch, not the sum):
+            # the reducer gets the accumulated buffer in one piece afterwards (grad_accumulated_callback; skipped under reducer.no_sync())
             gbuf = torch.zeros_like(self._flat)
+            self.grad_ready_callback = self.backward_start_callback = self.grad_sync_callback = None
         self._gbuf = gbuf
         self._written = []
         if self.backward_start_callback is not None:
@@ -237,7 +239,8 @@ class HipNetBase(nn.Module):
             if self._s2_active is not None:
                 torch.cuda.current_stream().wait_stream(self._s2_active)     # join: the optimizer reads every gradient
                 self._s2_active = None
-        if self.grad_sync_callback is not None:
+        self.grad_ready_callback, self.backward_start_callback, self.grad_sync_callback = reducer_cb
+        if self.grad_sync_callback is not None and not accumulate:
             # every bucket all-reduce has been launched by now: order the launch stream behind them (a stream-level wait on RCCL,
             # the host does not stall), so that ANY caller's `loss.backward(); optimizer.step()` -- the reference's epoch_training
             # loop, unet3d/train/training_utils.py:71-72 -- steps on fully reduced, averaged gradients without calling the reducer
@@ -253,4 +256,10 @@ class HipNetBase(nn.Module):
             else:
                 p.grad.add_(g)
         self._gbuf = None
+        if accumulate and getattr(self, "grad_accumulated_callback", None) is not None:
+            if all(p.grad is not None and p.grad.data_ptr() == self._flat_grad.data_ptr() + 4 * o for p, o in zip(ps, self._offsets) if p.requires_grad):
+                self.grad_accumulated_callback(self._flat_grad)        # the sum of the micro-batch gradients, reduced in one piece
+            else:
+                raise RuntimeError("gradient accumulation with the DDP reducer needs the .grad tensors this engine created (views of its flat "
+                                   "gradient buffer): do not replace p.grad between the micro-batches")
         return grads, dx_t

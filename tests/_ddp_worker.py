@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 from oracle import unet3d_ref as R  # noqa: E402  (synthetic inputs only)
 
 
-def main(out_dir, device="cpu"):
+def main(out_dir, device="cpu", mode="step"):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
@@ -56,6 +56,23 @@ def main(out_dir, device="cpu"):
     if on_gpu:
         x, y = x.cuda(), y.cuda()
     rec = {"sd0": sd0, "losses": [], "n_buckets": None}
+    if mode == "accum":
+        # two micro-batches per optimizer step: the first accumulates locally (reducer.no_sync()), the second reduces the accumulated sum
+        x2, y2 = R.synthetic_case(1, 4, (16, 16, 16), 3, seed=rank + 10)
+        if on_gpu:
+            x2, y2 = x2.cuda(), y2.cuda()
+        opt.zero_grad(set_to_none=True)
+        with red.no_sync():
+            crit(m(x), y).backward()
+        local = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+        crit(m(x2), y2).backward()
+        rec["local_first"] = local
+        rec["grads"] = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+        opt.step()
+        rec["sd2"] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        torch.save(rec, os.path.join(out_dir, f"rank{rank}.pt"))
+        dist.destroy_process_group()
+        return
     for _ in range(2):
         opt.zero_grad(set_to_none=True)
         loss = crit(m(x), y)
@@ -72,4 +89,4 @@ def main(out_dir, device="cpu"):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "cpu")
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "cpu", sys.argv[3] if len(sys.argv) > 3 else "step")

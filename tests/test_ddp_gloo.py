@@ -33,17 +33,46 @@ def test_two_rank_bucketed_allreduce_on_hip_kernels(tmp_path, hip_backend):
     _two_rank_step(tmp_path, "cuda")
 
 
-def _two_rank_step(tmp_path, device):
+def _run_workers(tmp_path, device, mode="step"):
     port = _free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ddp_worker.py"), str(tmp_path), device], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ddp_worker.py"), str(tmp_path), device, mode], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    recs = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
+    return [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
+
+
+def test_two_rank_gradient_accumulation_with_no_sync(tmp_path, emu_backend):
+    """Two micro-batches per step (torch DDP's no_sync idiom): the first backward accumulates locally, the second reduces the SUM.
+    Expected gradient on every rank = mean over ranks of (g(micro-batch 1) + g(micro-batch 2))."""
+    recs = _run_workers(tmp_path, "cpu", "accum")
+    want = None
+    for r in range(2):
+        sd = {k: v.clone().requires_grad_(True) for k, v in recs[0]["sd0"].items()}
+        for seed in (r, r + 10):
+            x, y = R.synthetic_case(1, 4, (16, 16, 16), 3, seed=seed)
+            O.dice_loss(R.unet3d_forward(sd, x, (1, 1, 1)), y).backward()
+        if r == 0:
+            x, y = R.synthetic_case(1, 4, (16, 16, 16), 3, seed=0)
+            sd1 = {k: v.clone().requires_grad_(True) for k, v in recs[0]["sd0"].items()}
+            O.dice_loss(R.unet3d_forward(sd1, x, (1, 1, 1)), y).backward()
+            for k, v in sd1.items():                        # under no_sync nothing was exchanged: rank 0 still holds its own gradient
+                assert C.rel_err(recs[0]["local_first"][k], v.grad) < 1e-3, k
+        g = {k: v.grad / 2 for k, v in sd.items()}
+        want = g if want is None else {k: want[k] + g[k] for k in g}
+    for r in range(2):
+        for k, v in want.items():
+            assert C.rel_err(recs[r]["grads"][k], v) < 1e-3, (r, k)
+    for k in recs[0]["sd2"]:
+        assert torch.equal(recs[0]["sd2"][k], recs[1]["sd2"][k]), k
+
+
+def _two_rank_step(tmp_path, device):
+    recs = _run_workers(tmp_path, device)
     # broadcast: both ranks start from rank 0's weights
     for k in recs[0]["sd0"]:
         assert torch.equal(recs[0]["sd0"][k], recs[1]["sd0"][k]), k
