@@ -58,7 +58,6 @@ class HipNetBase(nn.Module):
         self.backward_side_stream = os.environ.get("MI355_SIDE_STREAM", "1") != "0"
         self._s2 = None
         self._s2_active = None
-        self._ws2 = None
 
     # ---- flat parameter storage --------------------------------------------------------------------------------
     def _params(self):
@@ -168,7 +167,7 @@ class HipNetBase(nn.Module):
     def _wgrad_stream(self, be, *used):
         """Context for a weight-gradient launch. Default: nothing (the launch goes to the current stream, in program order).
         With `backward_side_stream` the launch is forked onto the side stream after everything enqueued so far (its inputs are
-        complete), with its own workspace; `used` (Acts / tensors the kernel reads) are marked as in use by that stream so that the
+        complete); `used` (Acts / tensors the kernel reads) are marked as in use by that stream so that the
         caching allocator does not hand their memory out again before the kernel has run. _backward_impl joins the streams."""
         s2 = self._s2_active
         if s2 is None:
@@ -180,12 +179,8 @@ class HipNetBase(nn.Module):
         for t in used:
             if t is not None:
                 (t.buf if hasattr(t, "buf") else t).record_stream(s2)
-        main_ws, be._ws = be._ws, self._ws2
-        try:
-            with torch.cuda.stream(s2):
-                yield
-        finally:
-            self._ws2, be._ws = be._ws, main_ws
+        with torch.cuda.stream(s2):           # its scratch: Backend.ws() keeps one workspace per launch stream
+            yield
 
     def _flush_ready(self):
         """Report parameters whose gradient kernels have been enqueued (DDP launches the bucket all-reduce from here)."""

@@ -42,22 +42,18 @@ class HipGraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         optimizer.zero_grad(set_to_none=True)        # capture writes the gradients in place (no accumulate branch)
         model.mark_parameters_updated()              # the pack kernels are part of every replay
-        be = model._be
-        ws_before = None if be is None or be._ws is None else be._ws.data_ptr()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             logits = model(self.x)
             loss = criterion(logits, self.y)
             loss.backward()
-        # The captured kernels have the ADDRESS of the backend workspace baked in. Keep that tensor alive for the life of the graph:
-        # a later eager op that needs a larger workspace makes Backend.ws() allocate a new one and drop its own reference, and
-        # without this reference the caching allocator (the reference loop calls empty_cache() every iteration,
-        # unet3d/train/training_utils.py:66) could hand the old block to another tensor that replay() would then scribble over.
+        # The captured kernels have the ADDRESSES of the backend workspaces baked in. Backend.ws() keeps one workspace per launch stream;
+        # the capture stream's was allocated during capture (from the graph's private pool, where stream-ordered reuse replays
+        # faithfully). Hold a reference to every workspace for the life of the graph: a later eager op that needs a larger one makes
+        # Backend.ws() allocate anew and drop its own reference, and without ours the caching allocator (the reference loop calls
+        # empty_cache() every iteration, unet3d/train/training_utils.py:66) could hand a block the graph still writes to another tensor.
         be = model._be
-        self._ws_ref = None if be is None else be._ws
-        if ws_before is not None and self._ws_ref is not None and self._ws_ref.data_ptr() != ws_before:
-            raise RuntimeError("HipGraphedTrainStep: the backend workspace was reallocated DURING capture (warm-up did not size it); "
-                               "raise `warmup` or run one eager step first")
+        self._ws_refs = None if be is None else [t for t in be._ws_by_stream.values() if t is not None]
         self.logits = logits.detach()                # static outputs, refreshed by every replay
         self.loss = loss.detach()
         self._grads = [(p, p.grad) for p in model.parameters() if p.grad is not None]

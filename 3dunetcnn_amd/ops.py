@@ -125,7 +125,7 @@ class Backend:
                 raise RuntimeError("3dunetcnn_amd needs an MI355X (no HIP device visible); there is no CPU fallback")
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
-        self._ws = None
+        self._ws_by_stream = {}     # launch stream handle -> workspace tensor: kernels of different streams must not share scratch
         self.precision = PREC_F32   # arithmetic of the 3x3x3 stride-1 convs: see set_precision()
         self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
         # norm statistics leave with the producing conv's epilogue (csrc/gn_fuse.h). False: every statistic is a standalone pass
@@ -143,10 +143,16 @@ class Backend:
         return 0
 
     def ws(self, nbytes):
-        if self._ws is None or self._ws.numel() * 4 < nbytes:
-            self._ws = None
-            self._ws = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=torch.float32, device=self.device)
-        return self._ws
+        """Workspace of the CURRENT launch stream (grown on demand, allocated under that stream so that the caching allocator
+        ties its reuse to it). One per stream: the weight-gradient side stream of engine.py runs concurrently with the main
+        stream, and a shared scratch buffer would be written by two kernels at once."""
+        key = self.stream()
+        cur = self._ws_by_stream.get(key)
+        if cur is None or cur.numel() * 4 < nbytes:
+            self._ws_by_stream[key] = None
+            cur = self._ws_by_stream[key] = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=torch.float32, device=self.device)
+        return cur
+
 
     def empty_act(self, n, d, h, w, c, ld=None):
         return Act(torch.empty(n, d, h, w, ld or c, dtype=torch.float32, device=self.device), 0, c)

@@ -137,3 +137,47 @@ def test_dice_ce_rejects_degenerate_weights():
         losses.HipDiceCELoss(sigmoid=True, lambda_dice=0.0, lambda_ce=0.0)
     with pytest.raises(ValueError):
         losses.HipDiceCELoss(sigmoid=True, lambda_dice=-1.0)
+
+
+def _amp_step(dev, be):
+    """The reference's `training.amp = true` path (train/train.py:33-37: GradScaler; training_utils.py:60-69, 93-96: autocast around
+    model + criterion, scaler.scale(loss).backward(), scaler.step(optimizer), scaler.update()). The HIP modules keep fp32 arithmetic
+    under torch's autocast (it only re-types torch ops); what must work is the protocol: a scaled incoming gradient, GradScaler's in-place
+    unscale of the .grad views of the flat buffer, its inf check and the optimizer step. One scaled step == one plain step."""
+    res = {}
+    x, y = R.synthetic_case(1, 4, (16, 16, 16), 3)
+    x, y = x.to(dev), y.to(dev)
+    for amp in (False, True):
+        torch.manual_seed(8)
+        m = unet.HipUNet3D(**KW).to(dev).eval()
+        crit = losses.HipDiceLoss(sigmoid=True)
+        opt = optim.HipAdam(m.parameters(), lr=1e-3)
+        if be is not None:
+            m._be = crit._be = opt._be = be
+        opt.zero_grad()
+        if amp:
+            scaler = torch.amp.GradScaler(dev)
+            with torch.autocast(device_type=dev):
+                loss = crit(m(x), y)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            assert scaler.get_scale() >= 65536.0                       # no inf / nan was found: the step was taken, the scale kept
+        else:
+            loss = crit(m(x), y)
+            loss.backward()
+            opt.step()
+        res[amp] = (float(loss.detach()), {k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    assert abs(res[True][0] - res[False][0]) < 1e-6
+    for k, v in res[False][1].items():
+        # Adam's first step is lr * g / (|g| + eps): scaling and unscaling the gradient by 2^16 is exact in fp32
+        assert float((res[True][1][k] - v).abs().max()) <= 1e-6, k
+
+
+@pytest.mark.gpu
+def test_grad_scaler_and_autocast_protocol_gpu(hip_backend):
+    _amp_step("cuda", None)
+
+
+def test_grad_scaler_and_autocast_protocol_on_emulator(emu_backend):
+    _amp_step("cpu", emu_backend)
