@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_bf16(ConvBArgs a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float u = v[e] * sc[e] + sh[e];
-            v[e] = u > 0.f ? u : u * sl[e];
+            v[e] = fmaxf(u, u * sl[e]);          // act(u) for 0 <= slope <= 1
           }
         }
 #pragma unroll

@@ -41,11 +41,21 @@ struct ConvArgs {
 // FUSE: the epilogue also reduces norm statistics of what it stores (gn_fuse.h): 1 = moments of the output (forward), 2 = the
 // norm-backward partial sums (dgrad). Separate instantiations so that the plain kernels keep their register budget (the extra
 // live values cost a wave of occupancy per SIMD in several configurations).
+// Waves per SIMD the register allocator must fit (512 registers / waves, accumulators in AGPRs included): several instantiations sit
+// one or two VGPRs above a boundary otherwise and lose a wave for it.
+// The two-level (TL) form keeps a second accumulator set; of those with 2 tiles per wave only the 2x2-wave layout fits 4 waves.
+constexpr int conv_min_waves(int tiles, bool tl, int wn, bool fullj) {
+  if (!tl) return tiles <= 2 ? 4 : tiles <= 4 ? 3 : 2;
+  return tiles == 1 ? 4 : tiles == 2 ? (wn == 2 ? 4 : fullj ? 3 : 2) : 2;
+}
+
 template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT, int INMODE, bool TL = false, bool FULLJ = false, int FUSE = 0>
-__global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
+__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(conv_min_waves(MT * NT, TL, WN, FULLJ))
+void conv3d_mfma(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TZ * TY * TX == 32 * WM * MT, "tile voxels must equal 32*WM*MT");
   static_assert(KC % 8 == 0, "channel chunk is a multiple of 8");
+  static_assert(KD * KD * KD == 1 || (KD * KD * KD) % 3 == 0, "the tap loop is unrolled by three");
   constexpr int HZ = (TZ - 1) * STRIDE + KD, HY = (TY - 1) * STRIDE + KD, HX = (TX - 1) * STRIDE + KD;
   constexpr int HV = HZ * HY * HX;
   constexpr int VS = KC + PADV;
@@ -106,7 +116,31 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
   const int sq = tid % Q;       // this thread's channel quad inside the chunk (fixed: 256 % Q == 0)
   const int sv0 = tid / Q;
 
+  // B fragments (packed weights [tap][ci/4][co][4]) are addressed as (wave-uniform slab pointer, in SGPRs) + (this lane's fixed 32-bit
+  // byte offset inside a slab): no per-lane 64-bit index arithmetic in the tap loop. SQ counters
+  // (profiles/r2_sq_counters_conv_kernels.txt) show MFMA-busy % + 4 x VALU-instruction % ~ 94 % of the SIMD cycles in these kernels:
+  // vector-ALU instructions are paid in matrix time.
+  const unsigned lane_b = (unsigned)(half * a.CoutP + co_base + li) * 16u;
+  const size_t tap_slab = (size_t)CQ * a.CoutP;
+  auto load_b = [&](float4 (&bf)[J][NT], const float4* slab, int jn_) {      // slab: tap and chunk applied, wave-uniform
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        bf[j][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < jn_)
+          bf[j][nt] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slab + (size_t)(2 * j) * a.CoutP + nt * 32) + lane_b);
+      }
+  };
+
   for (int c0 = 0; c0 < a.CinP; c0 += KC) {
+    // k-groups of this chunk that exist (CinP is a multiple of 8 but not necessarily of KC); wave-uniform
+    const int jn = FULLJ ? J : ((a.CinP - c0) / 8 < J ? (a.CinP - c0) / 8 : J);
+    const float4* wpc = wp4 + (size_t)(c0 / 4) * a.CoutP;      // this chunk's channel quads inside every tap slab
+    // 3x3x3: the first tap's B fragments are requested before the tile is staged, their latency hides under the staging loads
+    // (0.3-0.6 % per layer); the 1x1x1 kernels measured 5-13 % faster asking after the barrier (fewer registers while staging)
+    float4 b0[ZIP ? 1 : J][ZIP ? 1 : NT];
+    if constexpr (!ZIP && T > 1) load_b(b0, wpc, jn);
     // ---- stage the haloed input tile for channels [c0, c0+KC) ----
     __syncthreads();
     {
@@ -192,8 +226,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
             float4 v = ld[kk];
             if (INMODE == MI355_IN_AFFINE_ACT) {
               v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-              v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
-              v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+              // act(u) = max(u, slope * u) for 0 <= slope <= 1 (ReLU, LeakyReLU, identity): no compare / select
+              v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
             }
             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(lds + hv * VS + 4 * sq) = v;
@@ -204,9 +238,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
     __syncthreads();
 
     // ---- 27 taps x KC/8 k-groups, B fragments prefetched one tap ahead ----
-    const int cq0 = c0 / 4 + half;
-    // k-groups of this chunk that exist (CinP is a multiple of 8 but not necessarily of KC); wave-uniform
-    const int jn = FULLJ ? J : ((a.CinP - c0) / 8 < J ? (a.CinP - c0) / 8 : J);
+    if constexpr (!ZIP && T == 1) load_b(b0, wpc, jn);
     if constexpr (ZIP) {
       const int az = zcls >> 1, ay = zcls & 1;
       const int ny = ay ? 2 : 1, ncomb = (az ? 2 : 1) * ny;
@@ -221,7 +253,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
               b3[dx][j][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (j < jn) b3[dx][j][nt] = wp4[((size_t)(((dz * 3 + dy) * 3 + dx) * CQ + cq0 + 2 * j)) * a.CoutP + co_base + nt * 32 + li];
+              if (j < jn) b3[dx][j][nt] = wp4[((size_t)(((dz * 3 + dy) * 3 + dx) * CQ + c0 / 4 + half + 2 * j)) * a.CoutP + co_base + nt * 32 + li];
             }
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
@@ -243,51 +275,63 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a) {
         }
       }
     } else {
-    float4 bcur[J][NT], bnext[J][NT];
+      auto run_tap = [&](const float4 (&bf)[J][NT], int tap) {
+        const int dz = tap / (KD * KD), dy = (tap / KD) % KD, dx = tap % KD;      // wave-uniform: scalar ALU
+        const int toff = ((dz * HY + dy) * HX + dx) * VS;
 #pragma unroll
-    for (int j = 0; j < J; ++j)
+        for (int j = 0; j < J; ++j) {
+          if (j >= jn) continue;
+          float4 af[MT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        bcur[j][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < jn) bcur[j][nt] = wp4[((size_t)(0 * CQ + cq0 + 2 * j)) * a.CoutP + co_base + nt * 32 + li];
-      }
-
-#pragma unroll 1
-    for (int tap = 0; tap < T; ++tap) {
-      const int tn = tap + 1 < T ? tap + 1 : tap;
+          for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const float4*>(lds + abase[mt] + toff + j * 8);
 #pragma unroll
-      for (int j = 0; j < J; ++j)
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          bnext[j][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (j < jn) bnext[j][nt] = wp4[((size_t)(tn * CQ + cq0 + 2 * j)) * a.CoutP + co_base + nt * 32 + li];
+            for (int nt = 0; nt < NT; ++nt) {
+              f32x16& ac = TL ? accc[TL ? mt : 0][TL ? nt : 0] : acc[mt][nt];
+              ac = MFMA_32x32x2(af[mt].x, bf[j][nt].x, ac);
+              ac = MFMA_32x32x2(af[mt].y, bf[j][nt].y, ac);
+              ac = MFMA_32x32x2(af[mt].z, bf[j][nt].z, ac);
+              ac = MFMA_32x32x2(af[mt].w, bf[j][nt].w, ac);
+            }
         }
-
-      SCHED_BARRIER();      // the B loads of the NEXT tap stay above this tap's MFMAs (the scheduler otherwise sinks them to their use)
-      const int dz = tap / (KD * KD), dy = (tap / KD) % KD, dx = tap % KD;
-      const int toff = ((dz * HY + dy) * HX + dx) * VS;
+      };
+      // B fragments run one tap ahead of the MFMAs that use them. Two forms, chosen per tile shape by measurement
+      // (tools/bench_conv_layers.py, profiles/r2_ab_experiments.txt):
+      //  * three register sets rotating through an unroll-by-three body (27 = 9 x 3; a peeled odd tap made the compiler keep a
+      //    second copy of every accumulator): no "current = next" moves -- 4-6 % faster where a wave holds up to two tiles;
+      //  * two sets with the move: what the 4-tile (2 x 2) waves and the 2 x 2-wave layout prefer (the third set costs them the
+      //    registers their A fragments were read ahead in).
+      constexpr bool ROT3 = !(MT * NT == 4 || (WM == 2 && WN == 2 && MT * NT == 2));
+      if constexpr (T == 1) {
+        run_tap(b0, 0);
+      } else if constexpr (ROT3) {
+        float4 b1[J][NT], b2[J][NT];
+#pragma unroll 1
+        for (int tap = 0; tap < T; tap += 3) {
+          load_b(b1, wpc + tap_slab * (tap + 1), jn);
+          SCHED_BARRIER();      // the B loads of the NEXT tap stay above this tap's MFMAs (the scheduler otherwise sinks them to their use)
+          run_tap(b0, tap);
+          load_b(b2, wpc + tap_slab * (tap + 2), jn);
+          SCHED_BARRIER();
+          run_tap(b1, tap + 1);
+          if (tap + 3 < T) load_b(b0, wpc + tap_slab * (tap + 3), jn);      // wave-uniform branch
+          SCHED_BARRIER();
+          run_tap(b2, tap + 2);
+        }
+      } else {
+        float4 b1[J][NT];
+#pragma unroll 1
+        for (int tap = 0; tap < T; ++tap) {
+          load_b(b1, wpc + tap_slab * (tap + 1 < T ? tap + 1 : tap), jn);
+          SCHED_BARRIER();
+          run_tap(b0, tap);
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        if (j >= jn) continue;
-        float4 af[MT];
+          for (int j = 0; j < J; ++j)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const float4*>(lds + abase[mt] + toff + j * 8);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            f32x16& ac = TL ? accc[TL ? mt : 0][TL ? nt : 0] : acc[mt][nt];
-            ac = MFMA_32x32x2(af[mt].x, bcur[j][nt].x, ac);
-            ac = MFMA_32x32x2(af[mt].y, bcur[j][nt].y, ac);
-            ac = MFMA_32x32x2(af[mt].z, bcur[j][nt].z, ac);
-            ac = MFMA_32x32x2(af[mt].w, bcur[j][nt].w, ac);
-          }
+            for (int nt = 0; nt < NT; ++nt) b0[j][nt] = b1[j][nt];
+        }
       }
-#pragma unroll
-      for (int j = 0; j < J; ++j)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bcur[j][nt] = bnext[j][nt];
-    }
     }
     if (TL) {
 #pragma unroll
@@ -591,6 +635,7 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
   if (x->c % 4 || x->ld % 4 || x->ld < x->c || y->ld < y->c || x->n != y->n) return MI355_EINVAL;
   if (((uintptr_t)x->p & 15) || ((uintptr_t)wp & 15)) return MI355_EINVAL;
   if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift)) return MI355_EINVAL;
+  if (d->in_mode == MI355_IN_AFFINE_ACT && !(d->act_slope >= 0.f && d->act_slope <= 1.f)) return MI355_EINVAL;   // act(u) = max(u, slope*u)
   if (d->in_mode < 0 || d->in_mode > 3) return MI355_EINVAL;
   if ((d->in_mode == MI355_IN_S2D || d->out_mode == MI355_OUT_D2S) && d->kd != 1) return MI355_EUNSUPPORTED;
   if (d->in_mode == MI355_IN_S2D && d->out_mode == MI355_OUT_D2S) return MI355_EUNSUPPORTED;

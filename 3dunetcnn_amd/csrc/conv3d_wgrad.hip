@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
       float4 v = px[k];
       if (INMODE == MI355_IN_AFFINE_ACT) {
         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-        v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
-        v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+        // act(u) = max(u, slope * u) for 0 <= slope <= 1 (ReLU 0, LeakyReLU 0.01, identity 1): 2 packed ops per pair, no compare/select
+        v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
       }
       if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float4*>(lds_x + hv * 32 + 4 * sq) = v;
@@ -303,8 +303,8 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ring(WgradArgs a) {
     auto prologue = [&](float4 v) {
       if (INMODE == MI355_IN_AFFINE_ACT) {
         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-        v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
-        v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+        // act(u) = max(u, slope * u) for 0 <= slope <= 1 (ReLU 0, LeakyReLU 0.01, identity 1): 2 packed ops per pair, no compare/select
+        v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
       }
       return v;
     };
@@ -330,17 +330,22 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ring(WgradArgs a) {
       const bool more = z + 1 < ze;
       if (more) { load_x(z + 2); load_dy(z + 1); }
       SCHED_BARRIER();                 // the loads stay above the MFMA loop they overlap with
-      int soff[NTW];
+      // Operand addresses = one per-lane base per tap (ring slot, tap offset, channel li, and the lane's voxel parity `half`:
+      // voxel v = 2 ks + half sits in the same row as 2 ks, so half contributes a constant 32 floats) + a COMPILE-TIME offset per
+      // k-step: with the k loop fully unrolled every ds_read carries its offset as an immediate and the loop has no address
+      // arithmetic at all. (SQ counters, profiles/r2_sq_counters_conv_kernels.txt: MFMA-busy % + 4 x VALU instructions % ~ 94 % of the
+      // SIMD cycles in every conv kernel -- a VALU instruction costs its 4 issue cycles of matrix time, so they are counted.)
+      const float* xp[NTW];
 #pragma unroll
-      for (int ti = 0; ti < NTW; ++ti) soff[ti] = ((z + tdz[ti]) & 3) * XSLOT + tin[ti];
-      const float* dys = lds_dy + (z & 1) * DSLOT + li;
-#pragma unroll 4
+      for (int ti = 0; ti < NTW; ++ti) xp[ti] = lds_x + ((z + tdz[ti]) & 3) * XSLOT + tin[ti] + half * 32;
+      const float* dys = lds_dy + (z & 1) * DSLOT + li + half * 32;
+#pragma unroll
       for (int ks = 0; ks < PV / 2; ++ks) {
-        const int v = 2 * ks + half;
-        const float av = dys[v * 32];
-        const int xb = ((v / TX) * HX + v % TX) * 32;
+        const int v2 = 2 * ks;
+        const float av = dys[v2 * 32];
+        const int xb = ((v2 / TX) * HX + v2 % TX) * 32;
 #pragma unroll
-        for (int ti = 0; ti < NTW; ++ti) acc[ti] = MFMA_32x32x2(av, lds_x[soff[ti] + xb], acc[ti]);
+        for (int ti = 0; ti < NTW; ++ti) acc[ti] = MFMA_32x32x2(av, xp[ti][xb], acc[ti]);
       }
       SCHED_BARRIER();
       if (more) { commit_x(z + 2); commit_dy(z + 1); }
@@ -531,6 +536,7 @@ extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float
   if (((uintptr_t)x->p & 15) || ((uintptr_t)dy->p & 15)) return MI355_EINVAL;
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
   if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift)) return MI355_EINVAL;
+  if (d->in_mode == MI355_IN_AFFINE_ACT && !(d->act_slope >= 0.f && d->act_slope <= 1.f)) return MI355_EINVAL;
   if (d->precision < MI355_PREC_F32 || d->precision > MI355_PREC_BF16) return MI355_EINVAL;
   if (mi355_conv3d_c4_ok(x, d)) return mi355_conv3d_c4_wgrad_impl(x, dy, dw, d, ws, ws_bytes, stream);
   if (wgrad_uses_bf16(d)) return mi355_conv3d_wgrad_bf16_impl(x, dy, dw, d, ws, ws_bytes, stream);

@@ -151,8 +151,7 @@ __global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArg
               float4 t = t8[k][e];
               if (INMODE == MI355_IN_AFFINE_ACT) {
                 t.x = t.x * sc[0] + sh[0]; t.y = t.y * sc[1] + sh[1]; t.z = t.z * sc[2] + sh[2]; t.w = t.w * sc[3] + sh[3];
-                t.x = t.x > 0.f ? t.x : t.x * sl[0]; t.y = t.y > 0.f ? t.y : t.y * sl[1];
-                t.z = t.z > 0.f ? t.z : t.z * sl[2]; t.w = t.w > 0.f ? t.w : t.w * sl[3];
+                t.x = fmaxf(t.x, t.x * sl[0]); t.y = fmaxf(t.y, t.y * sl[1]); t.z = fmaxf(t.z, t.z * sl[2]); t.w = fmaxf(t.w, t.w * sl[3]);   // 0 <= slope <= 1
               }
               const bool ok = rowok && ix >= 0 && ix < a.W && 8 * oct + e < 18;
               v[e][0] = ok ? t.x : 0.f; v[e][1] = ok ? t.y : 0.f; v[e][2] = ok ? t.z : 0.f; v[e][3] = ok ? t.w : 0.f;

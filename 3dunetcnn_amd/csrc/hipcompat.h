@@ -19,6 +19,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // lane holds D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] for r in [0,16).
 #define MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) float name[]
+// register budget: the allocator must fit at least n waves per SIMD (512 unified registers / n, accumulators included)
+#define MIN_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n)))
 // v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+0..7] and B[k=8*(l>>5)+0..7][j=l&31] as 8 packed bf16
 // (16 bytes, carried here as uint4); same C/D map as the f32 form. 32 cycles per SIMD = 16x the f32 MFMA rate.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -193,8 +193,7 @@ __device__ __forceinline__ float4 proj_prologue(float4 v, const float* sc, const
   const float4 s4 = *reinterpret_cast<const float4*>(sc + (size_t)n * Cin + c);
   const float4 h4 = *reinterpret_cast<const float4*>(sh + (size_t)n * Cin + c);
   v.x = v.x * s4.x + h4.x; v.y = v.y * s4.y + h4.y; v.z = v.z * s4.z + h4.z; v.w = v.w * s4.w + h4.w;
-  v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
-  v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+  v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope); v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);   // 0 <= slope <= 1
   return v;
 }
 
@@ -336,6 +335,7 @@ extern "C" int mi355_proj_fwd(const mi355_act* x, const float* in_scale, const f
                               const float* bias, float* logits, int32_t cout, void* stream) {
   if (!act_ok(x) || !w || !logits || cout < 1 || cout > PROJ_MAX_COUT || x->c > PROJ_MAX_CIN) return MI355_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MI355_EINVAL;
+  if (in_scale && !(act_slope >= 0.f && act_slope <= 1.f)) return MI355_EINVAL;       // act(u) = max(u, slope * u)
   const long long V = (long long)x->d * x->h * x->w;
   const size_t lds = ((size_t)PROJ_TV * (x->c + 1) + (size_t)cout * x->c) * sizeof(float);
   if (lds > 64 * 1024) return MI355_EUNSUPPORTED;
@@ -349,6 +349,7 @@ extern "C" int mi355_proj_bwd(const mi355_act* x, const float* in_scale, const f
                               void* ws, size_t ws_bytes, void* stream) {
   if (!act_ok(x) || !w || !dlogits || !dw || !ws || cout < 1 || cout > PROJ_MAX_COUT || x->c > PROJ_MAX_CIN) return MI355_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MI355_EINVAL;
+  if (in_scale && !(act_slope >= 0.f && act_slope <= 1.f)) return MI355_EINVAL;
   if (dx && (!act_ok(dx) || !same_shape(x, dx))) return MI355_EINVAL;
   if (ws_bytes < mi355_proj_workspace(x, cout)) return MI355_EWORKSPACE;
   const long long V = (long long)x->d * x->h * x->w;

@@ -67,7 +67,8 @@ typedef struct mi355_conv_desc {
   int32_t stride;    /* 1 or 2 (applies to IN_PLAIN / IN_AFFINE_ACT) */
   int32_t pad;       /* front zero padding per axis (kd/2 for the reference's convs) */
   int32_t in_mode;   /* MI355_IN_* */
-  float act_slope;   /* IN_AFFINE_ACT: 0 -> ReLU (myronenko.py:13), 0.01 -> LeakyReLU (DynUNet) */
+  float act_slope;   /* IN_AFFINE_ACT: 0 -> ReLU (myronenko.py:13), 0.01 -> LeakyReLU (DynUNet). Must lie in [0, 1] (so must every entry of
+                        in_slope): the kernels evaluate act(u) as max(u, slope * u) */
   const float* in_scale; /* [n][cin]  IN_AFFINE_ACT */
   const float* in_shift; /* [n][cin]  IN_AFFINE_ACT */
   const float* bias;     /* [cout] or NULL (ConvTranspose3d / DynUNet output block keep a bias) */

@@ -5,15 +5,27 @@ here="$(cd "$(dirname "$0")" && pwd)"
 root="$(cd "$here/../.." && pwd)"
 src="$root/3dunetcnn_amd/csrc"
 objs=()
+pids=()
+rebuilt=0
 for f in "$src"/*.hip; do
   o="$here/build/$(basename "$f" .hip).o"
   mkdir -p "$here/build"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$here/emu.h" -nt "$o" ] || [ "$src/hipcompat.h" -nt "$o" ] || [ "$root/include/mi355_unet3d.h" -nt "$o" ]; then
     g++ -std=c++20 -O2 -g -fPIC -DMI355_EMU -Wno-unknown-pragmas -I"$here" -I"$src" -x c++ -c "$f" -o "$o" &
+    pids+=($!)
+    rebuilt=1
   fi
   objs+=("$o")
 done
-wait
-g++ -std=c++20 -O2 -g -fPIC -c "$here/emu.cpp" -o "$here/build/emu.o"
-g++ -shared -o "$here/libmi355unet3d_emu.so" "${objs[@]}" "$here/build/emu.o" -lpthread
-echo "built $here/libmi355unet3d_emu.so"
+for p in "${pids[@]}"; do wait "$p"; done      # a failed compile fails the script (plain `wait` would hide it)
+so="$here/libmi355unet3d_emu.so"
+if [ ! -f "$here/build/emu.o" ] || [ "$here/emu.cpp" -nt "$here/build/emu.o" ] || [ "$here/emu.h" -nt "$here/build/emu.o" ]; then
+  g++ -std=c++20 -O2 -g -fPIC -c "$here/emu.cpp" -o "$here/build/emu.o"
+  rebuilt=1
+fi
+if [ "$rebuilt" = 1 ] || [ ! -f "$so" ]; then
+  # link beside the target and rename: parallel test workers that call this script never see a half-written library
+  g++ -shared -o "$so.$$" "${objs[@]}" "$here/build/emu.o" -lpthread
+  mv -f "$so.$$" "$so"
+fi
+echo "built $so"

@@ -251,4 +251,5 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetc
 #define LAUNCH_CHECK() 0
 #define SET_MAX_DYN_LDS(kernel, bytes) do {} while (0)
 #define SCHED_BARRIER() do {} while (0)
+#define MIN_WAVES_PER_SIMD(n)
 #define SLEEP_64CLK(n) do {} while (0)
