@@ -74,7 +74,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[NS]) {
 
 // FUSE: 0 plain epilogue, 1 + moment records of the output, 2 + norm-backward sums (dgrad): as conv3d_fwd.hip
 template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT, int INMODE, int FUSE = 0>
-__global__ __launch_bounds__(256) void conv3d_k3_bf16(ConvBArgs a) {
+// LDS holds 3 workgroups of the largest tile: the register allocator must fit 3 waves per SIMD too (several variants sat one or two
+// registers above), except the 4-tile waves with a norm prologue or the norm-backward epilogue, which would spill.
+__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD((MT * NT >= 4 && (INMODE == MI355_IN_AFFINE_ACT || FUSE == 2)) ? 2 : 3)
+void conv3d_k3_bf16(ConvBArgs a) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TZ * TY / 2 == WM * MT, "M tiles (2 x-rows of 16 voxels) must equal WM*MT");
   constexpr int TX = 16;
@@ -151,46 +154,53 @@ __global__ __launch_bounds__(256) void conv3d_k3_bf16(ConvBArgs a) {
           }
         }
       }
-      // Two phases: (1) every global load of this thread's staging units is issued from a clamped, always-valid address
-      // -- no branch around a load, so all of them are in flight together instead of one dependent round trip per unit --
-      // (2) mask / normalise / split / write to LDS.
+      // Batches of UB staging units, two phases each: (1) the global loads of the batch are issued from clamped, always-valid
+      // addresses -- no branch around a load, so they are in flight together instead of one dependent round trip per unit --
+      // (2) mask / normalise / split / write to LDS. One batch of all 11 units held 88 registers and cost the norm-prologue
+      // variants a wave of occupancy (2 instead of 3 workgroups per CU: 0.88 vs 0.63 ms on the 32-channel 128^3 layer).
       constexpr int UP = (HV * OCT + 255) / 256;       // staging units (one halo voxel x 8 channels) per thread
+      constexpr int UB = UP <= 6 ? UP : (UP + 1) / 2;
       const int c0q = v0ok ? c : 0, c1q = v1ok ? c + 4 : c0q;
-      float4 ld0[UP], ld1[UP];
 #pragma unroll
-      for (int k = 0; k < UP; ++k) {
-        int hv = sv0 + k * (256 / OCT);
-        if (hv >= HV) hv = HV - 1;
-        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
-        int iz = tz0 - a.pad + hz, iy = ty0 - a.pad + hy, ix = tx0 - a.pad + hx;
-        iz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
-        iy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
-        ix = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
-        const float* src = a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld;
-        ld0[k] = *reinterpret_cast<const float4*>(src + c0q);
-        ld1[k] = *reinterpret_cast<const float4*>(src + c1q);
-      }
+      for (int k0 = 0; k0 < UP; k0 += UB) {
+        float4 ld0[UB], ld1[UB];
 #pragma unroll
-      for (int k = 0; k < UP; ++k) {
-        const int hv = sv0 + k * (256 / OCT);
-        if (hv >= HV) continue;
-        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
-        const int iz = tz0 - a.pad + hz, iy = ty0 - a.pad + hy, ix = tx0 - a.pad + hx;
-        const bool inb = iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi;
-        float v[8] = {ld0[k].x, ld0[k].y, ld0[k].z, ld0[k].w, ld1[k].x, ld1[k].y, ld1[k].z, ld1[k].w};
-        if (INMODE == MI355_IN_AFFINE_ACT) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float u = v[e] * sc[e] + sh[e];
-            v[e] = fmaxf(u, u * sl[e]);          // act(u) for 0 <= slope <= 1
-          }
+        for (int kk = 0; kk < UB; ++kk) {
+          if (k0 + kk >= UP) continue;
+          int hv = sv0 + (k0 + kk) * (256 / OCT);
+          if (hv >= HV) hv = HV - 1;
+          const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+          int iz = tz0 - a.pad + hz, iy = ty0 - a.pad + hy, ix = tx0 - a.pad + hx;
+          iz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
+          iy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
+          ix = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
+          const float* src = a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld;
+          ld0[kk] = *reinterpret_cast<const float4*>(src + c0q);
+          ld1[kk] = *reinterpret_cast<const float4*>(src + c1q);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { if (!(inb && v0ok)) v[e] = 0.f; if (!(inb && v1ok)) v[4 + e] = 0.f; }
-        uint4 pl[NS];
-        split8<NS>(v, pl);
+        for (int kk = 0; kk < UB; ++kk) {
+          if (k0 + kk >= UP) continue;
+          const int hv = sv0 + (k0 + kk) * (256 / OCT);
+          if (hv >= HV) continue;
+          const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+          const int iz = tz0 - a.pad + hz, iy = ty0 - a.pad + hy, ix = tx0 - a.pad + hx;
+          const bool inb = iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi;
+          float v[8] = {ld0[kk].x, ld0[kk].y, ld0[kk].z, ld0[kk].w, ld1[kk].x, ld1[kk].y, ld1[kk].z, ld1[kk].w};
+          if (INMODE == MI355_IN_AFFINE_ACT) {
 #pragma unroll
-        for (int p = 0; p < NS; ++p) lds[hv * VSQ + p * OCT + so] = pl[p];
+            for (int e = 0; e < 8; ++e) {
+              const float u = v[e] * sc[e] + sh[e];
+              v[e] = fmaxf(u, u * sl[e]);          // act(u) for 0 <= slope <= 1
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { if (!(inb && v0ok)) v[e] = 0.f; if (!(inb && v1ok)) v[4 + e] = 0.f; }
+          uint4 pl[NS];
+          split8<NS>(v, pl);
+#pragma unroll
+          for (int p = 0; p < NS; ++p) lds[hv * VSQ + p * OCT + so] = pl[p];
+        }
       }
     }
     __syncthreads();
@@ -290,6 +300,19 @@ __global__ __launch_bounds__(256) void conv3d_k3_bf16(ConvBArgs a) {
       for (int mt = 0; mt < MT; ++mt) {
         const int m = wm * MT + mt;
         const int mz = m / (TY / 2), my0 = (m % (TY / 2)) * 2;
+        // FUSE 2: the 16 reads of the normalised tensor of this tile first, from clamped addresses (see conv3d_fwd.hip)
+        float gxv[16];
+        if constexpr (FUSE == 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            int rr, rtx;
+            mtile_lane(row, rr, rtx);
+            int oz = tz0 + mz, oy = ty0 + my0 + rr, ox = tx0 + rtx;
+            oz = oz < a.Do ? oz : a.Do - 1; oy = oy < a.Ho ? oy : a.Ho - 1; ox = ox < a.Wo ? ox : a.Wo - 1;
+            gxv[r] = a.g.gx[((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.g.gxld + coc];
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -307,7 +330,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_bf16(ConvBArgs a) {
             const float t = v - K0;
             s0 += t; s1 += t * t;
           } else {
-            const float xv = a.g.gx[ovox * a.g.gxld + co];
+            const float xv = gxv[r];
             const float u = xv * gsc + gsh;
             const float du = u > 0.f ? v : v * a.g.gslope;
             s0 += du; s1 += du * ((xv - gmean) * grstd);
