@@ -130,7 +130,25 @@ void conv3d_k3_bf16(ConvBArgs a) {
   const int CQ8 = a.CinP / 8;
   const int so = tid % OCT, sv0 = tid / OCT;
 
+  const unsigned lane_b = (unsigned)(half * NS * a.CoutP + co_base + li) * 16u;      // this lane's byte offset inside a weight slab
+  const size_t tap_slab = (size_t)CQ8 * NS * a.CoutP;                                // uint4 per tap
+  auto load_b = [&](uint4 (&bf)[J][NS][NT], const uint4* slab, int jn_) {           // slab: tap and chunk applied, wave-uniform
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int p = 0; p < NS; ++p)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          bf[j][p][nt] = make_uint4(0u, 0u, 0u, 0u);
+          if (j < jn_)
+            bf[j][p][nt] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(slab + ((size_t)(2 * j) * NS + p) * a.CoutP + nt * 32) + lane_b);
+        }
+  };
+
   for (int c0 = 0; c0 < a.CinP; c0 += KC) {
+    const int jn = (a.CinP - c0) / 16 < J ? (a.CinP - c0) / 16 : J;   // k-steps of this chunk that exist; wave-uniform
+    const uint4* wpc = a.wp + (size_t)(c0 / 8) * NS * a.CoutP;          // this chunk's channel octets inside every tap slab
+    uint4 b0[J][NS][NT], b1[J][NS][NT], b2[J][NS][NT];
     // ---- stage the haloed input tile for channels [c0, c0+KC): normalise/activate, split into bf16 planes ----
     __syncthreads();
     {
@@ -203,49 +221,122 @@ void conv3d_k3_bf16(ConvBArgs a) {
         }
       }
     }
+    load_b(b0, wpc, jn);              // taps 0 and 1: requested once the staging registers are free, in flight across the barrier
+    load_b(b1, wpc + tap_slab, jn);
     __syncthreads();
 
-    // ---- 27 taps x J k-steps; B fragments prefetched one step ahead ----
-    const int jn = (a.CinP - c0) / 16 < J ? (a.CinP - c0) / 16 : J;   // wave-uniform
-    const int cq0 = c0 / 8 + half;
-    const int nsteps = 27 * jn;
-    uint4 bcur[NS][NT], bnext[NS][NT];
+    // ---- 27 taps x J k-steps. B fragments (weights, L1/L2 resident) are requested TWO TAPS ahead of the MFMAs that use them, in
+    // three register sets that rotate through an unroll-by-three body (27 = 9 x 3): a bf16 k-step is only 32 * MT * NT matrix
+    // cycles, so one step of lead (the first version) left every step waiting for its weights. Addresses = wave-uniform slab
+    // pointer + one 32-bit lane offset; no "current = next" moves, no tap / k-step counters in vector registers.
+    auto run_tap = [&](const uint4 (&bf)[J][NS][NT], int tap) {
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;      // wave-uniform: scalar ALU
+      const int toff = ((dz * HY + dy) * HX + dx) * VSQ;
 #pragma unroll
-    for (int p = 0; p < NS; ++p)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        bcur[p][nt] = a.wp[((size_t)(0 * CQ8 + cq0) * NS + p) * a.CoutP + co_base + nt * 32 + li];
-    int tap = 0, j = 0;
-    for (int s = 0; s < nsteps; ++s) {
-      int jnx = j + 1, tapn = tap;
-      if (jnx == jn) { jnx = 0; tapn = tap + 1; }
-      const int tl = tapn < 27 ? tapn : 26;       // the last step prefetches a valid (unused) address
-#pragma unroll
-      for (int p = 0; p < NS; ++p)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          bnext[p][nt] = a.wp[((size_t)(tl * CQ8 + cq0 + 2 * jnx) * NS + p) * a.CoutP + co_base + nt * 32 + li];
-      SCHED_BARRIER();     // the B loads of the NEXT step stay above this step's MFMAs (the scheduler otherwise sinks them to their use)
-      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-      const int toff = ((dz * HY + dy) * HX + dx) * VSQ + 2 * j;
-      uint4 af[MT][NS];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int p = 0; p < NS; ++p) af[mt][p] = lds[abase[mt] + toff + p * OCT];
-#pragma unroll
-      for (int q = 0; q < P; ++q)
+      for (int j = 0; j < J; ++j) {
+        if (j >= jn) continue;
+        uint4 af[MT][NS];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = MFMA_32x32x16_BF16(af[mt][Products<NS>::pa[q]], bcur[Products<NS>::pb[q]][nt], acc[mt][nt]);
+          for (int p = 0; p < NS; ++p) af[mt][p] = lds[abase[mt] + toff + 2 * j + p * OCT];
 #pragma unroll
-      for (int p = 0; p < NS; ++p)
+        for (int q = 0; q < P; ++q)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bcur[p][nt] = bnext[p][nt];
-      tap = tapn; j = jnx;
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = MFMA_32x32x16_BF16(af[mt][Products<NS>::pa[q]], bf[j][Products<NS>::pb[q]][nt], acc[mt][nt]);
+      }
+    };
+#pragma unroll 1
+    for (int tap = 0; tap < 27; tap += 3) {
+      load_b(b2, wpc + tap_slab * (tap + 2), jn);
+      SCHED_BARRIER();      // the requests stay above the MFMAs (the scheduler otherwise sinks them to their use)
+      run_tap(b0, tap);
+      if (tap + 3 < 27) load_b(b0, wpc + tap_slab * (tap + 3), jn);      // wave-uniform branches
+      SCHED_BARRIER();
+      run_tap(b1, tap + 1);
+      if (tap + 4 < 27) load_b(b1, wpc + tap_slab * (tap + 4), jn);
+      SCHED_BARRIER();
+      run_tap(b2, tap + 2);
     }
+  }
+
+  // ---- epilogue, interior tiles (all of a 128^3 layer's but its ragged edge): accumulator register r of an M tile is x position r of
+  // x-row ((0b0110 >> (r >> 2)) & 1) ^ half (mtile_lane, inverted), so a lane needs two row pointers per tile and wave-uniform
+  // offsets r * ld -- the general path below recomputes the lane map, three bound checks and two 64-bit voxel indices per value,
+  // which cost more vector-ALU time than the whole MFMA phase of a bf16 tile. ----
+  const bool interior = tz0 + TZ <= a.Do && ty0 + TY <= a.Ho && tx0 + TX <= a.Wo && a.offz == 0 && a.offy == 0 && a.offx == 0 &&
+                        a.yD == a.Do && a.yH == a.Ho && a.yW == a.Wo;                      // workgroup-uniform
+  if (interior) {
+    constexpr int K = FUSE == 1 ? 3 : 2;
+    float vals[NT][K];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = co_base + nt * 32 + li;
+      const bool cov = co < a.Cout;
+      const int coc = cov ? co : a.Cout - 1;
+      float bs = 0.f, cs = 1.f;
+      if (a.bias) bs = a.bias[coc];
+      if (a.out_chscale) cs = a.out_chscale[(size_t)n * a.Cout + coc];
+      float K0 = 0.f, s0 = 0.f, s1 = 0.f, gsc = 1.f, gsh = 0.f, gmean = 0.f, grstd = 1.f;
+      if constexpr (FUSE == 2) {
+        const int grp = coc / (a.Cout / a.g.ggroups);
+        gsc = a.g.gscale[(size_t)n * a.Cout + coc]; gsh = a.g.gshift[(size_t)n * a.Cout + coc];
+        gmean = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = wm * MT + mt;
+        const int mz = m / (TY / 2), my0 = (m % (TY / 2)) * 2;
+        const size_t vrow = (((size_t)n * a.Do + tz0 + mz) * a.Ho + ty0 + my0) * a.Wo + tx0;      // x-row 0 of the tile, x = 0
+        const size_t vA = vrow + (size_t)half * a.Wo, vB = vrow + (size_t)(half ^ 1) * a.Wo;      // this lane's two x-rows
+        float* yA = a.y + vA * a.yld + coc;
+        float* yB = a.y + vB * a.yld + coc;
+        float gxv[16];
+        if constexpr (FUSE == 2) {
+          const float* gA = a.g.gx + vA * a.g.gxld + coc;
+          const float* gB = a.g.gx + vB * a.g.gxld + coc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gxv[r] = (((0x6 >> (r >> 2)) & 1) ? gB : gA)[(size_t)r * a.g.gxld];
+        }
+        const float* rA = a.res ? a.res + vA * a.resld + coc : nullptr;
+        const float* rB = a.res ? a.res + vB * a.resld + coc : nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool rowb = (0x6 >> (r >> 2)) & 1;
+          float v = acc[mt][nt][r] + bs;
+          if (a.res) v += (rowb ? rB : rA)[(size_t)r * a.resld];
+          v *= cs;
+          if (cov) (rowb ? yB : yA)[(size_t)r * a.yld] = v;
+          if constexpr (FUSE == 1) {
+            if (mt == 0 && r == 0) K0 = v;
+            const float t = v - K0;
+            s0 += t; s1 += t * t;
+          } else if constexpr (FUSE == 2) {
+            const float xv = gxv[r];
+            const float u = xv * gsc + gsh;
+            const float du = u > 0.f ? v : v * a.g.gslope;
+            s0 += du; s1 += du * ((xv - gmean) * grstd);
+          }
+        }
+      }
+      if constexpr (FUSE == 1) {
+        const float c = cov ? (float)(MT * 16) : 0.f;
+        const float m2 = s1 - s0 * s0 / (float)(MT * 16);
+        vals[nt][0] = c; vals[nt][1] = cov ? s0 + c * K0 : 0.f; vals[nt][2] = (cov && m2 > 0.f) ? m2 : 0.f;
+      } else if constexpr (FUSE == 2) {
+        vals[nt][0] = cov ? s0 : 0.f; vals[nt][1] = cov ? s1 : 0.f;
+      }
+    }
+    if constexpr (FUSE != 0) {
+      const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
+      const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
+      float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * K;
+      gn_fuse_reduce_store<K, NT, WM, WN>(vals, lds_f, wm, wn, half, li, tid, dst, cot * (32 * WN * NT), a.Cout);
+    }
+    return;
   }
 
   // ---- epilogue: bias, residual, dropout scale, windowed store (channel-contiguous across lanes) ----
@@ -437,7 +528,7 @@ static int launch_b(ConvBArgs& a, int in_mode, void* stream) {
 template <int NS>
 static int dispatch_ns(ConvBArgs& a, int in_mode, long long vox, void* stream) {
   // big volumes: 4x4x16 tiles (256 voxels), 4 waves along M; small: 2x4x16 tiles (128 voxels) so the grid still fills the chip
-  constexpr int J = NS == 1 ? 2 : 1;
+  constexpr int J = NS == 1 ? 2 : 1;      // (one 16-channel k-step per chunk for NS = 1 too: more workgroups per CU, measured 10 % slower)
   if constexpr (NS < 3) {     // the 3-plane tile of the big configuration would exceed the 64 KiB LDS window
     if (vox >= 256LL * 512) {
       if (a.Cout > 32) return launch_b<4, 4, J, NS, 4, 1, 2, 2>(a, in_mode, stream);
