@@ -343,6 +343,86 @@ void conv3d_mfma(ConvArgs a) {
     }
   }
 
+  // ---- epilogue, interior tiles (everything but the ragged edge of a layer): accumulator register r of M tile m is voxel
+  // tv = 32 m + (r & 3) + 8 (r >> 2) + 4 half of the tile, i.e. x = 4 half + (r & 3) and 8-voxel row 4 m + (r >> 2): one base
+  // pointer per lane and tile plus wave-uniform offsets. The general path below spends ~30 vector-ALU instructions per stored
+  // value on the lane map, the bound checks and two 64-bit voxel indices. ----
+  // (not for the 4-tile waves with the norm-backward sums: both paths in one kernel spill there; same speed either way)
+  if constexpr (!ZIP && ((TX == 8 && TY % 4 == 0) || (KD == 1 && TX == 256 && TY == 1 && TZ == 1)) && !(FUSE == 2 && MT * NT >= 4)) {
+    const bool interior = tz0 + TZ <= a.Do && ty0 + TY <= a.Ho && tx0 + TX <= a.Wo && a.offz == 0 && a.offy == 0 && a.offx == 0 &&
+                          a.yD == a.Do && a.yH == a.Ho && a.yW == a.Wo && !(KD == 1 && a.outmode == MI355_OUT_D2S);      // workgroup-uniform
+    if (interior) {
+      constexpr int K = FUSE == 1 ? 3 : 2;
+      float vals[NT][K];
+      const size_t rowstep = TX == 8 ? (size_t)a.Wo : 8;      // voxels between accumulator rows r and r + 4 (1x1x1 tiles are flat)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = co_base + nt * 32 + li;
+        const bool cov = co < a.Cout;
+        const int coc = cov ? co : a.Cout - 1;
+        float bs = 0.f, cs = 1.f;
+        if (a.bias) bs = a.bias[coc];
+        if (a.out_chscale) cs = a.out_chscale[(size_t)n * a.Cout + coc];
+        float K0 = 0.f, s0 = 0.f, s1 = 0.f, gsc = 1.f, gsh = 0.f, gmean = 0.f, grstd = 1.f;
+        if constexpr (FUSE == 2) {
+          const int grp = coc / (a.Cout / a.g.ggroups);
+          gsc = a.g.gscale[(size_t)n * a.Cout + coc]; gsh = a.g.gshift[(size_t)n * a.Cout + coc];
+          gmean = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int tv0 = (wm * MT + mt) * 32 + 4 * half;      // this lane's voxel for r = 0
+          const size_t v0 = (((size_t)n * a.Do + tz0 + tv0 / (TY * TX)) * a.Ho + ty0 + (tv0 / TX) % TY) * a.Wo + tx0 + tv0 % TX;
+          float* yp = a.y + v0 * a.yld + coc;
+          const float* rp = a.res ? a.res + v0 * a.resld + coc : nullptr;
+          // FUSE 2: the 16 reads of the normalised tensor of this tile go out ahead of their use
+          constexpr int GB = 16;
+          const float* gp = FUSE == 2 ? a.g.gx + v0 * a.g.gxld + coc : nullptr;
+#pragma unroll
+          for (int r0 = 0; r0 < 16; r0 += GB) {
+            float gxv[GB];
+            if constexpr (FUSE == 2) {
+#pragma unroll
+              for (int r = r0; r < r0 + GB; ++r) gxv[r - r0] = gp[((size_t)(r >> 2) * rowstep + (r & 3)) * a.g.gxld];
+            }
+#pragma unroll
+            for (int r = r0; r < r0 + GB; ++r) {
+              const size_t eo = (size_t)(r >> 2) * rowstep + (r & 3);      // wave-uniform
+              float v = acc[mt][nt][r] + bs;
+              if (a.res) v += rp[eo * a.resld];
+              v *= cs;
+              if (cov) yp[eo * a.yld] = v;
+              if constexpr (FUSE == 1) {
+                if (mt == 0 && r == 0) K0 = v;
+                const float t = v - K0;
+                s0 += t; s1 += t * t;
+              } else if constexpr (FUSE == 2) {
+                const float xv = gxv[r - r0];
+                const float u = xv * gsc + gsh;
+                const float du = u > 0.f ? v : v * a.g.gslope;
+                s0 += du; s1 += du * ((xv - gmean) * grstd);
+              }
+            }
+          }
+        }
+        if constexpr (FUSE == 1) {
+          const float c = cov ? (float)(MT * 16) : 0.f;
+          const float m2 = s1 - s0 * s0 / (float)(MT * 16);
+          vals[nt][0] = c; vals[nt][1] = cov ? s0 + c * K0 : 0.f; vals[nt][2] = (cov && m2 > 0.f) ? m2 : 0.f;
+        } else if constexpr (FUSE == 2) {
+          vals[nt][0] = cov ? s0 : 0.f; vals[nt][1] = cov ? s1 : 0.f;
+        }
+      }
+      if constexpr (FUSE != 0) {
+        const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
+        const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
+        float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * K;
+        gn_fuse_reduce_store<K, NT, WM, WN>(vals, lds, wm, wn, half, li, tid, dst, cot * (32 * WN * NT), a.Cout);
+      }
+      return;
+    }
+  }
+
   // ---- epilogue: bias, residual, dropout scale, windowed store ----
   if constexpr (FUSE == 0) {
 #pragma unroll
