@@ -269,7 +269,12 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    if not args.no_kernel_events:
+    # Per-launch HIP events go into the timed region only when its launches are serialized (MI355_SIDE_STREAM=0: the rocprofv3 command
+    # of profiles/): with the weight gradients on a second stream (the default) a launch's duration is not its own, the roofline is
+    # measured on extra steps after the timed region (below), and ~1200 event records per step inside the timed region are pure
+    # perturbation (bf16, batch 4: 57.6 -> 75.0 ms/step with them).
+    side = bool(getattr(model, "backward_side_stream", False)) and dev.type == "cuda"
+    if not args.no_kernel_events and not side:
         be.prof = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -286,7 +291,7 @@ def main():
     prof = prof_timed
     roof_note = "HIP events over the timed region"
     ROOF_STEPS = 3
-    if prof_timed is not None and getattr(model, "backward_side_stream", False) and dev.type == "cuda":
+    if not args.no_kernel_events and side:
         model.backward_side_stream = False
         step()
         barrier()
