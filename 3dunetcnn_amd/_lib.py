@@ -23,6 +23,13 @@ class MiGnBwdFuse(Structure):
                 ("groups", c_int32), ("act_slope", c_float), ("partials_out", c_void_p)]
 
 
+class MiDiceOpts(Structure):
+    """mi355_dice_opts: the monai DiceLoss options beyond the shipped configuration."""
+    _fields_ = [("activation", c_int32), ("target_kind", c_int32), ("batch", c_int32), ("squared_pred", c_int32),
+                ("include_background", c_int32), ("jaccard", c_int32), ("reduction", c_int32),
+                ("smooth_nr", c_float), ("smooth_dr", c_float), ("class_weight", c_void_p)]
+
+
 class MiConvDesc(Structure):
     _fields_ = [("kd", c_int32), ("stride", c_int32), ("pad", c_int32), ("in_mode", c_int32),
                 ("act_slope", c_float),
@@ -94,6 +101,10 @@ SIGNATURES = {
     "mi355_dice_workspace": (c_size_t, [c_int32, c_int32, c_int64]),
     "mi355_dice_fwd_bwd": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_float, c_float, c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "mi355_dice_ex_forward": (ctypes.c_int, [POINTER(MiDiceOpts), c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_size_t,
+                                             c_void_p]),
+    "mi355_dice_ex_backward": (ctypes.c_int, [POINTER(MiDiceOpts), c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_int32, c_void_p,
+                                              c_void_p, c_void_p]),
     "mi355_ce_workspace": (c_size_t, [c_int64]),
     "mi355_ce_fwd_bwd": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_float, c_void_p, c_int32,
                                         c_void_p, c_int32, c_float, c_void_p, c_size_t, c_void_p]),

@@ -52,8 +52,12 @@ __global__ void dice_partial_kernel(const float* logits, const void* target, int
 //            class) is replaced by the largest finite weight of that sample; f = 1 - (2 sum_c w_c I_c + snr)/(sum_c w_c (G_c + P_c) + sdr);
 //            loss = mean over samples.
 // c0 = 1 when include_background=False: channel 0 is left out of the loss (zero gradient).
+// jaccard (variant 0): denominator 2 (D - I) instead of D. class_w: one factor per counted class (or NULL). reduction 0 mean / 1 sum /
+// 2 none: with "none" loss[] receives one value per term (n-major, counted classes only; one row with batch) and the coefficients are those
+// of sum (the caller applies the upstream gradient of every term).
 __global__ void dice_finalize_kernel(const float* ws, int B, int N, int C, int batch, float snr, float sdr, float grad_scale,
-                                     int variant, int c0, float* stats, float* coef, float* loss) {
+                                     int variant, int c0, float* stats, float* coef, float* loss,
+                                     int jaccard, const float* class_w, int reduction) {
   __shared__ double sums[3 * 1024];
   __shared__ double fsum[256];
   const int NC = N * C;
@@ -67,7 +71,7 @@ __global__ void dice_finalize_kernel(const float* ws, int B, int N, int C, int b
   double f = 0.0;
   const int Ce = C - c0;                                  // channels that count
   if (variant == 0) {
-    const int K = batch ? Ce : N * Ce;                    // number of terms in the mean
+    const int K = reduction != 0 ? 1 : (batch ? Ce : N * Ce);      // number of terms in the mean
     for (int i = threadIdx.x; i < NC; i += blockDim.x) {
       const int c = i % C;
       if (c < c0) { coef[2 * i] = 0.f; coef[2 * i + 1] = 0.f; continue; }
@@ -76,10 +80,18 @@ __global__ void dice_finalize_kernel(const float* ws, int B, int N, int C, int b
         I = 0.0; D = 0.0;
         for (int n = 0; n < N; ++n) { I += sums[3 * (n * C + c)]; D += sums[3 * (n * C + c) + 1] + sums[3 * (n * C + c) + 2]; }
       } else { I = sums[3 * i]; D = sums[3 * i + 1] + sums[3 * i + 2]; }
-      const double den = D + (double)sdr;
-      coef[2 * i] = (float)((double)grad_scale * 2.0 / (K * den));
-      coef[2 * i + 1] = (float)((double)grad_scale * (2.0 * I + (double)snr) / (K * den * den));
-      if (!batch || i < C) f += (1.0 - (2.0 * I + (double)snr) / den) / K;
+      const double w = class_w ? (double)class_w[c - c0] : 1.0;
+      const double num = 2.0 * I + (double)snr;
+      const double den = (jaccard ? 2.0 * (D - I) : D) + (double)sdr;
+      const double s = (double)grad_scale * w / K;
+      // f = 1 - num / den:  df/dI = -(2 den - num dden/dI) / den^2,  df/dD = num dden/dD / den^2;  dL/dp = -a y + b (1 | 2p)
+      coef[2 * i] = (float)(s * (jaccard ? 2.0 * (den + num) : 2.0 * den) / (den * den));
+      coef[2 * i + 1] = (float)(s * (jaccard ? 2.0 : 1.0) * num / (den * den));
+      const double term = w * (1.0 - num / den);
+      if (!batch || i < C) {
+        if (reduction == 2) loss[batch ? c - c0 : (i / C) * Ce + c - c0] = (float)term;
+        else f += term / K;
+      }
     }
   } else {
     const int K = batch ? 1 : N;
@@ -108,7 +120,7 @@ __global__ void dice_finalize_kernel(const float* ws, int B, int N, int C, int b
   fsum[threadIdx.x] = f;
   __syncthreads();
   for (int s = blockDim.x / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) fsum[threadIdx.x] += fsum[threadIdx.x + s]; __syncthreads(); }
-  if (threadIdx.x == 0) loss[0] = (float)fsum[0];
+  if (threadIdx.x == 0 && !(variant == 0 && reduction == 2)) loss[0] = (float)fsum[0];
 }
 
 __global__ void dice_grad_kernel(const float* logits, const void* target, int target_u8, long long V, int NC, int sigmoid, int squared,
@@ -122,6 +134,89 @@ __global__ void dice_grad_kernel(const float* logits, const void* target, int ta
     float g = -coef[2 * nc] * y + coef[2 * nc + 1] * (squared ? 2.f * p : 1.f);
     if (sigmoid) g *= p * (1.f - p);
     dlogits[idx] = g;
+  }
+}
+
+
+// ---- extended Dice (monai DiceLoss options beyond the shipped configuration: softmax, to_onehot_y, jaccard, weight, reduction) ----
+#define DICE_MAX_C 16
+__device__ __forceinline__ float dice_y(const void* target, int kind, long long V, int C, int n, int c, long long v) {
+  if (kind == MI355_DICE_TARGET_LABELS) return ((const int*)target)[(size_t)n * V + v] == c ? 1.f : 0.f;
+  const size_t i = ((size_t)n * C + c) * V + v;
+  return kind == MI355_DICE_TARGET_U8 ? (float)((const unsigned char*)target)[i] : ((const float*)target)[i];
+}
+// p[c] = act(z[c]) for the C channels of one voxel
+__device__ __forceinline__ void dice_probs(const float* z, long long V, int C, int act, long long v, float (&p)[DICE_MAX_C]) {
+  if (act == MI355_DICE_ACT_SOFTMAX) {
+    float m = -3.4e38f;
+    for (int c = 0; c < C; ++c) { p[c] = z[(size_t)c * V + v]; m = p[c] > m ? p[c] : m; }
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) { p[c] = expf(p[c] - m); sum += p[c]; }
+    const float inv = 1.f / sum;
+    for (int c = 0; c < C; ++c) p[c] *= inv;
+  } else {
+    for (int c = 0; c < C; ++c) { const float zz = z[(size_t)c * V + v]; p[c] = act == MI355_DICE_ACT_SIGMOID ? sigmoidf_(zz) : zz; }
+  }
+}
+
+// grid (B, N): one block = one voxel range of one sample, all channels; partial layout = dice_partial_kernel's [n*C + c][B][3]
+__global__ void dice_ex_partial_kernel(const float* logits, const void* target, int kind, long long V, int C, int act, int squared, float* ws) {
+  __shared__ float red[256];
+  const int n = blockIdx.y, blk = blockIdx.x, B = gridDim.x;
+  const long long per = (V + B - 1) / B;
+  const long long vb = (long long)blk * per, ve = vb + per < V ? vb + per : V;
+  const float* z = logits + (size_t)n * C * V;
+  float sI[DICE_MAX_C], sP[DICE_MAX_C], sY[DICE_MAX_C];
+  for (int c = 0; c < C; ++c) { sI[c] = 0.f; sP[c] = 0.f; sY[c] = 0.f; }
+  for (long long v = vb + threadIdx.x; v < ve; v += blockDim.x) {
+    float p[DICE_MAX_C];
+    dice_probs(z, V, C, act, v, p);
+    for (int c = 0; c < C; ++c) {
+      const float y = dice_y(target, kind, V, C, n, c, v);
+      sI[c] += p[c] * y;
+      sP[c] += squared ? p[c] * p[c] : p[c];
+      sY[c] += squared ? y * y : y;
+    }
+  }
+  for (int c = 0; c < C; ++c)
+    for (int k = 0; k < 3; ++k) {
+      __syncthreads();
+      red[threadIdx.x] = k == 0 ? sI[c] : k == 1 ? sP[c] : sY[c];
+      __syncthreads();
+      for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) ws[(((size_t)n * C + c) * B + blk) * 3 + k] = red[0];
+    }
+}
+
+// dlogits = sum over terms of upstream(term) * d(term)/dlogits. upstream: NULL (1 for every term), one value (mean / sum) or one per
+// term ("none": n-major over the counted classes; one row with batch).
+__global__ void dice_ex_grad_kernel(const float* logits, const void* target, int kind, long long V, int N, int C, int act, int squared,
+                                    const float* coef, const float* upstream, int n_up, int batch, int c0, float* dlogits) {
+  const long long total = (long long)N * V;
+  const int Ce = C - c0;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(idx / V);
+    const long long v = idx - (long long)n * V;
+    const float* z = logits + (size_t)n * C * V;
+    float p[DICE_MAX_C], g[DICE_MAX_C];
+    dice_probs(z, V, C, act, v, p);
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float up = 1.f;
+      if (upstream) up = n_up == 1 ? upstream[0] : (c >= c0 ? upstream[batch ? c - c0 : n * Ce + c - c0] : 0.f);
+      const float y = dice_y(target, kind, V, C, n, c, v);
+      g[c] = up * (-coef[2 * (n * C + c)] * y + coef[2 * (n * C + c) + 1] * (squared ? 2.f * p[c] : 1.f));
+      dot += g[c] * p[c];
+    }
+    for (int c = 0; c < C; ++c) {
+      float d = g[c];
+      if (act == MI355_DICE_ACT_SIGMOID) d *= p[c] * (1.f - p[c]);
+      else if (act == MI355_DICE_ACT_SOFTMAX) d = p[c] * (g[c] - dot);
+      dlogits[((size_t)n * C + c) * V + v] = d;
+    }
   }
 }
 
@@ -234,7 +329,7 @@ extern "C" int mi355_dice_fwd_bwd(const float* logits, const void* target, int32
   LAUNCH(dice_partial_kernel, dim3(B, NC), dim3(256), 0, stream, logits, target, target_is_u8, (long long)voxels, sigmoid, squared_pred, part);
   int rc = LAUNCH_CHECK(); if (rc) return rc;
   LAUNCH(dice_finalize_kernel, dim3(1), dim3(256), 0, stream, (const float*)part, B, n, c, batch, smooth_nr, smooth_dr, grad_scale, variant,
-         include_background ? 0 : 1, stats, coef, loss);
+         include_background ? 0 : 1, stats, coef, loss, 0, (const float*)nullptr, 0);
   rc = LAUNCH_CHECK(); if (rc) return rc;
   if (dlogits) {
     const long long total = (long long)NC * voxels;
@@ -244,6 +339,47 @@ extern "C" int mi355_dice_fwd_bwd(const float* logits, const void* target, int32
     rc = LAUNCH_CHECK();
   }
   return rc;
+}
+
+static int dice_ex_check(const mi355_dice_opts* o, int32_t n, int32_t c, int64_t voxels) {
+  if (!o || n <= 0 || c <= 0 || voxels <= 0) return MI355_EINVAL;
+  if (o->activation < MI355_DICE_ACT_NONE || o->activation > MI355_DICE_ACT_SOFTMAX) return MI355_EINVAL;
+  if (o->target_kind < MI355_DICE_TARGET_F32 || o->target_kind > MI355_DICE_TARGET_LABELS) return MI355_EINVAL;
+  if (o->reduction < MI355_DICE_REDUCE_MEAN || o->reduction > MI355_DICE_REDUCE_NONE) return MI355_EINVAL;
+  if (!o->include_background && c < 2) return MI355_EINVAL;
+  if (c > DICE_MAX_C || (size_t)n * c > 1024) return MI355_EUNSUPPORTED;
+  return MI355_OK;
+}
+
+extern "C" int mi355_dice_ex_forward(const mi355_dice_opts* o, const float* logits, const void* target, int32_t n, int32_t c, int64_t voxels,
+                                     float* loss, void* ws, size_t ws_bytes, void* stream) {
+  int rc = dice_ex_check(o, n, c, voxels); if (rc) return rc;
+  if (!logits || !target || !loss || !ws) return MI355_EINVAL;
+  if (ws_bytes < mi355_dice_workspace(n, c, voxels)) return MI355_EWORKSPACE;
+  const int NC = n * c, B = dice_blocks(voxels);
+  float* part = (float*)ws; float* stats = part + (size_t)NC * B * 3; float* coef = stats + (size_t)NC * 3;
+  LAUNCH(dice_ex_partial_kernel, dim3(B, n), dim3(256), 0, stream, logits, target, o->target_kind, (long long)voxels, c, o->activation,
+         o->squared_pred, part);
+  rc = LAUNCH_CHECK(); if (rc) return rc;
+  LAUNCH(dice_finalize_kernel, dim3(1), dim3(256), 0, stream, (const float*)part, B, n, c, o->batch, o->smooth_nr, o->smooth_dr, 1.0f,
+         MI355_DICE_PLAIN, o->include_background ? 0 : 1, stats, coef, loss, o->jaccard, o->class_weight, o->reduction);
+  return LAUNCH_CHECK();
+}
+
+extern "C" int mi355_dice_ex_backward(const mi355_dice_opts* o, const float* logits, const void* target, int32_t n, int32_t c, int64_t voxels,
+                                      const float* upstream, int32_t n_upstream, float* dlogits, const void* ws, void* stream) {
+  int rc = dice_ex_check(o, n, c, voxels); if (rc) return rc;
+  if (!logits || !target || !dlogits || !ws) return MI355_EINVAL;
+  const int ce = c - (o->include_background ? 0 : 1);
+  const int terms = o->reduction == MI355_DICE_REDUCE_NONE ? (o->batch ? ce : n * ce) : 1;
+  if (upstream && n_upstream != terms) return MI355_EINVAL;
+  const int NC = n * c, B = dice_blocks(voxels);
+  const float* coef = (const float*)ws + (size_t)NC * B * 3 + (size_t)NC * 3;
+  const long long total = (long long)n * voxels;
+  long long grid = (total + 255) / 256; if (grid > 16384) grid = 16384;
+  LAUNCH(dice_ex_grad_kernel, dim3((unsigned)grid), dim3(256), 0, stream, logits, target, o->target_kind, (long long)voxels, n, c, o->activation,
+         o->squared_pred, coef, upstream, n_upstream, o->batch, o->include_background ? 0 : 1, dlogits);
+  return LAUNCH_CHECK();
 }
 
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long count, float lr, float b1, float b2, float eps,

@@ -42,31 +42,61 @@ def _scaled(ctx, g):
     return d.mul_(g)
 
 
+class _DiceExFunction(torch.autograd.Function):
+    """DiceLoss with the options the one-call fused kernel does not carry (softmax, label-map targets, jaccard, weight, reduction):
+    forward = sums + finalisation, backward = one pass that applies the upstream gradient of every term."""
+    @staticmethod
+    def forward(ctx, logits, target, mod, activation):
+        be = mod._be or _ops.default_backend(logits.device)
+        logits, target = logits.contiguous(), target.contiguous()
+        cw = mod.class_weight
+        if cw is not None:
+            cw = cw.to(device=logits.device, dtype=torch.float32).contiguous()
+        loss, state = be.dice_ex_forward(logits, target, activation=activation, batch=mod.batch, squared_pred=mod.squared_pred,
+                                         include_background=mod.include_background, jaccard=mod.jaccard, reduction=mod.reduction,
+                                         smooth_nr=mod.smooth_nr, smooth_dr=mod.smooth_dr, class_weight=cw)
+        ctx.saved = (be, logits, target, state)
+        if mod.reduction != "none":
+            return loss.reshape(())
+        ce = logits.shape[1] - (0 if mod.include_background else 1)
+        lead = [ce] if mod.batch else [logits.shape[0], ce]            # MONAI: f.view(list(f.shape[0:2]) + [1] * (input.dim() - 2))
+        return loss.reshape(lead + [1] * (logits.dim() - 2))
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.saved is None:
+            raise RuntimeError("loss backward called a second time: its saved tensors are released by the first backward")
+        be, logits, target, state = ctx.saved
+        ctx.saved = None
+        return be.dice_ex_backward(logits, target, state, g), None, None, None
+
+
 class HipDiceLoss(nn.Module):
+    """monai.losses.DiceLoss. The shipped configuration (sigmoid / no activation, same-shape targets, reduction="mean") is one fused
+    pass (value + gradient); softmax, to_onehot_y, jaccard, weight and reduction="sum" / "none" run the two-call form. other_act (an
+    arbitrary Python callable) cannot run inside a kernel and raises."""
     def __init__(self, include_background=True, to_onehot_y=False, sigmoid=False, softmax=False, other_act=None,
                  squared_pred=False, jaccard=False, reduction="mean", smooth_nr=1e-5, smooth_dr=1e-5, batch=False, weight=None):
         super().__init__()
-        unsupported = []
-        if to_onehot_y:
-            unsupported.append("to_onehot_y=True")
-        if softmax:
-            unsupported.append("softmax=True")
+        if other_act is not None and not callable(other_act):
+            raise TypeError(f"other_act must be None or callable but is {type(other_act).__name__}.")       # MONAI's checks, same messages
+        if int(sigmoid) + int(softmax) + int(other_act is not None) > 1:
+            raise ValueError("Incompatible values: more than 1 of [sigmoid=True, softmax=True, other_act is not None].")
         if other_act is not None:
-            unsupported.append("other_act")
-        if jaccard:
-            unsupported.append("jaccard=True")
-        if reduction != "mean":
-            unsupported.append(f"reduction={reduction!r}")
-        if weight is not None:
-            unsupported.append("weight")
-        if unsupported:
-            raise NotImplementedError("HipDiceLoss does not implement: " + ", ".join(unsupported))
-        self.sigmoid = bool(sigmoid)
-        self.squared_pred = bool(squared_pred)
-        self.batch = bool(batch)
+            raise NotImplementedError(f"{type(self).__name__} does not implement: other_act (a Python callable cannot run inside the fused kernels)")
+        reduction = str(getattr(reduction, "value", reduction)).lower()
+        if reduction not in ("mean", "sum", "none"):
+            raise ValueError(f'Unsupported reduction: {reduction}, available options are ["mean", "sum", "none"].')
+        if self.generalized and (to_onehot_y or softmax or jaccard or weight is not None or reduction != "mean"):
+            raise NotImplementedError("HipGeneralizedDiceLoss implements sigmoid / no activation, same-shape targets, reduction='mean'")
+        self.sigmoid, self.softmax, self.to_onehot_y = bool(sigmoid), bool(softmax), bool(to_onehot_y)
+        self.squared_pred, self.jaccard, self.batch = bool(squared_pred), bool(jaccard), bool(batch)
+        self.reduction = reduction
         self.smooth_nr = float(smooth_nr)
         self.smooth_dr = float(smooth_dr)
         self.include_background = bool(include_background)
+        weight = torch.as_tensor(weight, dtype=torch.float32) if weight is not None else None
+        self.register_buffer("class_weight", weight)
         self._be = None
 
     generalized = False
@@ -74,13 +104,46 @@ class HipDiceLoss(nn.Module):
     def forward(self, input, target):
         if input.device.type != "cuda" and self._be is None:
             raise RuntimeError(f"{type(self).__name__} runs on an MI355X only (no CPU fallback)")
-        if not self.include_background and input.shape[1] == 1:
+        c = input.shape[1]
+        if not self.include_background and c == 1:
             raise ValueError("single channel prediction, `include_background=False` ignored is not supported: pass include_background=True")
-        if target.shape != input.shape:
-            raise AssertionError(f"ground truth has different shape ({tuple(target.shape)}) from input ({tuple(input.shape)})")
-        if target.dtype not in (torch.uint8, torch.float32):
-            target = target.to(torch.float32)
-        return _DiceFunction.apply(input.float(), target, self)
+        softmax = self.softmax and c > 1                   # MONAI: "single channel prediction, `softmax=True` ignored."
+        onehot = self.to_onehot_y and c > 1                # MONAI: "single channel prediction, `to_onehot_y=True` ignored."
+        ce = c - (0 if self.include_background else 1)
+        cw = self.class_weight
+        if cw is not None and ce != 1:
+            if cw.ndim == 0:
+                cw = cw.repeat(ce)
+            elif cw.shape[0] != ce:
+                raise ValueError("the length of the `weight` sequence should be the same as the number of classes. "
+                                 "If `include_background=False`, the weight should not include the background category class 0.")
+            if float(cw.min()) < 0:
+                raise ValueError("the value/values of the `weight` should be no less than 0.")
+        else:
+            cw = None                                        # MONAI applies the weight only for more than one class
+        if onehot:
+            if target.shape[0] != input.shape[0] or target.shape[1] != 1 or target.shape[2:] != input.shape[2:]:
+                raise AssertionError("labels should have a channel with length equal to one.")             # monai.networks.one_hot
+            target = target.to(torch.int32)
+        else:
+            if target.shape != input.shape:
+                raise AssertionError(f"ground truth has different shape ({tuple(target.shape)}) from input ({tuple(input.shape)})")
+            if target.dtype not in (torch.uint8, torch.float32):
+                target = target.to(torch.float32)
+        if not (softmax or onehot or self.jaccard or cw is not None or self.reduction != "mean"):
+            return _DiceFunction.apply(input.float(), target, self)
+        if c > 16:
+            raise NotImplementedError("more than 16 classes")
+        mod = self if cw is self.class_weight else _WithWeight(self, cw)
+        return _DiceExFunction.apply(input.float(), target, mod, "softmax" if softmax else ("sigmoid" if self.sigmoid else None))
+
+
+class _WithWeight:
+    """the module's options with the per-call class weight (a scalar weight is expanded to the number of counted classes per call)"""
+    def __init__(self, mod, cw):
+        self.__dict__.update({k: getattr(mod, k) for k in ("_be", "batch", "squared_pred", "include_background", "jaccard", "reduction",
+                                                           "smooth_nr", "smooth_dr")})
+        self.class_weight = cw
 
 
 class _CEFunction(torch.autograd.Function):

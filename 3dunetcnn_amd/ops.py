@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (IN_AFFINE_ACT, IN_PLAIN, IN_S2D, IN_ZERO_INSERT, OUT_D2S, OUT_PLAIN, PREC_F32, PRECISIONS, W_OIDHW4,  # noqa: F401
-                   W_PACKED, W_PACKED_F32_NARROW, MiAct, MiConvDesc, MiGnBwdFuse, check)
+                   W_PACKED, W_PACKED_F32_NARROW, MiAct, MiConvDesc, MiDiceOpts, MiGnBwdFuse, check)
 
 
 class Act:
@@ -460,6 +460,42 @@ class Backend:
                                           smooth_dr, loss.data_ptr(),
                                           _p(dlogits), grad_scale, ws.data_ptr(), ws.numel() * 4, self.stream()), "dice_fwd_bwd")
         return loss, dlogits
+
+    DICE_ACT = {None: 0, "sigmoid": 1, "softmax": 2}
+    DICE_REDUCE = {"mean": 0, "sum": 1, "none": 2}
+
+    def _dice_opts(self, target, activation, batch, squared_pred, include_background, jaccard, reduction, smooth_nr, smooth_dr, class_weight):
+        kind = 2 if target.dtype == torch.int32 else (1 if target.dtype == torch.uint8 else 0)
+        return MiDiceOpts(self.DICE_ACT[activation], kind, int(batch), int(squared_pred), int(include_background), int(jaccard),
+                          self.DICE_REDUCE[reduction], float(smooth_nr), float(smooth_dr), _p(class_weight))
+
+    def dice_ex_forward(self, logits, target, activation="sigmoid", batch=False, squared_pred=False, include_background=True, jaccard=False,
+                        reduction="mean", smooth_nr=1e-5, smooth_dr=1e-5, class_weight=None):
+        """monai DiceLoss with the options the fused mi355_dice_fwd_bwd does not carry. target: same shape as the logits (uint8 / fp32) or
+        an int32 label map [n, 1, ...] (to_onehot_y). Returns (loss values [1] or one per term, state for dice_ex_backward)."""
+        assert logits.is_contiguous() and target.is_contiguous() and logits.dtype == torch.float32
+        n, c = logits.shape[0], logits.shape[1]
+        vox = logits[0, 0].numel()
+        assert (target.dtype == torch.int32 and target.numel() == n * vox) or (target.dtype in (torch.uint8, torch.float32) and target.shape == logits.shape)
+        ce = c - (0 if include_background else 1)
+        terms = (ce if batch else n * ce) if reduction == "none" else 1
+        loss = torch.empty(terms, dtype=torch.float32, device=self.device)
+        o = self._dice_opts(target, activation, batch, squared_pred, include_background, jaccard, reduction, smooth_nr, smooth_dr, class_weight)
+        ws = torch.empty(self.lib.mi355_dice_workspace(n, c, vox) // 4, dtype=torch.float32, device=self.device)   # kept for backward
+        check(self.lib.mi355_dice_ex_forward(ctypes.byref(o), logits.data_ptr(), target.data_ptr(), n, c, vox, loss.data_ptr(), ws.data_ptr(),
+                                             ws.numel() * 4, self.stream()), "dice_ex_forward")
+        return loss, (o, ws, class_weight)
+
+    def dice_ex_backward(self, logits, target, state, upstream):
+        """d(sum_t upstream[t] * loss[t]) / d(logits); upstream: fp32 tensor with one value per loss value."""
+        o, ws, _keep = state
+        n, c = logits.shape[0], logits.shape[1]
+        vox = logits[0, 0].numel()
+        dlogits = torch.empty_like(logits)
+        upstream = upstream.reshape(-1).contiguous().float()
+        check(self.lib.mi355_dice_ex_backward(ctypes.byref(o), logits.data_ptr(), target.data_ptr(), n, c, vox, upstream.data_ptr(),
+                                              upstream.numel(), dlogits.data_ptr(), ws.data_ptr(), self.stream()), "dice_ex_backward")
+        return dlogits
 
     def cross_entropy(self, logits, target, mode="softmax", weight=1.0, loss=None, dlogits=None, want_grad=True, grad_scale=1.0):
         """mode "softmax": CrossEntropyLoss(mean) with probability targets; "bce": BCEWithLogitsLoss(mean). `loss` / `dlogits`

@@ -294,6 +294,34 @@ int mi355_dice_fwd_bwd(const float* logits, const void* target, int32_t target_i
                        float smooth_nr, float smooth_dr, float* loss, float* dlogits, float grad_scale, void* ws, size_t ws_bytes,
                        void* stream);
 
+/* The options of monai.losses.DiceLoss beyond the shipped configuration (the reference builds the loss from the config's kwargs:
+ * unet3d/scripts/script_utils.py:61-77): channel softmax, label-map targets (to_onehot_y), jaccard, per-class weight, reduction.
+ * Forward and backward are separate calls: with reduction "none" the upstream gradient is one value per term.
+ *   activation: applied to the logits before the sums; softmax runs over ALL channels, then include_background == 0 drops channel 0.
+ *   target_kind: F32 / U8 = same shape as the logits; LABELS = int32 [n][voxels] class indices (y_c = label == c).
+ *   class_weight: device pointer, one factor per COUNTED class (c, or c-1 without background), or NULL.
+ *   loss: 1 value (mean / sum) or one per term (none: [n][counted classes], or [counted classes] with batch).
+ *   ws: mi355_dice_workspace(n, c, voxels) bytes, written by forward and read by backward (the caller keeps it).
+ *   upstream: device pointer to d(result)/d(loss value[s]) (n_upstream = number of loss values) or NULL for 1. */
+#define MI355_DICE_ACT_NONE 0
+#define MI355_DICE_ACT_SIGMOID 1
+#define MI355_DICE_ACT_SOFTMAX 2
+#define MI355_DICE_TARGET_F32 0
+#define MI355_DICE_TARGET_U8 1
+#define MI355_DICE_TARGET_LABELS 2
+#define MI355_DICE_REDUCE_MEAN 0
+#define MI355_DICE_REDUCE_SUM 1
+#define MI355_DICE_REDUCE_NONE 2
+typedef struct mi355_dice_opts {
+  int32_t activation, target_kind, batch, squared_pred, include_background, jaccard, reduction;
+  float smooth_nr, smooth_dr;
+  const float* class_weight;
+} mi355_dice_opts;
+int mi355_dice_ex_forward(const mi355_dice_opts* opts, const float* logits, const void* target, int32_t n, int32_t c, int64_t voxels,
+                          float* loss, void* ws, size_t ws_bytes, void* stream);
+int mi355_dice_ex_backward(const mi355_dice_opts* opts, const float* logits, const void* target, int32_t n, int32_t c, int64_t voxels,
+                           const float* upstream, int32_t n_upstream, float* dlogits, const void* ws, void* stream);
+
 /* ---- cross-entropy --------------------------------------------------------------------------- */
 /* The cross-entropy leg of the reference's loss look-up (scripts/script_utils.py:61-77: torch.nn.BCEWithLogitsLoss /
  * CrossEntropyLoss via the torch fallback, monai.losses.DiceCELoss), fused into one pass over the logits: loss value and

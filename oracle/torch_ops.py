@@ -48,12 +48,22 @@ def conv_transpose_pad(x, w, bias, target_dhw):
     return F.pad(y, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2, dz // 2, dz - dz // 2])
 
 
-def dice_loss(logits, target, sigmoid=True, batch=False, squared_pred=False, smooth_nr=1e-5, smooth_dr=1e-5, include_background=True):
-    """monai.losses.DiceLoss(reduction="mean") restated (MONAI >= 1.2 is un-vendored and unpinned: requirements.txt:4).
-    Call site unet3d/scripts/script_utils.py:72; config brats2020_config.json:112-116. include_background=False drops
-    channel 0 of both tensors first."""
+def dice_loss(logits, target, sigmoid=True, batch=False, squared_pred=False, smooth_nr=1e-5, smooth_dr=1e-5, include_background=True,
+              softmax=False, to_onehot_y=False, jaccard=False, weight=None, reduction="mean"):
+    """monai.losses.DiceLoss restated (MONAI >= 1.2 is un-vendored and unpinned: requirements.txt:4; PARITY UNPINNED -- the formulas are
+    additionally pinned by the hand-worked values of tests/golden/handworked.json). Call site unet3d/scripts/script_utils.py:72; config
+    brats2020_config.json:112-116. Order as in MONAI's forward: activation (sigmoid | channel softmax, ignored for one channel), one-hot
+    of a label-map target (ignored for one channel), include_background=False drops channel 0 of both tensors, sums, jaccard
+    (denominator 2 (D - I)), per-class weight (only for more than one counted class), reduction mean | sum | none
+    ("none": [N, C, 1, 1, 1], or [C, 1, 1, 1] with batch)."""
+    c = logits.shape[1]
     p = torch.sigmoid(logits) if sigmoid else logits
-    y = target.to(p.dtype)
+    if softmax and c > 1:
+        p = torch.softmax(p, 1)
+    y = target
+    if to_onehot_y and c > 1:
+        y = torch.zeros_like(p).scatter_(1, target.long(), 1.0)
+    y = y.to(p.dtype)
     if not include_background:
         p, y = p[:, 1:], y[:, 1:]
     axes = list(range(2, p.dim()))
@@ -64,8 +74,20 @@ def dice_loss(logits, target, sigmoid=True, batch=False, squared_pred=False, smo
         g, q = torch.sum(y * y, dim=axes), torch.sum(p * p, dim=axes)
     else:
         g, q = torch.sum(y, dim=axes), torch.sum(p, dim=axes)
-    f = 1.0 - (2.0 * inter + smooth_nr) / (g + q + smooth_dr)
-    return torch.mean(f)
+    den = g + q
+    if jaccard:
+        den = 2.0 * (den - inter)
+    f = 1.0 - (2.0 * inter + smooth_nr) / (den + smooth_dr)
+    if weight is not None and y.shape[1] != 1:
+        w = torch.as_tensor(weight, dtype=f.dtype)
+        if w.ndim == 0:
+            w = w.repeat(y.shape[1])
+        f = f * w
+    if reduction == "mean":
+        return torch.mean(f)
+    if reduction == "sum":
+        return torch.sum(f)
+    return f.view(list(f.shape[0:2]) + [1] * (logits.dim() - 2))
 
 
 def generalized_dice_loss(logits, target, sigmoid=True, batch=False, smooth_nr=1e-5, smooth_dr=1e-5, include_background=True):

@@ -21,6 +21,14 @@ CASE gdl.    GeneralizedDiceLoss(w_type="square", sigmoid): per sample w_c = 1 /
   replaces by the largest finite weight of that sample; loss = 1 - (2 * sum_c w_c I_c + 1e-5) / (sum_c w_c (sum p_c + sum y_c) + 1e-5).
   Same tensors: w0 = 1/4, w1 = inf -> 1/4:  numerator 2 * (1/4 * 5/4 + 1/4 * 0) = 5/8, denominator 1/4 * 4 + 1/4 * 1 = 5/4
       loss = 1 - (0.625 + 1e-5) / (1.25 + 1e-5) = 0.499996000032...
+CASE dice options (monai DiceLoss kwargs beyond the shipped configuration), on the two-sample tensors of CASE dice:
+  jaccard: the denominator D = sum p + sum y becomes 2 (D - I): sample 0 channel 0: 1 - 2.50001 / (2 (4 - 5/4) + 1e-5) = 1 - 2.50001 / 5.50001.
+  weight (w0, w1) multiplies the per-class values before the reduction; reduction "sum" adds the n * c values, "none" returns them.
+  softmax (instead of sigmoid) over the TWO channels of a voxel: (z0, z1) = (ln 3, -ln 3) -> p = (9/10, 1/10); (-ln 3, -ln 3) -> (1/2, 1/2);
+  (0, -ln 3) -> (3/4, 1/4). Sample 0: p0 = (9/10, 1/2, 3/4, 3/4), y0 = (1, 0, 1, 0): I = 33/20, sum p = 29/10, sum y = 2:
+      f = 1 - (3.3 + 1e-5) / (4.9 + 1e-5) = 0.32653...
+  to_onehot_y: the target is a label map l(v) in {0, 1}; y_c(v) = [l(v) = c]. include_background=False keeps channel 1 only (softmax
+  still runs over both channels first).
 CASE window. 1-D plan of MONAI's dense_patch_slices: image 20, roi 8, overlap 0.25 -> interval int(8 * 0.75) = 6; starts
   min(i * 6, 20 - 8) until the window reaches the end: (0, 6, 12).  image 19 -> (0, 6, 11).  image 8 -> (0).  overlap 0.5 on 240 with
   roi 128: interval 64 -> (0, 64, 112).  Gaussian importance, roi 8, sigma = 0.125 * 8 = 1, centre (8 - 1) / 2 = 3.5:
@@ -109,6 +117,61 @@ def dice_cases():
             "dice_two_samples": dice(logits2, target2), "dice_two_samples_batch": dice(logits2, target2, batch=True),
             "gdl": gdl(logits, target), "gdl_two_samples": gdl(logits2, target2),
             "closed_forms": {"f0": 1 - 2.50001 / 4.00001, "f1": 1 - 1e-5 / 1.00001, "gdl": 1 - 0.62501 / 1.25001}}
+
+
+def dice_option_cases(base):
+    """The per-(n, c) Dice values of the two-sample tensors under the option combinations, from scalar arithmetic."""
+    lg, tg = base["logits2"], base["target2"]
+    labels = [[1 if tg[n][1][v] else 0 for v in range(4)] for n in range(2)]      # a label map: class 1 where channel 1 of the target is set
+
+    def probs(n, v, act):
+        z = [lg[n][c][v] for c in range(2)]
+        if act == "sigmoid":
+            return [sigmoid(t) for t in z]
+        m = max(z)
+        e = [math.exp(t - m) for t in z]
+        return [t / sum(e) for t in e]
+
+    def terms(act="sigmoid", onehot=False, jaccard=False, squared=False, batch=False, weight=None, background=True):
+        c0 = 0 if background else 1
+        s = [[[0.0, 0.0, 0.0] for _ in range(2)] for _ in range(2)]
+        for n in range(2):
+            for v in range(4):
+                p = probs(n, v, act)
+                for c in range(2):
+                    y = (1.0 if labels[n][v] == c else 0.0) if onehot else float(tg[n][c][v])
+                    s[n][c][0] += p[c] * y
+                    s[n][c][1] += p[c] * p[c] if squared else p[c]
+                    s[n][c][2] += y * y if squared else y
+        rows = [[[sum(s[n][c][k] for n in range(2)) for k in range(3)] for c in range(2)]] if batch else s
+        out = []
+        for row in rows:
+            r = []
+            for c in range(c0, 2):
+                inter, den = row[c][0], row[c][1] + row[c][2]
+                if jaccard:
+                    den = 2.0 * (den - inter)
+                f = 1.0 - (2.0 * inter + EPS) / (den + EPS)
+                if weight is not None and 2 - c0 != 1:
+                    f *= weight[c - c0]
+                r.append(f)
+            out.append(r)
+        return out
+
+    def flat(t):
+        return [x for r in t for x in r]
+
+    def mean(t):
+        return sum(flat(t)) / len(flat(t))
+
+    return {"labels": labels,
+            "jaccard": mean(terms(jaccard=True)), "jaccard_squared_batch": mean(terms(jaccard=True, squared=True, batch=True)),
+            "weight": mean(terms(weight=[2.0, 0.5])), "sum": sum(flat(terms())), "none": terms(), "none_batch": terms(batch=True),
+            "softmax": mean(terms(act="softmax")), "softmax_none": terms(act="softmax"),
+            "softmax_onehot": mean(terms(act="softmax", onehot=True)),
+            "softmax_onehot_nobg_sum": sum(flat(terms(act="softmax", onehot=True, background=False))),
+            "sigmoid_onehot_jaccard_weight_none": terms(onehot=True, jaccard=True, weight=[2.0, 0.5]),
+            "closed_forms": {"jaccard_n0c0": 1 - 2.50001 / 5.50001, "softmax_n0c0": 1 - 3.30001 / 4.90001}}
 
 
 # ---- sliding window (SURVEY.md 8f-1) -----------------------------------------------------------------------------------------------
@@ -261,6 +324,7 @@ def dynunet_case():
 
 def main():
     out = {"dice": dice_cases(), "window": window_cases(), "dynunet": dynunet_case()}
+    out["dice_options"] = dice_option_cases(out["dice"])
     with open(os.path.join(HERE, "handworked.json"), "w") as f:
         json.dump(out, f)
     d = out["dice"]

@@ -71,6 +71,21 @@ def test_norm_loss_and_pointwise_reject_bad_arguments(emu_backend):
     z = torch.zeros(1, 3, 4, 4, 4)
     assert lib.mi355_dice_fwd_bwd(z.data_ptr(), z.data_ptr(), 0, 1, 3, 64, 1, 0, 0, 7, 1, 1e-5, 1e-5, f.data_ptr(), None, 1.0, f.data_ptr(), 16384, 0) == EINVAL
     assert lib.mi355_dice_fwd_bwd(z.data_ptr(), z.data_ptr(), 0, 1, 1, 64, 1, 0, 0, 0, 0, 1e-5, 1e-5, f.data_ptr(), None, 1.0, f.data_ptr(), 16384, 0) == EINVAL
+    MiDiceOpts = importlib.import_module("3dunetcnn_amd._lib").MiDiceOpts
+    def opts(**kw):
+        base = dict(activation=1, target_kind=0, batch=0, squared_pred=0, include_background=1, jaccard=0, reduction=0, smooth_nr=1e-5,
+                    smooth_dr=1e-5, class_weight=None)
+        base.update(kw)
+        return ctypes.byref(MiDiceOpts(**base))
+    ex_f, ex_b = lib.mi355_dice_ex_forward, lib.mi355_dice_ex_backward
+    assert ex_f(opts(), z.data_ptr(), z.data_ptr(), 1, 3, 64, f.data_ptr(), f.data_ptr(), 16384, 0) == 0
+    assert ex_f(opts(activation=3), z.data_ptr(), z.data_ptr(), 1, 3, 64, f.data_ptr(), f.data_ptr(), 16384, 0) == EINVAL
+    assert ex_f(opts(target_kind=5), z.data_ptr(), z.data_ptr(), 1, 3, 64, f.data_ptr(), f.data_ptr(), 16384, 0) == EINVAL
+    assert ex_f(opts(reduction=3), z.data_ptr(), z.data_ptr(), 1, 3, 64, f.data_ptr(), f.data_ptr(), 16384, 0) == EINVAL
+    assert ex_f(opts(include_background=0), z.data_ptr(), z.data_ptr(), 1, 1, 64, f.data_ptr(), f.data_ptr(), 16384, 0) == EINVAL
+    assert ex_f(opts(), z.data_ptr(), z.data_ptr(), 1, 17, 64, f.data_ptr(), f.data_ptr(), 16384, 0) == EUNSUPPORTED      # more than 16 classes
+    assert ex_f(opts(), z.data_ptr(), z.data_ptr(), 1, 3, 64, f.data_ptr(), f.data_ptr(), 16, 0) == EWORKSPACE
+    assert ex_b(opts(reduction=2), z.data_ptr(), z.data_ptr(), 1, 3, 64, f.data_ptr(), 2, z.data_ptr(), f.data_ptr(), 0) == EINVAL   # 3 terms, 2 upstream values
     assert lib.mi355_ce_fwd_bwd(z.data_ptr(), z.data_ptr(), 0, 1, 17, 64, 0, 1.0, f.data_ptr(), 0, None, 0, 1.0, f.data_ptr(), 16384, 0) == EINVAL
     assert lib.mi355_ce_fwd_bwd(z.data_ptr(), z.data_ptr(), 0, 1, 3, 64, 0, 1.0, f.data_ptr(), 0, None, 0, 1.0, f.data_ptr(), 16, 0) == EWORKSPACE
     m = (ctypes.c_float * 12)(*([0.0] * 12))

@@ -69,6 +69,68 @@ def _hip_losses(be, dev):
         assert abs(float(crit(lg.to(dev), tg.to(dev))) - FX["dice"][key]) < 2e-6, key
 
 
+# (fixture key, DiceLoss kwargs, label-map target?)
+OPTION_CASES = [
+    ("jaccard", dict(sigmoid=True, jaccard=True), False),
+    ("jaccard_squared_batch", dict(sigmoid=True, jaccard=True, squared_pred=True, batch=True), False),
+    ("weight", dict(sigmoid=True, weight=[2.0, 0.5]), False),
+    ("sum", dict(sigmoid=True, reduction="sum"), False),
+    ("none", dict(sigmoid=True, reduction="none"), False),
+    ("none_batch", dict(sigmoid=True, reduction="none", batch=True), False),
+    ("softmax", dict(softmax=True), False),
+    ("softmax_none", dict(softmax=True, reduction="none"), False),
+    ("softmax_onehot", dict(softmax=True, to_onehot_y=True), True),
+    ("softmax_onehot_nobg_sum", dict(softmax=True, to_onehot_y=True, include_background=False, reduction="sum"), True),
+    ("sigmoid_onehot_jaccard_weight_none", dict(sigmoid=True, to_onehot_y=True, jaccard=True, weight=[2.0, 0.5], reduction="none"), True),
+]
+
+
+def _option_inputs(labels, dtype):
+    lg, tg = _dice_tensors(True, dtype)
+    if labels:
+        tg = torch.tensor(FX["dice_options"]["labels"], dtype=torch.int64).reshape(2, 1, 1, 2, 2)
+    return lg, tg
+
+
+def test_dice_option_fixture_matches_its_closed_forms():
+    d = FX["dice_options"]
+    assert abs(d["none"][0][0] - (1 - 2.50001 / 4.00001)) < 1e-15 and abs(d["none"][0][1] - (1 - 1e-5 / 1.00001)) < 1e-15
+    assert abs(d["softmax_none"][0][0] - (1 - 3.30001 / 4.90001)) < 1e-15
+    assert abs(d["sum"] - sum(sum(r) for r in d["none"])) < 1e-15
+    assert abs(d["closed_forms"]["jaccard_n0c0"] - (1 - 2.50001 / 5.50001)) < 1e-15
+
+
+@pytest.mark.parametrize("key,kw,labels", OPTION_CASES, ids=[c[0] for c in OPTION_CASES])
+def test_oracle_dice_options_match_hand_values(key, kw, labels):
+    lg, tg = _option_inputs(labels, torch.float64)
+    okw = dict(kw)
+    okw.setdefault("sigmoid", False)
+    got = O.dice_loss(lg, tg, **okw)
+    want = torch.tensor(FX["dice_options"][key], dtype=torch.float64)
+    assert got.numel() == want.numel() and float((got.reshape(-1) - want.reshape(-1)).abs().max()) < 1e-12
+    if kw.get("reduction") == "none":          # MONAI: f.view(list(f.shape[0:2]) + [1] * 3) -- [N, C, 1, 1, 1], or [C, 1, 1, 1] with batch
+        assert list(got.shape) == ([want.shape[1]] if kw.get("batch") else list(want.shape)) + [1, 1, 1]
+
+
+def _hip_dice_options(be, dev):
+    for key, kw, labels in OPTION_CASES:
+        lg, tg = _option_inputs(labels, torch.float32)
+        crit = losses.HipDiceLoss(**kw)
+        crit._be = be
+        got = crit(lg.to(dev), tg.to(dev)).detach().cpu().double().reshape(-1)
+        want = torch.tensor(FX["dice_options"][key], dtype=torch.float64).reshape(-1)
+        assert got.numel() == want.numel() and float((got - want).abs().max()) < 3e-6, key
+
+
+def test_hip_dice_options_match_hand_values_on_emulator(emu_backend):
+    _hip_dice_options(emu_backend, "cpu")
+
+
+@pytest.mark.gpu
+def test_hip_dice_options_match_hand_values_on_gpu(hip_backend):
+    _hip_dice_options(None, "cuda")
+
+
 def test_hip_losses_match_hand_values_on_emulator(emu_backend):
     _hip_losses(emu_backend, "cpu")
 

@@ -71,6 +71,83 @@ def test_losses_gpu(name, mk, ref, c):
     _check(mk(), ref, None, "cuda", 2, c, (40, 48, 36), name)
 
 
+# monai DiceLoss options beyond the shipped configuration (the reference passes the config's loss kwargs straight to the class:
+# unet3d/scripts/script_utils.py:61-77): (constructor kwargs, channels, label-map target?)
+EX_CASES = [
+    ("softmax", dict(softmax=True), 4, False),
+    ("softmax_onehot_nobg", dict(softmax=True, to_onehot_y=True, include_background=False), 4, True),
+    ("onehot_sigmoid", dict(sigmoid=True, to_onehot_y=True), 3, True),
+    ("jaccard", dict(sigmoid=True, jaccard=True), 3, False),
+    ("jaccard_squared_batch", dict(sigmoid=True, jaccard=True, squared_pred=True, batch=True), 3, False),
+    ("weight", dict(sigmoid=True, weight=[0.2, 1.0, 3.0]), 3, False),
+    ("weight_scalar_nobg", dict(sigmoid=True, weight=2.5, include_background=False), 3, False),
+    ("sum", dict(sigmoid=True, reduction="sum"), 3, False),
+    ("none", dict(sigmoid=True, reduction="none"), 3, False),
+    ("none_batch_nobg", dict(softmax=True, reduction="none", batch=True, include_background=False), 4, False),
+    ("none_softmax_weight_jaccard", dict(softmax=True, reduction="none", weight=[1.0, 0.5, 2.0, 0.0], jaccard=True), 4, False),
+    ("no_activation", dict(reduction="sum", jaccard=True), 2, False),
+]
+
+
+def _check_ex(kw, be, dev, n, c, dhw, labels):
+    z, t = _data(n, c, dhw, seed=3)
+    if labels:
+        t = torch.randint(0, c, (n, 1) + tuple(dhw), generator=torch.Generator().manual_seed(5))
+    if not (kw.get("sigmoid") or kw.get("softmax")):
+        z = torch.sigmoid(z)                                   # "probabilities in": keep the values in the range Dice is meant for
+    okw = {("sigmoid" if k == "sigmoid" else k): v for k, v in kw.items()}
+    okw.setdefault("sigmoid", False)
+    zr = z.clone().requires_grad_(True)
+    ref = O.dice_loss(zr, t, **okw)
+    up = torch.rand(ref.shape, generator=torch.Generator().manual_seed(7)) + 0.5      # a different upstream gradient for every term
+    (ref * up).sum().backward()
+    crit = losses.HipDiceLoss(**kw)
+    if be is not None:
+        crit._be = be
+    zg = z.to(dev).requires_grad_(True)
+    loss = crit(zg, t.to(dev))
+    assert loss.shape == ref.shape
+    (loss * up.to(dev)).sum().backward()
+    assert C.rel_err(loss.detach().cpu(), ref.detach()) < TOL
+    assert C.rel_err(zg.grad.cpu(), zr.grad) < TOL
+
+
+@pytest.mark.parametrize("name,kw,c,labels", EX_CASES, ids=[c[0] for c in EX_CASES])
+def test_dice_options_on_emulator(emu_backend, name, kw, c, labels):
+    _check_ex(kw, emu_backend, "cpu", 2, c, (9, 8, 10), labels)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,c,labels", EX_CASES, ids=[c[0] for c in EX_CASES])
+def test_dice_options_gpu(name, kw, c, labels):
+    _check_ex(kw, None, "cuda", 2, c, (40, 48, 36), labels)
+
+
+def test_dice_option_validation_matches_monai():
+    """monai.losses.DiceLoss.__init__ / forward checks (same exception types; messages restated from MONAI 1.3)."""
+    with pytest.raises(ValueError, match="Incompatible values"):
+        losses.HipDiceLoss(sigmoid=True, softmax=True)
+    with pytest.raises(TypeError, match="other_act must be None or callable"):
+        losses.HipDiceLoss(other_act=3)
+    with pytest.raises(NotImplementedError, match="other_act"):
+        losses.HipDiceLoss(other_act=torch.tanh)
+    with pytest.raises(ValueError, match="Unsupported reduction"):
+        losses.HipDiceLoss(reduction="median")
+    crit = losses.HipDiceLoss(sigmoid=True, weight=[1.0, 2.0])
+    crit._be = object()                                        # the checks below run before any kernel
+    z, t = torch.zeros(1, 3, 4, 4, 4), torch.zeros(1, 3, 4, 4, 4)
+    with pytest.raises(ValueError, match="length of the `weight` sequence"):
+        crit(z, t)
+    crit = losses.HipDiceLoss(sigmoid=True, weight=[1.0, -2.0, 1.0])
+    crit._be = object()
+    with pytest.raises(ValueError, match="no less than 0"):
+        crit(z, t)
+    crit = losses.HipDiceLoss(softmax=True, to_onehot_y=True)
+    crit._be = object()
+    with pytest.raises(AssertionError, match="channel with length equal to one"):
+        crit(z, t)
+
+
 def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         losses.HipDiceCELoss(softmax=True)
