@@ -60,6 +60,7 @@ void conv3d_mfma(ConvArgs a) {
   constexpr int HV = HZ * HY * HX;
   constexpr int VS = KC + PADV;
   constexpr int Q = KC / 4;
+  constexpr bool ROWSTAGE = KD == 3 && HX * Q <= 256 && (INMODE == MI355_IN_PLAIN || INMODE == MI355_IN_AFFINE_ACT);
   constexpr int J = KC / 8;
   constexpr int T = KD * KD * KD;
   DYN_LDS(lds);
@@ -186,6 +187,64 @@ void conv3d_mfma(ConvArgs a) {
           const int iz = tz0 / 2 + hv / (ZCY * ZCX), iy = ty0 / 2 + (hv / ZCX) % ZCY, ix = tx0 / 2 + hv % ZCX;
           const bool ok = cvalid && iz < a.Di && iy < a.Hi && ix < a.Wi;
           *reinterpret_cast<float4*>(lds + hv * VS + 4 * sq) = ok ? ld[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else if constexpr (ROWSTAGE) {
+        // Row-structured staging (3x3x3, plain / norm-prologue inputs): a thread owns one (halo x, channel quad) pair and walks the
+        // (z, y) rows of the halo, RP rows at a time. Its x coordinate, x clamp / validity and channel offset are per-thread
+        // constants, a row costs an add-with-carry for (hz, hy), two clamps and ONE 64-bit multiply-add for the address, and the LDS
+        // address is a per-thread base plus a compile-time offset -- ~35 vector-ALU instructions per staged float4 instead of ~60
+        // (flat voxel index -> two divisions, three clamps and the voxel index chain, all done twice). SQ counters after the tap-loop
+        // work (profiles/r2_sq_counters_conv_kernels_after.txt): staging arithmetic is what is left of the vector-ALU share. Measured:
+        // 32->32 @128^3 -1.5...-2 %, the other layers +-0.5 % (profiles/r2_ab_experiments.txt, section 9).
+        constexpr int TPR = HX * Q, RP = 256 / TPR, NR = HZ * HY, UP = (NR + RP - 1) / RP, UB = 4;
+        const bool tact = tid < RP * TPR;                        // 240 of 256 threads stage (10 x 4 quads x 6 rows)
+        const int rt = tact ? tid / TPR : 0, xt = tid % TPR;
+        const int hx = xt / Q, q4 = xt % Q;
+        const int cr = c0 + 4 * q4;
+        const bool crv = cr < a.Cin;
+        float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 rsl = make_float4(a.slope, a.slope, a.slope, a.slope);
+        if (INMODE == MI355_IN_AFFINE_ACT && crv) {
+          rsc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + cr);
+          rsh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + cr);
+          if (a.in_slope) rsl = *reinterpret_cast<const float4*>(a.in_slope + cr);
+        }
+        const int ix = tx0 * STRIDE - a.pad + hx;
+        const bool xok = tact && crv && ix >= 0 && ix < a.Wi;
+        const int ixc = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
+        const float* colp = a.x + (size_t)ixc * a.xld + (crv ? cr : 0);      // this thread's column: row offset added per unit
+        const unsigned rowpitch = (unsigned)a.Wi * (unsigned)a.xld;           // floats per (z, y) row
+        const int hz0 = rt / HY, hy0 = rt % HY;
+        float* ldst = lds + ((rt * HX + hx) * VS + 4 * q4);                  // + k * RP * HX * VS per unit: an immediate
+#pragma unroll
+        for (int k0 = 0; k0 < UP; k0 += UB) {
+          float4 ld[UB];
+          bool ok[UB];
+#pragma unroll
+          for (int kk = 0; kk < UB; ++kk) {
+            if (k0 + kk >= UP) continue;
+            const int k = k0 + kk;
+            int hy = hy0 + (k * RP) % HY, hz = hz0 + (k * RP) / HY;
+            if (hy >= HY) { hy -= HY; hz += 1; }
+            if (hz >= HZ) hz = HZ - 1;                            // the ragged last round re-reads a valid row (not stored)
+            const int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy;
+            const int izc = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1), iyc = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
+            ok[kk] = xok && iz >= 0 && iz < a.Di && iy >= 0 && iy < a.Hi;
+            ld[kk] = *reinterpret_cast<const float4*>(colp + (size_t)(unsigned)((n * a.Di + izc) * a.Hi + iyc) * rowpitch);
+          }
+#pragma unroll
+          for (int kk = 0; kk < UB; ++kk) {
+            if (k0 + kk >= UP) continue;
+            const int k = k0 + kk;
+            if ((UP * RP > NR && k == UP - 1 && rt + k * RP >= NR) || !tact) continue;
+            float4 v = ld[kk];
+            if (INMODE == MI355_IN_AFFINE_ACT) {
+              v.x = v.x * rsc.x + rsh.x; v.y = v.y * rsc.y + rsh.y; v.z = v.z * rsc.z + rsh.z; v.w = v.w * rsc.w + rsh.w;
+              v.x = fmaxf(v.x, v.x * rsl.x); v.y = fmaxf(v.y, v.y * rsl.y); v.z = fmaxf(v.z, v.z * rsl.z); v.w = fmaxf(v.w, v.w * rsl.w);
+            }
+            if (!ok[kk]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(ldst + k * (RP * HX * VS)) = v;
+          }
         }
       } else {
         // Batches of UB staging units: all loads of a batch are issued from clamped, always-valid addresses before the first
