@@ -55,8 +55,9 @@ template <> struct Products<2> { static constexpr int P = 3; static constexpr in
 template <> struct Products<3> { static constexpr int P = 6; static constexpr int pa[6] = {2, 1, 0, 1, 0, 0}; static constexpr int pb[6] = {0, 1, 2, 0, 1, 0}; };
 
 // split 8 floats into NS bf16 planes, each plane one uint4 (8 packed bf16)
-template <int NS>
+template <int NS, bool F16 = false>
 __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[NS]) {
+  static_assert(!F16 || NS == 1, "fp16 operands are not split");
   float r[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) r[e] = v[e];
@@ -65,7 +66,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[NS]) {
     unsigned w[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      w[e] = pack_bf16x2(r[2 * e], r[2 * e + 1]);
+      w[e] = pack_lp2<F16>(r[2 * e], r[2 * e + 1]);
       if (p + 1 < NS) { r[2 * e] -= bf16lo_to_f32(w[e]); r[2 * e + 1] -= bf16hi_to_f32(w[e]); }
     }
     out[p] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -73,7 +74,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[NS]) {
 }
 
 // FUSE: 0 plain epilogue, 1 + moment records of the output, 2 + norm-backward sums (dgrad): as conv3d_fwd.hip
-template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT, int INMODE, int FUSE = 0>
+// F16: MI355_PREC_F16 -- the single operand plane is IEEE fp16 instead of bf16 (same tile, same loop, v_mfma_f32_32x32x16_f16)
+template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT, int INMODE, int FUSE = 0, bool F16 = false>
 // LDS holds 3 workgroups of the largest tile: the register allocator must fit 3 waves per SIMD too (several variants sat one or two
 // registers above), except the 4-tile waves with a norm prologue or the norm-backward epilogue, which would spill.
 __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD((MT * NT >= 4 && (INMODE == MI355_IN_AFFINE_ACT || FUSE == 2)) ? 2 : 3)
@@ -215,7 +217,7 @@ void conv3d_k3_bf16(ConvBArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) { if (!(inb && v0ok)) v[e] = 0.f; if (!(inb && v1ok)) v[4 + e] = 0.f; }
           uint4 pl[NS];
-          split8<NS>(v, pl);
+          split8<NS, F16>(v, pl);
 #pragma unroll
           for (int p = 0; p < NS; ++p) lds[hv * VSQ + p * OCT + so] = pl[p];
         }
@@ -246,7 +248,7 @@ void conv3d_k3_bf16(ConvBArgs a) {
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = MFMA_32x32x16_BF16(af[mt][Products<NS>::pa[q]], bf[j][Products<NS>::pb[q]][nt], acc[mt][nt]);
+              acc[mt][nt] = mfma_lp<F16>(af[mt][Products<NS>::pa[q]], bf[j][Products<NS>::pb[q]][nt], acc[mt][nt]);
       }
     };
 #pragma unroll 1
@@ -447,7 +449,7 @@ void conv3d_k3_bf16(ConvBArgs a) {
 // ---- weight packing: OIDHW fp32 -> [tap][ciP/8][plane][coP][8] bf16 planes ------------------------------------------
 // mode 0: forward pack of a Conv3d weight; mode 1: dgrad pack (taps flipped, roles of ci/co swapped); cout/cin are the
 // PACKED roles as in mi355_pack_conv_weight.
-__global__ void pack_weight_bf16_kernel(const float* w, unsigned short* wp, int cout, int cin, int T, int coutP, int cinP, int mode, int NS) {
+__global__ void pack_weight_bf16_kernel(const float* w, unsigned short* wp, int cout, int cin, int T, int coutP, int cinP, int mode, int NS, int f16) {
   const size_t total = (size_t)T * (cinP / 8) * coutP * 8;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int e = idx & 7;
@@ -463,7 +465,7 @@ __global__ void pack_weight_bf16_kernel(const float* w, unsigned short* wp, int 
       else v = w[((size_t)i * cout + o) * T + tf];
     }
     for (int p = 0; p < NS; ++p) {
-      const unsigned pk = pack_bf16x2(v, 0.f);
+      const unsigned pk = f16 ? pack_f16x2(v, 0.f) : pack_bf16x2(v, 0.f);
       wp[((((size_t)t * (cinP / 8) + i8) * NS + p) * coutP + o) * 8 + e] = (unsigned short)(pk & 0xffffu);
       v -= bf16lo_to_f32(pk);
     }
@@ -475,6 +477,7 @@ static int nsplit_of(int precision) {
     case MI355_PREC_BF16X3: return 2;
     case MI355_PREC_BF16X6: return 3;
     case MI355_PREC_BF16: return 1;
+    case MI355_PREC_F16: return 1;
     default: return 0;
   }
 }
@@ -493,12 +496,13 @@ extern "C" int mi355_pack_conv_weight_bf16(const float* w, void* wp, int32_t cou
   const int coutP = (cout + 31) / 32 * 32, cinP = (cin + 15) / 16 * 16;
   const size_t total = (size_t)27 * cinP * coutP;
   int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-  LAUNCH(pack_weight_bf16_kernel, dim3(grid), dim3(256), 0, stream, w, (unsigned short*)wp, cout, cin, 27, coutP, cinP, mode, ns);
+  LAUNCH(pack_weight_bf16_kernel, dim3(grid), dim3(256), 0, stream, w, (unsigned short*)wp, cout, cin, 27, coutP, cinP, mode, ns,
+         precision == MI355_PREC_F16 ? 1 : 0);
   return LAUNCH_CHECK();
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------------------------
-template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT>
+template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT, bool F16>
 static int launch_b(ConvBArgs& a, int in_mode, void* stream) {
   constexpr int HV = (TZ + 2) * (TY + 2) * 18;
   constexpr int VSQ = NS * 2 * J + 1;
@@ -512,31 +516,31 @@ static int launch_b(ConvBArgs& a, int in_mode, void* stream) {
   if (a.g.mom && a.g.gnb) return MI355_EUNSUPPORTED;
   if (a.g.mom) {
     if (in_mode == MI355_IN_PLAIN)
-      LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+      LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 1, F16>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
     else
-      LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+      LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT, 1, F16>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   } else if (a.g.gnb) {
     if (in_mode != MI355_IN_PLAIN) return MI355_EUNSUPPORTED;
-    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 2>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 2, F16>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   } else if (in_mode == MI355_IN_PLAIN)
-    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 0, F16>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   else
-    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT, 0, F16>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   return LAUNCH_CHECK();
 }
 
-template <int NS>
+template <int NS, bool F16 = false>
 static int dispatch_ns(ConvBArgs& a, int in_mode, long long vox, void* stream) {
   // big volumes: 4x4x16 tiles (256 voxels), 4 waves along M; small: 2x4x16 tiles (128 voxels) so the grid still fills the chip
   constexpr int J = NS == 1 ? 2 : 1;      // (one 16-channel k-step per chunk for NS = 1 too: more workgroups per CU, measured 10 % slower)
   if constexpr (NS < 3) {     // the 3-plane tile of the big configuration would exceed the 64 KiB LDS window
     if (vox >= 256LL * 512) {
-      if (a.Cout > 32) return launch_b<4, 4, J, NS, 4, 1, 2, 2>(a, in_mode, stream);
-      return launch_b<4, 4, J, NS, 4, 1, 2, 1>(a, in_mode, stream);
+      if (a.Cout > 32) return launch_b<4, 4, J, NS, 4, 1, 2, 2, F16>(a, in_mode, stream);
+      return launch_b<4, 4, J, NS, 4, 1, 2, 1, F16>(a, in_mode, stream);
     }
   }
-  if (a.Cout > 32) return launch_b<2, 4, J, NS, 2, 2, 2, 1>(a, in_mode, stream);
-  return launch_b<2, 4, J, NS, 4, 1, 1, 1>(a, in_mode, stream);
+  if (a.Cout > 32) return launch_b<2, 4, J, NS, 2, 2, 2, 1, F16>(a, in_mode, stream);
+  return launch_b<2, 4, J, NS, 4, 1, 1, 1, F16>(a, in_mode, stream);
 }
 
 // spatial tiles (= epilogue records per sample) of the configuration dispatch_ns picks; 0: this call cannot fuse statistics
@@ -578,6 +582,7 @@ int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_a
   a.pad = d->pad;
   if (a.res && a.resld < a.Cout) return MI355_EINVAL;
   const long long vox = (long long)a.Do * a.Ho * a.Wo * a.N;
+  if (d->precision == MI355_PREC_F16) return dispatch_ns<1, true>(a, d->in_mode, vox, stream);
   if (ns == 1) return dispatch_ns<1>(a, d->in_mode, vox, stream);
   if (ns == 2) return dispatch_ns<2>(a, d->in_mode, vox, stream);
   return dispatch_ns<3>(a, d->in_mode, vox, stream);

@@ -203,7 +203,7 @@ template <> struct C4Prod<1> { static constexpr int P = 1; static constexpr int 
 template <> struct C4Prod<2> { static constexpr int P = 3; static constexpr int pa[3] = {1, 0, 0}; static constexpr int pb[3] = {0, 1, 0}; };
 template <> struct C4Prod<3> { static constexpr int P = 6; static constexpr int pa[6] = {2, 1, 0, 1, 0, 0}; static constexpr int pb[6] = {0, 1, 2, 0, 1, 0}; };   // smallest terms first
 
-template <int NS, int INMODE, bool FUSE>
+template <int NS, int INMODE, bool FUSE, bool F16 = false>      // F16: MI355_PREC_F16, the single plane is fp16
 __global__ __launch_bounds__(256) void conv3d_c4_fwd_bf16(C4Args a) {
   constexpr int TZ = 4, TY = 8, TX = 8, HZ = 6, HY = 10, HX = 10, HV = HZ * HY * HX, MT = 2, KS = 7;
   constexpr int P = C4Prod<NS>::P;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void conv3d_c4_fwd_bf16(C4Args a) {
       const int ks = k >> 4, hh = (k >> 3) & 1, e = k & 7;
 #pragma unroll
       for (int p = 0; p < NS; ++p) {
-        const unsigned pk = pack_bf16x2(v, 0.f);
+        const unsigned pk = pack_lp2<F16>(v, 0.f);
         w16[((((ks * 2 + hh) * NS + p) * 32 + co) << 3) + e] = (unsigned short)(pk & 0xffffu);
         v -= bf16lo_to_f32(pk);
       }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void conv3d_c4_fwd_bf16(C4Args a) {
       if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int p = 0; p < NS; ++p) {
-        const unsigned lo = pack_bf16x2(v.x, v.y), hi = pack_bf16x2(v.z, v.w);
+        const unsigned lo = pack_lp2<F16>(v.x, v.y), hi = pack_lp2<F16>(v.z, v.w);
         lds_x[hv * NS + p] = make_uint2(lo, hi);
         if (p + 1 < NS) { v.x -= bf16lo_to_f32(lo); v.y -= bf16hi_to_f32(lo); v.z -= bf16lo_to_f32(hi); v.w -= bf16hi_to_f32(hi); }
       }
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void conv3d_c4_fwd_bf16(C4Args a) {
           af[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
 #pragma unroll
-        for (int q = 0; q < P; ++q) acc[mt] = MFMA_32x32x16_BF16(af[C4Prod<NS>::pa[q]], bf[C4Prod<NS>::pb[q]], acc[mt]);
+        for (int q = 0; q < P; ++q) acc[mt] = mfma_lp<F16>(af[C4Prod<NS>::pa[q]], bf[C4Prod<NS>::pb[q]], acc[mt]);
       }
     }
     // ---- epilogue (as conv3d_c4_fwd) ----
@@ -577,7 +577,9 @@ int mi355_conv3d_c4_fwd_impl(const mi355_act* x, const float* w, const mi355_act
     const long long wg = cols * a.splits;
     if (wg > 0x7fffffffLL) return MI355_EINVAL;
     const int ns = d->precision == MI355_PREC_BF16X3 ? 2 : (d->precision == MI355_PREC_BF16X6 ? 3 : 1);
-#define MI355_C4B(NSV, IM, FU) LAUNCH((conv3d_c4_fwd_bf16<NSV, IM, FU>), dim3((unsigned)wg), dim3(256), 0, stream, a)
+#define MI355_C4B(NSV, IM, FU) \
+    do { if (d->precision == MI355_PREC_F16) LAUNCH((conv3d_c4_fwd_bf16<NSV == 1 ? 1 : NSV, IM, FU, NSV == 1>), dim3((unsigned)wg), dim3(256), 0, stream, a); \
+         else LAUNCH((conv3d_c4_fwd_bf16<NSV, IM, FU>), dim3((unsigned)wg), dim3(256), 0, stream, a); } while (0)
 #define MI355_C4B_NS(NSV)                                                                                  \
     do {                                                                                                   \
       if (a.mom) { if (d->in_mode == MI355_IN_PLAIN) MI355_C4B(NSV, MI355_IN_PLAIN, true); else MI355_C4B(NSV, MI355_IN_AFFINE_ACT, true); }   \

@@ -792,7 +792,7 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
   if ((d->in_mode == MI355_IN_S2D || d->out_mode == MI355_OUT_D2S) && d->kd != 1) return MI355_EUNSUPPORTED;
   if (d->in_mode == MI355_IN_S2D && d->out_mode == MI355_OUT_D2S) return MI355_EUNSUPPORTED;
   if (d->out_mode != MI355_OUT_PLAIN && d->out_mode != MI355_OUT_D2S) return MI355_EINVAL;
-  if (d->precision < MI355_PREC_F32 || d->precision > MI355_PREC_BF16) return MI355_EINVAL;
+  if (d->precision < MI355_PREC_F32 || d->precision > MI355_PREC_F16) return MI355_EINVAL;
   if (d->wformat == MI355_W_OIDHW4) return mi355_conv3d_c4_fwd_impl(x, wp, y, d, stream);
   const bool wants_stats = d->moments_out || d->gn_bwd;
   if (d->wformat == MI355_W_PACKED_F32_NARROW) return wants_stats ? MI355_EUNSUPPORTED : mi355_conv3d_narrow_impl(x, wp, y, d, stream);

@@ -537,7 +537,7 @@ extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
   if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift)) return MI355_EINVAL;
   if (d->in_mode == MI355_IN_AFFINE_ACT && !(d->act_slope >= 0.f && d->act_slope <= 1.f)) return MI355_EINVAL;
-  if (d->precision < MI355_PREC_F32 || d->precision > MI355_PREC_BF16) return MI355_EINVAL;
+  if (d->precision < MI355_PREC_F32 || d->precision > MI355_PREC_F16) return MI355_EINVAL;
   if (mi355_conv3d_c4_ok(x, d)) return mi355_conv3d_c4_wgrad_impl(x, dy, dw, d, ws, ws_bytes, stream);
   if (wgrad_uses_bf16(d)) return mi355_conv3d_wgrad_bf16_impl(x, dy, dw, d, ws, ws_bytes, stream);
   if (wgrad_uses_ring(d)) {

@@ -38,7 +38,7 @@ template <> struct WProducts<2> { static constexpr int P = 3; static constexpr i
 template <> struct WProducts<3> { static constexpr int P = 6; static constexpr int pa[6] = {2, 1, 0, 1, 0, 0}; static constexpr int pb[6] = {0, 1, 2, 0, 1, 0}; };
 
 // column c of an 8-voxel x 4-channel register block -> NS planes of 8 packed bf16
-template <int NS>
+template <int NS, bool F16 = false>
 __device__ __forceinline__ void split_col(const float (&v)[8][4], int c, uint4 (&out)[NS]) {
   float r[8];
 #pragma unroll
@@ -48,7 +48,7 @@ __device__ __forceinline__ void split_col(const float (&v)[8][4], int c, uint4 (
     unsigned w[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      w[e] = pack_bf16x2(r[2 * e], r[2 * e + 1]);
+      w[e] = pack_lp2<F16>(r[2 * e], r[2 * e + 1]);
       if (p + 1 < NS) { r[2 * e] -= bf16lo_to_f32(w[e]); r[2 * e + 1] -= bf16hi_to_f32(w[e]); }
     }
     out[p] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -68,7 +68,7 @@ __device__ __forceinline__ uint4 shift_run(const uint4& b0, const uint4& b1) {
 // global memory -- every load of the tile issued before the first use, from clamped always-valid addresses (a branch around a
 // load would serialise the round trips) --, transform/split/transpose it and write it to the other dy buffer / the free slot
 // of a 4-plane ring. One barrier per tile; global-memory latency is never on the consumers' path.
-template <int NS, int MT, int NLW, int INMODE>
+template <int NS, int MT, int NLW, int INMODE, bool F16 = false>      // F16: MI355_PREC_F16, the single plane is fp16
 __global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArgs a) {
   constexpr int TY = 4, ROWS = 4, HY = 6, XO = 3, RING = 4;
   constexpr int COT = 32 * MT;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArg
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
               uint4 pl[NS];
-              split_col<NS>(v, cc, pl);
+              split_col<NS, F16>(v, cc, pl);
 #pragma unroll
               for (int p = 0; p < NS; ++p) ldsB[(p * 32 + 4 * q + cc) * CSB + (slot * HY + hy) * XO + oct] = pl[p];
             }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArg
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
               uint4 pl[NS];
-              split_col<NS>(v, cc, pl);
+              split_col<NS, F16>(v, cc, pl);
 #pragma unroll
               for (int p = 0; p < NS; ++p) ldsA[((buf * NS + p) * COT + 4 * qq + cc) * CSA + row * 2 + oct] = pl[p];
             }
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArg
           for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-              acc[dx][mt] = MFMA_32x32x16_BF16(af[mt][WProducts<NS>::pa[qq]], bf[dx][WProducts<NS>::pb[qq]], acc[dx][mt]);
+              acc[dx][mt] = mfma_lp<F16>(af[mt][WProducts<NS>::pa[qq]], bf[dx][WProducts<NS>::pb[qq]], acc[dx][mt]);
       }
     }
     __syncthreads();
@@ -271,6 +271,7 @@ static int nsplit_of_w(int precision) {
     case MI355_PREC_BF16X3: return 2;
     case MI355_PREC_BF16X6: return 3;
     case MI355_PREC_BF16: return 1;
+    case MI355_PREC_F16: return 1;
     default: return 0;
   }
 }
@@ -306,18 +307,18 @@ size_t mi355_conv3d_wgrad_bf16_workspace(const mi355_act* x, const mi355_act* dy
   return p.ok ? p.ws_bytes : 0;
 }
 
-template <int NS, int MT>
+template <int NS, int MT, bool F16 = false>
 static int launch_wb(WgradBArgs& a, const WBPlan& p, int in_mode, void* stream) {
   constexpr int NLW = MT == 1 ? 4 : 3;     // producer waves: 4 cover a tile's 208 staging units in one round; MT = 2 is VGPR-limited to 12 waves
   constexpr size_t lds = ((size_t)2 * NS * 32 * MT * 9 + (size_t)NS * 32 * 73) * 16;
   static_assert(lds <= 160 * 1024, "LDS");
   dim3 grid(p.splits, p.ciTiles, p.coTilesWG);
   if (in_mode == MI355_IN_PLAIN) {
-    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_PLAIN>), lds);
-    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_PLAIN>), grid, dim3(576 + 64 * NLW), lds, stream, a);
+    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_PLAIN, F16>), lds);
+    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_PLAIN, F16>), grid, dim3(576 + 64 * NLW), lds, stream, a);
   } else {
-    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_AFFINE_ACT>), lds);
-    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_AFFINE_ACT>), grid, dim3(576 + 64 * NLW), lds, stream, a);
+    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_AFFINE_ACT, F16>), lds);
+    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_AFFINE_ACT, F16>), grid, dim3(576 + 64 * NLW), lds, stream, a);
   }
   return LAUNCH_CHECK();
 }
@@ -336,7 +337,8 @@ int mi355_conv3d_wgrad_bf16_impl(const mi355_act* x, const mi355_act* dy, float*
   a.splits = p.splits; a.ciTiles = p.ciTiles; a.coTiles32 = p.coTiles32;
   const int ns = nsplit_of_w(d->precision);
   int rc;
-  if (p.mt == 2) rc = ns == 1 ? launch_wb<1, 2>(a, p, d->in_mode, stream) : launch_wb<2, 2>(a, p, d->in_mode, stream);
+  if (d->precision == MI355_PREC_F16) rc = p.mt == 2 ? launch_wb<1, 2, true>(a, p, d->in_mode, stream) : launch_wb<1, 1, true>(a, p, d->in_mode, stream);
+  else if (p.mt == 2) rc = ns == 1 ? launch_wb<1, 2>(a, p, d->in_mode, stream) : launch_wb<2, 2>(a, p, d->in_mode, stream);
   else rc = ns == 1 ? launch_wb<1, 1>(a, p, d->in_mode, stream) : ns == 2 ? launch_wb<2, 1>(a, p, d->in_mode, stream) : launch_wb<3, 1>(a, p, d->in_mode, stream);
   if (rc) return rc;
   return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, p.splits, p.ciTiles, stream);

@@ -33,6 +33,16 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   f32x2_t v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+// v_mfma_f32_32x32x16_f16: the same operand / result maps with IEEE half operands (what torch's CUDA autocast runs convolutions in)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+#define MFMA_32x32x16_F16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
+// two floats -> two fp16 (round to nearest even, as tensor.half()) packed in one dword: v_cvt_pk_f16_f32
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+}
 // two fp32 lanes per VGPR pair: v_pk_fma_f32 (the vector ALU's full fp32 rate needs the packed form)
 typedef f32x2_t pkf2;
 __device__ __forceinline__ pkf2 make_pkf2(float x, float y) { pkf2 v = {x, y}; return v; }
@@ -57,6 +67,12 @@ __device__ __forceinline__ pkf2 pk_fma(pkf2 a, pkf2 b, pkf2 c) { return __builti
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// 16-bit operand type of the matrix pipe: bf16 (the split-operand modes and MI355_PREC_BF16) or fp16 (MI355_PREC_F16)
+template <bool F16> __device__ __forceinline__ unsigned pack_lp2(float lo, float hi) { return F16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
+template <bool F16> __device__ __forceinline__ f32x16 mfma_lp(const uint4& a, const uint4& b, f32x16 c) {
+  if constexpr (F16) return MFMA_32x32x16_F16(a, b, c);
+  else return MFMA_32x32x16_BF16(a, b, c);
+}
 // value of the bf16 stored in the low / high half of a packed dword
 __device__ __forceinline__ float bf16lo_to_f32(unsigned p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(unsigned p) { return __uint_as_float(p & 0xffff0000u); }

@@ -41,7 +41,7 @@ class HipNetBase(nn.Module):
 
     def _init_engine(self):
         self._be = None
-        self.conv_precision = None   # None: the backend's setting; "fp32" | "bf16x6" | "bf16x3" | "bf16": per-module override
+        self.conv_precision = None   # None: the backend's setting; "fp32" | "bf16x6" | "bf16x3" | "bf16" | "fp16": per-module override
         self._flat = None          # flat parameter buffer (views are the nn.Parameters)
         self._flat_grad = None
         self._packed = {}          # id(param) -> [version, {mode: packed tensor}, data_ptr]

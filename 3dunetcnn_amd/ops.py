@@ -133,7 +133,8 @@ class Backend:
         self.fused_stats = os.environ.get("MI355_FUSED_STATS", "1") != "0"
 
     def set_precision(self, name):
-        """"fp32" (exact f32 MFMA, default) | "bf16x3" | "bf16x6" (split-bf16 fp32 emulation) | "bf16" (mixed precision)."""
+        """"fp32" (exact f32 MFMA, default) | "bf16x3" | "bf16x6" (split-bf16 fp32 emulation) | "bf16" | "fp16" (mixed precision: operands
+        rounded to bf16 / IEEE fp16 while staged, fp32 accumulate and fp32 tensors; "fp16" is the arithmetic of torch's CUDA autocast)."""
         self.precision = PRECISIONS[name] if isinstance(name, str) else int(name)
 
     # -- plumbing ------------------------------------------------------------------------------------------------
@@ -533,7 +534,7 @@ def default_backend(device=None):
     dev = torch.cuda.current_device() if device is None else int(device)
     if dev not in _default:
         _default[dev] = Backend(device=torch.device("cuda", dev))
-        env = os.environ.get("MI355_PRECISION")        # fp32 (default) | bf16x6 | bf16x3 | bf16
+        env = os.environ.get("MI355_PRECISION")        # fp32 (default) | bf16x6 | bf16x3 | bf16 | fp16
         if env:
             _default[dev].set_precision(env)
     return _default[dev]

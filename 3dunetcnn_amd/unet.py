@@ -456,12 +456,18 @@ class HipUNet3D(HipNetBase):
 class HipAutocastUNet(HipUNet3D):
     """Drop-in for the reference's AutocastUNet (unet3d/models/pytorch/segmentation/unet.py:53-58), which runs UNet3D.forward
     under torch.cuda.amp.autocast (fp16 convolutions with fp32 accumulate, norms in fp32). MI355X equivalent: the 3x3x3
-    convolutions take the bf16 matrix path (operands rounded to bf16 while staged, fp32 accumulate; bf16 has fp32's exponent
-    range, so no GradScaler is needed), everything else stays fp32 -- BASELINE configs[2]'s "bf16 mixed precision"."""
+    convolutions take the 16-bit matrix path (operands rounded while staged, fp32 accumulate, fp32 tensors), everything else stays fp32.
+      autocast_dtype="bf16" (default): BASELINE configs[2]'s "bf16 mixed precision"; bf16 has fp32's exponent range, no GradScaler needed.
+      autocast_dtype="fp16": the reference class's own arithmetic (CUDA autocast defaults to fp16; v_mfma_f32_32x32x16_f16): 8x smaller
+        rounding error than bf16, fp16's range -- train it with torch's GradScaler as the reference's `training.amp` path does
+        (train/training_utils.py:60-69, 93-96), which this module's backward supports (tests/test_boundary.py)."""
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, *args, autocast_dtype="bf16", **kwargs):
         super().__init__(*args, **kwargs)
-        self.conv_precision = "bf16"
+        name = {torch.bfloat16: "bf16", torch.float16: "fp16", torch.half: "fp16"}.get(autocast_dtype, autocast_dtype)
+        if name not in ("bf16", "fp16"):
+            raise ValueError(f"autocast_dtype must be 'bf16' / torch.bfloat16 or 'fp16' / torch.float16, got {autocast_dtype!r}")
+        self.conv_precision = name
 
 
 class HipAutoImplantUNet(HipUNet3D):

@@ -39,13 +39,15 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0
 HBM_PEAK_GBPS = 8000.0
 
 
-DTYPE = {"fp32": "f32", "bf16x3": "f32 (3xbf16 split-MFMA emulation)", "bf16x6": "f32 (6xbf16 split-MFMA emulation)", "bf16": "bf16 (mixed)"}
+DTYPE = {"fp32": "f32", "bf16x3": "f32 (3xbf16 split-MFMA emulation)", "bf16x6": "f32 (6xbf16 split-MFMA emulation)", "bf16": "bf16 (mixed)", "fp16": "f16 (mixed)"}
 ARITH = {"fp32": "3x3x3 convs on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate)",
          "bf16x3": "3x3x3 stride-1 convs: fp32 operands split hi+lo bf16, 3 v_mfma_f32_32x32x16_bf16 products per MAC, fp32 accumulate "
                    "(product error <= 2^-16); everything else fp32",
          "bf16x6": "3x3x3 stride-1 convs: fp32 operands split into 3 bf16 planes, 6 bf16 MFMA products per MAC, fp32 accumulate "
                    "(product error ~2^-23, fp32-class); everything else fp32",
-         "bf16": "3x3x3 stride-1 convs: operands rounded to bf16, fp32 accumulate (autocast-style mixed precision); everything else fp32"}
+         "bf16": "3x3x3 stride-1 convs: operands rounded to bf16, fp32 accumulate (autocast-style mixed precision); everything else fp32",
+         "fp16": "3x3x3 stride-1 convs: operands rounded to IEEE fp16 (v_mfma_f32_32x32x16_f16), fp32 accumulate -- the arithmetic of the "
+                 "reference's AutocastUNet under CUDA autocast; everything else fp32"}
 
 
 def parse():
@@ -55,7 +57,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=2, help="volumes per GPU (BASELINE configs[1]: 2)")
     ap.add_argument("--size", type=int, default=128, help="cubic patch edge (BASELINE configs[1]: 128)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x6", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x6", "bf16", "fp16"],
                     help="arithmetic of the 3x3x3 stride-1 convs: exact f32 MFMA (default) | split-bf16 fp32 emulation | bf16")
     ap.add_argument("--model", default="unet3d", choices=["unet3d", "dynunet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -328,7 +330,7 @@ def main():
         ach = fl / secs / 1e12
         on_bf16 = "bf16" in name
         peak = BF16_MFMA_PEAK_TFLOPS if on_bf16 else FP32_MFMA_PEAK_TFLOPS
-        products = {"bf16x3": 3, "bf16x6": 6, "bf16": 1}.get(args.precision, 1) if on_bf16 else 1
+        products = {"bf16x3": 3, "bf16x6": 6, "bf16": 1, "fp16": 1}.get(args.precision, 1) if on_bf16 else 1
         traffic, traffic_src = pmc_traffic(name, args.precision)
         roofline = {"bound": "mfma", "kernel": name, "measured": roof_note, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",

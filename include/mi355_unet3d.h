@@ -54,6 +54,9 @@ typedef struct mi355_act {
                                 product error <= ~2^-16 relative ("3xBF16 fp32 emulation"). 2.5 PFLOP/s / 3 peak. */
 #define MI355_PREC_BF16X6 2  /* 3 planes, the 6 products of order <= 2: ~2^-23, fp32-class. 2.5 PFLOP/s / 6 peak. */
 #define MI355_PREC_BF16 3    /* operands rounded to bf16, one product: autocast-style mixed precision. 2.5 PFLOP/s peak. */
+#define MI355_PREC_F16 4     /* operands rounded to IEEE fp16 (round to nearest even), one v_mfma_f32_32x32x16_f16 product, fp32 accumulate:
+                                the arithmetic of torch.cuda.amp.autocast (fp16) around the reference's AutocastUNet
+                                (models/pytorch/segmentation/unet.py:53-58); outputs stay fp32. 2.5 PFLOP/s peak. */
 
 /* Output-side layout of the conv kernels. */
 #define MI355_OUT_PLAIN 0

@@ -204,14 +204,19 @@ def test_bucketed_allreduce_over_rccl_single_rank():
         dist.destroy_process_group()
 
 
-def test_autocast_unet_bf16_mixed_precision():
-    """HipAutocastUNet (reference AutocastUNet, unet.py:53-58; BASELINE configs[2] 'bf16 mixed precision'): 3x3x3 convs on the
-    bf16 matrix path, fp32 everywhere else. Tolerance is bf16's (8 mantissa bits): logits 3e-2, loss 1e-2 vs the fp32 oracle;
-    a few optimizer steps must reduce the loss like the fp32 run does."""
+@pytest.mark.parametrize("mode,tol_out,tol_loss", [("bf16", 3e-2, 1e-2), ("fp16", 4e-3, 2e-3)])
+def test_autocast_unet_mixed_precision(mode, tol_out, tol_loss):
+    """HipAutocastUNet (reference AutocastUNet, unet.py:53-58): 3x3x3 convs on the 16-bit matrix path, fp32 everywhere else.
+    bf16 = BASELINE configs[2] 'bf16 mixed precision' (8 significand bits: logits 3e-2, loss 1e-2 vs the fp32 oracle); fp16 = the
+    reference class's own CUDA-autocast arithmetic (11 bits: 4e-3 / 2e-3). With fp16 the training steps go through torch's GradScaler,
+    as the reference's amp path does (training_utils.py:60-69, 93-96). A few optimizer steps must reduce the loss like the fp32 run does."""
     torch.manual_seed(11)
     kw = dict(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1, 2])
-    m = unet.HipAutocastUNet(**kw).cuda().eval()
-    assert m.conv_precision == "bf16"
+    m = unet.HipAutocastUNet(autocast_dtype=mode, **kw).cuda().eval()
+    assert m.conv_precision == mode and unet.HipAutocastUNet(**kw).conv_precision == "bf16"
+    assert unet.HipAutocastUNet(autocast_dtype=torch.float16, **kw).conv_precision == "fp16"
+    with pytest.raises(ValueError):
+        unet.HipAutocastUNet(autocast_dtype="fp8", **kw)
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
     x, y = R.synthetic_case(2, 4, (32, 32, 32), 3)
     ref = R.unet3d_forward(sd, x, (1, 1, 2))
@@ -219,17 +224,23 @@ def test_autocast_unet_bf16_mixed_precision():
     crit = losses.HipDiceLoss(sigmoid=True)
     out = m(x.cuda())
     loss = crit(out, y.cuda())
-    assert 1e-5 < C.rel_err(out, ref.detach()) < 3e-2          # really the bf16 path (not bit-close), within bf16 tolerance
-    assert abs(float(loss) - float(lref)) / float(lref) < 1e-2
+    assert 1e-5 < C.rel_err(out, ref.detach()) < tol_out       # really the 16-bit path (not bit-close), within its tolerance
+    assert abs(float(loss) - float(lref)) / float(lref) < tol_loss
     be = importlib.import_module("3dunetcnn_amd.ops").default_backend()
     assert be.precision == 0                                    # the per-module override does not leak into the backend
     opt = optim.HipAdam(m.parameters(), lr=1e-3)
+    scaler = torch.amp.GradScaler("cuda") if mode == "fp16" else None
     first = None
     for _ in range(8):
         opt.zero_grad()
         l = crit(m(x.cuda()), y.cuda())
-        l.backward()
-        opt.step()
+        if scaler is None:
+            l.backward()
+            opt.step()
+        else:
+            scaler.scale(l).backward()
+            scaler.step(opt)
+            scaler.update()
         first = float(l) if first is None else first
     assert float(l) < first
 

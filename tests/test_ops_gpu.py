@@ -62,7 +62,7 @@ def test_conv_dgrad_first_layer(hip_backend, kw):
 
 def test_conv_dgrad_first_layer_every_precision_mode(hip_backend):
     # the narrow-output kernel is exact fp32 whatever the backend's arithmetic mode (the fp32 pack is selected in ops.PackedWeight)
-    for mode in ("bf16x3", "bf16x6", "bf16"):
+    for mode in ("bf16x3", "bf16x6", "bf16", "fp16"):
         hip_backend.set_precision(mode)
         try:
             assert C.case_conv_dgrad(hip_backend, 1, 4, 32, (12, 16, 20)) < TOL
@@ -227,10 +227,10 @@ def test_layout(hip_backend):
 
 
 # ---- split-bf16 matrix path of the 3x3x3 stride-1 convs (csrc/conv3d_bf16.hip): fp32 in/out, products on bf16 MFMA ----
-BF16_TOL = {"bf16x3": 1e-4, "bf16x6": 5e-6, "bf16": 3e-2}
+BF16_TOL = {"bf16x3": 1e-4, "bf16x6": 5e-6, "bf16": 3e-2, "fp16": 4e-3}      # fp16: MI355_PREC_F16, 11 significand bits
 
 
-@pytest.fixture(params=["bf16x3", "bf16x6", "bf16"])
+@pytest.fixture(params=["bf16x3", "bf16x6", "bf16", "fp16"])
 def prec_backend(hip_backend, request):
     hip_backend.set_precision(request.param)
     yield hip_backend, BF16_TOL[request.param]

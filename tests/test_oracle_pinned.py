@@ -106,6 +106,61 @@ def test_emulated_kernels_reproduce_golden(emu_backend, name):
         assert C.rel_err(p.grad, g["grads"][k]) < 1e-3, k
 
 
+def _autocast_golden(be, dev):
+    """HipAutocastUNet against the REFERENCE graph run under torch.autocast (tests/golden/unet3d_small_autocast.pt, generated by
+    oracle/make_golden.py from the imported reference; AutocastUNet = UNet3D.forward under autocast, unet.py:53-58). Two 16-bit
+    roundings of the same fp32 network are compared, so the bound is the sum of both errors; the HIP modes keep fp32 tensors between
+    the convolutions (the reference rounds every conv OUTPUT to 16 bits too), so they must also be at least as close to the fp32
+    logits as the reference's own autocast result is."""
+    a = torch.load(os.path.join(GOLD, "unet3d_small_autocast.pt"))
+    g = torch.load(os.path.join(GOLD, a["bundle"]))
+    res = {}
+    for mode, tol in (("fp16", 4e-3), ("bf16", 3e-2)):
+        m = unet.HipAutocastUNet(autocast_dtype=mode, **g["kwargs"]).to(dev).eval()
+        if be is not None:
+            m._be = be
+        m.load_state_dict(g["state_dict"])
+        with torch.no_grad():
+            out = m(g["x"].to(dev)).cpu()
+        ref16, ref32 = a["logits_" + mode], g["logits"]
+        e_ref = C.rel_err(ref16, ref32)                      # the reference's own autocast error
+        e_hip = C.rel_err(out, ref32)
+        assert C.rel_err(out, ref16) < tol, (mode, C.rel_err(out, ref16))
+        assert 1e-6 < e_hip <= e_ref, (mode, e_hip, e_ref)  # really the 16-bit path, and no worse than the reference's
+        res[mode] = e_hip
+    assert res["fp16"] < 0.25 * res["bf16"]                  # 11 vs 8 significand bits
+    return res
+
+
+def test_autocast_unet_matches_reference_under_autocast_on_emulator(emu_backend):
+    _autocast_golden(emu_backend, "cpu")
+
+
+@pytest.mark.gpu
+def test_autocast_unet_matches_reference_under_autocast_gpu():
+    print(_autocast_golden(None, "cuda"))
+
+
+def test_fp16_mode_rounds_operands_like_tensor_half(emu_backend):
+    """MI355_PREC_F16 = conv of the fp16-ROUNDED operands (round to nearest even, as tensor.half()) with exact products and fp32
+    accumulation: against F.conv3d of the rounded tensors the difference is accumulation order only."""
+    import torch.nn.functional as F
+    be = emu_backend
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 32, 4, 6, 18, generator=g) * 3.0
+    w = torch.randn(32, 32, 3, 3, 3, generator=g) * 0.05
+    ref = F.conv3d(x.half().float(), w.half().float(), padding=1)
+    be.set_precision("fp16")
+    try:
+        xa, ya = C.to_act(be, x), C.to_act(be, torch.zeros_like(ref))
+        be.conv_fwd(xa, be.pack_weight(w, 0), ya, 3, 1)
+        out = C.from_act(ya)
+    finally:
+        be.set_precision("fp32")
+    assert C.rel_err(out, ref) < 2e-6
+    assert C.rel_err(out, F.conv3d(x, w, padding=1)) > 1e-5        # and it is not the fp32 path
+
+
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "mi355_unet3d.h")).read()
     declared = set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", hdr))

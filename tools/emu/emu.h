@@ -233,6 +233,58 @@ static inline f32x16 emu_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
   return c;
 }
 #define MFMA_32x32x16_BF16(a, b, c) emu_mfma_32x32x16_bf16(a, b, c)
+// fp16 operands (v_cvt_pk_f16_f32: round to nearest even; v_mfma_f32_32x32x16_f16): same maps, same "exact products, one rounding" model
+static inline unsigned emu_f2h(float f) {           // IEEE binary16, round to nearest even, subnormals and overflow to inf
+  const unsigned u = __float_as_uint(f), sign = (u >> 16) & 0x8000u;
+  const unsigned e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+  if (e == 0xffu) return sign | 0x7c00u | (m ? 0x200u : 0u);
+  const int ex = (int)e - 127 + 15;
+  if (ex >= 31) return sign | 0x7c00u;
+  if (ex <= 0) {
+    if (ex < -10) return sign;
+    const unsigned mm = m | 0x800000u;                     // 24-bit significand
+    const int shift = 14 - ex;                             // 14 .. 24
+    unsigned h = mm >> shift;
+    const unsigned rem = mm & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (h & 1u))) ++h;
+    return sign | h;
+  }
+  unsigned h = ((unsigned)ex << 10) | (m >> 13);
+  const unsigned rem = m & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;   // may carry into the exponent (and to inf): still the right value
+  return sign | h;
+}
+static inline float emu_h2f(unsigned h) {
+  const unsigned sign = (h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  if (e == 0) return (sign ? -1.f : 1.f) * ldexpf((float)m, -24);
+  if (e == 31) return __uint_as_float(sign | 0x7f800000u | (m << 13));
+  return __uint_as_float(sign | ((e + 112u) << 23) | (m << 13));
+}
+static inline unsigned pack_f16x2(float lo, float hi) { return emu_f2h(lo) | (emu_f2h(hi) << 16); }
+static inline f32x16 emu_mfma_32x32x16_f16(uint4 a, uint4 b, f32x16 c) {
+  emu::BlockState* bs = emu::g_bs;
+  int t = emu::flat_tid();
+  int wbase = (t / 64) * 64, l = t % 64;
+  bs->mfma_a4[t] = a; bs->mfma_b4[t] = b;
+  emu::wave_barrier();
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    double acc = (double)c[r];
+    for (int h = 0; h < 2; ++h) {
+      const unsigned* pa = &bs->mfma_a4[wbase + 32 * h + row].x;
+      const unsigned* pb = &bs->mfma_b4[wbase + 32 * h + col].x;
+      for (int e = 0; e < 4; ++e) {
+        acc += (double)emu_h2f(pa[e] & 0xffffu) * (double)emu_h2f(pb[e] & 0xffffu);
+        acc += (double)emu_h2f(pa[e] >> 16) * (double)emu_h2f(pb[e] >> 16);
+      }
+    }
+    c[r] = (float)acc;
+  }
+  emu::wave_barrier();
+  return c;
+}
+#define MFMA_32x32x16_F16(a, b, c) emu_mfma_32x32x16_f16(a, b, c)
 
 static inline float atomicAdd(float* p, float v) {
   std::atomic_ref<float> r(*p); float old = r.load();
