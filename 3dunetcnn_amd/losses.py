@@ -146,6 +146,14 @@ class _WithWeight:
         self.class_weight = cw
 
 
+def _onehot_u8(be, labels, n_classes):
+    """class-index map [N, 1, ...] or [N, ...] -> uint8 one-hot [N, C, ...] on the device (mi355_one_hot, one launch per sample)."""
+    if labels.dim() >= 2 and labels.shape[1] == 1 and labels.dim() > 2:
+        labels = labels[:, 0]
+    groups = [[c] for c in range(n_classes)]
+    return torch.stack([be.one_hot(labels[i].float().contiguous(), groups) for i in range(labels.shape[0])])
+
+
 class _CEFunction(torch.autograd.Function):
     """loss = lambda_dice * Dice + lambda_ce * CE (either weight may be 0), value and d/dlogits from the fused HIP passes."""
     @staticmethod
@@ -153,14 +161,31 @@ class _CEFunction(torch.autograd.Function):
         be = mod._be or _ops.default_backend(logits.device)
         want = ctx.needs_input_grad[0]
         logits, target = logits.contiguous(), target.contiguous()
+        c = logits.shape[1]
+        if target.shape != logits.shape:                      # class indices (to_onehot_y / index targets): one-hot once, both terms use it
+            target = _onehot_u8(be, target, c)
         loss = dlogits = None
+        dice_ex = getattr(mod, "dice_ex", None)              # options the one-call Dice kernel does not carry
+        summed = getattr(mod, "reduction", "mean") == "sum"
         if mod.lambda_dice != 0.0:
-            loss, dlogits = be.dice(logits, target, sigmoid=mod.sigmoid, batch=mod.batch, squared_pred=mod.squared_pred,
-                                    smooth_nr=mod.smooth_nr, smooth_dr=mod.smooth_dr, want_grad=want, grad_scale=mod.lambda_dice,
-                                    include_background=mod.include_background)
+            if dice_ex is None and not summed:
+                loss, dlogits = be.dice(logits, target, sigmoid=mod.sigmoid, batch=mod.batch, squared_pred=mod.squared_pred,
+                                        smooth_nr=mod.smooth_nr, smooth_dr=mod.smooth_dr, want_grad=want, grad_scale=mod.lambda_dice,
+                                        include_background=mod.include_background)
+            else:
+                act = "softmax" if (dice_ex or {}).get("softmax") and c > 1 else ("sigmoid" if mod.sigmoid else None)
+                loss, state = be.dice_ex_forward(logits, target, activation=act, batch=mod.batch, squared_pred=mod.squared_pred,
+                                                 include_background=mod.include_background, jaccard=bool((dice_ex or {}).get("jaccard")),
+                                                 reduction="sum" if summed else "mean", smooth_nr=mod.smooth_nr, smooth_dr=mod.smooth_dr)
+                if want:
+                    dlogits = be.dice_ex_backward(logits, target, state, torch.full((1,), mod.lambda_dice, dtype=torch.float32,
+                                                                                    device=logits.device))
             loss.mul_(mod.lambda_dice)
         if mod.lambda_ce != 0.0:
-            loss, dlogits = be.cross_entropy(logits, target, mode=mod.ce_mode, weight=mod.lambda_ce, loss=loss,
+            w = mod.lambda_ce
+            if summed:                                        # CrossEntropyLoss / BCEWithLogitsLoss(reduction="sum") = mean x count
+                w *= logits.shape[0] * logits[0, 0].numel() * (1 if mod.ce_mode == "softmax" else c)
+            loss, dlogits = be.cross_entropy(logits, target, mode=mod.ce_mode, weight=w, loss=loss,
                                              dlogits=dlogits if want else None, want_grad=want)
         ctx.dlogits = dlogits
         return loss.reshape(())
@@ -193,27 +218,41 @@ class _CEBase(nn.Module):
     def forward(self, input, target):
         if input.device.type != "cuda" and getattr(self, "_be", None) is None:
             raise RuntimeError(f"{type(self).__name__} runs on an MI355X only (no CPU fallback)")
-        if target.shape != input.shape:
+        index_shape = (input.shape[0],) + tuple(input.shape[2:])
+        as_index = getattr(self, "index_targets", False) and input.shape[1] > 1 and \
+            tuple(target.shape) in (index_shape, (input.shape[0], 1) + tuple(input.shape[2:]))
+        if target.shape != input.shape and not as_index:
             raise AssertionError(f"ground truth has different shape ({tuple(target.shape)}) from input ({tuple(input.shape)})")
         if input.shape[1] > 16:
             raise NotImplementedError("more than 16 classes")
-        if target.dtype not in (torch.uint8, torch.float32):
+        if not as_index and target.dtype not in (torch.uint8, torch.float32):
             target = target.to(torch.float32)
         return _CEFunction.apply(input.float(), target, self)
 
 
 class HipDiceCELoss(_CEBase):
-    """monai.losses.DiceCELoss: lambda_dice * DiceLoss(...) + lambda_ce * CrossEntropyLoss(mean)(input, one-hot target as
-    probabilities) for more than one channel, BCEWithLogitsLoss(mean) for a single channel."""
+    """monai.losses.DiceCELoss: lambda_dice * DiceLoss(...) + lambda_ce * CrossEntropyLoss(input, target) for more than one channel,
+    BCEWithLogitsLoss for a single channel. softmax / jaccard / squared_pred / batch / include_background configure the Dice term,
+    to_onehot_y takes a class-index target [N, 1, ...], reduction "mean" | "sum" applies to both terms. Not implemented (raise): `weight`
+    (MONAI hands it to the CE term too), `label_smoothing`, `other_act`, reduction "none"."""
     def __init__(self, include_background=True, to_onehot_y=False, sigmoid=False, softmax=False, other_act=None, squared_pred=False,
                  jaccard=False, reduction="mean", smooth_nr=1e-5, smooth_dr=1e-5, batch=False, weight=None, lambda_dice=1.0,
                  lambda_ce=1.0, label_smoothing=0.0):
         super().__init__()
-        bad = [k for k, v in dict(to_onehot_y=to_onehot_y, softmax=softmax,
-                                  other_act=other_act is not None, jaccard=jaccard, reduction=reduction != "mean",
+        reduction = str(getattr(reduction, "value", reduction)).lower()
+        if other_act is not None and not callable(other_act):
+            raise TypeError(f"other_act must be None or callable but is {type(other_act).__name__}.")
+        if int(sigmoid) + int(softmax) + int(other_act is not None) > 1:
+            raise ValueError("Incompatible values: more than 1 of [sigmoid=True, softmax=True, other_act is not None].")
+        bad = [k for k, v in dict(other_act=other_act is not None, reduction=reduction not in ("mean", "sum"),
                                   weight=weight is not None, label_smoothing=label_smoothing != 0.0).items() if v]
         if bad:
             raise NotImplementedError("HipDiceCELoss does not implement: " + ", ".join(bad))
+        # softmax / jaccard go to the Dice term only (MONAI: the CE term always sees the raw logits); to_onehot_y: a class-index target
+        # [N, 1, ...] is expanded once on the device and both terms use the expansion (CE of indices == CE of their one-hot)
+        self.dice_ex = dict(softmax=bool(softmax), jaccard=bool(jaccard)) if (softmax or jaccard) else None
+        self.index_targets = bool(to_onehot_y)
+        self.reduction = reduction
         self.sigmoid, self.squared_pred, self.batch = bool(sigmoid), bool(squared_pred), bool(batch)
         self.smooth_nr, self.smooth_dr = float(smooth_nr), float(smooth_dr)
         self.lambda_dice, self.lambda_ce = float(lambda_dice), float(lambda_ce)
@@ -240,7 +279,9 @@ class HipBCEWithLogitsLoss(_CEBase):
 
 
 class HipCrossEntropyLoss(_CEBase):
-    """torch.nn.CrossEntropyLoss(reduction="mean") with class-PROBABILITY targets of the input's shape (one-hot uint8 / float)."""
+    """torch.nn.CrossEntropyLoss(reduction="mean") with class-PROBABILITY targets of the input's shape (one-hot uint8 / float) or
+    class-INDEX targets [N, ...] (expanded to one-hot on the device; `ignore_index` entries are not supported)."""
+    index_targets = True
     def __init__(self, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction="mean", label_smoothing=0.0):
         super().__init__()
         if weight is not None or reduction != "mean" or label_smoothing != 0.0 or size_average is not None or reduce is not None:

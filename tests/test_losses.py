@@ -32,6 +32,8 @@ def _check(crit, ref_fn, be, dev, n, c, dhw, name=""):
     z, t = _data(n, c, dhw)
     if "empty" in name:
         t = _empty(t)
+    if "labels" in name:                           # class-index target [N, 1, ...] (to_onehot_y / torch's index form)
+        t = torch.randint(0, c, (n, 1) + tuple(dhw), generator=torch.Generator().manual_seed(5))
     zr = z.clone().requires_grad_(True)
     ref = ref_fn(zr, t)
     ref.backward()
@@ -55,6 +57,16 @@ CASES = [
      lambda z, t: O.generalized_dice_loss(z, t, True, include_background=False), 4),
     ("gdl_batch", lambda: losses.HipGeneralizedDiceLoss(sigmoid=True, batch=True), lambda z, t: O.generalized_dice_loss(z, t, True, batch=True), 3),
     ("gdl_empty_class", lambda: losses.HipGeneralizedDiceLoss(sigmoid=True), lambda z, t: O.generalized_dice_loss(z, _empty(t), True), 3),
+    ("dicece_softmax_labels", lambda: losses.HipDiceCELoss(softmax=True, to_onehot_y=True),
+     lambda z, t: O.dice_loss(z, t, False, softmax=True, to_onehot_y=True) + F.cross_entropy(z, t[:, 0]), 4),
+    ("dicece_softmax_labels_nobg_weighted", lambda: losses.HipDiceCELoss(softmax=True, to_onehot_y=True, include_background=False,
+                                                                          lambda_dice=0.5, lambda_ce=1.5),
+     lambda z, t: 0.5 * O.dice_loss(z, t, False, softmax=True, to_onehot_y=True, include_background=False) + 1.5 * F.cross_entropy(z, t[:, 0]), 3),
+    ("dicece_jaccard_sum", lambda: losses.HipDiceCELoss(sigmoid=True, jaccard=True, reduction="sum"),
+     lambda z, t: O.dice_loss(z, t, True, jaccard=True, reduction="sum") + F.cross_entropy(z, t.float(), reduction="sum"), 3),
+    ("dicece_1ch_sum", lambda: losses.HipDiceCELoss(sigmoid=True, reduction="sum"),
+     lambda z, t: O.dice_loss(z, t, True, reduction="sum") + F.binary_cross_entropy_with_logits(z, t.float(), reduction="sum"), 1),
+    ("ce_labels", lambda: losses.HipCrossEntropyLoss(), lambda z, t: F.cross_entropy(z, t[:, 0]), 5),
     ("bce", lambda: losses.HipBCEWithLogitsLoss(), lambda z, t: F.binary_cross_entropy_with_logits(z, t.float()), 3),
     ("ce", lambda: losses.HipCrossEntropyLoss(), lambda z, t: F.cross_entropy(z, t.float()), 4),
 ]
@@ -149,8 +161,12 @@ def test_dice_option_validation_matches_monai():
 
 
 def test_unsupported_options_raise():
-    with pytest.raises(NotImplementedError):
-        losses.HipDiceCELoss(softmax=True)
+    with pytest.raises(NotImplementedError, match="weight"):
+        losses.HipDiceCELoss(softmax=True, weight=[1.0, 2.0])
+    with pytest.raises(NotImplementedError, match="reduction"):
+        losses.HipDiceCELoss(sigmoid=True, reduction="none")
+    with pytest.raises(ValueError, match="Incompatible values"):
+        losses.HipDiceCELoss(sigmoid=True, softmax=True)
     with pytest.raises(NotImplementedError):
         losses.HipBCEWithLogitsLoss(pos_weight=torch.ones(3))
     with pytest.raises(NotImplementedError):
