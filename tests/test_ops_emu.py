@@ -1,6 +1,7 @@
 """Kernel-logic parity on CPU: the SAME kernel sources compiled against tools/emu (fibers + fmaf-chain MFMA) vs the
 torch-CPU oracle. Small shapes only; the real parity gate is test_ops_gpu.py (-m gpu)."""
 import pytest
+import torch
 
 import op_cases as C
 
@@ -317,4 +318,37 @@ def test_norm_backward_sums_from_dgrad_epilogue_bf16_paths(prec_backend, kw):
 def test_conv_wgrad_ring_tall_planes(emu_backend, kw):
     assert C.case_conv_wgrad(emu_backend, **kw) < TOL
 
+
+# ---- the interior-tile epilogue and the general one must store the same bits ----
+@pytest.mark.parametrize("prec,kd,cin,cout,dhw", [
+    ("fp32", 3, 32, 32, (4, 8, 16)), ("fp32", 3, 16, 64, (8, 8, 8)), ("fp32", 3, 64, 32, (4, 4, 8)),
+    ("bf16", 3, 32, 32, (4, 8, 32)), ("bf16x3", 3, 16, 64, (4, 4, 16)), ("fp16", 3, 32, 32, (4, 4, 16)),
+])
+def test_interior_and_general_epilogues_store_identical_values(emu_backend, prec, kd, cin, cout, dhw):
+    """A layer whose extents are tile multiples takes the interior-tile epilogue (one base pointer per lane, wave-uniform offsets) in
+    every workgroup; writing the same result into a destination that is one voxel larger per axis, shifted by (1, 1, 1), forces the
+    general epilogue (per-value lane map, bound checks, window test). Same accumulators, same bias / residual / dropout-scale
+    arithmetic: the stored values must be bitwise equal."""
+    be = emu_backend
+    g = torch.Generator().manual_seed(21)
+    d, h, w = dhw
+    n = 2
+    x = torch.randn(n, cin, d, h, w, generator=g)
+    wt = torch.randn(cout, cin, kd, kd, kd, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, d, h, w, generator=g)
+    cs = (torch.rand(n, cout, generator=g) > 0.3).float() * 1.25
+    be.set_precision(prec)
+    try:
+        xa, ra = C.to_act(be, x), C.to_act(be, res)
+        wp = be.pack_weight(wt, 0)
+        y1 = C.to_act(be, torch.zeros(n, cout, d, h, w))
+        be.conv_fwd(xa, wp, y1, kd, 1, bias=b, residual=ra, chscale=cs)
+        y2 = C.to_act(be, torch.full((n, cout, d + 1, h + 1, w + 1), 7.0))
+        be.conv_fwd(xa, wp, y2, kd, 1, bias=b, residual=ra, chscale=cs, off=(1, 1, 1), out_dhw=(d, h, w))
+    finally:
+        be.set_precision("fp32")
+    a, c2 = C.from_act(y1), C.from_act(y2)
+    assert torch.equal(a, c2[:, :, 1:, 1:, 1:])
+    assert bool((c2[:, :, 0] == 7.0).all()) and bool((c2[:, :, :, 0] == 7.0).all()) and bool((c2[..., 0] == 7.0).all())
 
