@@ -61,8 +61,9 @@ def test_pmc_traffic_lookup_checks_provenance(tmp_path, monkeypatch):
     assert b.pmc_traffic("conv3d_wgrad_ring (+reduce)", "fp32")[0] is None
 
 
-def test_committed_bench_line_has_the_contract_shape():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_fp32.json")))
+@pytest.mark.parametrize("name", ["r1_bench_fp32.json", "r2_bench_fp32.json"])
+def test_committed_bench_line_has_the_contract_shape(name):
+    line = json.load(open(os.path.join(ROOT, "profiles", name)))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
@@ -77,6 +78,13 @@ def test_committed_bench_line_has_the_contract_shape():
     assert roof["traffic"] is None or roof["traffic"] >= roof["algorithmic_bytes_per_launch"]
     cpu = line["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0
+    if name.startswith("r2"):
+        # the round-2 line: traffic from a PMC summary collected on the kernel sources it was measured with, the dominant kernel's launch
+        # time consistent with its share of the step, one entry per rank
+        assert roof["traffic"] is not None and "stale" not in roof["traffic_source"]
+        assert line["per_rank_ms_per_step"] == [line["ms_per_step"]]
+        assert abs(roof["avg_launch_ms"] * roof["launches"] / 3 / line["ms_per_step"] - roof["share_of_step"]) < 0.02      # 3 roofline steps
+        assert set(line["precision_modes"]) == {"bf16x6", "bf16x3", "bf16"}
 
 
 def test_bench_needs_a_gpu():
@@ -108,7 +116,8 @@ def test_launcher_environment_wins_over_self_launch(emu_backend):
     WORLD_SIZE=1 and --gpus 1 prints n_gpus 1."""
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--size", "8", "--batch", "1", "--steps", "1",
-                        "--warmup", "1", "--emulator-plumbing-test"], capture_output=True, text=True, env=env, timeout=900)
+                        "--warmup", "1", "--precision", "fp16", "--emulator-plumbing-test"], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] == 1 and line["per_rank_ms_per_step"] == [line["ms_per_step"]]
+    assert line["dtype"] == "f16 (mixed)" and "v_mfma_f32_32x32x16_f16" in line["config"]["conv_arithmetic"]      # the fp16 mode end to end
