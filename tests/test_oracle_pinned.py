@@ -141,6 +141,31 @@ def test_autocast_unet_matches_reference_under_autocast_gpu():
     print(_autocast_golden(None, "cuda"))
 
 
+def test_mixed_precision_gradients_against_the_reference_gradients(emu_backend):
+    """Whole-network gradients of the 16-bit modes against the REFERENCE's fp32 gradients of the golden bundle (dgrad and wgrad run on
+    the 16-bit pipe too). A freshly initialised norm + Dice network amplifies operand rounding ~40x, so the bound is
+    global: relative error of the concatenated gradient and its cosine to the reference's -- measured fp16 2.0e-2 / 1 - 2e-4,
+    bf16 6.1e-2 / 1 - 1.8e-3."""
+    g = torch.load(os.path.join(GOLD, "unet3d_small.pt"))
+    res = {}
+    for mode, tol, cos_min in (("fp16", 5e-2, 0.999), ("bf16", 1.5e-1, 0.99)):
+        m = unet.HipAutocastUNet(autocast_dtype=mode, **g["kwargs"]).eval()
+        m._be = emu_backend
+        m.load_state_dict(g["state_dict"])
+        crit = losses.HipDiceLoss(sigmoid=True)
+        crit._be = emu_backend
+        loss = crit(m(g["x"]), g["y"])
+        loss.backward()
+        a = torch.cat([p.grad.reshape(-1) for _, p in m.named_parameters()])
+        b = torch.cat([g["grads"][k].reshape(-1) for k, _ in m.named_parameters()])
+        rel = float((a - b).norm() / b.norm())
+        cos = float((a * b).sum() / a.norm() / b.norm())
+        assert abs(float(loss.detach()) - float(g["loss"])) / float(g["loss"]) < 1e-4
+        assert rel < tol and cos > cos_min, (mode, rel, cos)
+        res[mode] = rel
+    assert res["fp16"] < 0.5 * res["bf16"]
+
+
 def test_fp16_mode_rounds_operands_like_tensor_half(emu_backend):
     """MI355_PREC_F16 = conv of the fp16-ROUNDED operands (round to nearest even, as tensor.half()) with exact products and fp32
     accumulation: against F.conv3d of the rounded tensors the difference is accumulation order only."""
