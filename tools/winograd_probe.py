@@ -1,6 +1,7 @@
 """Developer tool (CPU): numerical probe for a 3-D Winograd F(2x2x2, 3x3x3) convolution in fp32 (tools/NEXT.md). Computes
 conv3d(x, w, padding=1) through the transform domain with fp32 arithmetic and compares it -- and the direct fp32 convolution -- with
-the fp64 direct result.    python tools/winograd_probe.py [cin] [cout] [size]"""
+the fp64 direct result; and the weight gradient through F(3x3, 2x2) in the plane x direct z (the form built on branch winograd-prep).
+    python tools/winograd_probe.py [cin] [cout] [size]"""
 import sys
 
 import torch
@@ -47,3 +48,33 @@ print(f"  Winograd in fp64          {float((w64 - ref).abs().max() / scale):.2e}
 print(f"  direct conv in fp32       {float((d32.double() - ref).abs().max() / scale):.2e}")
 print(f"  Winograd F(2,3)^3 in fp32 {float((w32.double() - ref).abs().max() / scale):.2e}")
 print(f"  rms ratio Winograd / direct: {float((w32.double() - ref).pow(2).mean().sqrt() / (d32.double() - ref).pow(2).mean().sqrt()):.2f}")
+
+
+# ---- weight gradient: F(3x3, 2x2) in the (y, x) plane, direct along z (what conv3d_wino2d_wgrad computes) ----
+A2 = torch.tensor([[1, 0], [1, 1], [1, -1], [0, -1]], dtype=torch.float64)                  # dy-tile transform (4x2)
+GT = torch.tensor([[1, .5, .5, 0], [0, .5, -.5, 0], [0, .5, .5, 1]], dtype=torch.float64)    # tap transform (3x4)
+
+
+def winograd_wgrad(x, dy, dtype):
+    n, ci, D, H, W = x.shape
+    xp = F.pad(x.to(dtype), (1, 1, 1, 1, 1, 1))
+    dw = torch.zeros(dy.shape[1], ci, 3, 3, 3, dtype=dtype)
+    h = t3(A2, dy.to(dtype).unfold(3, 2, 2).unfold(4, 2, 2), (5, 6))
+    for dz in range(3):
+        V = t3(BT, xp[:, :, dz:dz + D].unfold(3, 4, 2).unfold(4, 4, 2), (5, 6))
+        dw[:, :, dz] = t3(GT, torch.einsum("nozyxab,nczyxab->ocab", h, V), (2, 3))
+    return dw
+
+
+xa = torch.randn(2, cin, S, S, S).relu() + 0.1 * torch.randn(2, cin, S, S, S)       # post-activation-like input
+dy = torch.randn(2, cout, S, S, S) * 1e-3
+w0 = torch.zeros(cout, cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+(gref,) = torch.autograd.grad(F.conv3d(xa.double(), w0, padding=1), w0, dy.double())
+w1 = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+(g32,) = torch.autograd.grad(F.conv3d(xa, w1, padding=1), w1, dy)
+sc = gref.abs().max()
+print("weight gradient over 2 x size^3 voxels, max |error| / max |dw| against the fp64 direct gradient:")
+print(f"  Winograd in fp64          {float((winograd_wgrad(xa, dy, torch.float64) - gref).abs().max() / sc):.2e}   (algebra check)")
+print(f"  direct wgrad in fp32      {float((g32.double() - gref).abs().max() / sc):.2e}")
+print(f"  Winograd F(3,2)^2 in fp32 {float((winograd_wgrad(xa, dy, torch.float32).double() - gref).abs().max() / sc):.2e}")
+
