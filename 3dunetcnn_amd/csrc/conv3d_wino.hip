@@ -1,0 +1,240 @@
+// 3x3x3 stride-1 conv3d forward / dgrad in exact-type fp32 with FEWER multiplications: Winograd F(2x2, 3x3) in the (y, x) plane,
+// direct along z. PREPARED ON THE CPU EMULATOR, NOT YET MEASURED ON AN MI355X (tools/NEXT.md "The one algorithmic lever left").
+//
+// Same op as conv3d_fwd.hip (reference: unet3d/models/pytorch/classification/resnet.py:12-22 called from myronenko.py:17-21; the
+// GroupNorm-apply + ReLU prologue and the bias / residual / Dropout3d-scale epilogue are fused the same way). Arithmetic per output
+// voxel and (ci, co): 16 transform points per 2x2 outputs x 3 z-taps = 12 multiplications instead of 27. Numerics: the transform
+// matrices have entries 0, +-1, +-1/2; measured on the CPU (tools/winograd_probe.py) the fp32 result is as close to an fp64
+// convolution as the direct fp32 kernel's (max error 3e-7 .. 9e-7 of max |y|).
+//
+//   input transform   V = B^T d B    (4x4 input window d of one channel, B^T rows: d0-d2, d1+d2, d2-d1, d1-d3)
+//   filter transform  U = G g G^T    (3x3 (dy,dx) slice g of one (co, ci, dz), done once per optimizer step by the pack kernel)
+//   point-wise        M[p] = sum_{ci, dz} V[p][plane z + dz - 1][ci] * U[p][dz][ci][co]          <- the MFMA work, p = 0..15
+//   output transform  Y = A^T M A    (2x2 outputs, A^T rows: m0+m1+m2, m1-m2-m3)
+//
+// Workgroup = 256 threads = 4 waves; output tile = 2 z-planes x 8 (y) x 16 (x) voxels = per plane 4 x 8 = 32 Winograd tiles of 2x2 = the
+// M dimension of one 32x32 MFMA tile; N = 32 output channels; K = 8 input channels per LDS chunk (one float4 per k-half, exactly the
+// operand scheme of conv3d_mfma: lane l supplies A[tile = l & 31][k = l >> 5], four MFMAs per float4). A workgroup walks the 4 input
+// planes its 2 output planes see; every input plane is staged (haloed 10 x 18 voxels, normalised + activated on the way in), transformed
+// ONCE into the 16 points (32 additions per (tile, channel)) and used by the 1-2 (output plane, dz) pairs that see it. Wave w owns the
+// points (i = w, j = 0..3) of both output planes: 8 accumulator tiles = 128 registers. The output transform contracts j inside the wave
+// and i across the waves through LDS.
+#include "hipcompat.h"
+#include "../../include/mi355_unet3d.h"
+
+struct WinoArgs {
+  const float* x; int xld;
+  const float* up;                       // transformed weights [(p * 3 + dz)][ciP / 4][coP][4]
+  float* y; int yld;
+  const float* res; int resld;
+  const float* in_scale; const float* in_shift; float slope; const float* in_slope;
+  const float* out_chscale; const float* bias;
+  int N, D, H, W, Cin, CinP, Cout, CoutP;
+  int tilesZ, tilesY, tilesX, coTiles;
+};
+
+template <int INMODE>
+__global__ __launch_bounds__(256) void conv3d_wino2d(WinoArgs a) {
+  constexpr int TZ = 2, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HV = HY * HX;      // output tile; haloed input plane
+  constexpr int KC = 8;                  // input channels per chunk
+  constexpr int XS = 12;                 // floats per staged voxel (8 + 4 pad: the transform's strided reads stay conflict-free)
+  constexpr int NT = 32;                 // Winograd tiles per plane (4 x 8 of 2x2 outputs)
+  __shared__ __attribute__((aligned(16))) float lds[8192];      // 32 KB: xs [HV][XS] (8.6 KB) | vs [16][NT][KC] (16 KB); later zs [4][2][32][32]
+  float* xs = lds;
+  float* vs = lds + HV * XS + 16;        // keep 16-byte alignment
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+  int b = blockIdx.x;
+  const int cot = b % a.coTiles; b /= a.coTiles;
+  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+  const int tz0 = (b % a.tilesZ) * TZ; b /= a.tilesZ;
+  const int n = b;
+  const int co_base = cot * 32;
+
+  f32x16 acc[TZ][4];
+#pragma unroll
+  for (int oz = 0; oz < TZ; ++oz)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[oz][j][r] = 0.f;
+
+  const float4* up4 = reinterpret_cast<const float4*>(a.up);
+  const int CQ = a.CinP / 4;
+  // staging: a thread owns (halo voxel, channel quad) units; 2 quads per voxel
+  // transform: thread (tile t = tid >> 3, channel c = tid & 7)
+  const int tt = tid >> 3, tc = tid & 7;
+  const int tty = tt >> 3, ttx = tt & 7;
+
+  for (int c0 = 0; c0 < a.CinP; c0 += KC) {
+    for (int pz = 0; pz < TZ + 2; ++pz) {
+      const int iz = tz0 - 1 + pz;
+      __syncthreads();                   // the previous plane's MFMAs are done with vs, its transform with xs
+      // ---- stage the haloed input plane iz, channels [c0, c0 + 8) ----
+      for (int u = tid; u < HV * 2; u += 256) {
+        const int hv = u >> 1, q = u & 1;
+        const int hy = hv / HX, hx = hv % HX;
+        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+        const int c = c0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin) {
+          v = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + c);
+          if (INMODE == MI355_IN_AFFINE_ACT) {
+            const float4 sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
+            const float4 sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
+            float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
+            if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + c);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
+          }
+        }
+        *reinterpret_cast<float4*>(xs + hv * XS + 4 * q) = v;
+      }
+      __syncthreads();
+      // ---- input transform: V = B^T d B of the 4x4 window of tile (tty, ttx), channel tc ----
+      {
+        float d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) d[r][s] = xs[((2 * tty + r) * HX + 2 * ttx + s) * XS + tc];
+        float t[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {          // rows: B^T d
+          t[0][s] = d[0][s] - d[2][s]; t[1][s] = d[1][s] + d[2][s]; t[2][s] = d[2][s] - d[1][s]; t[3][s] = d[1][s] - d[3][s];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {          // columns: (B^T d) B
+          const float v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3];
+          vs[((4 * i + 0) * NT + tt) * KC + tc] = v0;
+          vs[((4 * i + 1) * NT + tt) * KC + tc] = v1;
+          vs[((4 * i + 2) * NT + tt) * KC + tc] = v2;
+          vs[((4 * i + 3) * NT + tt) * KC + tc] = v3;
+        }
+      }
+      __syncthreads();
+      // ---- point-wise products: wave w owns points (w, 0..3); this input plane serves output plane oz with z-tap dz = pz - oz ----
+#pragma unroll
+      for (int oz = 0; oz < TZ; ++oz) {
+        const int dz = pz - oz;
+        if (dz < 0 || dz > 2) continue;        // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int p = 4 * wave + j;
+          const float4 af = *reinterpret_cast<const float4*>(vs + (p * NT + li) * KC + 4 * half);
+          const float4 bf = up4[((size_t)(p * 3 + dz) * CQ + c0 / 4 + half) * a.CoutP + co_base + li];
+          acc[oz][j] = MFMA_32x32x2(af.x, bf.x, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.y, bf.y, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.z, bf.z, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.w, bf.w, acc[oz][j]);
+        }
+      }
+    }
+  }
+
+  // ---- output transform Y = A^T M A, bias / residual / dropout scale, store ----
+  // inside the wave: Z[b] = sum_j A^T[b][j] M[w][j];  across the waves (LDS): Y[a][b] = sum_i A^T[a][i] Z_i[b];  wave w' then owns (a, b) = (w' >> 1, w' & 1)
+  float* zs = lds;                        // [i = wave][b][tile 32][co 32]
+  const int oa = wave >> 1, ob = wave & 1;
+  const int co = co_base + li;
+  const bool cov = co < a.Cout;
+  float bs = 0.f, cs = 1.f;
+  if (cov && a.bias) bs = a.bias[co];
+  if (cov && a.out_chscale) cs = a.out_chscale[(size_t)n * a.Cout + co];
+#pragma unroll
+  for (int oz = 0; oz < TZ; ++oz) {
+    __syncthreads();                      // every wave is done with vs / the previous plane's zs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;      // tile index of accumulator register r
+      const float m0 = acc[oz][0][r], m1 = acc[oz][1][r], m2 = acc[oz][2][r], m3 = acc[oz][3][r];
+      zs[((wave * 2 + 0) * 32 + row) * 32 + li] = m0 + m1 + m2;
+      zs[((wave * 2 + 1) * 32 + row) * 32 + li] = m1 - m2 - m3;
+    }
+    __syncthreads();
+    const int z = tz0 + oz;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float z0 = zs[((0 * 2 + ob) * 32 + row) * 32 + li], z1 = zs[((1 * 2 + ob) * 32 + row) * 32 + li];
+      const float z2 = zs[((2 * 2 + ob) * 32 + row) * 32 + li], z3 = zs[((3 * 2 + ob) * 32 + row) * 32 + li];
+      float v = (oa == 0 ? z0 + z1 + z2 : z1 - z2 - z3) + bs;
+      const int yy = ty0 + 2 * (row >> 3) + oa, xx = tx0 + 2 * (row & 7) + ob;
+      if (!cov || z >= a.D || yy >= a.H || xx >= a.W) continue;
+      const size_t vox = (((size_t)n * a.D + z) * a.H + yy) * a.W + xx;
+      if (a.res) v += a.res[vox * a.resld + co];
+      v *= cs;
+      a.y[vox * a.yld + co] = v;
+    }
+  }
+}
+
+// ---- filter transform: U[(i,j)][dz][ci][co] = sum_{dy,dx} G[i][dy] G[j][dx] w[...], G rows: g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2 ----
+// mode 0: forward, w OIDHW [cout][cin][3][3][3]. mode 1: dgrad of Conv3d: roles swapped ("out" = ci, "in" = co), all three taps flipped.
+__global__ void wino_pack_weight_kernel(const float* w, float* up, int cout, int cin, int coutP, int cinP, int mode) {
+  const size_t total = (size_t)48 * (cinP / 4) * coutP * 4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int e = idx & 3;
+    size_t r = idx >> 2;
+    const int o = r % coutP; r /= coutP;
+    const int iq = r % (cinP / 4); r /= (cinP / 4);
+    const int pd = (int)r, p = pd / 3, dz = pd % 3;
+    const int pi = p >> 2, pj = p & 3;
+    const int i = iq * 4 + e;
+    float v = 0.f;
+    if (o < cout && i < cin) {
+      float g[3][3];
+      for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx)
+          g[dy][dx] = mode == 0 ? w[((size_t)o * cin + i) * 27 + (dz * 3 + dy) * 3 + dx]
+                                : w[((size_t)i * cout + o) * 27 + ((2 - dz) * 3 + (2 - dy)) * 3 + (2 - dx)];      // w[co = i][ci = o], flipped
+      float t[3];                           // row pi of G applied along dy
+      for (int dx = 0; dx < 3; ++dx)
+        t[dx] = pi == 0 ? g[0][dx] : pi == 1 ? 0.5f * (g[0][dx] + g[1][dx] + g[2][dx]) : pi == 2 ? 0.5f * (g[0][dx] - g[1][dx] + g[2][dx]) : g[2][dx];
+      v = pj == 0 ? t[0] : pj == 1 ? 0.5f * (t[0] + t[1] + t[2]) : pj == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2];
+    }
+    up[idx] = v;
+  }
+}
+
+extern "C" size_t mi355_wino_weight_elems(int32_t cout, int32_t cin) {
+  if (cout <= 0 || cin <= 0) return 0;
+  const size_t coutP = (cout + 31) / 32 * 32, cinP = (cin + 7) / 8 * 8;
+  return (size_t)48 * cinP * coutP;
+}
+
+extern "C" int mi355_wino_pack_weight(const float* w, float* up, int32_t cout, int32_t cin, int32_t mode, void* stream) {
+  if (!w || !up || cout <= 0 || cin <= 0 || mode < 0 || mode > 1) return MI355_EINVAL;
+  const int coutP = (cout + 31) / 32 * 32, cinP = (cin + 7) / 8 * 8;     // logical packed dims: cout = "out", cin = "in" of THIS conv
+  const size_t total = (size_t)48 * cinP * coutP;
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  LAUNCH(wino_pack_weight_kernel, dim3(grid), dim3(256), 0, stream, w, up, cout, cin, coutP, cinP, mode);
+  return LAUNCH_CHECK();
+}
+
+// x, y: NDHWC activations of the same extent; up: mi355_wino_pack_weight of the [y->c][x->c] (mode 0) weights; desc: kd 3, stride 1, pad 1,
+// plain / norm-prologue input, plain un-windowed output; bias, residual, out_chscale as in mi355_conv3d_fwd.
+extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
+  if (!x || !y || !up || !d || !x->p || !y->p) return MI355_EINVAL;
+  if (d->kd != 3 || d->stride != 1 || d->pad != 1 || d->out_mode != MI355_OUT_PLAIN) return MI355_EUNSUPPORTED;
+  if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
+  if (d->off_z || d->off_y || d->off_x || d->out_d != y->d || d->out_h != y->h || d->out_w != y->w) return MI355_EUNSUPPORTED;
+  if (x->d != y->d || x->h != y->h || x->w != y->w || x->n != y->n) return MI355_EINVAL;
+  if (x->c % 4 || x->ld % 4 || x->ld < x->c || y->ld < y->c || ((uintptr_t)x->p & 15) || ((uintptr_t)up & 15)) return MI355_EINVAL;
+  if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift || !(d->act_slope >= 0.f && d->act_slope <= 1.f))) return MI355_EINVAL;
+  if (d->moments_out || d->gn_bwd) return MI355_EUNSUPPORTED;
+  if (d->residual && d->residual_ld < y->c) return MI355_EINVAL;
+  WinoArgs a;
+  a.x = (const float*)x->p; a.xld = x->ld; a.up = up; a.y = (float*)y->p; a.yld = y->ld;
+  a.res = d->residual; a.resld = d->residual_ld;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope;
+  a.out_chscale = d->out_chscale; a.bias = d->bias;
+  a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cin = x->c; a.CinP = (x->c + 7) / 8 * 8;
+  a.Cout = y->c; a.CoutP = (y->c + 31) / 32 * 32;
+  a.tilesZ = ceil_div(a.D, 2); a.tilesY = ceil_div(a.H, 8); a.tilesX = ceil_div(a.W, 16); a.coTiles = a.CoutP / 32;
+  const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
+  if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wino2d<MI355_IN_PLAIN>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  else LAUNCH((conv3d_wino2d<MI355_IN_AFFINE_ACT>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  return LAUNCH_CHECK();
+}

@@ -233,6 +233,22 @@ class Backend:
         self.prof.append((name.value.decode(), flops, byts, e0, e1))
         return self._fold_after(y, gparts)
 
+    # -- Winograd form of the 3x3x3 stride-1 conv (csrc/conv3d_wino.hip): prepared, not yet measured, not used by the modules ----------
+    def wino_pack_weight(self, w, mode=0):
+        """w OIDHW [cout, cin, 3, 3, 3] -> transformed weights for conv_fwd_wino (mode 0: forward; mode 1: dgrad, i.e. a conv from
+        cout to cin channels)."""
+        cout, cin = (w.shape[0], w.shape[1]) if mode == 0 else (w.shape[1], w.shape[0])
+        up = torch.empty(self.lib.mi355_wino_weight_elems(cout, cin), dtype=torch.float32, device=self.device)
+        check(self.lib.mi355_wino_pack_weight(w.contiguous().data_ptr(), up.data_ptr(), cout, cin, mode, self.stream()), "wino_pack_weight")
+        return up
+
+    def conv_fwd_wino(self, x, up, y, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, bias=None, residual=None, chscale=None,
+                      in_slope=None):
+        keep = []
+        d = self._desc(3, 1, 1, in_mode, slope, scale, shift, bias, residual, chscale, (0, 0, 0), y.shape[1:4], keep, in_slope, OUT_PLAIN)
+        xd, yd = x.desc(), y.desc()
+        check(self.lib.mi355_conv3d_wino_fwd(ctypes.byref(xd), up.data_ptr(), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_wino_fwd")
+
     def _fold_after(self, y, gparts):
         if y.mom is not None:
             rec, nb, c = y.mom[0]

@@ -1,0 +1,54 @@
+"""Winograd F(2x2, 3x3) x direct-z form of the 3x3x3 stride-1 convolution (csrc/conv3d_wino.hip) on the CPU emulator, against
+F.conv3d: fp32, tolerance 1e-5 (measured ~1e-6). PREPARED, not yet measured on an MI355X (tools/NEXT.md)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import op_cases as C
+from oracle import torch_ops as O
+
+ops = C.ops
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=8, cout=32, dhw=(2, 8, 16)),                                   # exactly one tile
+    dict(n=2, cin=32, cout=32, dhw=(4, 8, 16), bias=True),                       # two z tiles, four channel chunks
+    dict(n=1, cin=16, cout=64, dhw=(3, 9, 19), norm=True, residual=True, chscale=True),      # ragged in every axis, two channel tiles
+    dict(n=1, cin=12, cout=40, dhw=(5, 6, 7), norm=True, slope=0.01, bias=True),  # partial channel chunk and tile
+])
+def test_wino_forward_matches_conv3d(emu_backend, kw):
+    be = emu_backend
+    n, cin, cout, dhw = kw["n"], kw["cin"], kw["cout"], kw["dhw"]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, cin, *dhw, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, 3, generator=g) * (1.0 / (cin * 27) ** 0.5)
+    normspec = gamma = beta = None
+    if kw.get("norm"):
+        groups = 4
+        gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+        normspec = (groups, gamma, beta, 1e-5, kw.get("slope", 0.0))
+    b = torch.randn(cout, generator=g) if kw.get("bias") else None
+    res = torch.randn(n, cout, *dhw, generator=g) if kw.get("residual") else None
+    cs = (torch.rand(n, cout, generator=g) > 0.3).float() * 1.25 if kw.get("chscale") else None
+    ref = O.conv_block(x, wt, 1, 1, normspec, b, res, cs)
+    xa, ya = C.to_act(be, x), C.to_act(be, torch.zeros_like(ref))
+    up = be.wino_pack_weight(wt, 0)
+    extra = {}
+    if normspec:
+        mr, sc, sh = be.gn_stats(xa, normspec[0], 1e-5, gamma, beta)
+        extra = dict(in_mode=ops.IN_AFFINE_ACT, slope=normspec[4], scale=sc, shift=sh)
+    be.conv_fwd_wino(xa, up, ya, bias=b, residual=C.to_act(be, res) if res is not None else None, chscale=cs, **extra)
+    assert C.rel_err(C.from_act(ya), ref) < 1e-5
+
+
+def test_wino_dgrad_pack_matches_autograd(emu_backend):
+    be = emu_backend
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 16, 4, 8, 16, generator=g, requires_grad=True)
+    wt = torch.randn(32, 16, 3, 3, 3, generator=g) * 0.05
+    y = F.conv3d(x, wt, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    dya, dxa = C.to_act(be, dy), C.to_act(be, torch.zeros_like(x.detach()))
+    be.conv_fwd_wino(dya, be.wino_pack_weight(wt, 1), dxa)
+    assert C.rel_err(C.from_act(dxa), dx_ref) < 1e-5
