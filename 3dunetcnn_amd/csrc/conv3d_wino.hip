@@ -21,6 +21,7 @@
 // and i across the waves through LDS.
 #include "hipcompat.h"
 #include "../../include/mi355_unet3d.h"
+#include "gn_fuse.h"
 
 struct WinoArgs {
   const float* x; int xld;
@@ -31,9 +32,11 @@ struct WinoArgs {
   const float* out_chscale; const float* bias;
   int N, D, H, W, Cin, CinP, Cout, CoutP;
   int tilesZ, tilesY, tilesX, coTiles;
+  GnFuseArgs g;                          // norm statistics fused into the epilogue (gn_fuse.h), as in conv3d_mfma
 };
 
-template <int INMODE>
+// FUSE: 0 plain epilogue, 1 + moment records of the output, 2 + norm-backward sums (dgrad): as conv3d_mfma
+template <int INMODE, int FUSE = 0>
 __global__ __launch_bounds__(256) void conv3d_wino2d(WinoArgs a) {
   constexpr int TZ = 2, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HV = HY * HX;      // output tile; haloed input plane
   constexpr int KC = 8;                  // input channels per chunk
@@ -141,6 +144,15 @@ __global__ __launch_bounds__(256) void conv3d_wino2d(WinoArgs a) {
   float bs = 0.f, cs = 1.f;
   if (cov && a.bias) bs = a.bias[co];
   if (cov && a.out_chscale) cs = a.out_chscale[(size_t)n * a.Cout + co];
+  // FUSE 1: one-pass moments about K0 = the lane's first stored value; FUSE 2: sum du, sum du * xhat (gn_fuse.h)
+  float K0 = 0.f, s0 = 0.f, s1 = 0.f, gsc = 1.f, gsh = 0.f, gmean = 0.f, grstd = 1.f;
+  int cnt = 0;
+  if constexpr (FUSE == 2) {
+    const int coc = cov ? co : a.Cout - 1;
+    const int grp = coc / (a.Cout / a.g.ggroups);
+    gsc = a.g.gscale[(size_t)n * a.Cout + coc]; gsh = a.g.gshift[(size_t)n * a.Cout + coc];
+    gmean = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
+  }
 #pragma unroll
   for (int oz = 0; oz < TZ; ++oz) {
     __syncthreads();                      // every wave is done with vs / the previous plane's zs
@@ -165,7 +177,34 @@ __global__ __launch_bounds__(256) void conv3d_wino2d(WinoArgs a) {
       if (a.res) v += a.res[vox * a.resld + co];
       v *= cs;
       a.y[vox * a.yld + co] = v;
+      if constexpr (FUSE == 1) {
+        if (cnt == 0) K0 = v;
+        const float t = v - K0;
+        s0 += t; s1 += t * t;
+        ++cnt;
+      } else if constexpr (FUSE == 2) {
+        const float xv = a.g.gx[vox * a.g.gxld + co];
+        const float u = xv * gsc + gsh;
+        const float du = u > 0.f ? v : v * a.g.gslope;
+        s0 += du; s1 += du * ((xv - gmean) * grstd);
+      }
     }
+  }
+  if constexpr (FUSE != 0) {
+    // wave w' holds the (a, b) = (w' >> 1, w' & 1) outputs of every tile: the four waves are the "WM" waves of gn_fuse_reduce_store
+    constexpr int K = FUSE == 1 ? 3 : 2;
+    float vals[1][K];
+    if constexpr (FUSE == 1) {
+      const float c = (float)cnt;
+      const float m2 = cnt > 0 ? s1 - s0 * s0 / c : 0.f;
+      vals[0][0] = c; vals[0][1] = s0 + c * K0; vals[0][2] = m2 > 0.f ? m2 : 0.f;
+    } else {
+      vals[0][0] = s0; vals[0][1] = s1;
+    }
+    const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
+    const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
+    float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * K;
+    gn_fuse_reduce_store<K, 1, 4, 1>(vals, lds, wave, 0, half, li, tid, dst, co_base, a.Cout);
   }
 }
 
@@ -222,9 +261,18 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   if (x->d != y->d || x->h != y->h || x->w != y->w || x->n != y->n) return MI355_EINVAL;
   if (x->c % 4 || x->ld % 4 || x->ld < x->c || y->ld < y->c || ((uintptr_t)x->p & 15) || ((uintptr_t)up & 15)) return MI355_EINVAL;
   if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift || !(d->act_slope >= 0.f && d->act_slope <= 1.f))) return MI355_EINVAL;
-  if (d->moments_out || d->gn_bwd) return MI355_EUNSUPPORTED;
   if (d->residual && d->residual_ld < y->c) return MI355_EINVAL;
   WinoArgs a;
+  memset(&a.g, 0, sizeof(a.g));
+  if (d->moments_out && d->gn_bwd) return MI355_EUNSUPPORTED;
+  a.g.mom = d->moments_out;
+  if (d->gn_bwd) {
+    const mi355_gn_bwd_fuse* f = d->gn_bwd;
+    if (d->in_mode != MI355_IN_PLAIN) return MI355_EUNSUPPORTED;
+    if (!f->gx || !f->scale || !f->shift || !f->mean_rstd || !f->partials_out || f->groups <= 0 || y->c % f->groups || f->gx_ld < y->c) return MI355_EINVAL;
+    a.g.gnb = f->partials_out; a.g.gx = f->gx; a.g.gxld = f->gx_ld; a.g.gscale = f->scale; a.g.gshift = f->shift; a.g.gmr = f->mean_rstd;
+    a.g.ggroups = f->groups; a.g.gslope = f->act_slope;
+  }
   a.x = (const float*)x->p; a.xld = x->ld; a.up = up; a.y = (float*)y->p; a.yld = y->ld;
   a.res = d->residual; a.resld = d->residual_ld;
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope;
@@ -234,7 +282,20 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   a.tilesZ = ceil_div(a.D, 2); a.tilesY = ceil_div(a.H, 8); a.tilesX = ceil_div(a.W, 16); a.coTiles = a.CoutP / 32;
   const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
-  if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wino2d<MI355_IN_PLAIN>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-  else LAUNCH((conv3d_wino2d<MI355_IN_AFFINE_ACT>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  const dim3 grid((unsigned)blocks), blk(256);
+  if (a.g.mom) {
+    if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wino2d<MI355_IN_PLAIN, 1>), grid, blk, 0, stream, a);
+    else LAUNCH((conv3d_wino2d<MI355_IN_AFFINE_ACT, 1>), grid, blk, 0, stream, a);
+  } else if (a.g.gnb) {
+    LAUNCH((conv3d_wino2d<MI355_IN_PLAIN, 2>), grid, blk, 0, stream, a);
+  } else if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wino2d<MI355_IN_PLAIN>), grid, blk, 0, stream, a);
+  else LAUNCH((conv3d_wino2d<MI355_IN_AFFINE_ACT>), grid, blk, 0, stream, a);
   return LAUNCH_CHECK();
+}
+
+// spatial tiles (= epilogue records per sample) of this kernel's 2 x 8 x 16 tiling
+extern "C" int32_t mi355_conv3d_wino_stats_blocks(const mi355_act* y) {
+  if (!y) return 0;
+  const long long b = (long long)ceil_div(y->d, 2) * ceil_div(y->h, 8) * ceil_div(y->w, 16);
+  return b > 0 && b <= 0x7fffffffLL ? (int32_t)b : 0;
 }

@@ -243,11 +243,28 @@ class Backend:
         return up
 
     def conv_fwd_wino(self, x, up, y, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, bias=None, residual=None, chscale=None,
-                      in_slope=None):
+                      in_slope=None, moments=False, gnb=None):
+        """Same contract as conv_fwd for a 3x3x3 stride-1 conv (moments / gnb: the fused statistics of the epilogue)."""
         keep = []
         d = self._desc(3, 1, 1, in_mode, slope, scale, shift, bias, residual, chscale, (0, 0, 0), y.shape[1:4], keep, in_slope, OUT_PLAIN)
         xd, yd = x.desc(), y.desc()
+        y.mom = None
+        gparts = None
+        if self.fused_stats and (moments or gnb is not None):
+            nb = self.lib.mi355_conv3d_wino_stats_blocks(ctypes.byref(yd))
+            if moments:
+                rec = torch.empty(x.shape[0], nb, y.c, 3, dtype=torch.float32, device=self.device)
+                d.moments_out = rec.data_ptr()
+                y.mom = [(rec, nb, y.c)]
+            elif in_mode == IN_PLAIN:
+                gx, st, groups, gslope = gnb
+                rec = torch.empty(x.shape[0], nb, y.c, 2, dtype=torch.float32, device=self.device)
+                fuse = MiGnBwdFuse(gx.ptr(), gx.ld, st[1].data_ptr(), st[2].data_ptr(), st[0].data_ptr(), groups, gslope, rec.data_ptr())
+                d.gn_bwd = ctypes.pointer(fuse)
+                keep.extend([fuse, gx, st])
+                gparts = (rec, nb)
         check(self.lib.mi355_conv3d_wino_fwd(ctypes.byref(xd), up.data_ptr(), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_wino_fwd")
+        return self._fold_after(y, gparts)
 
     def _fold_after(self, y, gparts):
         if y.mom is not None:

@@ -52,3 +52,62 @@ def test_wino_dgrad_pack_matches_autograd(emu_backend):
     dya, dxa = C.to_act(be, dy), C.to_act(be, torch.zeros_like(x.detach()))
     be.conv_fwd_wino(dya, be.wino_pack_weight(wt, 1), dxa)
     assert C.rel_err(C.from_act(dxa), dx_ref) < 1e-5
+
+
+class _WinoBackend:
+    """The emulator backend with its 3x3x3 stride-1 convolutions redirected to the Winograd kernel, so that the shared op cases
+    (tests/op_cases.py: epilogue fusions, concat slices, fused statistics) run against it unchanged."""
+    def __init__(self, be):
+        self._be = be
+        self.wino_calls = 0
+
+    def __getattr__(self, name):
+        return getattr(self._be, name)
+
+    def pack_weight(self, w, mode, *a, **k):
+        if w.shape[2:] == (3, 3, 3) and mode in (0, 1):
+            return ("wino", self._be.wino_pack_weight(w, mode), self._be.pack_weight(w, mode, *a, **k))
+        return self._be.pack_weight(w, mode, *a, **k)
+
+    def conv_fwd(self, x, wp, y, kd, stride=1, pad=None, **kw):
+        if isinstance(wp, tuple):
+            if kd == 3 and stride == 1 and kw.get("off", (0, 0, 0)) == (0, 0, 0) and kw.get("in_mode", ops.IN_PLAIN) in (ops.IN_PLAIN, ops.IN_AFFINE_ACT):
+                kw.pop("off", None); kw.pop("out_dhw", None)
+                self.wino_calls += 1
+                return self._be.conv_fwd_wino(x, wp[1], y, **kw)
+            wp = wp[2]
+        return self._be.conv_fwd(x, wp, y, kd, stride, pad, **kw)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=32, cout=32, dhw=(3, 5, 19), norm=True, residual=True, chscale=True),
+    dict(n=1, cin=8, cout=64, dhw=(4, 4, 16), norm=True, yld=128, yc0=32),                   # concat slice of a wider buffer
+    dict(n=2, cin=4, cout=32, dhw=(3, 4, 17), bias=True),
+    dict(n=1, cin=48, cout=40, dhw=(2, 6, 9), norm=True, slope=0.01),
+])
+def test_wino_shared_forward_cases(emu_backend, kw):
+    be = _WinoBackend(emu_backend)
+    assert C.case_conv_fwd(be, **kw) < 1e-5
+    assert be.wino_calls == 1
+
+
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=64, dhw=(3, 4, 18)), dict(n=2, cin=64, cout=32, dhw=(4, 4, 16))])
+def test_wino_shared_dgrad_cases(emu_backend, kw):
+    assert C.case_conv_dgrad(_WinoBackend(emu_backend), **kw) < 1e-5
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=32, cout=32, dhw=(3, 5, 19), residual=True, chscale=True),
+    dict(n=1, cin=16, cout=64, dhw=(4, 8, 16), yld=128, yc0=32),
+    dict(n=2, cin=16, cout=40, dhw=(2, 6, 9), groups_out=40),
+])
+def test_wino_epilogue_moments(emu_backend, kw):
+    assert C.case_conv_moments(_WinoBackend(emu_backend), **kw) < 2e-5
+
+
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(3, 5, 19)), dict(n=2, cin=64, cout=16, dhw=(4, 4, 16), slope=0.01)])
+def test_wino_norm_backward_sums_from_dgrad_epilogue(emu_backend, kw):
+    be = _WinoBackend(emu_backend)
+    r = C.case_gn_bwd_fused(be, **kw)
+    assert all(v < 2e-4 for v in r.values()), r
+    assert be.wino_calls == 1
