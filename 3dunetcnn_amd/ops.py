@@ -102,6 +102,12 @@ class PackedWeight:
             self._bf16[precision] = out
         return self._bf16[precision]
 
+    def wino(self):
+        """Winograd-domain weights of a 3x3x3 kernel (csrc/conv3d_wino.hip), packed on first use."""
+        if getattr(self, "_wino", None) is None:
+            self._wino = self.be.wino_pack_weight(self.w, self.mode)
+        return self._wino
+
     def ptr_for(self, desc):
         if (self.mode == 0 and self.cin == 4 and self.kd == 3 and desc.stride == 1 and desc.pad == 1 and desc.out_mode == OUT_PLAIN
                 and desc.in_mode in (IN_PLAIN, IN_AFFINE_ACT)):
@@ -127,6 +133,9 @@ class Backend:
         self.device = torch.device(device)
         self._ws_by_stream = {}     # launch stream handle -> workspace tensor: kernels of different streams must not share scratch
         self.precision = PREC_F32   # arithmetic of the 3x3x3 stride-1 convs: see set_precision()
+        # EXPERIMENT SWITCH (prepared on the emulator, not yet measured): MI355_WINOGRAD=1 routes the eligible fp32 3x3x3 stride-1
+        # forward / dgrad convolutions to the Winograd kernel
+        self.winograd = os.environ.get("MI355_WINOGRAD", "0") == "1"
         self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
         # norm statistics leave with the producing conv's epilogue (csrc/gn_fuse.h). False: every statistic is a standalone pass
         # over the tensor again (the round-1 form; kept as the cross-check of the fused path, tests/test_ops_gpu.py)
@@ -191,6 +200,11 @@ class Backend:
         pad = kd // 2 if pad is None else pad
         if out_dhw is None:
             out_dhw = x.shape[1:4] if out_mode == OUT_D2S else y.shape[1:4]
+        if (self.winograd and self.precision == PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT)
+                and out_mode == OUT_PLAIN and tuple(off) == (0, 0, 0) and tuple(out_dhw) == tuple(y.shape[1:4]) and wp.mode in (0, 1)
+                and wp.cin >= 8 and wp.cout >= 8 and x.shape[1:4] == y.shape[1:4] and self.prof is None):
+            return self.conv_fwd_wino(x, wp.wino(), y, in_mode=in_mode, slope=slope, scale=scale, shift=shift, bias=bias, residual=residual,
+                                      chscale=chscale, in_slope=in_slope, moments=moments, gnb=gnb)
         keep = []
         d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep, in_slope, out_mode)
         xd, yd = x.desc(), y.desc()

@@ -111,3 +111,39 @@ def test_wino_norm_backward_sums_from_dgrad_epilogue(emu_backend, kw):
     r = C.case_gn_bwd_fused(be, **kw)
     assert all(v < 2e-4 for v in r.values()), r
     assert be.wino_calls == 1
+
+
+def test_whole_network_step_on_the_winograd_kernels(emu_backend):
+    """MI355_WINOGRAD switch: every eligible 3x3x3 stride-1 forward / dgrad conv of a UNet3D step on the Winograd kernel (weight
+    gradients stay on the direct kernels), against the golden bundle generated from the reference."""
+    import importlib
+    import os
+    unet = importlib.import_module("3dunetcnn_amd.unet")
+    losses = importlib.import_module("3dunetcnn_amd.losses")
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet3d_small.pt"))
+    be = emu_backend
+    be.winograd = True
+    calls = {"n": 0}
+    orig = be.conv_fwd_wino
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    be.conv_fwd_wino = counted
+    try:
+        m = unet.HipUNet3D(**g["kwargs"]).eval()
+        m._be = be
+        m.load_state_dict(g["state_dict"])
+        crit = losses.HipDiceLoss(sigmoid=True)
+        crit._be = be
+        out = m(g["x"])
+        loss = crit(out, g["y"])
+        loss.backward()
+    finally:
+        be.winograd = False
+        del be.conv_fwd_wino
+    assert calls["n"] >= 20
+    assert C.rel_err(out, g["logits"]) < 1e-3
+    assert abs(float(loss.detach()) - float(g["loss"])) / float(g["loss"]) < 1e-3
+    for k, p in m.named_parameters():
+        assert C.rel_err(p.grad, g["grads"][k]) < 1e-3, k
