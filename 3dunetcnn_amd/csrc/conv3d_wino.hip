@@ -20,6 +20,8 @@
 // points (i = w, j = 0..3) of both output planes: 8 accumulator tiles = 128 registers. The output transform contracts j inside the wave
 // and i across the waves through LDS.
 #include "hipcompat.h"
+#include <type_traits>
+#include <cstdlib>
 #include "../../include/mi355_unet3d.h"
 #include "gn_fuse.h"
 
@@ -36,15 +38,20 @@ struct WinoArgs {
 };
 
 // FUSE: 0 plain epilogue, 1 + moment records of the output, 2 + norm-backward sums (dgrad): as conv3d_mfma
-template <int INMODE, int FUSE = 0>
-__global__ __launch_bounds__(256) void conv3d_wino2d(WinoArgs a) {
+// PIPE: software-pipelined main loop (one barrier per input plane: the MFMAs of plane k share the instruction stream with the transform
+// of plane k + 1, the global loads of plane k + 2 are in flight) instead of stage / barrier / transform / barrier / MFMA / barrier.
+template <int INMODE, int FUSE = 0, bool PIPE = false>
+__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_wino2d(WinoArgs a) {      // 128 accumulator registers + <= 128 others
   constexpr int TZ = 2, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HV = HY * HX;      // output tile; haloed input plane
   constexpr int KC = 8;                  // input channels per chunk
   constexpr int XS = 12;                 // floats per staged voxel (8 + 4 pad: the transform's strided reads stay conflict-free)
   constexpr int NT = 32;                 // Winograd tiles per plane (4 x 8 of 2x2 outputs)
-  __shared__ __attribute__((aligned(16))) float lds[8192];      // 32 KB: xs [HV][XS] (8.6 KB) | vs [16][NT][KC] (16 KB); later zs [4][2][32][32]
+  constexpr int XSF = HV * XS + 16, VSF = 16 * NT * KC;          // floats per staged plane (16-byte aligned) / per transformed plane
+  constexpr int LDSF = PIPE ? 2 * (XSF + VSF) : 8192;           // PIPE: two of each (49 KB); else xs | vs in 32 KB; later zs [4][2][32][32]
+  static_assert(LDSF >= 8192, "the output transform exchanges 4 x 2 x 32 x 32 floats through LDS");
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
   float* xs = lds;
-  float* vs = lds + HV * XS + 16;        // keep 16-byte alignment
+  float* vs = lds + (PIPE ? 2 : 1) * XSF;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
   int b = blockIdx.x;
   const int cot = b % a.coTiles; b /= a.coTiles;
@@ -69,6 +76,116 @@ __global__ __launch_bounds__(256) void conv3d_wino2d(WinoArgs a) {
   const int tt = tid >> 3, tc = tid & 7;
   const int tty = tt >> 3, ttx = tt & 7;
 
+  if constexpr (PIPE) {
+    // phase k = (channel chunk, input plane pz): planes of a chunk are unrolled (pz, hence the (output plane, dz) pairs and the buffer
+    // parity, are compile-time); the phase after (c0, 3) is (c0 + KC, 0)
+    auto plane_loads = [&](int c0_, int pz_, float4 (&ld)[2], bool (&ok)[2]) {
+      const int iz = tz0 - 1 + pz_;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        int u = tid + 256 * k;
+        const bool act = u < HV * 2;
+        if (!act) u = 0;
+        const int hv = u >> 1, q = u & 1;
+        const int iy = ty0 - 1 + hv / HX, ix = tx0 - 1 + hv % HX;
+        const int c = c0_ + 4 * q;
+        ok[k] = act && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin;
+        const int izc = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1), iyc = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1), ixc = ix < 0 ? 0 : (ix < a.W ? ix : a.W - 1);
+        ld[k] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + izc) * a.H + iyc) * a.W + ixc) * a.xld + (c < a.Cin ? c : 0));
+      }
+    };
+    auto plane_store = [&](float* xsb, int c0_, const float4 (&ld)[2], const bool (&ok)[2]) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int u = tid + 256 * k;
+        if (u >= HV * 2) continue;
+        const int hv = u >> 1, q = u & 1, c = c0_ + 4 * q;
+        float4 v = ld[k];
+        if (INMODE == MI355_IN_AFFINE_ACT && ok[k]) {
+          const float4 sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
+          const float4 sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
+          float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
+          if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + c);
+          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+          v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
+        }
+        if (!ok[k]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(xsb + hv * XS + 4 * q) = v;
+      }
+    };
+    auto transform = [&](const float* xsb, float* vsb) {
+      float d[4][4], t[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) d[r][s2] = xsb[((2 * tty + r) * HX + 2 * ttx + s2) * XS + tc];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        t[0][s2] = d[0][s2] - d[2][s2]; t[1][s2] = d[1][s2] + d[2][s2]; t[2][s2] = d[2][s2] - d[1][s2]; t[3][s2] = d[1][s2] - d[3][s2];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vsb[((4 * i + 0) * NT + tt) * KC + tc] = t[i][0] - t[i][2];
+        vsb[((4 * i + 1) * NT + tt) * KC + tc] = t[i][1] + t[i][2];
+        vsb[((4 * i + 2) * NT + tt) * KC + tc] = t[i][2] - t[i][1];
+        vsb[((4 * i + 3) * NT + tt) * KC + tc] = t[i][1] - t[i][3];
+      }
+    };
+    auto mfma_plane = [&](const float* vsb, int c0_, auto pzc) {
+      constexpr int PZ = decltype(pzc)::value;
+#pragma unroll
+      for (int oz = 0; oz < TZ; ++oz) {
+        const int dz = PZ - oz;
+        if (dz < 0 || dz > 2) continue;          // compile-time after unrolling
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int p = 4 * wave + j;
+          const float4 af = *reinterpret_cast<const float4*>(vsb + (p * NT + li) * KC + 4 * half);
+          const float4 bf = up4[((size_t)(p * 3 + dz) * CQ + c0_ / 4 + half) * a.CoutP + co_base + li];
+          acc[oz][j] = MFMA_32x32x2(af.x, bf.x, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.y, bf.y, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.z, bf.z, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.w, bf.w, acc[oz][j]);
+        }
+      }
+    };
+    float4 ld[2];
+    bool ok[2];
+    // prologue: plane (0, 0) staged and transformed, plane (0, 1) staged
+    plane_loads(0, 0, ld, ok);
+    plane_store(xs, 0, ld, ok);
+    plane_loads(0, 1, ld, ok);
+    __syncthreads();
+    transform(xs, vs);
+    plane_store(xs + XSF, 0, ld, ok);
+    __syncthreads();
+    for (int c0 = 0; c0 < a.CinP; c0 += KC) {
+      const bool more = c0 + KC < a.CinP;                 // another chunk follows (workgroup-uniform)
+      // phase (c0, 0): MFMA plane 0 | transform plane 1 | loads of plane 2
+      plane_loads(c0, 2, ld, ok);
+      mfma_plane(vs, c0, std::integral_constant<int, 0>());
+      transform(xs + XSF, vs + VSF);
+      plane_store(xs, c0, ld, ok);
+      __syncthreads();
+      // phase (c0, 1): MFMA plane 1 | transform plane 2 | loads of plane 3
+      plane_loads(c0, 3, ld, ok);
+      mfma_plane(vs + VSF, c0, std::integral_constant<int, 1>());
+      transform(xs, vs);
+      plane_store(xs + XSF, c0, ld, ok);
+      __syncthreads();
+      // phase (c0, 2): MFMA plane 2 | transform plane 3 | loads of the next chunk's plane 0
+      if (more) plane_loads(c0 + KC, 0, ld, ok);
+      mfma_plane(vs, c0, std::integral_constant<int, 2>());
+      transform(xs + XSF, vs + VSF);
+      if (more) plane_store(xs, c0 + KC, ld, ok);
+      __syncthreads();
+      // phase (c0, 3): MFMA plane 3 | transform of the next chunk's plane 0 | loads of its plane 1
+      if (more) plane_loads(c0 + KC, 1, ld, ok);
+      mfma_plane(vs + VSF, c0, std::integral_constant<int, 3>());
+      if (more) { transform(xs, vs); plane_store(xs + XSF, c0 + KC, ld, ok); }
+      __syncthreads();
+    }
+  } else {
   for (int c0 = 0; c0 < a.CinP; c0 += KC) {
     for (int pz = 0; pz < TZ + 2; ++pz) {
       const int iz = tz0 - 1 + pz;
@@ -133,6 +250,7 @@ __global__ __launch_bounds__(256) void conv3d_wino2d(WinoArgs a) {
         }
       }
     }
+  }
   }
 
   // ---- output transform Y = A^T M A, bias / residual / dropout scale, store ----
@@ -283,13 +401,18 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
   const dim3 grid((unsigned)blocks), blk(256);
+  const char* pe = getenv("MI355_WINO_PIPE");                  // A/B switch, read per call (tests flip it); default: pipelined
+  const bool pipe = !(pe && pe[0] == '0');
+#define WINO_LAUNCH(IM, FU)                                                                         \
+  do { if (pipe) LAUNCH((conv3d_wino2d<IM, FU, true>), grid, blk, 0, stream, a);                   \
+       else LAUNCH((conv3d_wino2d<IM, FU, false>), grid, blk, 0, stream, a); } while (0)
   if (a.g.mom) {
-    if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wino2d<MI355_IN_PLAIN, 1>), grid, blk, 0, stream, a);
-    else LAUNCH((conv3d_wino2d<MI355_IN_AFFINE_ACT, 1>), grid, blk, 0, stream, a);
+    if (d->in_mode == MI355_IN_PLAIN) WINO_LAUNCH(MI355_IN_PLAIN, 1); else WINO_LAUNCH(MI355_IN_AFFINE_ACT, 1);
   } else if (a.g.gnb) {
-    LAUNCH((conv3d_wino2d<MI355_IN_PLAIN, 2>), grid, blk, 0, stream, a);
-  } else if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wino2d<MI355_IN_PLAIN>), grid, blk, 0, stream, a);
-  else LAUNCH((conv3d_wino2d<MI355_IN_AFFINE_ACT>), grid, blk, 0, stream, a);
+    WINO_LAUNCH(MI355_IN_PLAIN, 2);
+  } else if (d->in_mode == MI355_IN_PLAIN) WINO_LAUNCH(MI355_IN_PLAIN, 0);
+  else WINO_LAUNCH(MI355_IN_AFFINE_ACT, 0);
+#undef WINO_LAUNCH
   return LAUNCH_CHECK();
 }
 

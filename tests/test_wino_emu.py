@@ -10,6 +10,12 @@ from oracle import torch_ops as O
 ops = C.ops
 
 
+@pytest.fixture(autouse=True, params=["1", "0"], ids=["pipelined", "three-barrier"])
+def wino_variant(request, monkeypatch):
+    """both main-loop forms of the kernel (MI355_WINO_PIPE, read by the library at every call)"""
+    monkeypatch.setenv("MI355_WINO_PIPE", request.param)
+
+
 @pytest.mark.parametrize("kw", [
     dict(n=1, cin=8, cout=32, dhw=(2, 8, 16)),                                   # exactly one tile
     dict(n=2, cin=32, cout=32, dhw=(4, 8, 16), bias=True),                       # two z tiles, four channel chunks
