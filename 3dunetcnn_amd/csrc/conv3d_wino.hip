@@ -283,6 +283,18 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_wino2d(WinoA
     }
     __syncthreads();
     const int z = tz0 + oz;
+    // FUSE 2: the 16 reads of the normalised tensor go out first, from clamped (always valid) addresses (conv3d_fwd.hip: inside the
+    // loop every one of them is a dependent round trip behind the stores -- the first GPU measurement showed exactly that)
+    float gxv[16];
+    if constexpr (FUSE == 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        int yy = ty0 + 2 * (row >> 3) + oa, xx = tx0 + 2 * (row & 7) + ob, zc = z;
+        zc = zc < a.D ? zc : a.D - 1; yy = yy < a.H ? yy : a.H - 1; xx = xx < a.W ? xx : a.W - 1;
+        gxv[r] = a.g.gx[((((size_t)n * a.D + zc) * a.H + yy) * a.W + xx) * a.g.gxld + (cov ? co : a.Cout - 1)];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_wino2d(WinoA
         s0 += t; s1 += t * t;
         ++cnt;
       } else if constexpr (FUSE == 2) {
-        const float xv = a.g.gx[vox * a.g.gxld + co];
+        const float xv = gxv[r];
         const float u = xv * gsc + gsh;
         const float du = u > 0.f ? v : v * a.g.gslope;
         s0 += du; s1 += du * ((xv - gmean) * grstd);
