@@ -144,13 +144,11 @@ def test_whole_network_step_on_the_winograd_kernels(hip_backend):
         return orig(*a, **k)
     be.conv_fwd_wino = counted
     try:
-        m = unet.HipUNet3D(**g["kwargs"]).eval()
-        m._be = be
+        m = unet.HipUNet3D(**g["kwargs"]).cuda().eval()
         m.load_state_dict(g["state_dict"])
         crit = losses.HipDiceLoss(sigmoid=True)
-        crit._be = be
-        out = m(g["x"])
-        loss = crit(out, g["y"])
+        out = m(g["x"].cuda())
+        loss = crit(out, g["y"].cuda())
         loss.backward()
     finally:
         be.winograd = False
