@@ -40,7 +40,9 @@ struct WinoArgs {
 // FUSE: 0 plain epilogue, 1 + moment records of the output, 2 + norm-backward sums (dgrad): as conv3d_mfma
 // PIPE: software-pipelined main loop (one barrier per input plane: the MFMAs of plane k share the instruction stream with the transform
 // of plane k + 1, the global loads of plane k + 2 are in flight) instead of stage / barrier / transform / barrier / MFMA / barrier.
-template <int INMODE, int FUSE = 0, bool PIPE = false>
+// BEARLY (with PIPE): the phase's weight fragments are requested first, the transform of the next plane runs under their latency, then
+// the MFMAs -- instead of MFMAs (weights requested at their use) followed by the transform.
+template <int INMODE, int FUSE = 0, bool PIPE = false, bool BEARLY = false>
 __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_wino2d(WinoArgs a) {      // 128 accumulator registers + <= 128 others
   constexpr int TZ = 2, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HV = HY * HX;      // output tile; haloed input plane
   constexpr int KC = 8;                  // input channels per chunk
@@ -131,22 +133,44 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_wino2d(WinoA
         vsb[((4 * i + 3) * NT + tt) * KC + tc] = t[i][1] - t[i][3];
       }
     };
-    auto mfma_plane = [&](const float* vsb, int c0_, auto pzc) {
+    auto b_loads = [&](float4 (&bfr)[TZ][4], int c0_, auto pzc) {
       constexpr int PZ = decltype(pzc)::value;
 #pragma unroll
       for (int oz = 0; oz < TZ; ++oz) {
         const int dz = PZ - oz;
         if (dz < 0 || dz > 2) continue;          // compile-time after unrolling
 #pragma unroll
+        for (int j = 0; j < 4; ++j)
+          bfr[oz][j] = up4[((size_t)((4 * wave + j) * 3 + dz) * CQ + c0_ / 4 + half) * a.CoutP + co_base + li];
+      }
+    };
+    auto mfma_run = [&](const float* vsb, const float4 (&bfr)[TZ][4], auto pzc) {
+      constexpr int PZ = decltype(pzc)::value;
+#pragma unroll
+      for (int oz = 0; oz < TZ; ++oz) {
+        const int dz = PZ - oz;
+        if (dz < 0 || dz > 2) continue;
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int p = 4 * wave + j;
-          const float4 af = *reinterpret_cast<const float4*>(vsb + (p * NT + li) * KC + 4 * half);
-          const float4 bf = up4[((size_t)(p * 3 + dz) * CQ + c0_ / 4 + half) * a.CoutP + co_base + li];
-          acc[oz][j] = MFMA_32x32x2(af.x, bf.x, acc[oz][j]);
-          acc[oz][j] = MFMA_32x32x2(af.y, bf.y, acc[oz][j]);
-          acc[oz][j] = MFMA_32x32x2(af.z, bf.z, acc[oz][j]);
-          acc[oz][j] = MFMA_32x32x2(af.w, bf.w, acc[oz][j]);
+          const float4 af = *reinterpret_cast<const float4*>(vsb + ((4 * wave + j) * NT + li) * KC + 4 * half);
+          acc[oz][j] = MFMA_32x32x2(af.x, bfr[oz][j].x, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.y, bfr[oz][j].y, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.z, bfr[oz][j].z, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.w, bfr[oz][j].w, acc[oz][j]);
         }
+      }
+    };
+    // one phase: MFMAs of the plane in `vcur`, transform of the next plane `xnext` -> `vnext` (if any), in the order BEARLY selects
+    auto phase = [&](const float* vcur, int c0_, auto pzc, bool has_next, const float* xnext, float* vnext) {
+      float4 bfr[TZ][4];
+      b_loads(bfr, c0_, pzc);
+      if constexpr (BEARLY) {
+        if (has_next) transform(xnext, vnext);
+        SCHED_BARRIER();
+        mfma_run(vcur, bfr, pzc);
+      } else {
+        mfma_run(vcur, bfr, pzc);
+        if (has_next) transform(xnext, vnext);
       }
     };
     float4 ld[2];
@@ -163,26 +187,23 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_wino2d(WinoA
       const bool more = c0 + KC < a.CinP;                 // another chunk follows (workgroup-uniform)
       // phase (c0, 0): MFMA plane 0 | transform plane 1 | loads of plane 2
       plane_loads(c0, 2, ld, ok);
-      mfma_plane(vs, c0, std::integral_constant<int, 0>());
-      transform(xs + XSF, vs + VSF);
+      phase(vs, c0, std::integral_constant<int, 0>(), true, xs + XSF, vs + VSF);
       plane_store(xs, c0, ld, ok);
       __syncthreads();
       // phase (c0, 1): MFMA plane 1 | transform plane 2 | loads of plane 3
       plane_loads(c0, 3, ld, ok);
-      mfma_plane(vs + VSF, c0, std::integral_constant<int, 1>());
-      transform(xs, vs);
+      phase(vs + VSF, c0, std::integral_constant<int, 1>(), true, xs, vs);
       plane_store(xs + XSF, c0, ld, ok);
       __syncthreads();
       // phase (c0, 2): MFMA plane 2 | transform plane 3 | loads of the next chunk's plane 0
       if (more) plane_loads(c0 + KC, 0, ld, ok);
-      mfma_plane(vs, c0, std::integral_constant<int, 2>());
-      transform(xs + XSF, vs + VSF);
+      phase(vs, c0, std::integral_constant<int, 2>(), true, xs + XSF, vs + VSF);
       if (more) plane_store(xs, c0 + KC, ld, ok);
       __syncthreads();
       // phase (c0, 3): MFMA plane 3 | transform of the next chunk's plane 0 | loads of its plane 1
       if (more) plane_loads(c0 + KC, 1, ld, ok);
-      mfma_plane(vs + VSF, c0, std::integral_constant<int, 3>());
-      if (more) { transform(xs, vs); plane_store(xs + XSF, c0 + KC, ld, ok); }
+      phase(vs + VSF, c0, std::integral_constant<int, 3>(), more, xs, vs);
+      if (more) plane_store(xs + XSF, c0 + KC, ld, ok);
       __syncthreads();
     }
   } else {
@@ -413,10 +434,13 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
   const dim3 grid((unsigned)blocks), blk(256);
-  const char* pe = getenv("MI355_WINO_PIPE");                  // A/B switch, read per call (tests flip it); default: pipelined
+  const char* pe = getenv("MI355_WINO_PIPE");                  // A/B switches, read per call (tests flip them); default: pipelined
   const bool pipe = !(pe && pe[0] == '0');
+  const char* be_ = getenv("MI355_WINO_BEARLY");               // weights first, transform under their latency (default off until measured)
+  const bool bearly = be_ && be_[0] == '1';
 #define WINO_LAUNCH(IM, FU)                                                                         \
-  do { if (pipe) LAUNCH((conv3d_wino2d<IM, FU, true>), grid, blk, 0, stream, a);                   \
+  do { if (pipe && bearly) LAUNCH((conv3d_wino2d<IM, FU, true, true>), grid, blk, 0, stream, a);   \
+       else if (pipe) LAUNCH((conv3d_wino2d<IM, FU, true>), grid, blk, 0, stream, a);              \
        else LAUNCH((conv3d_wino2d<IM, FU, false>), grid, blk, 0, stream, a); } while (0)
   if (a.g.mom) {
     if (d->in_mode == MI355_IN_PLAIN) WINO_LAUNCH(MI355_IN_PLAIN, 1); else WINO_LAUNCH(MI355_IN_AFFINE_ACT, 1);

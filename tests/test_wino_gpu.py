@@ -10,10 +10,11 @@ from oracle import torch_ops as O
 ops = C.ops
 
 
-@pytest.fixture(autouse=True, params=["1", "0"], ids=["pipelined", "three-barrier"])
+@pytest.fixture(autouse=True, params=[("1", "0"), ("1", "1"), ("0", "0")], ids=["pipelined", "pipelined-weights-first", "three-barrier"])
 def wino_variant(request, monkeypatch):
-    """both main-loop forms of the kernel (MI355_WINO_PIPE, read by the library at every call)"""
-    monkeypatch.setenv("MI355_WINO_PIPE", request.param)
+    """the main-loop forms of the kernel (MI355_WINO_PIPE / MI355_WINO_BEARLY, read by the library at every call)"""
+    monkeypatch.setenv("MI355_WINO_PIPE", request.param[0])
+    monkeypatch.setenv("MI355_WINO_BEARLY", request.param[1])
 
 
 @pytest.mark.gpu
