@@ -136,6 +136,7 @@ class Backend:
         # EXPERIMENT SWITCH (prepared on the emulator, not yet measured): MI355_WINOGRAD=1 routes the eligible fp32 3x3x3 stride-1
         # forward / dgrad convolutions to the Winograd kernel
         self.winograd = os.environ.get("MI355_WINOGRAD", "0") == "1"
+        self.winograd_wgrad = os.environ.get("MI355_WINOGRAD_WGRAD", "0") == "1"      # the weight gradients too (first version, never measured)
         self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
         # norm statistics leave with the producing conv's epilogue (csrc/gn_fuse.h). False: every statistic is a standalone pass
         # over the tensor again (the round-1 form; kept as the cross-check of the fused path, tests/test_ops_gpu.py)
@@ -297,6 +298,15 @@ class Backend:
         d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, None, None, None, (0, 0, 0),
                        x.shape[1:4] if out_mode == OUT_D2S else dy.shape[1:4], keep, in_slope, out_mode)
         xd, dyd = x.desc(), dy.desc()
+        if (self.winograd_wgrad and self.precision == PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT)
+                and out_mode == OUT_PLAIN and x.c >= 8 and dy.c >= 8 and self.prof is None):
+            nbytes = self.lib.mi355_conv3d_wino_wgrad_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))
+            if nbytes:
+                ws = self.ws(nbytes)
+                assert dw.is_contiguous()
+                check(self.lib.mi355_conv3d_wino_wgrad(ctypes.byref(xd), ctypes.byref(dyd), dw.data_ptr(), ctypes.byref(d), ws.data_ptr(),
+                                                       ws.numel() * 4, self.stream()), "conv3d_wino_wgrad")
+                return
         nbytes = self.lib.mi355_conv3d_wgrad_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))
         if nbytes == 0:
             raise RuntimeError("conv3d_wgrad: unsupported configuration")

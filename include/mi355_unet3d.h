@@ -292,6 +292,10 @@ int mi355_wino_pack_weight(const float* w, float* up, int32_t cout, int32_t cin,
 int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const mi355_act* y, const mi355_conv_desc* desc, void* stream);
 /* records per sample its fused-statistics epilogues (desc->moments_out / desc->gn_bwd, formats of gn_fuse.h) write: 2 x 8 x 16 voxel tiles */
 int32_t mi355_conv3d_wino_stats_blocks(const mi355_act* y);
+/* weight gradient in the same domain (F(3x3, 2x2) x direct z): contract of mi355_conv3d_wgrad for kd 3 / stride 1 / pad 1 */
+size_t mi355_conv3d_wino_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* desc);
+int mi355_conv3d_wino_wgrad(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* desc, void* ws, size_t ws_bytes,
+                            void* stream);
 
 /* ---- Dice loss -------------------------------------------------------------------------------- */
 /* monai.losses.DiceLoss as configured by examples/brats2020/brats2020_config.json:112-116 (sigmoid=True,

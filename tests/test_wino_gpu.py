@@ -1,5 +1,5 @@
-"""GPU twins of tests/test_wino_emu.py: the Winograd kernel through the C ABI on an MI355X (same cases, same tolerances).
-Generated from that file: keep the two in step."""
+"""GPU twins of tests/test_wino_emu.py: the Winograd kernels through the C ABI on an MI355X (same cases, same tolerances).
+Generated from that file: keep the two in step. Never run on hardware yet."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -128,15 +128,15 @@ def test_wino_norm_backward_sums_from_dgrad_epilogue(hip_backend, kw):
 
 @pytest.mark.gpu
 def test_whole_network_step_on_the_winograd_kernels(hip_backend):
-    """MI355_WINOGRAD switch: every eligible 3x3x3 stride-1 forward / dgrad conv of a UNet3D step on the Winograd kernel (weight
-    gradients stay on the direct kernels), against the golden bundle generated from the reference."""
+    """MI355_WINOGRAD + MI355_WINOGRAD_WGRAD switches: every eligible 3x3x3 stride-1 forward / dgrad / wgrad conv of a UNet3D step on the
+    Winograd kernels, against the golden bundle generated from the reference."""
     import importlib
     import os
     unet = importlib.import_module("3dunetcnn_amd.unet")
     losses = importlib.import_module("3dunetcnn_amd.losses")
     g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet3d_small.pt"))
     be = hip_backend
-    be.winograd = True
+    be.winograd = be.winograd_wgrad = True
     calls = {"n": 0}
     orig = be.conv_fwd_wino
 
@@ -152,10 +152,27 @@ def test_whole_network_step_on_the_winograd_kernels(hip_backend):
         loss = crit(out, g["y"].cuda())
         loss.backward()
     finally:
-        be.winograd = False
+        be.winograd = be.winograd_wgrad = False
         del be.conv_fwd_wino
     assert calls["n"] >= 20
     assert C.rel_err(out, g["logits"]) < 1e-3
     assert abs(float(loss.detach()) - float(g["loss"])) / float(g["loss"]) < 1e-3
     for k, p in m.named_parameters():
         assert C.rel_err(p.grad, g["grads"][k]) < 1e-3, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(n=2, cin=32, cout=32, dhw=(3, 8, 8), norm=True),
+    dict(n=1, cin=8, cout=64, dhw=(4, 9, 17)),                                   # ragged plane tiles, two co tiles
+    dict(n=1, cin=40, cout=96, dhw=(5, 3, 7), norm=True, slope=0.01),            # partial channel tiles
+    dict(n=2, cin=32, cout=32, dhw=(5, 16, 32), norm=True),                      # many plane tiles per workgroup split
+])
+def test_wino_wgrad_matches_autograd(hip_backend, kw):
+    be = hip_backend
+    be.winograd_wgrad = True
+    try:
+        assert C.case_conv_wgrad(be, **kw) < 1e-4
+    finally:
+        be.winograd_wgrad = False
+
