@@ -620,6 +620,179 @@ __global__ __launch_bounds__(512) void conv3d_wino2d_wgrad(WinoWArgs a) {
   }
 }
 
+// Software-pipelined form of the same kernel: the 16 points are split into two halves (rows i = 0,1 and i = 2,3 of the point grid); wave w
+// owns point w of each half. While the MFMAs of one half run, the other half of the same / the next plane tile is transformed into the
+// other buffer, and the global loads of the tile after next are in flight: two barriers per plane tile, none of them waiting for memory.
+template <int INMODE>
+__global__ __launch_bounds__(512) void conv3d_wino2d_wgrad_pipe(WinoWArgs a) {
+  constexpr int TY = 8, TX = 8, HX = 10, HV = 100, XS = 36, TS = 16;
+  constexpr int XSF = HV * XS, DSF = 64 * XS, HF = 8 * 32 * TS;  // one staged x tile, one staged dy tile, one half of V or Dv
+  constexpr int LDSF = 2 * (XSF + DSF) + 4 * HF;                 // 28192 floats = 110 KB
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  auto xsb_ = [&](int i) { return lds + i * (XSF + DSF); };                      // staged tile buffer i: x tile, then the dy tile
+  auto vh_ = [&](int h) { return lds + 2 * (XSF + DSF) + h * 2 * HF; };          // half h: V, then Dv
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+  const int split = blockIdx.x, pair = blockIdx.y, dz = blockIdx.z;
+  const int cot = pair / a.ciTiles, cit = pair % a.ciTiles;
+  const int ci0 = cit * 32, co0 = cot * 32;
+  const int per = (a.ntiles + a.splits - 1) / a.splits;
+  const int t_begin = split * per, t_end = t_begin + per < a.ntiles ? t_begin + per : a.ntiles;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  const int tt = tid >> 5, tc = tid & 31, tty = tt >> 2, ttx = tt & 3;
+
+  // plane tiles whose input plane z + dz - 1 is padding contribute nothing: the walk skips them (workgroup-uniform)
+  auto next_valid = [&](int pt) {
+    while (pt < t_end) {
+      const int z = (pt / (a.tilesX * a.tilesY)) % a.D, iz = z + dz - 1;
+      if (iz >= 0 && iz < a.D) break;
+      ++pt;
+    }
+    return pt;
+  };
+  struct Staged { float4 x[2]; float4 d; };
+  auto tile_loads = [&](int pt, Staged& st) {
+    int b = pt;
+    const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+    const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+    const int z = b % a.D, n = b / a.D, iz = z + dz - 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int u = tid + 512 * k;
+      st.x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u >= HV * 8) continue;
+      const int hv = u >> 3, q = u & 7;
+      const int iy = ty0 - 1 + hv / HX, ix = tx0 - 1 + hv % HX, c = ci0 + 4 * q;
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin) {
+        float4 v = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + c);
+        if (INMODE == MI355_IN_AFFINE_ACT) {
+          const float4 sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
+          const float4 sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
+          float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
+          if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + c);
+          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+          v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
+        }
+        st.x[k] = v;
+      }
+    }
+    {
+      const int vv = tid >> 3, q = tid & 7;
+      const int yy = ty0 + (vv >> 3), xx = tx0 + (vv & 7), c = co0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (yy < a.H && xx < a.W && c < a.Cout) {
+        const float* p = a.dy + ((((size_t)n * a.D + z) * a.H + yy) * a.W + xx) * a.dyld + c;
+        v.x = p[0];
+        if (c + 1 < a.Cout) v.y = p[1];
+        if (c + 2 < a.Cout) v.z = p[2];
+        if (c + 3 < a.Cout) v.w = p[3];
+      }
+      st.d = v;
+    }
+  };
+  auto tile_store = [&](float* buf, const Staged& st) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int u = tid + 512 * k;
+      if (u >= HV * 8) continue;
+      *reinterpret_cast<float4*>(buf + (u >> 3) * XS + 4 * (u & 7)) = st.x[k];
+    }
+    *reinterpret_cast<float4*>(buf + XSF + (tid >> 3) * XS + 4 * (tid & 7)) = st.d;
+  };
+  // transform the point rows i = 2 * hsel, 2 * hsel + 1 of tile (tty, ttx), channel tc, from the staged tile `buf` into half buffer `vh`
+  auto transform_half = [&](const float* buf, float* vh, int hsel) {
+    float d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) d[r][s2] = buf[((2 * tty + r) * HX + 2 * ttx + s2) * XS + tc];
+    const float* ds = buf + XSF;
+    const float h00 = ds[((2 * tty) * TX + 2 * ttx) * XS + tc], h01 = ds[((2 * tty) * TX + 2 * ttx + 1) * XS + tc];
+    const float h10 = ds[((2 * tty + 1) * TX + 2 * ttx) * XS + tc], h11 = ds[((2 * tty + 1) * TX + 2 * ttx + 1) * XS + tc];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int i = 2 * hsel + ii;                               // hsel is workgroup-uniform
+      float t[4], r[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+        t[s2] = i == 0 ? d[0][s2] - d[2][s2] : i == 1 ? d[1][s2] + d[2][s2] : i == 2 ? d[2][s2] - d[1][s2] : d[1][s2] - d[3][s2];
+      r[0] = i == 0 ? h00 : i == 1 ? h00 + h10 : i == 2 ? h00 - h10 : -h10;
+      r[1] = i == 0 ? h01 : i == 1 ? h01 + h11 : i == 2 ? h01 - h11 : -h11;
+      float* vp = vh + ((4 * ii) * 32 + tc) * TS + tt;
+      vp[0 * 32 * TS] = t[0] - t[2]; vp[1 * 32 * TS] = t[1] + t[2]; vp[2 * 32 * TS] = t[2] - t[1]; vp[3 * 32 * TS] = t[1] - t[3];
+      float* dp = vh + HF + ((4 * ii) * 32 + tc) * TS + tt;
+      dp[0 * 32 * TS] = r[0]; dp[1 * 32 * TS] = r[0] + r[1]; dp[2 * 32 * TS] = r[0] - r[1]; dp[3 * 32 * TS] = -r[1];
+    }
+  };
+  auto mfma_half = [&](const float* vh, f32x16& ac) {           // this wave's point of the half: local index `wave`
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      const float4 af = *reinterpret_cast<const float4*>(vh + HF + (wave * 32 + li) * TS + 8 * kg + 4 * half);
+      const float4 bf = *reinterpret_cast<const float4*>(vh + (wave * 32 + li) * TS + 8 * kg + 4 * half);
+      ac = MFMA_32x32x2(af.x, bf.x, ac);
+      ac = MFMA_32x32x2(af.y, bf.y, ac);
+      ac = MFMA_32x32x2(af.z, bf.z, ac);
+      ac = MFMA_32x32x2(af.w, bf.w, ac);
+    }
+  };
+
+  Staged st;
+  int p0 = next_valid(t_begin);
+  if (p0 < t_end) {
+    int p1 = next_valid(p0 + 1);
+    // prologue: tile 0 staged and its first half transformed, tile 1 staged
+    tile_loads(p0, st); tile_store(xsb_(0), st);
+    if (p1 < t_end) { tile_loads(p1, st); tile_store(xsb_(1), st); }
+    __syncthreads();
+    transform_half(xsb_(0), vh_(0), 0);
+    __syncthreads();
+    int cur = 0;                                                 // parity of the staged buffer holding the current tile
+    int pk = p0, pk1 = p1;
+    while (pk < t_end) {
+      const int pk2 = pk1 < t_end ? next_valid(pk1 + 1) : t_end;
+      // phase A: MFMA half 0 of the tile | transform its half 1
+      mfma_half(vh_(0), acc[0]);
+      transform_half(xsb_(cur), vh_(1), 1);
+      __syncthreads();
+      // phase B: MFMA half 1 | transform half 0 of the next tile | stage the tile after next into this tile's buffer
+      if (pk2 < t_end) tile_loads(pk2, st);
+      mfma_half(vh_(1), acc[1]);
+      if (pk1 < t_end) transform_half(xsb_(cur ^ 1), vh_(0), 0);
+      if (pk2 < t_end) tile_store(xsb_(cur), st);
+      __syncthreads();
+      pk = pk1; pk1 = pk2; cur ^= 1;
+    }
+  }
+
+  // ---- output transform through LDS (point of half h, wave w: p = 8 h + w) and slab write: as the three-barrier kernel ----
+  __syncthreads();
+  float* Ms = lds;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      Ms[((8 * q + wave) * 32 + row) * 32 + li] = acc[q][r];
+    }
+  __syncthreads();
+  const float GT[3][4] = {{1.f, 0.5f, 0.5f, 0.f}, {0.f, 0.5f, -0.5f, 0.f}, {0.f, 0.5f, 0.5f, 1.f}};
+  float* slab = a.ws + (((size_t)pair * a.splits + split) * 27 + dz * 9) * 1024;
+  for (int idx = tid; idx < 9 * 1024; idx += 512) {
+    const int tap = idx >> 10, e = idx & 1023;
+    const int ta = tap / 3, tb = tap % 3;
+    float o = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o += GT[ta][i] * GT[tb][j] * Ms[(4 * i + j) * 1024 + e];
+    slab[(size_t)tap * 1024 + e] = o;
+  }
+}
+
 struct WinoWPlan { int tilesY, tilesX, ntiles, splits, ciTiles, coTiles; size_t ws_bytes; int ok; };
 static WinoWPlan plan_wino_wgrad(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
   WinoWPlan p; memset(&p, 0, sizeof(p));
@@ -662,7 +835,11 @@ extern "C" int mi355_conv3d_wino_wgrad(const mi355_act* x, const mi355_act* dy, 
   a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Cout = dy->c;
   a.tilesY = p.tilesY; a.tilesX = p.tilesX; a.ntiles = p.ntiles; a.splits = p.splits; a.ciTiles = p.ciTiles; a.coTiles = p.coTiles;
   const dim3 grid(p.splits, p.ciTiles * p.coTiles, 3);
-  if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wino2d_wgrad<MI355_IN_PLAIN>), grid, dim3(512), 0, stream, a);
+  const char* pe = getenv("MI355_WINO_PIPE");                  // same A/B switch as the forward kernel; default: pipelined
+  if (!(pe && pe[0] == '0')) {
+    if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wino2d_wgrad_pipe<MI355_IN_PLAIN>), grid, dim3(512), 0, stream, a);
+    else LAUNCH((conv3d_wino2d_wgrad_pipe<MI355_IN_AFFINE_ACT>), grid, dim3(512), 0, stream, a);
+  } else if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wino2d_wgrad<MI355_IN_PLAIN>), grid, dim3(512), 0, stream, a);
   else LAUNCH((conv3d_wino2d_wgrad<MI355_IN_AFFINE_ACT>), grid, dim3(512), 0, stream, a);
   const int rc = LAUNCH_CHECK(); if (rc) return rc;
   return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, p.splits, p.ciTiles, stream);
