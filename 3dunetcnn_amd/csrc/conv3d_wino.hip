@@ -560,10 +560,10 @@ __global__ __launch_bounds__(512) void conv3d_wino2d_wgrad(WinoWArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        V[((4 * i + 0) * 32 + tc) * TS + tt] = t[i][0] - t[i][2];
-        V[((4 * i + 1) * 32 + tc) * TS + tt] = t[i][1] + t[i][2];
-        V[((4 * i + 2) * 32 + tc) * TS + tt] = t[i][2] - t[i][1];
-        V[((4 * i + 3) * 32 + tc) * TS + tt] = t[i][1] - t[i][3];
+        V[((4 * i + 0) * TS + tt) * 32 + tc] = t[i][0] - t[i][2];
+        V[((4 * i + 1) * TS + tt) * 32 + tc] = t[i][1] + t[i][2];
+        V[((4 * i + 2) * TS + tt) * 32 + tc] = t[i][2] - t[i][1];
+        V[((4 * i + 3) * TS + tt) * 32 + tc] = t[i][1] - t[i][3];
       }
       const float h00 = dss[((2 * tty) * TX + 2 * ttx) * XS + tc], h01 = dss[((2 * tty) * TX + 2 * ttx + 1) * XS + tc];
       const float h10 = dss[((2 * tty + 1) * TX + 2 * ttx) * XS + tc], h11 = dss[((2 * tty + 1) * TX + 2 * ttx + 1) * XS + tc];
@@ -572,10 +572,10 @@ __global__ __launch_bounds__(512) void conv3d_wino2d_wgrad(WinoWArgs a) {
       const float* rr[4] = {r0, r1, r2, r3};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        Dv[((4 * i + 0) * 32 + tc) * TS + tt] = rr[i][0];
-        Dv[((4 * i + 1) * 32 + tc) * TS + tt] = rr[i][0] + rr[i][1];
-        Dv[((4 * i + 2) * 32 + tc) * TS + tt] = rr[i][0] - rr[i][1];
-        Dv[((4 * i + 3) * 32 + tc) * TS + tt] = -rr[i][1];
+        Dv[((4 * i + 0) * TS + tt) * 32 + tc] = rr[i][0];
+        Dv[((4 * i + 1) * TS + tt) * 32 + tc] = rr[i][0] + rr[i][1];
+        Dv[((4 * i + 2) * TS + tt) * 32 + tc] = rr[i][0] - rr[i][1];
+        Dv[((4 * i + 3) * TS + tt) * 32 + tc] = -rr[i][1];
       }
     }
     __syncthreads();
@@ -585,12 +585,12 @@ __global__ __launch_bounds__(512) void conv3d_wino2d_wgrad(WinoWArgs a) {
       const int p = 2 * wave + q;
 #pragma unroll
       for (int kg = 0; kg < 2; ++kg) {
-        const float4 af = *reinterpret_cast<const float4*>(Dv + (p * 32 + li) * TS + 8 * kg + 4 * half);
-        const float4 bf = *reinterpret_cast<const float4*>(V + (p * 32 + li) * TS + 8 * kg + 4 * half);
-        acc[q] = MFMA_32x32x2(af.x, bf.x, acc[q]);
-        acc[q] = MFMA_32x32x2(af.y, bf.y, acc[q]);
-        acc[q] = MFMA_32x32x2(af.z, bf.z, acc[q]);
-        acc[q] = MFMA_32x32x2(af.w, bf.w, acc[q]);
+        // [point][tile][channel] layout: the transform writes and these reads are both 32 consecutive floats per instruction
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int t = 8 * kg + 4 * half + e;
+          acc[q] = MFMA_32x32x2(Dv[(p * TS + t) * 32 + li], V[(p * TS + t) * 32 + li], acc[q]);
+        }
       }
     }
   }
@@ -722,21 +722,20 @@ __global__ __launch_bounds__(512) void conv3d_wino2d_wgrad_pipe(WinoWArgs a) {
         t[s2] = i == 0 ? d[0][s2] - d[2][s2] : i == 1 ? d[1][s2] + d[2][s2] : i == 2 ? d[2][s2] - d[1][s2] : d[1][s2] - d[3][s2];
       r[0] = i == 0 ? h00 : i == 1 ? h00 + h10 : i == 2 ? h00 - h10 : -h10;
       r[1] = i == 0 ? h01 : i == 1 ? h01 + h11 : i == 2 ? h01 - h11 : -h11;
-      float* vp = vh + ((4 * ii) * 32 + tc) * TS + tt;
+      float* vp = vh + ((4 * ii) * TS + tt) * 32 + tc;          // [point][tile][channel]: 32 consecutive floats per write instruction
       vp[0 * 32 * TS] = t[0] - t[2]; vp[1 * 32 * TS] = t[1] + t[2]; vp[2 * 32 * TS] = t[2] - t[1]; vp[3 * 32 * TS] = t[1] - t[3];
-      float* dp = vh + HF + ((4 * ii) * 32 + tc) * TS + tt;
+      float* dp = vh + HF + ((4 * ii) * TS + tt) * 32 + tc;
       dp[0 * 32 * TS] = r[0]; dp[1 * 32 * TS] = r[0] + r[1]; dp[2 * 32 * TS] = r[0] - r[1]; dp[3 * 32 * TS] = -r[1];
     }
   };
   auto mfma_half = [&](const float* vh, f32x16& ac) {           // this wave's point of the half: local index `wave`
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
-      const float4 af = *reinterpret_cast<const float4*>(vh + HF + (wave * 32 + li) * TS + 8 * kg + 4 * half);
-      const float4 bf = *reinterpret_cast<const float4*>(vh + (wave * 32 + li) * TS + 8 * kg + 4 * half);
-      ac = MFMA_32x32x2(af.x, bf.x, ac);
-      ac = MFMA_32x32x2(af.y, bf.y, ac);
-      ac = MFMA_32x32x2(af.z, bf.z, ac);
-      ac = MFMA_32x32x2(af.w, bf.w, ac);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int t = 8 * kg + 4 * half + e;
+        ac = MFMA_32x32x2(vh[HF + (wave * TS + t) * 32 + li], vh[(wave * TS + t) * 32 + li], ac);
+      }
     }
   };
 
