@@ -124,6 +124,11 @@ class PackedWeight:
 
 
 class Backend:
+    # the one measurement so far (profiles/r2_winograd_prep_measurement.txt): no gain on the 16^3 level (256 channels), 16-36 % above it
+    WINO_MIN_VOXELS = 32 ** 3
+    # executed / algorithmic multiplications of the Winograd kernels (bench.py reports both rates)
+    WINO_EXECUTED = {"conv3d_wino2d": 12.0 / 27.0, "conv3d_wino2d_wgrad (+reduce)": 16.0 / 36.0}
+
     def __init__(self, lib=None, device=None):
         self.lib = lib if lib is not None else _lib.load_library()
         if device is None:
@@ -137,6 +142,7 @@ class Backend:
         # forward / dgrad convolutions to the Winograd kernel
         self.winograd = os.environ.get("MI355_WINOGRAD", "0") == "1"
         self.winograd_wgrad = os.environ.get("MI355_WINOGRAD_WGRAD", "0") == "1"      # the weight gradients too (first version, never measured)
+
         self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
         # norm statistics leave with the producing conv's epilogue (csrc/gn_fuse.h). False: every statistic is a standalone pass
         # over the tensor again (the round-1 form; kept as the cross-check of the fused path, tests/test_ops_gpu.py)
@@ -203,7 +209,8 @@ class Backend:
             out_dhw = x.shape[1:4] if out_mode == OUT_D2S else y.shape[1:4]
         if (self.winograd and self.precision == PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT)
                 and out_mode == OUT_PLAIN and tuple(off) == (0, 0, 0) and tuple(out_dhw) == tuple(y.shape[1:4]) and wp.mode in (0, 1)
-                and wp.cin >= 8 and wp.cout >= 8 and x.shape[1:4] == y.shape[1:4] and self.prof is None):
+                and wp.cin >= 8 and wp.cout >= 8 and x.shape[1:4] == y.shape[1:4]
+                and x.shape[1] * x.shape[2] * x.shape[3] >= self.WINO_MIN_VOXELS):
             return self.conv_fwd_wino(x, wp.wino(), y, in_mode=in_mode, slope=slope, scale=scale, shift=shift, bias=bias, residual=residual,
                                       chscale=chscale, in_slope=in_slope, moments=moments, gnb=gnb)
         keep = []
@@ -278,7 +285,14 @@ class Backend:
                 d.gn_bwd = ctypes.pointer(fuse)
                 keep.extend([fuse, gx, st])
                 gparts = (rec, nb)
+        if self.prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         check(self.lib.mi355_conv3d_wino_fwd(ctypes.byref(xd), up.data_ptr(), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_wino_fwd")
+        if self.prof is not None:
+            e1.record()
+            nvox = y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3]
+            self.prof.append(("conv3d_wino2d", 2.0 * nvox * x.c * y.c * 27, 4.0 * (nvox * (x.c + y.c) + 27 * x.c * y.c), e0, e1))
         return self._fold_after(y, gparts)
 
     def _fold_after(self, y, gparts):
@@ -299,13 +313,21 @@ class Backend:
                        x.shape[1:4] if out_mode == OUT_D2S else dy.shape[1:4], keep, in_slope, out_mode)
         xd, dyd = x.desc(), dy.desc()
         if (self.winograd_wgrad and self.precision == PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT)
-                and out_mode == OUT_PLAIN and x.c >= 8 and dy.c >= 8 and self.prof is None):
+                and out_mode == OUT_PLAIN and x.c >= 8 and dy.c >= 8 and x.shape[1] * x.shape[2] * x.shape[3] >= self.WINO_MIN_VOXELS):
             nbytes = self.lib.mi355_conv3d_wino_wgrad_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))
             if nbytes:
                 ws = self.ws(nbytes)
                 assert dw.is_contiguous()
+                if self.prof is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 check(self.lib.mi355_conv3d_wino_wgrad(ctypes.byref(xd), ctypes.byref(dyd), dw.data_ptr(), ctypes.byref(d), ws.data_ptr(),
                                                        ws.numel() * 4, self.stream()), "conv3d_wino_wgrad")
+                if self.prof is not None:
+                    e1.record()
+                    nvox = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3]
+                    self.prof.append(("conv3d_wino2d_wgrad (+reduce)", 2.0 * nvox * x.c * dy.c * 27,
+                                      4.0 * (nvox * (x.c + dy.c) + 27 * x.c * dy.c), e0, e1))
                 return
         nbytes = self.lib.mi355_conv3d_wgrad_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))
         if nbytes == 0:

@@ -130,6 +130,7 @@ def test_whole_network_step_on_the_winograd_kernels(emu_backend):
     g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet3d_small.pt"))
     be = emu_backend
     be.winograd = be.winograd_wgrad = True
+    be.WINO_MIN_VOXELS = 0                 # the golden bundle is 20 x 16 x 24: route every level
     calls = {"n": 0}
     orig = be.conv_fwd_wino
 
@@ -148,7 +149,7 @@ def test_whole_network_step_on_the_winograd_kernels(emu_backend):
         loss.backward()
     finally:
         be.winograd = be.winograd_wgrad = False
-        del be.conv_fwd_wino
+        del be.conv_fwd_wino, be.WINO_MIN_VOXELS
     assert calls["n"] >= 20
     assert C.rel_err(out, g["logits"]) < 1e-3
     assert abs(float(loss.detach()) - float(g["loss"])) / float(g["loss"]) < 1e-3
@@ -165,8 +166,10 @@ def test_whole_network_step_on_the_winograd_kernels(emu_backend):
 def test_wino_wgrad_matches_autograd(emu_backend, kw):
     be = emu_backend
     be.winograd_wgrad = True
+    be.WINO_MIN_VOXELS = 0
     try:
         assert C.case_conv_wgrad(be, **kw) < 1e-4
     finally:
         be.winograd_wgrad = False
+        del be.WINO_MIN_VOXELS
 
