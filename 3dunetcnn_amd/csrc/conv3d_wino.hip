@@ -40,9 +40,11 @@ struct WinoArgs {
 // FUSE: 0 plain epilogue, 1 + moment records of the output, 2 + norm-backward sums (dgrad): as conv3d_mfma
 // PIPE: software-pipelined main loop (one barrier per input plane: the MFMAs of plane k share the instruction stream with the transform
 // of plane k + 1, the global loads of plane k + 2 are in flight) instead of stage / barrier / transform / barrier / MFMA / barrier.
-// BEARLY (with PIPE): the phase's weight fragments are requested first, the transform of the next plane runs under their latency, then
+// BMODE 1 (with PIPE): the phase's weight fragments are requested first, the transform of the next plane runs under their latency, then
 // the MFMAs -- instead of MFMAs (weights requested at their use) followed by the transform.
-template <int INMODE, int FUSE = 0, bool PIPE = false, bool BEARLY = false>
+// BMODE 2 (with PIPE): the weight fragments of a phase's FIRST (output plane, dz) use are requested during the previous phase, those of its
+// second use at its start (they arrive under the first use's MFMAs): the ISA of BMODE 0 shows every phase opening with a wait for its weights.
+template <int INMODE, int FUSE = 0, bool PIPE = false, int BMODE = 0>
 __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_wino2d(WinoArgs a) {      // 128 accumulator registers + <= 128 others
   constexpr int TZ = 2, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HV = HY * HX;      // output tile; haloed input plane
   constexpr int KC = 8;                  // input channels per chunk
@@ -116,14 +118,12 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_wino2d(WinoA
       }
     };
     auto transform = [&](const float* xsb, float* vsb) {
-      float d[4][4], t[4][4];
+      float t[4][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) d[r][s2] = xsb[((2 * tty + r) * HX + 2 * ttx + s2) * XS + tc];
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        t[0][s2] = d[0][s2] - d[2][s2]; t[1][s2] = d[1][s2] + d[2][s2]; t[2][s2] = d[2][s2] - d[1][s2]; t[3][s2] = d[1][s2] - d[3][s2];
+      for (int s2 = 0; s2 < 4; ++s2) {          // one window column at a time: 4 values live instead of 16
+        const float* col = xsb + ((2 * tty) * HX + 2 * ttx + s2) * XS + tc;
+        const float d0 = col[0], d1 = col[HX * XS], d2 = col[2 * HX * XS], d3 = col[3 * HX * XS];
+        t[0][s2] = d0 - d2; t[1][s2] = d1 + d2; t[2][s2] = d2 - d1; t[3][s2] = d1 - d3;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -164,12 +164,51 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_wino2d(WinoA
     auto phase = [&](const float* vcur, int c0_, auto pzc, bool has_next, const float* xnext, float* vnext) {
       float4 bfr[TZ][4];
       b_loads(bfr, c0_, pzc);
-      if constexpr (BEARLY) {
+      if constexpr (BMODE == 1) {
         if (has_next) transform(xnext, vnext);
         SCHED_BARRIER();
         mfma_run(vcur, bfr, pzc);
       } else {
         mfma_run(vcur, bfr, pzc);
+        if (has_next) transform(xnext, vnext);
+      }
+    };
+    // BMODE 2. First use of phase pz: output plane 0 (dz = pz) for pz = 0..2, output plane 1 (dz = 2) for pz = 3; second use (pz = 1, 2):
+    // output plane 1 with dz = pz - 1.
+    auto b_use = [&](float4 (&bu)[4], int c0_, int dz) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bu[j] = up4[((size_t)((4 * wave + j) * 3 + dz) * CQ + c0_ / 4 + half) * a.CoutP + co_base + li];
+    };
+    auto mfma_use = [&](const float* vsb, const float4 (&bu)[4], f32x16 (&ac)[4]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 af = *reinterpret_cast<const float4*>(vsb + ((4 * wave + j) * NT + li) * KC + 4 * half);
+        ac[j] = MFMA_32x32x2(af.x, bu[j].x, ac[j]);
+        ac[j] = MFMA_32x32x2(af.y, bu[j].y, ac[j]);
+        ac[j] = MFMA_32x32x2(af.z, bu[j].z, ac[j]);
+        ac[j] = MFMA_32x32x2(af.w, bu[j].w, ac[j]);
+      }
+    };
+    // Two fragment sets, each requested one USE ahead. Single-use phases (pz = 0, 3): first use from bx, the next phase's first use is
+    // requested into by. Two-use phases (pz = 1, 2): first use from bx, second use requested into by at the start, the next phase's first
+    // use into bx once the first use's MFMAs have consumed it. (c0n, pzn): the next phase; pzn < 0: none.
+    auto phase_pf = [&](const float* vcur, int c0_, auto pzc, bool has_next, const float* xnext, float* vnext,
+                        float4 (&bx)[4], float4 (&by)[4], int c0n, int pzn) {
+      constexpr int PZ = decltype(pzc)::value;
+      const int dzn = pzn == 3 ? 2 : pzn;
+      if constexpr (PZ == 1 || PZ == 2) {
+        b_use(by, c0_, PZ - 1);
+        SCHED_BARRIER();
+        mfma_use(vcur, bx, acc[0]);
+        if (has_next) transform(xnext, vnext);
+        if (pzn >= 0) b_use(bx, c0n, dzn);
+        SCHED_BARRIER();
+        mfma_use(vcur, by, acc[1]);
+      } else {
+        if (pzn >= 0) b_use(by, c0n, dzn);
+        SCHED_BARRIER();
+        mfma_use(vcur, bx, acc[PZ == 3 ? 1 : 0]);
         if (has_next) transform(xnext, vnext);
       }
     };
@@ -183,8 +222,29 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_wino2d(WinoA
     transform(xs, vs);
     plane_store(xs + XSF, 0, ld, ok);
     __syncthreads();
+    float4 bA[4], bB[4];
+    if constexpr (BMODE == 2) b_use(bA, 0, 0);                   // first use of phase (0, 0)
     for (int c0 = 0; c0 < a.CinP; c0 += KC) {
       const bool more = c0 + KC < a.CinP;                 // another chunk follows (workgroup-uniform)
+      if constexpr (BMODE == 2) {
+        plane_loads(c0, 2, ld, ok);
+        phase_pf(vs, c0, std::integral_constant<int, 0>(), true, xs + XSF, vs + VSF, bA, bB, c0, 1);      // next first use -> bB
+        plane_store(xs, c0, ld, ok);
+        __syncthreads();
+        plane_loads(c0, 3, ld, ok);
+        phase_pf(vs + VSF, c0, std::integral_constant<int, 1>(), true, xs, vs, bB, bA, c0, 2);                // second use in bA, next first -> bB
+        plane_store(xs + XSF, c0, ld, ok);
+        __syncthreads();
+        if (more) plane_loads(c0 + KC, 0, ld, ok);
+        phase_pf(vs, c0, std::integral_constant<int, 2>(), true, xs + XSF, vs + VSF, bB, bA, c0, 3);      // second use in bA, next first -> bB
+        if (more) plane_store(xs, c0 + KC, ld, ok);
+        __syncthreads();
+        if (more) plane_loads(c0 + KC, 1, ld, ok);
+        phase_pf(vs + VSF, c0, std::integral_constant<int, 3>(), more, xs, vs, bB, bA, c0 + KC, more ? 0 : -1);      // next chunk's first use -> bA
+        if (more) plane_store(xs + XSF, c0 + KC, ld, ok);
+        __syncthreads();
+        continue;
+      }
       // phase (c0, 0): MFMA plane 0 | transform plane 1 | loads of plane 2
       plane_loads(c0, 2, ld, ok);
       phase(vs, c0, std::integral_constant<int, 0>(), true, xs + XSF, vs + VSF);
@@ -436,11 +496,12 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   const dim3 grid((unsigned)blocks), blk(256);
   const char* pe = getenv("MI355_WINO_PIPE");                  // A/B switches, read per call (tests flip them); default: pipelined
   const bool pipe = !(pe && pe[0] == '0');
-  const char* be_ = getenv("MI355_WINO_BEARLY");               // weights first, transform under their latency (default off until measured)
-  const bool bearly = be_ && be_[0] == '1';
+  const char* be_ = getenv("MI355_WINO_BMODE");                // weights: 0 at their use | 1 first, transform under their latency | 2 a phase ahead
+  const int bmode = be_ ? (be_[0] == '1' ? 1 : be_[0] == '0' ? 0 : 2) : 2;      // default: 2 (never measured: the ISA of 0 stalls on them)
 #define WINO_LAUNCH(IM, FU)                                                                         \
-  do { if (pipe && bearly) LAUNCH((conv3d_wino2d<IM, FU, true, true>), grid, blk, 0, stream, a);   \
-       else if (pipe) LAUNCH((conv3d_wino2d<IM, FU, true>), grid, blk, 0, stream, a);              \
+  do { if (pipe && bmode == 2) LAUNCH((conv3d_wino2d<IM, FU, true, 2>), grid, blk, 0, stream, a); \
+       else if (pipe && bmode == 1) LAUNCH((conv3d_wino2d<IM, FU, true, 1>), grid, blk, 0, stream, a); \
+       else if (pipe) LAUNCH((conv3d_wino2d<IM, FU, true, 0>), grid, blk, 0, stream, a);           \
        else LAUNCH((conv3d_wino2d<IM, FU, false>), grid, blk, 0, stream, a); } while (0)
   if (a.g.mom) {
     if (d->in_mode == MI355_IN_PLAIN) WINO_LAUNCH(MI355_IN_PLAIN, 1); else WINO_LAUNCH(MI355_IN_AFFINE_ACT, 1);

@@ -10,11 +10,12 @@ from oracle import torch_ops as O
 ops = C.ops
 
 
-@pytest.fixture(autouse=True, params=[("1", "0"), ("1", "1"), ("0", "0")], ids=["pipelined", "pipelined-weights-first", "three-barrier"])
+@pytest.fixture(autouse=True, params=[("1", "2"), ("1", "0"), ("1", "1"), ("0", "0")],
+                ids=["pipelined-weights-ahead", "pipelined", "pipelined-weights-first", "three-barrier"])
 def wino_variant(request, monkeypatch):
-    """the main-loop forms of the kernel (MI355_WINO_PIPE / MI355_WINO_BEARLY, read by the library at every call)"""
+    """the main-loop forms of the kernels (MI355_WINO_PIPE / MI355_WINO_BMODE, read by the library at every call)"""
     monkeypatch.setenv("MI355_WINO_PIPE", request.param[0])
-    monkeypatch.setenv("MI355_WINO_BEARLY", request.param[1])
+    monkeypatch.setenv("MI355_WINO_BMODE", request.param[1])
 
 
 @pytest.mark.parametrize("kw", [

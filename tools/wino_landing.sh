@@ -6,10 +6,12 @@ tag=${1:-wino}; out=gpurun_out/$tag; mkdir -p $out
 timeout 900 python -m pytest tests/test_wino_gpu.py -q -m gpu > $out/tests.txt 2>&1; tail -3 $out/tests.txt
 # 2. forward / dgrad per layer: direct kernel vs the three Winograd loop forms
 MI355_WINOGRAD=0 python tools/bench_conv_layers.py > $out/layers_direct.txt 2>&1
-MI355_WINOGRAD=1 MI355_WINO_PIPE=1 MI355_WINO_BEARLY=0 python tools/bench_conv_layers.py > $out/layers_wino_pipe.txt 2>&1
-MI355_WINOGRAD=1 MI355_WINO_PIPE=1 MI355_WINO_BEARLY=1 python tools/bench_conv_layers.py > $out/layers_wino_bearly.txt 2>&1
+MI355_WINOGRAD=1 MI355_WINO_PIPE=1 MI355_WINO_BMODE=2 python tools/bench_conv_layers.py > $out/layers_wino_b2.txt 2>&1      # weights one use ahead (default)
+MI355_WINOGRAD=1 MI355_WINO_PIPE=1 MI355_WINO_BMODE=0 python tools/bench_conv_layers.py > $out/layers_wino_b0.txt 2>&1      # the form measured in round 2
+MI355_WINOGRAD=1 MI355_WINO_PIPE=1 MI355_WINO_BMODE=1 python tools/bench_conv_layers.py > $out/layers_wino_b1.txt 2>&1      # weights first, transform under their latency
 MI355_WINOGRAD=1 MI355_WINO_PIPE=0 python tools/bench_conv_layers.py > $out/layers_wino_3barrier.txt 2>&1
-paste $out/layers_direct.txt $out/layers_wino_pipe.txt $out/layers_wino_bearly.txt $out/layers_wino_3barrier.txt | grep -E "k3|sum" | cut -c1-50,85-100,135-150,185-200
+echo "layer | direct | wino BMODE 2 | BMODE 0 | BMODE 1 | three-barrier"
+paste $out/layers_direct.txt $out/layers_wino_b2.txt $out/layers_wino_b0.txt $out/layers_wino_b1.txt $out/layers_wino_3barrier.txt | grep -E "k3|sum" | cut -c1-50,85-100,135-150,185-200,235-250
 # 3. weight gradient per layer: ring kernel vs Winograd (pipelined / three-barrier)
 for c in "32 32 128" "64 64 64" "128 128 32" "256 256 16" "64 32 128"; do
   for v in "0 1" "1 1" "1 0"; do set -- $v
