@@ -1,0 +1,906 @@
+// 3x3x3 stride-1 conv3d forward / dgrad in exact-type fp32 with FEWER multiplications: Winograd F(2x2, 3x3) in the (y, x) plane,
+// direct along z. PREPARED ON THE CPU EMULATOR, NOT YET MEASURED ON AN MI355X (tools/NEXT.md "The one algorithmic lever left").
+//
+// Same op as conv3d_fwd.hip (reference: unet3d/models/pytorch/classification/resnet.py:12-22 called from myronenko.py:17-21; the
+// GroupNorm-apply + ReLU prologue and the bias / residual / Dropout3d-scale epilogue are fused the same way). Arithmetic per output
+// voxel and (ci, co): 16 transform points per 2x2 outputs x 3 z-taps = 12 multiplications instead of 27. Numerics: the transform
+// matrices have entries 0, +-1, +-1/2; measured on the CPU (tools/winograd_probe.py) the fp32 result is as close to an fp64
+// convolution as the direct fp32 kernel's (max error 3e-7 .. 9e-7 of max |y|).
+//
+//   input transform   V = B^T d B    (4x4 input window d of one channel, B^T rows: d0-d2, d1+d2, d2-d1, d1-d3)
+//   filter transform  U = G g G^T    (3x3 (dy,dx) slice g of one (co, ci, dz), done once per optimizer step by the pack kernel)
+//   point-wise        M[p] = sum_{ci, dz} V[p][plane z + dz - 1][ci] * U[p][dz][ci][co]          <- the MFMA work, p = 0..15
+//   output transform  Y = A^T M A    (2x2 outputs, A^T rows: m0+m1+m2, m1-m2-m3)
+//
+// Workgroup = 256 threads = 4 waves; output tile = 2 z-planes x 8 (y) x 16 (x) voxels = per plane 4 x 8 = 32 Winograd tiles of 2x2 = the
+// M dimension of one 32x32 MFMA tile; N = 32 output channels; K = 8 input channels per LDS chunk (one float4 per k-half, exactly the
+// operand scheme of conv3d_mfma: lane l supplies A[tile = l & 31][k = l >> 5], four MFMAs per float4). A workgroup walks the 4 input
+// planes its 2 output planes see; every input plane is staged (haloed 10 x 18 voxels, normalised + activated on the way in), transformed
+// ONCE into the 16 points (32 additions per (tile, channel)) and used by the 1-2 (output plane, dz) pairs that see it. Wave w owns the
+// points (i = w, j = 0..3) of both output planes: 8 accumulator tiles = 128 registers. The output transform contracts j inside the wave
+// and i across the waves through LDS.
+#include "hipcompat.h"
+#include <type_traits>
+#include <cstdlib>
+#include "../../include/mi355_unet3d.h"
+#include "gn_fuse.h"
+
+struct WinoArgs {
+  const float* x; int xld;
+  const float* up;                       // transformed weights [(p * 3 + dz)][ciP / 4][coP][4]
+  float* y; int yld;
+  const float* res; int resld;
+  const float* in_scale; const float* in_shift; float slope; const float* in_slope;
+  const float* out_chscale; const float* bias;
+  int N, D, H, W, Cin, CinP, Cout, CoutP;
+  int tilesZ, tilesY, tilesX, coTiles;
+  GnFuseArgs g;                          // norm statistics fused into the epilogue (gn_fuse.h), as in conv3d_mfma
+};
+
+// FUSE: 0 plain epilogue, 1 + moment records of the output, 2 + norm-backward sums (dgrad): as conv3d_mfma
+// PIPE: software-pipelined main loop (one barrier per input plane: the MFMAs of plane k share the instruction stream with the transform
+// of plane k + 1, the global loads of plane k + 2 are in flight) instead of stage / barrier / transform / barrier / MFMA / barrier.
+// BMODE 1 (with PIPE): the phase's weight fragments are requested first, the transform of the next plane runs under their latency, then
+// the MFMAs -- instead of MFMAs (weights requested at their use) followed by the transform.
+// BMODE 2 (with PIPE): the weight fragments of a phase's FIRST (output plane, dz) use are requested during the previous phase, those of its
+// second use at its start (they arrive under the first use's MFMAs): the ISA of BMODE 0 shows every phase opening with a wait for its weights.
+template <int INMODE, int FUSE = 0, bool PIPE = false, int BMODE = 0>
+__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_wino2d(WinoArgs a) {      // 128 accumulator registers + <= 128 others
+  constexpr int TZ = 2, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HV = HY * HX;      // output tile; haloed input plane
+  constexpr int KC = 8;                  // input channels per chunk
+  constexpr int XS = 12;                 // floats per staged voxel (8 + 4 pad: the transform's strided reads stay conflict-free)
+  constexpr int NT = 32;                 // Winograd tiles per plane (4 x 8 of 2x2 outputs)
+  constexpr int XSF = HV * XS + 16, VSF = 16 * NT * KC;          // floats per staged plane (16-byte aligned) / per transformed plane
+  constexpr int LDSF = PIPE ? 2 * (XSF + VSF) : 8192;           // PIPE: two of each (49 KB); else xs | vs in 32 KB; later zs [4][2][32][32]
+  static_assert(LDSF >= 8192, "the output transform exchanges 4 x 2 x 32 x 32 floats through LDS");
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  float* xs = lds;
+  float* vs = lds + (PIPE ? 2 : 1) * XSF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+  int b = blockIdx.x;
+  const int cot = b % a.coTiles; b /= a.coTiles;
+  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+  const int tz0 = (b % a.tilesZ) * TZ; b /= a.tilesZ;
+  const int n = b;
+  const int co_base = cot * 32;
+
+  f32x16 acc[TZ][4];
+#pragma unroll
+  for (int oz = 0; oz < TZ; ++oz)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[oz][j][r] = 0.f;
+
+  const float4* up4 = reinterpret_cast<const float4*>(a.up);
+  const int CQ = a.CinP / 4;
+  // staging: a thread owns (halo voxel, channel quad) units; 2 quads per voxel
+  // transform: thread (tile t = tid >> 3, channel c = tid & 7)
+  const int tt = tid >> 3, tc = tid & 7;
+  const int tty = tt >> 3, ttx = tt & 7;
+
+  if constexpr (PIPE) {
+    // phase k = (channel chunk, input plane pz): planes of a chunk are unrolled (pz, hence the (output plane, dz) pairs and the buffer
+    // parity, are compile-time); the phase after (c0, 3) is (c0 + KC, 0)
+    auto plane_loads = [&](int c0_, int pz_, float4 (&ld)[2], bool (&ok)[2]) {
+      const int iz = tz0 - 1 + pz_;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        int u = tid + 256 * k;
+        const bool act = u < HV * 2;
+        if (!act) u = 0;
+        const int hv = u >> 1, q = u & 1;
+        const int iy = ty0 - 1 + hv / HX, ix = tx0 - 1 + hv % HX;
+        const int c = c0_ + 4 * q;
+        ok[k] = act && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin;
+        const int izc = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1), iyc = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1), ixc = ix < 0 ? 0 : (ix < a.W ? ix : a.W - 1);
+        ld[k] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + izc) * a.H + iyc) * a.W + ixc) * a.xld + (c < a.Cin ? c : 0));
+      }
+    };
+    auto plane_store = [&](float* xsb, int c0_, const float4 (&ld)[2], const bool (&ok)[2]) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int u = tid + 256 * k;
+        if (u >= HV * 2) continue;
+        const int hv = u >> 1, q = u & 1, c = c0_ + 4 * q;
+        float4 v = ld[k];
+        if (INMODE == MI355_IN_AFFINE_ACT && ok[k]) {
+          const float4 sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
+          const float4 sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
+          float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
+          if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + c);
+          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+          v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
+        }
+        if (!ok[k]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(xsb + hv * XS + 4 * q) = v;
+      }
+    };
+    auto transform = [&](const float* xsb, float* vsb) {
+      float t[4][4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {          // one window column at a time: 4 values live instead of 16
+        const float* col = xsb + ((2 * tty) * HX + 2 * ttx + s2) * XS + tc;
+        const float d0 = col[0], d1 = col[HX * XS], d2 = col[2 * HX * XS], d3 = col[3 * HX * XS];
+        t[0][s2] = d0 - d2; t[1][s2] = d1 + d2; t[2][s2] = d2 - d1; t[3][s2] = d1 - d3;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vsb[((4 * i + 0) * NT + tt) * KC + tc] = t[i][0] - t[i][2];
+        vsb[((4 * i + 1) * NT + tt) * KC + tc] = t[i][1] + t[i][2];
+        vsb[((4 * i + 2) * NT + tt) * KC + tc] = t[i][2] - t[i][1];
+        vsb[((4 * i + 3) * NT + tt) * KC + tc] = t[i][1] - t[i][3];
+      }
+    };
+    auto b_loads = [&](float4 (&bfr)[TZ][4], int c0_, auto pzc) {
+      constexpr int PZ = decltype(pzc)::value;
+#pragma unroll
+      for (int oz = 0; oz < TZ; ++oz) {
+        const int dz = PZ - oz;
+        if (dz < 0 || dz > 2) continue;          // compile-time after unrolling
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          bfr[oz][j] = up4[((size_t)((4 * wave + j) * 3 + dz) * CQ + c0_ / 4 + half) * a.CoutP + co_base + li];
+      }
+    };
+    auto mfma_run = [&](const float* vsb, const float4 (&bfr)[TZ][4], auto pzc) {
+      constexpr int PZ = decltype(pzc)::value;
+#pragma unroll
+      for (int oz = 0; oz < TZ; ++oz) {
+        const int dz = PZ - oz;
+        if (dz < 0 || dz > 2) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 af = *reinterpret_cast<const float4*>(vsb + ((4 * wave + j) * NT + li) * KC + 4 * half);
+          acc[oz][j] = MFMA_32x32x2(af.x, bfr[oz][j].x, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.y, bfr[oz][j].y, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.z, bfr[oz][j].z, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.w, bfr[oz][j].w, acc[oz][j]);
+        }
+      }
+    };
+    // one phase: MFMAs of the plane in `vcur`, transform of the next plane `xnext` -> `vnext` (if any), in the order BEARLY selects
+    auto phase = [&](const float* vcur, int c0_, auto pzc, bool has_next, const float* xnext, float* vnext) {
+      float4 bfr[TZ][4];
+      b_loads(bfr, c0_, pzc);
+      if constexpr (BMODE == 1) {
+        if (has_next) transform(xnext, vnext);
+        SCHED_BARRIER();
+        mfma_run(vcur, bfr, pzc);
+      } else {
+        mfma_run(vcur, bfr, pzc);
+        if (has_next) transform(xnext, vnext);
+      }
+    };
+    // BMODE 2. First use of phase pz: output plane 0 (dz = pz) for pz = 0..2, output plane 1 (dz = 2) for pz = 3; second use (pz = 1, 2):
+    // output plane 1 with dz = pz - 1.
+    auto b_use = [&](float4 (&bu)[4], int c0_, int dz) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bu[j] = up4[((size_t)((4 * wave + j) * 3 + dz) * CQ + c0_ / 4 + half) * a.CoutP + co_base + li];
+    };
+    auto mfma_use = [&](const float* vsb, const float4 (&bu)[4], f32x16 (&ac)[4]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 af = *reinterpret_cast<const float4*>(vsb + ((4 * wave + j) * NT + li) * KC + 4 * half);
+        ac[j] = MFMA_32x32x2(af.x, bu[j].x, ac[j]);
+        ac[j] = MFMA_32x32x2(af.y, bu[j].y, ac[j]);
+        ac[j] = MFMA_32x32x2(af.z, bu[j].z, ac[j]);
+        ac[j] = MFMA_32x32x2(af.w, bu[j].w, ac[j]);
+      }
+    };
+    // Two fragment sets, each requested one USE ahead. Single-use phases (pz = 0, 3): first use from bx, the next phase's first use is
+    // requested into by. Two-use phases (pz = 1, 2): first use from bx, second use requested into by at the start, the next phase's first
+    // use into bx once the first use's MFMAs have consumed it. (c0n, pzn): the next phase; pzn < 0: none.
+    auto phase_pf = [&](const float* vcur, int c0_, auto pzc, bool has_next, const float* xnext, float* vnext,
+                        float4 (&bx)[4], float4 (&by)[4], int c0n, int pzn) {
+      constexpr int PZ = decltype(pzc)::value;
+      const int dzn = pzn == 3 ? 2 : pzn;
+      if constexpr (PZ == 1 || PZ == 2) {
+        b_use(by, c0_, PZ - 1);
+        SCHED_BARRIER();
+        mfma_use(vcur, bx, acc[0]);
+        if (has_next) transform(xnext, vnext);
+        if (pzn >= 0) b_use(bx, c0n, dzn);
+        SCHED_BARRIER();
+        mfma_use(vcur, by, acc[1]);
+      } else {
+        if (pzn >= 0) b_use(by, c0n, dzn);
+        SCHED_BARRIER();
+        mfma_use(vcur, bx, acc[PZ == 3 ? 1 : 0]);
+        if (has_next) transform(xnext, vnext);
+      }
+    };
+    float4 ld[2];
+    bool ok[2];
+    // prologue: plane (0, 0) staged and transformed, plane (0, 1) staged
+    plane_loads(0, 0, ld, ok);
+    plane_store(xs, 0, ld, ok);
+    plane_loads(0, 1, ld, ok);
+    __syncthreads();
+    transform(xs, vs);
+    plane_store(xs + XSF, 0, ld, ok);
+    __syncthreads();
+    float4 bA[4], bB[4];
+    if constexpr (BMODE == 2) b_use(bA, 0, 0);                   // first use of phase (0, 0)
+    for (int c0 = 0; c0 < a.CinP; c0 += KC) {
+      const bool more = c0 + KC < a.CinP;                 // another chunk follows (workgroup-uniform)
+      if constexpr (BMODE == 2) {
+        plane_loads(c0, 2, ld, ok);
+        phase_pf(vs, c0, std::integral_constant<int, 0>(), true, xs + XSF, vs + VSF, bA, bB, c0, 1);      // next first use -> bB
+        plane_store(xs, c0, ld, ok);
+        __syncthreads();
+        plane_loads(c0, 3, ld, ok);
+        phase_pf(vs + VSF, c0, std::integral_constant<int, 1>(), true, xs, vs, bB, bA, c0, 2);                // second use in bA, next first -> bB
+        plane_store(xs + XSF, c0, ld, ok);
+        __syncthreads();
+        if (more) plane_loads(c0 + KC, 0, ld, ok);
+        phase_pf(vs, c0, std::integral_constant<int, 2>(), true, xs + XSF, vs + VSF, bB, bA, c0, 3);      // second use in bA, next first -> bB
+        if (more) plane_store(xs, c0 + KC, ld, ok);
+        __syncthreads();
+        if (more) plane_loads(c0 + KC, 1, ld, ok);
+        phase_pf(vs + VSF, c0, std::integral_constant<int, 3>(), more, xs, vs, bB, bA, c0 + KC, more ? 0 : -1);      // next chunk's first use -> bA
+        if (more) plane_store(xs + XSF, c0 + KC, ld, ok);
+        __syncthreads();
+        continue;
+      }
+      // phase (c0, 0): MFMA plane 0 | transform plane 1 | loads of plane 2
+      plane_loads(c0, 2, ld, ok);
+      phase(vs, c0, std::integral_constant<int, 0>(), true, xs + XSF, vs + VSF);
+      plane_store(xs, c0, ld, ok);
+      __syncthreads();
+      // phase (c0, 1): MFMA plane 1 | transform plane 2 | loads of plane 3
+      plane_loads(c0, 3, ld, ok);
+      phase(vs + VSF, c0, std::integral_constant<int, 1>(), true, xs, vs);
+      plane_store(xs + XSF, c0, ld, ok);
+      __syncthreads();
+      // phase (c0, 2): MFMA plane 2 | transform plane 3 | loads of the next chunk's plane 0
+      if (more) plane_loads(c0 + KC, 0, ld, ok);
+      phase(vs, c0, std::integral_constant<int, 2>(), true, xs + XSF, vs + VSF);
+      if (more) plane_store(xs, c0 + KC, ld, ok);
+      __syncthreads();
+      // phase (c0, 3): MFMA plane 3 | transform of the next chunk's plane 0 | loads of its plane 1
+      if (more) plane_loads(c0 + KC, 1, ld, ok);
+      phase(vs + VSF, c0, std::integral_constant<int, 3>(), more, xs, vs);
+      if (more) plane_store(xs + XSF, c0 + KC, ld, ok);
+      __syncthreads();
+    }
+  } else {
+  for (int c0 = 0; c0 < a.CinP; c0 += KC) {
+    for (int pz = 0; pz < TZ + 2; ++pz) {
+      const int iz = tz0 - 1 + pz;
+      __syncthreads();                   // the previous plane's MFMAs are done with vs, its transform with xs
+      // ---- stage the haloed input plane iz, channels [c0, c0 + 8) ----
+      for (int u = tid; u < HV * 2; u += 256) {
+        const int hv = u >> 1, q = u & 1;
+        const int hy = hv / HX, hx = hv % HX;
+        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+        const int c = c0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin) {
+          v = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + c);
+          if (INMODE == MI355_IN_AFFINE_ACT) {
+            const float4 sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
+            const float4 sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
+            float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
+            if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + c);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
+          }
+        }
+        *reinterpret_cast<float4*>(xs + hv * XS + 4 * q) = v;
+      }
+      __syncthreads();
+      // ---- input transform: V = B^T d B of the 4x4 window of tile (tty, ttx), channel tc ----
+      {
+        float d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) d[r][s] = xs[((2 * tty + r) * HX + 2 * ttx + s) * XS + tc];
+        float t[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {          // rows: B^T d
+          t[0][s] = d[0][s] - d[2][s]; t[1][s] = d[1][s] + d[2][s]; t[2][s] = d[2][s] - d[1][s]; t[3][s] = d[1][s] - d[3][s];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {          // columns: (B^T d) B
+          const float v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3];
+          vs[((4 * i + 0) * NT + tt) * KC + tc] = v0;
+          vs[((4 * i + 1) * NT + tt) * KC + tc] = v1;
+          vs[((4 * i + 2) * NT + tt) * KC + tc] = v2;
+          vs[((4 * i + 3) * NT + tt) * KC + tc] = v3;
+        }
+      }
+      __syncthreads();
+      // ---- point-wise products: wave w owns points (w, 0..3); this input plane serves output plane oz with z-tap dz = pz - oz ----
+#pragma unroll
+      for (int oz = 0; oz < TZ; ++oz) {
+        const int dz = pz - oz;
+        if (dz < 0 || dz > 2) continue;        // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int p = 4 * wave + j;
+          const float4 af = *reinterpret_cast<const float4*>(vs + (p * NT + li) * KC + 4 * half);
+          const float4 bf = up4[((size_t)(p * 3 + dz) * CQ + c0 / 4 + half) * a.CoutP + co_base + li];
+          acc[oz][j] = MFMA_32x32x2(af.x, bf.x, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.y, bf.y, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.z, bf.z, acc[oz][j]);
+          acc[oz][j] = MFMA_32x32x2(af.w, bf.w, acc[oz][j]);
+        }
+      }
+    }
+  }
+  }
+
+  // ---- output transform Y = A^T M A, bias / residual / dropout scale, store ----
+  // inside the wave: Z[b] = sum_j A^T[b][j] M[w][j];  across the waves (LDS): Y[a][b] = sum_i A^T[a][i] Z_i[b];  wave w' then owns (a, b) = (w' >> 1, w' & 1)
+  float* zs = lds;                        // [i = wave][b][tile 32][co 32]
+  const int oa = wave >> 1, ob = wave & 1;
+  const int co = co_base + li;
+  const bool cov = co < a.Cout;
+  float bs = 0.f, cs = 1.f;
+  if (cov && a.bias) bs = a.bias[co];
+  if (cov && a.out_chscale) cs = a.out_chscale[(size_t)n * a.Cout + co];
+  // FUSE 1: one-pass moments about K0 = the lane's first stored value; FUSE 2: sum du, sum du * xhat (gn_fuse.h)
+  float K0 = 0.f, s0 = 0.f, s1 = 0.f, gsc = 1.f, gsh = 0.f, gmean = 0.f, grstd = 1.f;
+  int cnt = 0;
+  if constexpr (FUSE == 2) {
+    const int coc = cov ? co : a.Cout - 1;
+    const int grp = coc / (a.Cout / a.g.ggroups);
+    gsc = a.g.gscale[(size_t)n * a.Cout + coc]; gsh = a.g.gshift[(size_t)n * a.Cout + coc];
+    gmean = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
+  }
+#pragma unroll
+  for (int oz = 0; oz < TZ; ++oz) {
+    __syncthreads();                      // every wave is done with vs / the previous plane's zs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;      // tile index of accumulator register r
+      const float m0 = acc[oz][0][r], m1 = acc[oz][1][r], m2 = acc[oz][2][r], m3 = acc[oz][3][r];
+      zs[((wave * 2 + 0) * 32 + row) * 32 + li] = m0 + m1 + m2;
+      zs[((wave * 2 + 1) * 32 + row) * 32 + li] = m1 - m2 - m3;
+    }
+    __syncthreads();
+    const int z = tz0 + oz;
+    // FUSE 2: the 16 reads of the normalised tensor go out first, from clamped (always valid) addresses (conv3d_fwd.hip: inside the
+    // loop every one of them is a dependent round trip behind the stores -- the first GPU measurement showed exactly that)
+    float gxv[16];
+    if constexpr (FUSE == 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        int yy = ty0 + 2 * (row >> 3) + oa, xx = tx0 + 2 * (row & 7) + ob, zc = z;
+        zc = zc < a.D ? zc : a.D - 1; yy = yy < a.H ? yy : a.H - 1; xx = xx < a.W ? xx : a.W - 1;
+        gxv[r] = a.g.gx[((((size_t)n * a.D + zc) * a.H + yy) * a.W + xx) * a.g.gxld + (cov ? co : a.Cout - 1)];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float z0 = zs[((0 * 2 + ob) * 32 + row) * 32 + li], z1 = zs[((1 * 2 + ob) * 32 + row) * 32 + li];
+      const float z2 = zs[((2 * 2 + ob) * 32 + row) * 32 + li], z3 = zs[((3 * 2 + ob) * 32 + row) * 32 + li];
+      float v = (oa == 0 ? z0 + z1 + z2 : z1 - z2 - z3) + bs;
+      const int yy = ty0 + 2 * (row >> 3) + oa, xx = tx0 + 2 * (row & 7) + ob;
+      if (!cov || z >= a.D || yy >= a.H || xx >= a.W) continue;
+      const size_t vox = (((size_t)n * a.D + z) * a.H + yy) * a.W + xx;
+      if (a.res) v += a.res[vox * a.resld + co];
+      v *= cs;
+      a.y[vox * a.yld + co] = v;
+      if constexpr (FUSE == 1) {
+        if (cnt == 0) K0 = v;
+        const float t = v - K0;
+        s0 += t; s1 += t * t;
+        ++cnt;
+      } else if constexpr (FUSE == 2) {
+        const float xv = gxv[r];
+        const float u = xv * gsc + gsh;
+        const float du = u > 0.f ? v : v * a.g.gslope;
+        s0 += du; s1 += du * ((xv - gmean) * grstd);
+      }
+    }
+  }
+  if constexpr (FUSE != 0) {
+    // wave w' holds the (a, b) = (w' >> 1, w' & 1) outputs of every tile: the four waves are the "WM" waves of gn_fuse_reduce_store
+    constexpr int K = FUSE == 1 ? 3 : 2;
+    float vals[1][K];
+    if constexpr (FUSE == 1) {
+      const float c = (float)cnt;
+      const float m2 = cnt > 0 ? s1 - s0 * s0 / c : 0.f;
+      vals[0][0] = c; vals[0][1] = s0 + c * K0; vals[0][2] = m2 > 0.f ? m2 : 0.f;
+    } else {
+      vals[0][0] = s0; vals[0][1] = s1;
+    }
+    const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
+    const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
+    float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * K;
+    gn_fuse_reduce_store<K, 1, 4, 1>(vals, lds, wave, 0, half, li, tid, dst, co_base, a.Cout);
+  }
+}
+
+// ---- filter transform: U[(i,j)][dz][ci][co] = sum_{dy,dx} G[i][dy] G[j][dx] w[...], G rows: g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2 ----
+// mode 0: forward, w OIDHW [cout][cin][3][3][3]. mode 1: dgrad of Conv3d: roles swapped ("out" = ci, "in" = co), all three taps flipped.
+__global__ void wino_pack_weight_kernel(const float* w, float* up, int cout, int cin, int coutP, int cinP, int mode) {
+  const size_t total = (size_t)48 * (cinP / 4) * coutP * 4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int e = idx & 3;
+    size_t r = idx >> 2;
+    const int o = r % coutP; r /= coutP;
+    const int iq = r % (cinP / 4); r /= (cinP / 4);
+    const int pd = (int)r, p = pd / 3, dz = pd % 3;
+    const int pi = p >> 2, pj = p & 3;
+    const int i = iq * 4 + e;
+    float v = 0.f;
+    if (o < cout && i < cin) {
+      float g[3][3];
+      for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx)
+          g[dy][dx] = mode == 0 ? w[((size_t)o * cin + i) * 27 + (dz * 3 + dy) * 3 + dx]
+                                : w[((size_t)i * cout + o) * 27 + ((2 - dz) * 3 + (2 - dy)) * 3 + (2 - dx)];      // w[co = i][ci = o], flipped
+      float t[3];                           // row pi of G applied along dy
+      for (int dx = 0; dx < 3; ++dx)
+        t[dx] = pi == 0 ? g[0][dx] : pi == 1 ? 0.5f * (g[0][dx] + g[1][dx] + g[2][dx]) : pi == 2 ? 0.5f * (g[0][dx] - g[1][dx] + g[2][dx]) : g[2][dx];
+      v = pj == 0 ? t[0] : pj == 1 ? 0.5f * (t[0] + t[1] + t[2]) : pj == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2];
+    }
+    up[idx] = v;
+  }
+}
+
+extern "C" size_t mi355_wino_weight_elems(int32_t cout, int32_t cin) {
+  if (cout <= 0 || cin <= 0) return 0;
+  const size_t coutP = (cout + 31) / 32 * 32, cinP = (cin + 7) / 8 * 8;
+  return (size_t)48 * cinP * coutP;
+}
+
+extern "C" int mi355_wino_pack_weight(const float* w, float* up, int32_t cout, int32_t cin, int32_t mode, void* stream) {
+  if (!w || !up || cout <= 0 || cin <= 0 || mode < 0 || mode > 1) return MI355_EINVAL;
+  const int coutP = (cout + 31) / 32 * 32, cinP = (cin + 7) / 8 * 8;     // logical packed dims: cout = "out", cin = "in" of THIS conv
+  const size_t total = (size_t)48 * cinP * coutP;
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  LAUNCH(wino_pack_weight_kernel, dim3(grid), dim3(256), 0, stream, w, up, cout, cin, coutP, cinP, mode);
+  return LAUNCH_CHECK();
+}
+
+// x, y: NDHWC activations of the same extent; up: mi355_wino_pack_weight of the [y->c][x->c] (mode 0) weights; desc: kd 3, stride 1, pad 1,
+// plain / norm-prologue input, plain un-windowed output; bias, residual, out_chscale as in mi355_conv3d_fwd.
+extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
+  if (!x || !y || !up || !d || !x->p || !y->p) return MI355_EINVAL;
+  if (d->kd != 3 || d->stride != 1 || d->pad != 1 || d->out_mode != MI355_OUT_PLAIN) return MI355_EUNSUPPORTED;
+  if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
+  if (d->off_z || d->off_y || d->off_x || d->out_d != y->d || d->out_h != y->h || d->out_w != y->w) return MI355_EUNSUPPORTED;
+  if (x->d != y->d || x->h != y->h || x->w != y->w || x->n != y->n) return MI355_EINVAL;
+  if (x->c % 4 || x->ld % 4 || x->ld < x->c || y->ld < y->c || ((uintptr_t)x->p & 15) || ((uintptr_t)up & 15)) return MI355_EINVAL;
+  if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift || !(d->act_slope >= 0.f && d->act_slope <= 1.f))) return MI355_EINVAL;
+  if (d->residual && d->residual_ld < y->c) return MI355_EINVAL;
+  WinoArgs a;
+  memset(&a.g, 0, sizeof(a.g));
+  if (d->moments_out && d->gn_bwd) return MI355_EUNSUPPORTED;
+  a.g.mom = d->moments_out;
+  if (d->gn_bwd) {
+    const mi355_gn_bwd_fuse* f = d->gn_bwd;
+    if (d->in_mode != MI355_IN_PLAIN) return MI355_EUNSUPPORTED;
+    if (!f->gx || !f->scale || !f->shift || !f->mean_rstd || !f->partials_out || f->groups <= 0 || y->c % f->groups || f->gx_ld < y->c) return MI355_EINVAL;
+    a.g.gnb = f->partials_out; a.g.gx = f->gx; a.g.gxld = f->gx_ld; a.g.gscale = f->scale; a.g.gshift = f->shift; a.g.gmr = f->mean_rstd;
+    a.g.ggroups = f->groups; a.g.gslope = f->act_slope;
+  }
+  a.x = (const float*)x->p; a.xld = x->ld; a.up = up; a.y = (float*)y->p; a.yld = y->ld;
+  a.res = d->residual; a.resld = d->residual_ld;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope;
+  a.out_chscale = d->out_chscale; a.bias = d->bias;
+  a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cin = x->c; a.CinP = (x->c + 7) / 8 * 8;
+  a.Cout = y->c; a.CoutP = (y->c + 31) / 32 * 32;
+  a.tilesZ = ceil_div(a.D, 2); a.tilesY = ceil_div(a.H, 8); a.tilesX = ceil_div(a.W, 16); a.coTiles = a.CoutP / 32;
+  const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
+  const dim3 grid((unsigned)blocks), blk(256);
+  const char* pe = getenv("MI355_WINO_PIPE");                  // A/B switches, read per call (tests flip them); default: pipelined
+  const bool pipe = !(pe && pe[0] == '0');
+  const char* be_ = getenv("MI355_WINO_BMODE");                // weights: 0 at their use | 1 first, transform under their latency | 2 a phase ahead
+  const int bmode = be_ ? (be_[0] == '1' ? 1 : be_[0] == '0' ? 0 : 2) : 2;      // default: 2 (never measured: the ISA of 0 stalls on them)
+#define WINO_LAUNCH(IM, FU)                                                                         \
+  do { if (pipe && bmode == 2) LAUNCH((conv3d_wino2d<IM, FU, true, 2>), grid, blk, 0, stream, a); \
+       else if (pipe && bmode == 1) LAUNCH((conv3d_wino2d<IM, FU, true, 1>), grid, blk, 0, stream, a); \
+       else if (pipe) LAUNCH((conv3d_wino2d<IM, FU, true, 0>), grid, blk, 0, stream, a);           \
+       else LAUNCH((conv3d_wino2d<IM, FU, false>), grid, blk, 0, stream, a); } while (0)
+  if (a.g.mom) {
+    if (d->in_mode == MI355_IN_PLAIN) WINO_LAUNCH(MI355_IN_PLAIN, 1); else WINO_LAUNCH(MI355_IN_AFFINE_ACT, 1);
+  } else if (a.g.gnb) {
+    WINO_LAUNCH(MI355_IN_PLAIN, 2);
+  } else if (d->in_mode == MI355_IN_PLAIN) WINO_LAUNCH(MI355_IN_PLAIN, 0);
+  else WINO_LAUNCH(MI355_IN_AFFINE_ACT, 0);
+#undef WINO_LAUNCH
+  return LAUNCH_CHECK();
+}
+
+// spatial tiles (= epilogue records per sample) of this kernel's 2 x 8 x 16 tiling
+extern "C" int32_t mi355_conv3d_wino_stats_blocks(const mi355_act* y) {
+  if (!y) return 0;
+  const long long b = (long long)ceil_div(y->d, 2) * ceil_div(y->h, 8) * ceil_div(y->w, 16);
+  return b > 0 && b <= 0x7fffffffLL ? (int32_t)b : 0;
+}
+
+// =====================================================================================================================================
+// Weight gradient in the same Winograd domain: F(3x3, 2x2) in the (y, x) plane, direct along z. PREPARED ON THE EMULATOR, first version
+// (three barriers per step, no pipelining).
+//   dw[co][ci][dz][a][b] = sum_{n, z, tiles} sum_{i,j<2} dy[z][2ty+i][2tx+j][co] * in(x)[z+dz-1][2ty+i+a-1][2tx+j+b-1][ci]
+//                        = G^T [ sum_{n, z, tiles} (A h A^T) (.) (B^T d B) ] G        per (co, ci, dz)
+// with h the 2x2 dy tile, d the 4x4 input window of the SAME tile (the forward kernel's window), B^T as in the forward kernel,
+// A = [[1,0],[1,1],[1,-1],[0,-1]] and G^T = [[1,1/2,1/2,0],[0,1/2,-1/2,0],[0,1/2,1/2,1]] (the F(2,3) output / filter transforms with their
+// roles exchanged; checked against the direct sum in double). 16 multiplications per tile and (ci, co, dz) instead of 4 x 9 = 36.
+// Workgroup = 512 threads = 8 waves for one (32 co x 32 ci pair, dz, split): per step one 8x8-voxel plane tile (16 Winograd tiles = the K
+// dimension of 8 MFMAs per point); wave w owns points 2w, 2w + 1 (two 32x32 accumulator tiles). Partial results go to the slab workspace
+// of conv3d_wgrad.hip ([pair][slab][tap][32 co][32 ci]) and are reduced by its deterministic second pass.
+int mi355_wgrad_reduce_launch(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles, void* stream);
+
+struct WinoWArgs {
+  const float* x; int xld;
+  const float* dy; int dyld;
+  float* ws;
+  const float* in_scale; const float* in_shift; float slope; const float* in_slope;
+  int N, D, H, W, Cin, Cout;
+  int tilesY, tilesX, ntiles;            // plane tiles: index = ((n * D + z) * tilesY + ty) * tilesX + tx
+  int splits, ciTiles, coTiles;
+};
+
+template <int INMODE>
+__global__ __launch_bounds__(512) void conv3d_wino2d_wgrad(WinoWArgs a) {
+  constexpr int TY = 8, TX = 8, HY = 10, HX = 10, HV = HY * HX, XS = 36, TS = 16;
+  constexpr int XSF = HV * XS, DSF = 64 * XS, VF = 16 * 32 * TS;
+  constexpr int LDSF = XSF + DSF + 2 * VF;                       // 22288 floats = 87 KB (>= 16384: the output transform's exchange)
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  float* xs = lds; float* dss = lds + XSF; float* V = dss + DSF; float* Dv = V + VF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+  const int split = blockIdx.x, pair = blockIdx.y, dz = blockIdx.z;
+  const int cot = pair / a.ciTiles, cit = pair % a.ciTiles;
+  const int ci0 = cit * 32, co0 = cot * 32;
+  const int per = (a.ntiles + a.splits - 1) / a.splits;
+  const int t_begin = split * per, t_end = t_begin + per < a.ntiles ? t_begin + per : a.ntiles;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  const int tt = tid >> 5, tc = tid & 31;                        // transform: (Winograd tile 0..15, channel 0..31)
+  const int tty = tt >> 2, ttx = tt & 3;
+
+  for (int pt = t_begin; pt < t_end; ++pt) {
+    int b = pt;
+    const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+    const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+    const int z = b % a.D, n = b / a.D;
+    const int iz = z + dz - 1;
+    if (iz < 0 || iz >= a.D) continue;                           // the input plane is padding: no contribution (workgroup-uniform)
+    __syncthreads();
+    // ---- stage the haloed input plane tile (32 channels) and the dy plane tile (32 channels) ----
+    for (int u = tid; u < HV * 8; u += 512) {
+      const int hv = u >> 3, q = u & 7;
+      const int iy = ty0 - 1 + hv / HX, ix = tx0 - 1 + hv % HX;
+      const int c = ci0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin) {
+        v = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + c);
+        if (INMODE == MI355_IN_AFFINE_ACT) {
+          const float4 sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
+          const float4 sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
+          float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
+          if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + c);
+          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+          v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
+        }
+      }
+      *reinterpret_cast<float4*>(xs + hv * XS + 4 * q) = v;
+    }
+    {
+      const int vv = tid >> 3, q = tid & 7;                      // 64 voxels x 8 channel quads = 512 units
+      const int yy = ty0 + (vv >> 3), xx = tx0 + (vv & 7);
+      const int c = co0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (yy < a.H && xx < a.W && c < a.Cout) {
+        const float* p = a.dy + ((((size_t)n * a.D + z) * a.H + yy) * a.W + xx) * a.dyld + c;
+        // dy channel counts need not be multiples of 4 beyond Cout: guarded element-wise
+        v.x = p[0];
+        if (c + 1 < a.Cout) v.y = p[1];
+        if (c + 2 < a.Cout) v.z = p[2];
+        if (c + 3 < a.Cout) v.w = p[3];
+      }
+      *reinterpret_cast<float4*>(dss + vv * XS + 4 * q) = v;
+    }
+    __syncthreads();
+    // ---- transforms: V = B^T d B (input window of tile tt, channel tc), Dv = A h A^T (dy tile tt, channel tc) ----
+    {
+      float d[4][4], t[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) d[r][s] = xs[((2 * tty + r) * HX + 2 * ttx + s) * XS + tc];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        t[0][s] = d[0][s] - d[2][s]; t[1][s] = d[1][s] + d[2][s]; t[2][s] = d[2][s] - d[1][s]; t[3][s] = d[1][s] - d[3][s];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        V[((4 * i + 0) * TS + tt) * 32 + tc] = t[i][0] - t[i][2];
+        V[((4 * i + 1) * TS + tt) * 32 + tc] = t[i][1] + t[i][2];
+        V[((4 * i + 2) * TS + tt) * 32 + tc] = t[i][2] - t[i][1];
+        V[((4 * i + 3) * TS + tt) * 32 + tc] = t[i][1] - t[i][3];
+      }
+      const float h00 = dss[((2 * tty) * TX + 2 * ttx) * XS + tc], h01 = dss[((2 * tty) * TX + 2 * ttx + 1) * XS + tc];
+      const float h10 = dss[((2 * tty + 1) * TX + 2 * ttx) * XS + tc], h11 = dss[((2 * tty + 1) * TX + 2 * ttx + 1) * XS + tc];
+      // rows: A h -> (h0., h0. + h1., h0. - h1., -h1.), then the same along the columns
+      const float r0[2] = {h00, h01}, r1[2] = {h00 + h10, h01 + h11}, r2[2] = {h00 - h10, h01 - h11}, r3[2] = {-h10, -h11};
+      const float* rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Dv[((4 * i + 0) * TS + tt) * 32 + tc] = rr[i][0];
+        Dv[((4 * i + 1) * TS + tt) * 32 + tc] = rr[i][0] + rr[i][1];
+        Dv[((4 * i + 2) * TS + tt) * 32 + tc] = rr[i][0] - rr[i][1];
+        Dv[((4 * i + 3) * TS + tt) * 32 + tc] = -rr[i][1];
+      }
+    }
+    __syncthreads();
+    // ---- point-wise products over the 16 tiles: acc[co][ci] += Dv[p][co][t] * V[p][ci][t] ----
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = 2 * wave + q;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        // [point][tile][channel] layout: the transform writes and these reads are both 32 consecutive floats per instruction
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int t = 8 * kg + 4 * half + e;
+          acc[q] = MFMA_32x32x2(Dv[(p * TS + t) * 32 + li], V[(p * TS + t) * 32 + li], acc[q]);
+        }
+      }
+    }
+  }
+
+  // ---- output transform: taps[a][b] = sum_{i,j} G^T[a][i] G^T[b][j] M[4i + j], through LDS; slab write ----
+  __syncthreads();
+  float* Ms = lds;                                               // [16 points][32 co][32 ci]
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;         // co
+      Ms[((2 * wave + q) * 32 + row) * 32 + li] = acc[q][r];
+    }
+  __syncthreads();
+  const float GT[3][4] = {{1.f, 0.5f, 0.5f, 0.f}, {0.f, 0.5f, -0.5f, 0.f}, {0.f, 0.5f, 0.5f, 1.f}};
+  float* slab = a.ws + (((size_t)pair * a.splits + split) * 27 + dz * 9) * 1024;
+  for (int idx = tid; idx < 9 * 1024; idx += 512) {
+    const int tap = idx >> 10, e = idx & 1023;
+    const int ta = tap / 3, tb = tap % 3;
+    float o = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o += GT[ta][i] * GT[tb][j] * Ms[(4 * i + j) * 1024 + e];
+    slab[(size_t)tap * 1024 + e] = o;
+  }
+}
+
+// Software-pipelined form of the same kernel: the 16 points are split into two halves (rows i = 0,1 and i = 2,3 of the point grid); wave w
+// owns point w of each half. While the MFMAs of one half run, the other half of the same / the next plane tile is transformed into the
+// other buffer, and the global loads of the tile after next are in flight: two barriers per plane tile, none of them waiting for memory.
+template <int INMODE>
+__global__ __launch_bounds__(512) void conv3d_wino2d_wgrad_pipe(WinoWArgs a) {
+  constexpr int TY = 8, TX = 8, HX = 10, HV = 100, XS = 36, TS = 16;
+  constexpr int XSF = HV * XS, DSF = 64 * XS, HF = 8 * 32 * TS;  // one staged x tile, one staged dy tile, one half of V or Dv
+  constexpr int LDSF = 2 * (XSF + DSF) + 4 * HF;                 // 28192 floats = 110 KB
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  auto xsb_ = [&](int i) { return lds + i * (XSF + DSF); };                      // staged tile buffer i: x tile, then the dy tile
+  auto vh_ = [&](int h) { return lds + 2 * (XSF + DSF) + h * 2 * HF; };          // half h: V, then Dv
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+  const int split = blockIdx.x, pair = blockIdx.y, dz = blockIdx.z;
+  const int cot = pair / a.ciTiles, cit = pair % a.ciTiles;
+  const int ci0 = cit * 32, co0 = cot * 32;
+  const int per = (a.ntiles + a.splits - 1) / a.splits;
+  const int t_begin = split * per, t_end = t_begin + per < a.ntiles ? t_begin + per : a.ntiles;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  const int tt = tid >> 5, tc = tid & 31, tty = tt >> 2, ttx = tt & 3;
+
+  // plane tiles whose input plane z + dz - 1 is padding contribute nothing: the walk skips them (workgroup-uniform)
+  auto next_valid = [&](int pt) {
+    while (pt < t_end) {
+      const int z = (pt / (a.tilesX * a.tilesY)) % a.D, iz = z + dz - 1;
+      if (iz >= 0 && iz < a.D) break;
+      ++pt;
+    }
+    return pt;
+  };
+  struct Staged { float4 x[2]; float4 d; };
+  auto tile_loads = [&](int pt, Staged& st) {
+    int b = pt;
+    const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+    const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+    const int z = b % a.D, n = b / a.D, iz = z + dz - 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int u = tid + 512 * k;
+      st.x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u >= HV * 8) continue;
+      const int hv = u >> 3, q = u & 7;
+      const int iy = ty0 - 1 + hv / HX, ix = tx0 - 1 + hv % HX, c = ci0 + 4 * q;
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin) {
+        float4 v = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + c);
+        if (INMODE == MI355_IN_AFFINE_ACT) {
+          const float4 sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
+          const float4 sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
+          float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
+          if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + c);
+          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+          v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
+        }
+        st.x[k] = v;
+      }
+    }
+    {
+      const int vv = tid >> 3, q = tid & 7;
+      const int yy = ty0 + (vv >> 3), xx = tx0 + (vv & 7), c = co0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (yy < a.H && xx < a.W && c < a.Cout) {
+        const float* p = a.dy + ((((size_t)n * a.D + z) * a.H + yy) * a.W + xx) * a.dyld + c;
+        v.x = p[0];
+        if (c + 1 < a.Cout) v.y = p[1];
+        if (c + 2 < a.Cout) v.z = p[2];
+        if (c + 3 < a.Cout) v.w = p[3];
+      }
+      st.d = v;
+    }
+  };
+  auto tile_store = [&](float* buf, const Staged& st) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int u = tid + 512 * k;
+      if (u >= HV * 8) continue;
+      *reinterpret_cast<float4*>(buf + (u >> 3) * XS + 4 * (u & 7)) = st.x[k];
+    }
+    *reinterpret_cast<float4*>(buf + XSF + (tid >> 3) * XS + 4 * (tid & 7)) = st.d;
+  };
+  // transform the point rows i = 2 * hsel, 2 * hsel + 1 of tile (tty, ttx), channel tc, from the staged tile `buf` into half buffer `vh`
+  auto transform_half = [&](const float* buf, float* vh, int hsel) {
+    float d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) d[r][s2] = buf[((2 * tty + r) * HX + 2 * ttx + s2) * XS + tc];
+    const float* ds = buf + XSF;
+    const float h00 = ds[((2 * tty) * TX + 2 * ttx) * XS + tc], h01 = ds[((2 * tty) * TX + 2 * ttx + 1) * XS + tc];
+    const float h10 = ds[((2 * tty + 1) * TX + 2 * ttx) * XS + tc], h11 = ds[((2 * tty + 1) * TX + 2 * ttx + 1) * XS + tc];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int i = 2 * hsel + ii;                               // hsel is workgroup-uniform
+      float t[4], r[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+        t[s2] = i == 0 ? d[0][s2] - d[2][s2] : i == 1 ? d[1][s2] + d[2][s2] : i == 2 ? d[2][s2] - d[1][s2] : d[1][s2] - d[3][s2];
+      r[0] = i == 0 ? h00 : i == 1 ? h00 + h10 : i == 2 ? h00 - h10 : -h10;
+      r[1] = i == 0 ? h01 : i == 1 ? h01 + h11 : i == 2 ? h01 - h11 : -h11;
+      float* vp = vh + ((4 * ii) * TS + tt) * 32 + tc;          // [point][tile][channel]: 32 consecutive floats per write instruction
+      vp[0 * 32 * TS] = t[0] - t[2]; vp[1 * 32 * TS] = t[1] + t[2]; vp[2 * 32 * TS] = t[2] - t[1]; vp[3 * 32 * TS] = t[1] - t[3];
+      float* dp = vh + HF + ((4 * ii) * TS + tt) * 32 + tc;
+      dp[0 * 32 * TS] = r[0]; dp[1 * 32 * TS] = r[0] + r[1]; dp[2 * 32 * TS] = r[0] - r[1]; dp[3 * 32 * TS] = -r[1];
+    }
+  };
+  auto mfma_half = [&](const float* vh, f32x16& ac) {           // this wave's point of the half: local index `wave`
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int t = 8 * kg + 4 * half + e;
+        ac = MFMA_32x32x2(vh[HF + (wave * TS + t) * 32 + li], vh[(wave * TS + t) * 32 + li], ac);
+      }
+    }
+  };
+
+  Staged st;
+  int p0 = next_valid(t_begin);
+  if (p0 < t_end) {
+    int p1 = next_valid(p0 + 1);
+    // prologue: tile 0 staged and its first half transformed, tile 1 staged
+    tile_loads(p0, st); tile_store(xsb_(0), st);
+    if (p1 < t_end) { tile_loads(p1, st); tile_store(xsb_(1), st); }
+    __syncthreads();
+    transform_half(xsb_(0), vh_(0), 0);
+    __syncthreads();
+    int cur = 0;                                                 // parity of the staged buffer holding the current tile
+    int pk = p0, pk1 = p1;
+    while (pk < t_end) {
+      const int pk2 = pk1 < t_end ? next_valid(pk1 + 1) : t_end;
+      // phase A: MFMA half 0 of the tile | transform its half 1
+      mfma_half(vh_(0), acc[0]);
+      transform_half(xsb_(cur), vh_(1), 1);
+      __syncthreads();
+      // phase B: MFMA half 1 | transform half 0 of the next tile | stage the tile after next into this tile's buffer
+      if (pk2 < t_end) tile_loads(pk2, st);
+      mfma_half(vh_(1), acc[1]);
+      if (pk1 < t_end) transform_half(xsb_(cur ^ 1), vh_(0), 0);
+      if (pk2 < t_end) tile_store(xsb_(cur), st);
+      __syncthreads();
+      pk = pk1; pk1 = pk2; cur ^= 1;
+    }
+  }
+
+  // ---- output transform through LDS (point of half h, wave w: p = 8 h + w) and slab write: as the three-barrier kernel ----
+  __syncthreads();
+  float* Ms = lds;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      Ms[((8 * q + wave) * 32 + row) * 32 + li] = acc[q][r];
+    }
+  __syncthreads();
+  const float GT[3][4] = {{1.f, 0.5f, 0.5f, 0.f}, {0.f, 0.5f, -0.5f, 0.f}, {0.f, 0.5f, 0.5f, 1.f}};
+  float* slab = a.ws + (((size_t)pair * a.splits + split) * 27 + dz * 9) * 1024;
+  for (int idx = tid; idx < 9 * 1024; idx += 512) {
+    const int tap = idx >> 10, e = idx & 1023;
+    const int ta = tap / 3, tb = tap % 3;
+    float o = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o += GT[ta][i] * GT[tb][j] * Ms[(4 * i + j) * 1024 + e];
+    slab[(size_t)tap * 1024 + e] = o;
+  }
+}
+
+struct WinoWPlan { int tilesY, tilesX, ntiles, splits, ciTiles, coTiles; size_t ws_bytes; int ok; };
+static WinoWPlan plan_wino_wgrad(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  WinoWPlan p; memset(&p, 0, sizeof(p));
+  if (!x || !dy || !d || d->kd != 3 || d->stride != 1 || d->pad != 1 || d->out_mode != MI355_OUT_PLAIN) return p;
+  if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return p;
+  if (x->d != dy->d || x->h != dy->h || x->w != dy->w || x->n != dy->n || x->c % 4 || x->ld % 4) return p;
+  p.tilesY = ceil_div(dy->h, 8); p.tilesX = ceil_div(dy->w, 8);
+  const long long nt = (long long)dy->n * dy->d * p.tilesY * p.tilesX;
+  if (nt <= 0 || nt > 0x7fffffffLL) return p;
+  p.ntiles = (int)nt;
+  p.ciTiles = ceil_div(x->c, 32); p.coTiles = ceil_div(dy->c, 32);
+  const int pairs = p.ciTiles * p.coTiles;
+  int splits = ceil_div(256, 3 * pairs);                          // one 512-thread workgroup per CU: ~256 workgroups in flight
+  const int max_splits = p.ntiles >= 16 ? p.ntiles / 16 : 1;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int per = ceil_div(p.ntiles, splits);
+  p.splits = ceil_div(p.ntiles, per);
+  p.ws_bytes = (size_t)pairs * p.splits * 27 * 1024 * sizeof(float);
+  p.ok = 1;
+  return p;
+}
+
+extern "C" size_t mi355_conv3d_wino_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  const WinoWPlan p = plan_wino_wgrad(x, dy, d);
+  return p.ok ? p.ws_bytes : 0;
+}
+
+// dw: OIDHW [dy->c][x->c][3][3][3]; same contract as mi355_conv3d_wgrad for kd 3 / stride 1 / pad 1 (norm prologue on x honoured)
+extern "C" int mi355_conv3d_wino_wgrad(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d, void* ws, size_t ws_bytes,
+                                       void* stream) {
+  if (!x || !dy || !dw || !d || !ws || !x->p || !dy->p) return MI355_EINVAL;
+  const WinoWPlan p = plan_wino_wgrad(x, dy, d);
+  if (!p.ok) return MI355_EUNSUPPORTED;
+  if (ws_bytes < p.ws_bytes) return MI355_EWORKSPACE;
+  if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift || !(d->act_slope >= 0.f && d->act_slope <= 1.f))) return MI355_EINVAL;
+  WinoWArgs a;
+  a.x = (const float*)x->p; a.xld = x->ld; a.dy = (const float*)dy->p; a.dyld = dy->ld; a.ws = (float*)ws;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope;
+  a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Cout = dy->c;
+  a.tilesY = p.tilesY; a.tilesX = p.tilesX; a.ntiles = p.ntiles; a.splits = p.splits; a.ciTiles = p.ciTiles; a.coTiles = p.coTiles;
+  const dim3 grid(p.splits, p.ciTiles * p.coTiles, 3);
+  const char* pe = getenv("MI355_WINO_PIPE");                  // same A/B switch as the forward kernel; default: pipelined
+  if (!(pe && pe[0] == '0')) {
+    if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wino2d_wgrad_pipe<MI355_IN_PLAIN>), grid, dim3(512), 0, stream, a);
+    else LAUNCH((conv3d_wino2d_wgrad_pipe<MI355_IN_AFFINE_ACT>), grid, dim3(512), 0, stream, a);
+  } else if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wino2d_wgrad<MI355_IN_PLAIN>), grid, dim3(512), 0, stream, a);
+  else LAUNCH((conv3d_wino2d_wgrad<MI355_IN_AFFINE_ACT>), grid, dim3(512), 0, stream, a);
+  const int rc = LAUNCH_CHECK(); if (rc) return rc;
+  return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, p.splits, p.ciTiles, stream);
+}

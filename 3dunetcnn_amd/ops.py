@@ -102,6 +102,12 @@ class PackedWeight:
             self._bf16[precision] = out
         return self._bf16[precision]
 
+    def wino(self):
+        """Winograd-domain weights of a 3x3x3 kernel (csrc/conv3d_wino.hip), packed on first use."""
+        if getattr(self, "_wino", None) is None:
+            self._wino = self.be.wino_pack_weight(self.w, self.mode)
+        return self._wino
+
     def ptr_for(self, desc):
         if (self.mode == 0 and self.cin == 4 and self.kd == 3 and desc.stride == 1 and desc.pad == 1 and desc.out_mode == OUT_PLAIN
                 and desc.in_mode in (IN_PLAIN, IN_AFFINE_ACT)):
@@ -118,6 +124,11 @@ class PackedWeight:
 
 
 class Backend:
+    # the one measurement so far (profiles/r2_winograd_prep_measurement.txt): no gain on the 16^3 level (256 channels), 16-36 % above it
+    WINO_MIN_VOXELS = 32 ** 3
+    # executed / algorithmic multiplications of the Winograd kernels (bench.py reports both rates)
+    WINO_EXECUTED = {"conv3d_wino2d": 12.0 / 27.0, "conv3d_wino2d_wgrad (+reduce)": 16.0 / 36.0}
+
     def __init__(self, lib=None, device=None):
         self.lib = lib if lib is not None else _lib.load_library()
         if device is None:
@@ -127,6 +138,11 @@ class Backend:
         self.device = torch.device(device)
         self._ws_by_stream = {}     # launch stream handle -> workspace tensor: kernels of different streams must not share scratch
         self.precision = PREC_F32   # arithmetic of the 3x3x3 stride-1 convs: see set_precision()
+        # EXPERIMENT SWITCH (prepared on the emulator, not yet measured): MI355_WINOGRAD=1 routes the eligible fp32 3x3x3 stride-1
+        # forward / dgrad convolutions to the Winograd kernel
+        self.winograd = os.environ.get("MI355_WINOGRAD", "0") == "1"
+        self.winograd_wgrad = os.environ.get("MI355_WINOGRAD_WGRAD", "0") == "1"      # the weight gradients too (first version, never measured)
+
         self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
         # norm statistics leave with the producing conv's epilogue (csrc/gn_fuse.h). False: every statistic is a standalone pass
         # over the tensor again (the round-1 form; kept as the cross-check of the fused path, tests/test_ops_gpu.py)
@@ -191,6 +207,12 @@ class Backend:
         pad = kd // 2 if pad is None else pad
         if out_dhw is None:
             out_dhw = x.shape[1:4] if out_mode == OUT_D2S else y.shape[1:4]
+        if (self.winograd and self.precision == PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT)
+                and out_mode == OUT_PLAIN and tuple(off) == (0, 0, 0) and tuple(out_dhw) == tuple(y.shape[1:4]) and wp.mode in (0, 1)
+                and wp.cin >= 8 and wp.cout >= 8 and x.shape[1:4] == y.shape[1:4]
+                and x.shape[1] * x.shape[2] * x.shape[3] >= self.WINO_MIN_VOXELS):
+            return self.conv_fwd_wino(x, wp.wino(), y, in_mode=in_mode, slope=slope, scale=scale, shift=shift, bias=bias, residual=residual,
+                                      chscale=chscale, in_slope=in_slope, moments=moments, gnb=gnb)
         keep = []
         d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep, in_slope, out_mode)
         xd, yd = x.desc(), y.desc()
@@ -233,6 +255,46 @@ class Backend:
         self.prof.append((name.value.decode(), flops, byts, e0, e1))
         return self._fold_after(y, gparts)
 
+    # -- Winograd form of the 3x3x3 stride-1 conv (csrc/conv3d_wino.hip): prepared, not yet measured, not used by the modules ----------
+    def wino_pack_weight(self, w, mode=0):
+        """w OIDHW [cout, cin, 3, 3, 3] -> transformed weights for conv_fwd_wino (mode 0: forward; mode 1: dgrad, i.e. a conv from
+        cout to cin channels)."""
+        cout, cin = (w.shape[0], w.shape[1]) if mode == 0 else (w.shape[1], w.shape[0])
+        up = torch.empty(self.lib.mi355_wino_weight_elems(cout, cin), dtype=torch.float32, device=self.device)
+        check(self.lib.mi355_wino_pack_weight(w.contiguous().data_ptr(), up.data_ptr(), cout, cin, mode, self.stream()), "wino_pack_weight")
+        return up
+
+    def conv_fwd_wino(self, x, up, y, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, bias=None, residual=None, chscale=None,
+                      in_slope=None, moments=False, gnb=None):
+        """Same contract as conv_fwd for a 3x3x3 stride-1 conv (moments / gnb: the fused statistics of the epilogue)."""
+        keep = []
+        d = self._desc(3, 1, 1, in_mode, slope, scale, shift, bias, residual, chscale, (0, 0, 0), y.shape[1:4], keep, in_slope, OUT_PLAIN)
+        xd, yd = x.desc(), y.desc()
+        y.mom = None
+        gparts = None
+        if self.fused_stats and (moments or gnb is not None):
+            nb = self.lib.mi355_conv3d_wino_stats_blocks(ctypes.byref(yd))
+            if moments:
+                rec = torch.empty(x.shape[0], nb, y.c, 3, dtype=torch.float32, device=self.device)
+                d.moments_out = rec.data_ptr()
+                y.mom = [(rec, nb, y.c)]
+            elif in_mode == IN_PLAIN:
+                gx, st, groups, gslope = gnb
+                rec = torch.empty(x.shape[0], nb, y.c, 2, dtype=torch.float32, device=self.device)
+                fuse = MiGnBwdFuse(gx.ptr(), gx.ld, st[1].data_ptr(), st[2].data_ptr(), st[0].data_ptr(), groups, gslope, rec.data_ptr())
+                d.gn_bwd = ctypes.pointer(fuse)
+                keep.extend([fuse, gx, st])
+                gparts = (rec, nb)
+        if self.prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(self.lib.mi355_conv3d_wino_fwd(ctypes.byref(xd), up.data_ptr(), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_wino_fwd")
+        if self.prof is not None:
+            e1.record()
+            nvox = y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3]
+            self.prof.append(("conv3d_wino2d", 2.0 * nvox * x.c * y.c * 27, 4.0 * (nvox * (x.c + y.c) + 27 * x.c * y.c), e0, e1))
+        return self._fold_after(y, gparts)
+
     def _fold_after(self, y, gparts):
         if y.mom is not None:
             rec, nb, c = y.mom[0]
@@ -250,6 +312,23 @@ class Backend:
         d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, None, None, None, (0, 0, 0),
                        x.shape[1:4] if out_mode == OUT_D2S else dy.shape[1:4], keep, in_slope, out_mode)
         xd, dyd = x.desc(), dy.desc()
+        if (self.winograd_wgrad and self.precision == PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT)
+                and out_mode == OUT_PLAIN and x.c >= 8 and dy.c >= 8 and x.shape[1] * x.shape[2] * x.shape[3] >= self.WINO_MIN_VOXELS):
+            nbytes = self.lib.mi355_conv3d_wino_wgrad_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))
+            if nbytes:
+                ws = self.ws(nbytes)
+                assert dw.is_contiguous()
+                if self.prof is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                check(self.lib.mi355_conv3d_wino_wgrad(ctypes.byref(xd), ctypes.byref(dyd), dw.data_ptr(), ctypes.byref(d), ws.data_ptr(),
+                                                       ws.numel() * 4, self.stream()), "conv3d_wino_wgrad")
+                if self.prof is not None:
+                    e1.record()
+                    nvox = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3]
+                    self.prof.append(("conv3d_wino2d_wgrad (+reduce)", 2.0 * nvox * x.c * dy.c * 27,
+                                      4.0 * (nvox * (x.c + dy.c) + 27 * x.c * dy.c), e0, e1))
+                return
         nbytes = self.lib.mi355_conv3d_wgrad_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))
         if nbytes == 0:
             raise RuntimeError("conv3d_wgrad: unsupported configuration")

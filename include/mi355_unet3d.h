@@ -282,6 +282,21 @@ int mi355_zscore(const float* x, float* y, int32_t c, int64_t voxels, void* ws, 
 int mi355_resample_affine(const float* src, float* dst, int32_t c, int32_t sd, int32_t sh, int32_t sw, int32_t dd, int32_t dh,
                           int32_t dw, const float* m, int32_t mode, int32_t padding, void* stream);
 
+/* ---- Winograd F(2x2, 3x3) x direct-z form of the 3x3x3 stride-1 convolution (csrc/conv3d_wino.hip) --------------------------------
+ * PREPARED ON THE CPU EMULATOR, NOT YET MEASURED ON HARDWARE: not used by the Python modules. Same operation as mi355_conv3d_fwd for
+ * kd 3 / stride 1 / pad 1, plain or norm-prologue input, plain un-windowed output (bias, residual, out_chscale and the fused statistics
+ * honoured), fp32, 12 instead of 27 multiplications per output and (ci, co). Weights: mi355_wino_pack_weight (mode 0 forward,
+ * mode 1 dgrad of Conv3d, as mi355_pack_conv_weight) into mi355_wino_weight_elems(cout, cin) floats. */
+size_t mi355_wino_weight_elems(int32_t cout, int32_t cin);
+int mi355_wino_pack_weight(const float* w, float* up, int32_t cout, int32_t cin, int32_t mode, void* stream);
+int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const mi355_act* y, const mi355_conv_desc* desc, void* stream);
+/* records per sample its fused-statistics epilogues (desc->moments_out / desc->gn_bwd, formats of gn_fuse.h) write: 2 x 8 x 16 voxel tiles */
+int32_t mi355_conv3d_wino_stats_blocks(const mi355_act* y);
+/* weight gradient in the same domain (F(3x3, 2x2) x direct z): contract of mi355_conv3d_wgrad for kd 3 / stride 1 / pad 1 */
+size_t mi355_conv3d_wino_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* desc);
+int mi355_conv3d_wino_wgrad(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* desc, void* ws, size_t ws_bytes,
+                            void* stream);
+
 /* ---- Dice loss -------------------------------------------------------------------------------- */
 /* monai.losses.DiceLoss as configured by examples/brats2020/brats2020_config.json:112-116 (sigmoid=True,
  * include_background=True, smooth_nr=smooth_dr=1e-5, reduction="mean"), plus `batch` and `squared_pred`.

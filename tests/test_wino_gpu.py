@@ -1,0 +1,182 @@
+"""GPU twins of tests/test_wino_emu.py: the Winograd kernels through the C ABI on an MI355X (same cases, same tolerances).
+Generated from that file: keep the two in step. Never run on hardware yet."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import op_cases as C
+from oracle import torch_ops as O
+
+ops = C.ops
+
+
+@pytest.fixture(autouse=True, params=[("1", "2"), ("1", "0"), ("1", "1"), ("0", "0")],
+                ids=["pipelined-weights-ahead", "pipelined", "pipelined-weights-first", "three-barrier"])
+def wino_variant(request, monkeypatch):
+    """the main-loop forms of the kernels (MI355_WINO_PIPE / MI355_WINO_BMODE, read by the library at every call)"""
+    monkeypatch.setenv("MI355_WINO_PIPE", request.param[0])
+    monkeypatch.setenv("MI355_WINO_BMODE", request.param[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=8, cout=32, dhw=(2, 8, 16)),                                   # exactly one tile
+    dict(n=2, cin=32, cout=32, dhw=(4, 8, 16), bias=True),                       # two z tiles, four channel chunks
+    dict(n=1, cin=16, cout=64, dhw=(3, 9, 19), norm=True, residual=True, chscale=True),      # ragged in every axis, two channel tiles
+    dict(n=1, cin=12, cout=40, dhw=(5, 6, 7), norm=True, slope=0.01, bias=True),  # partial channel chunk and tile
+])
+def test_wino_forward_matches_conv3d(hip_backend, kw):
+    be = hip_backend
+    n, cin, cout, dhw = kw["n"], kw["cin"], kw["cout"], kw["dhw"]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, cin, *dhw, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, 3, generator=g) * (1.0 / (cin * 27) ** 0.5)
+    normspec = gamma = beta = None
+    if kw.get("norm"):
+        groups = 4
+        gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+        normspec = (groups, gamma, beta, 1e-5, kw.get("slope", 0.0))
+    b = torch.randn(cout, generator=g) if kw.get("bias") else None
+    res = torch.randn(n, cout, *dhw, generator=g) if kw.get("residual") else None
+    cs = (torch.rand(n, cout, generator=g) > 0.3).float() * 1.25 if kw.get("chscale") else None
+    ref = O.conv_block(x, wt, 1, 1, normspec, b, res, cs)
+    xa, ya = C.to_act(be, x), C.to_act(be, torch.zeros_like(ref))
+    up = be.wino_pack_weight(wt, 0)
+    extra = {}
+    if normspec:
+        mr, sc, sh = be.gn_stats(xa, normspec[0], 1e-5, gamma, beta)
+        extra = dict(in_mode=ops.IN_AFFINE_ACT, slope=normspec[4], scale=sc, shift=sh)
+    be.conv_fwd_wino(xa, up, ya, bias=b, residual=C.to_act(be, res) if res is not None else None, chscale=cs, **extra)
+    assert C.rel_err(C.from_act(ya), ref) < 1e-5
+
+
+@pytest.mark.gpu
+def test_wino_dgrad_pack_matches_autograd(hip_backend):
+    be = hip_backend
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 16, 4, 8, 16, generator=g, requires_grad=True)
+    wt = torch.randn(32, 16, 3, 3, 3, generator=g) * 0.05
+    y = F.conv3d(x, wt, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    dya, dxa = C.to_act(be, dy), C.to_act(be, torch.zeros_like(x.detach()))
+    be.conv_fwd_wino(dya, be.wino_pack_weight(wt, 1), dxa)
+    assert C.rel_err(C.from_act(dxa), dx_ref) < 1e-5
+
+
+class _WinoBackend:
+    """The emulator backend with its 3x3x3 stride-1 convolutions redirected to the Winograd kernel, so that the shared op cases
+    (tests/op_cases.py: epilogue fusions, concat slices, fused statistics) run against it unchanged."""
+    def __init__(self, be):
+        self._be = be
+        self.wino_calls = 0
+
+    def __getattr__(self, name):
+        return getattr(self._be, name)
+
+    def pack_weight(self, w, mode, *a, **k):
+        if w.shape[2:] == (3, 3, 3) and mode in (0, 1):
+            return ("wino", self._be.wino_pack_weight(w, mode), self._be.pack_weight(w, mode, *a, **k))
+        return self._be.pack_weight(w, mode, *a, **k)
+
+    def conv_fwd(self, x, wp, y, kd, stride=1, pad=None, **kw):
+        if isinstance(wp, tuple):
+            if kd == 3 and stride == 1 and kw.get("off", (0, 0, 0)) == (0, 0, 0) and kw.get("in_mode", ops.IN_PLAIN) in (ops.IN_PLAIN, ops.IN_AFFINE_ACT):
+                kw.pop("off", None); kw.pop("out_dhw", None)
+                self.wino_calls += 1
+                return self._be.conv_fwd_wino(x, wp[1], y, **kw)
+            wp = wp[2]
+        return self._be.conv_fwd(x, wp, y, kd, stride, pad, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=32, cout=32, dhw=(3, 5, 19), norm=True, residual=True, chscale=True),
+    dict(n=1, cin=8, cout=64, dhw=(4, 4, 16), norm=True, yld=128, yc0=32),                   # concat slice of a wider buffer
+    dict(n=2, cin=4, cout=32, dhw=(3, 4, 17), bias=True),
+    dict(n=1, cin=48, cout=40, dhw=(2, 6, 9), norm=True, slope=0.01),
+])
+def test_wino_shared_forward_cases(hip_backend, kw):
+    be = _WinoBackend(hip_backend)
+    assert C.case_conv_fwd(be, **kw) < 1e-5
+    assert be.wino_calls == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=64, dhw=(3, 4, 18)), dict(n=2, cin=64, cout=32, dhw=(4, 4, 16))])
+def test_wino_shared_dgrad_cases(hip_backend, kw):
+    assert C.case_conv_dgrad(_WinoBackend(hip_backend), **kw) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=32, cout=32, dhw=(3, 5, 19), residual=True, chscale=True),
+    dict(n=1, cin=16, cout=64, dhw=(4, 8, 16), yld=128, yc0=32),
+    dict(n=2, cin=16, cout=40, dhw=(2, 6, 9), groups_out=40),
+])
+def test_wino_epilogue_moments(hip_backend, kw):
+    assert C.case_conv_moments(_WinoBackend(hip_backend), **kw) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(3, 5, 19)), dict(n=2, cin=64, cout=16, dhw=(4, 4, 16), slope=0.01)])
+def test_wino_norm_backward_sums_from_dgrad_epilogue(hip_backend, kw):
+    be = _WinoBackend(hip_backend)
+    r = C.case_gn_bwd_fused(be, **kw)
+    assert all(v < 2e-4 for v in r.values()), r
+    assert be.wino_calls == 1
+
+
+@pytest.mark.gpu
+def test_whole_network_step_on_the_winograd_kernels(hip_backend):
+    """MI355_WINOGRAD + MI355_WINOGRAD_WGRAD switches: every eligible 3x3x3 stride-1 forward / dgrad / wgrad conv of a UNet3D step on the
+    Winograd kernels, against the golden bundle generated from the reference."""
+    import importlib
+    import os
+    unet = importlib.import_module("3dunetcnn_amd.unet")
+    losses = importlib.import_module("3dunetcnn_amd.losses")
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet3d_small.pt"))
+    be = hip_backend
+    be.winograd = be.winograd_wgrad = True
+    be.WINO_MIN_VOXELS = 0                 # the golden bundle is 20 x 16 x 24: route every level
+    calls = {"n": 0}
+    orig = be.conv_fwd_wino
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    be.conv_fwd_wino = counted
+    try:
+        m = unet.HipUNet3D(**g["kwargs"]).cuda().eval()
+        m.load_state_dict(g["state_dict"])
+        crit = losses.HipDiceLoss(sigmoid=True)
+        out = m(g["x"].cuda())
+        loss = crit(out, g["y"].cuda())
+        loss.backward()
+    finally:
+        be.winograd = be.winograd_wgrad = False
+        del be.conv_fwd_wino, be.WINO_MIN_VOXELS
+    assert calls["n"] >= 20
+    assert C.rel_err(out, g["logits"]) < 1e-3
+    assert abs(float(loss.detach()) - float(g["loss"])) / float(g["loss"]) < 1e-3
+    for k, p in m.named_parameters():
+        assert C.rel_err(p.grad, g["grads"][k]) < 1e-3, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(n=2, cin=32, cout=32, dhw=(3, 8, 8), norm=True),
+    dict(n=1, cin=8, cout=64, dhw=(4, 9, 17)),                                   # ragged plane tiles, two co tiles
+    dict(n=1, cin=40, cout=96, dhw=(5, 3, 7), norm=True, slope=0.01),            # partial channel tiles
+    dict(n=2, cin=32, cout=32, dhw=(5, 16, 32), norm=True),                      # many plane tiles per workgroup split
+])
+def test_wino_wgrad_matches_autograd(hip_backend, kw):
+    be = hip_backend
+    be.winograd_wgrad = True
+    be.WINO_MIN_VOXELS = 0
+    try:
+        assert C.case_conv_wgrad(be, **kw) < 1e-4
+    finally:
+        be.winograd_wgrad = False
+        del be.WINO_MIN_VOXELS
+
