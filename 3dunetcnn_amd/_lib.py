@@ -5,7 +5,7 @@ or cannot be loaded this module raises -- there is no CPU or PyTorch fallback.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libmi355unet3d.so"
@@ -114,8 +114,8 @@ SIGNATURES = {
     "mi355_ce_workspace": (c_size_t, [c_int64]),
     "mi355_ce_fwd_bwd": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_float, c_void_p, c_int32,
                                         c_void_p, c_int32, c_float, c_void_p, c_size_t, c_void_p]),
-    "mi355_adam_step": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
-                                       c_float, c_int32, c_float, c_void_p]),
+    "mi355_adam_step": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double, c_double,
+                                       c_double, c_int32, c_float, c_void_p]),
     "mi355_version": (c_char_p, []),
 }
 

@@ -34,7 +34,9 @@ def newer(a, b):
 
 def build(force=False, verbose=True):
     srcs = sources()
-    deps = [os.path.join(CSRC, "hipcompat.h"), os.path.join(HERE, "..", "include", "mi355_unet3d.h")]
+    # every header a kernel source may include: editing any of them rebuilds all objects
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    deps.append(os.path.join(HERE, "..", "include", "mi355_unet3d.h"))
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     jobs = []

@@ -382,8 +382,8 @@ extern "C" int mi355_dice_ex_backward(const mi355_dice_opts* o, const float* log
   return LAUNCH_CHECK();
 }
 
-__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long count, float lr, float b1, float b2, float eps,
-                            float wd, float bc1, float bc2_sqrt, float gscale) {
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long count, float step_size, float b1, float omb1, float b2,
+                            float omb2, float eps, float wd, float bc2_sqrt, float gscale) {
   const long long n4 = count / 4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 pv = reinterpret_cast<float4*>(p)[i];
@@ -395,10 +395,10 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long l
     for (int e = 0; e < 4; ++e) {
       float gg = ge[e] * gscale;
       if (wd != 0.f) gg += wd * pe[e];
-      me[e] = b1 * me[e] + (1.f - b1) * gg;
-      ve[e] = b2 * ve[e] + (1.f - b2) * gg * gg;
+      me[e] = b1 * me[e] + omb1 * gg;
+      ve[e] = b2 * ve[e] + omb2 * gg * gg;
       const float denom = sqrtf(ve[e]) / bc2_sqrt + eps;
-      pe[e] -= (lr / bc1) * (me[e] / denom);
+      pe[e] -= step_size * (me[e] / denom);
     }
     reinterpret_cast<float4*>(p)[i] = make_float4(pe[0], pe[1], pe[2], pe[3]);
     reinterpret_cast<float4*>(m)[i] = make_float4(me[0], me[1], me[2], me[3]);
@@ -410,22 +410,23 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long l
   if (t < count) {
     float gg = g[t] * gscale;
     if (wd != 0.f) gg += wd * p[t];
-    const float mm = b1 * m[t] + (1.f - b1) * gg;
-    const float vv = b2 * v[t] + (1.f - b2) * gg * gg;
+    const float mm = b1 * m[t] + omb1 * gg;
+    const float vv = b2 * v[t] + omb2 * gg * gg;
     m[t] = mm; v[t] = vv;
-    p[t] -= (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    p[t] -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
   }
 }
 
 extern "C" int mi355_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
-                               float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream) {
+                               double lr, double beta1, double beta2, double eps, double weight_decay, int32_t step, float grad_scale,
+                               void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || count <= 0 || step < 1) return MI355_EINVAL;
   if (((uintptr_t)param & 15) || ((uintptr_t)grad & 15) || ((uintptr_t)exp_avg & 15) || ((uintptr_t)exp_avg_sq & 15)) return MI355_EINVAL;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
   long long grid = (count / 4 + 255) / 256; if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
-  LAUNCH(adam_kernel, dim3((unsigned)grid), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, (long long)count, lr, beta1, beta2, eps,
-         weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  LAUNCH(adam_kernel, dim3((unsigned)grid), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, (long long)count, (float)(lr / bc1), (float)beta1,
+         (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)sqrt(bc2), grad_scale);
   return LAUNCH_CHECK();
 }
 

@@ -19,6 +19,7 @@ Averaging happens exactly once, here (ReduceOp.AVG on RCCL, SUM followed by 1/wo
 `HipAdam.grad_scale` at 1.0 when a reducer is attached.
 """
 import contextlib
+import warnings
 
 import torch.distributed as dist
 
@@ -96,7 +97,18 @@ class GradientBucketReducer:
     def _on_accumulated(self, flat_grad):
         """A backward has ADDED its gradients onto existing ones (engine.py): reduce the accumulated flat buffer in one piece -- the
         per-bucket overlap is not available here, the micro-batch backward could not know it was the last."""
-        if not self._sync or (self.world == 1 and not self.reduce_single_rank):
+        if not self._sync:
+            self._unsynced_pending = True
+            return
+        if not getattr(self, "_unsynced_pending", False) and not getattr(self, "_warned_accumulate", False):
+            # not the closing micro-batch of a no_sync() accumulation: a plain step whose .grad tensors were kept (zero_grad(set_to_none=
+            # False)) lands here every time and silently loses the bucketed overlap
+            self._warned_accumulate = True
+            warnings.warn("GradientBucketReducer: backward found existing .grad tensors outside a no_sync() accumulation: the gradients "
+                          "are all-reduced in ONE blocking piece after backward (no per-bucket overlap). Use "
+                          "optimizer.zero_grad(set_to_none=True) for plain steps", stacklevel=3)
+        self._unsynced_pending = False
+        if self.world == 1 and not self.reduce_single_rank:
             return
         if self.average and dist.get_backend(self.pg) == "nccl":
             dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, group=self.pg)
@@ -110,6 +122,8 @@ class GradientBucketReducer:
         if self._built_for != self.model._flat.data_ptr():
             self._build()
         self.gbuf = gbuf
+        if not self._sync:
+            self._unsynced_pending = True      # first micro-batch of a no_sync() accumulation
         self.pending = list(self.pending_init)
         self._works = []
         self.n_launched = 0            # bucket all-reduces launched during this backward (diagnostics / tests)

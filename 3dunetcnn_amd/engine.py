@@ -129,9 +129,12 @@ class HipNetBase(nn.Module):
             raise RuntimeError(f"{type(self).__name__} does not run under torch.nn.DataParallel (n_gpus > 1 in the reference's "
                                "build_or_load_model): use one process per GPU -- `python bench.py --gpus N`, or "
                                "3dunetcnn_amd.ddp.GradientBucketReducer under torch.distributed (INTEGRATION.md, multi-GPU)")
-        self.flatten_parameters()
-        if self._be is not None and x.device.type == "cuda" and self._be.device.type == "cuda" and x.device != self._be.device:
-            raise RuntimeError(f"{type(self).__name__}: input on {x.device} but the module lives on {self._be.device}")
+        flat = self.flatten_parameters()
+        if self._be is not None and flat.device.type == "cuda" and self._be.device.type == "cuda" and flat.device != self._be.device:
+            self._be = None                   # the module was moved (.to / .cuda(i)) since its last forward: take that device's backend
+            self._packed = {}
+        if x.device.type == "cuda" and flat.device.type == "cuda" and x.device != flat.device:
+            raise RuntimeError(f"{type(self).__name__}: input on {x.device} but the module lives on {flat.device}")
         with self._device_guard(x):
             return _NetFunction.apply(self, x.contiguous().float(), *self._params())
 
@@ -234,7 +237,8 @@ class HipNetBase(nn.Module):
             if self._s2_active is not None:
                 torch.cuda.current_stream().wait_stream(self._s2_active)     # join: the optimizer reads every gradient
                 self._s2_active = None
-        self.grad_ready_callback, self.backward_start_callback, self.grad_sync_callback = reducer_cb
+            # also on an exception (an OOM the caller catches): a later backward must not run without its gradient exchange
+            self.grad_ready_callback, self.backward_start_callback, self.grad_sync_callback = reducer_cb
         if self.grad_sync_callback is not None and not accumulate:
             # every bucket all-reduce has been launched by now: order the launch stream behind them (a stream-level wait on RCCL,
             # the host does not stall), so that ANY caller's `loss.backward(); optimizer.step()` -- the reference's epoch_training

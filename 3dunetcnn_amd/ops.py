@@ -124,7 +124,7 @@ class PackedWeight:
 
 
 class Backend:
-    # the one measurement so far (profiles/r2_winograd_prep_measurement.txt): no gain on the 16^3 level (256 channels), 16-36 % above it
+    # measured twice (profiles/r2_winograd_prep_measurement.txt, r3_winograd_landing.txt): no gain on the 16^3 level (256 channels), 20-38 % above it
     WINO_MIN_VOXELS = 32 ** 3
     # executed / algorithmic multiplications of the Winograd kernels (bench.py reports both rates)
     WINO_EXECUTED = {"conv3d_wino2d": 12.0 / 27.0, "conv3d_wino2d_wgrad (+reduce)": 16.0 / 36.0}
@@ -138,10 +138,14 @@ class Backend:
         self.device = torch.device(device)
         self._ws_by_stream = {}     # launch stream handle -> workspace tensor: kernels of different streams must not share scratch
         self.precision = PREC_F32   # arithmetic of the 3x3x3 stride-1 convs: see set_precision()
-        # EXPERIMENT SWITCH (prepared on the emulator, not yet measured): MI355_WINOGRAD=1 routes the eligible fp32 3x3x3 stride-1
-        # forward / dgrad convolutions to the Winograd kernel
-        self.winograd = os.environ.get("MI355_WINOGRAD", "0") == "1"
-        self.winograd_wgrad = os.environ.get("MI355_WINOGRAD_WGRAD", "0") == "1"      # the weight gradients too (first version, never measured)
+        # The eligible fp32 3x3x3 stride-1 forward / dgrad convolutions (>= WINO_MIN_VOXELS voxels, >= 8 channels either side) run on the
+        # Winograd F(2x2, 3x3) x direct-z kernel (csrc/conv3d_wino.hip): 12 instead of 27 multiplications per output and (ci, co), fp32
+        # error equal to the direct kernel's. Measured on MI355X (round 3, profiles/r3_winograd_landing.txt): layer set 21.96 -> 15.28 ms,
+        # UNet3D 128^3 batch-2 step 87.1 -> 75.2 ms. MI355_WINOGRAD=0 selects the direct kernels (the A/B and cross-check form).
+        self.winograd = os.environ.get("MI355_WINOGRAD", "1") == "1"
+        # Winograd weight gradient F(3x3, 2x2) x direct z: measured 2x SLOWER than conv3d_wgrad_ring (4.06 vs 1.94 ms at 32->32 @128^3):
+        # stays an experiment switch
+        self.winograd_wgrad = os.environ.get("MI355_WINOGRAD_WGRAD", "0") == "1"
 
         self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
         # norm statistics leave with the producing conv's epilogue (csrc/gn_fuse.h). False: every statistic is a standalone pass
@@ -255,11 +259,13 @@ class Backend:
         self.prof.append((name.value.decode(), flops, byts, e0, e1))
         return self._fold_after(y, gparts)
 
-    # -- Winograd form of the 3x3x3 stride-1 conv (csrc/conv3d_wino.hip): prepared, not yet measured, not used by the modules ----------
+    # -- Winograd form of the 3x3x3 stride-1 conv (csrc/conv3d_wino.hip) -------------------------------------------------------------
     def wino_pack_weight(self, w, mode=0):
         """w OIDHW [cout, cin, 3, 3, 3] -> transformed weights for conv_fwd_wino (mode 0: forward; mode 1: dgrad, i.e. a conv from
         cout to cin channels)."""
         cout, cin = (w.shape[0], w.shape[1]) if mode == 0 else (w.shape[1], w.shape[0])
+        if w.device != self.device or w.dtype != torch.float32:
+            raise ValueError(f"wino_pack_weight: weight on {w.device} ({w.dtype}), backend on {self.device}: fp32 on the backend device expected")
         up = torch.empty(self.lib.mi355_wino_weight_elems(cout, cin), dtype=torch.float32, device=self.device)
         check(self.lib.mi355_wino_pack_weight(w.contiguous().data_ptr(), up.data_ptr(), cout, cin, mode, self.stream()), "wino_pack_weight")
         return up

@@ -161,6 +161,7 @@ class HipUNet3D(HipNetBase):
             self.activation = None
         self.n_in_channels = n_features
         self.dropout_generator = None
+        self.last_dropout_scale = None
         self._init_engine()
 
     # ---- forward -----------------------------------------------------------------------------------------------
@@ -238,6 +239,7 @@ class HipUNet3D(HipNetBase):
                 p = layer.dropout_p
                 keepmask = torch.rand(n, cout, device=be.device, generator=self.dropout_generator) >= p
                 chscale = keepmask.float() / (1.0 - p)
+                self.last_dropout_scale = chscale        # [N, C] keep mask / (1 - p) the forward drew (what parity tests hand the oracle)
             saved.append(self._block_fwd(be, blk, x, out, chscale, keep, out_moments or j < nb - 1))
             x = out
         return saved

@@ -359,9 +359,12 @@ int mi355_ce_fwd_bwd(const float* logits, const void* target, int32_t target_is_
 
 /* ---- optimizer -------------------------------------------------------------------------------- */
 /* torch.optim.Adam(lr, betas, eps, weight_decay=0, amsgrad=False).step() (script_utils.py:80-81) over one flat
- * parameter buffer; grad is multiplied by grad_scale first (1/world_size after the RCCL sum). step is 1-based. */
+ * parameter buffer; grad is multiplied by grad_scale first (1/world_size after the RCCL sum). step is 1-based.
+ * Hyper-parameters are doubles, as torch's Python scalars are: the fp32 factors the kernel multiplies by are float(1 - beta),
+ * float(lr / (1 - beta1^step)), ... rounded ONCE from the double expression, exactly what torch hands its kernels
+ * (float(1 - 0.999) and 1.f - float(0.999) differ by 1.3e-5 relative; tests/test_launch_audit.py found it). */
 int mi355_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
-                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+                    double lr, double beta1, double beta2, double eps, double weight_decay, int32_t step, float grad_scale, void* stream);
 
 /* Library / build identification: returns e.g. "mi355_unet3d gfx950 <version>". */
 const char* mi355_version(void);

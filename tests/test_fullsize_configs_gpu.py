@@ -1,0 +1,93 @@
+"""BASELINE.json configs[3] and configs[4] at their FULL sizes against the oracle:
+
+  C4  deep UNet3D (encoder_blocks [1,2,2,2,4], 5 levels, 96.8 M parameters), 160 x 192 x 128 patch, N = 1: logits and loss of the
+      train-mode step against the fp32 CPU oracle graph (same Dropout3d mask), and EVERY launch of the step (forward, backward, Adam)
+      against fp64 from the same inputs (tests/launch_audit.py) -- the conditioning-independent form of gradient parity;
+  C5  sliding-window inference over a 240 x 240 x 155 whole-brain volume with overlapping 128^3 windows (3 x 3 x 2 = 18 windows at
+      overlap 0.5, unet3d/predict/volumetric.py:131-177 + scripts/script_utils.py:290-293), Gaussian importance map:
+      HipSlidingWindowInferer driving HipUNet3D vs oracle/sliding_window_ref.py driving oracle/unet3d_ref.py on the CPU.
+"""
+import importlib
+import os
+import time
+
+import pytest
+import torch
+
+import launch_audit as A
+import op_cases as C
+from oracle import sliding_window_ref as SW
+from oracle import torch_ops as O
+from oracle import unet3d_ref as R
+from test_launch_audit import BOUNDS
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+unet = importlib.import_module("3dunetcnn_amd.unet")
+losses = importlib.import_module("3dunetcnn_amd.losses")
+optim = importlib.import_module("3dunetcnn_amd.optim")
+inferer = importlib.import_module("3dunetcnn_amd.inferer")
+
+
+def test_c4_five_level_160x192x128_train_step(hip_backend):
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    torch.manual_seed(1234)
+    enc = [1, 2, 2, 2, 4]
+    m = unet.HipUNet3D(n_features=4, n_outputs=3, encoder_blocks=enc).cuda().train()
+    assert sum(p.numel() for p in m.parameters()) == 96822184
+    m.dropout_generator = torch.Generator(device="cuda").manual_seed(3)
+    x, y = R.synthetic_case(1, 4, (160, 192, 128), 3)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}      # weights BEFORE the optimizer step
+    crit = losses.HipDiceLoss(sigmoid=True)
+    opt = optim.HipAdam(m.parameters(), lr=1e-3)
+    with A.audited(hip_backend) as au:
+        opt.zero_grad(set_to_none=True)
+        out = m(x.cuda())
+        loss = crit(out, y.cuda())
+        loss.backward()
+        opt.step()
+    out_c, loss_v = out.detach().cpu(), float(loss.detach())
+    ds = m.last_dropout_scale.detach().cpu()
+    del m, out, opt
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = R.unet3d_forward(sd, x, tuple(enc), dropout_scale=ds)
+        lref = float(O.dice_loss(ref, y))
+    e = {"logits": C.rel_err(out_c, ref), "loss": abs(loss_v - lref) / abs(lref), "oracle_s": round(time.perf_counter() - t0, 1)}
+    worst, counts = au.worst(), au.counts()
+    print(e, {k: (counts[k], f"{worst[k]['err']:.1e}") for k in sorted(worst)})
+    assert e["logits"] < TOL and e["loss"] < TOL, e
+    assert counts["conv_fwd"] >= 120 and counts["conv_wgrad"] >= 50 and counts["gn_act_bwd"] >= 32 and counts["adam"] == 1, counts
+    bad = [r for r in au.records if r["err"] > BOUNDS[r["kind"]]]
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("mode", ["gaussian"])       # the constant map is the w = 1 special case (test_fullsize_gpu.py covers both)
+def test_c5_sliding_window_240x240x155_matches_oracle(mode):
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    torch.manual_seed(1234)
+    m = unet.HipUNet3D(n_features=4, n_outputs=3).cuda().eval()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(1, 4, 240, 240, 155, generator=torch.Generator().manual_seed(2))
+    roi = (128, 128, 128)
+    inf = inferer.HipSlidingWindowInferer(roi, sw_batch_size=2, overlap=0.5, mode=mode)
+    with torch.no_grad():
+        out = inf(x.cuda(), m).cpu()
+    calls = {"n": 0}
+
+    def predictor(win):
+        calls["n"] += win.shape[0]
+        return R.unet3d_forward(sd, win)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = SW.sliding_window_inference(x, roi, 2, predictor, overlap=0.5, mode=mode)
+    print(mode, "oracle windows", calls["n"], "seconds", round(time.perf_counter() - t0, 1), "err", C.rel_err(out, ref))
+    assert calls["n"] == 18                                     # starts {0, 64, 112}^2 x {0, 27}
+    assert out.shape == ref.shape == (1, 3, 240, 240, 155)
+    assert C.rel_err(out, ref) < TOL
+    # the decoded segmentation the reference writes (sigmoid > 0.5, predict/volumetric.py:151-156) agrees voxel for voxel except where the
+    # probability sits on the threshold to fp32 resolution
+    a, b = torch.sigmoid(out) > 0.5, torch.sigmoid(ref) > 0.5
+    near = (torch.sigmoid(ref) - 0.5).abs() < 1e-4
+    assert not ((a != b) & ~near).any()

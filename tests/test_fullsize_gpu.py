@@ -87,6 +87,28 @@ def test_fp32_mfma_and_split_bf16_kernels_agree_128cube(hip_backend, cin, cout):
         assert C.rel_err(b, a) < 1e-5
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 32)])
+def test_winograd_and_direct_kernels_agree_128cube(hip_backend, cin, cout):
+    """The product routing (Winograd F(2x2,3x3) x direct-z forward / dgrad, csrc/conv3d_wino.hip) against the direct exact-fp32 MFMA
+    kernels (MI355_WINOGRAD=0) on the full-size layers: two independently written kernels, same op."""
+    be = hip_backend
+    x, dy, w, kw = _conv_triplet(be, 2, cin, cout, True)
+    outs = {}
+    old = be.winograd
+    try:
+        for wino in (True, False):
+            be.winograd = wino
+            y, dx = be.empty_act(2, S, S, S, cout), be.empty_act(2, S, S, S, cin)
+            be.conv_fwd(x, be.pack_weight(w, 0), y, 3, 1, **kw)
+            be.conv_fwd(dy, be.pack_weight(w, 1), dx, 3, 1)
+            outs[wino] = (y.tensor().clone(), dx.tensor().clone())
+    finally:
+        be.winograd = old
+    for a, b in zip(outs[True], outs[False]):
+        assert C.rel_err(a, b) < 3e-6
+        assert not torch.equal(a, b)                            # they ARE different kernels (the switch took effect)
+
+
 def test_unet3d_step_128cube_batch2_properties():
     torch.manual_seed(1234)
     m = unet.HipUNet3D(n_features=4, n_outputs=3).cuda().eval()

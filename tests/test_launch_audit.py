@@ -1,0 +1,136 @@
+"""Per-launch fp64 audit of whole training steps (tests/launch_audit.py): every kernel launch of a step -- in TRAIN mode, Dropout3d
+active, the mode bench.py times -- is recomputed in fp64 on the CPU from the same input tensors and must agree to the bound its own
+arithmetic explains. This is the conditioning-independent backward-parity check: the whole-network gradient comparisons
+(tests/test_model_gpu.py, test_headline_parity_gpu.py) have to allow for gradients that are differences of large cancelling sums;
+a per-launch comparison from identical inputs does not.
+
+CPU twin (emulator build of the same kernel sources) at a small size validates the audit itself and the kernels' index logic;
+the `-m gpu` tests run the BASELINE configs[1] headline step (UNet3D 128^3, batch 2) and the BraTS-config DynUNet at 64^3
+(BASELINE configs[0]) on the MI355X.
+"""
+import functools
+import importlib
+
+import pytest
+import torch
+
+import launch_audit as A
+from oracle import unet3d_ref as R
+
+unet = importlib.import_module("3dunetcnn_amd.unet")
+dynunet = importlib.import_module("3dunetcnn_amd.dynunet")
+losses = importlib.import_module("3dunetcnn_amd.losses")
+optim = importlib.import_module("3dunetcnn_amd.optim")
+
+# bound per launch kind: max |kernel - fp64| / max |fp64| over the audited sample (for weight gradients: / max |dw| of the tensor).
+# fp32 products + fp32 accumulation of K terms sit at ~1e-7 .. 1e-6; 1e-5 is the bar VERDICT r2 item 1(b) names.
+BOUNDS = {"conv_fwd": 1e-5, "conv_d2s": 1e-5, "conv_wgrad": 1e-5, "gn_stats": 1e-5, "gn_act_bwd": 1e-5, "upsample_fwd": 1e-6,
+          "upsample_bwd": 1e-6, "chscale": 1e-6, "add": 1e-6, "layout": 0.0, "proj_fwd": 1e-5, "proj_bwd": 1e-5, "dice": 1e-5, "adam": 1e-6,
+          "adam_update": 2e-3}
+
+
+def _step(be, model, x, y, dev, **akw):
+    crit = losses.HipDiceLoss(sigmoid=True)
+    opt = optim.HipAdam(model.parameters(), lr=1e-3)
+    model._be = crit._be = opt._be = be
+    with A.audited(be, **akw) as au:
+        opt.zero_grad(set_to_none=True)
+        out = model(x.to(dev))
+        loss = crit(out, y.to(dev))
+        loss.backward()
+        opt.step()
+    return au, float(loss.detach())
+
+
+def _check(au, need):
+    worst, counts = au.worst(), au.counts()
+    summary = {k: (counts[k], f"{worst[k]['err']:.1e}") for k in sorted(worst)}
+    print(summary)
+    for kind, n in need.items():
+        assert counts.get(kind, 0) >= n, (kind, counts)
+    bad = [r for r in au.records if r["err"] > BOUNDS[r["kind"]]]
+    assert not bad, bad[:10]
+
+
+def test_audit_unet3d_train_step_emulator(emu_backend):
+    """The audit on the CPU emulator: a reduced UNet3D (3 levels, width 8) at 16^3 in train mode. Small thresholds force the sampled
+    (block / channel-subset) paths of the audit, so the sampling logic is exercised against kernels known good from the op tests."""
+    torch.manual_seed(5)
+    m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1, 2]).train()
+    m.backward_side_stream = False
+    x, y = R.synthetic_case(2, 4, (16, 16, 16), 3)
+    au, loss = _step(emu_backend, m, x, y, "cpu", block_macs=2e5, full_macs=1e6, wgrad_channels=3)
+    assert m.last_dropout_scale is not None and 0.0 < loss <= 1.0
+    _check(au, {"conv_fwd": 30, "conv_wgrad": 15, "gn_act_bwd": 8, "gn_stats": 8, "chscale": 1, "upsample_fwd": 2, "upsample_bwd": 2, "adam": 1})
+
+
+@pytest.mark.parametrize("tc", [False, True])
+def test_audit_odd_sizes_emulator(emu_backend, tc):
+    """Ragged sizes: the pad / crop window of the up-sampling path (unet.py:34-40) and, with use_transposed_convolutions, the zero-insert
+    forward into that window and its stride-2 dgrad / wgrad."""
+    torch.manual_seed(8)
+    m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1, 1], use_transposed_convolutions=tc).train()
+    m.backward_side_stream = False
+    x, y = R.synthetic_case(1, 4, (10, 11, 9), 3)
+    au, _ = _step(emu_backend, m, x, y, "cpu", block_macs=2e5, full_macs=1e6, wgrad_channels=3)
+    _check(au, {"conv_fwd": 20, "conv_wgrad": 10})
+
+
+def test_audit_detects_a_wrong_launch(emu_backend):
+    """The audit must fail on a wrong kernel result: corrupt ONE output voxel of one conv launch after it ran."""
+    torch.manual_seed(5)
+    m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1]).eval()
+    m.backward_side_stream = False
+    be = emu_backend
+    x, y = R.synthetic_case(1, 4, (8, 8, 8), 3)
+    orig = be.conv_fwd
+    state = {"n": 0}
+
+    @functools.wraps(orig)
+    def corrupting(xa, wp, ya, *a, **k):
+        r = orig(xa, wp, ya, *a, **k)
+        state["n"] += 1
+        if state["n"] == 3:
+            ya.tensor()[0, 0, 0, 0, 0] += 1e-2
+        return r
+    be.conv_fwd = corrupting
+    try:
+        au, _ = _step(be, m, x, y, "cpu")
+    finally:
+        del be.conv_fwd
+    assert sum(r["err"] > BOUNDS[r["kind"]] for r in au.records if r["kind"] == "conv_fwd") == 1
+
+
+def test_audit_dynunet_train_step_emulator(emu_backend):
+    torch.manual_seed(6)
+    m = dynunet.HipDynUNet(spatial_dims=3, in_channels=4, out_channels=3, kernel_size=[3] * 3, strides=[1, 2, 2], upsample_kernel_size=[2, 2],
+                           filters=[8, 16, 24]).train()
+    m.backward_side_stream = False
+    x, y = R.synthetic_case(1, 4, (16, 16, 16), 3)
+    au, _ = _step(emu_backend, m, x, y, "cpu", block_macs=2e5, full_macs=1e6, wgrad_channels=3)
+    _check(au, {"conv_fwd": 10, "conv_d2s": 4, "conv_wgrad": 8, "gn_act_bwd": 4})
+
+
+@pytest.mark.gpu
+def test_audit_headline_train_step_gpu(hip_backend):
+    """BASELINE configs[1], the step bench.py times: default UNet3D, 128^3, batch 2, fp32, train mode (Dropout3d mask drawn on the device),
+    product routing (Winograd forward / dgrad on the eligible layers, weight gradients on the second stream)."""
+    torch.manual_seed(1234)
+    m = unet.HipUNet3D(n_features=4, n_outputs=3).cuda().train()
+    x, y = R.synthetic_case(2, 4, (128, 128, 128), 3)
+    au, loss = _step(hip_backend, m, x, y, "cuda")
+    assert m.last_dropout_scale is not None and 0.0 < loss < 1.0
+    _check(au, {"conv_fwd": 100, "conv_wgrad": 40, "gn_act_bwd": 26, "gn_stats": 26, "chscale": 1, "upsample_fwd": 3, "upsample_bwd": 3,
+                "proj_fwd": 1, "proj_bwd": 1, "dice": 1, "adam": 1})
+
+
+@pytest.mark.gpu
+def test_audit_brats_dynunet_train_step_gpu(hip_backend):
+    """BASELINE configs[0] network: the BraTS2020-config DynUNet (examples/brats2020/brats2020_config.json:2-107) at 1 x 4 x 64^3."""
+    torch.manual_seed(1234)
+    m = dynunet.HipDynUNet(spatial_dims=3, in_channels=4, out_channels=3, kernel_size=[3] * 6, strides=[1] + [2] * 5,
+                           upsample_kernel_size=[2] * 5, filters=[64, 96, 128, 192, 256, 384]).cuda().train()
+    x, y = R.synthetic_case(1, 4, (64, 64, 64), 3)
+    au, loss = _step(hip_backend, m, x, y, "cuda")
+    assert 0.0 < loss < 1.0
+    _check(au, {"conv_fwd": 30, "conv_d2s": 10, "conv_wgrad": 20, "gn_act_bwd": 10, "dice": 1, "adam": 1})

@@ -8,6 +8,14 @@ import op_cases as C
 TOL = C.TOL
 
 
+@pytest.fixture(autouse=True)
+def _direct_conv_kernels(emu_backend):
+    """Op tests of the DIRECT conv kernels: Winograd routing off (tests/test_wino_emu.py holds the Winograd kernel to the same cases)."""
+    old, emu_backend.winograd = emu_backend.winograd, False
+    yield
+    emu_backend.winograd = old
+
+
 def ok(r):
     vals = r.values() if isinstance(r, dict) else [r]
     return all(v < TOL for v in vals)

@@ -4,6 +4,15 @@ import pytest
 import op_cases as C
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _direct_conv_kernels(hip_backend):
+    """These are the op tests of the DIRECT conv kernels: the Winograd routing of Backend.conv_fwd is off here (tests/test_wino_gpu.py
+    holds the Winograd kernel to the same cases; tests/test_fullsize_gpu.py compares the two at 128^3)."""
+    old, hip_backend.winograd = hip_backend.winograd, False
+    yield
+    hip_backend.winograd = old
 TOL = C.TOL
 
 

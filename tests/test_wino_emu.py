@@ -130,6 +130,7 @@ def test_whole_network_step_on_the_winograd_kernels(emu_backend):
     losses = importlib.import_module("3dunetcnn_amd.losses")
     g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet3d_small.pt"))
     be = emu_backend
+    old_routing = (be.winograd, be.winograd_wgrad)
     be.winograd = be.winograd_wgrad = True
     be.WINO_MIN_VOXELS = 0                 # the golden bundle is 20 x 16 x 24: route every level
     calls = {"n": 0}
@@ -149,7 +150,7 @@ def test_whole_network_step_on_the_winograd_kernels(emu_backend):
         loss = crit(out, g["y"])
         loss.backward()
     finally:
-        be.winograd = be.winograd_wgrad = False
+        be.winograd, be.winograd_wgrad = old_routing
         del be.conv_fwd_wino, be.WINO_MIN_VOXELS
     assert calls["n"] >= 20
     assert C.rel_err(out, g["logits"]) < 1e-3

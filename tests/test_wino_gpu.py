@@ -1,5 +1,5 @@
 """GPU twins of tests/test_wino_emu.py: the Winograd kernels through the C ABI on an MI355X (same cases, same tolerances).
-Generated from that file: keep the two in step. Never run on hardware yet."""
+Generated from that file: keep the two in step."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -41,12 +41,12 @@ def test_wino_forward_matches_conv3d(hip_backend, kw):
     cs = (torch.rand(n, cout, generator=g) > 0.3).float() * 1.25 if kw.get("chscale") else None
     ref = O.conv_block(x, wt, 1, 1, normspec, b, res, cs)
     xa, ya = C.to_act(be, x), C.to_act(be, torch.zeros_like(ref))
-    up = be.wino_pack_weight(wt, 0)
+    up = be.wino_pack_weight(C.dev(be, wt), 0)                    # every pointer handed to the library lives on the backend's device
     extra = {}
     if normspec:
-        mr, sc, sh = be.gn_stats(xa, normspec[0], 1e-5, gamma, beta)
+        mr, sc, sh = be.gn_stats(xa, normspec[0], 1e-5, C.dev(be, gamma), C.dev(be, beta))
         extra = dict(in_mode=ops.IN_AFFINE_ACT, slope=normspec[4], scale=sc, shift=sh)
-    be.conv_fwd_wino(xa, up, ya, bias=b, residual=C.to_act(be, res) if res is not None else None, chscale=cs, **extra)
+    be.conv_fwd_wino(xa, up, ya, bias=C.dev(be, b), residual=C.to_act(be, res) if res is not None else None, chscale=C.dev(be, cs), **extra)
     assert C.rel_err(C.from_act(ya), ref) < 1e-5
 
 
@@ -60,7 +60,7 @@ def test_wino_dgrad_pack_matches_autograd(hip_backend):
     dy = torch.randn(y.shape, generator=g)
     (dx_ref,) = torch.autograd.grad(y, x, dy)
     dya, dxa = C.to_act(be, dy), C.to_act(be, torch.zeros_like(x.detach()))
-    be.conv_fwd_wino(dya, be.wino_pack_weight(wt, 1), dxa)
+    be.conv_fwd_wino(dya, be.wino_pack_weight(C.dev(be, wt), 1), dxa)
     assert C.rel_err(C.from_act(dxa), dx_ref) < 1e-5
 
 
@@ -137,6 +137,7 @@ def test_whole_network_step_on_the_winograd_kernels(hip_backend):
     losses = importlib.import_module("3dunetcnn_amd.losses")
     g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet3d_small.pt"))
     be = hip_backend
+    old_routing = (be.winograd, be.winograd_wgrad)
     be.winograd = be.winograd_wgrad = True
     be.WINO_MIN_VOXELS = 0                 # the golden bundle is 20 x 16 x 24: route every level
     calls = {"n": 0}
@@ -154,7 +155,7 @@ def test_whole_network_step_on_the_winograd_kernels(hip_backend):
         loss = crit(out, g["y"].cuda())
         loss.backward()
     finally:
-        be.winograd = be.winograd_wgrad = False
+        be.winograd, be.winograd_wgrad = old_routing
         del be.conv_fwd_wino, be.WINO_MIN_VOXELS
     assert calls["n"] >= 20
     assert C.rel_err(out, g["logits"]) < 1e-3
