@@ -127,7 +127,7 @@ class Backend:
     # measured twice (profiles/r2_winograd_prep_measurement.txt, r3_winograd_landing.txt): no gain on the 16^3 level (256 channels), 20-38 % above it
     WINO_MIN_VOXELS = 32 ** 3
     # executed / algorithmic multiplications of the Winograd kernels (bench.py reports both rates)
-    WINO_EXECUTED = {"conv3d_wino2d": 12.0 / 27.0, "conv3d_wino2d_wgrad (+reduce)": 16.0 / 36.0}
+    WINO_EXECUTED = {"conv3d_wino2d": 12.0 / 27.0, "conv3d_wino2d_wgrad (+reduce)": 16.0 / 36.0, "conv3d_wgrad_wino_ring (+reduce)": 16.0 / 36.0}
 
     def __init__(self, lib=None, device=None):
         self.lib = lib if lib is not None else _lib.load_library()
@@ -146,6 +146,8 @@ class Backend:
         # Winograd weight gradient F(3x3, 2x2) x direct z: measured 2x SLOWER than conv3d_wgrad_ring (4.06 vs 1.94 ms at 32->32 @128^3):
         # stays an experiment switch
         self.winograd_wgrad = os.environ.get("MI355_WINOGRAD_WGRAD", "0") == "1"
+        # the plane-ring form of the Winograd weight gradient (csrc/conv3d_wgrad_wino.hip): "ring"
+        self.wgrad_form = os.environ.get("MI355_WGRAD_FORM", "direct")      # direct | wino
 
         self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
         # norm statistics leave with the producing conv's epilogue (csrc/gn_fuse.h). False: every statistic is a standalone pass
@@ -318,6 +320,23 @@ class Backend:
         d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, None, None, None, (0, 0, 0),
                        x.shape[1:4] if out_mode == OUT_D2S else dy.shape[1:4], keep, in_slope, out_mode)
         xd, dyd = x.desc(), dy.desc()
+        if (self.wgrad_form == "wino" and self.precision == PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT)
+                and out_mode == OUT_PLAIN and x.c >= 8 and dy.c >= 8 and x.shape[1] * x.shape[2] * x.shape[3] >= self.WINO_MIN_VOXELS):
+            nbytes = self.lib.mi355_conv3d_wgrad_wino_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))
+            if nbytes:
+                ws = self.ws(nbytes)
+                assert dw.is_contiguous()
+                if self.prof is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                check(self.lib.mi355_conv3d_wgrad_wino(ctypes.byref(xd), ctypes.byref(dyd), dw.data_ptr(), ctypes.byref(d), ws.data_ptr(),
+                                                       ws.numel() * 4, self.stream()), "conv3d_wgrad_wino")
+                if self.prof is not None:
+                    e1.record()
+                    nvox = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3]
+                    self.prof.append(("conv3d_wgrad_wino_ring (+reduce)", 2.0 * nvox * x.c * dy.c * 27,
+                                      4.0 * (nvox * (x.c + dy.c) + 27 * x.c * dy.c), e0, e1))
+                return
         if (self.winograd_wgrad and self.precision == PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT)
                 and out_mode == OUT_PLAIN and x.c >= 8 and dy.c >= 8 and x.shape[1] * x.shape[2] * x.shape[3] >= self.WINO_MIN_VOXELS):
             nbytes = self.lib.mi355_conv3d_wino_wgrad_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))

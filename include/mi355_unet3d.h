@@ -283,8 +283,8 @@ int mi355_resample_affine(const float* src, float* dst, int32_t c, int32_t sd, i
                           int32_t dw, const float* m, int32_t mode, int32_t padding, void* stream);
 
 /* ---- Winograd F(2x2, 3x3) x direct-z form of the 3x3x3 stride-1 convolution (csrc/conv3d_wino.hip) --------------------------------
- * PREPARED ON THE CPU EMULATOR, NOT YET MEASURED ON HARDWARE: not used by the Python modules. Same operation as mi355_conv3d_fwd for
- * kd 3 / stride 1 / pad 1, plain or norm-prologue input, plain un-windowed output (bias, residual, out_chscale and the fused statistics
+ * The product path of the eligible fp32 forward / dgrad convolutions (round 3; replaces the ATen / cuDNN call behind nn.Conv3d of
+ * unet3d/models/pytorch/classification/resnet.py:12-17). Same operation as mi355_conv3d_fwd for kd 3 / stride 1 / pad 1, plain or norm-prologue input, plain un-windowed output (bias, residual, out_chscale and the fused statistics
  * honoured), fp32, 12 instead of 27 multiplications per output and (ci, co). Weights: mi355_wino_pack_weight (mode 0 forward,
  * mode 1 dgrad of Conv3d, as mi355_pack_conv_weight) into mi355_wino_weight_elems(cout, cin) floats. */
 size_t mi355_wino_weight_elems(int32_t cout, int32_t cin);
@@ -295,6 +295,11 @@ int32_t mi355_conv3d_wino_stats_blocks(const mi355_act* y);
 /* weight gradient in the same domain (F(3x3, 2x2) x direct z): contract of mi355_conv3d_wgrad for kd 3 / stride 1 / pad 1 */
 size_t mi355_conv3d_wino_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* desc);
 int mi355_conv3d_wino_wgrad(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* desc, void* ws, size_t ws_bytes,
+                            void* stream);
+/* the z-marching plane-ring form of the same weight gradient (csrc/conv3d_wgrad_wino.hip): all three dz per workgroup, every plane
+ * staged and transformed once. MI355_EUNSUPPORTED for channel counts that are not multiples of 4 (use mi355_conv3d_wgrad). */
+size_t mi355_conv3d_wgrad_wino_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* desc);
+int mi355_conv3d_wgrad_wino(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* desc, void* ws, size_t ws_bytes,
                             void* stream);
 
 /* ---- Dice loss -------------------------------------------------------------------------------- */

@@ -175,3 +175,31 @@ def test_wino_wgrad_matches_autograd(emu_backend, kw):
         be.winograd_wgrad = False
         del be.WINO_MIN_VOXELS
 
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=32, cout=32, dhw=(1, 4, 8)),                                   # one plane, exactly one plane tile
+    dict(n=2, cin=32, cout=32, dhw=(3, 8, 8), norm=True),                        # two tile rows, the ring wraps once
+    dict(n=1, cin=8, cout=64, dhw=(4, 9, 17)),                                   # ragged plane tiles, two co tiles, partial ci tile
+    dict(n=1, cin=40, cout=96, dhw=(5, 3, 7), norm=True, slope=0.01),            # partial channel tiles both sides
+    dict(n=2, cin=32, cout=32, dhw=(7, 16, 32), norm=True),                      # several columns per workgroup, ring wraps twice
+])
+def test_wgrad_wino_ring_matches_autograd(emu_backend, kw):
+    """The plane-ring Winograd weight gradient (csrc/conv3d_wgrad_wino.hip) on the shared weight-gradient case."""
+    be = emu_backend
+    old = (be.wgrad_form, getattr(be, "WINO_MIN_VOXELS"))
+    be.wgrad_form, be.WINO_MIN_VOXELS = "wino", 0
+    calls = {"n": 0}
+    orig = be.lib.mi355_conv3d_wgrad_wino
+
+    def counted(*a):
+        calls["n"] += 1
+        return orig(*a)
+    be.lib.mi355_conv3d_wgrad_wino = counted
+    try:
+        assert C.case_conv_wgrad(be, **kw) < 1e-4
+    finally:
+        be.lib.mi355_conv3d_wgrad_wino = orig
+        be.wgrad_form = old[0]
+        del be.WINO_MIN_VOXELS
+    assert calls["n"] == 1
