@@ -146,8 +146,10 @@ class Backend:
         # Winograd weight gradient F(3x3, 2x2) x direct z: measured 2x SLOWER than conv3d_wgrad_ring (4.06 vs 1.94 ms at 32->32 @128^3):
         # stays an experiment switch
         self.winograd_wgrad = os.environ.get("MI355_WINOGRAD_WGRAD", "0") == "1"
-        # the plane-ring form of the Winograd weight gradient (csrc/conv3d_wgrad_wino.hip): "ring"
-        self.wgrad_form = os.environ.get("MI355_WGRAD_FORM", "direct")      # direct | wino
+        # Weight gradients of the same layers: "wino" = the plane-ring Winograd kernel (csrc/conv3d_wgrad_wino.hip: all three dz per
+        # workgroup, every plane transformed once), "direct" = conv3d_wgrad_ring. Measured on MI355X (round 3,
+        # profiles/r3_wgrad_wino_ring_ab.txt): 32->32 @128^3 1.93 -> 1.21 ms, layer set 1.55-1.63x, UNet3D step 74.7 -> 64.1 ms.
+        self.wgrad_form = os.environ.get("MI355_WGRAD_FORM", "wino")
 
         self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
         # norm statistics leave with the producing conv's epilogue (csrc/gn_fuse.h). False: every statistic is a standalone pass
