@@ -22,6 +22,7 @@
 // Partial 27-tap tiles go to the slab workspace of conv3d_wgrad.hip ([pair][slab][tap][32 co][32 ci]) and are reduced by its
 // deterministic second pass.
 #include "hipcompat.h"
+#include <type_traits>
 #include "../../include/mi355_unet3d.h"
 
 int mi355_wgrad_reduce_launch(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles, void* stream);
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wino_ring(WWRArgs a) {
   const int cx = ci0 + 4 * sq, cdy = co0 + 4 * sq;
   const bool xvalid = cx < a.Cin, dyvalid = cdy < a.Cout, xunit = tid < HV * 8, dunit = tid < PV * 8;
   // transform units: thread = (channel tc, tile tt, row half th): rows i = 2 th, 2 th + 1 of the 4 x 4 point grid
-  const int tc = tid & 31, tt = (tid >> 5) & 7, th = tid >> 8;
+  const int tc = tid & 31, tt = (tid >> 5) & 7, th = WAVE_UNIFORM(tid >> 8);
   const int tty = tt >> 2, ttx = tt & 3;
   const size_t xplane = (size_t)a.H * a.W * a.xld, dyplane = (size_t)a.H * a.W * a.dyld;
 
@@ -98,7 +99,11 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wino_ring(WWRArgs a) {
       px = *reinterpret_cast<const float4*>(xsrc + (size_t)p * xplane);
       pd = *reinterpret_cast<const float4*>(dsrc + (size_t)p * dyplane);
     };
-    auto commit_plane = [&](int p) {
+    // PAR = p & 1 (staging buffer), SLOT = p % 3 (ring slot): compile-time in the unrolled plane loop below, so every LDS address of a
+    // step is a per-lane base fixed for the column + an immediate (the first version computed p % 3 at run time: 39 address
+    // instructions and 20 selects per step, SQ counters profiles/r3_sq_counters_wino.txt)
+    auto commit_plane = [&](auto parc) {
+      constexpr int PAR = decltype(parc)::value;
       if (xunit) {
         float4 v = px;
         if (INMODE == MI355_IN_AFFINE_ACT) {
@@ -106,65 +111,62 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wino_ring(WWRArgs a) {
           v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
         }
         if (!xin) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(xst + (p & 1) * XS + sv * 32 + 4 * sq) = v;
+        *reinterpret_cast<float4*>(xst + PAR * XS + sv * 32 + 4 * sq) = v;
       }
-      if (dunit) *reinterpret_cast<float4*>(dst_ + (p & 1) * DS + sv * 32 + 4 * sq) = din ? pd : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dunit) *reinterpret_cast<float4*>(dst_ + PAR * DS + sv * 32 + 4 * sq) = din ? pd : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    // transform of plane p from its staging buffers into ring slot p % 3: this thread's two point rows of V and of Dv
-    auto transform = [&](int p) {
-      const float* xb = xst + (p & 1) * XS + ((2 * tty) * HX + 2 * ttx) * 32 + tc;
-      float* vdst = Vr + (p % 3) * RS + (8 * th * NT + tt) * 32 + tc;          // point 4 i + j at ((4 i + j) * NT + tt) * 32 + tc, i = 2 th + ii
-      // rows: B^T d. Half 0 (i = 0, 1) needs window rows 0, 1, 2; half 1 (i = 2, 3) rows 1, 2, 3
-      float t0[4], t1[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float d1 = xb[(1 * HX + s) * 32], d2 = xb[(2 * HX + s) * 32];
-        const float de = xb[((th ? 3 : 0) * HX + s) * 32];                     // d0 (half 0) or d3 (half 1)
-        t0[s] = th ? d2 - d1 : de - d2;                                         // i = 2: d2 - d1 | i = 0: d0 - d2
-        t1[s] = th ? d1 - de : d1 + d2;                                         // i = 3: d1 - d3 | i = 1: d1 + d2
-      }
-      vdst[(0 * NT) * 32] = t0[0] - t0[2]; vdst[(1 * NT) * 32] = t0[1] + t0[2]; vdst[(2 * NT) * 32] = t0[2] - t0[1]; vdst[(3 * NT) * 32] = t0[1] - t0[3];
-      vdst[(4 * NT) * 32] = t1[0] - t1[2]; vdst[(5 * NT) * 32] = t1[1] + t1[2]; vdst[(6 * NT) * 32] = t1[2] - t1[1]; vdst[(7 * NT) * 32] = t1[1] - t1[3];
-      // Dv = A h A^T: rows (h0., h0. + h1., h0. - h1., -h1.), then the same along the columns
-      const float* db = dst_ + (p & 1) * DS + ((2 * tty) * TX + 2 * ttx) * 32 + tc;
+    // transform of a plane from staging buffer PAR into ring slot SLOT: this thread's two point rows of V and of Dv. `th` is wave-uniform
+    // (waves 0-3: rows i = 0, 1; waves 4-7: rows i = 2, 3): a scalar branch, not per-lane selects.
+    auto transform = [&](auto parc, auto slotc) {
+      constexpr int PAR = decltype(parc)::value, SLOT = decltype(slotc)::value;
+      const float* xb = xst + PAR * XS + ((2 * tty) * HX + 2 * ttx) * 32 + tc;
+      float* vdst = Vr + SLOT * RS + tt * 32 + tc;                              // point 4 i + j at ((4 i + j) * NT + tt) * 32 + tc
+      const float* db = dst_ + PAR * DS + ((2 * tty) * TX + 2 * ttx) * 32 + tc;
+      float* ddst = Dr + SLOT * RS + tt * 32 + tc;
       const float h00 = db[0], h01 = db[32], h10 = db[TX * 32], h11 = db[(TX + 1) * 32];
-      const float r0a = th ? h00 - h10 : h00, r0b = th ? h01 - h11 : h01;       // i = 2 | i = 0
-      const float r1a = th ? -h10 : h00 + h10, r1b = th ? -h11 : h01 + h11;     // i = 3 | i = 1
-      float* ddst = Dr + (p % 3) * RS + (8 * th * NT + tt) * 32 + tc;
-      ddst[(0 * NT) * 32] = r0a; ddst[(1 * NT) * 32] = r0a + r0b; ddst[(2 * NT) * 32] = r0a - r0b; ddst[(3 * NT) * 32] = -r0b;
-      ddst[(4 * NT) * 32] = r1a; ddst[(5 * NT) * 32] = r1a + r1b; ddst[(6 * NT) * 32] = r1a - r1b; ddst[(7 * NT) * 32] = -r1b;
+      float t0[4], t1[4];
+      if (th == 0) {                                                            // rows i = 0: d0 - d2, i = 1: d1 + d2 (window rows 0, 1, 2)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float d0 = xb[(0 * HX + s) * 32], d1 = xb[(1 * HX + s) * 32], d2 = xb[(2 * HX + s) * 32];
+          t0[s] = d0 - d2; t1[s] = d1 + d2;
+        }
+        vdst[(0 * NT) * 32] = t0[0] - t0[2]; vdst[(1 * NT) * 32] = t0[1] + t0[2]; vdst[(2 * NT) * 32] = t0[2] - t0[1]; vdst[(3 * NT) * 32] = t0[1] - t0[3];
+        vdst[(4 * NT) * 32] = t1[0] - t1[2]; vdst[(5 * NT) * 32] = t1[1] + t1[2]; vdst[(6 * NT) * 32] = t1[2] - t1[1]; vdst[(7 * NT) * 32] = t1[1] - t1[3];
+        // Dv = A h A^T, rows i = 0: h0., i = 1: h0. + h1.; columns (r0, r0 + r1, r0 - r1, -r1)
+        const float ra = h00 + h10, rb = h01 + h11;
+        ddst[(0 * NT) * 32] = h00; ddst[(1 * NT) * 32] = h00 + h01; ddst[(2 * NT) * 32] = h00 - h01; ddst[(3 * NT) * 32] = -h01;
+        ddst[(4 * NT) * 32] = ra; ddst[(5 * NT) * 32] = ra + rb; ddst[(6 * NT) * 32] = ra - rb; ddst[(7 * NT) * 32] = -rb;
+      } else {                                                                  // rows i = 2: d2 - d1, i = 3: d1 - d3 (window rows 1, 2, 3)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float d1 = xb[(1 * HX + s) * 32], d2 = xb[(2 * HX + s) * 32], d3 = xb[(3 * HX + s) * 32];
+          t0[s] = d2 - d1; t1[s] = d1 - d3;
+        }
+        vdst[(8 * NT) * 32] = t0[0] - t0[2]; vdst[(9 * NT) * 32] = t0[1] + t0[2]; vdst[(10 * NT) * 32] = t0[2] - t0[1]; vdst[(11 * NT) * 32] = t0[1] - t0[3];
+        vdst[(12 * NT) * 32] = t1[0] - t1[2]; vdst[(13 * NT) * 32] = t1[1] + t1[2]; vdst[(14 * NT) * 32] = t1[2] - t1[1]; vdst[(15 * NT) * 32] = t1[1] - t1[3];
+        // rows i = 2: h0. - h1., i = 3: -h1.
+        const float ra = h00 - h10, rb = h01 - h11;
+        ddst[(8 * NT) * 32] = ra; ddst[(9 * NT) * 32] = ra + rb; ddst[(10 * NT) * 32] = ra - rb; ddst[(11 * NT) * 32] = -rb;
+        ddst[(12 * NT) * 32] = -h10; ddst[(13 * NT) * 32] = -h10 - h11; ddst[(14 * NT) * 32] = h11 - h10; ddst[(15 * NT) * 32] = h11;
+      }
     };
-
-    // ---- prologue of the column: plane 0 staged and transformed, plane 1 staged, ring slot of plane -1 zeroed ----
-    load_plane(0);
-    commit_plane(0);
-    if (a.D > 1) load_plane(1);
-    {
-      float4* z4 = reinterpret_cast<float4*>(Vr + 2 * RS);  // slot (-1) % 3 == 2 of both rings
-      float4* y4 = reinterpret_cast<float4*>(Dr + 2 * RS);
-      for (int i = tid; i < RS / 4; i += 512) { z4[i] = make_float4(0.f, 0.f, 0.f, 0.f); y4[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    }
-    __syncthreads();
-    transform(0);
-    if (a.D > 1) commit_plane(1);
-    __syncthreads();
-
-    for (int p = 0; p < a.D; ++p) {
+    // one plane step; P6 = p % 6 fixes the staging parity and the ring slots at compile time
+    auto step = [&](int p, auto p6c) {
+      constexpr int P6 = decltype(p6c)::value, SP = P6 % 3, SM = (P6 + 2) % 3;       // ring slots of planes p and p - 1
       const bool has1 = p + 1 < a.D, has2 = p + 2 < a.D;     // workgroup-uniform
       if (has2) load_plane(p + 2);
       SCHED_BARRIER();                                       // the loads stay above the MFMAs they overlap with
-      const int sp = p % 3, sm = (p + 2) % 3;                // ring slots of planes p and p - 1
       // operand fragments of this wave's two points: tile (K) index 2 ks + half, channel li -- read once, used by three MFMAs each
       float fvp[2][NT / 2], fvm[2][NT / 2], fdp[2][NT / 2], fdm[2][NT / 2];
+      const float* fb = lds + ((2 * wave) * NT + half) * 32 + li;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int o = ((2 * wave + q) * NT + half) * 32 + li;
+      for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int ks = 0; ks < NT / 2; ++ks) {
-          fvp[q][ks] = Vr[sp * RS + o + ks * 64]; fvm[q][ks] = Vr[sm * RS + o + ks * 64];
-          fdp[q][ks] = Dr[sp * RS + o + ks * 64]; fdm[q][ks] = Dr[sm * RS + o + ks * 64];
+          fvp[q][ks] = fb[SP * RS + q * NT * 32 + ks * 64]; fvm[q][ks] = fb[SM * RS + q * NT * 32 + ks * 64];
+          fdp[q][ks] = fb[(3 + SP) * RS + q * NT * 32 + ks * 64]; fdm[q][ks] = fb[(3 + SM) * RS + q * NT * 32 + ks * 64];
         }
-      }
 #pragma unroll
       for (int ks = 0; ks < NT / 2; ++ks)
 #pragma unroll
@@ -173,10 +175,38 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wino_ring(WWRArgs a) {
           acc[1][q] = MFMA_32x32x2(fdp[q][ks], fvp[q][ks], acc[1][q]);     // dy plane p,     input plane p     : dz = 1
           acc[0][q] = MFMA_32x32x2(fdp[q][ks], fvm[q][ks], acc[0][q]);     // dy plane p,     input plane p - 1 : dz = 0
         }
-      if (has1) transform(p + 1);
+      if (has1) transform(std::integral_constant<int, (P6 + 1) & 1>(), std::integral_constant<int, (P6 + 1) % 3>());
       SCHED_BARRIER();
-      if (has2) commit_plane(p + 2);
+      if (has2) commit_plane(std::integral_constant<int, P6 & 1>());        // plane p + 2 has the parity of p
       __syncthreads();
+    };
+
+    // ---- prologue of the column: plane 0 staged and transformed, plane 1 staged, ring slot of plane -1 zeroed ----
+    load_plane(0);
+    commit_plane(std::integral_constant<int, 0>());
+    if (a.D > 1) load_plane(1);
+    {
+      float4* z4 = reinterpret_cast<float4*>(Vr + 2 * RS);  // slot (-1) % 3 == 2 of both rings
+      float4* y4 = reinterpret_cast<float4*>(Dr + 2 * RS);
+      for (int i = tid; i < RS / 4; i += 512) { z4[i] = make_float4(0.f, 0.f, 0.f, 0.f); y4[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+    __syncthreads();
+    transform(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+    if (a.D > 1) commit_plane(std::integral_constant<int, 1>());
+    __syncthreads();
+
+    for (int p = 0; p < a.D; p += 6) {
+      step(p, std::integral_constant<int, 0>());
+      if (p + 1 >= a.D) break;
+      step(p + 1, std::integral_constant<int, 1>());
+      if (p + 2 >= a.D) break;
+      step(p + 2, std::integral_constant<int, 2>());
+      if (p + 3 >= a.D) break;
+      step(p + 3, std::integral_constant<int, 3>());
+      if (p + 4 >= a.D) break;
+      step(p + 4, std::integral_constant<int, 4>());
+      if (p + 5 >= a.D) break;
+      step(p + 5, std::integral_constant<int, 5>());
     }
   }
 

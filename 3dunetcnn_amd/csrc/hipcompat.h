@@ -59,6 +59,14 @@ __device__ __forceinline__ pkf2 pk_fma(pkf2 a, pkf2 b, pkf2 c) { return __builti
   do { if ((bytes) > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); } while (0)
 #endif
 
+// a value the program knows to be the same in all 64 lanes (derived from the wave index): moved to a scalar register, so that a branch on
+// it is a scalar branch and a select on it disappears
+#ifdef MI355_EMU
+#define WAVE_UNIFORM(x) (x)
+#else
+#define WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
 #define MI355_OK 0
 #define MI355_EINVAL (-1)
 #define MI355_EUNSUPPORTED (-2)
