@@ -519,388 +519,3 @@ extern "C" int32_t mi355_conv3d_wino_stats_blocks(const mi355_act* y) {
   const long long b = (long long)ceil_div(y->d, 2) * ceil_div(y->h, 8) * ceil_div(y->w, 16);
   return b > 0 && b <= 0x7fffffffLL ? (int32_t)b : 0;
 }
-
-// =====================================================================================================================================
-// Weight gradient in the same Winograd domain: F(3x3, 2x2) in the (y, x) plane, direct along z. PREPARED ON THE EMULATOR, first version
-// (three barriers per step, no pipelining).
-//   dw[co][ci][dz][a][b] = sum_{n, z, tiles} sum_{i,j<2} dy[z][2ty+i][2tx+j][co] * in(x)[z+dz-1][2ty+i+a-1][2tx+j+b-1][ci]
-//                        = G^T [ sum_{n, z, tiles} (A h A^T) (.) (B^T d B) ] G        per (co, ci, dz)
-// with h the 2x2 dy tile, d the 4x4 input window of the SAME tile (the forward kernel's window), B^T as in the forward kernel,
-// A = [[1,0],[1,1],[1,-1],[0,-1]] and G^T = [[1,1/2,1/2,0],[0,1/2,-1/2,0],[0,1/2,1/2,1]] (the F(2,3) output / filter transforms with their
-// roles exchanged; checked against the direct sum in double). 16 multiplications per tile and (ci, co, dz) instead of 4 x 9 = 36.
-// Workgroup = 512 threads = 8 waves for one (32 co x 32 ci pair, dz, split): per step one 8x8-voxel plane tile (16 Winograd tiles = the K
-// dimension of 8 MFMAs per point); wave w owns points 2w, 2w + 1 (two 32x32 accumulator tiles). Partial results go to the slab workspace
-// of conv3d_wgrad.hip ([pair][slab][tap][32 co][32 ci]) and are reduced by its deterministic second pass.
-int mi355_wgrad_reduce_launch(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles, void* stream);
-
-struct WinoWArgs {
-  const float* x; int xld;
-  const float* dy; int dyld;
-  float* ws;
-  const float* in_scale; const float* in_shift; float slope; const float* in_slope;
-  int N, D, H, W, Cin, Cout;
-  int tilesY, tilesX, ntiles;            // plane tiles: index = ((n * D + z) * tilesY + ty) * tilesX + tx
-  int splits, ciTiles, coTiles;
-};
-
-template <int INMODE>
-__global__ __launch_bounds__(512) void conv3d_wino2d_wgrad(WinoWArgs a) {
-  constexpr int TY = 8, TX = 8, HY = 10, HX = 10, HV = HY * HX, XS = 36, TS = 16;
-  constexpr int XSF = HV * XS, DSF = 64 * XS, VF = 16 * 32 * TS;
-  constexpr int LDSF = XSF + DSF + 2 * VF;                       // 22288 floats = 87 KB (>= 16384: the output transform's exchange)
-  __shared__ __attribute__((aligned(16))) float lds[LDSF];
-  float* xs = lds; float* dss = lds + XSF; float* V = dss + DSF; float* Dv = V + VF;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
-  const int split = blockIdx.x, pair = blockIdx.y, dz = blockIdx.z;
-  const int cot = pair / a.ciTiles, cit = pair % a.ciTiles;
-  const int ci0 = cit * 32, co0 = cot * 32;
-  const int per = (a.ntiles + a.splits - 1) / a.splits;
-  const int t_begin = split * per, t_end = t_begin + per < a.ntiles ? t_begin + per : a.ntiles;
-
-  f32x16 acc[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-  const int tt = tid >> 5, tc = tid & 31;                        // transform: (Winograd tile 0..15, channel 0..31)
-  const int tty = tt >> 2, ttx = tt & 3;
-
-  for (int pt = t_begin; pt < t_end; ++pt) {
-    int b = pt;
-    const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
-    const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
-    const int z = b % a.D, n = b / a.D;
-    const int iz = z + dz - 1;
-    if (iz < 0 || iz >= a.D) continue;                           // the input plane is padding: no contribution (workgroup-uniform)
-    __syncthreads();
-    // ---- stage the haloed input plane tile (32 channels) and the dy plane tile (32 channels) ----
-    for (int u = tid; u < HV * 8; u += 512) {
-      const int hv = u >> 3, q = u & 7;
-      const int iy = ty0 - 1 + hv / HX, ix = tx0 - 1 + hv % HX;
-      const int c = ci0 + 4 * q;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin) {
-        v = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + c);
-        if (INMODE == MI355_IN_AFFINE_ACT) {
-          const float4 sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
-          const float4 sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
-          float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
-          if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + c);
-          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-          v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
-        }
-      }
-      *reinterpret_cast<float4*>(xs + hv * XS + 4 * q) = v;
-    }
-    {
-      const int vv = tid >> 3, q = tid & 7;                      // 64 voxels x 8 channel quads = 512 units
-      const int yy = ty0 + (vv >> 3), xx = tx0 + (vv & 7);
-      const int c = co0 + 4 * q;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (yy < a.H && xx < a.W && c < a.Cout) {
-        const float* p = a.dy + ((((size_t)n * a.D + z) * a.H + yy) * a.W + xx) * a.dyld + c;
-        // dy channel counts need not be multiples of 4 beyond Cout: guarded element-wise
-        v.x = p[0];
-        if (c + 1 < a.Cout) v.y = p[1];
-        if (c + 2 < a.Cout) v.z = p[2];
-        if (c + 3 < a.Cout) v.w = p[3];
-      }
-      *reinterpret_cast<float4*>(dss + vv * XS + 4 * q) = v;
-    }
-    __syncthreads();
-    // ---- transforms: V = B^T d B (input window of tile tt, channel tc), Dv = A h A^T (dy tile tt, channel tc) ----
-    {
-      float d[4][4], t[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) d[r][s] = xs[((2 * tty + r) * HX + 2 * ttx + s) * XS + tc];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        t[0][s] = d[0][s] - d[2][s]; t[1][s] = d[1][s] + d[2][s]; t[2][s] = d[2][s] - d[1][s]; t[3][s] = d[1][s] - d[3][s];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        V[((4 * i + 0) * TS + tt) * 32 + tc] = t[i][0] - t[i][2];
-        V[((4 * i + 1) * TS + tt) * 32 + tc] = t[i][1] + t[i][2];
-        V[((4 * i + 2) * TS + tt) * 32 + tc] = t[i][2] - t[i][1];
-        V[((4 * i + 3) * TS + tt) * 32 + tc] = t[i][1] - t[i][3];
-      }
-      const float h00 = dss[((2 * tty) * TX + 2 * ttx) * XS + tc], h01 = dss[((2 * tty) * TX + 2 * ttx + 1) * XS + tc];
-      const float h10 = dss[((2 * tty + 1) * TX + 2 * ttx) * XS + tc], h11 = dss[((2 * tty + 1) * TX + 2 * ttx + 1) * XS + tc];
-      // rows: A h -> (h0., h0. + h1., h0. - h1., -h1.), then the same along the columns
-      const float r0[2] = {h00, h01}, r1[2] = {h00 + h10, h01 + h11}, r2[2] = {h00 - h10, h01 - h11}, r3[2] = {-h10, -h11};
-      const float* rr[4] = {r0, r1, r2, r3};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        Dv[((4 * i + 0) * TS + tt) * 32 + tc] = rr[i][0];
-        Dv[((4 * i + 1) * TS + tt) * 32 + tc] = rr[i][0] + rr[i][1];
-        Dv[((4 * i + 2) * TS + tt) * 32 + tc] = rr[i][0] - rr[i][1];
-        Dv[((4 * i + 3) * TS + tt) * 32 + tc] = -rr[i][1];
-      }
-    }
-    __syncthreads();
-    // ---- point-wise products over the 16 tiles: acc[co][ci] += Dv[p][co][t] * V[p][ci][t] ----
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int p = 2 * wave + q;
-#pragma unroll
-      for (int kg = 0; kg < 2; ++kg) {
-        // [point][tile][channel] layout: the transform writes and these reads are both 32 consecutive floats per instruction
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int t = 8 * kg + 4 * half + e;
-          acc[q] = MFMA_32x32x2(Dv[(p * TS + t) * 32 + li], V[(p * TS + t) * 32 + li], acc[q]);
-        }
-      }
-    }
-  }
-
-  // ---- output transform: taps[a][b] = sum_{i,j} G^T[a][i] G^T[b][j] M[4i + j], through LDS; slab write ----
-  __syncthreads();
-  float* Ms = lds;                                               // [16 points][32 co][32 ci]
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;         // co
-      Ms[((2 * wave + q) * 32 + row) * 32 + li] = acc[q][r];
-    }
-  __syncthreads();
-  const float GT[3][4] = {{1.f, 0.5f, 0.5f, 0.f}, {0.f, 0.5f, -0.5f, 0.f}, {0.f, 0.5f, 0.5f, 1.f}};
-  float* slab = a.ws + (((size_t)pair * a.splits + split) * 27 + dz * 9) * 1024;
-  for (int idx = tid; idx < 9 * 1024; idx += 512) {
-    const int tap = idx >> 10, e = idx & 1023;
-    const int ta = tap / 3, tb = tap % 3;
-    float o = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o += GT[ta][i] * GT[tb][j] * Ms[(4 * i + j) * 1024 + e];
-    slab[(size_t)tap * 1024 + e] = o;
-  }
-}
-
-// Software-pipelined form of the same kernel: the 16 points are split into two halves (rows i = 0,1 and i = 2,3 of the point grid); wave w
-// owns point w of each half. While the MFMAs of one half run, the other half of the same / the next plane tile is transformed into the
-// other buffer, and the global loads of the tile after next are in flight: two barriers per plane tile, none of them waiting for memory.
-template <int INMODE>
-__global__ __launch_bounds__(512) void conv3d_wino2d_wgrad_pipe(WinoWArgs a) {
-  constexpr int TY = 8, TX = 8, HX = 10, HV = 100, XS = 36, TS = 16;
-  constexpr int XSF = HV * XS, DSF = 64 * XS, HF = 8 * 32 * TS;  // one staged x tile, one staged dy tile, one half of V or Dv
-  constexpr int LDSF = 2 * (XSF + DSF) + 4 * HF;                 // 28192 floats = 110 KB
-  __shared__ __attribute__((aligned(16))) float lds[LDSF];
-  auto xsb_ = [&](int i) { return lds + i * (XSF + DSF); };                      // staged tile buffer i: x tile, then the dy tile
-  auto vh_ = [&](int h) { return lds + 2 * (XSF + DSF) + h * 2 * HF; };          // half h: V, then Dv
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
-  const int split = blockIdx.x, pair = blockIdx.y, dz = blockIdx.z;
-  const int cot = pair / a.ciTiles, cit = pair % a.ciTiles;
-  const int ci0 = cit * 32, co0 = cot * 32;
-  const int per = (a.ntiles + a.splits - 1) / a.splits;
-  const int t_begin = split * per, t_end = t_begin + per < a.ntiles ? t_begin + per : a.ntiles;
-
-  f32x16 acc[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-  const int tt = tid >> 5, tc = tid & 31, tty = tt >> 2, ttx = tt & 3;
-
-  // plane tiles whose input plane z + dz - 1 is padding contribute nothing: the walk skips them (workgroup-uniform)
-  auto next_valid = [&](int pt) {
-    while (pt < t_end) {
-      const int z = (pt / (a.tilesX * a.tilesY)) % a.D, iz = z + dz - 1;
-      if (iz >= 0 && iz < a.D) break;
-      ++pt;
-    }
-    return pt;
-  };
-  struct Staged { float4 x[2]; float4 d; };
-  auto tile_loads = [&](int pt, Staged& st) {
-    int b = pt;
-    const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
-    const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
-    const int z = b % a.D, n = b / a.D, iz = z + dz - 1;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int u = tid + 512 * k;
-      st.x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (u >= HV * 8) continue;
-      const int hv = u >> 3, q = u & 7;
-      const int iy = ty0 - 1 + hv / HX, ix = tx0 - 1 + hv % HX, c = ci0 + 4 * q;
-      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin) {
-        float4 v = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + c);
-        if (INMODE == MI355_IN_AFFINE_ACT) {
-          const float4 sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c);
-          const float4 sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c);
-          float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
-          if (a.in_slope) sl = *reinterpret_cast<const float4*>(a.in_slope + c);
-          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-          v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
-        }
-        st.x[k] = v;
-      }
-    }
-    {
-      const int vv = tid >> 3, q = tid & 7;
-      const int yy = ty0 + (vv >> 3), xx = tx0 + (vv & 7), c = co0 + 4 * q;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (yy < a.H && xx < a.W && c < a.Cout) {
-        const float* p = a.dy + ((((size_t)n * a.D + z) * a.H + yy) * a.W + xx) * a.dyld + c;
-        v.x = p[0];
-        if (c + 1 < a.Cout) v.y = p[1];
-        if (c + 2 < a.Cout) v.z = p[2];
-        if (c + 3 < a.Cout) v.w = p[3];
-      }
-      st.d = v;
-    }
-  };
-  auto tile_store = [&](float* buf, const Staged& st) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int u = tid + 512 * k;
-      if (u >= HV * 8) continue;
-      *reinterpret_cast<float4*>(buf + (u >> 3) * XS + 4 * (u & 7)) = st.x[k];
-    }
-    *reinterpret_cast<float4*>(buf + XSF + (tid >> 3) * XS + 4 * (tid & 7)) = st.d;
-  };
-  // transform the point rows i = 2 * hsel, 2 * hsel + 1 of tile (tty, ttx), channel tc, from the staged tile `buf` into half buffer `vh`
-  auto transform_half = [&](const float* buf, float* vh, int hsel) {
-    float d[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) d[r][s2] = buf[((2 * tty + r) * HX + 2 * ttx + s2) * XS + tc];
-    const float* ds = buf + XSF;
-    const float h00 = ds[((2 * tty) * TX + 2 * ttx) * XS + tc], h01 = ds[((2 * tty) * TX + 2 * ttx + 1) * XS + tc];
-    const float h10 = ds[((2 * tty + 1) * TX + 2 * ttx) * XS + tc], h11 = ds[((2 * tty + 1) * TX + 2 * ttx + 1) * XS + tc];
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      const int i = 2 * hsel + ii;                               // hsel is workgroup-uniform
-      float t[4], r[2];
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2)
-        t[s2] = i == 0 ? d[0][s2] - d[2][s2] : i == 1 ? d[1][s2] + d[2][s2] : i == 2 ? d[2][s2] - d[1][s2] : d[1][s2] - d[3][s2];
-      r[0] = i == 0 ? h00 : i == 1 ? h00 + h10 : i == 2 ? h00 - h10 : -h10;
-      r[1] = i == 0 ? h01 : i == 1 ? h01 + h11 : i == 2 ? h01 - h11 : -h11;
-      float* vp = vh + ((4 * ii) * TS + tt) * 32 + tc;          // [point][tile][channel]: 32 consecutive floats per write instruction
-      vp[0 * 32 * TS] = t[0] - t[2]; vp[1 * 32 * TS] = t[1] + t[2]; vp[2 * 32 * TS] = t[2] - t[1]; vp[3 * 32 * TS] = t[1] - t[3];
-      float* dp = vh + HF + ((4 * ii) * TS + tt) * 32 + tc;
-      dp[0 * 32 * TS] = r[0]; dp[1 * 32 * TS] = r[0] + r[1]; dp[2 * 32 * TS] = r[0] - r[1]; dp[3 * 32 * TS] = -r[1];
-    }
-  };
-  auto mfma_half = [&](const float* vh, f32x16& ac) {           // this wave's point of the half: local index `wave`
-#pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int t = 8 * kg + 4 * half + e;
-        ac = MFMA_32x32x2(vh[HF + (wave * TS + t) * 32 + li], vh[(wave * TS + t) * 32 + li], ac);
-      }
-    }
-  };
-
-  Staged st;
-  int p0 = next_valid(t_begin);
-  if (p0 < t_end) {
-    int p1 = next_valid(p0 + 1);
-    // prologue: tile 0 staged and its first half transformed, tile 1 staged
-    tile_loads(p0, st); tile_store(xsb_(0), st);
-    if (p1 < t_end) { tile_loads(p1, st); tile_store(xsb_(1), st); }
-    __syncthreads();
-    transform_half(xsb_(0), vh_(0), 0);
-    __syncthreads();
-    int cur = 0;                                                 // parity of the staged buffer holding the current tile
-    int pk = p0, pk1 = p1;
-    while (pk < t_end) {
-      const int pk2 = pk1 < t_end ? next_valid(pk1 + 1) : t_end;
-      // phase A: MFMA half 0 of the tile | transform its half 1
-      mfma_half(vh_(0), acc[0]);
-      transform_half(xsb_(cur), vh_(1), 1);
-      __syncthreads();
-      // phase B: MFMA half 1 | transform half 0 of the next tile | stage the tile after next into this tile's buffer
-      if (pk2 < t_end) tile_loads(pk2, st);
-      mfma_half(vh_(1), acc[1]);
-      if (pk1 < t_end) transform_half(xsb_(cur ^ 1), vh_(0), 0);
-      if (pk2 < t_end) tile_store(xsb_(cur), st);
-      __syncthreads();
-      pk = pk1; pk1 = pk2; cur ^= 1;
-    }
-  }
-
-  // ---- output transform through LDS (point of half h, wave w: p = 8 h + w) and slab write: as the three-barrier kernel ----
-  __syncthreads();
-  float* Ms = lds;
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      Ms[((8 * q + wave) * 32 + row) * 32 + li] = acc[q][r];
-    }
-  __syncthreads();
-  const float GT[3][4] = {{1.f, 0.5f, 0.5f, 0.f}, {0.f, 0.5f, -0.5f, 0.f}, {0.f, 0.5f, 0.5f, 1.f}};
-  float* slab = a.ws + (((size_t)pair * a.splits + split) * 27 + dz * 9) * 1024;
-  for (int idx = tid; idx < 9 * 1024; idx += 512) {
-    const int tap = idx >> 10, e = idx & 1023;
-    const int ta = tap / 3, tb = tap % 3;
-    float o = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o += GT[ta][i] * GT[tb][j] * Ms[(4 * i + j) * 1024 + e];
-    slab[(size_t)tap * 1024 + e] = o;
-  }
-}
-
-struct WinoWPlan { int tilesY, tilesX, ntiles, splits, ciTiles, coTiles; size_t ws_bytes; int ok; };
-static WinoWPlan plan_wino_wgrad(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
-  WinoWPlan p; memset(&p, 0, sizeof(p));
-  if (!x || !dy || !d || d->kd != 3 || d->stride != 1 || d->pad != 1 || d->out_mode != MI355_OUT_PLAIN) return p;
-  if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return p;
-  if (x->d != dy->d || x->h != dy->h || x->w != dy->w || x->n != dy->n || x->c % 4 || x->ld % 4) return p;
-  p.tilesY = ceil_div(dy->h, 8); p.tilesX = ceil_div(dy->w, 8);
-  const long long nt = (long long)dy->n * dy->d * p.tilesY * p.tilesX;
-  if (nt <= 0 || nt > 0x7fffffffLL) return p;
-  p.ntiles = (int)nt;
-  p.ciTiles = ceil_div(x->c, 32); p.coTiles = ceil_div(dy->c, 32);
-  const int pairs = p.ciTiles * p.coTiles;
-  int splits = ceil_div(256, 3 * pairs);                          // one 512-thread workgroup per CU: ~256 workgroups in flight
-  const int max_splits = p.ntiles >= 16 ? p.ntiles / 16 : 1;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  const int per = ceil_div(p.ntiles, splits);
-  p.splits = ceil_div(p.ntiles, per);
-  p.ws_bytes = (size_t)pairs * p.splits * 27 * 1024 * sizeof(float);
-  p.ok = 1;
-  return p;
-}
-
-extern "C" size_t mi355_conv3d_wino_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
-  const WinoWPlan p = plan_wino_wgrad(x, dy, d);
-  return p.ok ? p.ws_bytes : 0;
-}
-
-// dw: OIDHW [dy->c][x->c][3][3][3]; same contract as mi355_conv3d_wgrad for kd 3 / stride 1 / pad 1 (norm prologue on x honoured)
-extern "C" int mi355_conv3d_wino_wgrad(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d, void* ws, size_t ws_bytes,
-                                       void* stream) {
-  if (!x || !dy || !dw || !d || !ws || !x->p || !dy->p) return MI355_EINVAL;
-  const WinoWPlan p = plan_wino_wgrad(x, dy, d);
-  if (!p.ok) return MI355_EUNSUPPORTED;
-  if (ws_bytes < p.ws_bytes) return MI355_EWORKSPACE;
-  if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift || !(d->act_slope >= 0.f && d->act_slope <= 1.f))) return MI355_EINVAL;
-  WinoWArgs a;
-  a.x = (const float*)x->p; a.xld = x->ld; a.dy = (const float*)dy->p; a.dyld = dy->ld; a.ws = (float*)ws;
-  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope;
-  a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Cout = dy->c;
-  a.tilesY = p.tilesY; a.tilesX = p.tilesX; a.ntiles = p.ntiles; a.splits = p.splits; a.ciTiles = p.ciTiles; a.coTiles = p.coTiles;
-  const dim3 grid(p.splits, p.ciTiles * p.coTiles, 3);
-  const char* pe = getenv("MI355_WINO_PIPE");                  // same A/B switch as the forward kernel; default: pipelined
-  if (!(pe && pe[0] == '0')) {
-    if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wino2d_wgrad_pipe<MI355_IN_PLAIN>), grid, dim3(512), 0, stream, a);
-    else LAUNCH((conv3d_wino2d_wgrad_pipe<MI355_IN_AFFINE_ACT>), grid, dim3(512), 0, stream, a);
-  } else if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_wino2d_wgrad<MI355_IN_PLAIN>), grid, dim3(512), 0, stream, a);
-  else LAUNCH((conv3d_wino2d_wgrad<MI355_IN_AFFINE_ACT>), grid, dim3(512), 0, stream, a);
-  const int rc = LAUNCH_CHECK(); if (rc) return rc;
-  return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, p.splits, p.ciTiles, stream);
-}

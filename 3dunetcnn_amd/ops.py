@@ -127,7 +127,7 @@ class Backend:
     # measured twice (profiles/r2_winograd_prep_measurement.txt, r3_winograd_landing.txt): no gain on the 16^3 level (256 channels), 20-38 % above it
     WINO_MIN_VOXELS = 32 ** 3
     # executed / algorithmic multiplications of the Winograd kernels (bench.py reports both rates)
-    WINO_EXECUTED = {"conv3d_wino2d": 12.0 / 27.0, "conv3d_wino2d_wgrad (+reduce)": 16.0 / 36.0, "conv3d_wgrad_wino_ring (+reduce)": 16.0 / 36.0}
+    WINO_EXECUTED = {"conv3d_wino2d": 12.0 / 27.0, "conv3d_wgrad_wino_ring (+reduce)": 16.0 / 36.0}
 
     def __init__(self, lib=None, device=None):
         self.lib = lib if lib is not None else _lib.load_library()
@@ -143,12 +143,11 @@ class Backend:
         # error equal to the direct kernel's. Measured on MI355X (round 3, profiles/r3_winograd_landing.txt): layer set 21.96 -> 15.28 ms,
         # UNet3D 128^3 batch-2 step 87.1 -> 75.2 ms. MI355_WINOGRAD=0 selects the direct kernels (the A/B and cross-check form).
         self.winograd = os.environ.get("MI355_WINOGRAD", "1") == "1"
-        # Winograd weight gradient F(3x3, 2x2) x direct z: measured 2x SLOWER than conv3d_wgrad_ring (4.06 vs 1.94 ms at 32->32 @128^3):
-        # stays an experiment switch
-        self.winograd_wgrad = os.environ.get("MI355_WINOGRAD_WGRAD", "0") == "1"
         # Weight gradients of the same layers: "wino" = the plane-ring Winograd kernel (csrc/conv3d_wgrad_wino.hip: all three dz per
         # workgroup, every plane transformed once), "direct" = conv3d_wgrad_ring. Measured on MI355X (round 3,
-        # profiles/r3_wgrad_wino_ring_ab.txt): 32->32 @128^3 1.93 -> 1.21 ms, layer set 1.55-1.63x, UNet3D step 74.7 -> 64.1 ms.
+        # profiles/r3_wgrad_wino_ring_ab.txt): 32->32 @128^3 1.93 -> 1.21 (-> 1.13) ms, layer set 1.55-1.7x, UNet3D step 74.7 -> 64.1 ms.
+        # (A first Winograd weight gradient -- one dz per workgroup, planes transformed three times -- measured 2x SLOWER than the ring
+        # kernel, profiles/r3_winograd_landing.txt, and was deleted.)
         self.wgrad_form = os.environ.get("MI355_WGRAD_FORM", "wino")
 
         self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
@@ -337,23 +336,6 @@ class Backend:
                     e1.record()
                     nvox = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3]
                     self.prof.append(("conv3d_wgrad_wino_ring (+reduce)", 2.0 * nvox * x.c * dy.c * 27,
-                                      4.0 * (nvox * (x.c + dy.c) + 27 * x.c * dy.c), e0, e1))
-                return
-        if (self.winograd_wgrad and self.precision == PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT)
-                and out_mode == OUT_PLAIN and x.c >= 8 and dy.c >= 8 and x.shape[1] * x.shape[2] * x.shape[3] >= self.WINO_MIN_VOXELS):
-            nbytes = self.lib.mi355_conv3d_wino_wgrad_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))
-            if nbytes:
-                ws = self.ws(nbytes)
-                assert dw.is_contiguous()
-                if self.prof is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                check(self.lib.mi355_conv3d_wino_wgrad(ctypes.byref(xd), ctypes.byref(dyd), dw.data_ptr(), ctypes.byref(d), ws.data_ptr(),
-                                                       ws.numel() * 4, self.stream()), "conv3d_wino_wgrad")
-                if self.prof is not None:
-                    e1.record()
-                    nvox = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3]
-                    self.prof.append(("conv3d_wino2d_wgrad (+reduce)", 2.0 * nvox * x.c * dy.c * 27,
                                       4.0 * (nvox * (x.c + dy.c) + 27 * x.c * dy.c), e0, e1))
                 return
         nbytes = self.lib.mi355_conv3d_wgrad_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))

@@ -292,12 +292,10 @@ int mi355_wino_pack_weight(const float* w, float* up, int32_t cout, int32_t cin,
 int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const mi355_act* y, const mi355_conv_desc* desc, void* stream);
 /* records per sample its fused-statistics epilogues (desc->moments_out / desc->gn_bwd, formats of gn_fuse.h) write: 2 x 8 x 16 voxel tiles */
 int32_t mi355_conv3d_wino_stats_blocks(const mi355_act* y);
-/* weight gradient in the same domain (F(3x3, 2x2) x direct z): contract of mi355_conv3d_wgrad for kd 3 / stride 1 / pad 1 */
-size_t mi355_conv3d_wino_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* desc);
-int mi355_conv3d_wino_wgrad(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* desc, void* ws, size_t ws_bytes,
-                            void* stream);
-/* the z-marching plane-ring form of the same weight gradient (csrc/conv3d_wgrad_wino.hip): all three dz per workgroup, every plane
- * staged and transformed once. MI355_EUNSUPPORTED for channel counts that are not multiples of 4 (use mi355_conv3d_wgrad). */
+/* weight gradient in the same domain, F(3x3, 2x2) x direct z (csrc/conv3d_wgrad_wino.hip; replaces the ATen weight-gradient call behind
+ * nn.Conv3d.backward for resnet.py:12-17): contract of mi355_conv3d_wgrad for kd 3 / stride 1 / pad 1. A z-marching plane ring: all
+ * three dz per workgroup, every plane staged and transformed once. MI355_EUNSUPPORTED for channel counts that are not multiples
+ * of 4 (use mi355_conv3d_wgrad). */
 size_t mi355_conv3d_wgrad_wino_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* desc);
 int mi355_conv3d_wgrad_wino(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* desc, void* ws, size_t ws_bytes,
                             void* stream);

@@ -129,7 +129,7 @@ def test_wino_norm_backward_sums_from_dgrad_epilogue(hip_backend, kw):
 
 @pytest.mark.gpu
 def test_whole_network_step_on_the_winograd_kernels(hip_backend):
-    """MI355_WINOGRAD + MI355_WINOGRAD_WGRAD switches: every eligible 3x3x3 stride-1 forward / dgrad / wgrad conv of a UNet3D step on the
+    """Product routing with the size threshold removed: every eligible 3x3x3 stride-1 forward / dgrad / wgrad conv of a UNet3D step on the
     Winograd kernels, against the golden bundle generated from the reference."""
     import importlib
     import os
@@ -137,8 +137,8 @@ def test_whole_network_step_on_the_winograd_kernels(hip_backend):
     losses = importlib.import_module("3dunetcnn_amd.losses")
     g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet3d_small.pt"))
     be = hip_backend
-    old_routing = (be.winograd, be.winograd_wgrad)
-    be.winograd = be.winograd_wgrad = True
+    old_routing = (be.winograd, be.wgrad_form)
+    be.winograd, be.wgrad_form = True, "wino"
     be.WINO_MIN_VOXELS = 0                 # the golden bundle is 20 x 16 x 24: route every level
     calls = {"n": 0}
     orig = be.conv_fwd_wino
@@ -155,32 +155,13 @@ def test_whole_network_step_on_the_winograd_kernels(hip_backend):
         loss = crit(out, g["y"].cuda())
         loss.backward()
     finally:
-        be.winograd, be.winograd_wgrad = old_routing
+        be.winograd, be.wgrad_form = old_routing
         del be.conv_fwd_wino, be.WINO_MIN_VOXELS
     assert calls["n"] >= 20
     assert C.rel_err(out, g["logits"]) < 1e-3
     assert abs(float(loss.detach()) - float(g["loss"])) / float(g["loss"]) < 1e-3
     for k, p in m.named_parameters():
         assert C.rel_err(p.grad, g["grads"][k]) < 1e-3, k
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("kw", [
-    dict(n=2, cin=32, cout=32, dhw=(3, 8, 8), norm=True),
-    dict(n=1, cin=8, cout=64, dhw=(4, 9, 17)),                                   # ragged plane tiles, two co tiles
-    dict(n=1, cin=40, cout=96, dhw=(5, 3, 7), norm=True, slope=0.01),            # partial channel tiles
-    dict(n=2, cin=32, cout=32, dhw=(5, 16, 32), norm=True),                      # many plane tiles per workgroup split
-])
-def test_wino_wgrad_matches_autograd(hip_backend, kw):
-    be = hip_backend
-    be.winograd_wgrad = True
-    be.WINO_MIN_VOXELS = 0
-    try:
-        assert C.case_conv_wgrad(be, **kw) < 1e-4
-    finally:
-        be.winograd_wgrad = False
-        del be.WINO_MIN_VOXELS
-
 
 
 @pytest.mark.gpu
