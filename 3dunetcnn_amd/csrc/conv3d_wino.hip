@@ -34,6 +34,7 @@ struct WinoArgs {
   const float* out_chscale; const float* bias;
   int N, D, H, W, Cin, CinP, Cout, CoutP;
   int tilesZ, tilesY, tilesX, coTiles;
+  int zsplits, zper;                     // conv3d_wino2d_zring: z ranges [zs * zper, min(D, (zs + 1) * zper)) per workgroup
   GnFuseArgs g;                          // norm statistics fused into the epilogue (gn_fuse.h), as in conv3d_mfma
 };
 
@@ -419,6 +420,291 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_wino2d(WinoA
   }
 }
 
+// =====================================================================================================================================
+// The same operation as a z-MARCHING workgroup (round 3). conv3d_wino2d above stages and transforms 4 input planes for every 2 output
+// planes, so a transformed (plane, channel chunk) feeds 1.5 MFMA groups on average and the SQ counters show the price
+// (profiles/r3_sq_counters_wino.txt: 8.2 vector-ALU instructions per MFMA against 2.8 in the direct kernel; MFMA pipe busy 45 %).
+// Here a 512-thread workgroup owns an 8 (y) x 16 (x) voxel column x 32 output channels over a whole z range and walks the input planes
+// once: every (plane, 8-channel chunk) is staged and transformed ONCE and multiplied into the three output planes that see it
+// (dz = 0, 1, 2), whose accumulators stay in registers: 16 points x 3 output planes = 48 tiles over 8 waves = 6 per wave (96 registers),
+// 24 MFMAs per wave and phase from 2 A fragments (ds_read_b128) and 6 weight fragments. When input plane t has been multiplied, output
+// plane t - 1 is complete: its output transform (in-wave over j, across the waves over i through 64 KB of LDS), bias / residual /
+// Dropout3d scale / store and the fused norm statistics run, and its accumulator slot is zeroed for output plane t + 2. The plane loop
+// is unrolled by three, so the slot of every accumulator is a compile-time index.
+// Software pipeline, one barrier per phase (= input plane x channel chunk): MFMAs of phase k | the weight fragments of phase k + 1 are
+// requested once the MFMAs of phase k have been issued | transform of phase k + 1 | global loads of phase k + 2 in flight, written to
+// the other staging buffer after the MFMAs.
+// Fused statistics: one record per (sample, workgroup, channel) accumulated over the whole z range (instead of one per 2 x 8 x 16 tile).
+template <int INMODE, int FUSE>
+__global__ __launch_bounds__(512) void conv3d_wino2d_zring(WinoArgs a) {
+  constexpr int TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HV = HY * HX;
+  constexpr int KC = 8, XS = 12, NT = 32;
+  constexpr int XSF = HV * XS + 16, VSF = 16 * NT * KC, PF = 8 * 2 * 32 * 32;
+  DYN_LDS(lds);
+  float* xs = lds;                                         // 2 staged chunks [halo voxel][8 + 4 pad]
+  float* vs = lds + 2 * XSF;                               // 2 transformed chunks [point][tile][channel]
+  float* P = vs + 2 * VSF;                                 // output-transform exchange [wave][b][tile][co]
+  float* prm = P + PF;                                     // norm prologue of this sample: scale | shift | slope, CinP each
+  const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6), half = lane >> 5, li = lane & 31;
+  int b = blockIdx.x;
+  const int cot = b % a.coTiles; b /= a.coTiles;
+  const int txi = b % a.tilesX; b /= a.tilesX;
+  const int tyi = b % a.tilesY; b /= a.tilesY;
+  const int zs = b % a.zsplits; b /= a.zsplits;
+  const int n = b;
+  const int tx0 = txi * TX, ty0 = tyi * TY, co_base = cot * 32;
+  const int zb = zs * a.zper, ze = zb + a.zper < a.D ? zb + a.zper : a.D, L = ze - zb;
+  const int NC = a.CinP / KC, K = (L + 2) * NC;            // phases: input planes zb - 1 .. ze, NC chunks each
+
+  if (INMODE == MI355_IN_AFFINE_ACT) {
+    for (int c = tid; c < a.CinP; c += 512) {
+      const bool in = c < a.Cin;
+      prm[c] = in ? a.in_scale[(size_t)n * a.Cin + c] : 0.f;
+      prm[a.CinP + c] = in ? a.in_shift[(size_t)n * a.Cin + c] : 0.f;
+      prm[2 * a.CinP + c] = in ? (a.in_slope ? a.in_slope[c] : a.slope) : 0.f;
+    }
+  }
+
+  f32x16 acc[3][2];                                        // [output plane slot][point q: p = 2 * wave + q]
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][q][r] = 0.f;
+
+  // staging unit of this thread: (halo voxel sv, channel quad sq) of the 180 x 2 units of a chunk; fixed for the whole kernel
+  const bool sunit = tid < HV * 2;
+  const int sv = sunit ? tid >> 1 : 0, sq = tid & 1;
+  const int siy = ty0 - 1 + sv / HX, six = tx0 - 1 + sv % HX;
+  const bool sin = sunit && siy >= 0 && siy < a.H && six >= 0 && six < a.W;
+  const size_t xplane = (size_t)a.H * a.W * a.xld;
+  const float* xsrc = a.x + (size_t)n * a.D * xplane + ((size_t)(siy < 0 ? 0 : (siy < a.H ? siy : a.H - 1)) * a.W + (six < 0 ? 0 : (six < a.W ? six : a.W - 1))) * a.xld;
+  // transform unit: (channel tc, tile tt) and the row half th (wave-uniform): point rows i = 2 th, 2 th + 1
+  const int tc = tid & 7, tt = (tid >> 3) & 31, th = wave >> 2;
+  const int tty = tt >> 3, ttx = tt & 7;
+  const float4* up4 = reinterpret_cast<const float4*>(a.up);
+  const int CQ = a.CinP / 4;
+
+  float4 ld;
+  bool lok;
+  // a phase is (input plane index t, chunk index ci); `adv` steps it forward by one (no division in the loop)
+  auto adv = [&](int& t, int& ci) { if (++ci >= NC) { ci = 0; ++t; } };
+  auto loads = [&](int t, int ci) {
+    const int ip = zb - 1 + t, c0 = ci * KC;
+    const int c = c0 + 4 * sq;
+    lok = sin && ip >= 0 && ip < a.D && c < a.Cin;
+    const int ipc = ip < 0 ? 0 : (ip < a.D ? ip : a.D - 1);
+    ld = *reinterpret_cast<const float4*>(xsrc + (size_t)ipc * xplane + (c < a.Cin ? c : 0));
+  };
+  auto commit = [&](int ci, int par) {
+    if (!sunit) return;
+    float4 v = ld;
+    if (INMODE == MI355_IN_AFFINE_ACT) {
+      const int c = ci * KC + 4 * sq;
+      const float4 sc = *reinterpret_cast<const float4*>(prm + c), sh = *reinterpret_cast<const float4*>(prm + a.CinP + c);
+      const float4 sl = *reinterpret_cast<const float4*>(prm + 2 * a.CinP + c);
+      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+      v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
+    }
+    if (!lok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(xs + par * XSF + sv * XS + 4 * sq) = v;
+  };
+  auto transform = [&](int par) {
+    const float* col = xs + par * XSF + ((2 * tty) * HX + 2 * ttx) * XS + tc;
+    float* vd = vs + par * VSF + tt * KC + tc;             // point 4 i + j at ((4 i + j) * NT + tt) * KC + tc
+    float t0[4], t1[4];
+    if (th == 0) {                                         // rows i = 0: d0 - d2, i = 1: d1 + d2
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const float d0 = col[s2 * XS], d1 = col[(HX + s2) * XS], d2 = col[(2 * HX + s2) * XS];
+        t0[s2] = d0 - d2; t1[s2] = d1 + d2;
+      }
+      vd[(0 * NT) * KC] = t0[0] - t0[2]; vd[(1 * NT) * KC] = t0[1] + t0[2]; vd[(2 * NT) * KC] = t0[2] - t0[1]; vd[(3 * NT) * KC] = t0[1] - t0[3];
+      vd[(4 * NT) * KC] = t1[0] - t1[2]; vd[(5 * NT) * KC] = t1[1] + t1[2]; vd[(6 * NT) * KC] = t1[2] - t1[1]; vd[(7 * NT) * KC] = t1[1] - t1[3];
+    } else {                                               // rows i = 2: d2 - d1, i = 3: d1 - d3
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const float d1 = col[(HX + s2) * XS], d2 = col[(2 * HX + s2) * XS], d3 = col[(3 * HX + s2) * XS];
+        t0[s2] = d2 - d1; t1[s2] = d1 - d3;
+      }
+      vd[(8 * NT) * KC] = t0[0] - t0[2]; vd[(9 * NT) * KC] = t0[1] + t0[2]; vd[(10 * NT) * KC] = t0[2] - t0[1]; vd[(11 * NT) * KC] = t0[1] - t0[3];
+      vd[(12 * NT) * KC] = t1[0] - t1[2]; vd[(13 * NT) * KC] = t1[1] + t1[2]; vd[(14 * NT) * KC] = t1[2] - t1[1]; vd[(15 * NT) * KC] = t1[1] - t1[3];
+    }
+  };
+  float4 bfr[2][3];                                        // weight fragments of the next MFMA phase: [point q][dz]
+  auto b_loads = [&](int ci) {
+    const float4* bp = up4 + (size_t)(2 * ci + half) * a.CoutP + co_base + li;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) bfr[q][dz] = bp[(size_t)(((2 * wave + q) * 3 + dz) * CQ) * a.CoutP];
+  };
+
+  // ---- epilogue state: fused statistics accumulate over the whole z range ----
+  const int ea = (wave & 3) >> 1, eb = wave & 1, eth = wave >> 2;    // this wave's (a, b) output of every 2x2 tile, and its tile half
+  const int co = co_base + li;
+  const bool cov = co < a.Cout;
+  float bs = 0.f, cs = 1.f;
+  if (cov && a.bias) bs = a.bias[co];
+  if (cov && a.out_chscale) cs = a.out_chscale[(size_t)n * a.Cout + co];
+  float K0 = 0.f, s0 = 0.f, s1 = 0.f, gsc = 1.f, gsh = 0.f, gmean = 0.f, grstd = 1.f;
+  int cnt = 0;
+  if constexpr (FUSE == 2) {
+    const int coc = cov ? co : a.Cout - 1;
+    const int grp = coc / (a.Cout / a.g.ggroups);
+    gsc = a.g.gscale[(size_t)n * a.Cout + coc]; gsh = a.g.gshift[(size_t)n * a.Cout + coc];
+    gmean = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
+  }
+  // output plane z from accumulator slot SE (its last input plane has been multiplied and the phase barrier passed)
+  auto epilogue = [&](int z, auto sec) {
+    constexpr int SE = decltype(sec)::value;
+    // in-wave part over this wave's two j: A^T rows (1, 1, 1, 0) and (0, 1, -1, -1)
+    const bool jh = wave & 1;                              // wave-uniform: j = 0, 1 or j = 2, 3
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;   // tile
+      const float m0 = acc[SE][0][r], m1 = acc[SE][1][r];
+      P[((wave * 2 + 0) * 32 + row) * 32 + li] = jh ? m0 : m0 + m1;
+      P[((wave * 2 + 1) * 32 + row) * 32 + li] = jh ? -m0 - m1 : m1;
+    }
+    // reads that do not depend on the exchange go out before the barrier: the normalised tensor (FUSE 2) and the residual
+    float gxv[8], rsv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int tile = eth * 16 + half * 8 + r;
+      int yy = ty0 + 2 * (tile >> 3) + ea, xx = tx0 + 2 * (tile & 7) + eb;
+      yy = yy < a.H ? yy : a.H - 1; xx = xx < a.W ? xx : a.W - 1;
+      const size_t vox = (((size_t)n * a.D + z) * a.H + yy) * a.W + xx;
+      if constexpr (FUSE == 2) gxv[r] = a.g.gx[vox * a.g.gxld + (cov ? co : a.Cout - 1)];
+      rsv[r] = a.res ? a.res[vox * a.resld + (cov ? co : a.Cout - 1)] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int tile = eth * 16 + half * 8 + r;
+      const float* pz = P + (eb * 32 + tile) * 32 + li;     // wave w, output column b at ((w * 2 + b) * 32 + tile) * 32 + li
+      // across the waves: row i of the point grid = waves 2 i, 2 i + 1; A^T rows over i: (1, 1, 1, 0) and (0, 1, -1, -1)
+      float v;
+      if (ea == 0) v = (pz[0 * 2048] + pz[1 * 2048]) + (pz[2 * 2048] + pz[3 * 2048]) + (pz[4 * 2048] + pz[5 * 2048]);
+      else v = (pz[2 * 2048] + pz[3 * 2048]) - (pz[4 * 2048] + pz[5 * 2048]) - (pz[6 * 2048] + pz[7 * 2048]);
+      v += bs;
+      const int yy = ty0 + 2 * (tile >> 3) + ea, xx = tx0 + 2 * (tile & 7) + eb;
+      if (!cov || yy >= a.H || xx >= a.W) continue;
+      const size_t vox = (((size_t)n * a.D + z) * a.H + yy) * a.W + xx;
+      v += rsv[r];
+      v *= cs;
+      a.y[vox * a.yld + co] = v;
+      if constexpr (FUSE == 1) {
+        if (cnt == 0) K0 = v;
+        const float t = v - K0;
+        s0 += t; s1 += t * t;
+        ++cnt;
+      } else if constexpr (FUSE == 2) {
+        const float xv = gxv[r];
+        const float u = xv * gsc + gsh;
+        const float du = u > 0.f ? v : v * a.g.gslope;
+        s0 += du; s1 += du * ((xv - gmean) * grstd);
+      }
+    }
+  };
+
+  // ---- pipeline prologue: phase 0 staged and transformed, phase 1 staged, the weight fragments of phase 0 requested ----
+  __syncthreads();                                         // prm
+  int t1 = 0, c1 = 0;                                      // phase k + 1 and k + 2 of the loop below, kept one / two steps ahead
+  loads(0, 0);
+  commit(0, 0);
+  adv(t1, c1);
+  if (K > 1) loads(t1, c1);
+  __syncthreads();
+  transform(0);
+  if (K > 1) commit(c1, 1);
+  b_loads(0);
+  __syncthreads();
+  int t2 = t1, c2 = c1;
+  adv(t2, c2);
+
+  // one phase; SL = slot of the output plane with the index of this input plane (t % 3)
+  auto phase = [&](int k, auto slc) {
+    constexpr int SL = decltype(slc)::value, S0 = (SL + 1) % 3, S1 = SL, S2 = (SL + 2) % 3;   // dz = 0 -> plane t + 1, 1 -> t, 2 -> t - 1
+    const int par = k & 1;
+    if (k + 2 < K) loads(t2, c2);
+    SCHED_BARRIER();
+    const float* vb = vs + par * VSF + ((2 * wave) * NT + li) * KC + 4 * half;
+    const float4 af0 = *reinterpret_cast<const float4*>(vb), af1 = *reinterpret_cast<const float4*>(vb + NT * KC);
+#define WZ_MFMA(e)                                                            \
+    acc[S0][0] = MFMA_32x32x2(af0.e, bfr[0][0].e, acc[S0][0]);                \
+    acc[S1][0] = MFMA_32x32x2(af0.e, bfr[0][1].e, acc[S1][0]);                \
+    acc[S2][0] = MFMA_32x32x2(af0.e, bfr[0][2].e, acc[S2][0]);                \
+    acc[S0][1] = MFMA_32x32x2(af1.e, bfr[1][0].e, acc[S0][1]);                \
+    acc[S1][1] = MFMA_32x32x2(af1.e, bfr[1][1].e, acc[S1][1]);                \
+    acc[S2][1] = MFMA_32x32x2(af1.e, bfr[1][2].e, acc[S2][1]);
+    WZ_MFMA(x) WZ_MFMA(y) WZ_MFMA(z) WZ_MFMA(w)
+#undef WZ_MFMA
+    SCHED_BARRIER();
+    if (k + 1 < K) {
+      b_loads(c1);                                         // into the registers the MFMAs above have read: in flight under the transform
+      transform(par ^ 1);
+    }
+    if (k + 2 < K) commit(c2, par);
+    __syncthreads();
+    t1 = t2; c1 = c2;
+    adv(t2, c2);
+  };
+  // input plane index t = 0 .. L + 1 (plane zb - 1 + t); after it, output plane index t - 1 (plane zb + t - 2) is complete
+  auto plane = [&](int t, auto slc) {
+    constexpr int SL = decltype(slc)::value, SE = (SL + 2) % 3;
+    for (int ci = 0; ci < NC; ++ci) phase(t * NC + ci, slc);
+    if (t >= 2) epilogue(zb + t - 2, std::integral_constant<int, SE>());
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[SE][q][r] = 0.f;
+  };
+  for (int t = 0; t < L + 2; t += 3) {
+    plane(t, std::integral_constant<int, 0>());
+    if (t + 1 >= L + 2) break;
+    plane(t + 1, std::integral_constant<int, 1>());
+    if (t + 2 >= L + 2) break;
+    plane(t + 2, std::integral_constant<int, 2>());
+  }
+
+  if constexpr (FUSE != 0) {
+    constexpr int KK = FUSE == 1 ? 3 : 2;
+    float vals[1][KK];
+    if constexpr (FUSE == 1) {
+      const float c = (float)cnt;
+      const float m2 = cnt > 0 ? s1 - s0 * s0 / c : 0.f;
+      vals[0][0] = c; vals[0][1] = s0 + c * K0; vals[0][2] = m2 > 0.f ? m2 : 0.f;
+    } else {
+      vals[0][0] = s0; vals[0][1] = s1;
+    }
+    const size_t rec = (size_t)n * ((size_t)a.zsplits * a.tilesY * a.tilesX) + ((size_t)zs * a.tilesY + tyi) * a.tilesX + txi;
+    float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * KK;
+    gn_fuse_reduce_store<KK, 1, 8, 1>(vals, P, wave, 0, half, li, tid, dst, co_base, a.Cout);
+  }
+}
+
+// z-range plan of conv3d_wino2d_zring for an output [n, d, h, w, c]: ~256 workgroups (one per CU), whole z ranges of >= 8 planes
+struct WinoZPlan { int tilesY, tilesX, coTiles, zsplits, zper, use; };
+static WinoZPlan plan_wino_zring(int n, int d, int h, int w, int cout) {
+  WinoZPlan p;
+  p.tilesY = ceil_div(h, 8); p.tilesX = ceil_div(w, 16); p.coTiles = ceil_div(cout, 32);
+  const long long spatial = (long long)n * p.tilesY * p.tilesX * p.coTiles;
+  int zsplits = (int)((256 + spatial - 1) / spatial);
+  const char* ze = getenv("MI355_WINO_ZSPLITS");            // tests: force the number of z ranges (1 = whole columns)
+  if (ze && atoi(ze) > 0) zsplits = atoi(ze);
+  if (zsplits < 1) zsplits = 1;
+  if (zsplits > d) zsplits = d;
+  p.zper = ceil_div(d, zsplits);
+  p.zsplits = ceil_div(d, p.zper);
+  const char* fe = getenv("MI355_WINO_FORM");              // tile | zring | (default) auto: the z-marching form where a z range has >= 8 planes
+  if (fe && fe[0] == 't') p.use = 0;
+  else if (fe && fe[0] == 'z') p.use = 1;
+  else p.use = p.zper >= 8;
+  return p;
+}
+
 // ---- filter transform: U[(i,j)][dz][ci][co] = sum_{dy,dx} G[i][dy] G[j][dx] w[...], G rows: g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2 ----
 // mode 0: forward, w OIDHW [cout][cin][3][3][3]. mode 1: dgrad of Conv3d: roles swapped ("out" = ci, "in" = co), all three taps flipped.
 __global__ void wino_pack_weight_kernel(const float* w, float* up, int cout, int cin, int coutP, int cinP, int mode) {
@@ -491,6 +777,26 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cin = x->c; a.CinP = (x->c + 7) / 8 * 8;
   a.Cout = y->c; a.CoutP = (y->c + 31) / 32 * 32;
   a.tilesZ = ceil_div(a.D, 2); a.tilesY = ceil_div(a.H, 8); a.tilesX = ceil_div(a.W, 16); a.coTiles = a.CoutP / 32;
+  const WinoZPlan zp = plan_wino_zring(a.N, a.D, a.H, a.W, a.Cout);
+  if (zp.use) {
+    a.zsplits = zp.zsplits; a.zper = zp.zper;
+    const long long zblocks = (long long)a.N * zp.zsplits * a.tilesY * a.tilesX * a.coTiles;
+    if (zblocks <= 0 || zblocks > 0x7fffffffLL) return MI355_EINVAL;
+    const int lds_bytes = (2 * (180 * 12 + 16) + 2 * 16 * 32 * 8 + 8 * 2 * 32 * 32 + 3 * a.CinP) * (int)sizeof(float);
+    const dim3 zgrid((unsigned)zblocks), zblk(512);
+#define WINO_ZLAUNCH(IM, FU)                                                                         \
+    do { SET_MAX_DYN_LDS((conv3d_wino2d_zring<IM, FU>), lds_bytes);                                    \
+         LAUNCH((conv3d_wino2d_zring<IM, FU>), zgrid, zblk, lds_bytes, stream, a); } while (0)
+    if (a.g.mom) {
+      if (d->in_mode == MI355_IN_PLAIN) WINO_ZLAUNCH(MI355_IN_PLAIN, 1); else WINO_ZLAUNCH(MI355_IN_AFFINE_ACT, 1);
+    } else if (a.g.gnb) {
+      WINO_ZLAUNCH(MI355_IN_PLAIN, 2);
+    } else if (d->in_mode == MI355_IN_PLAIN) WINO_ZLAUNCH(MI355_IN_PLAIN, 0);
+    else WINO_ZLAUNCH(MI355_IN_AFFINE_ACT, 0);
+#undef WINO_ZLAUNCH
+    return LAUNCH_CHECK();
+  }
+  a.zsplits = 1; a.zper = a.D;
   const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
   const dim3 grid((unsigned)blocks), blk(256);
@@ -513,9 +819,11 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   return LAUNCH_CHECK();
 }
 
-// spatial tiles (= epilogue records per sample) of this kernel's 2 x 8 x 16 tiling
+// epilogue records per sample: the 2 x 8 x 16 tiles of conv3d_wino2d, or the (z range, 8 x 16 column) workgroups of conv3d_wino2d_zring
 extern "C" int32_t mi355_conv3d_wino_stats_blocks(const mi355_act* y) {
   if (!y) return 0;
+  const WinoZPlan zp = plan_wino_zring(y->n, y->d, y->h, y->w, y->c);
+  if (zp.use) return (int32_t)((long long)zp.zsplits * zp.tilesY * zp.tilesX);
   const long long b = (long long)ceil_div(y->d, 2) * ceil_div(y->h, 8) * ceil_div(y->w, 16);
   return b > 0 && b <= 0x7fffffffLL ? (int32_t)b : 0;
 }

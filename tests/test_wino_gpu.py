@@ -10,12 +10,16 @@ from oracle import torch_ops as O
 ops = C.ops
 
 
-@pytest.fixture(autouse=True, params=[("1", "2"), ("1", "0"), ("1", "1"), ("0", "0")],
-                ids=["pipelined-weights-ahead", "pipelined", "pipelined-weights-first", "three-barrier"])
+@pytest.fixture(autouse=True, params=[("1", "2", "zring", "1"), ("1", "2", "zring", "2"), ("1", "2", "zring", ""), ("1", "2", "tile", ""), ("1", "0", "tile", ""),
+                                       ("1", "1", "tile", ""), ("0", "0", "tile", "")],
+                ids=["z-marching-whole-columns", "z-marching-two-ranges", "z-marching", "pipelined-weights-ahead", "pipelined", "pipelined-weights-first", "three-barrier"])
 def wino_variant(request, monkeypatch):
-    """the main-loop forms of the kernels (MI355_WINO_PIPE / MI355_WINO_BMODE, read by the library at every call)"""
+    """the forms of the forward kernel: the z-marching workgroup (conv3d_wino2d_zring) and the main-loop variants of the tile kernel
+    (MI355_WINO_FORM / MI355_WINO_PIPE / MI355_WINO_BMODE, read by the library at every call)"""
     monkeypatch.setenv("MI355_WINO_PIPE", request.param[0])
     monkeypatch.setenv("MI355_WINO_BMODE", request.param[1])
+    monkeypatch.setenv("MI355_WINO_FORM", request.param[2])
+    monkeypatch.setenv("MI355_WINO_ZSPLITS", request.param[3])
 
 
 @pytest.mark.gpu

@@ -13,7 +13,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MODES = ("norm+moments", "plain", "plain+gnb")
-LAYERS = [(32, 32, 128, 3), (64, 64, 64, 3), (128, 128, 32, 3), (256, 256, 16, 3), (64, 32, 128, 3), (32, 64, 64, 1), (128, 64, 64, 1)]
+LAYERS = [(32, 32, 128, 3), (64, 32, 128, 3), (32, 64, 128, 3), (64, 64, 64, 3), (128, 128, 64, 3), (128, 128, 32, 3), (256, 256, 32, 3), (256, 256, 16, 3),
+          (32, 64, 64, 1), (128, 64, 64, 1)]
 
 
 def one(path):
