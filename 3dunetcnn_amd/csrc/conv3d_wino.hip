@@ -685,8 +685,329 @@ __global__ __launch_bounds__(512) void conv3d_wino2d_zring(WinoArgs a) {
   }
 }
 
+// =====================================================================================================================================
+// The tile kernel again with EIGHT waves per workgroup (round 3). The SQ counters of conv3d_wino2d (profiles/r3_sq_counters_wino.txt)
+// show a latency-bound kernel, not a busy one: matrix pipe 51 %, vector ALU 22 % of the SIMD cycles, the waves spend half of their
+// resident time in s_waitcnt -- at 256 registers per wave only two waves share a SIMD, and both run the same barrier-separated phases.
+// Here the same 2 x 8 x 16 voxel x 32 channel tile (same grid, same statistics records) is computed by 512 threads: wave w owns the two
+// points p = 2 w, 2 w + 1 of both output planes = 4 accumulator tiles = 64 registers, the kernel fits 128 registers, and FOUR waves
+// (two workgroups) share a SIMD. Per phase a wave reads its two A fragments once (both uses of a two-use phase share them), a thread
+// stages one float4 and transforms half a (tile, channel) window (two point rows, as conv3d_wino2d_zring), the norm prologue comes from
+// LDS. Weight fragments: two rotating sets, each requested one use ahead (the BMODE 2 order of conv3d_wino2d).
+// Output transform: in-wave over the wave's two j, across the waves through a 64 KB exchange (the main loop's LDS, reused).
+#ifndef WINO_ABL
+#define WINO_ABL 0            // developer ablations of conv3d_wino2d_w8 (tools/build_variant.sh ... -DWINO_ABL=mask): 1 no input loads, 2 no weight loads, 4 no transform, 8 no stores
+#endif
+template <int INMODE, int FUSE>
+__global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(WinoArgs a) {
+  constexpr int TZ = 2, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HV = HY * HX;
+  constexpr int KC = 8, XS = 12, NT = 32;
+  constexpr int XSF = HV * XS + 16, VSF = 16 * NT * KC, PF = 8 * 2 * 32 * 32;
+  static_assert(2 * (XSF + VSF) <= PF, "the main loop's buffers live inside the exchange area");
+  DYN_LDS(lds);
+  float* xs = lds;                                         // 2 staged planes [halo voxel][8 + 4 pad]
+  float* vs = lds + 2 * XSF;                               // 2 transformed planes [point][tile][channel]
+  float* P = lds;                                          // epilogue: output-transform exchange [wave][b][tile][co]
+  float* prm = lds + PF;                                   // norm prologue of this sample: scale | shift | slope, CinP each
+  const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6), half = lane >> 5, li = lane & 31;
+  // Workgroup -> (channel tile, spatial tile). The hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own
+  // L2), so the plain order b = spatial * coTiles + cot gives XCD x the channel tiles cot = x mod coTiles (their weights stay in that
+  // L2: good) but every (8 / coTiles)-th spatial tile (the halo and the z overlap of neighbouring tiles are fetched once per XCD).
+  // Where the numbers divide, XCD x = (cot, group g) takes a CONTIGUOUS range of spatial tiles instead.
+  int b = blockIdx.x, cot;
+  {
+    const int nct = a.coTiles, S = gridDim.x / nct, ng = nct < 8 && 8 % nct == 0 ? 8 / nct : 0;
+    if (ng > 0 && S % ng == 0) {
+      const int x = b & 7;
+      cot = x % nct;
+      b = (x / nct) * (S / ng) + (b >> 3);
+    } else {
+      cot = b % nct; b /= nct;
+    }
+  }
+  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+  const int tz0 = (b % a.tilesZ) * TZ; b /= a.tilesZ;
+  const int n = b;
+  const int co_base = cot * 32;
+
+  if (INMODE == MI355_IN_AFFINE_ACT) {
+    for (int c = tid; c < a.CinP; c += 512) {
+      const bool in = c < a.Cin;
+      prm[c] = in ? a.in_scale[(size_t)n * a.Cin + c] : 0.f;
+      prm[a.CinP + c] = in ? a.in_shift[(size_t)n * a.Cin + c] : 0.f;
+      prm[2 * a.CinP + c] = in ? (a.in_slope ? a.in_slope[c] : a.slope) : 0.f;
+    }
+  }
+
+  f32x16 acc[TZ][2];                                       // [output plane][point q: p = 2 * wave + q]
+#pragma unroll
+  for (int oz = 0; oz < TZ; ++oz)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[oz][q][r] = 0.f;
+
+  // staging unit of this thread: (halo voxel sv, channel quad sq) of the 180 x 2 units of a plane chunk; fixed for the whole kernel.
+  // Addresses are a workgroup-uniform base (scalar registers) plus one 32-bit lane offset inside the plane.
+  const bool sunit = tid < HV * 2;
+  const int sv = sunit ? tid >> 1 : 0, sq = tid & 1;
+  const int siy = ty0 - 1 + sv / HX, six = tx0 - 1 + sv % HX;
+  const bool sin = sunit && siy >= 0 && siy < a.H && six >= 0 && six < a.W;
+  const size_t xplane = (size_t)a.H * a.W * a.xld;
+  const float* xn = a.x + (size_t)n * a.D * xplane;        // sample n
+  const unsigned xoff = (unsigned)(((siy < 0 ? 0 : (siy < a.H ? siy : a.H - 1)) * a.W + (six < 0 ? 0 : (six < a.W ? six : a.W - 1))) * a.xld + 4 * sq);
+  const unsigned soff = (unsigned)(sv * XS + 4 * sq);      // staged position
+  const bool sq0 = sq == 0;
+  // transform unit: (channel tc, tile tt) and the row half th (wave-uniform): point rows i = 2 th, 2 th + 1
+  const int tc = tid & 7, tt = (tid >> 3) & 31, th = wave >> 2;
+  const int tty = tt >> 3, ttx = tt & 7;
+  const float4* up4 = reinterpret_cast<const float4*>(a.up);
+  const int CQ = a.CinP / 4;
+
+  float4 ld = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool lok = false;
+  auto loads = [&](int c0_, int pz_) {
+    if (!sunit) return;
+    const int iz = tz0 - 1 + pz_;
+    const bool call = c0_ + 8 <= a.Cin;                    // both quads of the chunk exist (Cin is a multiple of 4)
+    lok = sin && iz >= 0 && iz < a.D && (call || sq0);
+    const int izc = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1);
+    const float* base = xn + (size_t)izc * xplane + c0_;  // uniform
+#if WINO_ABL & 1
+    ld = make_float4((float)izc, (float)c0_, 1.f, 2.f); (void)base;
+#else
+    ld = *reinterpret_cast<const float4*>(base + (call ? xoff : xoff - 4u * sq));      // a missing quad re-reads the first one (zeroed by lok)
+#endif
+  };
+  auto commit = [&](float* xsb, int c0_) {
+    if (!sunit) return;
+    float4 v = ld;
+    if (INMODE == MI355_IN_AFFINE_ACT) {
+      const int c = c0_ + 4 * sq;
+      const float4 sc = *reinterpret_cast<const float4*>(prm + c), sh = *reinterpret_cast<const float4*>(prm + a.CinP + c);
+      const float4 sl = *reinterpret_cast<const float4*>(prm + 2 * a.CinP + c);
+      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+      v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
+    }
+    if (!lok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(xsb + soff) = v;
+  };
+  auto transform = [&](const float* xsb, float* vsb) {
+#if WINO_ABL & 4
+    return;
+#endif
+    const float* col = xsb + ((2 * tty) * HX + 2 * ttx) * XS + tc;
+    float* vd = vsb + tt * KC + tc;                        // point 4 i + j at ((4 i + j) * NT + tt) * KC + tc
+    float t0[4], t1[4];
+    if (th == 0) {                                         // rows i = 0: d0 - d2, i = 1: d1 + d2
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const float d0 = col[s2 * XS], d1 = col[(HX + s2) * XS], d2 = col[(2 * HX + s2) * XS];
+        t0[s2] = d0 - d2; t1[s2] = d1 + d2;
+      }
+      vd[(0 * NT) * KC] = t0[0] - t0[2]; vd[(1 * NT) * KC] = t0[1] + t0[2]; vd[(2 * NT) * KC] = t0[2] - t0[1]; vd[(3 * NT) * KC] = t0[1] - t0[3];
+      vd[(4 * NT) * KC] = t1[0] - t1[2]; vd[(5 * NT) * KC] = t1[1] + t1[2]; vd[(6 * NT) * KC] = t1[2] - t1[1]; vd[(7 * NT) * KC] = t1[1] - t1[3];
+    } else {                                               // rows i = 2: d2 - d1, i = 3: d1 - d3
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const float d1 = col[(HX + s2) * XS], d2 = col[(2 * HX + s2) * XS], d3 = col[(3 * HX + s2) * XS];
+        t0[s2] = d2 - d1; t1[s2] = d1 - d3;
+      }
+      vd[(8 * NT) * KC] = t0[0] - t0[2]; vd[(9 * NT) * KC] = t0[1] + t0[2]; vd[(10 * NT) * KC] = t0[2] - t0[1]; vd[(11 * NT) * KC] = t0[1] - t0[3];
+      vd[(12 * NT) * KC] = t1[0] - t1[2]; vd[(13 * NT) * KC] = t1[1] + t1[2]; vd[(14 * NT) * KC] = t1[2] - t1[1]; vd[(15 * NT) * KC] = t1[1] - t1[3];
+    }
+  };
+  // weight fragments of one use: the wave's two points, z-tap dz, channels [c0_, c0_ + 8): uniform base + one 32-bit lane offset
+  const unsigned boff = (unsigned)(half * a.CoutP + co_base + li);          // in float4s
+  const size_t bstep = (size_t)CQ * a.CoutP;               // float4s between consecutive (point, dz) slabs
+  auto b_use = [&](float4 (&bu)[2], int c0_, int dz) {
+    const float4* q0 = up4 + (size_t)(c0_ / 4) * a.CoutP + (size_t)((2 * wave) * 3 + dz) * bstep;      // uniform
+#if WINO_ABL & 2
+    bu[0] = make_float4((float)c0_, (float)dz, 0.5f, 0.25f); bu[1] = make_float4((float)dz, (float)c0_, 0.25f, 0.5f); (void)q0;
+#else
+    bu[0] = q0[boff];
+    bu[1] = (q0 + 3 * bstep)[boff];
+#endif
+  };
+  auto mfma_use = [&](const float4 (&af)[2], const float4 (&bu)[2], f32x16 (&ac)[2]) {
+    ac[0] = MFMA_32x32x2(af[0].x, bu[0].x, ac[0]);
+    ac[1] = MFMA_32x32x2(af[1].x, bu[1].x, ac[1]);
+    ac[0] = MFMA_32x32x2(af[0].y, bu[0].y, ac[0]);
+    ac[1] = MFMA_32x32x2(af[1].y, bu[1].y, ac[1]);
+    ac[0] = MFMA_32x32x2(af[0].z, bu[0].z, ac[0]);
+    ac[1] = MFMA_32x32x2(af[1].z, bu[1].z, ac[1]);
+    ac[0] = MFMA_32x32x2(af[0].w, bu[0].w, ac[0]);
+    ac[1] = MFMA_32x32x2(af[1].w, bu[1].w, ac[1]);
+  };
+  // One channel chunk = 4 phases (input planes pz = 0..3 of the tile). The weights W[dz] of a chunk are loaded ONCE: input plane pz
+  // multiplies W[pz] into output plane 0 and W[pz - 1] into output plane 1, so W[dz] serves two consecutive phases from the same
+  // registers (the ablation run profiles/r3_wino_w8_ablation.txt prices the weight stream from L2 at 12-20 % of the kernel when every
+  // use re-requests it). Two fragment sets rotate: on entry S0 holds W0 and S1 is free; phase 0 requests W1 into S1; phase 1 runs
+  // (plane 1, W0), then requests W2 into S0, then (plane 0, W1); phase 2 runs (plane 1, W1), requests the NEXT chunk's W0 into S1, then
+  // (plane 0, W2); phase 3 runs (plane 1, W2). On exit S1 holds the next W0 (moved to S0 by the caller). Every request has at
+  // least one phase of lead, and a phase-opening request precedes the phase's input-plane loads in program order (vmcnt retires in
+  // order: a weight wait must never include a younger HBM load).
+  auto a_frags = [&](float4 (&af)[2], const float* vcur) {
+    const float* vb = vcur + ((2 * wave) * NT + li) * KC + 4 * half;
+    af[0] = *reinterpret_cast<const float4*>(vb);
+    af[1] = *reinterpret_cast<const float4*>(vb + NT * KC);
+  };
+  auto chunk = [&](int c0, float4 (&S0)[2], float4 (&S1)[2]) {
+    const bool more = c0 + KC < a.CinP;                    // another chunk follows (workgroup-uniform)
+    float4 af[2];
+    // phase 0: plane 0 x W0 -> output plane 0 | transform plane 1 | loads of plane 2
+    b_use(S1, c0, 1);
+    loads(c0, 2);
+    a_frags(af, vs);
+    SCHED_BARRIER();
+    mfma_use(af, S0, acc[0]);
+    transform(xs + XSF, vs + VSF);
+    commit(xs, c0);
+    __syncthreads();
+    // phase 1: plane 1 x W0 -> output plane 1, x W1 -> output plane 0 | transform plane 2 | loads of plane 3
+    loads(c0, 3);
+    a_frags(af, vs + VSF);
+    SCHED_BARRIER();
+    mfma_use(af, S0, acc[1]);
+    b_use(S0, c0, 2);
+    transform(xs, vs);
+    SCHED_BARRIER();
+    mfma_use(af, S1, acc[0]);
+    commit(xs + XSF, c0);
+    __syncthreads();
+    // phase 2: plane 2 x W1 -> output plane 1, x W2 -> output plane 0 | transform plane 3 | loads of the next chunk's plane 0
+    if (more) loads(c0 + KC, 0);
+    a_frags(af, vs);
+    SCHED_BARRIER();
+    mfma_use(af, S1, acc[1]);
+    if (more) b_use(S1, c0 + KC, 0);
+    transform(xs + XSF, vs + VSF);
+    SCHED_BARRIER();
+    mfma_use(af, S0, acc[0]);
+    if (more) commit(xs, c0 + KC);
+    __syncthreads();
+    // phase 3: plane 3 x W2 -> output plane 1 | transform of the next chunk's plane 0 | loads of its plane 1
+    if (more) loads(c0 + KC, 1);
+    a_frags(af, vs + VSF);
+    SCHED_BARRIER();
+    mfma_use(af, S0, acc[1]);
+    if (more) { transform(xs, vs); commit(xs + XSF, c0 + KC); }
+    __syncthreads();
+  };
+
+  // prologue: planes 0 and 1 of the first chunk requested together, W0 requested; plane 0 staged and transformed, plane 1 staged
+  __syncthreads();                                         // prm
+  float4 bA[2], bB[2];
+  b_use(bA, 0, 0);
+  loads(0, 0);
+  const float4 ld0 = ld;
+  const bool lok0 = lok;
+  loads(0, 1);
+  { const float4 ld1 = ld; const bool lok1 = lok; ld = ld0; lok = lok0; commit(xs, 0); ld = ld1; lok = lok1; }
+  commit(xs + XSF, 0);
+  __syncthreads();
+  transform(xs, vs);
+  __syncthreads();
+  for (int c0 = 0; c0 < a.CinP; c0 += KC) {
+    chunk(c0, bA, bB);
+    bA[0] = bB[0]; bA[1] = bB[1];                          // the next chunk's W0 (8 register moves per 4 phases keep ONE loop body)
+  }
+
+  // ---- output transform Y = A^T M A, bias / residual / dropout scale, store ----
+  // wave w = (i = w >> 1, j half = w & 1). In-wave over its two j: A^T rows (1, 1, 1, 0) and (0, 1, -1, -1); across the waves over i.
+  // Wave w' then owns output (a, b) = ((w' & 3) >> 1, w' & 1) of the tiles [16 * (w' >> 2), + 16).
+  const int ea = (wave & 3) >> 1, eb = wave & 1, eth = wave >> 2;
+  const bool jh = wave & 1;
+  const int co = co_base + li;
+  const bool cov = co < a.Cout;
+  float bs = 0.f, cs = 1.f;
+  if (cov && a.bias) bs = a.bias[co];
+  if (cov && a.out_chscale) cs = a.out_chscale[(size_t)n * a.Cout + co];
+  float K0 = 0.f, s0 = 0.f, s1 = 0.f, gsc = 1.f, gsh = 0.f, gmean = 0.f, grstd = 1.f;
+  int cnt = 0;
+  if constexpr (FUSE == 2) {
+    const int coc = cov ? co : a.Cout - 1;
+    const int grp = coc / (a.Cout / a.g.ggroups);
+    gsc = a.g.gscale[(size_t)n * a.Cout + coc]; gsh = a.g.gshift[(size_t)n * a.Cout + coc];
+    gmean = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
+  }
+#pragma unroll
+  for (int oz = 0; oz < TZ; ++oz) {
+    if (oz > 0) __syncthreads();                           // the previous plane's exchange has been read (the main loop ends on a barrier)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;   // tile index of accumulator register r
+      const float m0 = acc[oz][0][r], m1 = acc[oz][1][r];
+      P[((wave * 2 + 0) * 32 + row) * 32 + li] = jh ? m0 : m0 + m1;
+      P[((wave * 2 + 1) * 32 + row) * 32 + li] = jh ? -m0 - m1 : m1;
+    }
+    const int z = tz0 + oz;
+    const int zc = z < a.D ? z : a.D - 1;
+    // reads that do not depend on the exchange go out before the barrier: the normalised tensor (FUSE 2) and the residual
+    float gxv[8], rsv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int tile = eth * 16 + half * 8 + r;
+      int yy = ty0 + 2 * (tile >> 3) + ea, xx = tx0 + 2 * (tile & 7) + eb;
+      yy = yy < a.H ? yy : a.H - 1; xx = xx < a.W ? xx : a.W - 1;
+      const size_t vox = (((size_t)n * a.D + zc) * a.H + yy) * a.W + xx;
+      if constexpr (FUSE == 2) gxv[r] = a.g.gx[vox * a.g.gxld + (cov ? co : a.Cout - 1)];
+      rsv[r] = a.res ? a.res[vox * a.resld + (cov ? co : a.Cout - 1)] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int tile = eth * 16 + half * 8 + r;
+      const float* pz = P + (eb * 32 + tile) * 32 + li;    // wave w, output column b at ((w * 2 + b) * 32 + tile) * 32 + li
+      float v;
+      if (ea == 0) v = (pz[0 * 2048] + pz[1 * 2048]) + (pz[2 * 2048] + pz[3 * 2048]) + (pz[4 * 2048] + pz[5 * 2048]);
+      else v = (pz[2 * 2048] + pz[3 * 2048]) - (pz[4 * 2048] + pz[5 * 2048]) - (pz[6 * 2048] + pz[7 * 2048]);
+      v += bs;
+      const int yy = ty0 + 2 * (tile >> 3) + ea, xx = tx0 + 2 * (tile & 7) + eb;
+      if (!cov || z >= a.D || yy >= a.H || xx >= a.W) continue;
+      const size_t vox = (((size_t)n * a.D + z) * a.H + yy) * a.W + xx;
+      v += rsv[r];
+      v *= cs;
+#if WINO_ABL & 8
+      if (v == 12345.678f)
+#endif
+      a.y[vox * a.yld + co] = v;
+      if constexpr (FUSE == 1) {
+        if (cnt == 0) K0 = v;
+        const float t = v - K0;
+        s0 += t; s1 += t * t;
+        ++cnt;
+      } else if constexpr (FUSE == 2) {
+        const float xv = gxv[r];
+        const float u = xv * gsc + gsh;
+        const float du = u > 0.f ? v : v * a.g.gslope;
+        s0 += du; s1 += du * ((xv - gmean) * grstd);
+      }
+    }
+  }
+  if constexpr (FUSE != 0) {
+    constexpr int KK = FUSE == 1 ? 3 : 2;
+    float vals[1][KK];
+    if constexpr (FUSE == 1) {
+      const float c = (float)cnt;
+      const float m2 = cnt > 0 ? s1 - s0 * s0 / c : 0.f;
+      vals[0][0] = c; vals[0][1] = s0 + c * K0; vals[0][2] = m2 > 0.f ? m2 : 0.f;
+    } else {
+      vals[0][0] = s0; vals[0][1] = s1;
+    }
+    const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
+    const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
+    float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * KK;
+    gn_fuse_reduce_store<KK, 1, 8, 1>(vals, P, wave, 0, half, li, tid, dst, co_base, a.Cout);
+  }
+}
+
 // z-range plan of conv3d_wino2d_zring for an output [n, d, h, w, c]: ~256 workgroups (one per CU), whole z ranges of >= 8 planes
-struct WinoZPlan { int tilesY, tilesX, coTiles, zsplits, zper, use; };
+struct WinoZPlan { int tilesY, tilesX, coTiles, zsplits, zper, use; };      // use: 0 tile, 1 zring, 2 w8
+#ifndef WINO_DEFAULT_FORM
+#define WINO_DEFAULT_FORM 2      // conv3d_wino2d_w8: measured 30.5 ms over the layer set against 33.3 (tile) and 36.9 (zring), profiles/r3_wino_forms.txt
+#endif
 static WinoZPlan plan_wino_zring(int n, int d, int h, int w, int cout) {
   WinoZPlan p;
   p.tilesY = ceil_div(h, 8); p.tilesX = ceil_div(w, 16); p.coTiles = ceil_div(cout, 32);
@@ -698,10 +1019,15 @@ static WinoZPlan plan_wino_zring(int n, int d, int h, int w, int cout) {
   if (zsplits > d) zsplits = d;
   p.zper = ceil_div(d, zsplits);
   p.zsplits = ceil_div(d, p.zper);
-  const char* fe = getenv("MI355_WINO_FORM");              // tile | zring | (default) auto: the z-marching form where a z range has >= 8 planes
-  if (fe && fe[0] == 't') p.use = 0;
-  else if (fe && fe[0] == 'z') p.use = 1;
-  else p.use = p.zper >= 8;
+  // MI355_WINO_FORM: tile (conv3d_wino2d, 4 waves) | w8 (conv3d_wino2d_w8, the same tile with 8 waves) | zring (z-marching) |
+  // auto (z-marching where a z range has >= 8 planes). Measured (profiles/r3_wino_forms.txt): zring loses to the tile form on the
+  // step (36.9 vs 33.3 ms over the layer set), so it is opt-in.
+  const char* fe = getenv("MI355_WINO_FORM");
+  if (fe && fe[0] == 'z') p.use = 1;
+  else if (fe && fe[0] == 'a') p.use = p.zper >= 8;
+  else if (fe && fe[0] == 't') p.use = 0;
+  else if (fe && fe[0] == 'w') p.use = 2;
+  else p.use = WINO_DEFAULT_FORM;
   return p;
 }
 
@@ -778,7 +1104,7 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   a.Cout = y->c; a.CoutP = (y->c + 31) / 32 * 32;
   a.tilesZ = ceil_div(a.D, 2); a.tilesY = ceil_div(a.H, 8); a.tilesX = ceil_div(a.W, 16); a.coTiles = a.CoutP / 32;
   const WinoZPlan zp = plan_wino_zring(a.N, a.D, a.H, a.W, a.Cout);
-  if (zp.use) {
+  if (zp.use == 1) {
     a.zsplits = zp.zsplits; a.zper = zp.zper;
     const long long zblocks = (long long)a.N * zp.zsplits * a.tilesY * a.tilesX * a.coTiles;
     if (zblocks <= 0 || zblocks > 0x7fffffffLL) return MI355_EINVAL;
@@ -799,6 +1125,21 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   a.zsplits = 1; a.zper = a.D;
   const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
+  if (zp.use == 2) {
+    const int lds_bytes = (8 * 2 * 32 * 32 + 3 * a.CinP) * (int)sizeof(float);
+    const dim3 wgrid((unsigned)blocks), wblk(512);
+#define WINO_WLAUNCH(IM, FU)                                                                         \
+    do { SET_MAX_DYN_LDS((conv3d_wino2d_w8<IM, FU>), lds_bytes);                                       \
+         LAUNCH((conv3d_wino2d_w8<IM, FU>), wgrid, wblk, lds_bytes, stream, a); } while (0)
+    if (a.g.mom) {
+      if (d->in_mode == MI355_IN_PLAIN) WINO_WLAUNCH(MI355_IN_PLAIN, 1); else WINO_WLAUNCH(MI355_IN_AFFINE_ACT, 1);
+    } else if (a.g.gnb) {
+      WINO_WLAUNCH(MI355_IN_PLAIN, 2);
+    } else if (d->in_mode == MI355_IN_PLAIN) WINO_WLAUNCH(MI355_IN_PLAIN, 0);
+    else WINO_WLAUNCH(MI355_IN_AFFINE_ACT, 0);
+#undef WINO_WLAUNCH
+    return LAUNCH_CHECK();
+  }
   const dim3 grid((unsigned)blocks), blk(256);
   const char* pe = getenv("MI355_WINO_PIPE");                  // A/B switches, read per call (tests flip them); default: pipelined
   const bool pipe = !(pe && pe[0] == '0');
@@ -823,7 +1164,7 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
 extern "C" int32_t mi355_conv3d_wino_stats_blocks(const mi355_act* y) {
   if (!y) return 0;
   const WinoZPlan zp = plan_wino_zring(y->n, y->d, y->h, y->w, y->c);
-  if (zp.use) return (int32_t)((long long)zp.zsplits * zp.tilesY * zp.tilesX);
+  if (zp.use == 1) return (int32_t)((long long)zp.zsplits * zp.tilesY * zp.tilesX);
   const long long b = (long long)ceil_div(y->d, 2) * ceil_div(y->h, 8) * ceil_div(y->w, 16);
   return b > 0 && b <= 0x7fffffffLL ? (int32_t)b : 0;
 }
