@@ -115,67 +115,105 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wino_ring(WWRArgs a) {
       }
       if (dunit) *reinterpret_cast<float4*>(dst_ + PAR * DS + sv * 32 + 4 * sq) = din ? pd : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    // transform of a plane from staging buffer PAR into ring slot SLOT: this thread's two point rows of V and of Dv. `th` is wave-uniform
-    // (waves 0-3: rows i = 0, 1; waves 4-7: rows i = 2, 3): a scalar branch, not per-lane selects.
-    auto transform = [&](auto parc, auto slotc) {
-      constexpr int PAR = decltype(parc)::value, SLOT = decltype(slotc)::value;
-      const float* xb = xst + PAR * XS + ((2 * tty) * HX + 2 * ttx) * 32 + tc;
-      float* vdst = Vr + SLOT * RS + tt * 32 + tc;                              // point 4 i + j at ((4 i + j) * NT + tt) * 32 + tc
+    // Transform of a plane from staging buffer PAR into ring slot SLOT: this thread's two point rows of V and of Dv. `th` (waves 0-3: 0,
+    // waves 4-7: 1) selects the rows, and it does so WITHOUT a branch -- the three window rows th, th + 1, th + 2 are read through a base
+    // address that contains th, the one sign that differs is a scalar, and the two result rows go to scalar-selected ring rows -- so that
+    // a plane step is ONE basic block and the scheduler directives below can spread the transform between the MFMAs:
+    //   th = 0 (window rows d0 d1 d2):  u = d0 - d2 -> point row 0,   o = d1 + d2 -> point row 1
+    //   th = 1 (window rows d1 d2 d3):  u = d1 - d3 -> point row 3,   o = d2 - d1 -> point row 2          (r0 r1 r2 = the rows read)
+    //   u = r0 - r2,  o = r1 + sg * (th ? r0 : r2),  sg = th ? -1 : +1       (x * (+-1) + y is exact: the same values as the branchy form)
+    // Dv = A h A^T, rows (h0., h0. + h1., h0. - h1., -h1.), columns (r0, r0 + r1, r0 - r1, -r1):
+    //   X = (h00 + sg h10, h01 + sg h11) -> point row th ? 2 : 1,   Y = th ? (-h10, -h11) : (h00, h01) -> point row th ? 3 : 0
+    struct TIn { float d[3][4]; float h00, h01, h10, h11; };
+    const float sg = th ? -1.f : 1.f;
+    const int urow = th ? 3 : 0, orow = th ? 2 : 1;            // V: point rows of u and o; Dv: rows of Y and X
+    auto transform_reads = [&](TIn& t, auto parc) {
+      constexpr int PAR = decltype(parc)::value;
+      const float* xb = xst + PAR * XS + ((2 * tty + th) * HX + 2 * ttx) * 32 + tc;
       const float* db = dst_ + PAR * DS + ((2 * tty) * TX + 2 * ttx) * 32 + tc;
-      float* ddst = Dr + SLOT * RS + tt * 32 + tc;
-      const float h00 = db[0], h01 = db[32], h10 = db[TX * 32], h11 = db[(TX + 1) * 32];
-      float t0[4], t1[4];
-      if (th == 0) {                                                            // rows i = 0: d0 - d2, i = 1: d1 + d2 (window rows 0, 1, 2)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float d0 = xb[(0 * HX + s) * 32], d1 = xb[(1 * HX + s) * 32], d2 = xb[(2 * HX + s) * 32];
-          t0[s] = d0 - d2; t1[s] = d1 + d2;
-        }
-        vdst[(0 * NT) * 32] = t0[0] - t0[2]; vdst[(1 * NT) * 32] = t0[1] + t0[2]; vdst[(2 * NT) * 32] = t0[2] - t0[1]; vdst[(3 * NT) * 32] = t0[1] - t0[3];
-        vdst[(4 * NT) * 32] = t1[0] - t1[2]; vdst[(5 * NT) * 32] = t1[1] + t1[2]; vdst[(6 * NT) * 32] = t1[2] - t1[1]; vdst[(7 * NT) * 32] = t1[1] - t1[3];
-        // Dv = A h A^T, rows i = 0: h0., i = 1: h0. + h1.; columns (r0, r0 + r1, r0 - r1, -r1)
-        const float ra = h00 + h10, rb = h01 + h11;
-        ddst[(0 * NT) * 32] = h00; ddst[(1 * NT) * 32] = h00 + h01; ddst[(2 * NT) * 32] = h00 - h01; ddst[(3 * NT) * 32] = -h01;
-        ddst[(4 * NT) * 32] = ra; ddst[(5 * NT) * 32] = ra + rb; ddst[(6 * NT) * 32] = ra - rb; ddst[(7 * NT) * 32] = -rb;
-      } else {                                                                  // rows i = 2: d2 - d1, i = 3: d1 - d3 (window rows 1, 2, 3)
+      for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float d1 = xb[(1 * HX + s) * 32], d2 = xb[(2 * HX + s) * 32], d3 = xb[(3 * HX + s) * 32];
-          t0[s] = d2 - d1; t1[s] = d1 - d3;
-        }
-        vdst[(8 * NT) * 32] = t0[0] - t0[2]; vdst[(9 * NT) * 32] = t0[1] + t0[2]; vdst[(10 * NT) * 32] = t0[2] - t0[1]; vdst[(11 * NT) * 32] = t0[1] - t0[3];
-        vdst[(12 * NT) * 32] = t1[0] - t1[2]; vdst[(13 * NT) * 32] = t1[1] + t1[2]; vdst[(14 * NT) * 32] = t1[2] - t1[1]; vdst[(15 * NT) * 32] = t1[1] - t1[3];
-        // rows i = 2: h0. - h1., i = 3: -h1.
-        const float ra = h00 - h10, rb = h01 - h11;
-        ddst[(8 * NT) * 32] = ra; ddst[(9 * NT) * 32] = ra + rb; ddst[(10 * NT) * 32] = ra - rb; ddst[(11 * NT) * 32] = -rb;
-        ddst[(12 * NT) * 32] = -h10; ddst[(13 * NT) * 32] = -h10 - h11; ddst[(14 * NT) * 32] = h11 - h10; ddst[(15 * NT) * 32] = h11;
-      }
+        for (int s = 0; s < 4; ++s) t.d[r][s] = xb[(r * HX + s) * 32];
+      t.h00 = db[0]; t.h01 = db[32]; t.h10 = db[TX * 32]; t.h11 = db[(TX + 1) * 32];
     };
-    // one plane step; P6 = p % 6 fixes the staging parity and the ring slots at compile time
-    auto step = [&](int p, auto p6c) {
+    auto transform_math = [&](const TIn& t, auto slotc) {
+      constexpr int SLOT = decltype(slotc)::value;
+      float* vu = Vr + SLOT * RS + (urow * 4 * NT + tt) * 32 + tc;               // point 4 i + j at ((4 i + j) * NT + tt) * 32 + tc
+      float* vo = Vr + SLOT * RS + (orow * 4 * NT + tt) * 32 + tc;
+      float* dY = Dr + SLOT * RS + (urow * 4 * NT + tt) * 32 + tc;
+      float* dX = Dr + SLOT * RS + (orow * 4 * NT + tt) * 32 + tc;
+      float u[4], o[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        u[s] = t.d[0][s] - t.d[2][s];
+        o[s] = fmaf(th ? t.d[0][s] : t.d[2][s], sg, t.d[1][s]);
+      }
+      vu[(0 * NT) * 32] = u[0] - u[2]; vu[(1 * NT) * 32] = u[1] + u[2]; vu[(2 * NT) * 32] = u[2] - u[1]; vu[(3 * NT) * 32] = u[1] - u[3];
+      vo[(0 * NT) * 32] = o[0] - o[2]; vo[(1 * NT) * 32] = o[1] + o[2]; vo[(2 * NT) * 32] = o[2] - o[1]; vo[(3 * NT) * 32] = o[1] - o[3];
+      const float xa = fmaf(t.h10, sg, t.h00), xb_ = fmaf(t.h11, sg, t.h01);
+      const float ya = th ? -t.h10 : t.h00, yb = th ? -t.h11 : t.h01;
+      dX[(0 * NT) * 32] = xa; dX[(1 * NT) * 32] = xa + xb_; dX[(2 * NT) * 32] = xa - xb_; dX[(3 * NT) * 32] = -xb_;
+      dY[(0 * NT) * 32] = ya; dY[(1 * NT) * 32] = ya + yb; dY[(2 * NT) * 32] = ya - yb; dY[(3 * NT) * 32] = -yb;
+    };
+    auto transform = [&](auto parc, auto slotc) {             // the whole transform (prologue of a column)
+      TIn t;
+      transform_reads(t, parc);
+      transform_math(t, slotc);
+    };
+    // The matrix work of plane p and the transform of plane p + 1 as ONE basic block, interleaved by the scheduler directives at its end:
+    // with one 512-thread workgroup per CU all eight waves run the same phase, so a transform that FOLLOWS the MFMAs (the first form of
+    // this kernel: 24 MFMAs, then 16 LDS reads, a wait, 24 adds, 16 LDS writes) leaves the matrix pipe idle for its whole duration. Here
+    // the transform's reads go out under the first MFMAs and its arithmetic and writes ride in the shadow of the rest (a 32x32x2 fp32
+    // MFMA occupies the pipe for 64 cycles; the wave issues a few other instructions behind each for free). The last plane of a column
+    // transforms a stale staging buffer into a ring slot nobody reads (no branch: a branch would split the block).
+    auto body = [&](auto p6c) {
       constexpr int P6 = decltype(p6c)::value, SP = P6 % 3, SM = (P6 + 2) % 3;       // ring slots of planes p and p - 1
-      const bool has1 = p + 1 < a.D, has2 = p + 2 < a.D;     // workgroup-uniform
-      if (has2) load_plane(p + 2);
-      SCHED_BARRIER();                                       // the loads stay above the MFMAs they overlap with
+      TIn t;
       // operand fragments of this wave's two points: tile (K) index 2 ks + half, channel li -- read once, used by three MFMAs each
-      float fvp[2][NT / 2], fvm[2][NT / 2], fdp[2][NT / 2], fdm[2][NT / 2];
+      float fvp[NT / 2][2], fvm[NT / 2][2], fdp[NT / 2][2], fdm[NT / 2][2];
       const float* fb = lds + ((2 * wave) * NT + half) * 32 + li;
+      auto frags = [&](int ks) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int ks = 0; ks < NT / 2; ++ks) {
-          fvp[q][ks] = fb[SP * RS + q * NT * 32 + ks * 64]; fvm[q][ks] = fb[SM * RS + q * NT * 32 + ks * 64];
-          fdp[q][ks] = fb[(3 + SP) * RS + q * NT * 32 + ks * 64]; fdm[q][ks] = fb[(3 + SM) * RS + q * NT * 32 + ks * 64];
+        for (int q = 0; q < 2; ++q) {
+          fdm[ks][q] = fb[(3 + SM) * RS + q * NT * 32 + ks * 64]; fvp[ks][q] = fb[SP * RS + q * NT * 32 + ks * 64];
+          fdp[ks][q] = fb[(3 + SP) * RS + q * NT * 32 + ks * 64]; fvm[ks][q] = fb[SM * RS + q * NT * 32 + ks * 64];
         }
+      };
+      frags(0);
+      transform_reads(t, std::integral_constant<int, (P6 + 1) & 1>());
+      frags(1); frags(2); frags(3);
 #pragma unroll
       for (int ks = 0; ks < NT / 2; ++ks)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {                        // six independent accumulators in flight
-          acc[2][q] = MFMA_32x32x2(fdm[q][ks], fvp[q][ks], acc[2][q]);     // dy plane p - 1, input plane p     : dz = 2
-          acc[1][q] = MFMA_32x32x2(fdp[q][ks], fvp[q][ks], acc[1][q]);     // dy plane p,     input plane p     : dz = 1
-          acc[0][q] = MFMA_32x32x2(fdp[q][ks], fvm[q][ks], acc[0][q]);     // dy plane p,     input plane p - 1 : dz = 0
+          acc[2][q] = MFMA_32x32x2(fdm[ks][q], fvp[ks][q], acc[2][q]);     // dy plane p - 1, input plane p     : dz = 2
+          acc[1][q] = MFMA_32x32x2(fdp[ks][q], fvp[ks][q], acc[1][q]);     // dy plane p,     input plane p     : dz = 1
+          acc[0][q] = MFMA_32x32x2(fdp[ks][q], fvm[ks][q], acc[0][q]);     // dy plane p,     input plane p - 1 : dz = 0
         }
-      if (has1) transform(std::integral_constant<int, (P6 + 1) & 1>(), std::integral_constant<int, (P6 + 1) % 3>());
+      transform_math(t, std::integral_constant<int, (P6 + 1) % 3>());
+#ifndef MI355_EMU
+      // Issue order (LDS reads in source order: k-group 0, the transform's 16, k-groups 1..3): 8 reads, then per MFMA i of the 24:
+      // reads 4 (i < 6: the transform's inputs and k-group 1), 2 (i = 6..9, 12..15: k-groups 2, 3, one group ahead of their use);
+      // from i = 6 two vector-ALU instructions, from i = 8 one LDS write
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        else if ((i >= 6 && i < 10) || (i >= 12 && i < 16)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        if (i >= 6) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        if (i >= 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+#endif
+    };
+    // one plane step; P6 = p % 6 fixes the staging parity and the ring slots at compile time
+    auto step = [&](int p, auto p6c) {
+      constexpr int P6 = decltype(p6c)::value;
+      const bool has2 = p + 2 < a.D;                         // workgroup-uniform
+      if (has2) load_plane(p + 2);
+      SCHED_BARRIER();                                       // the loads stay above the MFMAs they overlap with
+      body(p6c);
       SCHED_BARRIER();
       if (has2) commit_plane(std::integral_constant<int, P6 & 1>());        // plane p + 2 has the parity of p
       __syncthreads();

@@ -793,31 +793,41 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(Wi
     if (!lok) v = make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<float4*>(xsb + soff) = v;
   };
-  auto transform = [&](const float* xsb, float* vsb) {
+  // Input transform of this thread's (tile, channel), two of the four point rows. `th` (waves 0-3: 0, waves 4-7: 1) selects them WITHOUT
+  // a branch, so that a phase is one basic block and its transform can be spread between the MFMAs (scheduler directives in `chunk`):
+  //   th = 0 (window rows d0 d1 d2): u = d0 - d2 -> point row 0, o = d1 + d2 -> point row 1
+  //   th = 1 (window rows d1 d2 d3): u = d1 - d3 -> point row 3, o = d2 - d1 -> point row 2        (r0 r1 r2 = the rows read, base contains th)
+  //   u = r0 - r2,  o = r1 + sg * (th ? r0 : r2),  sg = th ? -1 : +1       (x * (+-1) + y is exact)
+  const float sg = th ? -1.f : 1.f;
+  const int toff = ((2 * tty + th) * HX + 2 * ttx) * XS + tc;                 // first window value read in a staged plane
+  const int uoff = ((th ? 12 : 0) * NT + tt) * KC + tc, ooff = ((th ? 8 : 4) * NT + tt) * KC + tc;      // point (4 i + j) at ((4 i + j) * NT + tt) * KC + tc
+  struct TIn { float d[3][4]; };
+  auto transform_reads = [&](TIn& t, const float* xsb) {
 #if WINO_ABL & 4
     return;
 #endif
-    const float* col = xsb + ((2 * tty) * HX + 2 * ttx) * XS + tc;
-    float* vd = vsb + tt * KC + tc;                        // point 4 i + j at ((4 i + j) * NT + tt) * KC + tc
-    float t0[4], t1[4];
-    if (th == 0) {                                         // rows i = 0: d0 - d2, i = 1: d1 + d2
+    const float* col = xsb + toff;
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        const float d0 = col[s2 * XS], d1 = col[(HX + s2) * XS], d2 = col[(2 * HX + s2) * XS];
-        t0[s2] = d0 - d2; t1[s2] = d1 + d2;
-      }
-      vd[(0 * NT) * KC] = t0[0] - t0[2]; vd[(1 * NT) * KC] = t0[1] + t0[2]; vd[(2 * NT) * KC] = t0[2] - t0[1]; vd[(3 * NT) * KC] = t0[1] - t0[3];
-      vd[(4 * NT) * KC] = t1[0] - t1[2]; vd[(5 * NT) * KC] = t1[1] + t1[2]; vd[(6 * NT) * KC] = t1[2] - t1[1]; vd[(7 * NT) * KC] = t1[1] - t1[3];
-    } else {                                               // rows i = 2: d2 - d1, i = 3: d1 - d3
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        const float d1 = col[(HX + s2) * XS], d2 = col[(2 * HX + s2) * XS], d3 = col[(3 * HX + s2) * XS];
-        t0[s2] = d2 - d1; t1[s2] = d1 - d3;
-      }
-      vd[(8 * NT) * KC] = t0[0] - t0[2]; vd[(9 * NT) * KC] = t0[1] + t0[2]; vd[(10 * NT) * KC] = t0[2] - t0[1]; vd[(11 * NT) * KC] = t0[1] - t0[3];
-      vd[(12 * NT) * KC] = t1[0] - t1[2]; vd[(13 * NT) * KC] = t1[1] + t1[2]; vd[(14 * NT) * KC] = t1[2] - t1[1]; vd[(15 * NT) * KC] = t1[1] - t1[3];
-    }
+      for (int s2 = 0; s2 < 4; ++s2) t.d[r][s2] = col[(r * HX + s2) * XS];
   };
+  auto transform_math = [&](const TIn& t, float* vsb) {
+#if WINO_ABL & 4
+    return;
+#endif
+    float u[4], o[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      u[s2] = t.d[0][s2] - t.d[2][s2];
+      o[s2] = fmaf(th ? t.d[0][s2] : t.d[2][s2], sg, t.d[1][s2]);
+    }
+    float* vu = vsb + uoff;
+    float* vo = vsb + ooff;
+    vu[(0 * NT) * KC] = u[0] - u[2]; vu[(1 * NT) * KC] = u[1] + u[2]; vu[(2 * NT) * KC] = u[2] - u[1]; vu[(3 * NT) * KC] = u[1] - u[3];
+    vo[(0 * NT) * KC] = o[0] - o[2]; vo[(1 * NT) * KC] = o[1] + o[2]; vo[(2 * NT) * KC] = o[2] - o[1]; vo[(3 * NT) * KC] = o[1] - o[3];
+  };
+  auto transform = [&](const float* xsb, float* vsb) { TIn t; transform_reads(t, xsb); transform_math(t, vsb); };
   // weight fragments of one use: the wave's two points, z-tap dz, channels [c0_, c0_ + 8): uniform base + one 32-bit lane offset
   const unsigned boff = (unsigned)(half * a.CoutP + co_base + li);          // in float4s
   const size_t bstep = (size_t)CQ * a.CoutP;               // float4s between consecutive (point, dz) slabs
@@ -853,46 +863,90 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(Wi
     af[0] = *reinterpret_cast<const float4*>(vb);
     af[1] = *reinterpret_cast<const float4*>(vb + NT * KC);
   };
+  // Scheduler directives of a phase body (one basic block: A fragments, transform reads, MFMAs, weight request, transform arithmetic
+  // and writes): the transform's LDS reads go out behind the first MFMAs, its arithmetic and writes ride in the shadow of the others
+  // (a 32x32x2 fp32 MFMA holds the pipe for 64 cycles), the weight request of a two-use phase is issued once the first use's MFMAs
+  // (which read the registers it overwrites) are out.
+#ifdef MI355_EMU
+#define W8_PATTERN_ONE_USE()
+#define W8_PATTERN_TWO_USE()
+#else
+#define W8_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define W8_PATTERN_ONE_USE() do {                                                            \
+    W8_SGB(0x100, 2);                                                                        \
+    W8_SGB(0x008, 1); W8_SGB(0x100, 3); W8_SGB(0x008, 1); W8_SGB(0x100, 3);                  \
+    W8_SGB(0x008, 1); W8_SGB(0x002, 4); W8_SGB(0x008, 1); W8_SGB(0x002, 4);                  \
+    W8_SGB(0x008, 1); W8_SGB(0x002, 4);                                                      \
+    W8_SGB(0x008, 1); W8_SGB(0x002, 3); W8_SGB(0x200, 2);                                    \
+    W8_SGB(0x008, 1); W8_SGB(0x002, 3); W8_SGB(0x200, 2);                                    \
+    W8_SGB(0x008, 1); W8_SGB(0x002, 3); W8_SGB(0x200, 2); } while (0)
+#define W8_PATTERN_TWO_USE() do {                                                            \
+    W8_SGB(0x100, 2);                                                                        \
+    W8_SGB(0x008, 1); W8_SGB(0x100, 2); W8_SGB(0x008, 1); W8_SGB(0x100, 2);                  \
+    W8_SGB(0x008, 1); W8_SGB(0x100, 2);                                                      \
+    W8_SGB(0x008, 1); W8_SGB(0x002, 3); W8_SGB(0x008, 1); W8_SGB(0x002, 3);                  \
+    W8_SGB(0x008, 1); W8_SGB(0x002, 3); W8_SGB(0x008, 1); W8_SGB(0x002, 3);                  \
+    W8_SGB(0x008, 1); W8_SGB(0x020, 2);                                                      \
+    W8_SGB(0x008, 1); W8_SGB(0x002, 2); W8_SGB(0x200, 1);                                    \
+    W8_SGB(0x008, 1); W8_SGB(0x002, 2); W8_SGB(0x200, 1);                                    \
+    W8_SGB(0x008, 1); W8_SGB(0x002, 2); W8_SGB(0x200, 1);                                    \
+    W8_SGB(0x008, 1); W8_SGB(0x002, 2); W8_SGB(0x200, 1);                                    \
+    W8_SGB(0x008, 4); } while (0)
+#endif
   auto chunk = [&](int c0, float4 (&S0)[2], float4 (&S1)[2]) {
     const bool more = c0 + KC < a.CinP;                    // another chunk follows (workgroup-uniform)
+    const int cn = more ? c0 + KC : c0;                    // the weight request of phase 2 is unconditional (no branch inside a phase body)
     float4 af[2];
+    TIn t;
     // phase 0: plane 0 x W0 -> output plane 0 | transform plane 1 | loads of plane 2
     b_use(S1, c0, 1);
     loads(c0, 2);
-    a_frags(af, vs);
     SCHED_BARRIER();
+    a_frags(af, vs);
+    transform_reads(t, xs + XSF);
     mfma_use(af, S0, acc[0]);
-    transform(xs + XSF, vs + VSF);
+    transform_math(t, vs + VSF);
+    W8_PATTERN_ONE_USE();
+    SCHED_BARRIER();
     commit(xs, c0);
     __syncthreads();
     // phase 1: plane 1 x W0 -> output plane 1, x W1 -> output plane 0 | transform plane 2 | loads of plane 3
     loads(c0, 3);
-    a_frags(af, vs + VSF);
     SCHED_BARRIER();
+    a_frags(af, vs + VSF);
+    transform_reads(t, xs);
     mfma_use(af, S0, acc[1]);
     b_use(S0, c0, 2);
-    transform(xs, vs);
-    SCHED_BARRIER();
+    transform_math(t, vs);
     mfma_use(af, S1, acc[0]);
+    W8_PATTERN_TWO_USE();
+    SCHED_BARRIER();
     commit(xs + XSF, c0);
     __syncthreads();
     // phase 2: plane 2 x W1 -> output plane 1, x W2 -> output plane 0 | transform plane 3 | loads of the next chunk's plane 0
     if (more) loads(c0 + KC, 0);
+    SCHED_BARRIER();
     a_frags(af, vs);
-    SCHED_BARRIER();
+    transform_reads(t, xs + XSF);
     mfma_use(af, S1, acc[1]);
-    if (more) b_use(S1, c0 + KC, 0);
-    transform(xs + XSF, vs + VSF);
-    SCHED_BARRIER();
+    b_use(S1, cn, 0);
+    transform_math(t, vs + VSF);
     mfma_use(af, S0, acc[0]);
+    W8_PATTERN_TWO_USE();
+    SCHED_BARRIER();
     if (more) commit(xs, c0 + KC);
     __syncthreads();
-    // phase 3: plane 3 x W2 -> output plane 1 | transform of the next chunk's plane 0 | loads of its plane 1
+    // phase 3: plane 3 x W2 -> output plane 1 | transform of the next chunk's plane 0 (after the last chunk: of a stale buffer, into a
+    // buffer nobody reads) | loads of its plane 1
     if (more) loads(c0 + KC, 1);
-    a_frags(af, vs + VSF);
     SCHED_BARRIER();
+    a_frags(af, vs + VSF);
+    transform_reads(t, xs);
     mfma_use(af, S0, acc[1]);
-    if (more) { transform(xs, vs); commit(xs + XSF, c0 + KC); }
+    transform_math(t, vs);
+    W8_PATTERN_ONE_USE();
+    SCHED_BARRIER();
+    if (more) commit(xs + XSF, c0 + KC);
     __syncthreads();
   };
 

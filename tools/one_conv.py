@@ -1,9 +1,11 @@
 """Developer tool (GPU): launch one conv layer a few times (for rocprofv3 --pmc runs).
-    python tools/one_conv.py <precision> <cin> <cout> <size> [fwd|fwdplain|wgrad] [iters]"""
+    [ONE_CONV_LIB=tools/libvar_x.so] python tools/one_conv.py <precision> <cin> <cout> <size> [fwd|fwdplain|wgrad] [iters]"""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("ONE_CONV_LIB"):          # a variant build of the library (tools/build_variant.sh) instead of the in-tree one
+    importlib.import_module("3dunetcnn_amd._lib").LIB_PATH = os.path.abspath(os.environ["ONE_CONV_LIB"])
 ops = importlib.import_module("3dunetcnn_amd.ops")
 be = ops.default_backend()
 prec, cin, cout, s = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
