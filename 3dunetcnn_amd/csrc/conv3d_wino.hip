@@ -35,6 +35,7 @@ struct WinoArgs {
   int N, D, H, W, Cin, CinP, Cout, CoutP;
   int tilesZ, tilesY, tilesX, coTiles;
   int zsplits, zper;                     // conv3d_wino2d_zring: z ranges [zs * zper, min(D, (zs + 1) * zper)) per workgroup
+  int vec4;                              // conv3d_wino2d_w8: output / residual / normalised tensor take 16-byte accesses per channel quad
   GnFuseArgs g;                          // norm statistics fused into the epilogue (gn_fuse.h), as in conv3d_mfma
 };
 
@@ -969,93 +970,219 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(Wi
   }
 
   // ---- output transform Y = A^T M A, bias / residual / dropout scale, store ----
-  // wave w = (i = w >> 1, j half = w & 1). In-wave over its two j: A^T rows (1, 1, 1, 0) and (0, 1, -1, -1); across the waves over i.
-  // Wave w' then owns output (a, b) = ((w' & 3) >> 1, w' & 1) of the tiles [16 * (w' >> 2), + 16).
-  const int ea = (wave & 3) >> 1, eb = wave & 1, eth = wave >> 2;
+  // wave w = (i = w >> 1, j half = w & 1). In-wave over its two j: A^T rows (1, 1, 1, 0) and (0, 1, -1, -1), written to the exchange
+  // P[wave][b][tile][co]; across the waves over i on the way out. The read side is VOXEL-major: a thread owns 4 consecutive channels
+  // (quad coq = tid & 7) of two output voxels per plane, so the exchange is read with ds_read_b128, residual / normalised tensor come
+  // in and the result goes out as 16-byte accesses (8 lanes = the 32 channels of a voxel, a wave = 8 consecutive voxels of a row; the
+  // ablation run priced the first, channel-per-lane epilogue -- 48 ds_read_b32 and 8 dword stores per lane and plane -- at 10 % of
+  // the layer set, profiles/r3_wino_w8_ablation.txt). `a.vec4` == 0 (an output, residual or normalised tensor that is not 16-byte
+  // aligned per voxel, or a channel count that is not a multiple of 4) takes the same path with scalar accesses.
   const bool jh = wave & 1;
-  const int co = co_base + li;
-  const bool cov = co < a.Cout;
-  float bs = 0.f, cs = 1.f;
-  if (cov && a.bias) bs = a.bias[co];
-  if (cov && a.out_chscale) cs = a.out_chscale[(size_t)n * a.Cout + co];
-  float K0 = 0.f, s0 = 0.f, s1 = 0.f, gsc = 1.f, gsh = 0.f, gmean = 0.f, grstd = 1.f;
+  const int coq = tid & 7, ea = (wave >> 1) & 1;           // voxel rows: y = (tid >> 7) + 4 s -> a = y & 1 is wave-uniform
+  const int co4 = co_base + 4 * coq;
+  float bs[4], cs[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool cv = co4 + e < a.Cout;
+    bs[e] = cv && a.bias ? a.bias[co4 + e] : 0.f;
+    cs[e] = cv && a.out_chscale ? a.out_chscale[(size_t)n * a.Cout + co4 + e] : 1.f;
+  }
+  const bool q_in = co4 < a.Cout, q_full = co4 + 4 <= a.Cout;      // any / all four channels of the quad exist
+  float K0[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  float gsc[4], gsh[4], gmean[4], grstd[4];
   int cnt = 0;
   if constexpr (FUSE == 2) {
-    const int coc = cov ? co : a.Cout - 1;
-    const int grp = coc / (a.Cout / a.g.ggroups);
-    gsc = a.g.gscale[(size_t)n * a.Cout + coc]; gsh = a.g.gshift[(size_t)n * a.Cout + coc];
-    gmean = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int coc = co4 + e < a.Cout ? co4 + e : a.Cout - 1;
+      const int grp = coc / (a.Cout / a.g.ggroups);
+      gsc[e] = a.g.gscale[(size_t)n * a.Cout + coc]; gsh[e] = a.g.gshift[(size_t)n * a.Cout + coc];
+      gmean[e] = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd[e] = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
+    }
   }
+  float* pw = P + ((wave * 2) * 32 + 4 * half) * 32 + li;  // this lane's partial rows: + (b * 32 + (r & 3) + 8 * (r >> 2)) * 32
+  auto ld4 = [&](const float* base, size_t off, float (&v)[4]) {          // 4 channels of a voxel; scalar where 16-byte access is not legal
+    if (a.vec4) {
+      const float4 t = *reinterpret_cast<const float4*>(base + off);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = co4 + e < a.Cout ? base[off + e] : 0.f;
+    }
+  };
+#if WINO_ABL & 16
+  {
+    float sacc = 0.f;
+#pragma unroll
+    for (int oz = 0; oz < TZ; ++oz)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[oz][q][r];
+    if (sacc == 12345.678f) a.y[tid] = sacc + bs[0] + cs[0];
+    return;
+  }
+#endif
 #pragma unroll
   for (int oz = 0; oz < TZ; ++oz) {
     if (oz > 0) __syncthreads();                           // the previous plane's exchange has been read (the main loop ends on a barrier)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;   // tile index of accumulator register r
-      const float m0 = acc[oz][0][r], m1 = acc[oz][1][r];
-      P[((wave * 2 + 0) * 32 + row) * 32 + li] = jh ? m0 : m0 + m1;
-      P[((wave * 2 + 1) * 32 + row) * 32 + li] = jh ? -m0 - m1 : m1;
+      const int rowoff = (r & 3) + 8 * (r >> 2);           // tile index of accumulator register r, less 4 * half
+      const float m0 = acc[oz][0][r], m1 = acc[oz][1][r], sm = m0 + m1;
+      pw[rowoff * 32] = jh ? m0 : sm;
+      pw[(32 + rowoff) * 32] = jh ? -sm : m1;
     }
-    const int z = tz0 + oz;
-    const int zc = z < a.D ? z : a.D - 1;
-    // reads that do not depend on the exchange go out before the barrier: the normalised tensor (FUSE 2) and the residual
-    float gxv[8], rsv[8];
+    // reads that do not depend on the exchange go out before the barrier: the normalised tensor (FUSE 2) and the residual (requesting
+    // both planes' at the top of the epilogue was measured: 27 spilled registers, the norm-backward form 16 % slower)
+    const int z = tz0 + oz, zc = z < a.D ? z : a.D - 1;
+    float gxv[2][4], rsv[2][4];
+    size_t vox[2];
+    bool vin[2];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int tile = eth * 16 + half * 8 + r;
-      int yy = ty0 + 2 * (tile >> 3) + ea, xx = tx0 + 2 * (tile & 7) + eb;
-      yy = yy < a.H ? yy : a.H - 1; xx = xx < a.W ? xx : a.W - 1;
-      const size_t vox = (((size_t)n * a.D + zc) * a.H + yy) * a.W + xx;
-      if constexpr (FUSE == 2) gxv[r] = a.g.gx[vox * a.g.gxld + (cov ? co : a.Cout - 1)];
-      rsv[r] = a.res ? a.res[vox * a.resld + (cov ? co : a.Cout - 1)] : 0.f;
+    for (int sI = 0; sI < 2; ++sI) {
+      const int v = (tid >> 3) + 64 * sI;
+      const int yy = ty0 + (v >> 4), xx = tx0 + (v & 15);
+      vin[sI] = q_in && z < a.D && yy < a.H && xx < a.W;
+      const int yc = yy < a.H ? yy : a.H - 1, xc = xx < a.W ? xx : a.W - 1;
+      vox[sI] = (((size_t)n * a.D + zc) * a.H + yc) * a.W + xc;
+      const int cq = q_in ? co4 : 0;                       // a quad beyond Cout reads (and drops) the first one
+      if constexpr (FUSE == 2) ld4(a.g.gx, vox[sI] * a.g.gxld + cq, gxv[sI]);
+      if (a.res) ld4(a.res, vox[sI] * a.resld + cq, rsv[sI]);
+      else { rsv[sI][0] = rsv[sI][1] = rsv[sI][2] = rsv[sI][3] = 0.f; }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int tile = eth * 16 + half * 8 + r;
-      const float* pz = P + (eb * 32 + tile) * 32 + li;    // wave w, output column b at ((w * 2 + b) * 32 + tile) * 32 + li
-      float v;
-      if (ea == 0) v = (pz[0 * 2048] + pz[1 * 2048]) + (pz[2 * 2048] + pz[3 * 2048]) + (pz[4 * 2048] + pz[5 * 2048]);
-      else v = (pz[2 * 2048] + pz[3 * 2048]) - (pz[4 * 2048] + pz[5 * 2048]) - (pz[6 * 2048] + pz[7 * 2048]);
-      v += bs;
-      const int yy = ty0 + 2 * (tile >> 3) + ea, xx = tx0 + 2 * (tile & 7) + eb;
-      if (!cov || z >= a.D || yy >= a.H || xx >= a.W) continue;
-      const size_t vox = (((size_t)n * a.D + z) * a.H + yy) * a.W + xx;
-      v += rsv[r];
-      v *= cs;
+    for (int sI = 0; sI < 2; ++sI) {
+      const int v = (tid >> 3) + 64 * sI;
+      const int tile = ((v >> 5) << 3) + ((v & 15) >> 1), eb = v & 1;      // (y >> 1) * 8 + (x >> 1); b = x & 1
+      const float4* pz = reinterpret_cast<const float4*>(P + (eb * 32 + tile) * 32 + 4 * coq);      // wave w at + w * 2048 floats
+      // across the waves: row i of the point grid = waves 2 i, 2 i + 1; A^T rows over i: (1, 1, 1, 0) and (0, 1, -1, -1)
+      float4 o;
+      if (ea == 0) {
+        const float4 p0 = pz[0 * 512], p1 = pz[1 * 512], p2 = pz[2 * 512], p3 = pz[3 * 512], p4 = pz[4 * 512], p5 = pz[5 * 512];
+        o.x = (p0.x + p1.x) + (p2.x + p3.x) + (p4.x + p5.x); o.y = (p0.y + p1.y) + (p2.y + p3.y) + (p4.y + p5.y);
+        o.z = (p0.z + p1.z) + (p2.z + p3.z) + (p4.z + p5.z); o.w = (p0.w + p1.w) + (p2.w + p3.w) + (p4.w + p5.w);
+      } else {
+        const float4 p2 = pz[2 * 512], p3 = pz[3 * 512], p4 = pz[4 * 512], p5 = pz[5 * 512], p6 = pz[6 * 512], p7 = pz[7 * 512];
+        o.x = (p2.x + p3.x) - (p4.x + p5.x) - (p6.x + p7.x); o.y = (p2.y + p3.y) - (p4.y + p5.y) - (p6.y + p7.y);
+        o.z = (p2.z + p3.z) - (p4.z + p5.z) - (p6.z + p7.z); o.w = (p2.w + p3.w) - (p4.w + p5.w) - (p6.w + p7.w);
+      }
+      if (!vin[sI]) continue;
+      float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = (ov[e] + bs[e] + rsv[sI][e]) * cs[e];
+      float* yp = a.y + vox[sI] * a.yld + co4;
 #if WINO_ABL & 8
-      if (v == 12345.678f)
+      if (ov[0] == 12345.678f)
 #endif
-      a.y[vox * a.yld + co] = v;
+      if (a.vec4 && q_full) *reinterpret_cast<float4*>(yp) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (co4 + e < a.Cout) yp[e] = ov[e];
+      }
       if constexpr (FUSE == 1) {
-        if (cnt == 0) K0 = v;
-        const float t = v - K0;
-        s0 += t; s1 += t * t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (cnt == 0) K0[e] = ov[e];
+          const float t = ov[e] - K0[e];
+          s0[e] += t; s1[e] += t * t;
+        }
         ++cnt;
       } else if constexpr (FUSE == 2) {
-        const float xv = gxv[r];
-        const float u = xv * gsc + gsh;
-        const float du = u > 0.f ? v : v * a.g.gslope;
-        s0 += du; s1 += du * ((xv - gmean) * grstd);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xv = gxv[sI][e];
+          const float u = xv * gsc[e] + gsh[e];
+          const float du = u > 0.f ? ov[e] : ov[e] * a.g.gslope;
+          s0[e] += du; s1[e] += du * ((xv - gmean[e]) * grstd[e]);
+        }
       }
     }
   }
   if constexpr (FUSE != 0) {
+    // Per-lane partials of 4 channels -> one record per (tile, channel). Lanes coq + 8 m (m = 0..7) of a wave hold the same channels:
+    // three xor-shuffle steps of PLAIN sums (fixed order: the lane with the lower m first), then the eight waves through LDS in wave
+    // order (Chan's merge, as everywhere). Moments: a lane's sums are about its own first value K0; before the shuffles they are moved
+    // to the wave's common shift Kc = K0 of lane m = 0 (sum (v - Kc) = s0 + c d, sum (v - Kc)^2 = s1 + d (2 s0 + c d), d = K0 - Kc: no
+    // division, no E[x^2] - E[x]^2 of raw values), and M2 = s1 - s0^2 / c is formed once per wave and channel.
     constexpr int KK = FUSE == 1 ? 3 : 2;
-    float vals[1][KK];
-    if constexpr (FUSE == 1) {
-      const float c = (float)cnt;
-      const float m2 = cnt > 0 ? s1 - s0 * s0 / c : 0.f;
-      vals[0][0] = c; vals[0][1] = s0 + c * K0; vals[0][2] = m2 > 0.f ? m2 : 0.f;
-    } else {
-      vals[0][0] = s0; vals[0][1] = s1;
+    float vals[4][KK];
+    float cw = (float)cnt;                                  // FUSE 1: stored voxels of this lane (the same for its four channels)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if constexpr (FUSE == 1) {
+        const float Kc = __shfl(K0[e], coq);
+        const float d = K0[e] - Kc;
+        vals[e][0] = Kc;
+        vals[e][2] = s1[e] + d * (2.f * s0[e] + cw * d);
+        vals[e][1] = s0[e] + cw * d;
+      } else {
+        vals[e][0] = s0[e]; vals[e][1] = s1[e];
+      }
     }
-    const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
-    const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
-    float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * KK;
-    gn_fuse_reduce_store<KK, 1, 8, 1>(vals, P, wave, 0, half, li, tid, dst, co_base, a.Cout);
+#pragma unroll
+    for (int step = 8; step < 64; step <<= 1) {
+      const bool upper = lane & step;
+      if constexpr (FUSE == 1) { const float oc = __shfl_xor(cw, step); cw = upper ? oc + cw : cw + oc; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = (FUSE == 1 ? 1 : 0); k < KK; ++k) {
+          const float o = __shfl_xor(vals[e][k], step);
+          vals[e][k] = upper ? o + vals[e][k] : vals[e][k] + o;
+        }
+    }
+    // the eight waves through LDS: moments as (count, sum about Kc, sum of squares about Kc, Kc) per wave, moved to wave 0's shift by
+    // the same identity and added in wave order; M2 = s1 - s0^2 / c once per channel
+    constexpr int KW = FUSE == 1 ? 4 : 2;
+    __syncthreads();                                       // every wave is done with the exchange
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float* pr = P + ((wave * 32) + 4 * coq + e) * KW;
+        if constexpr (FUSE == 1) { pr[0] = cw; pr[1] = vals[e][1]; pr[2] = vals[e][2]; pr[3] = vals[e][0]; }
+        else { pr[0] = vals[e][0]; pr[1] = vals[e][1]; }
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float r[KK];
+      if constexpr (FUSE == 1) {
+        const float K = P[tid * KW + 3];
+        float c = P[tid * KW], t0 = P[tid * KW + 1], t1 = P[tid * KW + 2];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) {
+          const float* pr = P + (w * 32 + tid) * KW;
+          const float cwv = pr[0], d = pr[3] - K;
+          t1 += pr[2] + d * (2.f * pr[1] + cwv * d);
+          t0 += pr[1] + cwv * d;
+          c += cwv;
+        }
+        const float m2 = c > 0.f ? t1 - t0 * t0 / c : 0.f;
+        r[0] = c; r[1] = t0 + c * K; r[2] = m2 > 0.f ? m2 : 0.f;
+      } else {
+#pragma unroll
+        for (int k = 0; k < KK; ++k) r[k] = P[tid * KW + k];
+#pragma unroll
+        for (int w = 1; w < 8; ++w)
+#pragma unroll
+          for (int k = 0; k < KK; ++k) r[k] += P[(w * 32 + tid) * KW + k];
+      }
+      const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
+      const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
+      float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * KK;
+      const int co = co_base + tid;
+      if (co < a.Cout) {
+#pragma unroll
+        for (int k = 0; k < KK; ++k) dst[(size_t)co * KK + k] = r[k];
+      }
+    }
   }
 }
+#undef W8_SGB
+#undef W8_PATTERN_ONE_USE
+#undef W8_PATTERN_TWO_USE
 
 // z-range plan of conv3d_wino2d_zring for an output [n, d, h, w, c]: ~256 workgroups (one per CU), whole z ranges of >= 8 planes
 struct WinoZPlan { int tilesY, tilesX, coTiles, zsplits, zper, use; };      // use: 0 tile, 1 zring, 2 w8
@@ -1157,6 +1284,8 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cin = x->c; a.CinP = (x->c + 7) / 8 * 8;
   a.Cout = y->c; a.CoutP = (y->c + 31) / 32 * 32;
   a.tilesZ = ceil_div(a.D, 2); a.tilesY = ceil_div(a.H, 8); a.tilesX = ceil_div(a.W, 16); a.coTiles = a.CoutP / 32;
+  a.vec4 = a.Cout % 4 == 0 && a.yld % 4 == 0 && !((uintptr_t)a.y & 15) && (!a.res || (a.resld % 4 == 0 && !((uintptr_t)a.res & 15))) &&
+           (!a.g.gnb || (a.g.gxld % 4 == 0 && !((uintptr_t)a.g.gx & 15)));
   const WinoZPlan zp = plan_wino_zring(a.N, a.D, a.H, a.W, a.Cout);
   if (zp.use == 1) {
     a.zsplits = zp.zsplits; a.zper = zp.zper;

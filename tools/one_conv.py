@@ -1,5 +1,5 @@
 """Developer tool (GPU): launch one conv layer a few times (for rocprofv3 --pmc runs).
-    [ONE_CONV_LIB=tools/libvar_x.so] python tools/one_conv.py <precision> <cin> <cout> <size> [fwd|fwdplain|wgrad] [iters]"""
+    [ONE_CONV_LIB=tools/libvar_x.so] python tools/one_conv.py <precision> <cin> <cout> <size> [fwd|fwdplain|fwdmom|fwdnormmom|wgrad] [iters]"""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,6 +27,10 @@ for it in range(iters):
         be.conv_fwd(x, wp, y, 3, 1, in_mode=ops.IN_AFFINE_ACT, scale=sc, shift=sh)
     elif what == "fwdplain":
         be.conv_fwd(x, wp, y, 3, 1)
+    elif what == "fwdmom":                   # plain input, fused moments of the output
+        be.conv_fwd(x, wp, y, 3, 1, moments=True)
+    elif what == "fwdnormmom":
+        be.conv_fwd(x, wp, y, 3, 1, in_mode=ops.IN_AFFINE_ACT, scale=sc, shift=sh, moments=True)
     else:
         be.conv_wgrad(x, y, dw, 3, 1, in_mode=ops.IN_AFFINE_ACT, scale=sc, shift=sh)
 e1.record()
