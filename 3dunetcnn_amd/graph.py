@@ -14,19 +14,36 @@ parameter gradient into the model's flat gradient buffer. What stays outside: th
 tensors and the optimizer step (one fused Adam launch; kept eager so lr schedulers -- ReduceLROnPlateau in the reference's
 config -- keep working and the bias-correction step count stays a host integer).
 
-Not for the multi-rank path: the bucketed RCCL all-reduce is launched from Python callbacks during backward (ddp.py).
+Multi-rank (a GradientBucketReducer attached to the model, ddp.py): the eager step launches its bucket all-reduces from Python
+callbacks inside backward, which a replayed graph cannot do. The graphed step therefore captures forward + loss + backward WITHOUT
+the callbacks and exchanges the whole flat gradient buffer in one all-reduce between the replay and the optimizer step
+(`reducer.allreduce_flat`): per step the host enqueues one hipGraphLaunch, one collective and one Adam kernel instead of ~600
+launches -- the form for many ranks on one host at short steps (the bf16 / small-patch configurations), at the price of an exchange
+that is not overlapped with backward (96 MB over xGMI, ~1 ms). `capture=False` runs the same step uncaptured (the host logic of this
+path on any device: the world-size-2 gloo test uses it with the CPU emulator).
 """
+import contextlib
 import torch
 
 
 class HipGraphedTrainStep:
-    def __init__(self, model, criterion, optimizer, example_x, example_y, warmup=2):
-        if getattr(model, "grad_ready_callback", None) is not None:
-            raise RuntimeError("HipGraphedTrainStep: the model has a GradientBucketReducer attached; graph replay cannot launch its "
-                               "all-reduces -- use the eager step for multi-rank training")
+    def __init__(self, model, criterion, optimizer, example_x, example_y, warmup=2, capture=True):
+        # the reducer attached to the model, if any (its bound method is the engine's grad_sync_callback)
+        sync = getattr(model, "grad_sync_callback", None)
+        self.reducer = getattr(sync, "__self__", None)
+        if sync is not None and not hasattr(self.reducer, "allreduce_flat"):
+            raise RuntimeError("HipGraphedTrainStep: the model's gradient callbacks do not belong to a GradientBucketReducer")
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.graph = None
+        if not capture:
+            model.flatten_parameters()
+            return
         if example_x.device.type != "cuda":
             raise RuntimeError("HipGraphedTrainStep runs on an MI355X only (no CPU fallback)")
-        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        with (self.reducer.detached() if self.reducer is not None else contextlib.nullcontext()):
+            self._capture(model, criterion, optimizer, example_x, example_y, warmup)
+
+    def _capture(self, model, criterion, optimizer, example_x, example_y, warmup):
         model.backward_side_stream = False           # one captured stream: the graph already removes the launch gaps the fork hides
         self.x = example_x.detach().clone()          # static inputs: every replay reads these addresses
         self.y = example_y.detach().clone()
@@ -58,9 +75,21 @@ class HipGraphedTrainStep:
         self.loss = loss.detach()
         self._grads = [(p, p.grad) for p in model.parameters() if p.grad is not None]
 
+    def _exchange(self):
+        if self.reducer is not None:
+            self.reducer.allreduce_flat(self.model._flat_grad)
+
     def __call__(self, x, y):
         """One training step on the batch (x, y) (shapes/dtypes of the example batch). Returns the loss (a static 0-dim device
         tensor: read it with .item() before the next call if the value is needed)."""
+        if self.graph is None:                       # capture=False: the same step, uncaptured
+            self.optimizer.zero_grad(set_to_none=True)
+            with (self.reducer.detached() if self.reducer is not None else contextlib.nullcontext()):
+                loss = self.criterion(self.model(x), y)
+                loss.backward()
+            self._exchange()
+            self.optimizer.step()
+            return loss.detach()
         if x.shape != self.x.shape or y.shape != self.y.shape or y.dtype != self.y.dtype:
             raise ValueError(f"HipGraphedTrainStep was captured for x {tuple(self.x.shape)}, y {tuple(self.y.shape)} {self.y.dtype}")
         if x.data_ptr() != self.x.data_ptr():
@@ -70,5 +99,6 @@ class HipGraphedTrainStep:
         self.graph.replay()
         for p, g in self._grads:                     # a zero_grad(set_to_none=True) between calls must not hide the gradients
             p.grad = g
+        self._exchange()                             # multi-rank: one all-reduce of the flat gradient buffer
         self.optimizer.step()
         return self.loss

@@ -65,6 +65,10 @@ def parse():
                          "c3 = configs[2] per-GPU shape (bf16 mixed, batch 4); c4 = configs[3] (5-level UNet3D, 160x192x128, batch 1); "
                          "c5 = configs[4] (sliding-window inference over 240x240x155, 128^3 windows). c3-c5 are reported for completeness "
                          "(parity-test cases, tests/test_fullsize_configs_gpu.py); the driver's line is c2")
+    ap.add_argument("--graph", action="store_true",
+                    help="the step as ONE replayed HIP graph (3dunetcnn_amd/graph.py): forward + loss + backward captured; with N > 1 the "
+                         "gradients are exchanged in one all-reduce of the flat buffer after the replay instead of per bucket from inside "
+                         "backward. ~600 host launches per step become 3 (many ranks on one host, short steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="disable the per-launch HIP events (roofline -> null)")
     ap.add_argument("--no-precision-modes", action="store_true",
@@ -322,12 +326,27 @@ def main():
     x, y = x.to(dev), y.to(dev)                                   # inputs resident in HBM before the timed region
     be.set_precision(args.precision)
 
-    def step():
+    host_s = [0.0, 0]                                             # host time spent enqueueing steps (no device sync inside), step count
+
+    def eager_step():
         optimizer.zero_grad(set_to_none=True)
         out = model(x)
         loss = criterion(out, y)
         loss.backward()                                           # the reducer's bucket all-reduces are launched from inside backward
         optimizer.step()                                          # and joined at its end (engine.py: grad_sync_callback)
+        return loss
+
+    graphed = None
+    if args.graph and dev.type == "cuda":
+        graph_mod = importlib.import_module("3dunetcnn_amd.graph")
+        graphed = graph_mod.HipGraphedTrainStep(model, criterion, optimizer, x, y)      # one flat all-reduce per step when N > 1
+        args.no_kernel_events = True                              # a replayed graph has no per-launch events
+
+    def step():
+        t = time.perf_counter()
+        loss = graphed(x, y) if graphed is not None else eager_step()
+        host_s[0] += time.perf_counter() - t
+        host_s[1] += 1
         return loss
 
     def barrier():
@@ -346,11 +365,13 @@ def main():
     side = bool(getattr(model, "backward_side_stream", False)) and dev.type == "cuda"
     if not args.no_kernel_events and not side:
         be.prof = []
+    host_s[0], host_s[1] = 0.0, 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    host_ms = host_s[0] / max(host_s[1], 1) * 1e3                 # this rank's Python / launch work per step inside the timed region
     prof_timed, be.prof = be.prof, None
     loss_val = float(loss.item())
     # Roofline pass. The timed region runs the weight-gradient kernels on a second stream (engine.py: backward_side_stream), where a
@@ -377,12 +398,13 @@ def main():
                      f"{serial_ms:.2f} ms/step; the timed region overlaps them with the dgrad chain on a second stream, where a launch's "
                      "duration is not its own)")
 
-    per_rank = [dt]
+    per_rank, per_rank_host = [dt], [host_ms]
     if world > 1:
-        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        mine = torch.tensor([dt, host_ms], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        per_rank = [float(t.item()) for t in every]
+        per_rank = [float(t[0].item()) for t in every]
+        per_rank_host = [float(t[1].item()) for t in every]
     dt = max(per_rank)                                            # the job is as slow as its slowest rank
 
     roofline = None
@@ -419,6 +441,10 @@ def main():
                "value": round(world * B * args.steps / dt, 4), "unit": "volumes/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
+               # host time a rank spends enqueueing one step (Python + ~600 C-ABI launches in the eager form, 3 launches with --graph);
+               # the step is GPU-bound while this stays below ms_per_step
+               "per_rank_host_enqueue_ms_per_step": [round(t, 3) for t in per_rank_host],
+               "step_form": "hip-graph replay + one flat all-reduce" if graphed is not None else "eager launches, bucketed all-reduce inside backward",
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision],
                "data": "synthetic" if not emu else "synthetic -- CPU-EMULATOR PLUMBING TEST, NOT A MEASUREMENT",
                "config": {"workload": f"BASELINE configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.config] }]: {model_desc}, {'x'.join(str(v) for v in dhw)} patch, batch {B}/GPU, fp32 tensors, "

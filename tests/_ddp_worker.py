@@ -73,6 +73,24 @@ def main(out_dir, device="cpu", mode="step"):
         torch.save(rec, os.path.join(out_dir, f"rank{rank}.pt"))
         dist.destroy_process_group()
         return
+    if mode == "graphstep":
+        # HipGraphedTrainStep with the reducer attached (graph.py): forward / backward without the per-bucket callbacks, ONE all-reduce
+        # of the flat gradient buffer, Adam. Captured as a HIP graph on the GPU; uncaptured (the same host logic) on the CPU emulator.
+        graph = importlib.import_module("3dunetcnn_amd.graph")
+        stepper = graph.HipGraphedTrainStep(m, crit, opt, x, y, capture=on_gpu)
+        assert stepper.reducer is red
+        for i in range(2):
+            loss = stepper(x, y)
+            if i == 0:
+                rec["grads"] = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+                rec["n_buckets"] = 0
+            m.mark_parameters_updated()
+            rec["losses"].append(float(loss))
+        assert m.grad_ready_callback is not None and m.grad_sync_callback is not None      # the reducer is attached again
+        rec["sd2"] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        torch.save(rec, os.path.join(out_dir, f"rank{rank}.pt"))
+        dist.destroy_process_group()
+        return
     for _ in range(2):
         opt.zero_grad(set_to_none=True)
         loss = crit(m(x), y)

@@ -31,9 +31,11 @@ def test_flag_defaults(monkeypatch):
 
 def test_cpu_baseline_leg_reports_the_contract_fields():
     r = _bench().cpu_baseline(32)          # 16^3 half-edge step, then the full 32^3 step: a second of CPU work
-    assert set(r) == {"value", "unit", "cores", "kind", "sample"}
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(r)          # the contract fields ...
+    assert {"seconds_per_step", "forward_s", "backward_s", "optimizer_s", "per_iteration_s"} <= set(r)      # ... and the SURVEY 8(d) split
     assert r["kind"] == "port" and r["unit"] == "volumes/s" and r["value"] > 0 and r["cores"] >= 1
-    assert "32^3" in r["sample"]
+    assert "32^3" in r["sample"] and "1 warm-up + 3 timed" in r["sample"] and len(r["per_iteration_s"]) == 3
+    assert abs(r["forward_s"] + r["backward_s"] + r["optimizer_s"] - r["seconds_per_step"]) < 0.25 * r["seconds_per_step"]
 
 
 def test_pmc_traffic_lookup_checks_provenance(tmp_path, monkeypatch):

@@ -71,12 +71,26 @@ def test_two_rank_gradient_accumulation_with_no_sync(tmp_path, emu_backend):
         assert torch.equal(recs[0]["sd2"][k], recs[1]["sd2"][k]), k
 
 
-def _two_rank_step(tmp_path, device):
-    recs = _run_workers(tmp_path, device)
+def test_two_rank_graphed_step_exchanges_the_flat_buffer(tmp_path, emu_backend):
+    """HipGraphedTrainStep with a GradientBucketReducer attached (graph.py): the step runs without the per-bucket callbacks and the
+    flat gradient buffer is all-reduced once before Adam. On CPU the step is uncaptured (capture=False: the same host logic); the
+    result must be the bucketed step's: mean-over-ranks gradients, identical weights on both ranks."""
+    _two_rank_step(tmp_path, "cpu", "graphstep")
+
+
+@pytest.mark.gpu
+def test_two_rank_graphed_step_on_hip_kernels(tmp_path, hip_backend):
+    """The same with both ranks on cuda:0: forward + loss + backward captured as a HIP graph, the flat all-reduce (gloo) and Adam
+    after every replay."""
+    _two_rank_step(tmp_path, "cuda", "graphstep")
+
+
+def _two_rank_step(tmp_path, device, mode="step"):
+    recs = _run_workers(tmp_path, device, mode)
     # broadcast: both ranks start from rank 0's weights
     for k in recs[0]["sd0"]:
         assert torch.equal(recs[0]["sd0"][k], recs[1]["sd0"][k]), k
-    assert recs[0]["n_buckets"] >= 3                      # the exchange really was split into several buckets
+    assert recs[0]["n_buckets"] >= 3 or mode == "graphstep"      # the eager exchange really was split into several buckets
     # oracle: mean over ranks of the per-rank gradient on rank-specific data
     want = None
     for r in range(2):

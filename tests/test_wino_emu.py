@@ -1,5 +1,6 @@
 """Winograd F(2x2, 3x3) x direct-z form of the 3x3x3 stride-1 convolution (csrc/conv3d_wino.hip) on the CPU emulator, against
-F.conv3d: fp32, tolerance 1e-5 (measured ~1e-6). PREPARED, not yet measured on an MI355X (tools/NEXT.md)."""
+F.conv3d: fp32, tolerance 1e-5 (measured ~1e-6). The emulator checks the index logic and the order of operations; the GPU twins
+(tests/test_wino_gpu.py) run the same cases through the HIP library."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -10,24 +11,12 @@ from oracle import torch_ops as O
 ops = C.ops
 
 
-@pytest.fixture(autouse=True, params=[("1", "2", "zring", "1"), ("1", "2", "zring", "2"), ("1", "2", "zring", ""), ("1", "2", "w8", ""), ("1", "2", "tile", ""), ("1", "0", "tile", ""),
-                                       ("1", "1", "tile", ""), ("0", "0", "tile", "")],
-                ids=["z-marching-whole-columns", "z-marching-two-ranges", "z-marching", "eight-waves", "pipelined-weights-ahead", "pipelined", "pipelined-weights-first", "three-barrier"])
-def wino_variant(request, monkeypatch):
-    """the forms of the forward kernel: the z-marching workgroup (conv3d_wino2d_zring) and the main-loop variants of the tile kernel
-    (MI355_WINO_FORM / MI355_WINO_PIPE / MI355_WINO_BMODE, read by the library at every call)"""
-    monkeypatch.setenv("MI355_WINO_PIPE", request.param[0])
-    monkeypatch.setenv("MI355_WINO_BMODE", request.param[1])
-    monkeypatch.setenv("MI355_WINO_FORM", request.param[2])
-    monkeypatch.setenv("MI355_WINO_ZSPLITS", request.param[3])
-
-
 @pytest.mark.parametrize("kw", [
     dict(n=1, cin=8, cout=32, dhw=(2, 8, 16)),                                   # exactly one tile
     dict(n=2, cin=32, cout=32, dhw=(4, 8, 16), bias=True),                       # two z tiles, four channel chunks
     dict(n=1, cin=16, cout=64, dhw=(3, 9, 19), norm=True, residual=True, chscale=True),      # ragged in every axis, two channel tiles
     dict(n=1, cin=12, cout=40, dhw=(5, 6, 7), norm=True, slope=0.01, bias=True),  # partial channel chunk and tile
-    dict(n=2, cin=8, cout=32, dhw=(8, 8, 16), bias=True),                        # 8 workgroups: the XCD-contiguous order of the w8 form
+    dict(n=2, cin=8, cout=32, dhw=(8, 8, 16), bias=True),                        # 8 workgroups: the XCD-contiguous workgroup order
     dict(n=1, cin=16, cout=64, dhw=(8, 8, 16), norm=True),                       # the same with two channel tiles (4 spatial groups)
 ])
 def test_wino_forward_matches_conv3d(emu_backend, kw):

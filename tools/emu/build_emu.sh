@@ -10,7 +10,11 @@ rebuilt=0
 for f in "$src"/*.hip; do
   o="$here/build/$(basename "$f" .hip).o"
   mkdir -p "$here/build"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$here/emu.h" -nt "$o" ] || [ "$src/hipcompat.h" -nt "$o" ] || [ "$root/include/mi355_unet3d.h" -nt "$o" ]; then
+  stale=0
+  for dep in "$f" "$here/emu.h" "$root/include/mi355_unet3d.h" "$src"/*.h; do      # every header a kernel source may include
+    if [ ! -f "$o" ] || [ "$dep" -nt "$o" ]; then stale=1; fi
+  done
+  if [ "$stale" = 1 ]; then
     g++ -std=c++20 -O2 -g -fPIC -DMI355_EMU -Wno-unknown-pragmas -I"$here" -I"$src" -x c++ -c "$f" -o "$o" &
     pids+=($!)
     rebuilt=1
