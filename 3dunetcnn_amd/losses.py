@@ -96,6 +96,10 @@ class HipDiceLoss(nn.Module):
         self.smooth_dr = float(smooth_dr)
         self.include_background = bool(include_background)
         weight = torch.as_tensor(weight, dtype=torch.float32) if weight is not None else None
+        # MONAI raises on a negative weight at every forward; the value cannot change between calls, so it is read ONCE, here, while the
+        # tensor is still on the host (a device read per forward would be a host sync inside the step and breaks stream capture);
+        # a weight assigned later through `class_weight` is the caller's responsibility
+        self._weight_negative = bool(weight is not None and weight.numel() and float(weight.min()) < 0)      # raised where MONAI raises: in forward
         self.register_buffer("class_weight", weight)
         self._be = None
 
@@ -117,7 +121,7 @@ class HipDiceLoss(nn.Module):
             elif cw.shape[0] != ce:
                 raise ValueError("the length of the `weight` sequence should be the same as the number of classes. "
                                  "If `include_background=False`, the weight should not include the background category class 0.")
-            if float(cw.min()) < 0:
+            if self._weight_negative:
                 raise ValueError("the value/values of the `weight` should be no less than 0.")
         else:
             cw = None                                        # MONAI applies the weight only for more than one class
@@ -280,11 +284,27 @@ class HipBCEWithLogitsLoss(_CEBase):
 
 class HipCrossEntropyLoss(_CEBase):
     """torch.nn.CrossEntropyLoss(reduction="mean") with class-PROBABILITY targets of the input's shape (one-hot uint8 / float) or
-    class-INDEX targets [N, ...] (expanded to one-hot on the device; `ignore_index` entries are not supported)."""
+    class-INDEX targets [N, ...] (expanded to one-hot on the device).
+
+    `ignore_index` is NOT implemented: torch drops voxels labelled `ignore_index` (default -100) from the sum AND from the mean's
+    denominator; here a label outside [0, C) expands to an all-zero one-hot row that contributes 0 to the sum but still counts in the
+    denominator, so the value differs from torch's whenever such labels occur. None of the reference's configurations produces them
+    (its label maps are re-encoded to {0..C-1} or to nested regions, unet3d/utils/one_hot.py). `validate_targets=True` checks every
+    index target for out-of-range labels and raises (one device read = a host sync per call: a debugging aid, off by default)."""
     index_targets = True
-    def __init__(self, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction="mean", label_smoothing=0.0):
+    def __init__(self, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction="mean", label_smoothing=0.0,
+                 validate_targets=False):
         super().__init__()
         if weight is not None or reduction != "mean" or label_smoothing != 0.0 or size_average is not None or reduce is not None:
             raise NotImplementedError("HipCrossEntropyLoss implements reduction='mean' without weights / smoothing")
         self.ce_mode = "softmax"
+        self.validate_targets = bool(validate_targets)
         self._be = None
+
+    def forward(self, input, target):
+        if self.validate_targets and target.dim() == input.dim() - 1:
+            lo, hi = int(target.min()), int(target.max())
+            if lo < 0 or hi >= input.shape[1]:
+                raise ValueError(f"HipCrossEntropyLoss: class-index target outside [0, {input.shape[1]}) (min {lo}, max {hi}): "
+                                 "ignore_index / out-of-range labels are not implemented")
+        return super().forward(input, target)

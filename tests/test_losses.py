@@ -174,3 +174,19 @@ def test_unsupported_options_raise():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="MI355X"):
             losses.HipBCEWithLogitsLoss()(torch.zeros(1, 3, 4, 4, 4), torch.zeros(1, 3, 4, 4, 4))
+
+
+def test_cross_entropy_index_targets_out_of_range_are_flagged_on_request():
+    """torch's ignore_index is not implemented (losses.py: HipCrossEntropyLoss docstring); `validate_targets=True` turns the silent
+    difference into an error before any kernel runs."""
+    crit = losses.HipCrossEntropyLoss(validate_targets=True)
+    crit._be = object()
+    z = torch.zeros(1, 3, 2, 2, 2)
+    t = torch.zeros(1, 2, 2, 2, dtype=torch.long)
+    t[0, 0, 0, 0] = -100
+    with pytest.raises(ValueError, match="ignore_index"):
+        crit(z, t)
+    t[0, 0, 0, 0] = 3
+    with pytest.raises(ValueError, match="outside"):
+        crit(z, t)
+
