@@ -124,8 +124,11 @@ class PackedWeight:
 
 
 class Backend:
-    # measured twice (profiles/r2_winograd_prep_measurement.txt, r3_winograd_landing.txt): no gain on the 16^3 level (256 channels), 20-38 % above it
-    WINO_MIN_VOXELS = 32 ** 3
+    # Routing threshold of the Winograd kernels (voxels per sample). The first, 4-wave form showed no gain on the 16^3 level (256 channels:
+    # profiles/r2_winograd_prep_measurement.txt, r3_winograd_landing.txt); the 8-wave kernel and the interleaved ring weight gradient do
+    # (profiles/r3_wino_forms.txt section 5: forward 0.231 -> 0.136 ms, weight gradient 0.338 -> 0.220 ms, step 57.5 -> 56.0 ms). Below
+    # 16^3 a launch has fewer workgroups than the chip has CUs: the direct kernels' smaller tiles stay.
+    WINO_MIN_VOXELS = 16 ** 3
     # executed / algorithmic multiplications of the Winograd kernels (bench.py reports both rates)
     WINO_EXECUTED = {"conv3d_wino2d": 12.0 / 27.0, "conv3d_wgrad_wino_ring (+reduce)": 16.0 / 36.0}
 
@@ -149,6 +152,8 @@ class Backend:
         # (A first Winograd weight gradient -- one dz per workgroup, planes transformed three times -- measured 2x SLOWER than the ring
         # kernel, profiles/r3_winograd_landing.txt, and was deleted.)
         self.wgrad_form = os.environ.get("MI355_WGRAD_FORM", "wino")
+        if os.environ.get("MI355_WINO_MIN_VOXELS"):          # A/B of the routing threshold (forward / dgrad and weight gradient alike)
+            self.WINO_MIN_VOXELS = int(os.environ["MI355_WINO_MIN_VOXELS"])
 
         self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
         # norm statistics leave with the producing conv's epilogue (csrc/gn_fuse.h). False: every statistic is a standalone pass

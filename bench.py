@@ -436,6 +436,22 @@ def main():
                     "all_kernels": {k: {"s": round(v[0], 5), "tflops": round(v[1] / v[0] / 1e12, 2), "launches": v[3]}
                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
 
+    # The north star's literal conv line: the 3x3x3 conv on the 4-channel 128^3 input (first layer), forward + backward against the HBM
+    # roofline. Algorithmic bytes per pass = x + y (+ weights) once: forward 604 MB, weight gradient 604 MB, data gradient 604 MB at N = 2.
+    first_layer = None
+    if prof:
+        fl = {k: v for k, v in agg.items() if k.startswith("conv3d_c4")}
+        if len(fl) >= 3:
+            secs_f = sum(v[0] for v in fl.values())
+            by_f = sum(v[2] for v in fl.values())
+            first_layer = {"kernels_ms_per_launch": {k: round(v[0] / v[3] * 1e3, 4) for k, v in fl.items()},
+                           "fwd_plus_bwd_ms": round(sum(v[0] / v[3] for v in fl.values()) * 1e3, 4),
+                           "algorithmic_bytes_fwd_plus_bwd": round(sum(v[2] / v[3] for v in fl.values())),
+                           "hbm_gbps_algorithmic": round(by_f / secs_f / 1e9, 1), "hbm_frac": round(by_f / secs_f / 1e9 / HBM_PEAK_GBPS, 4),
+                           "arithmetic": ARITH[args.precision],
+                           "bound": "exact fp32: 29 GFLOP per pass on the fp32 matrix / packed vector pipes = >= 0.18 ms per pass against 0.08-0.12 ms "
+                                    "of HBM time, i.e. the layer is arithmetic-bound in the headline precision and 60 % of 8 TB/s is out of "
+                                    "reach there (DESIGN.md section 3); the 16-bit modes move the forward to the bf16 pipe"}
     if rank == 0:
         out = {"metric": "training volumes/sec (128^3, 4ch->3cls)" if args.config != "c4" else "training volumes/sec (160x192x128, 4ch->3cls, 5 levels)",
                "value": round(world * B * args.steps / dt, 4), "unit": "volumes/s",
@@ -450,7 +466,7 @@ def main():
                "config": {"workload": f"BASELINE configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.config] }]: {model_desc}, {'x'.join(str(v) for v in dhw)} patch, batch {B}/GPU, fp32 tensors, "
                                       f"fwd + sigmoid-Dice + bwd + Adam" + (", Dropout3d on" if args.model == "unet3d" else ""),
                           "conv_arithmetic": ARITH[args.precision], "global_batch": world * B, "parallelism": f"dp{world}"},
-               "final_loss": round(loss_val, 6), "roofline": roofline}
+               "final_loss": round(loss_val, 6), "roofline": roofline, "first_layer": first_layer}
         if world == 1 and args.precision == "fp32" and not args.no_precision_modes and args.config == "c2":
             # informational: the same step with the opt-in arithmetic modes of the 3x3x3 stride-1 convs;
             # `value` above is the exact-fp32 number
