@@ -55,6 +55,7 @@ STATUS = {0: "ok", -1: "invalid argument (shape/alignment/null)", -2: "unsupport
 SIGNATURES = {
     "mi355_packed_weight_elems": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "mi355_pack_conv_weight": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "mi355_pack_weights_batch": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     "mi355_packed_weight_bytes_bf16": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "mi355_pack_conv_weight_bf16": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mi355_conv3d_uses_bf16": (ctypes.c_int, [POINTER(MiConvDesc)]),

@@ -15,6 +15,7 @@
 #include "hipcompat.h"
 #include "../../include/mi355_unet3d.h"
 #include "gn_fuse.h"
+#include "pack_values.h"
 
 struct ConvArgs {
   const float* x; int xld;
@@ -608,25 +609,34 @@ void conv3d_mfma(ConvArgs a) {
 //         flipped taps: wp[t'][ci][co] = w[ci][co][flip(t')]
 // mode 3: ConvTranspose3d dgrad = plain stride-2 correlation of dy: "in" = co, "out" = ci, taps not flipped.
 __global__ void pack_weight_kernel(const float* w, float* wp, int cout, int cin, int T, int coutP, int cinP, int mode) {
-  // logical packed dims: O (out), I (in)
+  // logical packed dims: O (out), I (in); the element definition is pack_values.h: pack_f32_value
   const size_t total = (size_t)T * (cinP / 4) * coutP * 4;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int e = idx & 3;
-    size_t r = idx >> 2;
-    const int o = r % coutP; r /= coutP;
-    const int iq = r % (cinP / 4); r /= (cinP / 4);
-    const int t = (int)r;
-    const int i = iq * 4 + e;
-    float v = 0.f;
-    if (o < cout && i < cin) {
-      const int tf = T - 1 - t;
-      if (mode == 0) v = w[((size_t)o * cin + i) * T + t];
-      else if (mode == 1) v = w[((size_t)i * cout + o) * T + tf];   // w[co=i][ci=o], here cout/cin are the packed roles
-      else if (mode == 2) v = w[((size_t)i * cout + o) * T + tf];   // w[ci=i][co=o][flip]
-      else v = w[((size_t)o * cin + i) * T + t];                      // mode 3: w[ci=o][co=i][t]
-    }
-    wp[idx] = v;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+    wp[idx] = pack_f32_value(w, idx, cout, cin, T, coutP, cinP, mode);
+}
+
+// Every pack of a training step in ONE launch: blockIdx.y = task, blockIdx.x strides over the task's elements.
+__global__ void pack_batch_kernel(const mi355_pack_task* tasks) {
+  const mi355_pack_task t = tasks[blockIdx.y];
+  const int coutP = (t.cout + 31) / 32 * 32, cinP = (t.cin + 7) / 8 * 8;
+  if (t.kind == MI355_PACK_WINO) {
+    const size_t total = (size_t)48 * cinP * coutP;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+      t.out[idx] = pack_wino_value(t.w, idx, t.cout, t.cin, coutP, cinP, t.mode);
+  } else {
+    const int T = t.kd * t.kd * t.kd;
+    const size_t total = (size_t)T * cinP * coutP;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+      t.out[idx] = pack_f32_value(t.w, idx, t.cout, t.cin, T, coutP, cinP, t.mode);
   }
+}
+
+// tasks: DEVICE array of ntasks records (the caller builds it once; the pointers of a training loop do not change from step to step).
+// blocks_per_task: workgroups (256 threads, grid-stride) per task, chosen by the caller from its largest task.
+extern "C" int mi355_pack_weights_batch(const mi355_pack_task* tasks, int32_t ntasks, int32_t blocks_per_task, void* stream) {
+  if (!tasks || ntasks <= 0 || ntasks > 65535 || blocks_per_task <= 0 || blocks_per_task > 4096) return MI355_EINVAL;
+  LAUNCH(pack_batch_kernel, dim3((unsigned)blocks_per_task, (unsigned)ntasks), dim3(256), 0, stream, tasks);
+  return LAUNCH_CHECK();
 }
 
 extern "C" size_t mi355_packed_weight_elems(int32_t cout, int32_t cin, int32_t kd, int32_t mode) {

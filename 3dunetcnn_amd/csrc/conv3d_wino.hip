@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include "../../include/mi355_unet3d.h"
 #include "gn_fuse.h"
+#include "pack_values.h"
 
 struct WinoArgs {
   const float* x; int xld;
@@ -386,8 +387,9 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(Wi
       pw[rowoff * 32] = jh ? m0 : sm;
       pw[(32 + rowoff) * 32] = jh ? -sm : m1;
     }
-    // reads that do not depend on the exchange go out before the barrier: the normalised tensor (FUSE 2) and the residual (requesting
-    // both planes' at the top of the epilogue was measured: 27 spilled registers, the norm-backward form 16 % slower)
+    // reads that do not depend on the exchange go out before the barrier: the normalised tensor (FUSE 2) and the residual. Measured and
+    // reverted (profiles/r3_wino_forms.txt): both planes' requests at the top of the epilogue (27 spilled registers, the norm-backward
+    // form 16 % slower) and plane 1's requests right after plane 0's barrier (23 spills, some reloaded inside the main loop: +12 %)
     const int z = tz0 + oz, zc = z < a.D ? z : a.D - 1;
     float gxv[2][4], rsv[2][4];
     size_t vox[2];
@@ -537,32 +539,11 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(Wi
 #undef W8_PATTERN_ONE_USE
 #undef W8_PATTERN_TWO_USE
 
-// ---- filter transform: U[(i,j)][dz][ci][co] = sum_{dy,dx} G[i][dy] G[j][dx] w[...], G rows: g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2 ----
-// mode 0: forward, w OIDHW [cout][cin][3][3][3]. mode 1: dgrad of Conv3d: roles swapped ("out" = ci, "in" = co), all three taps flipped.
+// ---- filter transform: U[(i,j)][dz][ci][co] = sum_{dy,dx} G[i][dy] G[j][dx] w[...] (pack_values.h: pack_wino_value) ----
 __global__ void wino_pack_weight_kernel(const float* w, float* up, int cout, int cin, int coutP, int cinP, int mode) {
   const size_t total = (size_t)48 * (cinP / 4) * coutP * 4;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int e = idx & 3;
-    size_t r = idx >> 2;
-    const int o = r % coutP; r /= coutP;
-    const int iq = r % (cinP / 4); r /= (cinP / 4);
-    const int pd = (int)r, p = pd / 3, dz = pd % 3;
-    const int pi = p >> 2, pj = p & 3;
-    const int i = iq * 4 + e;
-    float v = 0.f;
-    if (o < cout && i < cin) {
-      float g[3][3];
-      for (int dy = 0; dy < 3; ++dy)
-        for (int dx = 0; dx < 3; ++dx)
-          g[dy][dx] = mode == 0 ? w[((size_t)o * cin + i) * 27 + (dz * 3 + dy) * 3 + dx]
-                                : w[((size_t)i * cout + o) * 27 + ((2 - dz) * 3 + (2 - dy)) * 3 + (2 - dx)];      // w[co = i][ci = o], flipped
-      float t[3];                           // row pi of G applied along dy
-      for (int dx = 0; dx < 3; ++dx)
-        t[dx] = pi == 0 ? g[0][dx] : pi == 1 ? 0.5f * (g[0][dx] + g[1][dx] + g[2][dx]) : pi == 2 ? 0.5f * (g[0][dx] - g[1][dx] + g[2][dx]) : g[2][dx];
-      v = pj == 0 ? t[0] : pj == 1 ? 0.5f * (t[0] + t[1] + t[2]) : pj == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2];
-    }
-    up[idx] = v;
-  }
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+    up[idx] = pack_wino_value(w, idx, cout, cin, coutP, cinP, mode);
 }
 
 extern "C" size_t mi355_wino_weight_elems(int32_t cout, int32_t cin) {

@@ -100,12 +100,31 @@ class HipNetBase(nn.Module):
         parameter tensor to the OIDHW tensor that is packed (used for ConvTranspose3d(k2,s2) -> 1x1x1 GEMM weights)."""
         ent = self._packed.get(id(p))
         if ent is None or ent[0] != p._version or self._packs_dirty_local or ent[2] != p.data_ptr():
-            ent = [p._version, {}, p.data_ptr()]
+            ent = [p._version, {}, p.data_ptr(), transform is not None]
             self._packed[id(p)] = ent
         if mode not in ent[1]:
             w = p.data if transform is None else transform(p.data).contiguous()
             ent[1][mode] = self._be.pack_weight(w, mode)      # lazily packed per format (ops.PackedWeight)
         return ent[1][mode]
+
+    def _repack_stale(self, be, force):
+        """Start of a forward after an optimizer step: every pack whose parameter changed (version counter, or `force` after
+        mark_parameters_updated) is refreshed in ONE launch (Backend.repack_batch) instead of being dropped and rebuilt by ~70 single
+        launches during the step. Entries whose weight moved, or whose pack source is a transformed copy (ConvTranspose3d(k2, s2) as a
+        1x1x1 GEMM), are dropped and rebuilt lazily as before."""
+        batch = []
+        single = os.environ.get("MI355_BATCH_PACK", "1") == "0"      # A/B switch: the former one-launch-per-pack behaviour
+        for p in self._params():
+            ent = self._packed.get(id(p))
+            if ent is None or not (force or ent[0] != p._version):
+                continue
+            if single or ent[3] or ent[2] != p.data_ptr():
+                del self._packed[id(p)]
+                continue
+            ent[0] = p._version
+            batch.extend(ent[1].values())
+        if batch:
+            be.repack_batch(batch)
 
     # ---- forward / backward bridge -------------------------------------------------------------------------------
     def _check_input(self, x):
@@ -150,6 +169,9 @@ class HipNetBase(nn.Module):
             dev = self._flat.device if self._flat is not None else None
             self._be = _ops.default_backend(dev.index if dev is not None and dev.type == "cuda" else None)
         be = self._be
+        if self._packed:
+            self._repack_stale(be, self._packs_dirty)
+            self._packs_dirty = False                      # entries dropped there are rebuilt on first use (their entry is gone)
         self._packs_dirty_local = self._packs_dirty
         self._saved_precision = be.precision
         if self.conv_precision is not None:

@@ -53,9 +53,10 @@ class HipGraphedTrainStep:
         with torch.cuda.stream(side):
             # warm-up off the default stream: sizes the backend workspace, the flat gradient buffer and the allocator pools.
             # No optimizer step here -- constructing the graph must not change the weights.
-            for _ in range(max(1, warmup)):
+            for _ in range(max(2, warmup)):
                 optimizer.zero_grad(set_to_none=True)
                 criterion(model(self.x), self.y).backward()
+                model.mark_parameters_updated()      # the next forward repacks in one launch: its device task table exists before capture
         torch.cuda.current_stream().wait_stream(side)
         optimizer.zero_grad(set_to_none=True)        # capture writes the gradients in place (no accumulate branch)
         model.mark_parameters_updated()              # the pack kernels are part of every replay

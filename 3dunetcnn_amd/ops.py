@@ -194,6 +194,42 @@ class Backend:
         """w: Conv3d weight [O, I, k, k, k] (modes 0, 1) or ConvTranspose3d weight [I, O, k, k, k] (modes 2, 3)."""
         return PackedWeight(self, w, mode)
 
+    def repack_batch(self, packed):
+        """Refresh the fp32 and Winograd packs that the PackedWeights in `packed` hold from their (updated) weight tensors in ONE launch
+        (mi355_pack_weights_batch); their 16-bit packs are dropped and rebuilt on first use. The device task table is cached: in a
+        training loop neither the weights (views of the flat parameter buffer) nor the pack buffers move."""
+        import numpy as np
+        tasks, biggest = [], 1
+        for pw in packed:
+            pw._bf16 = {}
+            cinP, coutP = (pw.cin + 7) // 8 * 8, (pw.cout + 31) // 32 * 32
+            if pw._f32 is not None:
+                tasks.append((pw.w.data_ptr(), pw._f32.data_ptr(), pw.cout, pw.cin, pw.kd, pw.mode, 0, 0))
+                biggest = max(biggest, pw.kd ** 3 * cinP * coutP)
+            if getattr(pw, "_wino", None) is not None:
+                tasks.append((pw.w.data_ptr(), pw._wino.data_ptr(), pw.cout, pw.cin, pw.kd, pw.mode, 1, 0))
+                biggest = max(biggest, 48 * cinP * coutP)
+        if not tasks:
+            return 0
+        key = tuple(tasks)
+        if getattr(self, "_pack_table_key", None) != key and self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # a new table needs a host-to-device copy, which a stream capture cannot contain: the single-weight launches do the same work
+            for w, out, cout, cin, kd, mode, kind, _ in tasks:
+                if kind == 0:
+                    check(self.lib.mi355_pack_conv_weight(w, out, cout, cin, kd, mode, self.stream()), "pack_conv_weight")
+                else:
+                    check(self.lib.mi355_wino_pack_weight(w, out, cout, cin, mode, self.stream()), "wino_pack_weight")
+            return len(tasks)
+        if getattr(self, "_pack_table_key", None) != key:
+            rec = np.array(tasks, dtype=[("w", "<u8"), ("out", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("kd", "<i4"), ("mode", "<i4"),
+                                         ("kind", "<i4"), ("reserved", "<i4")])
+            assert rec.itemsize == 40                      # sizeof(mi355_pack_task)
+            self._pack_table = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
+            self._pack_table_key = key
+        blocks = max(1, min(1024, (biggest + 1023) // 1024))      # the largest task (256 -> 256 Winograd: 3.1 M elements) sets the grid; small tasks' extra workgroups exit
+        check(self.lib.mi355_pack_weights_batch(self._pack_table.data_ptr(), len(tasks), blocks, self.stream()), "pack_weights_batch")
+        return len(tasks)
+
     # -- conv ----------------------------------------------------------------------------------------------------
     def _desc(self, kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep, in_slope=None,
               out_mode=OUT_PLAIN):

@@ -365,15 +365,21 @@ def main():
     side = bool(getattr(model, "backward_side_stream", False)) and dev.type == "cuda"
     if not args.no_kernel_events and not side:
         be.prof = []
-    host_s[0], host_s[1] = 0.0, 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    host_ms = host_s[0] / max(host_s[1], 1) * 1e3                 # this rank's Python / launch work per step inside the timed region
     prof_timed, be.prof = be.prof, None
     loss_val = float(loss.item())
+    # Host enqueue time of one step, measured OUTSIDE the timed region on an idle device: inside it a GPU-bound loop runs the host into
+    # the launch queue's depth limit, and the time spent blocked there says nothing about the Python / launch work of a step.
+    host_s[0], host_s[1] = 0.0, 0
+    for _ in range(2):
+        step()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+    host_ms = host_s[0] / max(host_s[1], 1) * 1e3
     # Roofline pass. The timed region runs the weight-gradient kernels on a second stream (engine.py: backward_side_stream), where a
     # launch shares the chip with the dgrad chain and its HIP-event duration is not its own. The kernel's rate is therefore measured
     # on ROOF_STEPS extra steps right after the timed region with that overlap switched off (one stream, every launch alone);
@@ -457,8 +463,8 @@ def main():
                "value": round(world * B * args.steps / dt, 4), "unit": "volumes/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
-               # host time a rank spends enqueueing one step (Python + ~600 C-ABI launches in the eager form, 3 launches with --graph);
-               # the step is GPU-bound while this stays below ms_per_step
+               # host time a rank spends enqueueing one step onto an idle device (Python + ~600 C-ABI launches in the eager form, 3 launches
+               # with --graph; two extra steps after the timed region); the step is GPU-bound while this stays below ms_per_step
                "per_rank_host_enqueue_ms_per_step": [round(t, 3) for t in per_rank_host],
                "step_form": "hip-graph replay + one flat all-reduce" if graphed is not None else "eager launches, bucketed all-reduce inside backward",
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision],

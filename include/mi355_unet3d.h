@@ -129,6 +129,20 @@ typedef struct mi355_gn_bwd_fuse {
 size_t mi355_packed_weight_elems(int32_t cout, int32_t cin, int32_t kd, int32_t mode);
 int mi355_pack_conv_weight(const float* w, float* wp, int32_t cout, int32_t cin, int32_t kd, int32_t mode, void* stream);
 
+/* All fp32 / Winograd packs of a training step in ONE launch (the reference re-reads nn.Conv3d.weight on every call,
+ * unet3d/models/pytorch/classification/resnet.py:12-17; here the kernel-layout copies are refreshed once per optimizer step, and ~70
+ * launches of 5-12 us are 0.6 ms of launch latency per step). `tasks` is a DEVICE array: a caller whose weight and pack buffers keep
+ * their addresses (a training loop) builds it once. kind MI355_PACK_F32: out = mi355_pack_conv_weight(w, cout, cin, kd, mode);
+ * MI355_PACK_WINO: out = mi355_wino_pack_weight(w, cout, cin, mode) (kd ignored). blocks_per_task: 256-thread workgroups per task
+ * (grid-stride), 1..4096. */
+#define MI355_PACK_F32 0
+#define MI355_PACK_WINO 1
+typedef struct {
+  const float* w; float* out;
+  int32_t cout, cin, kd, mode, kind, reserved;
+} mi355_pack_task;
+int mi355_pack_weights_batch(const mi355_pack_task* tasks, int32_t ntasks, int32_t blocks_per_task, void* stream);
+
 /* Packed layouts of the bf16 paths: [tap][cinP/8][plane][coutP][8] bf16, cinP = roundup(cin,16), planes per `precision`.
  * Same `mode` / role conventions as mi355_pack_conv_weight (modes 0 and 1, kd == 3). mi355_conv3d_uses_bf16 tells the caller
  * which pack a given conv call consumes (1: the bf16 pack of desc->precision, 0: the fp32 pack). */

@@ -115,10 +115,10 @@ def test_emulated_dynunet_fwd_bwd(emu_backend):
 #   5 levels 32^3: grad 0.084, n_loose 3, max_err 6.8e-3 | 3 levels 16x24x32 batch 2: 0.110, 3, 4.1e-3 |
 #   BraTS config 64^3: 0.122, n_loose 64 of 70, max_err 0.166 -- with a 2^3 bottleneck nearly every gradient of this configuration sits
 #   at its conditioning floor ("numerically touchy"); what is held there is the error / allowance ratio.
-# n_loose of "five": 6 with the direct and the first Winograd kernels, 8 with conv3d_wino2d_w8 (another summation order; 55 of the 70
+# n_loose of "five": 6 with the direct and the first Winograd kernels, 8 with conv3d_wino2d_w8, 13 with the 16^3 level on it too (other summation orders; 55 of the 70
 # tensors are ill-conditioned here: noise floor 1.8e-2). The conditioning-INDEPENDENT criterion is tests/test_launch_audit.py (every
 # launch of the step against fp64 from the same inputs, <= 1e-5).
-RECORDED = {"five": dict(grad=0.5, n_loose=10, max_err_vs_fp32=3e-2, logits=5e-5), "three": dict(grad=0.5, n_loose=6, max_err_vs_fp32=2e-2, logits=5e-5),
+RECORDED = {"five": dict(grad=0.5, n_loose=16, max_err_vs_fp32=3e-2, logits=5e-5), "three": dict(grad=0.5, n_loose=6, max_err_vs_fp32=2e-2, logits=5e-5),
             "brats": dict(grad=0.5, n_loose=68, max_err_vs_fp32=0.5, logits=5e-5)}
 
 

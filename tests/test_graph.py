@@ -75,11 +75,24 @@ def test_graphed_step_train_mode_dropout_draws_a_new_mask_per_replay(hip_backend
 
 
 @pytest.mark.gpu
-def test_graphed_step_rejects_ddp_model(hip_backend):
+def test_graphed_step_accepts_ddp_model(hip_backend):
+    """A model with a GradientBucketReducer attached is captured WITHOUT the reducer's per-bucket callbacks (a replay cannot call back into
+    Python) and exchanges the flat gradient buffer after the replay (graph.py; world size 1 here: the exchange is a no-op, the
+    world-size-2 form is tests/test_ddp_gloo.py). The reducer must be attached again afterwards: an eager backward still uses it."""
     ddp = importlib.import_module("3dunetcnn_amd.ddp")
-    m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1]).cuda()
+    m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1]).cuda().eval()
     m.flatten_parameters()
-    ddp.GradientBucketReducer(m)
+    red = ddp.GradientBucketReducer(m)
     x, y = (t.cuda() for t in R.synthetic_case(1, 4, (16, 16, 16), 3))
-    with pytest.raises(RuntimeError, match="GradientBucketReducer"):
-        graph.HipGraphedTrainStep(m, losses.HipDiceLoss(sigmoid=True), optim.HipAdam(m.parameters()), x, y)
+    crit, opt = losses.HipDiceLoss(sigmoid=True), optim.HipAdam(m.parameters(), lr=1e-3)
+    before = m._flat.detach().clone()
+    step = graph.HipGraphedTrainStep(m, crit, opt, x, y)
+    assert step.reducer is red
+    assert m.grad_ready_callback is not None and m.grad_sync_callback is not None
+    assert torch.equal(m._flat, before)                     # construction does not step
+    l0 = float(step(x, y))
+    l1 = float(step(x, y))
+    assert l0 > 0 and l1 != l0 and not torch.equal(m._flat, before)
+    opt.zero_grad(set_to_none=True)
+    crit(m(x), y).backward()                                # eager backward through the re-attached reducer
+    assert red.n_launched == 0                              # (world size 1: no collective is issued)

@@ -82,7 +82,7 @@ def _run_pair(kw, enc, dhw, n, tc=False, seed=1234, train=False):
 # per-launch fp64 audit, which does not depend on it.
 RECORDED = {
     "32": dict(grad=0.02, n_loose=0, max_err_vs_fp32=3e-4, logits=2e-5),
-    "odd": dict(grad=0.02, n_loose=18, max_err_vs_fp32=3e-2, logits=2e-5),
+    "odd": dict(grad=0.25, n_loose=18, max_err_vs_fp32=3e-2, logits=2e-5),      # grad 0.11 since the 16^3 level runs on the Winograd kernels too (n_loose 0, max error 7e-4)
     "64": dict(grad=0.5, n_loose=30, max_err_vs_fp32=1.5e-2, logits=2e-5),
     "tc": dict(grad=0.02, n_loose=0, max_err_vs_fp32=1e-3, logits=2e-5),
     "five": dict(grad=0.25, n_loose=2, max_err_vs_fp32=1e-3, logits=2e-5),

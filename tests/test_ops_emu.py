@@ -360,3 +360,77 @@ def test_interior_and_general_epilogues_store_identical_values(emu_backend, prec
     assert torch.equal(a, c2[:, :, 1:, 1:, 1:])
     assert bool((c2[:, :, 0] == 7.0).all()) and bool((c2[:, :, :, 0] == 7.0).all()) and bool((c2[..., 0] == 7.0).all())
 
+
+def test_batched_repack_equals_single_packs(emu_backend):
+    """mi355_pack_weights_batch (one launch for every pack of a step) writes exactly what the single-weight pack kernels write: fp32
+    packs in the four modes, Winograd packs in both, ragged channel counts."""
+    be = emu_backend
+    g = torch.Generator().manual_seed(11)
+    ws = [(torch.randn(40, 12, 3, 3, 3, generator=g), 0), (torch.randn(40, 12, 3, 3, 3, generator=g), 1), (torch.randn(8, 24, 1, 1, 1, generator=g), 0),
+          (torch.randn(16, 8, 3, 3, 3, generator=g), 2), (torch.randn(16, 8, 3, 3, 3, generator=g), 3)]
+    packs = [be.pack_weight(w, m) for w, m in ws]
+    for pw in packs:
+        pw.f32()
+    packs[0].wino(); packs[1].wino()
+    for w, _ in ws:                                   # "optimizer step": the weights change in place
+        w.mul_(-0.5).add_(0.25)
+    assert be.repack_batch(packs) == 7
+    fresh = [be.pack_weight(w, m) for w, m in ws]
+    for a, b in zip(packs, fresh):
+        assert torch.equal(a._f32, b.f32())
+    assert torch.equal(packs[0]._wino, fresh[0].wino()) and torch.equal(packs[1]._wino, fresh[1].wino())
+    key = be._pack_table_key
+    assert be.repack_batch(packs) == 7 and be._pack_table_key is key      # the device table is reused
+
+
+def test_training_step_repacks_in_one_launch(emu_backend):
+    """From the second step on, the packs of a training step are refreshed by ONE mi355_pack_weights_batch launch at the start of the
+    forward (engine.py: _repack_stale) and no single-weight pack kernel runs; the step computes what a model with freshly built packs
+    computes from the same weights."""
+    import importlib
+    unet = importlib.import_module("3dunetcnn_amd.unet")
+    losses = importlib.import_module("3dunetcnn_amd.losses")
+    optim = importlib.import_module("3dunetcnn_amd.optim")
+    from oracle import unet3d_ref as R
+    be = emu_backend
+    torch.manual_seed(5)
+    kw = dict(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1])
+    m = unet.HipUNet3D(**kw).eval()
+    m._be = be
+    crit, opt = losses.HipDiceLoss(sigmoid=True), optim.HipAdam(m.parameters(), lr=1e-2)
+    crit._be = opt._be = be
+    x, y = R.synthetic_case(1, 4, (16, 16, 16), 3)
+    counts = {"single": 0, "batch": 0}
+    orig = {n: getattr(be.lib, n) for n in ("mi355_pack_conv_weight", "mi355_wino_pack_weight", "mi355_pack_weights_batch")}
+
+    def counted(name, key):
+        def f(*a):
+            counts[key] += 1
+            return orig[name](*a)
+        return f
+    be.lib.mi355_pack_conv_weight = counted("mi355_pack_conv_weight", "single")
+    be.lib.mi355_wino_pack_weight = counted("mi355_wino_pack_weight", "single")
+    be.lib.mi355_pack_weights_batch = counted("mi355_pack_weights_batch", "batch")
+    try:
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            crit(m(x), y).backward()
+            opt.step()
+        first = dict(counts)
+        assert first["single"] > 10 and first["batch"] == 1          # step 1 packs lazily, step 2 starts with the batch
+        opt.zero_grad(set_to_none=True)
+        out = m(x)
+        crit(out, y).backward()
+        assert counts["batch"] == 2 and counts["single"] == first["single"], counts
+    finally:
+        for n, f in orig.items():
+            setattr(be.lib, n, f)
+    m2 = unet.HipUNet3D(**kw).eval()                   # the same weights through freshly built packs
+    m2._be = be
+    m2.load_state_dict(m.state_dict())
+    out2 = m2(x)
+    crit(out2, y).backward()
+    assert torch.equal(out.detach(), out2.detach())
+    for (k, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p.grad, q.grad), k
+

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 root=$(pwd)
 for w in $what; do
 case $w in
-tests) timeout 1800 python -m pytest tests -m gpu -q -s > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $out/pytest_gpu.log; tail -3 $out/pytest_gpu.log;;
+tests) timeout 1800 python -m pytest tests -m gpu -q -s --durations=30 > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $out/pytest_gpu.log; tail -3 $out/pytest_gpu.log;;
 bench) timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 600 $out/bench.json;;
 trace) (cd /tmp && MI355_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $root/$out/trace -o bench -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-precision-modes > $root/$out/trace.log 2>&1)
   rm -f $out/trace/bench_kernel_trace.csv; ls $out/trace | head;;
