@@ -86,15 +86,6 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(Wi
   const int n = b;
   const int co_base = cot * 32;
 
-  if (INMODE == MI355_IN_AFFINE_ACT) {
-    for (int c = tid; c < a.CinP; c += 512) {
-      const bool in = c < a.Cin;
-      prm[c] = in ? a.in_scale[(size_t)n * a.Cin + c] : 0.f;
-      prm[a.CinP + c] = in ? a.in_shift[(size_t)n * a.Cin + c] : 0.f;
-      prm[2 * a.CinP + c] = in ? (a.in_slope ? a.in_slope[c] : a.slope) : 0.f;
-    }
-  }
-
   f32x16 acc[TZ][2];                                       // [output plane][point q: p = 2 * wave + q]
 #pragma unroll
   for (int oz = 0; oz < TZ; ++oz)
@@ -305,14 +296,24 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(Wi
     __syncthreads();
   };
 
-  // prologue: planes 0 and 1 of the first chunk requested together, W0 requested; plane 0 staged and transformed, plane 1 staged
-  __syncthreads();                                         // prm
+  // prologue: planes 0 and 1 of the first chunk requested together, W0 requested; plane 0 staged and transformed, plane 1 staged. The
+  // norm-prologue parameters are fetched AFTER those requests (they are a global round trip of their own: in front of them, as in the
+  // first version, the workgroup's first input plane left one memory latency later) and are in LDS before the first staging write.
   float4 bA[2], bB[2];
   b_use(bA, 0, 0);
   loads(0, 0);
   const float4 ld0 = ld;
   const bool lok0 = lok;
   loads(0, 1);
+  if (INMODE == MI355_IN_AFFINE_ACT) {
+    for (int c = tid; c < a.CinP; c += 512) {
+      const bool in = c < a.Cin;
+      prm[c] = in ? a.in_scale[(size_t)n * a.Cin + c] : 0.f;
+      prm[a.CinP + c] = in ? a.in_shift[(size_t)n * a.Cin + c] : 0.f;
+      prm[2 * a.CinP + c] = in ? (a.in_slope ? a.in_slope[c] : a.slope) : 0.f;
+    }
+    __syncthreads();
+  }
   { const float4 ld1 = ld; const bool lok1 = lok; ld = ld0; lok = lok0; commit(xs, 0); ld = ld1; lok = lok1; }
   commit(xs + XSF, 0);
   __syncthreads();

@@ -117,7 +117,7 @@ def self_launch(n):
     return rc
 
 
-PMC_FILE = os.path.join("profiles", "r2_bench_fp32_hbm_traffic_pmc.csv")
+PMC_FILE = os.path.join("profiles", "r3_bench_fp32_hbm_traffic_pmc.csv")
 
 
 def pmc_traffic(kernel_name, precision):
@@ -429,8 +429,14 @@ def main():
         products = {"bf16x3": 3, "bf16x6": 6, "bf16": 1, "fp16": 1}.get(args.precision, 1) if on_bf16 else 1
         traffic, traffic_src = pmc_traffic(name, args.precision)
         executed = getattr(be, "WINO_EXECUTED", {}).get(name, 1.0)
-        roofline = {"bound": "mfma", "kernel": name, "measured": roof_note, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
+        # `achieved` is ALGORITHMIC (2 * N * V * Cin * Cout * 27 per launch / duration). A Winograd kernel executes only
+        # `executed` of those multiplications, so its roofline in algorithmic units is the matrix peak / executed (12/27 forward / dgrad,
+        # 16/36 weight gradient): `peak` is that figure, `frac` = achieved / peak = executed rate / MFMA peak, always <= 1.
+        roofline = {"bound": "mfma", "kernel": name, "measured": roof_note, "achieved": round(ach, 2), "peak": round(peak / executed, 1), "unit": "TFLOP/s",
+                    "frac": round(ach * executed / peak, 4), "mfma_peak_tflops": peak,
+                    "peak_note": ("algorithmic-equivalent peak = fp32 MFMA peak %.1f / %.4f executed-over-algorithmic multiplications" % (peak, executed))
+                                 if executed != 1.0 else "dense MFMA peak of the arithmetic type (MI355X_MICROARCH.md)",
+                    "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(by / cnt),
                     "mfma_products_per_mac": products, "mfma_pipe_frac": round(ach * products / peak * executed, 4),
                     # Winograd kernels execute fewer multiplications than the algorithmic count `achieved` / `frac` are quoted in (they can
