@@ -615,27 +615,37 @@ __global__ void pack_weight_kernel(const float* w, float* wp, int cout, int cin,
     wp[idx] = pack_f32_value(w, idx, cout, cin, T, coutP, cinP, mode);
 }
 
-// Every pack of a training step in ONE launch: blockIdx.y = task, blockIdx.x strides over the task's elements.
-__global__ void pack_batch_kernel(const mi355_pack_task* tasks) {
-  const mi355_pack_task t = tasks[blockIdx.y];
+// Every pack of a training step in ONE launch. The tasks differ by three orders of magnitude (a 4 -> 32 first layer against a
+// 256 -> 256 Winograd pack of 3.1 M elements), so the grid is cut into equal CHUNKS of MI355_PACK_CHUNK work items: workgroup b
+// finds its task by bisection over the cumulative `first_chunk` column (a grid of (blocks per task) x tasks, the first version, left
+// the large tasks to too few workgroups: 0.92 ms for 0.55 GB of traffic).
+__global__ __launch_bounds__(256) void pack_batch_kernel(const mi355_pack_task* tasks, int ntasks) {
+  int lo = 0, hi = ntasks - 1;
+  const int chunk = blockIdx.x;
+  while (lo < hi) {                                          // last task whose first_chunk <= chunk (workgroup-uniform)
+    const int mid = (lo + hi + 1) >> 1;
+    if (tasks[mid].first_chunk <= chunk) lo = mid; else hi = mid - 1;
+  }
+  const mi355_pack_task t = tasks[lo];
   const int coutP = (t.cout + 31) / 32 * 32, cinP = (t.cin + 7) / 8 * 8;
-  if (t.kind == MI355_PACK_WINO) {
-    const size_t total = (size_t)48 * cinP * coutP;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
-      t.out[idx] = pack_wino_value(t.w, idx, t.cout, t.cin, coutP, cinP, t.mode);
-  } else {
-    const int T = t.kd * t.kd * t.kd;
-    const size_t total = (size_t)T * cinP * coutP;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
-      t.out[idx] = pack_f32_value(t.w, idx, t.cout, t.cin, T, coutP, cinP, t.mode);
+  const int T = t.kd * t.kd * t.kd;
+  // work items: an fp32 pack element, or one (dz, ci, co) of a Winograd pack (16 outputs from 9 weights, pack_values.h)
+  const size_t items = t.kind == MI355_PACK_WINO ? (size_t)3 * cinP * coutP : (size_t)T * cinP * coutP;
+  const size_t base = (size_t)(chunk - t.first_chunk) * MI355_PACK_CHUNK;
+#pragma unroll 2
+  for (int k = 0; k < MI355_PACK_CHUNK / 256; ++k) {
+    const size_t idx = base + (size_t)k * 256 + threadIdx.x;
+    if (idx >= items) break;
+    if (t.kind == MI355_PACK_WINO) pack_wino_item(t.w, t.out, idx, t.cout, t.cin, coutP, cinP, t.mode);
+    else t.out[idx] = pack_f32_value(t.w, idx, t.cout, t.cin, T, coutP, cinP, t.mode);
   }
 }
 
-// tasks: DEVICE array of ntasks records (the caller builds it once; the pointers of a training loop do not change from step to step).
-// blocks_per_task: workgroups (256 threads, grid-stride) per task, chosen by the caller from its largest task.
-extern "C" int mi355_pack_weights_batch(const mi355_pack_task* tasks, int32_t ntasks, int32_t blocks_per_task, void* stream) {
-  if (!tasks || ntasks <= 0 || ntasks > 65535 || blocks_per_task <= 0 || blocks_per_task > 4096) return MI355_EINVAL;
-  LAUNCH(pack_batch_kernel, dim3((unsigned)blocks_per_task, (unsigned)ntasks), dim3(256), 0, stream, tasks);
+// tasks: DEVICE array of ntasks records with `first_chunk` filled in (cumulative ceil(work items / MI355_PACK_CHUNK) of the tasks before);
+// total_chunks: the sum over all tasks. The caller builds the table once: the pointers of a training loop do not change from step to step.
+extern "C" int mi355_pack_weights_batch(const mi355_pack_task* tasks, int32_t ntasks, int32_t total_chunks, void* stream) {
+  if (!tasks || ntasks <= 0 || ntasks > 65535 || total_chunks <= 0) return MI355_EINVAL;
+  LAUNCH(pack_batch_kernel, dim3((unsigned)total_chunks), dim3(256), 0, stream, tasks, (int)ntasks);
   return LAUNCH_CHECK();
 }
 

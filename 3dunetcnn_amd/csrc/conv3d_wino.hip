@@ -540,11 +540,11 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(Wi
 #undef W8_PATTERN_ONE_USE
 #undef W8_PATTERN_TWO_USE
 
-// ---- filter transform: U[(i,j)][dz][ci][co] = sum_{dy,dx} G[i][dy] G[j][dx] w[...] (pack_values.h: pack_wino_value) ----
+// ---- filter transform: U[(i,j)][dz][ci][co] = sum_{dy,dx} G[i][dy] G[j][dx] w[...] (pack_values.h: pack_wino_item) ----
 __global__ void wino_pack_weight_kernel(const float* w, float* up, int cout, int cin, int coutP, int cinP, int mode) {
-  const size_t total = (size_t)48 * (cinP / 4) * coutP * 4;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
-    up[idx] = pack_wino_value(w, idx, cout, cin, coutP, cinP, mode);
+  const size_t items = (size_t)3 * (cinP / 4) * coutP * 4;          // one per (dz, ci, co): 16 points each
+  for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < items; r += (size_t)gridDim.x * blockDim.x)
+    pack_wino_item(w, up, r, cout, cin, coutP, cinP, mode);
 }
 
 extern "C" size_t mi355_wino_weight_elems(int32_t cout, int32_t cin) {
@@ -556,8 +556,8 @@ extern "C" size_t mi355_wino_weight_elems(int32_t cout, int32_t cin) {
 extern "C" int mi355_wino_pack_weight(const float* w, float* up, int32_t cout, int32_t cin, int32_t mode, void* stream) {
   if (!w || !up || cout <= 0 || cin <= 0 || mode < 0 || mode > 1) return MI355_EINVAL;
   const int coutP = (cout + 31) / 32 * 32, cinP = (cin + 7) / 8 * 8;     // logical packed dims: cout = "out", cin = "in" of THIS conv
-  const size_t total = (size_t)48 * cinP * coutP;
-  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  const size_t items = (size_t)3 * cinP * coutP;
+  int grid = (int)((items + 255) / 256); if (grid > 4096) grid = 4096;
   LAUNCH(wino_pack_weight_kernel, dim3(grid), dim3(256), 0, stream, w, up, cout, cin, coutP, cinP, mode);
   return LAUNCH_CHECK();
 }

@@ -21,22 +21,44 @@ __device__ __forceinline__ float pack_f32_value(const float* w, size_t idx, int 
 
 // Winograd-domain layout [(p * 3 + dz)][ciP / 4][coP][4], U = G g G^T of the (dy, dx) slice (conv3d_wino.hip), G rows: g0,
 // (g0+g1+g2)/2, (g0-g1+g2)/2, g2. mode 0: forward, w OIDHW [cout][cin][3][3][3]; mode 1: dgrad of Conv3d (roles swapped, taps flipped).
-__device__ __forceinline__ float pack_wino_value(const float* w, size_t idx, int cout, int cin, int coutP, int cinP, int mode) {
-  const int e = idx & 3;
-  size_t r = idx >> 2;
-  const int o = r % coutP; r /= coutP;
-  const int iq = r % (cinP / 4); r /= (cinP / 4);
-  const int pd = (int)r, p = pd / 3, dz = pd % 3;
-  const int pi = p >> 2, pj = p & 3;
+// One WORK ITEM = one (dz, ci, co): its 9 weights are read once and all 16 points written (a thread per output element, the first
+// form, read 9 weights per element: 16x the loads). Item index r runs over [dz][ciP / 4][coP][4], so that consecutive threads write
+// consecutive addresses inside each of the 16 point slabs.
+__device__ __forceinline__ void pack_wino_item(const float* w, float* up, size_t r, int cout, int cin, int coutP, int cinP, int mode) {
+  const int e = r & 3;
+  size_t q = r >> 2;
+  const int o = q % coutP; q /= coutP;
+  const int iq = q % (cinP / 4); q /= (cinP / 4);
+  const int dz = (int)q;
   const int i = iq * 4 + e;
-  if (o >= cout || i >= cin) return 0.f;
-  float g[3][3];
-  for (int dy = 0; dy < 3; ++dy)
-    for (int dx = 0; dx < 3; ++dx)
-      g[dy][dx] = mode == 0 ? w[((size_t)o * cin + i) * 27 + (dz * 3 + dy) * 3 + dx]
-                            : w[((size_t)i * cout + o) * 27 + ((2 - dz) * 3 + (2 - dy)) * 3 + (2 - dx)];      // w[co = i][ci = o], flipped
-  float t[3];                           // row pi of G applied along dy
-  for (int dx = 0; dx < 3; ++dx)
-    t[dx] = pi == 0 ? g[0][dx] : pi == 1 ? 0.5f * (g[0][dx] + g[1][dx] + g[2][dx]) : pi == 2 ? 0.5f * (g[0][dx] - g[1][dx] + g[2][dx]) : g[2][dx];
-  return pj == 0 ? t[0] : pj == 1 ? 0.5f * (t[0] + t[1] + t[2]) : pj == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2];
+  const size_t slab = (size_t)3 * (cinP / 4) * coutP * 4;          // floats between consecutive points
+  float* dst = up + ((size_t)dz * (cinP / 4) + iq) * coutP * 4 + (size_t)o * 4 + e;
+  float u[4][4];
+  if (o < cout && i < cin) {
+    float g[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+        g[dy][dx] = mode == 0 ? w[((size_t)o * cin + i) * 27 + (dz * 3 + dy) * 3 + dx]
+                              : w[((size_t)i * cout + o) * 27 + ((2 - dz) * 3 + (2 - dy)) * 3 + (2 - dx)];      // w[co = i][ci = o], flipped
+    float t[4][3];                        // G applied along dy
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      t[0][dx] = g[0][dx]; t[1][dx] = 0.5f * (g[0][dx] + g[1][dx] + g[2][dx]); t[2][dx] = 0.5f * (g[0][dx] - g[1][dx] + g[2][dx]); t[3][dx] = g[2][dx];
+    }
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi) {      // ... and along dx: the same expressions as the per-element form, bit for bit
+      u[pi][0] = t[pi][0]; u[pi][1] = 0.5f * (t[pi][0] + t[pi][1] + t[pi][2]); u[pi][2] = 0.5f * (t[pi][0] - t[pi][1] + t[pi][2]); u[pi][3] = t[pi][2];
+    }
+  } else {
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+      for (int pj = 0; pj < 4; ++pj) u[pi][pj] = 0.f;
+  }
+#pragma unroll
+  for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj) dst[(size_t)(pi * 4 + pj) * slab] = u[pi][pj];
 }

@@ -199,16 +199,17 @@ class Backend:
         (mi355_pack_weights_batch); their 16-bit packs are dropped and rebuilt on first use. The device task table is cached: in a
         training loop neither the weights (views of the flat parameter buffer) nor the pack buffers move."""
         import numpy as np
-        tasks, biggest = [], 1
+        CHUNK = 1024                                       # MI355_PACK_CHUNK work items (fp32: elements; Winograd: (dz, ci, co) triples)
+        tasks, chunks = [], 0
         for pw in packed:
             pw._bf16 = {}
             cinP, coutP = (pw.cin + 7) // 8 * 8, (pw.cout + 31) // 32 * 32
             if pw._f32 is not None:
-                tasks.append((pw.w.data_ptr(), pw._f32.data_ptr(), pw.cout, pw.cin, pw.kd, pw.mode, 0, 0))
-                biggest = max(biggest, pw.kd ** 3 * cinP * coutP)
+                tasks.append((pw.w.data_ptr(), pw._f32.data_ptr(), pw.cout, pw.cin, pw.kd, pw.mode, 0, chunks))
+                chunks += (pw.kd ** 3 * cinP * coutP + CHUNK - 1) // CHUNK
             if getattr(pw, "_wino", None) is not None:
-                tasks.append((pw.w.data_ptr(), pw._wino.data_ptr(), pw.cout, pw.cin, pw.kd, pw.mode, 1, 0))
-                biggest = max(biggest, 48 * cinP * coutP)
+                tasks.append((pw.w.data_ptr(), pw._wino.data_ptr(), pw.cout, pw.cin, pw.kd, pw.mode, 1, chunks))
+                chunks += (3 * cinP * coutP + CHUNK - 1) // CHUNK
         if not tasks:
             return 0
         key = tuple(tasks)
@@ -222,12 +223,11 @@ class Backend:
             return len(tasks)
         if getattr(self, "_pack_table_key", None) != key:
             rec = np.array(tasks, dtype=[("w", "<u8"), ("out", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("kd", "<i4"), ("mode", "<i4"),
-                                         ("kind", "<i4"), ("reserved", "<i4")])
+                                         ("kind", "<i4"), ("first_chunk", "<i4")])
             assert rec.itemsize == 40                      # sizeof(mi355_pack_task)
             self._pack_table = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
             self._pack_table_key = key
-        blocks = max(1, min(1024, (biggest + 1023) // 1024))      # the largest task (256 -> 256 Winograd: 3.1 M elements) sets the grid; small tasks' extra workgroups exit
-        check(self.lib.mi355_pack_weights_batch(self._pack_table.data_ptr(), len(tasks), blocks, self.stream()), "pack_weights_batch")
+        check(self.lib.mi355_pack_weights_batch(self._pack_table.data_ptr(), len(tasks), chunks, self.stream()), "pack_weights_batch")
         return len(tasks)
 
     # -- conv ----------------------------------------------------------------------------------------------------

@@ -133,15 +133,18 @@ int mi355_pack_conv_weight(const float* w, float* wp, int32_t cout, int32_t cin,
  * unet3d/models/pytorch/classification/resnet.py:12-17; here the kernel-layout copies are refreshed once per optimizer step, and ~70
  * launches of 5-12 us are 0.6 ms of launch latency per step). `tasks` is a DEVICE array: a caller whose weight and pack buffers keep
  * their addresses (a training loop) builds it once. kind MI355_PACK_F32: out = mi355_pack_conv_weight(w, cout, cin, kd, mode);
- * MI355_PACK_WINO: out = mi355_wino_pack_weight(w, cout, cin, mode) (kd ignored). blocks_per_task: 256-thread workgroups per task
- * (grid-stride), 1..4096. */
+ * MI355_PACK_WINO: out = mi355_wino_pack_weight(w, cout, cin, mode) (kd ignored). The launch is cut into chunks of MI355_PACK_CHUNK work
+ * items -- F32: one output element (mi355_packed_weight_elems of them); WINO: one (dz, ci, co) triple, 16 outputs from 9 weights
+ * (mi355_wino_weight_elems / 16 of them). `first_chunk` of a task = the chunks (ceil(items / MI355_PACK_CHUNK)) of all tasks before
+ * it, `total_chunks` = the sum over all tasks. */
 #define MI355_PACK_F32 0
 #define MI355_PACK_WINO 1
+#define MI355_PACK_CHUNK 1024
 typedef struct {
   const float* w; float* out;
-  int32_t cout, cin, kd, mode, kind, reserved;
+  int32_t cout, cin, kd, mode, kind, first_chunk;
 } mi355_pack_task;
-int mi355_pack_weights_batch(const mi355_pack_task* tasks, int32_t ntasks, int32_t blocks_per_task, void* stream);
+int mi355_pack_weights_batch(const mi355_pack_task* tasks, int32_t ntasks, int32_t total_chunks, void* stream);
 
 /* Packed layouts of the bf16 paths: [tap][cinP/8][plane][coutP][8] bf16, cinP = roundup(cin,16), planes per `precision`.
  * Same `mode` / role conventions as mi355_pack_conv_weight (modes 0 and 1, kd == 3). mi355_conv3d_uses_bf16 tells the caller
