@@ -50,6 +50,9 @@ struct WinoArgs {
 // once (both uses of a two-use phase share them), a thread stages one float4 and transforms half a (tile, channel) window (two point
 // rows), the norm prologue comes from LDS. Weight fragments: two rotating register sets, each weight loaded once per chunk.
 // Output transform: in-wave over the wave's two j, across the waves through a 64 KB exchange (the main loop's LDS, reused).
+#ifndef WINO_ZBRICK
+#define WINO_ZBRICK 8             // z tiles per brick of the workgroup order (A/B: -DWINO_ZBRICK=1 = x fastest)
+#endif
 #ifndef WINO_ABL
 #define WINO_ABL 0            // developer ablations of conv3d_wino2d_w8 (tools/build_variant.sh ... -DWINO_ABL=mask): 1 no input loads, 2 no weight loads, 4 no transform, 8 no stores
 #endif
@@ -80,9 +83,27 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(Wi
       cot = b % nct; b /= nct;
     }
   }
+  // Spatial order inside an XCD's range: bricks of WINO_ZBRICK z tiles, then x, y, z bricks. The ~64 workgroups resident on an XCD then
+  // cover 8 z tiles x 8 x tiles of one tile row: z neighbours (which share two of their four input planes) and x neighbours (the halo)
+  // are resident together and ~3 MB of input sit in the 4 MB L2; with x fastest (the first order) a z neighbour ran 128 workgroups
+  // later and every plane was fetched twice. Stated per launch in profiles/r3_bench_fp32_hbm_traffic_pmc.csv.
+  int tz;
+  if (a.tilesZ % WINO_ZBRICK == 0) {
+    const int zi = b % WINO_ZBRICK; b /= WINO_ZBRICK;
+    const int txi = b % a.tilesX; b /= a.tilesX;
+    const int tyi = b % a.tilesY; b /= a.tilesY;
+    const int zbk = b % (a.tilesZ / WINO_ZBRICK); b /= (a.tilesZ / WINO_ZBRICK);
+    tz = zbk * WINO_ZBRICK + zi;
+    b = (b * a.tilesY + tyi) * a.tilesX + txi;              // (n, ty, tx) for the common decode below
+  } else {
+    const int txi = b % a.tilesX, r1 = b / a.tilesX;
+    const int tyi = r1 % a.tilesY, r2 = r1 / a.tilesY;
+    tz = r2 % a.tilesZ;
+    b = ((r2 / a.tilesZ) * a.tilesY + tyi) * a.tilesX + txi;
+  }
   const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
   const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
-  const int tz0 = (b % a.tilesZ) * TZ; b /= a.tilesZ;
+  const int tz0 = tz * TZ;
   const int n = b;
   const int co_base = cot * 32;
 

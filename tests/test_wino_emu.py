@@ -18,6 +18,7 @@ ops = C.ops
     dict(n=1, cin=12, cout=40, dhw=(5, 6, 7), norm=True, slope=0.01, bias=True),  # partial channel chunk and tile
     dict(n=2, cin=8, cout=32, dhw=(8, 8, 16), bias=True),                        # 8 workgroups: the XCD-contiguous workgroup order
     dict(n=1, cin=16, cout=64, dhw=(8, 8, 16), norm=True),                       # the same with two channel tiles (4 spatial groups)
+    dict(n=1, cin=8, cout=32, dhw=(16, 16, 32), bias=True),                      # 8 z tiles: the z-brick workgroup order (32 workgroups)
 ])
 def test_wino_forward_matches_conv3d(emu_backend, kw):
     be = emu_backend
