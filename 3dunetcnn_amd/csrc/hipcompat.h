@@ -21,6 +21,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) float name[]
 // register budget: the allocator must fit at least n waves per SIMD (512 unified registers / n, accumulators included)
 #define MIN_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n)))
+// exactly one wave per SIMD: the wave owns a lane's whole 512-entry register file (256 architectural VGPRs + 256 AGPRs)
+#define ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
+// keep a value in the accumulation half of the register file from here on (an MFMA reads its A / B operands from AGPRs directly; without
+// the pin hipcc parks such values there as spill space and copies them back with v_accvgpr_read before every use)
+#define PIN_IN_AGPR(v) asm volatile("" : "+a"(v))
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+0..7] and B[k=8*(l>>5)+0..7][j=l&31] as 8 packed bf16
 // (16 bytes, carried here as uint4); same C/D map as the f32 form. 32 cycles per SIMD = 16x the f32 MFMA rate.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -317,6 +317,65 @@ def test_norm_backward_sums_from_dgrad_epilogue_bf16_paths(prec_backend, kw):
     assert all(v < 2e-5 for v in r.values()), r
 
 
+# ---- opt-in plane-ring form of the 16-bit forward / dgrad kernel (conv3d_k3_lp_zring, MI355_BF16_FORM=zring): 17..32 input channels,
+#      32 output channels, H % 8 == 0, W % 16 == 0 ----
+@pytest.fixture(params=[("bf16", ""), ("fp16", ""), ("bf16", "2"), ("bf16", "5")], ids=["bf16", "fp16", "bf16-two-z-ranges", "bf16-five-z-ranges"])
+def zring_backend(emu_backend, request, monkeypatch):
+    monkeypatch.setenv("MI355_BF16_FORM", "zring")
+    monkeypatch.setenv("MI355_BF16_ZSPLITS", request.param[1])
+    emu_backend.set_precision(request.param[0])
+    yield emu_backend, BF16_TOL[request.param[0]]
+    emu_backend.set_precision("fp32")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=32, cout=32, dhw=(5, 8, 16), norm=True, residual=True, chscale=True),      # one column, every epilogue operand
+    dict(n=2, cin=24, cout=32, dhw=(6, 16, 32), bias=True),                                  # 8 columns, padded input channels
+    dict(n=1, cin=32, cout=32, dhw=(1, 8, 16)),                                              # a single plane
+    dict(n=1, cin=20, cout=32, dhw=(9, 8, 32), norm=True, slope=0.01, yld=64, yc0=32),        # concat slice, leaky slope, 9 planes (ring wraps twice)
+])
+def test_conv_fwd_zring_form(zring_backend, kw):
+    be, tol = zring_backend
+    assert C.case_conv_fwd(be, **kw) < tol
+
+
+def test_conv_dgrad_zring_form(zring_backend):
+    be, tol = zring_backend
+    assert C.case_conv_dgrad(be, n=1, cin=32, cout=32, dhw=(6, 8, 16)) < tol
+
+
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(5, 8, 16), residual=True, chscale=True), dict(n=2, cin=32, cout=32, dhw=(4, 16, 16))])
+def test_conv_epilogue_moments_zring_form(zring_backend, kw):
+    be, tol = zring_backend
+    assert C.case_conv_moments(be, ytol=tol, strict_vs_oracle=False, **kw) < 2e-5
+
+
+def test_norm_backward_sums_zring_form(zring_backend):
+    be, tol = zring_backend
+    r = C.case_gn_bwd_fused(be, compare_unfused=True, n=1, cin=32, cout=32, dhw=(5, 8, 16))
+    assert all(v < 2e-5 for v in r.values()), r
+
+
+def test_zring_form_is_what_ran(emu_backend, monkeypatch):
+    """The switch routes an eligible call to the plane-ring kernel (its statistics records are per (z range, column), not per tile):
+    guards the tests above against silently exercising the tile kernel."""
+    import ctypes
+    be = emu_backend
+    be.set_precision("bf16")
+    try:
+        x = be.empty_act(1, 8, 8, 16, 32); y = be.empty_act(1, 8, 8, 16, 32)
+        xd, yd = x.desc(), y.desc()
+        d = C.ops._lib.MiConvDesc(); d.kd, d.stride, d.pad, d.precision = 3, 1, 1, be.precision
+        d.out_d, d.out_h, d.out_w = 8, 8, 16
+        monkeypatch.setenv("MI355_BF16_FORM", "tile")
+        tile_blocks = be.lib.mi355_conv3d_stats_blocks(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d))
+        monkeypatch.setenv("MI355_BF16_FORM", "zring")
+        monkeypatch.setenv("MI355_BF16_ZSPLITS", "2")
+        assert be.lib.mi355_conv3d_stats_blocks(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d)) == 2 != tile_blocks
+    finally:
+        be.set_precision("fp32")
+
+
 # ---- plane-ring wgrad on tall planes (>= 32 rows: many columns per workgroup, z chunks) ----
 @pytest.mark.parametrize("kw", [
     dict(n=2, cin=32, cout=32, dhw=(3, 34, 9), norm=True),            # ragged columns in y (34 = 8 x 4 + 2) and x, two samples

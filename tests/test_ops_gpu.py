@@ -292,3 +292,48 @@ def test_conv_dgrad_bf16_paths(prec_backend, kw):
 def test_conv_wgrad_bf16_paths(prec_backend, kw):
     be, tol = prec_backend
     assert C.case_conv_wgrad(be, **kw) < tol
+
+
+# ---- opt-in plane-ring form of the 16-bit forward / dgrad kernel (conv3d_k3_lp_zring, MI355_BF16_FORM=zring): GPU twins of the emulator
+#      cases in tests/test_ops_emu.py ----
+@pytest.fixture(params=[("bf16", ""), ("fp16", ""), ("bf16", "2"), ("bf16", "5")], ids=["bf16", "fp16", "bf16-two-z-ranges", "bf16-five-z-ranges"])
+def zring_backend(hip_backend, request, monkeypatch):
+    monkeypatch.setenv("MI355_BF16_FORM", "zring")
+    monkeypatch.setenv("MI355_BF16_ZSPLITS", request.param[1])
+    hip_backend.set_precision(request.param[0])
+    yield hip_backend, BF16_TOL[request.param[0]]
+    hip_backend.set_precision("fp32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(n=1, cin=32, cout=32, dhw=(5, 8, 16), norm=True, residual=True, chscale=True),
+    dict(n=2, cin=24, cout=32, dhw=(6, 16, 32), bias=True),
+    dict(n=1, cin=32, cout=32, dhw=(1, 8, 16)),
+    dict(n=1, cin=20, cout=32, dhw=(9, 8, 32), norm=True, slope=0.01, yld=64, yc0=32),
+    dict(n=2, cin=32, cout=32, dhw=(32, 32, 32), norm=True, residual=True),                   # 16 columns x 32 planes
+])
+def test_conv_fwd_zring_form(zring_backend, kw):
+    be, tol = zring_backend
+    assert C.case_conv_fwd(be, **kw) < tol
+
+
+@pytest.mark.gpu
+def test_conv_dgrad_zring_form(zring_backend):
+    be, tol = zring_backend
+    assert C.case_conv_dgrad(be, n=1, cin=32, cout=32, dhw=(6, 8, 16)) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(5, 8, 16), residual=True, chscale=True), dict(n=2, cin=32, cout=32, dhw=(4, 16, 16))])
+def test_conv_epilogue_moments_zring_form(zring_backend, kw):
+    be, tol = zring_backend
+    assert C.case_conv_moments(be, ytol=tol, strict_vs_oracle=False, **kw) < 2e-5
+
+
+@pytest.mark.gpu
+def test_norm_backward_sums_zring_form(zring_backend):
+    be, tol = zring_backend
+    r = C.case_gn_bwd_fused(be, compare_unfused=True, n=1, cin=32, cout=32, dhw=(5, 8, 16))
+    assert all(v < 2e-5 for v in r.values()), r
+

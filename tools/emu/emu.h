@@ -304,4 +304,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetc
 #define SET_MAX_DYN_LDS(kernel, bytes) do {} while (0)
 #define SCHED_BARRIER() do {} while (0)
 #define MIN_WAVES_PER_SIMD(n)
+#define ONE_WAVE_PER_SIMD
+#define PIN_IN_AGPR(v) ((void)0)
+typedef uint4 u32x4_t;
 #define SLEEP_64CLK(n) do {} while (0)
