@@ -356,6 +356,26 @@ def test_norm_backward_sums_zring_form(zring_backend):
     assert all(v < 2e-5 for v in r.values()), r
 
 
+def test_zring_form_default_routing(emu_backend, monkeypatch):
+    """Without the switch (default `auto`) an eligible 16-bit layer with >= 64 columns takes the plane-ring kernel -- here 64 columns of
+    3 planes in 3 z ranges of one plane each (a range shorter than the ring) -- and a layer with fewer columns keeps the tile kernel."""
+    import ctypes
+    monkeypatch.delenv("MI355_BF16_FORM", raising=False)
+    monkeypatch.delenv("MI355_BF16_ZSPLITS", raising=False)
+    be = emu_backend
+    be.set_precision("bf16")
+    try:
+        assert C.case_conv_fwd(be, n=2, cin=32, cout=32, dhw=(3, 32, 128), norm=True, residual=True) < BF16_TOL["bf16"]
+        d = C.ops._lib.MiConvDesc(); d.kd, d.stride, d.pad, d.precision = 3, 1, 1, be.precision
+        for (n, dd, h, w), want in (((2, 3, 32, 128), 3 * 4 * 8), ((1, 4, 8, 16), 2 * 2 * 1)):      # zring records | 2x4x16 tiles of the tile kernel
+            x = be.empty_act(n, dd, h, w, 32); y = be.empty_act(n, dd, h, w, 32)
+            xd, yd = x.desc(), y.desc()
+            d.out_d, d.out_h, d.out_w = dd, h, w
+            assert be.lib.mi355_conv3d_stats_blocks(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d)) == want
+    finally:
+        be.set_precision("fp32")
+
+
 def test_zring_form_is_what_ran(emu_backend, monkeypatch):
     """The switch routes an eligible call to the plane-ring kernel (its statistics records are per (z range, column), not per tile):
     guards the tests above against silently exercising the tile kernel."""
