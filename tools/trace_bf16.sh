@@ -1,6 +1,6 @@
 export TMPDIR=/tmp
 root=$(pwd)
-out=gpurun_out/r2k; mkdir -p $out
+out=gpurun_out/${1:-bf16}; mkdir -p $out
 (cd /tmp && MI355_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $root/$out/trace_bf16 -o bench -- python $root/bench.py --precision bf16 --steps 3 --warmup 1 --no-cpu-baseline --no-precision-modes --no-kernel-events > $root/$out/log.txt 2>&1)
 rm -f $out/trace_bf16/bench_kernel_trace.csv
 (cd /tmp && MI355_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $root/$out/pmc_fetch -o bench -- python $root/bench.py --precision bf16 --steps 1 --warmup 1 --no-cpu-baseline --no-precision-modes --no-kernel-events > $root/$out/pmc_fetch.log 2>&1)
