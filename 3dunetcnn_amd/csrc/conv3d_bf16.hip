@@ -654,6 +654,8 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring(Conv
   __syncthreads();
 
   f32x16 accE, accO;                                         // output planes at even / odd distance from zb
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { accE[r] = 0.f; accO[r] = 0.f; }
   // One output plane. R = (z - zb) & 3: its input planes z - 1, z, z + 1 sit in slots R, R + 1, R + 2 (mod 4), plane z + 2 (in the
   // register set `cur`) is written to slot R + 3, plane z + 3 is requested into `nxt`; `acc` takes plane z while the epilogue of plane
   // z - 1 (in `prev`) rides along.
