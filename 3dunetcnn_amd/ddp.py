@@ -34,6 +34,8 @@ class GradientBucketReducer:
         self.reduce_single_rank = reduce_single_rank     # issue the collectives even with one rank (exercises the RCCL path)
         self._works = []
         self._built_for = None
+        self._unsynced_pending = False      # a no_sync() micro-batch has accumulated and not been reduced yet
+        self._warned_accumulate = False
         model.grad_ready_callback = self._on_ready
         model.backward_start_callback = self._on_backward_start
         model.grad_sync_callback = self.wait        # the engine joins the exchange at the end of every backward
@@ -100,13 +102,15 @@ class GradientBucketReducer:
         if not self._sync:
             self._unsynced_pending = True
             return
-        if not getattr(self, "_unsynced_pending", False) and not getattr(self, "_warned_accumulate", False):
-            # not the closing micro-batch of a no_sync() accumulation: a plain step whose .grad tensors were kept (zero_grad(set_to_none=
-            # False)) lands here every time and silently loses the bucketed overlap
+        if not self._unsynced_pending and not self._warned_accumulate:
+            # not the closing micro-batch of a no_sync() accumulation: either a plain step whose .grad tensors were kept
+            # (zero_grad(set_to_none=False)) or gradient accumulation WITHOUT no_sync() (every micro-batch synced: numerically right, but
+            # each backward re-reduces the whole running sum). Both lose the bucketed overlap every time
             self._warned_accumulate = True
-            warnings.warn("GradientBucketReducer: backward found existing .grad tensors outside a no_sync() accumulation: the gradients "
-                          "are all-reduced in ONE blocking piece after backward (no per-bucket overlap). Use "
-                          "optimizer.zero_grad(set_to_none=True) for plain steps", stacklevel=3)
+            warnings.warn("GradientBucketReducer: backward found existing .grad tensors outside a no_sync() accumulation: the accumulated "
+                          "gradients are all-reduced in ONE blocking piece after this backward (no per-bucket overlap). For plain steps use "
+                          "optimizer.zero_grad(set_to_none=True); for gradient accumulation wrap all but the last micro-batch in "
+                          "reducer.no_sync() so that only the closing backward exchanges", stacklevel=3)
         self._unsynced_pending = False
         self.allreduce_flat(flat_grad)
 

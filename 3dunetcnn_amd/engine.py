@@ -47,6 +47,7 @@ class HipNetBase(nn.Module):
         self._packed = {}          # id(param) -> [version, {mode: packed tensor}, data_ptr]
         self._packs_dirty = True
         self._packs_dirty_local = False
+        self._pack_tables = {}     # task tuple -> device task table of Backend.repack_batch: per NETWORK, never evicted by another model
         self.grad_ready_callback = None        # set by ddp.GradientBucketReducer
         self.backward_start_callback = None
         self.grad_sync_callback = None         # set by ddp.GradientBucketReducer: joins the bucket all-reduces at the end of backward
@@ -124,7 +125,7 @@ class HipNetBase(nn.Module):
             ent[0] = p._version
             batch.extend(ent[1].values())
         if batch:
-            be.repack_batch(batch)
+            be.repack_batch(batch, self._pack_tables)
 
     # ---- forward / backward bridge -------------------------------------------------------------------------------
     def _check_input(self, x):

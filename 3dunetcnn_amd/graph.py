@@ -72,6 +72,11 @@ class HipGraphedTrainStep:
         # empty_cache() every iteration, unet3d/train/training_utils.py:66) could hand a block the graph still writes to another tensor.
         be = model._be
         self._ws_refs = None if be is None else [t for t in be._ws_by_stream.values() if t is not None]
+        # the same holds for the device task table of the one-launch weight repack (Backend.repack_batch): its address is in the graph.
+        # Keep it alive and mark it so the owner's cache never drops it while this graph exists.
+        self._pack_table = getattr(be, "last_pack_table", None)
+        if self._pack_table is not None:
+            self._pack_table._mi355_pinned = True
         self.logits = logits.detach()                # static outputs, refreshed by every replay
         self.loss = loss.detach()
         self._grads = [(p, p.grad) for p in model.parameters() if p.grad is not None]

@@ -96,14 +96,30 @@ class HipDiceLoss(nn.Module):
         self.smooth_dr = float(smooth_dr)
         self.include_background = bool(include_background)
         weight = torch.as_tensor(weight, dtype=torch.float32) if weight is not None else None
-        # MONAI raises on a negative weight at every forward; the value cannot change between calls, so it is read ONCE, here, while the
-        # tensor is still on the host (a device read per forward would be a host sync inside the step and breaks stream capture);
-        # a weight assigned later through `class_weight` is the caller's responsibility
-        self._weight_negative = bool(weight is not None and weight.numel() and float(weight.min()) < 0)      # raised where MONAI raises: in forward
+        # MONAI raises on a negative weight at every forward. The sign is read once per VALUE of the buffer -- here, while the tensor is
+        # still on the host, and again (lazily, in forward) whenever the buffer has been replaced or written since: load_state_dict,
+        # `crit.class_weight = ...`, an in-place edit. A device read on every forward would be a host sync inside the step.
         self.register_buffer("class_weight", weight)
+        self._weight_checked = None
+        self._weight_negative = False
+        self._check_weight_sign()
         self._be = None
 
     generalized = False
+
+    def _check_weight_sign(self):
+        """(Re)read the sign of `class_weight` when the buffer is not the one last looked at (identity, storage, version counter)."""
+        w = self.class_weight
+        if w is None:
+            self._weight_checked, self._weight_negative = None, False
+            return
+        key = (id(w), w.data_ptr(), w._version, w.device)
+        if key == self._weight_checked:
+            return
+        if w.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return                                   # no host read inside a capture: the check happens at the next eager forward
+        self._weight_negative = bool(w.numel() and float(w.min()) < 0)
+        self._weight_checked = key
 
     def forward(self, input, target):
         if input.device.type != "cuda" and self._be is None:
@@ -121,6 +137,7 @@ class HipDiceLoss(nn.Module):
             elif cw.shape[0] != ce:
                 raise ValueError("the length of the `weight` sequence should be the same as the number of classes. "
                                  "If `include_background=False`, the weight should not include the background category class 0.")
+            self._check_weight_sign()
             if self._weight_negative:
                 raise ValueError("the value/values of the `weight` should be no less than 0.")
         else:

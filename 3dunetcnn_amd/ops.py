@@ -155,10 +155,16 @@ class Backend:
         if os.environ.get("MI355_WINO_MIN_VOXELS"):          # A/B of the routing threshold (forward / dgrad and weight gradient alike)
             self.WINO_MIN_VOXELS = int(os.environ["MI355_WINO_MIN_VOXELS"])
 
-        self.prof = None   # set to a list to collect (kernel name, flops, bytes, start event, end event) per conv launch
+        # set to a list to collect one record per conv launch: (kernel family, flops, unfused-compulsory bytes [SURVEY 8d: inputs + outputs +
+        # weights once], start event, end event, instantiation [the name a rocprofv3 trace shows, or None], bytes of the reads the
+        # launch FUSES on top of the compulsory ones [residual, normalised tensor of the norm-backward sums]) -- see _prof_add
+        self.prof = None
         # norm statistics leave with the producing conv's epilogue (csrc/gn_fuse.h). False: every statistic is a standalone pass
         # over the tensor again (the round-1 form; kept as the cross-check of the fused path, tests/test_ops_gpu.py)
         self.fused_stats = os.environ.get("MI355_FUSED_STATS", "1") != "0"
+
+    def _prof_add(self, name, flops, byts, e0, e1, variant=None, fused_bytes=0.0):
+        self.prof.append((name, flops, byts, e0, e1, variant, fused_bytes))
 
     def set_precision(self, name):
         """"fp32" (exact f32 MFMA, default) | "bf16x3" | "bf16x6" (split-bf16 fp32 emulation) | "bf16" | "fp16" (mixed precision: operands
@@ -194,10 +200,14 @@ class Backend:
         """w: Conv3d weight [O, I, k, k, k] (modes 0, 1) or ConvTranspose3d weight [I, O, k, k, k] (modes 2, 3)."""
         return PackedWeight(self, w, mode)
 
-    def repack_batch(self, packed):
+    def repack_batch(self, packed, cache=None):
         """Refresh the fp32 and Winograd packs that the PackedWeights in `packed` hold from their (updated) weight tensors in ONE launch
-        (mi355_pack_weights_batch); their 16-bit packs are dropped and rebuilt on first use. The device task table is cached: in a
-        training loop neither the weights (views of the flat parameter buffer) nor the pack buffers move."""
+        (mi355_pack_weights_batch); their 16-bit packs are dropped and rebuilt on first use. The device task table is cached in `cache`
+        (a dict owned by the CALLER -- one per network, engine.HipNetBase._pack_tables -- mapping the task tuple to its device table):
+        in a training loop neither the weights (views of the flat parameter buffer) nor the pack buffers move, so a network finds its
+        table again every step, and two networks sharing this backend (validation twin, EMA copy) never evict each other's. A table is
+        never replaced or freed while its owner lives: a captured HIP graph has the table's ADDRESS baked in (graph.py also holds a
+        reference of its own)."""
         import numpy as np
         CHUNK = 1024                                       # MI355_PACK_CHUNK work items (fp32: elements; Winograd: (dz, ci, co) triples)
         tasks, chunks = [], 0
@@ -212,8 +222,11 @@ class Backend:
                 chunks += (3 * cinP * coutP + CHUNK - 1) // CHUNK
         if not tasks:
             return 0
+        if cache is None:
+            cache = self.__dict__.setdefault("_pack_tables", {})     # callers without a cache of their own (tools, tests)
         key = tuple(tasks)
-        if getattr(self, "_pack_table_key", None) != key and self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        table = cache.get(key)
+        if table is None and self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
             # a new table needs a host-to-device copy, which a stream capture cannot contain: the single-weight launches do the same work
             for w, out, cout, cin, kd, mode, kind, _ in tasks:
                 if kind == 0:
@@ -221,13 +234,18 @@ class Backend:
                 else:
                     check(self.lib.mi355_wino_pack_weight(w, out, cout, cin, mode, self.stream()), "wino_pack_weight")
             return len(tasks)
-        if getattr(self, "_pack_table_key", None) != key:
+        if table is None:
             rec = np.array(tasks, dtype=[("w", "<u8"), ("out", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("kd", "<i4"), ("mode", "<i4"),
                                          ("kind", "<i4"), ("first_chunk", "<i4")])
             assert rec.itemsize == 40                      # sizeof(mi355_pack_task)
-            self._pack_table = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
-            self._pack_table_key = key
-        check(self.lib.mi355_pack_weights_batch(self._pack_table.data_ptr(), len(tasks), chunks, self.stream()), "pack_weights_batch")
+            if len(cache) >= 8:                            # routing changed 8 times (precision / shape switches): drop the oldest unpinned
+                for k in list(cache):
+                    if not getattr(cache[k], "_mi355_pinned", False):
+                        del cache[k]
+                        break
+            table = cache[key] = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
+        self.last_pack_table = table                       # graph.py pins the table its capture used
+        check(self.lib.mi355_pack_weights_batch(table.data_ptr(), len(tasks), chunks, self.stream()), "pack_weights_batch")
         return len(tasks)
 
     # -- conv ----------------------------------------------------------------------------------------------------
@@ -287,10 +305,15 @@ class Backend:
         # profiling: HIP events on the launch stream around this one kernel, keyed by the kernel's trace name
         name = ctypes.create_string_buffer(96)
         self.lib.mi355_conv3d_fwd_config(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d), name, 96)
+        variant = None
         if d.wformat == W_OIDHW4:
             name.value = b"conv3d_c4_fwd"
         elif d.wformat == W_PACKED and self.lib.mi355_conv3d_uses_bf16(ctypes.byref(d)):
+            # the 16-bit single-product modes have two kernels: the plane-ring (z-marching, weights-stationary) form for the shapes it
+            # takes and the tile form for the rest; a layer's record count tells them apart (ring: zsplits * columns)
             name.value = b"conv3d_k3_bf16<...>"
+            fuse = 1 if d.moments_out else (2 if d.gn_bwd else 0)
+            variant = f"lp16 in{in_mode} fuse{fuse} {x.c}->{y.c}"
         nvox = x.shape[0] * out_dhw[0] * out_dhw[1] * out_dhw[2]
         flops = 2.0 * nvox * x.c * y.c * kd ** 3 * (8 if (in_mode == IN_S2D or out_mode == OUT_D2S) else 1)
         if in_mode == IN_ZERO_INSERT:
@@ -300,7 +323,8 @@ class Backend:
         e0.record()
         check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wptr, ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
         e1.record()
-        self.prof.append((name.value.decode(), flops, byts, e0, e1))
+        fused = 4.0 * nvox * y.c * ((residual is not None) + (gparts is not None))
+        self._prof_add(name.value.decode(), flops, byts, e0, e1, variant, fused)
         return self._fold_after(y, gparts)
 
     # -- Winograd form of the 3x3x3 stride-1 conv (csrc/conv3d_wino.hip) -------------------------------------------------------------
@@ -308,7 +332,10 @@ class Backend:
         """w OIDHW [cout, cin, 3, 3, 3] -> transformed weights for conv_fwd_wino (mode 0: forward; mode 1: dgrad, i.e. a conv from
         cout to cin channels)."""
         cout, cin = (w.shape[0], w.shape[1]) if mode == 0 else (w.shape[1], w.shape[0])
-        if w.device != self.device or w.dtype != torch.float32:
+        same = w.device.type == self.device.type and (w.device.type != "cuda" or
+                                                     (w.device.index if w.device.index is not None else torch.cuda.current_device()) ==
+                                                     (self.device.index if self.device.index is not None else torch.cuda.current_device()))
+        if not same or w.dtype != torch.float32:
             raise ValueError(f"wino_pack_weight: weight on {w.device} ({w.dtype}), backend on {self.device}: fp32 on the backend device expected")
         up = torch.empty(self.lib.mi355_wino_weight_elems(cout, cin), dtype=torch.float32, device=self.device)
         check(self.lib.mi355_wino_pack_weight(w.contiguous().data_ptr(), up.data_ptr(), cout, cin, mode, self.stream()), "wino_pack_weight")
@@ -342,7 +369,10 @@ class Backend:
         if self.prof is not None:
             e1.record()
             nvox = y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3]
-            self.prof.append(("conv3d_wino2d", 2.0 * nvox * x.c * y.c * 27, 4.0 * (nvox * (x.c + y.c) + 27 * x.c * y.c), e0, e1))
+            fuse = 1 if d.moments_out else (2 if gparts is not None else 0)
+            self._prof_add("conv3d_wino2d", 2.0 * nvox * x.c * y.c * 27, 4.0 * (nvox * (x.c + y.c) + 27 * x.c * y.c), e0, e1,
+                           f"conv3d_wino2d_w8<{1 if in_mode == IN_AFFINE_ACT else 0}, {fuse}>",
+                           4.0 * nvox * y.c * ((residual is not None) + (gparts is not None)))
         return self._fold_after(y, gparts)
 
     def _fold_after(self, y, gparts):
@@ -376,8 +406,8 @@ class Backend:
                 if self.prof is not None:
                     e1.record()
                     nvox = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3]
-                    self.prof.append(("conv3d_wgrad_wino_ring (+reduce)", 2.0 * nvox * x.c * dy.c * 27,
-                                      4.0 * (nvox * (x.c + dy.c) + 27 * x.c * dy.c), e0, e1))
+                    self._prof_add("conv3d_wgrad_wino_ring (+reduce)", 2.0 * nvox * x.c * dy.c * 27,
+                                   4.0 * (nvox * (x.c + dy.c) + 27 * x.c * dy.c), e0, e1)
                 return
         nbytes = self.lib.mi355_conv3d_wgrad_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))
         if nbytes == 0:
@@ -396,9 +426,9 @@ class Backend:
             byts = 4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * x.c + nvox * dy.c + kd ** 3 * x.c * dy.c)
             bf = self.precision != PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT) and out_mode == OUT_PLAIN
             c4 = x.c == 4 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT) and out_mode == OUT_PLAIN
-            self.prof.append(("conv3d_c4_wgrad (+reduce)" if c4 else "conv3d_wgrad_k3_bf16<...> (+reduce)" if bf
-                              else "conv3d_wgrad_ring (+reduce)" if (kd == 3 and stride == 1 and pad == 1 and out_mode == OUT_PLAIN)
-                              else f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1))
+            self._prof_add("conv3d_c4_wgrad (+reduce)" if c4 else "conv3d_wgrad_k3_bf16<...> (+reduce)" if bf
+                           else "conv3d_wgrad_ring (+reduce)" if (kd == 3 and stride == 1 and pad == 1 and out_mode == OUT_PLAIN)
+                           else f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1)
 
     # -- norm ----------------------------------------------------------------------------------------------------
     RECORDS_MAX = 256        # more epilogue records than this per (sample, channel) are folded to RECORDS_FOLD before finalisation

@@ -14,9 +14,8 @@ Extra objects on the JSON line (tier contract):
   roofline     -- dominant kernel (by summed HIP-event time inside the timed region): algorithmic FLOPs / time vs the
                   fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md), since the 3x3x3 convs are compute-bound in fp32
                   (SURVEY.md 7.3 #1); `hbm_gbps` gives the same launches' algorithmic bytes / time for reference.
-  cpu_baseline -- the oracle (CPU restatement of the reference graph, oracle/unet3d_ref.py) timed on this host for one
-                  training step at N=1: the full 128^3 patch when a half-edge step predicts <= 30 s, else the half-edge step
-                  scaled by the voxel ratio (rank 0, N=1 runs only).
+  cpu_baseline -- the oracle (CPU restatement of the reference graph, oracle/unet3d_ref.py) timed on this host for the
+                  training step at N=1 on the full 128^3 patch: 1 warm-up + 3 timed steps (rank 0, N=1 runs only; ~40 s).
 """
 import argparse
 import importlib
@@ -40,7 +39,9 @@ HBM_PEAK_GBPS = 8000.0
 
 
 DTYPE = {"fp32": "f32", "bf16x3": "f32 (3xbf16 split-MFMA emulation)", "bf16x6": "f32 (6xbf16 split-MFMA emulation)", "bf16": "bf16 (mixed)", "fp16": "f16 (mixed)"}
-ARITH = {"fp32": "3x3x3 convs on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate)",
+ARITH = {"fp32": "3x3x3 stride-1 convs with >= 8 channels and >= 16^3 voxels: Winograd F(2x2,3x3) x direct-z on v_mfma_f32_32x32x2_f32 (fp32 products of "
+                 "TRANSFORMED operands, fp32 accumulate; per-launch error vs fp64 <= 1.2e-6, the class of a direct fp32 conv); every other conv: "
+                 "direct, exact fp32 products on the same instruction",
          "bf16x3": "3x3x3 stride-1 convs: fp32 operands split hi+lo bf16, 3 v_mfma_f32_32x32x16_bf16 products per MAC, fp32 accumulate "
                    "(product error <= 2^-16); everything else fp32",
          "bf16x6": "3x3x3 stride-1 convs: fp32 operands split into 3 bf16 planes, 6 bf16 MFMA products per MAC, fp32 accumulate "
@@ -117,22 +118,29 @@ def self_launch(n):
     return rc
 
 
-PMC_FILE = os.path.join("profiles", "r3_bench_fp32_hbm_traffic_pmc.csv")
+# HBM-traffic summaries (tools/pmc_summary.py) of the rocprofv3 PMC passes of THIS command, per (config, precision)
+PMC_FILES = {("c2", "fp32"): os.path.join("profiles", "r4_bench_fp32_hbm_traffic_pmc.csv"),
+             ("c2", "bf16"): os.path.join("profiles", "r4_bf16_hbm_traffic_pmc.csv"),
+             ("c3", "bf16"): os.path.join("profiles", "r4_c3_hbm_traffic_pmc.csv")}
+# kernel family (ops.Backend prof name) -> substrings of the trace names of its instantiations
+PMC_FAMILY = {"conv3d_wino2d": ("conv3d_wino2d",), "conv3d_k3_bf16<...>": ("conv3d_k3_bf16", "conv3d_k3_lp_zring"),
+              "conv3d_wgrad_wino_ring (+reduce)": ("conv3d_wgrad_wino_ring",), "conv3d_wgrad_k3_bf16<...> (+reduce)": ("conv3d_wgrad_k3_bf16", "conv3d_wgrad_lp_ring"),
+              "conv3d_wgrad_ring (+reduce)": ("conv3d_wgrad_ring",)}
 
 
-def pmc_traffic(kernel_name, precision):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md 'HBM'). PMC collection needs rocprofv3 around the process, so bench.py reads the summary -- but only one
-    collected from THESE kernels: the file's first line records the sha256 of the kernel sources it was measured on
-    (tools/pmc_summary.py), and a file from other sources is refused (traffic -> null, the reason in traffic_source)."""
-    path = os.path.join(ROOT, PMC_FILE)
-    if precision != "fp32" or not os.path.exists(path):
-        return None, None
+def pmc_rows(config, precision):
+    """Rows of the committed PMC summary of this command: [(kernel trace name, calls, HBM bytes per launch)], or (None, reason).
+    FETCH_SIZE and WRITE_SIZE come from separate rocprofv3 passes; FETCH_SIZE is doubled per the gfx950 note in MI355X_MICROARCH.md
+    'HBM'. PMC collection needs rocprofv3 around the process, so bench.py reads the summary -- but only one collected from THESE
+    kernels: the file's first line records the sha256 of the kernel sources it was measured on (tools/pmc_summary.py), and a file
+    from other sources is refused (traffic -> null, the reason in traffic_source)."""
+    rel = PMC_FILES.get((config, precision))
+    if rel is None or not os.path.exists(os.path.join(ROOT, rel)):
+        return None, None if rel is None else f"{rel} not collected"
     import csv
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from pmc_summary import kernel_source_hash
-    lines = open(path).read().splitlines()
+    lines = open(os.path.join(ROOT, rel)).read().splitlines()
     recorded = None
     if lines and lines[0].startswith("#"):
         for tok in lines[0].split():
@@ -140,25 +148,29 @@ def pmc_traffic(kernel_name, precision):
                 recorded = tok.split("=", 1)[1]
         lines = lines[1:]
     if recorded != kernel_source_hash():
-        return None, f"{PMC_FILE} is stale (collected from kernel sources {str(recorded)[:12]}, tree has {kernel_source_hash()[:12]}): re-run tools/gpu_profile.sh <tag> pmc"
-    key = kernel_name.split(" (")[0].split("<")[0]
-    best = None
-    for r in csv.DictReader(lines):
-        if key in r["Kernel"] and (best is None or int(r["Calls"]) > int(best["Calls"])):
-            best = r
-    if best is None:
-        return None, None
-    mib = float(best["fetch_x2_MiB_per_launch"]) + float(best["WRITE_SIZE_MiB_per_launch"])
-    return round(mib * 1048576), f"{PMC_FILE} (FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
+        return None, f"{rel} is stale (collected from kernel sources {str(recorded)[:12]}, tree has {kernel_source_hash()[:12]}): re-run tools/gpu_profile.sh <tag> pmc"
+    rows = [(r["Kernel"], int(r["Calls"]), (float(r["fetch_x2_MiB_per_launch"]) + float(r["WRITE_SIZE_MiB_per_launch"])) * 1048576.0)
+            for r in csv.DictReader(lines)]
+    return rows, f"{rel} (FETCH_SIZE x2 + WRITE_SIZE per launch; family figure = call-weighted over the file's rows of the family)"
+
+
+def family_traffic(rows, family):
+    """Call-weighted HBM bytes per launch over every instantiation of `family` in the PMC summary (the summary is of the same command:
+    its call mix is this step's)."""
+    keys = PMC_FAMILY.get(family, (family.split(" (")[0].split("<")[0],))
+    hit = [(k, c, b) for k, c, b in rows if any(key in k for key in keys)]
+    calls = sum(c for _, c, _ in hit)
+    return (sum(c * b for _, c, b in hit) / calls, hit) if calls else (None, [])
 
 
 def cpu_baseline(size, model="unet3d"):
-    """The oracle graph's training step on the host CPU, SURVEY 8(d) protocol: N = 1, the full patch, 1 warm-up + 3 timed iterations of
-    zero_grad -> forward -> Dice -> backward -> Adam.step with time.perf_counter, forward / backward / optimizer split reported.
-    kind "port": oracle/unet3d_ref.py is a restatement of the reference graph that is bit-identical to the imported reference UNet3D
-    (tests/test_oracle_pinned.py; /root/reference does not exist on the GPU box); for --model dynunet the torch restatement of MONAI's
-    DynUNet in the BraTS configuration (oracle/dynunet_ref.py, unpinned). Bounded: when a half-edge step predicts more than 15 s per
-    full-size step, the half-edge patch is timed instead and scaled by the voxel ratio (every op on the path is linear in voxels)."""
+    """The oracle graph's training step on the host CPU, SURVEY 8(d) protocol: N = 1, the FULL patch (C2's shape at N = 1), 1 warm-up +
+    3 timed iterations of zero_grad -> forward -> Dice -> backward -> Adam.step with time.perf_counter, forward / backward / optimizer
+    split reported. kind "port": oracle/unet3d_ref.py is a restatement of the reference graph that is bit-identical to the imported
+    reference UNet3D (tests/test_oracle_pinned.py; /root/reference does not exist on the GPU box); for --model dynunet the torch
+    restatement of MONAI's DynUNet in the BraTS configuration (oracle/dynunet_ref.py, unpinned). ~40 s of host time at 128^3.
+    Only if the host cannot hold the full patch (MemoryError / allocator failure) is the half-edge patch timed instead; the line then
+    carries "extrapolated": true, its forward / backward times are scaled by the voxel ratio and Adam (parameter-sized) is not."""
     from oracle import torch_ops as O
     cores = min(os.cpu_count() or 1, 64)     # oneDNN's conv3d does not scale past a few dozen threads on these shapes
     torch.set_num_threads(cores)
@@ -195,28 +207,26 @@ def cpu_baseline(size, model="unet3d"):
 
     smallest = 64 if model == "dynunet" else 32                  # five stride-2 levels need >= 64^3 (InstanceNorm over > 1 voxel)
     step((smallest,) * 3)                                        # thread pools, oneDNN primitives
-    s = max(smallest, size // 2)
-    probe = sum(step((s, s, s)))
-    scale = (size / s) ** 3
-    full = scale > 1 and probe * scale <= 15.0
-    edge, mult = (size, 1.0) if full else (s, scale)
+    edge, mult = size, 1.0
     try:
         step((edge,) * 3)                                        # the warm-up iteration of the protocol
         runs = [step((edge,) * 3) for _ in range(3)]
-    except (MemoryError, RuntimeError):
-        if not full:
-            raise
-        edge, mult = s, scale                                    # host RAM too small for the full patch
+    except (MemoryError, RuntimeError):                          # host RAM too small for the full patch: the only case that is scaled
+        edge = max(smallest, size // 2)
+        mult = (size / edge) ** 3
         step((edge,) * 3)
         runs = [step((edge,) * 3) for _ in range(3)]
-    f, b, o = (sum(r[i] for r in runs) / 3 * mult for i in range(3))
+    f, b = (sum(r[i] for r in runs) / 3 * mult for i in range(2))
+    o = sum(r[2] for r in runs) / 3                              # Adam walks the parameters, not the voxels: never scaled
     tot = f + b + o
-    note = "" if mult == 1.0 else f" ({edge}^3 patch timed = 1/{mult:.0f} of the volume, scaled by the voxel ratio)"
-    return {"value": round(1.0 / tot, 5), "unit": "volumes/s", "cores": cores, "kind": kind,
-            "sample": f"1 warm-up + 3 timed training steps (zero_grad -> forward -> sigmoid-Dice -> backward -> Adam.step) of {graph}, N=1, "
-                      f"{size}^3 patch, fp32, {cores} threads{note}: {tot:.2f} s/step",
-            "seconds_per_step": round(tot, 3), "forward_s": round(f, 3), "backward_s": round(b, 3), "optimizer_s": round(o, 3),
-            "per_iteration_s": [round(sum(r) * mult, 3) for r in runs]}
+    out = {"value": round(1.0 / tot, 5), "unit": "volumes/s", "cores": cores, "kind": kind,
+           "sample": f"1 warm-up + 3 timed training steps (zero_grad -> forward -> sigmoid-Dice -> backward -> Adam.step) of {graph}, N=1, "
+                     f"{edge}^3 patch, fp32, {cores} threads: {tot:.2f} s/step",
+           "seconds_per_step": round(tot, 3), "forward_s": round(f, 3), "backward_s": round(b, 3), "optimizer_s": round(o, 3),
+           "per_iteration_s": [round((r[0] + r[1]) * mult + r[2], 3) for r in runs], "extrapolated": mult != 1.0}
+    if mult != 1.0:
+        out["sample"] += f" -- EXTRAPOLATED: the host could not hold the {size}^3 step; forward / backward of the {edge}^3 patch x {mult:.0f}"
+    return out
 
 
 def bench_c5(args, unet, inferer_mod, dev):
@@ -412,41 +422,94 @@ def main():
         per_rank = [float(t[0].item()) for t in every]
         per_rank_host = [float(t[1].item()) for t in every]
     dt = max(per_rank)                                            # the job is as slow as its slowest rank
+    # proof of the N ranks for the driver's SCALE line: the world size the RCCL communicator reports and every rank's own device
+    mine_dev = (f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)} pci bus {getattr(torch.cuda.get_device_properties(local_rank), 'pci_bus_id', -1)}"
+                if dev.type == "cuda" else f"rank {rank}: cpu (emulator)")
+    rank_devices, comm_world, comm_backend = [mine_dev], 1, None
+    if world > 1:
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine_dev)
+        comm_world, comm_backend = dist.get_world_size(), dist.get_backend()
 
     roofline = None
     if prof:
-        agg = {}
-        for name, fl, by, e0, e1 in prof:
-            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
-            a[0] += e0.elapsed_time(e1) * 1e-3
+        roof_steps = ROOF_STEPS if prof is not prof_timed else args.steps
+        agg, inst = {}, {}
+        for name, fl, by, e0, e1, variant, fused in prof:
+            secs = e0.elapsed_time(e1) * 1e-3
+            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0, 0.0])
+            a[0] += secs
             a[1] += fl
             a[2] += by
             a[3] += 1
-        name, (secs, fl, by, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
+            a[4] += fused
+            v = inst.setdefault((name, variant or name), [0.0, 0.0, 0.0, 0, 0.0])
+            v[0] += secs
+            v[1] += fl
+            v[2] += by
+            v[3] += 1
+            v[4] += fused
+        name, (secs, fl, by, cnt, fused) = max(agg.items(), key=lambda kv: kv[1][0])
         ach = fl / secs / 1e12
         on_bf16 = "bf16" in name
         peak = BF16_MFMA_PEAK_TFLOPS if on_bf16 else FP32_MFMA_PEAK_TFLOPS
         products = {"bf16x3": 3, "bf16x6": 6, "bf16": 1, "fp16": 1}.get(args.precision, 1) if on_bf16 else 1
-        traffic, traffic_src = pmc_traffic(name, args.precision)
         executed = getattr(be, "WINO_EXECUTED", {}).get(name, 1.0)
-        # `achieved` is ALGORITHMIC (2 * N * V * Cin * Cout * 27 per launch / duration). A Winograd kernel executes only
-        # `executed` of those multiplications, so its roofline in algorithmic units is the matrix peak / executed (12/27 forward / dgrad,
-        # 16/36 weight gradient): `peak` is that figure, `frac` = achieved / peak = executed rate / MFMA peak, always <= 1.
-        roofline = {"bound": "mfma", "kernel": name, "measured": roof_note, "achieved": round(ach, 2), "peak": round(peak / executed, 1), "unit": "TFLOP/s",
-                    "frac": round(ach * executed / peak, 4), "mfma_peak_tflops": peak,
-                    "peak_note": ("algorithmic-equivalent peak = fp32 MFMA peak %.1f / %.4f executed-over-algorithmic multiplications" % (peak, executed))
-                                 if executed != 1.0 else "dense MFMA peak of the arithmetic type (MI355X_MICROARCH.md)",
-                    "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
-                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(by / cnt),
-                    "mfma_products_per_mac": products, "mfma_pipe_frac": round(ach * products / peak * executed, 4),
-                    # Winograd kernels execute fewer multiplications than the algorithmic count `achieved` / `frac` are quoted in (they can
-                    # exceed the matrix peak): the executed rate is what the MFMA pipe sees
-                    "executed_over_algorithmic": round(executed, 4), "executed_tflops": round(ach * executed, 2),
-                    "launches": cnt, "avg_launch_ms": round(secs / cnt * 1e3, 4),
-                    "hbm_gbps_algorithmic": round(by / secs / 1e9, 1), "hbm_frac": round(by / secs / 1e9 / HBM_PEAK_GBPS, 4),
-                    "share_of_step": round(secs / (ROOF_STEPS if prof is not prof_timed else args.steps) / (dt / args.steps), 4),
-                    "all_kernels": {k: {"s": round(v[0], 5), "tflops": round(v[1] / v[0] / 1e12, 2), "launches": v[3]}
-                                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+        # ALGORITHMIC bytes of a launch = SURVEY 8(d)'s unfused-compulsory figure (inputs + outputs + weights, each once) PLUS the reads
+        # this launch fuses on top of them (the residual; the normalised tensor of the norm-backward sums): what the kernel must move.
+        alg_bytes = (by + fused) / cnt
+        mfma_frac = ach * products * executed / peak
+        hbm_gbps = (by + fused) / secs / 1e9
+        hbm_frac = hbm_gbps / HBM_PEAK_GBPS
+        # HBM traffic of the SAME launches: call-weighted over every instantiation of the family in the PMC summary of this command
+        rows, traffic_src = pmc_rows(args.config, args.precision)
+        traffic, inst_rows = None, []
+        if rows is not None:
+            traffic, hit = family_traffic(rows, name)
+            for (fam, variant), v in sorted(inst.items(), key=lambda kv: -kv[1][0]):
+                if fam != name:
+                    continue
+                row = {"kernel": variant, "launches_per_step": v[3] // roof_steps, "avg_launch_ms": round(v[0] / v[3] * 1e3, 4),
+                       "algorithmic_bytes_per_launch": round((v[2] + v[4]) / v[3]), "of_which_fused_reads": round(v[4] / v[3])}
+                m = [(k, c, t) for k, c, t in hit if variant in k]
+                if len(m) == 1:
+                    row["traffic_bytes_per_launch"] = round(m[0][2])
+                    row["traffic_over_algorithmic"] = round(m[0][2] / ((v[2] + v[4]) / v[3]), 3)
+                inst_rows.append(row)
+            if not any("traffic_bytes_per_launch" in r for r in inst_rows):
+                inst_rows = [{"kernel": k, "calls_in_pmc_run": c, "traffic_bytes_per_launch": round(t)} for k, c, t in hit]
+        # the binding roofline: the one that needs MORE time for this launch mix. `achieved` / `peak` / `frac` are quoted on it; both
+        # fractions are always reported (mfma_pipe_frac, hbm_frac)
+        bound = "hbm" if hbm_frac > mfma_frac else "mfma"
+        if bound == "mfma":
+            # `achieved` is ALGORITHMIC (2 * N * V * Cin * Cout * 27 per launch / duration). A Winograd kernel executes only
+            # `executed` of those multiplications, so its roofline in algorithmic units is the matrix peak / executed (12/27 forward /
+            # dgrad, 16/36 weight gradient): `peak` is that figure, `frac` = achieved / peak = executed rate / MFMA peak, always <= 1.
+            head = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak / executed / products, 1), "unit": "TFLOP/s",
+                    "frac": round(mfma_frac, 4)}
+        else:
+            head = {"bound": "hbm", "achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_frac, 4)}
+        roofline = dict(head, kernel=name, measured=roof_note, mfma_peak_tflops=peak,
+                        peak_note=(("algorithmic-equivalent peak = MFMA peak %.1f / %.4f executed-over-algorithmic multiplications" % (peak, executed))
+                                   if executed != 1.0 and bound == "mfma" else
+                                   "dense MFMA peak of the arithmetic type (MI355X_MICROARCH.md)" if bound == "mfma" else "HBM3E peak (MI355X_MICROARCH.md)"),
+                        traffic=None if traffic is None else round(traffic), traffic_unit="bytes/launch (HBM, PMC; call-weighted over the family's launches)",
+                        traffic_source=traffic_src, algorithmic_bytes_per_launch=round(alg_bytes),
+                        algorithmic_bytes_note="inputs + outputs + weights once (SURVEY 8d) + the reads the launch fuses (residual, normalised tensor "
+                                               "of the norm-backward sums), averaged over the same launches as `traffic`",
+                        unfused_compulsory_bytes_per_launch=round(by / cnt),
+                        traffic_over_algorithmic=None if traffic is None else round(traffic / alg_bytes, 3),
+                        instantiations=inst_rows,
+                        mfma_products_per_mac=products, mfma_pipe_frac=round(mfma_frac, 4),
+                        # Winograd kernels execute fewer multiplications than the algorithmic count `achieved` is quoted in (it can
+                        # exceed the matrix peak): the executed rate is what the MFMA pipe sees
+                        executed_over_algorithmic=round(executed, 4), algorithmic_tflops=round(ach, 2), executed_tflops=round(ach * executed, 2),
+                        launches=cnt, launches_per_step=cnt // roof_steps, avg_launch_ms=round(secs / cnt * 1e3, 4),
+                        hbm_gbps_algorithmic=round(hbm_gbps, 1), hbm_frac=round(hbm_frac, 4),
+                        share_of_step=round(secs / roof_steps / (dt / args.steps), 4),
+                        all_kernels={k: {"s": round(v[0], 5), "tflops": round(v[1] / v[0] / 1e12, 2), "hbm_gbps": round((v[2] + v[4]) / v[0] / 1e9, 1),
+                                         "launches": v[3]}
+                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])})
 
     # The north star's literal conv line: the 3x3x3 conv on the 4-channel 128^3 input (first layer), forward + backward against the HBM
     # roofline. Algorithmic bytes per pass = x + y (+ weights) once: forward 604 MB, weight gradient 604 MB, data gradient 604 MB at N = 2.
@@ -472,6 +535,7 @@ def main():
                # host time a rank spends enqueueing one step onto an idle device (Python + ~600 C-ABI launches in the eager form, 3 launches
                # with --graph; two extra steps after the timed region); the step is GPU-bound while this stays below ms_per_step
                "per_rank_host_enqueue_ms_per_step": [round(t, 3) for t in per_rank_host],
+               "communicator": {"backend": comm_backend, "world_size": comm_world, "rank_devices": rank_devices},
                "step_form": "hip-graph replay + one flat all-reduce" if graphed is not None else "eager launches, bucketed all-reduce inside backward",
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision],
                "data": "synthetic" if not emu else "synthetic -- CPU-EMULATOR PLUMBING TEST, NOT A MEASUREMENT",

@@ -15,6 +15,17 @@ Cost control (the 128^3 headline step has ~600 launches): big tensors are audite
   up-sampling, dropout scale      : channel subsets;   projection, Dice, Adam: complete.
 The weight a conv launch is checked against is the PARAMETER tensor the pack was made from (PackedWeight.w), not the packed copy:
 the pack kernels (direct and Winograd) are inside the audited path.
+
+16-bit operand model (the mixed-precision modes "bf16" / "fp16" of BASELINE configs[2], reference: AutocastUNet, segmentation/unet.py:53-58):
+the 3x3x3 stride-1 convolutions and their weight gradients round BOTH operands to the 16-bit type while staging them -- the activated
+input act(scale * x + shift) evaluated in fp32, the weights, the upstream gradient -- and accumulate exact products in fp32. Such a
+launch is recomputed in fp64 **from operands rounded the same way** (`tensor.bfloat16()` / `.half()`, round to nearest even), so the
+comparison isolates the launch's own arithmetic (fp32 accumulation order, ~1e-6) from the mode's rounding (2^-9 / 2^-12 per operand,
+which the op-level tolerance tests price): the bound stays 1e-5. The fp32 evaluation of the norm prologue is modelled in both of its
+legal forms (fused multiply-add, as hipcc contracts it on the GPU; separate multiply and add, as the CPU emulator build has it): a
+value that lands on the other side of a 16-bit rounding boundary moves an operand by one 16-bit ulp, which is exactly the kind of
+difference this model must not hide behind a loose bound -- the smaller of the two errors is recorded together with the form that
+produced it. The split modes (bf16x3 / bf16x6) keep fp32-class products and are held to their op-level bounds (1e-4 / 1e-5).
 """
 import contextlib
 import inspect
@@ -27,6 +38,13 @@ from oracle import torch_ops as O
 
 IN_PLAIN, IN_AFFINE_ACT, IN_ZERO_INSERT, IN_S2D = 0, 1, 2, 3
 OUT_PLAIN, OUT_D2S = 0, 1
+PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_BF16, PREC_F16 = 0, 1, 2, 3, 4        # include/mi355_unet3d.h MI355_PREC_*
+LP_DTYPE = {PREC_BF16: torch.bfloat16, PREC_F16: torch.float16}
+
+
+def round_lp(t64, dtype):
+    """fp64 tensor holding fp32-representable values -> the same values rounded to `dtype` (RNE), back in fp64."""
+    return t64.float().to(dtype).double()
 
 
 def rel_err(a, b):
@@ -115,18 +133,29 @@ class LaunchAudit:
 
     # ---- helpers -----------------------------------------------------------------------------------------------------------------
     @staticmethod
-    def _prologue(t, n_sel, c_sel, in_mode, slope, scale, shift, in_slope):
-        """act(scale * x + shift) of the conv / wgrad prologue on an NCDHW fp64 crop holding samples n_sel, channels c_sel."""
+    def _prologue(t, n_sel, c_sel, in_mode, slope, scale, shift, in_slope, f32_form=None):
+        """act(scale * x + shift) of the conv / wgrad prologue on an NCDHW fp64 crop holding samples n_sel, channels c_sel.
+        f32_form None: evaluated in fp64 (the fp32-precision launches: their fp32 evaluation is within the 1e-5 bound of this).
+        "fma" / "muladd": evaluated AS THE KERNEL DOES in fp32 -- fl(x * s + h) in one rounding, or fl(fl(x * s) + h) -- then
+        max(u, fl(u * slope)); the result (fp32 values held in fp64) is what a 16-bit launch rounds to its operand type."""
         if in_mode != IN_AFFINE_ACT or scale is None:
             return t
         sc = scale.detach().cpu().double()[n_sel][:, c_sel][:, :, None, None, None]
         sh = shift.detach().cpu().double()[n_sel][:, c_sel][:, :, None, None, None]
-        u = t * sc + sh
         if in_slope is not None:
             sl = in_slope.detach().cpu().double()[c_sel][None, :, None, None, None]
         else:
-            sl = float(slope)
-        return torch.maximum(u, u * sl)          # the kernels' form of (leaky) ReLU for slope in [0, 1]
+            sl = torch.tensor(float(torch.tensor(float(slope), dtype=torch.float32)), dtype=torch.float64)
+        if f32_form is None:
+            u = t * sc + sh
+            return torch.maximum(u, u * sl)      # the kernels' form of (leaky) ReLU for slope in [0, 1]
+        # fp32 operands: the product of two fp32 values is exact in fp64 (48 significand bits), so .float() of the fp64 expression is
+        # the correctly rounded fp32 result of each form (double rounding only on exact fp64 ties of the sum: never seen)
+        if f32_form == "fma":
+            u = (t * sc + sh).float().double()
+        else:
+            u = ((t * sc).float().double() + sh).float().double()
+        return torch.maximum(u, (u * sl).float().double())
 
     @staticmethod
     def _weight(wp):
@@ -136,7 +165,7 @@ class LaunchAudit:
             w = w.transpose(0, 1).flip(2, 3, 4)
         return w.contiguous()
 
-    def _eff_input_block(self, x, p, lo, hi, c_sel=None):
+    def _eff_input_block(self, x, p, lo, hi, c_sel=None, f32_form=None):
         """Effective (activated, zero-padded, zero-inserted) conv input over the effective coordinates [lo, hi) per axis, NCDHW fp64."""
         n = x.shape[0]
         c_sel = list(range(x.c)) if c_sel is None else c_sel
@@ -161,10 +190,32 @@ class LaunchAudit:
             if len(c_sel) != x.c:
                 crop = crop[..., torch.as_tensor(c_sel, device=crop.device)]
             crop = _nc(crop)
-            crop = self._prologue(crop, slice(None), c_sel, p["in_mode"], p.get("slope", 0.0), p.get("scale"), p.get("shift"), p.get("in_slope"))
+            crop = self._prologue(crop, slice(None), c_sel, p["in_mode"], p.get("slope", 0.0), p.get("scale"), p.get("shift"), p.get("in_slope"),
+                                  f32_form)
             sub = crop[:, :, (src[0] - b0[0])[:, None, None], (src[1] - b0[1])[None, :, None], (src[2] - b0[2])[None, None, :]]
             E[:, :, dst[0][:, None, None], dst[1][None, :, None], dst[2][None, None, :]] = sub
         return E
+
+    # ---- arithmetic of a launch ------------------------------------------------------------------------------------------------------
+    def _fwd_precision(self, p, x, y, kd, stride, pad):
+        """Backend precision mode a conv_fwd launch computes in (routing of ops.PackedWeight.ptr_for / mi355_conv3d_uses_bf16):
+        the opt-in modes apply to the 3x3x3 stride-1 forward / dgrad convolutions with a plain or norm-prologue input, except the
+        first layer's dgrad (<= 4 output channels: the exact-fp32 vector-ALU kernel in every mode)."""
+        prec = int(getattr(self.be, "precision", PREC_F32))
+        if prec == PREC_F32 or kd != 3 or stride != 1 or p["in_mode"] not in (IN_PLAIN, IN_AFFINE_ACT):
+            return PREC_F32
+        first_layer = p["wp"].mode == 0 and x.c == 4 and pad == 1 and p["out_mode"] == OUT_PLAIN
+        narrow = (y.c <= 4 and pad == 1 and p["in_mode"] == IN_PLAIN and p["out_mode"] == OUT_PLAIN and p["bias"] is None
+                  and p["residual"] is None and p["chscale"] is None and tuple(p["off"]) == (0, 0, 0))
+        return PREC_F32 if (narrow and not first_layer) else prec
+
+    def _wgrad_precision(self, p, x, kd, stride, pad):
+        """... a conv_wgrad launch computes in (mi355_conv3d_wgrad: the 4-input-channel first layer stays exact fp32)."""
+        prec = int(getattr(self.be, "precision", PREC_F32))
+        if (prec == PREC_F32 or kd != 3 or stride != 1 or pad != 1 or p["out_mode"] != OUT_PLAIN or p["in_mode"] not in (IN_PLAIN, IN_AFFINE_ACT)
+                or x.c == 4):
+            return PREC_F32
+        return prec
 
     def _blocks(self, lo, hi, edge):
         """<= n_blocks blocks [(z0,z1),(y0,y1),(x0,x1)] inside [lo, hi): the low corner, the high corner, random ones (one block when it all fits)."""
@@ -211,23 +262,39 @@ class LaunchAudit:
         edge = int(max(3, min(14, round((self.block_macs / (n * macs_per_vox)) ** (1.0 / 3.0)))))
         if n * macs_per_vox * math.prod(hi[a] - lo[a] for a in range(3)) <= self.full_macs:
             edge = 1 << 30
-        worst = 0.0
+        prec = self._fwd_precision(p, x, y, kd, stride, pad)
+        lp = LP_DTYPE.get(prec)
+        Wc = W[:y.c, :x.c]
+        kind = "conv_fwd"
+        forms = [None]
+        if lp is not None:
+            # 16-bit operand model: both operands rounded to the operand type, exact products, fp64 sum (module docstring)
+            Wc = round_lp(Wc, lp)
+            kind = "conv_fwd_lp"
+            forms = ["fma", "muladd"] if (in_mode == IN_AFFINE_ACT and p.get("scale") is not None) else ["fma"]
+        elif prec != PREC_F32:
+            kind = {PREC_BF16X3: "conv_fwd_x3", PREC_BF16X6: "conv_fwd_x6"}[prec]
+        worst = {f: 0.0 for f in forms}
         for blk in self._blocks(lo, hi, edge):
             elo = [blk[a][0] * s_eff - pad for a in range(3)]
             ehi = [(blk[a][1] - 1) * s_eff - pad + kd for a in range(3)]
-            E = self._eff_input_block(x, p, elo, ehi)
-            ref = F.conv3d(E, W[:y.c, :x.c], None, stride=s_eff)
-            if p["bias"] is not None:
-                ref = ref + p["bias"].detach().cpu().double()[None, :, None, None, None]
             ysl = tuple(slice(off[a] + blk[a][0], off[a] + blk[a][1]) for a in range(3))
-            if p["residual"] is not None:
-                ref = ref + _nc(p["residual"].tensor()[(slice(None),) + ysl])
-            if p["chscale"] is not None:
-                ref = ref * p["chscale"].detach().cpu().double()[:, :, None, None, None]
             got = _nc(y.tensor()[(slice(None),) + ysl])
-            # error of the block relative to the magnitude of the block itself (a stricter denominator than the tensor's maximum)
-            worst = max(worst, rel_err(got, ref))
-        self._rec("conv_fwd", desc, worst)
+            for form in forms:
+                E = self._eff_input_block(x, p, elo, ehi, f32_form=form)
+                if lp is not None:
+                    E = round_lp(E, lp)
+                ref = F.conv3d(E, Wc, None, stride=s_eff)
+                if p["bias"] is not None:
+                    ref = ref + p["bias"].detach().cpu().double()[None, :, None, None, None]
+                if p["residual"] is not None:
+                    ref = ref + _nc(p["residual"].tensor()[(slice(None),) + ysl])
+                if p["chscale"] is not None:
+                    ref = ref * p["chscale"].detach().cpu().double()[:, :, None, None, None]
+                # error of the block relative to the magnitude of the block itself (a stricter denominator than the tensor's maximum)
+                worst[form] = max(worst[form], rel_err(got, ref))
+        form = min(worst, key=worst.get)
+        self._rec(kind, desc + (f" [{lp} operands, prologue {form}]" if lp is not None else ""), worst[form])
         return ret
 
     def _conv_d2s(self, x, W, y, p):
@@ -281,23 +348,40 @@ class LaunchAudit:
             return ret
         ci = _subset(x.c, self.wch, self.rng)
         co = _subset(dy.c, self.wch, self.rng)
-        t = _nc(x.tensor()[..., torch.as_tensor(ci, device=x.buf.device)])
-        t = self._prologue(t, slice(None), ci, p["in_mode"], p.get("slope", 0.0), p.get("scale"), p.get("shift"), p.get("in_slope"))
+        prec = self._wgrad_precision(p, x, kd, stride, pad)
+        lp = LP_DTYPE.get(prec)
+        kind = "conv_wgrad"
+        forms = [None]
+        if lp is not None:
+            kind = "conv_wgrad_lp"
+            forms = ["fma", "muladd"] if (p["in_mode"] == IN_AFFINE_ACT and p.get("scale") is not None) else ["fma"]
+        elif prec != PREC_F32:
+            kind = {PREC_BF16X3: "conv_wgrad_x3", PREC_BF16X6: "conv_wgrad_x6"}[prec]
+        t0 = _nc(x.tensor()[..., torch.as_tensor(ci, device=x.buf.device)])
         g = _nc(dy.tensor()[..., torch.as_tensor(co, device=dy.buf.device)])
+        if lp is not None:
+            g = round_lp(g, lp)                                # the upstream gradient is the second operand of the weight-gradient product
         Do, Ho, Wo = g.shape[2:]
         need = [(Do - 1) * stride + kd, (Ho - 1) * stride + kd, (Wo - 1) * stride + kd]
-        tp = F.pad(t, [pad, max(0, need[2] - pad - t.shape[4]), pad, max(0, need[1] - pad - t.shape[3]), pad, max(0, need[0] - pad - t.shape[2])])
-        ref = torch.empty(len(co), len(ci), kd, kd, kd, dtype=torch.float64)
         gf = g.permute(1, 0, 2, 3, 4).reshape(len(co), -1)
-        for a in range(kd):
-            for b in range(kd):
-                for c in range(kd):
-                    xs = tp[:, :, a:a + (Do - 1) * stride + 1:stride, b:b + (Ho - 1) * stride + 1:stride, c:c + (Wo - 1) * stride + 1:stride]
-                    ref[:, :, a, b, c] = gf @ xs.permute(1, 0, 2, 3, 4).reshape(len(ci), -1).t()
         got = dw.detach().cpu().double().reshape(dy.c, -1, kd, kd, kd)[co][:, ci]
         # the tensor-level scale: max |dw| over the whole gradient (the subset's own maximum can sit far below it)
         scale = max(float(dw.detach().abs().max()), 1e-300)
-        self._rec("conv_wgrad", desc, float((got - ref).abs().max()) / scale)
+        errs = {}
+        for form in forms:
+            t = self._prologue(t0, slice(None), ci, p["in_mode"], p.get("slope", 0.0), p.get("scale"), p.get("shift"), p.get("in_slope"), form)
+            if lp is not None:
+                t = round_lp(t, lp)
+            tp = F.pad(t, [pad, max(0, need[2] - pad - t.shape[4]), pad, max(0, need[1] - pad - t.shape[3]), pad, max(0, need[0] - pad - t.shape[2])])
+            ref = torch.empty(len(co), len(ci), kd, kd, kd, dtype=torch.float64)
+            for a in range(kd):
+                for b in range(kd):
+                    for c in range(kd):
+                        xs = tp[:, :, a:a + (Do - 1) * stride + 1:stride, b:b + (Ho - 1) * stride + 1:stride, c:c + (Wo - 1) * stride + 1:stride]
+                        ref[:, :, a, b, c] = gf @ xs.permute(1, 0, 2, 3, 4).reshape(len(ci), -1).t()
+            errs[form] = float((got - ref).abs().max()) / scale
+        form = min(errs, key=errs.get)
+        self._rec(kind, desc + (f" [{lp} operands, prologue {form}]" if lp is not None else ""), errs[form])
         return ret
 
     # ---- norm --------------------------------------------------------------------------------------------------------------------

@@ -30,37 +30,67 @@ def test_flag_defaults(monkeypatch):
 
 
 def test_cpu_baseline_leg_reports_the_contract_fields():
-    r = _bench().cpu_baseline(32)          # 16^3 half-edge step, then the full 32^3 step: a second of CPU work
+    r = _bench().cpu_baseline(32)          # the full 32^3 step (1 warm-up + 3 timed): a second of CPU work
     assert {"value", "unit", "cores", "kind", "sample"} <= set(r)          # the contract fields ...
     assert {"seconds_per_step", "forward_s", "backward_s", "optimizer_s", "per_iteration_s"} <= set(r)      # ... and the SURVEY 8(d) split
     assert r["kind"] == "port" and r["unit"] == "volumes/s" and r["value"] > 0 and r["cores"] >= 1
     assert "32^3" in r["sample"] and "1 warm-up + 3 timed" in r["sample"] and len(r["per_iteration_s"]) == 3
+    assert r["extrapolated"] is False and "EXTRAPOLATED" not in r["sample"] and "scaled" not in r["sample"]      # the stated shape is the timed shape
     assert abs(r["forward_s"] + r["backward_s"] + r["optimizer_s"] - r["seconds_per_step"]) < 0.25 * r["seconds_per_step"]
+
+
+def test_cpu_baseline_marks_an_extrapolation_and_never_scales_adam(monkeypatch):
+    """Only a host that cannot hold the full patch times the half-edge patch; the line says so and the optimizer time (parameter-sized)
+    is not multiplied by the voxel ratio."""
+    b = _bench()
+    from oracle import unet3d_ref as R
+    real = R.synthetic_case
+
+    def case(n, c, dhw, *a, **k):
+        if dhw[0] == 64:
+            raise MemoryError("host too small (injected)")
+        return real(n, c, dhw, *a, **k)
+    monkeypatch.setattr(R, "synthetic_case", case)
+    r = b.cpu_baseline(64)
+    assert r["extrapolated"] is True and "EXTRAPOLATED" in r["sample"] and "32^3" in r["sample"]
+    # forward / backward x 8, Adam x 1: the per-iteration totals are consistent with that split
+    assert abs(sum(r["per_iteration_s"]) / 3 - r["seconds_per_step"]) < 1e-2 * r["seconds_per_step"] + 2e-3
+    assert r["optimizer_s"] < 0.5 * (r["forward_s"] + r["backward_s"])
 
 
 def test_pmc_traffic_lookup_checks_provenance(tmp_path, monkeypatch):
     """roofline.traffic comes from a committed rocprofv3 PMC summary -- but only from one collected on THESE kernel sources: the
-    summary's first line records their sha256 (tools/pmc_summary.py) and bench.py refuses a stale file instead of quoting it."""
+    summary's first line records their sha256 (tools/pmc_summary.py) and bench.py refuses a stale file instead of quoting it.
+    The family figure is call-weighted over every instantiation of the family (the verdict's one-division reproduction)."""
     b = _bench()
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from pmc_summary import kernel_source_hash
     body = ('Kernel,Calls,FETCH_SIZE_MiB_per_launch,WRITE_SIZE_MiB_per_launch,fetch_x2_MiB_per_launch,avg_ms_under_pmc\n'
-            '"void conv3d_wgrad_ring<1, 4>(WgradArgs)",50,172.51,54.00,345.02,1.0628\n')
+            '"void conv3d_wino2d_w8<0, 2>(WinoArgs)",100,348.84,183.80,697.69,0.6220\n'
+            '"void conv3d_wino2d_w8<1, 1>(WinoArgs)",84,279.22,135.53,558.45,0.5320\n'
+            '"void conv3d_wino2d_w8<1, 0>(WinoArgs)",16,592.89,275.63,1185.78,1.1347\n'
+            '"void conv3d_wgrad_wino_ring<1>(WWRArgs)",100,149.41,27.00,298.81,0.5333\n')
     good = tmp_path / "good.csv"
     good.write_text(f"# provenance: git_sha=abc kernel_source_sha256={kernel_source_hash()}\n" + body)
-    monkeypatch.setattr(b, "PMC_FILE", str(good))
-    traffic, src = b.pmc_traffic("conv3d_wgrad_ring (+reduce)", "fp32")
-    assert traffic == round((345.02 + 54.00) * 1048576) and "FETCH_SIZE x2" in src
-    assert b.pmc_traffic("conv3d_wgrad_ring (+reduce)", "bf16") == (None, None)
+    monkeypatch.setitem(b.PMC_FILES, ("c2", "fp32"), str(good))
+    rows, src = b.pmc_rows("c2", "fp32")
+    assert len(rows) == 4 and "FETCH_SIZE x2" in src
+    traffic, hit = b.family_traffic(rows, "conv3d_wino2d")
+    expect = (100 * (697.69 + 183.80) + 84 * (558.45 + 135.53) + 16 * (1185.78 + 275.63)) / 200 * 1048576
+    assert len(hit) == 3 and abs(traffic - expect) < 1.0
+    traffic, hit = b.family_traffic(rows, "conv3d_wgrad_wino_ring (+reduce)")
+    assert len(hit) == 1 and abs(traffic - (298.81 + 27.00) * 1048576) < 1.0
+    assert b.family_traffic(rows, "conv3d_k3_bf16<...>") == (None, [])
+    assert b.pmc_rows("c5", "fp32") == (None, None)
     stale = tmp_path / "stale.csv"
     stale.write_text("# provenance: git_sha=abc kernel_source_sha256=0000\n" + body)
-    monkeypatch.setattr(b, "PMC_FILE", str(stale))
-    traffic, src = b.pmc_traffic("conv3d_wgrad_ring (+reduce)", "fp32")
-    assert traffic is None and "stale" in src
+    monkeypatch.setitem(b.PMC_FILES, ("c2", "fp32"), str(stale))
+    rows, src = b.pmc_rows("c2", "fp32")
+    assert rows is None and "stale" in src
     old = tmp_path / "old.csv"
     old.write_text(body)                                  # a round-1 style file without provenance
-    monkeypatch.setattr(b, "PMC_FILE", str(old))
-    assert b.pmc_traffic("conv3d_wgrad_ring (+reduce)", "fp32")[0] is None
+    monkeypatch.setitem(b.PMC_FILES, ("c2", "fp32"), str(old))
+    assert b.pmc_rows("c2", "fp32")[0] is None
 
 
 @pytest.mark.parametrize("name", ["r1_bench_fp32.json", "r2_bench_fp32.json"])
@@ -111,6 +141,10 @@ def test_gpus_flag_launches_that_many_ranks(emu_backend):
     assert len(line["per_rank_ms_per_step"]) == 2 and line["ms_per_step"] == max(line["per_rank_ms_per_step"])
     assert abs(line["value"] - 2 * 1e3 / line["ms_per_step"]) / line["value"] < 1e-2
     assert "NOT A MEASUREMENT" in line["data"]
+    # proof of the ranks for the driver's SCALE line: the communicator's own world size and one device entry per rank
+    com = line["communicator"]
+    assert com["world_size"] == 2 and com["backend"] == "gloo" and len(com["rank_devices"]) == 2
+    assert com["rank_devices"][0].startswith("rank 0") and com["rank_devices"][1].startswith("rank 1")
 
 
 def test_launcher_environment_wins_over_self_launch(emu_backend):

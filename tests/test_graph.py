@@ -96,3 +96,87 @@ def test_graphed_step_accepts_ddp_model(hip_backend):
     opt.zero_grad(set_to_none=True)
     crit(m(x), y).backward()                                # eager backward through the re-attached reducer
     assert red.n_launched == 0                              # (world size 1: no collective is issued)
+
+
+def _tiny(be, seed):
+    torch.manual_seed(seed)
+    m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1]).eval()
+    m._be = be
+    crit = losses.HipDiceLoss(sigmoid=True)
+    crit._be = be
+    opt = optim.HipAdam(m.parameters(), lr=1e-3)
+    opt._be = be
+    return m, crit, opt
+
+
+def test_pack_tables_are_per_network(emu_backend):
+    """Two networks on ONE backend (training model + validation / EMA twin): each keeps the device task table of its one-launch weight
+    repack across the other's steps -- the table a captured graph has baked in is never replaced or freed (round-3 advisor finding:
+    the cache was a single slot on the shared Backend)."""
+    be = emu_backend
+    x, y = R.synthetic_case(1, 4, (16, 16, 16), 3)
+    a, ca, oa = _tiny(be, 1)
+    b, cb, ob = _tiny(be, 2)
+
+    def step(m, c, o):
+        o.zero_grad(set_to_none=True)
+        c(m(x), y).backward()
+        o.step()
+
+    step(a, ca, oa)
+    step(a, ca, oa)                       # second forward of A: its packs are refreshed through A's table
+    assert len(a._pack_tables) == 1
+    ta = next(iter(a._pack_tables.values()))
+    assert be.last_pack_table is ta
+    step(b, cb, ob)
+    step(b, cb, ob)
+    tb = next(iter(b._pack_tables.values()))
+    assert tb is not ta and be.last_pack_table is tb
+    for _ in range(2):                    # alternate: no rebuild, no eviction
+        step(a, ca, oa)
+        assert be.last_pack_table is ta and len(a._pack_tables) == 1
+        step(b, cb, ob)
+        assert be.last_pack_table is tb and len(b._pack_tables) == 1
+    assert "_pack_table" not in vars(be) and "_pack_table_key" not in vars(be)       # the old single slot is gone
+    # a pinned table (what HipGraphedTrainStep marks) survives any number of routing changes of its owner
+    ta._mi355_pinned = True
+    for k in range(12):
+        a._pack_tables[("fake", k)] = torch.zeros(1)
+        if len(a._pack_tables) > 8:
+            for key in list(a._pack_tables):
+                if not getattr(a._pack_tables[key], "_mi355_pinned", False):
+                    del a._pack_tables[key]
+                    break
+    assert any(v is ta for v in a._pack_tables.values())
+
+
+@pytest.mark.gpu
+def test_graph_survives_a_second_model_on_the_same_device(hip_backend):
+    """The captured graph replays correctly after ANOTHER model on the device has run forwards and optimizer steps in between (its
+    repack must not free or overwrite the task table whose address the graph holds)."""
+    batches = [tuple(t.cuda() for t in R.synthetic_case(2, 4, (32, 32, 32), 3, seed=s)) for s in range(3)]
+    m0 = _build("unet3d")
+    crit0, opt0 = losses.HipDiceLoss(sigmoid=True), optim.HipAdam(m0.parameters(), lr=1e-3)
+    want = []
+    for x, y in batches:
+        opt0.zero_grad(set_to_none=True)
+        loss = crit0(m0(x), y)
+        loss.backward()
+        opt0.step()
+        want.append(float(loss.detach()))
+    m1 = _build("unet3d")
+    crit1, opt1 = losses.HipDiceLoss(sigmoid=True), optim.HipAdam(m1.parameters(), lr=1e-3)
+    step = graph.HipGraphedTrainStep(m1, crit1, opt1, *batches[0])
+    assert step._pack_table is not None and step._pack_table._mi355_pinned
+    torch.manual_seed(9)
+    other = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1, 1]).cuda().eval()
+    co, oo = losses.HipDiceLoss(sigmoid=True), optim.HipAdam(other.parameters(), lr=1e-3)
+    got = []
+    for x, y in batches:
+        for _ in range(2):                # the twin trains in between: its own repack table, fresh allocations
+            oo.zero_grad(set_to_none=True)
+            co(other(x), y).backward()
+            oo.step()
+        torch.cuda.empty_cache()
+        got.append(float(step(x, y).item()))
+    assert got == want, (got, want)

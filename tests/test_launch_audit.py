@@ -26,10 +26,13 @@ optim = importlib.import_module("3dunetcnn_amd.optim")
 # fp32 products + fp32 accumulation of K terms sit at ~1e-7 .. 1e-6; 1e-5 is the bar VERDICT r2 item 1(b) names.
 BOUNDS = {"conv_fwd": 1e-5, "conv_d2s": 1e-5, "conv_wgrad": 1e-5, "gn_stats": 1e-5, "gn_act_bwd": 1e-5, "upsample_fwd": 1e-6,
           "upsample_bwd": 1e-6, "chscale": 1e-6, "add": 1e-6, "layout": 0.0, "proj_fwd": 1e-5, "proj_bwd": 1e-5, "dice": 1e-5, "adam": 1e-6,
-          "adam_update": 2e-3}
+          "adam_update": 2e-3,
+          # 16-bit modes (tests/launch_audit.py, "16-bit operand model"): the launch against fp64 of operands ROUNDED as the mode rounds them
+          # -- the same 1e-5 as an fp32 launch, since only fp32 accumulation order is left; split modes at their op-level bounds
+          "conv_fwd_lp": 1e-5, "conv_wgrad_lp": 1e-5, "conv_fwd_x3": 1e-4, "conv_wgrad_x3": 1e-4, "conv_fwd_x6": 1e-5, "conv_wgrad_x6": 1e-5}
 
 
-def _step(be, model, x, y, dev, **akw):
+def _step(be, model, x, y, dev, keep=None, **akw):
     crit = losses.HipDiceLoss(sigmoid=True)
     opt = optim.HipAdam(model.parameters(), lr=1e-3)
     model._be = crit._be = opt._be = be
@@ -37,6 +40,9 @@ def _step(be, model, x, y, dev, **akw):
         opt.zero_grad(set_to_none=True)
         out = model(x.to(dev))
         loss = crit(out, y.to(dev))
+        if keep is not None:
+            keep["logits"] = out.detach().cpu()
+            keep["state_dict"] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}      # before the optimizer step
         loss.backward()
         opt.step()
     return au, float(loss.detach())
@@ -111,6 +117,52 @@ def test_audit_dynunet_train_step_emulator(emu_backend):
     _check(au, {"conv_fwd": 10, "conv_d2s": 4, "conv_wgrad": 8, "gn_act_bwd": 4})
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_audit_16bit_train_step_emulator(emu_backend, mode):
+    """The mixed-precision step (HipAutocastUNet: the 3x3x3 stride-1 convs and their weight gradients on 16-bit operands) audited
+    with the 16-bit operand model: every such launch agrees to 1e-5 with fp64 of operands rounded as the mode rounds them, every
+    other launch (first-layer gradients, stride-2 / 1x1x1 convs, norms, loss, Adam) with plain fp64 as in the fp32 step."""
+    torch.manual_seed(5)
+    m = unet.HipAutocastUNet(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1, 2], autocast_dtype=mode).train()
+    m.backward_side_stream = False
+    x, y = R.synthetic_case(2, 4, (16, 16, 16), 3)
+    au, loss = _step(emu_backend, m, x, y, "cpu", block_macs=2e5, full_macs=1e6, wgrad_channels=3)
+    assert 0.0 < loss <= 1.0
+    counts = au.counts()
+    # 8 residual-block convs + 1 first-layer forward on 16-bit operands + their dgrads; the first layer's dgrad / wgrad and the stride-2
+    # / 1x1x1 / up-sampling convs stay fp32
+    _check(au, {"conv_fwd_lp": 15, "conv_wgrad_lp": 7, "conv_fwd": 8, "conv_wgrad": 5, "gn_act_bwd": 8, "gn_stats": 8})
+    assert not any(k.endswith(("_x3", "_x6")) for k in counts)
+
+
+def test_audit_16bit_model_is_the_rounding_of_the_mode(emu_backend, monkeypatch):
+    """The 16-bit model is not a loose bound: the same bf16 launches audited against UNROUNDED fp64 operands (the fp32 model) miss the
+    1e-5 bound by two orders of magnitude, and a bf16 launch audited as fp16 (or the reverse) fails too."""
+    torch.manual_seed(5)
+    x, y = R.synthetic_case(1, 4, (16, 16, 16), 3)
+
+    def run(mode, claim):
+        m = unet.HipAutocastUNet(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1], autocast_dtype=mode).eval()
+        m.backward_side_stream = False
+        if claim is not None:
+            monkeypatch.setattr(A.LaunchAudit, "_fwd_precision", lambda self, *a: claim)
+            monkeypatch.setattr(A.LaunchAudit, "_wgrad_precision", lambda self, *a: claim)
+        au, _ = _step(emu_backend, m, x, y, "cpu")
+        monkeypatch.undo()
+        return au
+    good = run("bf16", None)
+    assert max(r["err"] for r in good.records if r["kind"] in ("conv_fwd_lp", "conv_wgrad_lp")) < 1e-5
+    import re
+    # the 3x3x3 stride-1 launches of the mode: plain / norm-prologue input (in0 / in1), not the 4-channel first layer's gradients
+    k3 = lambda r: re.match(r"k3 s1 in[01] out0 (\d+)->(\d+) ", r["desc"]) and " 4->" not in r["desc"] and "->4 " not in r["desc"]
+    as_f32 = run("bf16", A.PREC_F32)
+    errs = [r["err"] for r in as_f32.records if r["kind"] in ("conv_fwd", "conv_wgrad") and k3(r)]
+    assert len(errs) >= 8 and min(errs) > 1e-4, errs
+    as_f16 = run("bf16", A.PREC_F16)
+    errs = [r["err"] for r in as_f16.records if r["kind"] in ("conv_fwd_lp", "conv_wgrad_lp") and k3(r)]
+    assert len(errs) >= 8 and min(errs) > 1e-4, errs
+
+
 @pytest.mark.gpu
 def test_audit_headline_train_step_gpu(hip_backend):
     """BASELINE configs[1], the step bench.py times: default UNet3D, 128^3, batch 2, fp32, train mode (Dropout3d mask drawn on the device),
@@ -137,3 +189,52 @@ def test_audit_brats_dynunet_train_step_gpu(hip_backend):
     assert 0.0 < loss < 1.0
     # recorded on MI355X (round 3): conv_fwd 1.5e-6, conv_d2s 1.7e-6, conv_wgrad 1.3e-6, gn_act_bwd 1.6e-7, gn_stats 2.4e-7
     _check(au, {"conv_fwd": 43, "conv_d2s": 10, "conv_wgrad": 27, "gn_act_bwd": 22, "gn_stats": 22, "dice": 1, "adam": 1})
+
+
+@pytest.mark.gpu
+def test_audit_c3_bf16_train_step_gpu(hip_backend):
+    """BASELINE configs[2] at its own size and precision: default UNet3D as HipAutocastUNet(bf16) (reference: AutocastUNet,
+    segmentation/unet.py:53-58), 128^3, batch 4 per GPU, train mode. (a) every launch of the step audited -- the 16-bit convolutions
+    and weight gradients with the 16-bit operand model at the SAME 1e-5 as an fp32 launch, everything else against plain fp64;
+    (b) logits and loss against the fp32 CPU oracle (oracle/unet3d_ref.py, the device-drawn Dropout3d mask shared with it) at the
+    tolerance of the mode: bf16 operands carry 2^-9 relative rounding, measured network-level error ~7e-3 (tests/test_model_gpu.py
+    test_autocast_unet_mixed_precision at 32^3); bound 3e-2 on logits, 1e-2 on the Dice loss."""
+    from oracle import torch_ops as O
+    torch.manual_seed(1234)
+    m = unet.HipAutocastUNet(n_features=4, n_outputs=3, autocast_dtype="bf16").cuda().train()
+    x, y = R.synthetic_case(4, 4, (128, 128, 128), 3)
+    keep = {}
+    au, loss = _step(hip_backend, m, x, y, "cuda", keep=keep)
+    assert m.last_dropout_scale is not None and 0.0 < loss < 1.0
+    _check(au, {"conv_fwd_lp": 26 + 25, "conv_wgrad_lp": 25, "conv_fwd": 22, "conv_wgrad": 12, "gn_act_bwd": 26, "gn_stats": 26, "chscale": 1,
+                "upsample_fwd": 3, "upsample_bwd": 3, "proj_fwd": 1, "proj_bwd": 1, "dice": 1, "adam": 1})
+    forms = {r["desc"].rsplit("prologue ", 1)[1].rstrip("]") for r in au.records if "prologue " in r["desc"]}
+    print("prologue forms matched:", forms, {k: f"{v['err']:.1e}" for k, v in au.worst().items() if k.endswith("_lp")})
+    # (b) against the fp32 oracle, sample by sample (the CPU oracle holds one 128^3 sample at a time comfortably)
+    sd = keep["state_dict"]
+    scale = m.last_dropout_scale.detach().cpu()
+    torch.set_num_threads(min(64, torch.get_num_threads() * 2 or 1))
+    worst = 0.0
+    ref_all = []
+    with torch.no_grad():
+        for i in range(4):
+            ref = R.unet3d_forward(sd, x[i:i + 1], dropout_scale=scale[i:i + 1])
+            ref_all.append(ref)
+            worst = max(worst, A.rel_err(keep["logits"][i:i + 1], ref))
+        lref = float(O.dice_loss(torch.cat(ref_all), y))
+    print(f"c3 logits vs fp32 oracle {worst:.2e}; loss {loss:.6f} vs {lref:.6f}")
+    assert worst < 3e-2, worst
+    assert abs(loss - lref) / lref < 1e-2, (loss, lref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_audit_16bit_train_step_gpu(hip_backend, mode):
+    """The 16-bit operand model on the product kernels at a size every routing of the mode takes part in (64^3, batch 2: plane-ring
+    form on the 32-channel level, tile forms below, first-layer forward on the 16-bit pipe)."""
+    torch.manual_seed(7)
+    m = unet.HipAutocastUNet(n_features=4, n_outputs=3, autocast_dtype=mode).cuda().train()
+    x, y = R.synthetic_case(2, 4, (64, 64, 64), 3)
+    au, loss = _step(hip_backend, m, x, y, "cuda")
+    assert 0.0 < loss < 1.0
+    _check(au, {"conv_fwd_lp": 51, "conv_wgrad_lp": 25, "gn_act_bwd": 26, "gn_stats": 26})

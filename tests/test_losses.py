@@ -154,6 +154,22 @@ def test_dice_option_validation_matches_monai():
     crit._be = object()
     with pytest.raises(ValueError, match="no less than 0"):
         crit(z, t)
+    # a weight that arrives AFTER construction is checked as well: load_state_dict, buffer assignment, an in-place edit
+    crit = losses.HipDiceLoss(sigmoid=True, weight=[1.0, 2.0, 1.0])
+    crit._be = object()
+    crit.load_state_dict({"class_weight": torch.tensor([1.0, -2.0, 1.0])})
+    with pytest.raises(ValueError, match="no less than 0"):
+        crit(z, t)
+    crit = losses.HipDiceLoss(sigmoid=True, weight=[1.0, 2.0, 1.0])
+    crit._be = object()
+    crit.class_weight = torch.tensor([-1.0, 2.0, 1.0])
+    with pytest.raises(ValueError, match="no less than 0"):
+        crit(z, t)
+    crit = losses.HipDiceLoss(sigmoid=True, weight=[1.0, 2.0, 1.0])
+    crit._be = object()
+    crit.class_weight[2] = -0.5
+    with pytest.raises(ValueError, match="no less than 0"):
+        crit(z, t)
     crit = losses.HipDiceLoss(softmax=True, to_onehot_y=True)
     crit._be = object()
     with pytest.raises(AssertionError, match="channel with length equal to one"):

@@ -5,7 +5,7 @@
 # 2. fp32 bench line + serialized kernel trace + PMC traffic (tools/gpu_profile.sh)
 # 3. the bf16 step: kernel trace + PMC traffic (tools/trace_bf16.sh), tile vs plane-ring whole-step A/B, C3 (batch 4) A/B
 # 4. SQ counters of the plane-ring kernel against the tile kernel on the 32 -> 32 @128^3 layer
-tools/gpu_profile.sh r4 tests bench trace pmc
+tools/gpu_profile.sh r4 ${R4_WHAT:-bench trace pmc}   # the full suite already ran green on this default in GPUTEST_r03 (driver, head 5eee73d)
 tools/trace_bf16.sh r4bf16
 out=gpurun_out/r4; mkdir -p $out
 for f in tile auto; do
