@@ -20,61 +20,7 @@
 // {4-11,16-19,28-31}) to the two x-rows of the tile, so every 16-lane group reads 16 distinct 16-byte slots: conflict-free.
 // Weights are pre-packed [tap][ci/8][plane][co][8] (bf16) so a lane fetches its B fragment with one 16-byte global load
 // (L2/L1 resident), software-prefetched one k-step ahead.
-#include "hipcompat.h"
-#include <type_traits>
-#include <cstdlib>
-#include "../../include/mi355_unet3d.h"
-#include "gn_fuse.h"
-
-struct ConvBArgs {
-  const float* x; int xld;
-  const uint4* wp;
-  float* y; int yld;
-  const float* res; int resld;
-  const float* in_scale; const float* in_shift; float slope; const float* in_slope;
-  const float* out_chscale; const float* bias;
-  int N, Di, Hi, Wi, Cin, CinP;       // CinP = roundup(Cin, 16)
-  int Do, Ho, Wo, Cout, CoutP;
-  int yD, yH, yW, offz, offy, offx;
-  int pad;
-  int tilesZ, tilesY, tilesX, coTiles, spatialTiles;
-  int zsplits, zper;         // conv3d_k3_lp_zring: z ranges [zs * zper, min(Do, (zs + 1) * zper)) per workgroup
-  GnFuseArgs g;            // norm statistics fused into the epilogue (gn_fuse.h)
-};
-
-// lane (0..31) of an M tile -> (x-row 0/1, x position 0..15): row = which ds_read_b128 lane group the lane belongs to
-__device__ __forceinline__ void mtile_lane(int li, int& row, int& tx) {
-  const int q = li >> 2;                    // quad index 0..7: quads {0,3,5,6} are group 0, {1,2,4,7} group 1
-  const int g1 = (0x96 >> q) & 1;           // 0b10010110
-  row = g1;
-  const int rank = g1 ? ((q == 1) ? 0 : (q == 2) ? 1 : (q == 4) ? 2 : 3) : ((q == 0) ? 0 : (q == 3) ? 1 : (q == 5) ? 2 : 3);
-  tx = rank * 4 + (li & 3);
-}
-
-template <int NS> struct Products;
-template <> struct Products<1> { static constexpr int P = 1; static constexpr int pa[1] = {0}; static constexpr int pb[1] = {0}; };
-template <> struct Products<2> { static constexpr int P = 3; static constexpr int pa[3] = {1, 0, 0}; static constexpr int pb[3] = {0, 1, 0}; };
-// smallest terms first
-template <> struct Products<3> { static constexpr int P = 6; static constexpr int pa[6] = {2, 1, 0, 1, 0, 0}; static constexpr int pb[6] = {0, 1, 2, 0, 1, 0}; };
-
-// split 8 floats into NS bf16 planes, each plane one uint4 (8 packed bf16)
-template <int NS, bool F16 = false>
-__device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[NS]) {
-  static_assert(!F16 || NS == 1, "fp16 operands are not split");
-  float r[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) r[e] = v[e];
-#pragma unroll
-  for (int p = 0; p < NS; ++p) {
-    unsigned w[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      w[e] = pack_lp2<F16>(r[2 * e], r[2 * e + 1]);
-      if (p + 1 < NS) { r[2 * e] -= bf16lo_to_f32(w[e]); r[2 * e + 1] -= bf16hi_to_f32(w[e]); }
-    }
-    out[p] = make_uint4(w[0], w[1], w[2], w[3]);
-  }
-}
+#include "conv3d_lp.h"
 
 // FUSE: 0 plain epilogue, 1 + moment records of the output, 2 + norm-backward sums (dgrad): as conv3d_fwd.hip
 // F16: MI355_PREC_F16 -- the single operand plane is IEEE fp16 instead of bf16 (same tile, same loop, v_mfma_f32_32x32x16_f16)
@@ -449,308 +395,62 @@ void conv3d_k3_bf16(ConvBArgs a) {
   }
 }
 
-// =====================================================================================================================================
-// Plane-ring (z-marching), WEIGHTS-STATIONARY form for the 16-bit single-product modes (MI355_PREC_BF16 / MI355_PREC_F16) with <= 32
-// input and exactly 32 output channels -- the 32 -> 32 layers of the 128^3 level are the largest group of launches of BASELINE configs[2].
-// Written at the end of round 3; default for the shapes it takes since its first measurement (plan_lp_zring below).
-// conv3d_k3_bf16 above runs at 20 % matrix-pipe utilisation on these layers: a 4 x 4 x 16 voxel tile is ONE staging round (load ->
-// convert -> LDS -> barrier) followed by 1.4 us of MFMAs and an epilogue, and its weight fragments stream from L1 (one 1 KB fragment per
-// 32-cycle MFMA and wave would be twice the L1 bandwidth of a CU at full matrix rate). Here a 256-thread workgroup owns an 8 (y) x 16 (x)
-// voxel column and marches it along z:
-//   * one wave per SIMD owns a lane's whole register file: the 27 x J weight fragments of the layer (216 registers at 32 input
-//     channels) are loaded ONCE per workgroup and pinned in AGPRs, from where the MFMA reads its B operand directly;
-//   * LDS holds a ring of 4 haloed input planes (10 x 18 voxels x 32 channels as 16-bit, 14.4 KB each): output plane z reads planes
-//     z - 1, z, z + 1 (27 x J conflict-free ds_read_b128 per wave) while plane z + 2 is converted and written; every input voxel is
-//     fetched once per column (halo 1.4x, no z re-reads: 2.5x in the tile form);
-//   * one barrier per output plane; the global loads of plane z + 3 are issued a whole step ahead (two register sets), the residual /
-//     normalised-tensor reads of the epilogue at the start of the step that consumes them;
-//   * the epilogue of plane z - 1 (two accumulator sets), the conversion of plane z + 2 and the MFMAs of plane z are ONE basic block,
-//     interleaved by scheduler directives -- with one wave per SIMD nothing else hides a latency. Fused statistics accumulate in
-//     registers over the whole z range: one record per (z range, column).
-// Wave w owns the M tile of rows 2 w, 2 w + 1 (32 voxels, the conflict-free lane -> voxel map of mtile_lane). Interior columns only
-// (H % 8 == 0, W % 16 == 0, plain un-windowed output): the dispatcher keeps the tile kernel for everything else.
-template <int J, int INMODE, int FUSE, bool F16>
-__global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring(ConvBArgs a) {
-  constexpr int TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HVP = HY * HX;      // haloed plane: 180 voxels
-  constexpr int OCT = 2 * J;                 // channel octets of the (padded) input: 2 (16 channels) or 4 (32)
-  constexpr int VSQ = OCT + 1;               // voxel stride in 16-byte units (odd)
-  constexpr int PLANE = HVP * VSQ;           // uint4 per ring slot
-  constexpr int UNITS = HVP * OCT;           // staging units (halo voxel, octet) per plane
-  constexpr int UP = (UNITS + 255) / 256;    // per thread
-  constexpr int NM = 27 * J;                 // MFMAs per output plane and wave
-  static_assert(256 % OCT == 0, "a thread stages one fixed channel octet");
-  static_assert(9 * UP + 16 <= NM, "the pieces of a step (conversion, unit stores, 16 output values) must fit its MFMAs");
-  DYN_LDS(lds_f);
-  uint4* lds = reinterpret_cast<uint4*>(lds_f);
-  const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6), half = lane >> 5, li = lane & 31;
-  int b = blockIdx.x;
-  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
-  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
-  const int zs = b % a.zsplits; b /= a.zsplits;
-  const int n = b;
-  const int zb = zs * a.zper, ze = zb + a.zper < a.Do ? zb + a.zper : a.Do;
-
-  // ---- weights: all 27 x J fragments of this lane, once, pinned in the accumulation registers ----
-  u32x4_t bw[NM];                              // (a native vector type: the register-class pin does not take HIP's uint4 struct)
-  {
-    const int CQ8 = a.CinP / 8;
-    const uint4* wl = a.wp + (size_t)half * a.CoutP + li;
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
-      bw[i] = __builtin_bit_cast(u32x4_t, wl[(size_t)((i / J) * CQ8 + 2 * (i % J)) * a.CoutP]);
-      PIN_IN_AGPR(bw[i]);
-    }
-  }
-
-  // ---- staging units of this thread: (halo voxel, octet so); geometry fixed for the column ----
-  const int so = tid % OCT;
-  const int c = 8 * so;
-  const bool v0ok = c < a.Cin, v1ok = c + 4 < a.Cin;
-  unsigned uoff[UP];                         // float offset inside an input plane (clamped, always valid)
-  bool uin[UP];                              // inside the volume in y and x
-  int ulds[UP];                              // uint4 offset inside a ring slot
-#pragma unroll
-  for (int k = 0; k < UP; ++k) {
-    const int u = tid + 256 * k;
-    const int hv = u < UNITS ? u / OCT : HVP - 1;           // threads beyond the unit count repeat the last voxel's unit (identical store)
-    const int iy = ty0 - 1 + hv / HX, ix = tx0 - 1 + hv % HX;
-    uin[k] = iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
-    const int iyc = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1), ixc = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
-    uoff[k] = (unsigned)((iyc * a.Wi + ixc) * a.xld);
-    ulds[k] = hv * VSQ + so;
-  }
-  const int c0q = v0ok ? c : 0, c1q = v1ok ? c + 4 : c0q;
-  float sc[8], sh[8], sl[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; sl[e] = a.slope; }
-  if (INMODE == MI355_IN_AFFINE_ACT) {
-#pragma unroll
-    for (int hq = 0; hq < 2; ++hq) {
-      if (hq ? v1ok : v0ok) {
-        const float4 s4 = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + c + 4 * hq);
-        const float4 h4 = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + c + 4 * hq);
-        sc[4 * hq] = s4.x; sc[4 * hq + 1] = s4.y; sc[4 * hq + 2] = s4.z; sc[4 * hq + 3] = s4.w;
-        sh[4 * hq] = h4.x; sh[4 * hq + 1] = h4.y; sh[4 * hq + 2] = h4.z; sh[4 * hq + 3] = h4.w;
-        if (a.in_slope) {
-          const float4 l4 = *reinterpret_cast<const float4*>(a.in_slope + c + 4 * hq);
-          sl[4 * hq] = l4.x; sl[4 * hq + 1] = l4.y; sl[4 * hq + 2] = l4.z; sl[4 * hq + 3] = l4.w;
-        }
-      }
-    }
-  }
-  const size_t xplane = (size_t)a.Hi * a.Wi * a.xld;
-  const float* xn = a.x + (size_t)n * a.Di * xplane;
-  // plane p (may lie outside the volume: clamped address, zeroed at the conversion) -> register set
-  auto loads = [&](float4 (&ld)[UP][2], int p) {
-    const int pc = p < 0 ? 0 : (p < a.Di ? p : a.Di - 1);
-    const float* base = xn + (size_t)pc * xplane;             // workgroup-uniform
-#pragma unroll
-    for (int k = 0; k < UP; ++k) {
-      ld[k][0] = *reinterpret_cast<const float4*>(base + uoff[k] + c0q);
-      ld[k][1] = *reinterpret_cast<const float4*>(base + uoff[k] + c1q);
-    }
-  };
-  // conversion of one staged element (norm + activation, mask) / of a unit's eight elements into its ring slot. The step below
-  // spreads these over the MFMAs of a plane one element at a time; the prologue runs a whole plane at once (`commit`).
-  auto conv_elem = [&](const float4 (&ld)[UP][2], int k, int e, bool pin) -> float {
-    const float4 q = ld[k][e >> 2];
-    float v = (e & 3) == 0 ? q.x : (e & 3) == 1 ? q.y : (e & 3) == 2 ? q.z : q.w;
-    if (INMODE == MI355_IN_AFFINE_ACT) {
-      const float u = v * sc[e] + sh[e];
-      v = fmaxf(u, u * sl[e]);
-    }
-    return (pin && uin[k] && (e < 4 ? v0ok : v1ok)) ? v : 0.f;
-  };
-  auto store_unit = [&](const float (&v)[8], int k, auto slotc) {
-    constexpr int SLOT = decltype(slotc)::value;
-    uint4 pl[1];
-    split8<1, F16>(v, pl);
-    lds[SLOT * PLANE + ulds[k]] = pl[0];
-  };
-  auto commit = [&](const float4 (&ld)[UP][2], int p, auto slotc) {
-    const bool pin = p >= 0 && p < a.Di;                      // workgroup-uniform
-#pragma unroll
-    for (int k = 0; k < UP; ++k) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = conv_elem(ld, k, e, pin);
-      store_unit(v, k, slotc);
-    }
-  };
-
-  // ---- this lane's A-operand position and its epilogue rows ----
-  int lrow, ltx;
-  mtile_lane(li, lrow, ltx);
-  const int abase = ((2 * wave + lrow) * HX + ltx) * VSQ + half;
-  const int co = li;                                          // Cout == 32 (dispatcher): every lane owns a real channel
-  float bs = 0.f, cs = 1.f;
-  if (a.bias) bs = a.bias[co];
-  if (a.out_chscale) cs = a.out_chscale[(size_t)n * a.Cout + co];
-  float K0 = 0.f, s0 = 0.f, s1 = 0.f, gsc = 1.f, gsh = 0.f, gmean = 0.f, grstd = 1.f;
-  bool first = true;
-  if constexpr (FUSE == 2) {
-    const int grp = co / (a.Cout / a.g.ggroups);
-    gsc = a.g.gscale[(size_t)n * a.Cout + co]; gsh = a.g.gshift[(size_t)n * a.Cout + co];
-    gmean = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
-  }
-  // Output plane z: accumulator register r is x position r of x-row ((0b0110 >> (r >> 2)) & 1) ^ half (mtile_lane inverted). Every
-  // address of the epilogue is a wave-uniform base (plane z, this wave's row pair, x position r: scalar registers) plus ONE 32-bit
-  // lane offset per x-row (the 16 + 16 + 16 per-lane 64-bit pointers of the first version cost 60 vector registers).
-  const size_t vrow0 = (((size_t)n * a.Do) * a.Ho + ty0 + 2 * wave) * a.Wo + tx0;      // plane 0, x-row 0 of this wave's tile, x = 0
-  const size_t oplane = (size_t)a.Ho * a.Wo;
-  const unsigned yoA = (unsigned)(half * a.Wo * a.yld + co), yoB = (unsigned)((half ^ 1) * a.Wo * a.yld + co);
-  const unsigned roA = (unsigned)(half * a.Wo * a.resld + co), roB = (unsigned)((half ^ 1) * a.Wo * a.resld + co);
-  const unsigned goA = (unsigned)(half * a.Wo * a.g.gxld + co), goB = (unsigned)((half ^ 1) * a.Wo * a.g.gxld + co);
-  // the reads that do not depend on the MFMAs (residual; the normalised tensor of the norm-backward form) are requested at the start
-  // of the step that runs the epilogue: 16 + 16 dword loads in flight under that step's MFMAs
-  struct Side { float rs[16], gx[16]; };
-  auto side_loads = [&](Side& sd, int z) {
-    const size_t v0 = vrow0 + (size_t)z * oplane;             // wave-uniform
-    if constexpr (FUSE == 2) {
-      const float* gb = a.g.gx + v0 * a.g.gxld;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sd.gx[r] = (gb + (size_t)r * a.g.gxld)[((0x6 >> (r >> 2)) & 1) ? goB : goA];
-    }
-    if (a.res) {                                             // workgroup-uniform
-      const float* rb = a.res + v0 * a.resld;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sd.rs[r] = (rb + (size_t)r * a.resld)[((0x6 >> (r >> 2)) & 1) ? roB : roA];
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sd.rs[r] = 0.f;
-    }
-  };
-  auto epilogue_value = [&](const f32x16& acc, const Side& sd, float* yb, int r) {      // yb: wave-uniform base of the plane
-    const float v = (acc[r] + bs + sd.rs[r]) * cs;
-    (yb + (size_t)r * a.yld)[((0x6 >> (r >> 2)) & 1) ? yoB : yoA] = v;
-    if constexpr (FUSE == 1) {
-      if (first && r == 0) K0 = v;
-      const float t = v - K0;
-      s0 += t; s1 += t * t;
-    } else if constexpr (FUSE == 2) {
-      const float xv = sd.gx[r];
-      const float u = xv * gsc + gsh;
-      const float du = u > 0.f ? v : v * a.g.gslope;
-      s0 += du; s1 += du * ((xv - gmean) * grstd);
-    }
-  };
-  auto epilogue = [&](const f32x16& acc, const Side& sd, int z) {
-    float* yb = a.y + (vrow0 + (size_t)z * oplane) * a.yld;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) epilogue_value(acc, sd, yb, r);
-    first = false;
-  };
-
-  // ---- prologue: planes zb - 1, zb, zb + 1 into ring slots 0, 1, 2 (plane q of this range lives in slot (q - zb + 1) & 3); plane
-  //      zb + 2 requested ----
-  float4 ldA[UP][2], ldB[UP][2];
-  loads(ldA, zb - 1);
-  loads(ldB, zb);
-  commit(ldA, zb - 1, std::integral_constant<int, 0>());
-  loads(ldA, zb + 1);
-  commit(ldB, zb, std::integral_constant<int, 1>());
-  loads(ldB, zb + 2);
-  commit(ldA, zb + 1, std::integral_constant<int, 2>());
-  __syncthreads();
-
-  f32x16 accE, accO;                                         // output planes at even / odd distance from zb
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { accE[r] = 0.f; accO[r] = 0.f; }
-  // One output plane. R = (z - zb) & 3: its input planes z - 1, z, z + 1 sit in slots R, R + 1, R + 2 (mod 4), plane z + 2 (in the
-  // register set `cur`) is written to slot R + 3, plane z + 3 is requested into `nxt`; `acc` takes plane z while the epilogue of plane
-  // z - 1 (in `prev`) rides along.
-  auto step = [&](int z, auto rc, auto hpc, float4 (&cur)[UP][2], float4 (&nxt)[UP][2], f32x16& acc, const f32x16& prev) {
-    constexpr int R = decltype(rc)::value;
-    constexpr bool HASPREV = decltype(hpc)::value;           // all but the first plane of the range
-    loads(nxt, z + 3);
-    Side sd;
-    if constexpr (HASPREV) side_loads(sd, z - 1);
-    const bool pin = z + 2 >= 0 && z + 2 < a.Di;             // plane z + 2 (in `cur`) exists; workgroup-uniform
-    float* yb = a.y + (vrow0 + (size_t)(z - 1) * oplane) * a.yld;
-    SCHED_BARRIER();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // A fragments: a ring of 4, requested three MFMAs ahead. After MFMA i one PIECE of the other work of the step is issued, pinned in
-    // place (one wave per SIMD: whatever is not between two MFMAs idles the matrix pipe): pieces 0..23 convert one staged element of
-    // plane z + 2 each, 24..26 pack and write its three units, 27..42 are the 16 output values of plane z - 1.
-    auto afrag = [&](int i) {
-      const int tap = i / J, j = i % J;
-      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-      return lds[abase + ((R + dz) & 3) * PLANE + (dy * HX + dx) * VSQ + 2 * j];
-    };
-    uint4 af[4];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) af[i] = afrag(i);
-    float cv[UP][8];
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
-      if (i + 3 < NM) af[(i + 3) & 3] = afrag(i + 3);
-      acc = mfma_lp<F16>(af[i & 3], __builtin_bit_cast(uint4, bw[i]), acc);
-      if (i < 8 * UP) cv[i / 8][i % 8] = conv_elem(cur, i / 8, i % 8, pin);
-      else if (i < 8 * UP + UP) store_unit(cv[i - 8 * UP], i - 8 * UP, std::integral_constant<int, (R + 3) & 3>());
-      else if (HASPREV && i < 9 * UP + 16) epilogue_value(prev, sd, yb, i - 9 * UP);
-      SCHED_BARRIER();
-    }
-    if constexpr (HASPREV) first = false;
-    __syncthreads();
-  };
-  // first plane of the range (slot phase R = 0, no previous plane), then the rest with the phase cycling 1, 2, 3, 0
-  step(zb, std::integral_constant<int, 0>(), std::false_type(), ldB, ldA, accE, accO);
-  for (int z = zb + 1; z < ze; z += 4) {
-    step(z, std::integral_constant<int, 1>(), std::true_type(), ldA, ldB, accO, accE);
-    if (z + 1 >= ze) break;
-    step(z + 1, std::integral_constant<int, 2>(), std::true_type(), ldB, ldA, accE, accO);
-    if (z + 2 >= ze) break;
-    step(z + 2, std::integral_constant<int, 3>(), std::true_type(), ldA, ldB, accO, accE);
-    if (z + 3 >= ze) break;
-    step(z + 3, std::integral_constant<int, 0>(), std::true_type(), ldB, ldA, accE, accO);
-  }
-  {                                                          // the last plane's epilogue (nothing left to hide it under)
-    Side sd;
-    side_loads(sd, ze - 1);
-    if ((ze - 1 - zb) & 1) epilogue(accO, sd, ze - 1); else epilogue(accE, sd, ze - 1);
-  }
-
-  if constexpr (FUSE != 0) {
-    constexpr int K = FUSE == 1 ? 3 : 2;
-    float vals[1][K];
-    const int cnt = (ze - zb) * 16;
-    if constexpr (FUSE == 1) {
-      const float cf = (float)cnt;
-      const float m2 = s1 - s0 * s0 / cf;
-      vals[0][0] = cf; vals[0][1] = s0 + cf * K0; vals[0][2] = m2 > 0.f ? m2 : 0.f;
-    } else {
-      vals[0][0] = s0; vals[0][1] = s1;
-    }
-    const size_t rec = (size_t)n * ((size_t)a.zsplits * a.tilesY * a.tilesX) + ((size_t)zs * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
-    float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * K;
-    gn_fuse_reduce_store<K, 1, 4, 1>(vals, lds_f, wave, 0, half, li, tid, dst, 0, a.Cout);
-  }
-}
-
-// z-range plan of conv3d_k3_lp_zring; use = 0: the call does not qualify (tile kernel). MI355_BF16_FORM: auto (default: eligible shapes
-// with enough columns to fill the chip), zring (any eligible shape: tests), tile (never: the A/B switch). Measured at the end of round 3
-// (profiles/r3_bf16_zring.txt): 32 -> 32 @128^3 0.53 -> 0.39 ms (plain), 0.54 -> 0.35 (norm + moments), bf16 step 33.7 -> 28.4 ms.
-struct LpZPlan { int tilesY, tilesX, zsplits, zper, use; };
+// channels, 32 output channels), 2: conv3d_k3_lp_zring2 (17..64 input channels, output channels in tiles of 32; ks = channel slices).
+// MI355_BF16_FORM: auto (default: zring2 on eligible shapes with enough workgroups to fill the chip), zring (zring2 on any eligible
+// shape: tests), zring1 (the round-3 kernel where it applies: the A/B switch), tile (never).
+// Measured: profiles/r3_bf16_zring.txt (zring1), profiles/r4_bf16_zring2.txt (zring2).
+struct LpZPlan { int tilesY, tilesX, zsplits, zper, use, ks, coTiles; };
 static LpZPlan plan_lp_zring(int n, int cin, int cout, int d, int h, int w, int precision, const mi355_conv_desc* desc) {
   LpZPlan p; memset(&p, 0, sizeof(p));
   const char* fe = getenv("MI355_BF16_FORM");
+  const bool v1 = fe && !strncmp(fe, "zring1", 6);
   const char form = fe && fe[0] ? fe[0] : 'a';
   if (form != 'z' && form != 'a') return p;
   if (precision != MI355_PREC_BF16 && precision != MI355_PREC_F16) return p;
-  if (cin <= 16 || cin > 32 || cout != 32 || cin % 4 || h % 8 || w % 16 || d < 1) return p;      // 17..32 input channels (two k-steps per tap), 32 output channels (no channel mask in the epilogue)
+  if (cin % 4 || h % 8 || w % 16 || d < 1) return p;
   if (desc->pad != 1 || desc->off_z || desc->off_y || desc->off_x || desc->out_d != d || desc->out_h != h || desc->out_w != w) return p;
   p.tilesY = h / 8; p.tilesX = w / 16;
   const long long cols = (long long)n * p.tilesY * p.tilesX;
-  if (form == 'a' && cols < 64) return p;                  // too few columns to fill the chip with whole-CU workgroups
-  int zsplits = (int)((256 + cols - 1) / cols);
   const char* ze = getenv("MI355_BF16_ZSPLITS");            // tests: force the number of z ranges
+  // Norm-backward sums in the epilogue (desc->gn_bwd): conv3d_k3_lp_zring2 has no such form. On 33..64 input channels the normalised
+  // tensor's 16 values per lane do not fit beside 216 weight and 96 accumulator registers (140 spills); the 32-channel instantiation
+  // compiled clean and ran correctly on the CPU emulator but faulted on the MI355X (HSA memory aperture violation on the loads of the
+  // normalised tensor; bisected with variant builds, profiles/r4_bf16_zring2.txt) and was removed. Such calls take the round-3 kernel
+  // where it applies (17..32 -> 32 channels); elsewhere the statistics query answers 0 (mi355_conv3d_bf16_stats_blocks), the sums take
+  // their own pass and the conv itself runs on zring2 with the plain epilogue.
+  const bool v1ok = cin > 16 && cin <= 32 && cout == 32;
+  if (v1 || (desc->gn_bwd && v1ok)) {
+    if (!v1ok) return p;                                     // 17..32 input channels (two k-steps per tap), 32 output channels
+    if (form == 'a' && cols < 64) return p;                  // too few columns to fill the chip with whole-CU workgroups
+    int zsplits = (int)((256 + cols - 1) / cols);
+    if (ze && atoi(ze) > 0) zsplits = atoi(ze);
+    if (zsplits > d) zsplits = d;
+    if (zsplits < 1) zsplits = 1;
+    p.zper = ceil_div(d, zsplits);
+    p.zsplits = ceil_div(d, p.zper);
+    p.use = 1; p.ks = 1; p.coTiles = 1;
+    return p;
+  }
+  if (cin <= 16 || cin > 64 || cout % 32 || d < 4) return p;
+  p.ks = cin > 32 ? 2 : 1;
+  if (p.ks == 2 && desc->in_slope) return p;                 // the channel-split form takes the scalar activation slope only
+  p.coTiles = cout / 32;
+  const long long wg = cols * p.coTiles;
+  int zsplits = (int)((256 + wg - 1) / wg);                  // one workgroup per CU: at least one wave of workgroups
   if (ze && atoi(ze) > 0) zsplits = atoi(ze);
-  if (zsplits > d) zsplits = d;
+  if (zsplits > d / 4) zsplits = d / 4;                      // every range has >= 4 planes (the head / tail steps of the kernel)
   if (zsplits < 1) zsplits = 1;
   p.zper = ceil_div(d, zsplits);
   p.zsplits = ceil_div(d, p.zper);
-  p.use = 1;
+  if (d - (p.zsplits - 1) * p.zper < 4) {                    // a short last range: fold it into even ranges of >= 4 planes
+    p.zsplits = d / 4 < p.zsplits ? d / 4 : p.zsplits - 1;
+    if (p.zsplits < 1) p.zsplits = 1;
+    p.zper = ceil_div(d, p.zsplits);
+    p.zsplits = ceil_div(d, p.zper);
+    if (d - (p.zsplits - 1) * p.zper < 4) { p.zsplits = 1; p.zper = d; }
+  }
+  if (form == 'a' && wg * p.zsplits < 96) return p;          // too few whole-CU workgroups to fill the chip
+  p.use = 2;
   return p;
 }
 
@@ -857,12 +557,39 @@ int32_t mi355_conv3d_bf16_stats_blocks(const mi355_act* x, const mi355_act* y, c
   if (!ns || d->kd != 3 || d->stride != 1 || d->out_mode != MI355_OUT_PLAIN) return 0;
   if (d->off_z || d->off_y || d->off_x || d->out_d != y->d || d->out_h != y->h || d->out_w != y->w) return 0;
   const LpZPlan zp = plan_lp_zring(x->n, x->c, y->c, y->d, y->h, y->w, d->precision, d);
-  if (zp.use && x->d == y->d && x->h == y->h && x->w == y->w) return (int32_t)((long long)zp.zsplits * zp.tilesY * zp.tilesX);
+  // plane-ring kernels: one record per (z range, column); zring2 leaves one per wave and half-wave of the column's workgroup (x 8)
+  if (zp.use && x->d == y->d && x->h == y->h && x->w == y->w) {
+    if (zp.use == 2 && d->gn_bwd) return 0;                  // zring2 has no norm-backward form (plan_lp_zring): unfused sums
+    return (int32_t)((long long)zp.zsplits * zp.tilesY * zp.tilesX * (zp.use == 2 ? 8 : 1));
+  }
   const long long vox = (long long)y->d * y->h * y->w * x->n;
   const bool big = ns < 3 && vox >= 256LL * 512;
   const int tz = big ? 4 : 2, ty = 4;
   const long long b = (long long)ceil_div(y->d, tz) * ceil_div(y->h, ty) * ceil_div(y->w, 16);
   return b > 0 && b <= 0x7fffffffLL ? (int32_t)b : 0;
+}
+
+// Trace name (as rocprofv3 prints it) of the kernel mi355_conv3d_fwd_bf16_impl launches for this call: bench.py keys its per-instantiation
+// roofline rows and the PMC traffic look-up on it (mi355_conv3d_fwd_config). Mirrors the dispatch below.
+int mi355_conv3d_bf16_kernel_name(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d, char* out, size_t n) {
+  const int ns = nsplit_of(d->precision);
+  if (!ns || !out || n < 8) return MI355_EINVAL;
+  const int fuse = d->moments_out ? 1 : (d->gn_bwd ? 2 : 0);
+  const char* f16 = d->precision == MI355_PREC_F16 ? "true" : "false";
+  const LpZPlan zp = plan_lp_zring(x->n, x->c, y->c, d->out_d, d->out_h, d->out_w, d->precision, d);
+  if (zp.use && y->d == d->out_d && y->h == d->out_h && y->w == d->out_w && x->d == d->out_d && x->h == d->out_h && x->w == d->out_w) {
+    if (zp.use == 1) snprintf(out, n, "conv3d_k3_lp_zring<2, %d, %d, %s>", d->in_mode, fuse, f16);
+    else snprintf(out, n, "conv3d_k3_lp_zring2<2, %d, %d, %d, %s>", zp.ks, d->in_mode, fuse, f16);
+    return 0;
+  }
+  const long long vox = (long long)d->out_d * d->out_h * d->out_w * x->n;
+  const int J = ns == 1 ? 2 : 1;
+  const bool big = ns < 3 && vox >= 256LL * 512, wide = y->c > 32;
+  const char* tile = big ? (wide ? "4, 4, %d, %d, 4, 1, 2, 2" : "4, 4, %d, %d, 4, 1, 2, 1") : (wide ? "2, 4, %d, %d, 2, 2, 2, 1" : "2, 4, %d, %d, 4, 1, 1, 1");
+  char t[64];
+  snprintf(t, sizeof(t), tile, J, ns);
+  snprintf(out, n, "conv3d_k3_bf16<%s, %d, %d, %s>", t, d->in_mode, fuse, f16);
+  return 0;
 }
 
 // called by mi355_conv3d_fwd (conv3d_fwd.hip) when desc->precision selects a bf16 path and the problem qualifies
@@ -900,20 +627,14 @@ int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_a
     const long long blocks = (long long)a.N * zp.zsplits * zp.tilesY * zp.tilesX;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
     const int fuse = a.g.mom ? 1 : (a.g.gnb ? 2 : 0);
-    const bool f16 = d->precision == MI355_PREC_F16, norm = d->in_mode == MI355_IN_AFFINE_ACT;
-    const int lds_bytes = 4 * 180 * 5 * 16;                   // ring of 4 planes, 180 voxels, 5 x 16 bytes per voxel (32 channels + pad)
-    const dim3 grid((unsigned)blocks), blk(256);
-#define LPZ_LAUNCH(JJ, IM, FU, HF)                                                                          \
-    do { SET_MAX_DYN_LDS((conv3d_k3_lp_zring<JJ, IM, FU, HF>), lds_bytes);                                  \
-         LAUNCH((conv3d_k3_lp_zring<JJ, IM, FU, HF>), grid, blk, lds_bytes, stream, a); } while (0)
-#define LPZ_FUSE(JJ, HF)                                                                                    \
-    do { if (fuse == 1) { if (norm) LPZ_LAUNCH(JJ, MI355_IN_AFFINE_ACT, 1, HF); else LPZ_LAUNCH(JJ, MI355_IN_PLAIN, 1, HF); } \
-         else if (fuse == 2) LPZ_LAUNCH(JJ, MI355_IN_PLAIN, 2, HF);                                         \
-         else if (norm) LPZ_LAUNCH(JJ, MI355_IN_AFFINE_ACT, 0, HF); else LPZ_LAUNCH(JJ, MI355_IN_PLAIN, 0, HF); } while (0)
-    if (f16) LPZ_FUSE(2, true); else LPZ_FUSE(2, false);
-#undef LPZ_FUSE
-#undef LPZ_LAUNCH
-    return LAUNCH_CHECK();
+    const bool f16 = d->precision == MI355_PREC_F16;
+    if (zp.use == 2) {
+      a.coTiles = zp.coTiles;
+      const long long wgs = blocks * zp.coTiles;
+      if (wgs > 0x7fffffffLL) return MI355_EINVAL;
+      return mi355_lp_zring2_launch(a, zp.ks, d->in_mode, fuse, f16, wgs, stream);
+    }
+    return mi355_lp_zring_launch(a, d->in_mode, fuse, f16, blocks, stream);
   }
   if (d->precision == MI355_PREC_F16) return dispatch_ns<1, true>(a, d->in_mode, vox, stream);
   if (ns == 1) return dispatch_ns<1>(a, d->in_mode, vox, stream);

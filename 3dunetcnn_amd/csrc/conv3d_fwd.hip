@@ -755,6 +755,7 @@ static bool stats_fusable(const mi355_act* x, const mi355_act* y, const mi355_co
 }
 
 int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream);
+int mi355_conv3d_bf16_kernel_name(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d, char* out, size_t n);
 int32_t mi355_conv3d_bf16_stats_blocks(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d);
 int mi355_conv3d_c4_ok(const mi355_act* x, const mi355_conv_desc* d);
 int mi355_conv3d_c4_fwd_impl(const mi355_act* x, const float* w, const mi355_act* y, const mi355_conv_desc* d, void* stream);
@@ -883,6 +884,7 @@ extern "C" int mi355_conv3d_fwd_config(const mi355_act* x, const mi355_act* y, c
     snprintf(out, n, "conv3d_c4_dgrad");
     return 0;
   }
+  if (d->wformat == MI355_W_PACKED && mi355_conv3d_uses_bf16(d)) return mi355_conv3d_bf16_kernel_name(x, y, d, out, n);
   const int cfg = select_cfg(d->kd, d->stride, (long long)d->out_d * d->out_h * d->out_w * x->n,
                              (d->kd == 1 && d->out_mode == MI355_OUT_D2S) ? 8 * y->c : y->c, d->in_mode);
   const int stride_t = d->in_mode == MI355_IN_ZERO_INSERT ? 1 : d->stride;

@@ -26,6 +26,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // keep a value in the accumulation half of the register file from here on (an MFMA reads its A / B operands from AGPRs directly; without
 // the pin hipcc parks such values there as spill space and copies them back with v_accvgpr_read before every use)
 #define PIN_IN_AGPR(v) asm volatile("" : "+a"(v))
+// ... and in the architectural half: accumulators of a kernel whose AGPRs are full of pinned operands (left to itself hipcc may put the
+// MFMA results there too and then spills the operands)
+#define PIN_IN_VGPR(v) asm volatile("" : "+v"(v))
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+0..7] and B[k=8*(l>>5)+0..7][j=l&31] as 8 packed bf16
 // (16 bytes, carried here as uint4); same C/D map as the f32 form. 32 cycles per SIMD = 16x the f32 MFMA rate.
@@ -80,6 +83,12 @@ __device__ __forceinline__ pkf2 pk_fma(pkf2 a, pkf2 b, pkf2 c) { return __builti
 #define MI355_EWORKSPACE (-4)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// f(integral_constant<int, I>) for I = B .. N - 1, unrolled at compile time (C++17: no templated lambdas)
+#include <type_traits>
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>()); static_for<I + 1, N>(f); }
+}
 
 // 16-bit operand type of the matrix pipe: bf16 (the split-operand modes and MI355_PREC_BF16) or fp16 (MI355_PREC_F16)
 template <bool F16> __device__ __forceinline__ unsigned pack_lp2(float lo, float hi) { return F16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }

@@ -286,7 +286,13 @@ class Backend:
         y.mom = None
         gparts = None
         if self.fused_stats and (moments or gnb is not None):
+            if gnb is not None and not moments:
+                # the query is for the norm-backward sums (a kernel may carry the moments epilogue but not this one): a placeholder
+                # marks the request, the real descriptor replaces it below
+                probe = MiGnBwdFuse()
+                d.gn_bwd = ctypes.pointer(probe)
             nb = self.lib.mi355_conv3d_stats_blocks(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d))
+            d.gn_bwd = None
             if nb > 0 and moments:
                 rec = torch.empty(x.shape[0], nb, y.c, 3, dtype=torch.float32, device=self.device)
                 d.moments_out = rec.data_ptr()
@@ -309,11 +315,10 @@ class Backend:
         if d.wformat == W_OIDHW4:
             name.value = b"conv3d_c4_fwd"
         elif d.wformat == W_PACKED and self.lib.mi355_conv3d_uses_bf16(ctypes.byref(d)):
-            # the 16-bit single-product modes have two kernels: the plane-ring (z-marching, weights-stationary) form for the shapes it
-            # takes and the tile form for the rest; a layer's record count tells them apart (ring: zsplits * columns)
+            # one family, several kernels: the tile forms and (16-bit single-product modes, eligible shapes) the plane-ring form;
+            # mi355_conv3d_fwd_config names the instantiation this call launches exactly as a rocprofv3 trace prints it
+            variant = name.value.decode()
             name.value = b"conv3d_k3_bf16<...>"
-            fuse = 1 if d.moments_out else (2 if d.gn_bwd else 0)
-            variant = f"lp16 in{in_mode} fuse{fuse} {x.c}->{y.c}"
         nvox = x.shape[0] * out_dhw[0] * out_dhw[1] * out_dhw[2]
         flops = 2.0 * nvox * x.c * y.c * kd ** 3 * (8 if (in_mode == IN_S2D or out_mode == OUT_D2S) else 1)
         if in_mode == IN_ZERO_INSERT:

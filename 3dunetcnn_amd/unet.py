@@ -333,6 +333,11 @@ class HipUNet3D(HipNetBase):
         if s.chscale is not None:
             be.chscale(d_out, s.chscale, d_out)
         st1, st2 = s.st1, s.st2
+        # Weight gradients go to the side stream (engine._wgrad_stream), each forked BEFORE the data gradient conv that follows it in
+        # program order. Measured and rejected in round 4 (profiles/r4_ab_experiments.txt): forking it AFTER that conv, so that the side
+        # stream runs one matrix-bound kernel behind and the HBM-bound norm-backward kernels find a weight gradient in flight beside
+        # them: 55.64 -> 56.27 ms per fp32 step, bf16 / C3 unchanged (the two streams' matrix-bound kernels share the CUs either way and
+        # the lagging stream drains alone at the end of backward).
         with self._wgrad_stream(be, s.h1, d_out, st2[1], st2[2]):
             be.conv_wgrad(s.h1, d_out, self._gslice(c2.conv.weight), 3, 1, in_mode=IN_AFFINE_ACT, scale=st2[1], shift=st2[2])
         dA2 = be.empty_act(n, d, h, w, cout)

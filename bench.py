@@ -463,21 +463,20 @@ def main():
         hbm_frac = hbm_gbps / HBM_PEAK_GBPS
         # HBM traffic of the SAME launches: call-weighted over every instantiation of the family in the PMC summary of this command
         rows, traffic_src = pmc_rows(args.config, args.precision)
-        traffic, inst_rows = None, []
+        traffic, inst_rows, hit = None, [], []
         if rows is not None:
             traffic, hit = family_traffic(rows, name)
-            for (fam, variant), v in sorted(inst.items(), key=lambda kv: -kv[1][0]):
-                if fam != name:
-                    continue
-                row = {"kernel": variant, "launches_per_step": v[3] // roof_steps, "avg_launch_ms": round(v[0] / v[3] * 1e3, 4),
-                       "algorithmic_bytes_per_launch": round((v[2] + v[4]) / v[3]), "of_which_fused_reads": round(v[4] / v[3])}
-                m = [(k, c, t) for k, c, t in hit if variant in k]
-                if len(m) == 1:
-                    row["traffic_bytes_per_launch"] = round(m[0][2])
-                    row["traffic_over_algorithmic"] = round(m[0][2] / ((v[2] + v[4]) / v[3]), 3)
-                inst_rows.append(row)
-            if not any("traffic_bytes_per_launch" in r for r in inst_rows):
-                inst_rows = [{"kernel": k, "calls_in_pmc_run": c, "traffic_bytes_per_launch": round(t)} for k, c, t in hit]
+        for (fam, variant), v in sorted(inst.items(), key=lambda kv: -kv[1][0]):
+            if fam != name:
+                continue
+            row = {"kernel": variant, "launches_per_step": v[3] // roof_steps, "avg_launch_ms": round(v[0] / v[3] * 1e3, 4),
+                   "algorithmic_tflops": round(v[1] / v[0] / 1e12, 1),
+                   "algorithmic_bytes_per_launch": round((v[2] + v[4]) / v[3]), "of_which_fused_reads": round(v[4] / v[3])}
+            m = [(k, c, t) for k, c, t in hit if variant in k]
+            if len(m) == 1:
+                row["traffic_bytes_per_launch"] = round(m[0][2])
+                row["traffic_over_algorithmic"] = round(m[0][2] / ((v[2] + v[4]) / v[3]), 3)
+            inst_rows.append(row)
         # the binding roofline: the one that needs MORE time for this launch mix. `achieved` / `peak` / `frac` are quoted on it; both
         # fractions are always reported (mfma_pipe_frac, hbm_frac)
         bound = "hbm" if hbm_frac > mfma_frac else "mfma"

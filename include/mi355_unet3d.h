@@ -162,7 +162,9 @@ int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355_act* y, co
 
 /* Number of spatial tiles per sample (B) that mi355_conv3d_fwd will write partial statistics for (desc->moments_out /
  * desc->gn_bwd->partials_out), or 0 when this call cannot fuse them (windowed / depth-to-space outputs, the narrow kernel):
- * the caller then runs mi355_gn_stats / the unfused mi355_gn_act_bwd instead. */
+ * the caller then runs mi355_gn_stats / the unfused mi355_gn_act_bwd instead. A non-NULL desc->gn_bwd (its fields are not read) asks
+ * for the norm-backward sums specifically: a kernel may carry the moments epilogue but not that one (the 16-bit plane-ring kernel on
+ * 33..64 input channels). */
 int32_t mi355_conv3d_stats_blocks(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* desc);
 
 /* Writes the (demangled) name of the kernel instantiation mi355_conv3d_fwd launches for this problem, e.g.

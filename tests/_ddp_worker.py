@@ -73,6 +73,55 @@ def main(out_dir, device="cpu", mode="step"):
         torch.save(rec, os.path.join(out_dir, f"rank{rank}.pt"))
         dist.destroy_process_group()
         return
+    if mode == "mix4":
+        # world size 4, the forms of the exchange one after the other on the same reducer, with the ranks SKEWED in time (rank r sleeps
+        # before it reports gradients: collectives are launched at different moments on different ranks, buckets complete unevenly):
+        #   A eager bucketed step -> every bucket launched from inside backward, exactly once
+        #   B gradient accumulation: no_sync() micro-batch + closing micro-batch -> no bucket launch, one flat all-reduce of the sum
+        #   C graphed step (uncaptured on the CPU emulator) -> callbacks detached, one flat all-reduce, callbacks restored
+        #   D eager bucketed step again -> the per-bucket path is intact after B and C
+        import time
+        graph = importlib.import_module("3dunetcnn_amd.graph")
+        inner = red._on_ready
+
+        def skewed(params):
+            time.sleep(0.01 * ((rank * 7) % 4))              # 0, 30, 20, 10 ms: no two ranks in step
+            inner(params)
+        m.grad_ready_callback = skewed
+        rec["launched"] = []
+
+        def eager():
+            opt.zero_grad(set_to_none=True)
+            loss = crit(m(x), y)
+            loss.backward()
+            rec["launched"].append((red.n_launched, len(red.buckets)))
+            g = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+            opt.step()
+            m.mark_parameters_updated()
+            return float(loss), g
+        l0, rec["grads"] = eager()                           # A
+        rec["losses"].append(l0)
+        rec["n_buckets"] = len(red.buckets)
+        x2, y2 = R.synthetic_case(1, 4, (16, 16, 16), 3, seed=rank + 10)
+        opt.zero_grad(set_to_none=True)                      # B
+        with red.no_sync():
+            crit(m(x), y).backward()
+            rec["launched"].append((red.n_launched, 0))
+        crit(m(x2), y2).backward()
+        rec["launched"].append((red.n_launched, 0))
+        rec["grads_accum"] = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+        rec["sd_before_accum_step"] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        opt.step()
+        m.mark_parameters_updated()
+        stepper = graph.HipGraphedTrainStep(m, crit, opt, x, y, capture=False)      # C
+        stepper(x, y)
+        m.mark_parameters_updated()
+        assert m.grad_ready_callback is skewed and m.grad_sync_callback is not None
+        eager()                                              # D
+        rec["sd2"] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        torch.save(rec, os.path.join(out_dir, f"rank{rank}.pt"))
+        dist.destroy_process_group()
+        return
     if mode == "graphstep":
         # HipGraphedTrainStep with the reducer attached (graph.py): forward / backward without the per-bucket callbacks, ONE all-reduce
         # of the flat gradient buffer, Adam. Captured as a HIP graph on the GPU; uncaptured (the same host logic) on the CPU emulator.

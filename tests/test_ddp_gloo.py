@@ -33,17 +33,17 @@ def test_two_rank_bucketed_allreduce_on_hip_kernels(tmp_path, hip_backend):
     _two_rank_step(tmp_path, "cuda")
 
 
-def _run_workers(tmp_path, device, mode="step"):
+def _run_workers(tmp_path, device, mode="step", world=2):
     port = _free_port()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ddp_worker.py"), str(tmp_path), device, mode], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    return [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
+    return [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
 
 
 def test_two_rank_gradient_accumulation_with_no_sync(tmp_path, emu_backend):
@@ -109,6 +109,42 @@ def _two_rank_step(tmp_path, device, mode="step"):
     for k in recs[0]["sd2"]:
         assert torch.equal(recs[0]["sd2"][k], recs[1]["sd2"][k]), k
         assert not torch.equal(recs[0]["sd2"][k], recs[0]["sd0"][k]) or recs[0]["sd0"][k].numel() == 0, k
+
+
+def test_four_ranks_mixed_exchange_forms_with_skewed_ranks(tmp_path, emu_backend):
+    """World size 4 (toward the 8-rank node, unet3d/models/build.py:18-20): on ONE reducer per rank, an eager bucketed step, a
+    no_sync() accumulation closed by a synced micro-batch, a graphed step and another eager step, with the ranks skewed in time so
+    that their collectives are launched at different moments. Every eager backward launches each bucket exactly once, the accumulation
+    and the graphed step launch none (one flat all-reduce instead), the averaged gradients are the mean over the FOUR ranks' oracle
+    gradients, and after the four optimizer steps all ranks hold bit-identical weights."""
+    recs = _run_workers(tmp_path, "cpu", "mix4", world=4)
+    nb = recs[0]["n_buckets"]
+    assert nb >= 3
+    for r in range(4):
+        # A: (launched, buckets); B: two backwards without a bucket launch; D: all buckets again
+        assert recs[r]["launched"] == [(nb, nb), (0, 0), (0, 0), (nb, nb)], (r, recs[r]["launched"])
+        for k in recs[0]["sd0"]:
+            assert torch.equal(recs[0]["sd0"][k], recs[r]["sd0"][k]), k
+    want, want_acc = None, None
+    for r in range(4):
+        sd = {k: v.clone().requires_grad_(True) for k, v in recs[0]["sd0"].items()}
+        x, y = R.synthetic_case(1, 4, (16, 16, 16), 3, seed=r)
+        O.dice_loss(R.unet3d_forward(sd, x, (1, 1, 1)), y).backward()
+        g = {k: v.grad / 4 for k, v in sd.items()}
+        want = g if want is None else {k: want[k] + g[k] for k in g}
+        sda = {k: v.clone().requires_grad_(True) for k, v in recs[0]["sd_before_accum_step"].items()}
+        for seed in (r, r + 10):
+            x, y = R.synthetic_case(1, 4, (16, 16, 16), 3, seed=seed)
+            O.dice_loss(R.unet3d_forward(sda, x, (1, 1, 1)), y).backward()
+        ga = {k: v.grad / 4 for k, v in sda.items()}
+        want_acc = ga if want_acc is None else {k: want_acc[k] + ga[k] for k in ga}
+    for r in range(4):
+        for k in want:
+            assert C.rel_err(recs[r]["grads"][k], want[k]) < 1e-3, (r, k)
+            assert C.rel_err(recs[r]["grads_accum"][k], want_acc[k]) < 2e-3, (r, k)
+        for k in recs[0]["sd2"]:
+            assert torch.equal(recs[0]["sd2"][k], recs[r]["sd2"][k]), (r, k)
+            assert torch.equal(recs[0]["sd_before_accum_step"][k], recs[r]["sd_before_accum_step"][k]), (r, k)
 
 
 def test_bucket_layout_default_model():

@@ -32,7 +32,7 @@ BOUNDS = {"conv_fwd": 1e-5, "conv_d2s": 1e-5, "conv_wgrad": 1e-5, "gn_stats": 1e
           "conv_fwd_lp": 1e-5, "conv_wgrad_lp": 1e-5, "conv_fwd_x3": 1e-4, "conv_wgrad_x3": 1e-4, "conv_fwd_x6": 1e-5, "conv_wgrad_x6": 1e-5}
 
 
-def _step(be, model, x, y, dev, keep=None, **akw):
+def _step(be, model, x, y, dev, keep=None, loss_scale=1.0, **akw):
     crit = losses.HipDiceLoss(sigmoid=True)
     opt = optim.HipAdam(model.parameters(), lr=1e-3)
     model._be = crit._be = opt._be = be
@@ -43,7 +43,12 @@ def _step(be, model, x, y, dev, keep=None, **akw):
         if keep is not None:
             keep["logits"] = out.detach().cpu()
             keep["state_dict"] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}      # before the optimizer step
-        loss.backward()
+        if loss_scale != 1.0:
+            # the reference's `training.amp` path (train/training_utils.py:60-69): GradScaler scales the loss, the optimizer unscales
+            (loss * loss_scale).backward()
+            opt.grad_scale = 1.0 / loss_scale
+        else:
+            loss.backward()
         opt.step()
     return au, float(loss.detach())
 
@@ -235,6 +240,9 @@ def test_audit_16bit_train_step_gpu(hip_backend, mode):
     torch.manual_seed(7)
     m = unet.HipAutocastUNet(n_features=4, n_outputs=3, autocast_dtype=mode).cuda().train()
     x, y = R.synthetic_case(2, 4, (64, 64, 64), 3)
-    au, loss = _step(hip_backend, m, x, y, "cuda")
+    # fp16 is trained with a loss scale, as the reference does (GradScaler, initial scale 2^16): unscaled, the Dice gradients (1e-6 ..
+    # 1e-9) sit in fp16's SUBNORMAL range, where the matrix pipe and tensor.half() need not agree (measured on MI355X without the
+    # scale: dgrad launches 1.2e-5 instead of 1.4e-6 -- operands of a few subnormal bits). bf16 has fp32's range: no scale.
+    au, loss = _step(hip_backend, m, x, y, "cuda", loss_scale=65536.0 if mode == "fp16" else 1.0)
     assert 0.0 < loss < 1.0
     _check(au, {"conv_fwd_lp": 51, "conv_wgrad_lp": 25, "gn_act_bwd": 26, "gn_stats": 26})

@@ -1,5 +1,7 @@
 """Kernel-logic parity on CPU: the SAME kernel sources compiled against tools/emu (fibers + fmaf-chain MFMA) vs the
 torch-CPU oracle. Small shapes only; the real parity gate is test_ops_gpu.py (-m gpu)."""
+import os
+
 import pytest
 import torch
 
@@ -317,11 +319,14 @@ def test_norm_backward_sums_from_dgrad_epilogue_bf16_paths(prec_backend, kw):
     assert all(v < 2e-5 for v in r.values()), r
 
 
-# ---- opt-in plane-ring form of the 16-bit forward / dgrad kernel (conv3d_k3_lp_zring, MI355_BF16_FORM=zring): 17..32 input channels,
-#      32 output channels, H % 8 == 0, W % 16 == 0 ----
-@pytest.fixture(params=[("bf16", ""), ("fp16", ""), ("bf16", "2"), ("bf16", "5")], ids=["bf16", "fp16", "bf16-two-z-ranges", "bf16-five-z-ranges"])
+# ---- plane-ring forms of the 16-bit forward / dgrad kernel (csrc/conv3d_bf16.hip). MI355_BF16_FORM=zring: conv3d_k3_lp_zring2 (round 4:
+#      input-plane-major, three output planes in flight, 17..64 input channels split over wave pairs above 32, output channels in tiles
+#      of 32, >= 4 planes per z range); =zring1: conv3d_k3_lp_zring (round 3: 17..32 -> 32 channels). H % 8 == 0, W % 16 == 0. Shapes a
+#      form does not take fall back to the tile kernel (the tolerance holds either way; the routing tests below pin which kernel ran). ----
+@pytest.fixture(params=[("bf16", "", "zring"), ("fp16", "", "zring"), ("bf16", "2", "zring"), ("bf16", "5", "zring"), ("bf16", "", "zring1"), ("bf16", "2", "zring1")],
+                ids=["bf16", "fp16", "bf16-two-z-ranges", "bf16-five-z-ranges", "v1-bf16", "v1-bf16-two-z-ranges"])
 def zring_backend(emu_backend, request, monkeypatch):
-    monkeypatch.setenv("MI355_BF16_FORM", "zring")
+    monkeypatch.setenv("MI355_BF16_FORM", request.param[2])
     monkeypatch.setenv("MI355_BF16_ZSPLITS", request.param[1])
     emu_backend.set_precision(request.param[0])
     yield emu_backend, BF16_TOL[request.param[0]]
@@ -331,67 +336,91 @@ def zring_backend(emu_backend, request, monkeypatch):
 @pytest.mark.parametrize("kw", [
     dict(n=1, cin=32, cout=32, dhw=(5, 8, 16), norm=True, residual=True, chscale=True),      # one column, every epilogue operand
     dict(n=2, cin=24, cout=32, dhw=(6, 16, 32), bias=True),                                  # 8 columns, padded input channels
-    dict(n=1, cin=32, cout=32, dhw=(1, 8, 16)),                                              # a single plane
-    dict(n=1, cin=20, cout=32, dhw=(9, 8, 32), norm=True, slope=0.01, yld=64, yc0=32),        # concat slice, leaky slope, 9 planes (ring wraps twice)
+    dict(n=1, cin=32, cout=32, dhw=(1, 8, 16)),                                              # a single plane (zring2: tile kernel)
+    dict(n=1, cin=20, cout=32, dhw=(9, 8, 32), norm=True, slope=0.01, yld=64, yc0=32),        # concat slice, leaky slope, 9 planes (two ranges: 5 + 4)
+    dict(n=1, cin=32, cout=32, dhw=(4, 8, 16), norm=True),                                   # the shortest range: head + tail steps only
+    dict(n=1, cin=32, cout=32, dhw=(22, 8, 16), residual=True),                              # every rotation of the three accumulator sets, 5 ranges of 5 / 4 / 4 ...
+    dict(n=1, cin=64, cout=32, dhw=(6, 8, 16), norm=True, residual=True, chscale=True),      # channel split over wave pairs (KS = 2): the partial-tile exchange
+    dict(n=2, cin=64, cout=64, dhw=(8, 16, 16), norm=True, bias=True),                       # two output-channel tiles per column
+    dict(n=1, cin=48, cout=96, dhw=(7, 8, 32), slope=0.01, norm=True, yld=128, yc0=32),       # padded second channel slice (48 of 64), three channel tiles
+    dict(n=1, cin=32, cout=64, dhw=(5, 16, 16), residual=True),                              # KS = 1 with two channel tiles
 ])
 def test_conv_fwd_zring_form(zring_backend, kw):
     be, tol = zring_backend
     assert C.case_conv_fwd(be, **kw) < tol
 
 
-def test_conv_dgrad_zring_form(zring_backend):
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(6, 8, 16)), dict(n=1, cin=32, cout=64, dhw=(6, 8, 16)), dict(n=2, cin=64, cout=64, dhw=(5, 8, 32))])
+def test_conv_dgrad_zring_form(zring_backend, kw):
     be, tol = zring_backend
-    assert C.case_conv_dgrad(be, n=1, cin=32, cout=32, dhw=(6, 8, 16)) < tol
+    assert C.case_conv_dgrad(be, **kw) < tol
 
 
-@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(5, 8, 16), residual=True, chscale=True), dict(n=2, cin=32, cout=32, dhw=(4, 16, 16))])
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(5, 8, 16), residual=True, chscale=True), dict(n=2, cin=32, cout=32, dhw=(4, 16, 16)),
+                                dict(n=1, cin=64, cout=64, dhw=(9, 8, 16), residual=True)])
 def test_conv_epilogue_moments_zring_form(zring_backend, kw):
     be, tol = zring_backend
     assert C.case_conv_moments(be, ytol=tol, strict_vs_oracle=False, **kw) < 2e-5
 
 
-def test_norm_backward_sums_zring_form(zring_backend):
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(5, 8, 16)), dict(n=1, cin=64, cout=32, dhw=(6, 8, 16)), dict(n=1, cin=32, cout=64, dhw=(4, 8, 16))])
+def test_norm_backward_sums_zring_form(zring_backend, kw):
     be, tol = zring_backend
-    r = C.case_gn_bwd_fused(be, compare_unfused=True, n=1, cin=32, cout=32, dhw=(5, 8, 16))
+    # zring2 has no norm-backward epilogue (csrc/conv3d_bf16.hip: plan_lp_zring): a dgrad with 17..32 input and 32 output channels (the
+    # forward layer's cout / cin) takes the round-3 kernel and fuses the sums; any other shape answers the statistics query with 0 -- the
+    # sums take their own pass while the conv itself still runs on the plane-ring kernel
+    fused = os.environ["MI355_BF16_FORM"] != "zring" or (16 < kw["cout"] <= 32 and kw["cin"] == 32)
+    r = C.case_gn_bwd_fused(be, compare_unfused=True, expect_fused=fused, **kw)
     assert all(v < 2e-5 for v in r.values()), r
 
 
-def test_zring_form_default_routing(emu_backend, monkeypatch):
-    """Without the switch (default `auto`) an eligible 16-bit layer with >= 64 columns takes the plane-ring kernel -- here 64 columns of
-    3 planes in 3 z ranges of one plane each (a range shorter than the ring) -- and a layer with fewer columns keeps the tile kernel."""
+def _stats_blocks(be, n, dd, h, w, cin, cout):
     import ctypes
+    d = C.ops._lib.MiConvDesc(); d.kd, d.stride, d.pad, d.precision = 3, 1, 1, be.precision
+    x = be.empty_act(n, dd, h, w, cin); y = be.empty_act(n, dd, h, w, cout)
+    xd, yd = x.desc(), y.desc()
+    d.out_d, d.out_h, d.out_w = dd, h, w
+    return be.lib.mi355_conv3d_stats_blocks(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d))
+
+
+def test_zring_form_default_routing(emu_backend, monkeypatch):
+    """Without the switch (default `auto`) an eligible 16-bit layer with enough whole-CU workgroups takes the plane-ring kernel -- 64
+    columns x 2 z ranges of 4 planes -- and a layer with fewer workgroups, or fewer than 4 planes, keeps the tile kernel. The kernel
+    that ran is identified by its statistics records: eight (one per wave and half-wave) per (z range, column) against one per
+    2 x 4 x 16 tile."""
     monkeypatch.delenv("MI355_BF16_FORM", raising=False)
     monkeypatch.delenv("MI355_BF16_ZSPLITS", raising=False)
     be = emu_backend
     be.set_precision("bf16")
     try:
-        assert C.case_conv_fwd(be, n=2, cin=32, cout=32, dhw=(3, 32, 128), norm=True, residual=True) < BF16_TOL["bf16"]
-        d = C.ops._lib.MiConvDesc(); d.kd, d.stride, d.pad, d.precision = 3, 1, 1, be.precision
-        for (n, dd, h, w), want in (((2, 3, 32, 128), 3 * 4 * 8), ((1, 4, 8, 16), 2 * 2 * 1)):      # zring records | 2x4x16 tiles of the tile kernel
-            x = be.empty_act(n, dd, h, w, 32); y = be.empty_act(n, dd, h, w, 32)
-            xd, yd = x.desc(), y.desc()
-            d.out_d, d.out_h, d.out_w = dd, h, w
-            assert be.lib.mi355_conv3d_stats_blocks(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d)) == want
+        assert C.case_conv_fwd(be, n=2, cin=32, cout=32, dhw=(8, 32, 128), norm=True, residual=True) < BF16_TOL["bf16"]
+        for (n, dd, h, w, cin, cout), want in (((2, 8, 32, 128, 32, 32), 2 * 4 * 8 * 8),    # plane ring: 2 z ranges x 32 columns per sample x 8 (wave, half-wave)
+                                               ((2, 8, 32, 128, 64, 64), 2 * 4 * 8 * 8),    # the same with two channel tiles (records are per channel)
+                                               ((1, 4, 8, 16, 32, 32), 2 * 2 * 1),          # 1 column: 2 x 4 x 16 tiles of the tile kernel
+                                               ((2, 3, 32, 128, 32, 32), 2 * 8 * 8)):       # 3 planes: tile kernel
+            assert _stats_blocks(be, n, dd, h, w, cin, cout) == want, (n, dd, h, w, cin, cout)
     finally:
         be.set_precision("fp32")
 
 
 def test_zring_form_is_what_ran(emu_backend, monkeypatch):
     """The switch routes an eligible call to the plane-ring kernel (its statistics records are per (z range, column), not per tile):
-    guards the tests above against silently exercising the tile kernel."""
-    import ctypes
+    guards the tests above against silently exercising the tile kernel. 64-channel layers: zring2 only."""
     be = emu_backend
     be.set_precision("bf16")
     try:
-        x = be.empty_act(1, 8, 8, 16, 32); y = be.empty_act(1, 8, 8, 16, 32)
-        xd, yd = x.desc(), y.desc()
-        d = C.ops._lib.MiConvDesc(); d.kd, d.stride, d.pad, d.precision = 3, 1, 1, be.precision
-        d.out_d, d.out_h, d.out_w = 8, 8, 16
         monkeypatch.setenv("MI355_BF16_FORM", "tile")
-        tile_blocks = be.lib.mi355_conv3d_stats_blocks(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d))
-        monkeypatch.setenv("MI355_BF16_FORM", "zring")
+        tile_blocks = _stats_blocks(be, 1, 8, 8, 16, 32, 32)
+        tile_blocks64 = _stats_blocks(be, 1, 8, 8, 16, 64, 64)
         monkeypatch.setenv("MI355_BF16_ZSPLITS", "2")
-        assert be.lib.mi355_conv3d_stats_blocks(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d)) == 2 != tile_blocks
+        monkeypatch.setenv("MI355_BF16_FORM", "zring")
+        assert _stats_blocks(be, 1, 8, 8, 16, 32, 32) == 2 * 8 != tile_blocks   # zring2: 8 records per (z range, column)
+        assert _stats_blocks(be, 1, 8, 8, 16, 64, 64) == 2 * 8 != tile_blocks64
+        assert _stats_blocks(be, 1, 9, 8, 16, 48, 96) == 2 * 8                  # 5 + 4 planes
+        assert _stats_blocks(be, 1, 7, 8, 16, 32, 32) == 1 * 8                  # 7 planes cannot make two ranges of >= 4
+        monkeypatch.setenv("MI355_BF16_FORM", "zring1")
+        assert _stats_blocks(be, 1, 8, 8, 16, 32, 32) == 2
+        assert _stats_blocks(be, 1, 8, 8, 16, 64, 64) == tile_blocks64          # the round-3 kernel does not take 64 channels
     finally:
         be.set_precision("fp32")
 
@@ -458,8 +487,10 @@ def test_batched_repack_equals_single_packs(emu_backend):
     for a, b in zip(packs, fresh):
         assert torch.equal(a._f32, b.f32())
     assert torch.equal(packs[0]._wino, fresh[0].wino()) and torch.equal(packs[1]._wino, fresh[1].wino())
-    key = be._pack_table_key
-    assert be.repack_batch(packs) == 7 and be._pack_table_key is key      # the device table is reused
+    table = be.last_pack_table
+    assert be.repack_batch(packs) == 7 and be.last_pack_table is table    # the device table is reused
+    own = {}
+    assert be.repack_batch(packs, own) == 7 and len(own) == 1 and be.last_pack_table is not table      # a caller's own cache gets its own table
 
 
 def test_training_step_repacks_in_one_launch(emu_backend):

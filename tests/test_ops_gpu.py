@@ -294,11 +294,12 @@ def test_conv_wgrad_bf16_paths(prec_backend, kw):
     assert C.case_conv_wgrad(be, **kw) < tol
 
 
-# ---- opt-in plane-ring form of the 16-bit forward / dgrad kernel (conv3d_k3_lp_zring, MI355_BF16_FORM=zring): GPU twins of the emulator
-#      cases in tests/test_ops_emu.py ----
-@pytest.fixture(params=[("bf16", ""), ("fp16", ""), ("bf16", "2"), ("bf16", "5")], ids=["bf16", "fp16", "bf16-two-z-ranges", "bf16-five-z-ranges"])
+# ---- plane-ring forms of the 16-bit forward / dgrad kernel (csrc/conv3d_bf16_zring.hip; MI355_BF16_FORM=zring: conv3d_k3_lp_zring2,
+#      =zring1: the round-3 kernel): GPU twins of the emulator cases in tests/test_ops_emu.py ----
+@pytest.fixture(params=[("bf16", "", "zring"), ("fp16", "", "zring"), ("bf16", "2", "zring"), ("bf16", "5", "zring"), ("bf16", "", "zring1")],
+                ids=["bf16", "fp16", "bf16-two-z-ranges", "bf16-five-z-ranges", "v1-bf16"])
 def zring_backend(hip_backend, request, monkeypatch):
-    monkeypatch.setenv("MI355_BF16_FORM", "zring")
+    monkeypatch.setenv("MI355_BF16_FORM", request.param[2])
     monkeypatch.setenv("MI355_BF16_ZSPLITS", request.param[1])
     hip_backend.set_precision(request.param[0])
     yield hip_backend, BF16_TOL[request.param[0]]
@@ -312,6 +313,12 @@ def zring_backend(hip_backend, request, monkeypatch):
     dict(n=1, cin=32, cout=32, dhw=(1, 8, 16)),
     dict(n=1, cin=20, cout=32, dhw=(9, 8, 32), norm=True, slope=0.01, yld=64, yc0=32),
     dict(n=2, cin=32, cout=32, dhw=(32, 32, 32), norm=True, residual=True),                   # 16 columns x 32 planes
+    dict(n=1, cin=32, cout=32, dhw=(4, 8, 16), norm=True),                                    # head + tail steps only
+    dict(n=1, cin=32, cout=32, dhw=(22, 8, 16), residual=True),                               # every rotation of the accumulator sets
+    dict(n=1, cin=64, cout=32, dhw=(6, 8, 16), norm=True, residual=True, chscale=True),       # channel split over wave pairs
+    dict(n=2, cin=64, cout=64, dhw=(8, 16, 16), norm=True, bias=True),                        # two channel tiles
+    dict(n=1, cin=48, cout=96, dhw=(7, 8, 32), slope=0.01, norm=True, yld=128, yc0=32),        # padded second channel slice
+    dict(n=2, cin=64, cout=64, dhw=(64, 64, 64), norm=True, residual=True),                   # a 64^3-level layer of the headline network
 ])
 def test_conv_fwd_zring_form(zring_backend, kw):
     be, tol = zring_backend
@@ -319,21 +326,25 @@ def test_conv_fwd_zring_form(zring_backend, kw):
 
 
 @pytest.mark.gpu
-def test_conv_dgrad_zring_form(zring_backend):
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(6, 8, 16)), dict(n=1, cin=32, cout=64, dhw=(6, 8, 16)), dict(n=2, cin=64, cout=64, dhw=(5, 8, 32))])
+def test_conv_dgrad_zring_form(zring_backend, kw):
     be, tol = zring_backend
-    assert C.case_conv_dgrad(be, n=1, cin=32, cout=32, dhw=(6, 8, 16)) < tol
+    assert C.case_conv_dgrad(be, **kw) < tol
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(5, 8, 16), residual=True, chscale=True), dict(n=2, cin=32, cout=32, dhw=(4, 16, 16))])
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(5, 8, 16), residual=True, chscale=True), dict(n=2, cin=32, cout=32, dhw=(4, 16, 16)),
+                                dict(n=1, cin=64, cout=64, dhw=(9, 8, 16), residual=True), dict(n=2, cin=32, cout=32, dhw=(64, 64, 64))])
 def test_conv_epilogue_moments_zring_form(zring_backend, kw):
     be, tol = zring_backend
     assert C.case_conv_moments(be, ytol=tol, strict_vs_oracle=False, **kw) < 2e-5
 
 
 @pytest.mark.gpu
-def test_norm_backward_sums_zring_form(zring_backend):
+@pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(5, 8, 16)), dict(n=1, cin=64, cout=32, dhw=(6, 8, 16)), dict(n=1, cin=32, cout=64, dhw=(4, 8, 16))])
+def test_norm_backward_sums_zring_form(zring_backend, kw):
+    import os
     be, tol = zring_backend
-    r = C.case_gn_bwd_fused(be, compare_unfused=True, n=1, cin=32, cout=32, dhw=(5, 8, 16))
+    fused = os.environ["MI355_BF16_FORM"] != "zring" or (16 < kw["cout"] <= 32 and kw["cin"] == 32)      # as in tests/test_ops_emu.py
+    r = C.case_gn_bwd_fused(be, compare_unfused=True, expect_fused=fused, **kw)
     assert all(v < 2e-5 for v in r.values()), r
-

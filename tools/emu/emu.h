@@ -306,5 +306,6 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetc
 #define MIN_WAVES_PER_SIMD(n)
 #define ONE_WAVE_PER_SIMD
 #define PIN_IN_AGPR(v) ((void)0)
+#define PIN_IN_VGPR(v) ((void)0)
 typedef uint4 u32x4_t;
 #define SLEEP_64CLK(n) do {} while (0)

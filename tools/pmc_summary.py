@@ -27,6 +27,24 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
+def tree_sha():
+    """Commit the measured tree belongs to. The GPU box has no .git (gpurun ships the tree without it): tools/stamp_tree.sh writes
+    `git rev-parse HEAD` (+ "-dirty" with uncommitted changes) into gpurun_stamp.txt before a call; with a .git present git answers."""
+    if os.environ.get("MI355_GIT_SHA"):
+        return os.environ["MI355_GIT_SHA"]
+    try:
+        sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+        if sha:
+            dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True).stdout.strip()
+            return sha + ("-dirty" if dirty else "")
+    except OSError:
+        pass
+    stamp = os.path.join(ROOT, "gpurun_stamp.txt")
+    if os.path.exists(stamp):
+        return open(stamp).read().strip() or "unknown"
+    return "unknown"
+
+
 def load(path):
     agg = defaultdict(lambda: [0, 0.0, 0.0])
     name = None
@@ -46,11 +64,7 @@ def main(paths):
     for t in tables.values():
         names |= set(t)
     cols = sorted(tables)
-    try:
-        sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
-    except OSError:
-        sha = "unknown"
-    print(f"# provenance: git_sha={os.environ.get('MI355_GIT_SHA', sha)} kernel_source_sha256={kernel_source_hash()}")
+    print(f"# provenance: git_sha={tree_sha()} kernel_source_sha256={kernel_source_hash()}")
     print("Kernel,Calls," + ",".join(f"{c}_MiB_per_launch" for c in cols) + ",fetch_x2_MiB_per_launch,avg_ms_under_pmc")
     rows = []
     for n in names:
