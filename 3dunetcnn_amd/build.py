@@ -15,6 +15,11 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmi355unet3d.so")
 OBJ = os.path.join(HERE, "csrc", "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# Per-source flags. The plane-ring kernels pin 216 weight registers in the AGPRs; left to its heuristics hipcc puts the MFMA accumulators
+# there as well, runs out of AGPRs, keeps the remaining weights in VGPRs and copies each into place before the MFMA that reads it (two
+# v_mov_b64 + s_nop per MFMA on a third of the MFMAs of the 64-channel form). -amdgpu-mfma-vgpr-form selects the VGPR-destination MFMA
+# forms: accumulators in the architectural half, every weight fragment in an AGPR, no copies, no spills (tools/lpz_one.sh).
+EXTRA_FLAGS = {"conv3d_bf16_zring.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def hipcc():
@@ -45,7 +50,7 @@ def build(force=False, verbose=True):
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or newer(s, o) or any(newer(d, o) for d in deps):
-            jobs.append([cc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([cc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -44,7 +44,9 @@ class HipGraphedTrainStep:
             self._capture(model, criterion, optimizer, example_x, example_y, warmup)
 
     def _capture(self, model, criterion, optimizer, example_x, example_y, warmup):
-        model.backward_side_stream = False           # one captured stream: the graph already removes the launch gaps the fork hides
+        # One captured stream: the graph already removes the launch gaps the fork hides. Capturing the weight gradients' side stream
+        # as a second graph branch was measured in round 4 and lost: 58.1 vs 55.9 ms per fp32 step (eager: 56.0; profiles/r4_ab_experiments.txt).
+        model.backward_side_stream = False
         self.x = example_x.detach().clone()          # static inputs: every replay reads these addresses
         self.y = example_y.detach().clone()
         model.flatten_parameters()
