@@ -21,6 +21,7 @@
 // Weights are pre-packed [tap][ci/8][plane][co][8] (bf16) so a lane fetches its B fragment with one 16-byte global load
 // (L2/L1 resident), software-prefetched one k-step ahead.
 #include "conv3d_lp.h"
+#include "pack_values.h"
 
 // FUSE: 0 plain epilogue, 1 + moment records of the output, 2 + norm-backward sums (dgrad): as conv3d_fwd.hip
 // F16: MI355_PREC_F16 -- the single operand plane is IEEE fp16 instead of bf16 (same tile, same loop, v_mfma_f32_32x32x16_f16)
@@ -459,25 +460,8 @@ static LpZPlan plan_lp_zring(int n, int cin, int cout, int d, int h, int w, int 
 // PACKED roles as in mi355_pack_conv_weight.
 __global__ void pack_weight_bf16_kernel(const float* w, unsigned short* wp, int cout, int cin, int T, int coutP, int cinP, int mode, int NS, int f16) {
   const size_t total = (size_t)T * (cinP / 8) * coutP * 8;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int e = idx & 7;
-    size_t r = idx >> 3;
-    const int o = r % coutP; r /= coutP;
-    const int i8 = r % (cinP / 8); r /= (cinP / 8);
-    const int t = (int)r;
-    const int i = i8 * 8 + e;
-    float v = 0.f;
-    if (o < cout && i < cin) {
-      const int tf = T - 1 - t;
-      if (mode == 0) v = w[((size_t)o * cin + i) * T + t];
-      else v = w[((size_t)i * cout + o) * T + tf];
-    }
-    for (int p = 0; p < NS; ++p) {
-      const unsigned pk = f16 ? pack_f16x2(v, 0.f) : pack_bf16x2(v, 0.f);
-      wp[((((size_t)t * (cinP / 8) + i8) * NS + p) * coutP + o) * 8 + e] = (unsigned short)(pk & 0xffffu);
-      v -= bf16lo_to_f32(pk);
-    }
-  }
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+    pack_lp_item(w, wp, idx, cout, cin, T, coutP, cinP, mode, NS, f16);      // pack_values.h (shared with mi355_pack_weights_batch)
 }
 
 static int nsplit_of(int precision) {

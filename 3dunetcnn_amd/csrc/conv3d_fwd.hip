@@ -627,16 +627,20 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const mi355_pack_task* 
     if (tasks[mid].first_chunk <= chunk) lo = mid; else hi = mid - 1;
   }
   const mi355_pack_task t = tasks[lo];
-  const int coutP = (t.cout + 31) / 32 * 32, cinP = (t.cin + 7) / 8 * 8;
+  const bool lp = t.kind >= MI355_PACK_LP;                  // 16-bit operand pack of precision t.kind - MI355_PACK_LP
+  const int coutP = (t.cout + 31) / 32 * 32, cinP = lp ? (t.cin + 15) / 16 * 16 : (t.cin + 7) / 8 * 8;
   const int T = t.kd * t.kd * t.kd;
-  // work items: an fp32 pack element, or one (dz, ci, co) of a Winograd pack (16 outputs from 9 weights, pack_values.h)
+  // work items: an fp32 / 16-bit pack element, or one (dz, ci, co) of a Winograd pack (16 outputs from 9 weights, pack_values.h)
   const size_t items = t.kind == MI355_PACK_WINO ? (size_t)3 * cinP * coutP : (size_t)T * cinP * coutP;
   const size_t base = (size_t)(chunk - t.first_chunk) * MI355_PACK_CHUNK;
+  const int prec = t.kind - MI355_PACK_LP;
+  const int ns = prec == MI355_PREC_BF16X3 ? 2 : (prec == MI355_PREC_BF16X6 ? 3 : 1);
 #pragma unroll 2
   for (int k = 0; k < MI355_PACK_CHUNK / 256; ++k) {
     const size_t idx = base + (size_t)k * 256 + threadIdx.x;
     if (idx >= items) break;
-    if (t.kind == MI355_PACK_WINO) pack_wino_item(t.w, t.out, idx, t.cout, t.cin, coutP, cinP, t.mode);
+    if (lp) pack_lp_item(t.w, reinterpret_cast<unsigned short*>(t.out), idx, t.cout, t.cin, T, coutP, cinP, t.mode, ns, prec == MI355_PREC_F16);
+    else if (t.kind == MI355_PACK_WINO) pack_wino_item(t.w, t.out, idx, t.cout, t.cin, coutP, cinP, t.mode);
     else t.out[idx] = pack_f32_value(t.w, idx, t.cout, t.cin, T, coutP, cinP, t.mode);
   }
 }

@@ -62,3 +62,26 @@ __device__ __forceinline__ void pack_wino_item(const float* w, float* up, size_t
 #pragma unroll
     for (int pj = 0; pj < 4; ++pj) dst[(size_t)(pi * 4 + pj) * slab] = u[pi][pj];
 }
+
+// 16-bit operand layouts of the bf16 matrix paths [tap][ciP / 8][plane][coP][8] (conv3d_bf16.hip), ciP = roundup(cin, 16): NS planes per
+// element (hi, residual of hi, ...) of bf16, or one plane of IEEE fp16. One WORK ITEM = one (tap, ci, co) element (its NS planes).
+__device__ __forceinline__ void pack_lp_item(const float* w, unsigned short* wp, size_t idx, int cout, int cin, int T, int coutP, int cinP,
+                                             int mode, int NS, int f16) {
+  const int e = idx & 7;
+  size_t r = idx >> 3;
+  const int o = r % coutP; r /= coutP;
+  const int i8 = r % (cinP / 8); r /= (cinP / 8);
+  const int t = (int)r;
+  const int i = i8 * 8 + e;
+  float v = 0.f;
+  if (o < cout && i < cin) {
+    const int tf = T - 1 - t;
+    if (mode == 0) v = w[((size_t)o * cin + i) * T + t];
+    else v = w[((size_t)i * cout + o) * T + tf];
+  }
+  for (int p = 0; p < NS; ++p) {
+    const unsigned pk = f16 ? pack_f16x2(v, 0.f) : pack_bf16x2(v, 0.f);
+    wp[((((size_t)t * (cinP / 8) + i8) * NS + p) * coutP + o) * 8 + e] = (unsigned short)(pk & 0xffffu);
+    v -= bf16lo_to_f32(pk);
+  }
+}

@@ -100,6 +100,7 @@ class PackedWeight:
             check(be.lib.mi355_pack_conv_weight_bf16(self.w.data_ptr(), out.data_ptr(), self.cout, self.cin, self.kd, self.mode, precision,
                                                      be.stream()), "pack_conv_weight_bf16")
             self._bf16[precision] = out
+        self._bf16_last = precision
         return self._bf16[precision]
 
     def wino(self):
@@ -201,8 +202,9 @@ class Backend:
         return PackedWeight(self, w, mode)
 
     def repack_batch(self, packed, cache=None):
-        """Refresh the fp32 and Winograd packs that the PackedWeights in `packed` hold from their (updated) weight tensors in ONE launch
-        (mi355_pack_weights_batch); their 16-bit packs are dropped and rebuilt on first use. The device task table is cached in `cache`
+        """Refresh the fp32, Winograd and 16-bit packs that the PackedWeights in `packed` hold from their (updated) weight tensors in ONE
+        launch (mi355_pack_weights_batch; round 4: the 16-bit packs too -- dropped and rebuilt on first use they were 50 launches of 6 us
+        per bf16 step). The device task table is cached in `cache`
         (a dict owned by the CALLER -- one per network, engine.HipNetBase._pack_tables -- mapping the task tuple to its device table):
         in a training loop neither the weights (views of the flat parameter buffer) nor the pack buffers move, so a network finds its
         table again every step, and two networks sharing this backend (validation twin, EMA copy) never evict each other's. A table is
@@ -212,7 +214,6 @@ class Backend:
         CHUNK = 1024                                       # MI355_PACK_CHUNK work items (fp32: elements; Winograd: (dz, ci, co) triples)
         tasks, chunks = [], 0
         for pw in packed:
-            pw._bf16 = {}
             cinP, coutP = (pw.cin + 7) // 8 * 8, (pw.cout + 31) // 32 * 32
             if pw._f32 is not None:
                 tasks.append((pw.w.data_ptr(), pw._f32.data_ptr(), pw.cout, pw.cin, pw.kd, pw.mode, 0, chunks))
@@ -220,6 +221,11 @@ class Backend:
             if getattr(pw, "_wino", None) is not None:
                 tasks.append((pw.w.data_ptr(), pw._wino.data_ptr(), pw.cout, pw.cin, pw.kd, pw.mode, 1, chunks))
                 chunks += (3 * cinP * coutP + CHUNK - 1) // CHUNK
+            last = getattr(pw, "_bf16_last", None)             # only the 16-bit pack in use is refreshed; packs of other precision modes
+            pw._bf16 = {k: v for k, v in pw._bf16.items() if k == last}      # (a mode switch) are dropped and rebuilt on first use
+            for prec, buf in pw._bf16.items():             # kind = MI355_PACK_LP + precision
+                tasks.append((pw.w.data_ptr(), buf.data_ptr(), pw.cout, pw.cin, pw.kd, pw.mode, 16 + int(prec), chunks))
+                chunks += (pw.kd ** 3 * ((pw.cin + 15) // 16 * 16) * coutP + CHUNK - 1) // CHUNK
         if not tasks:
             return 0
         if cache is None:
@@ -231,8 +237,10 @@ class Backend:
             for w, out, cout, cin, kd, mode, kind, _ in tasks:
                 if kind == 0:
                     check(self.lib.mi355_pack_conv_weight(w, out, cout, cin, kd, mode, self.stream()), "pack_conv_weight")
-                else:
+                elif kind == 1:
                     check(self.lib.mi355_wino_pack_weight(w, out, cout, cin, mode, self.stream()), "wino_pack_weight")
+                else:
+                    check(self.lib.mi355_pack_conv_weight_bf16(w, out, cout, cin, kd, mode, kind - 16, self.stream()), "pack_conv_weight_bf16")
             return len(tasks)
         if table is None:
             rec = np.array(tasks, dtype=[("w", "<u8"), ("out", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("kd", "<i4"), ("mode", "<i4"),

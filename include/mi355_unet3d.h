@@ -139,6 +139,8 @@ int mi355_pack_conv_weight(const float* w, float* wp, int32_t cout, int32_t cin,
  * it, `total_chunks` = the sum over all tasks. */
 #define MI355_PACK_F32 0
 #define MI355_PACK_WINO 1
+#define MI355_PACK_LP 16      /* kind = MI355_PACK_LP + precision (MI355_PREC_BF16X3 .. MI355_PREC_F16): out = mi355_pack_conv_weight_bf16(w, ..., precision),
+                                 modes 0 / 1, kd 3; work items = kd^3 * roundup(cin, 16) * roundup(cout, 32) */
 #define MI355_PACK_CHUNK 1024
 typedef struct {
   const float* w; float* out;

@@ -174,6 +174,30 @@ def test_unet3d_five_levels():
     C.assert_recorded(e, RECORDED["five"])
 
 
+# The same whole-network case on the DIRECT fp32 kernels at the bounds recorded BEFORE Winograd became the default route (round 2 table
+# above): the Winograd bounds in RECORDED are wider because that route rounds differently from the oracle's direct convolution on
+# ill-conditioned tensors; a regression of the direct kernels (still the route of stride-2, small-volume and narrow layers, and the
+# MI355_WINOGRAD=0 cross-check form) must not hide behind them.
+RECORDED_DIRECT = {"five": dict(grad=0.02, n_loose=0, max_err_vs_fp32=5e-5, logits=2e-5),
+                   "32": dict(grad=0.02, n_loose=0, max_err_vs_fp32=3e-4, logits=2e-5)}
+
+
+@pytest.mark.parametrize("rec", ["five", "32"])
+def test_unet3d_direct_kernels_hold_the_round2_bounds(rec, hip_backend):
+    old = hip_backend.winograd, hip_backend.wgrad_form
+    hip_backend.winograd, hip_backend.wgrad_form = False, "direct"
+    try:
+        if rec == "five":
+            e = _run_pair(dict(n_features=4, n_outputs=3, encoder_blocks=[1, 2, 2, 2, 4]), (1, 2, 2, 2, 4), (32, 48, 32), 1)
+        else:
+            e = _run_pair(dict(n_features=4, n_outputs=3), (1, 2, 2, 4), (32, 32, 32), 2)
+    finally:
+        hip_backend.winograd, hip_backend.wgrad_form = old
+    print("direct", rec, e)
+    assert e["logits"] < TOL and e["loss"] < TOL and e["grad"] <= 1.0, e
+    C.assert_recorded(e, RECORDED_DIRECT[rec])
+
+
 def test_training_steps_match_torch_adam():
     """3 optimizer steps (eval-mode graph so no dropout RNG) of HipUNet3D+HipDiceLoss+HipAdam vs oracle+torch.optim.Adam."""
     torch.manual_seed(7)

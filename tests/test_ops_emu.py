@@ -493,6 +493,29 @@ def test_batched_repack_equals_single_packs(emu_backend):
     assert be.repack_batch(packs, own) == 7 and len(own) == 1 and be.last_pack_table is not table      # a caller's own cache gets its own table
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "bf16x3", "bf16x6"])
+def test_batched_repack_refreshes_the_16bit_packs(emu_backend, prec):
+    """The 16-bit operand packs of a step ride in the same launch (kind MI355_PACK_LP + precision): bit-identical to
+    mi355_pack_conv_weight_bf16 in both modes, ragged channels; a pack of a precision mode that is no longer in use is dropped."""
+    be = emu_backend
+    g = torch.Generator().manual_seed(12)
+    pnum = C.ops.PRECISIONS[prec]
+    ws = [(torch.randn(40, 20, 3, 3, 3, generator=g), 0), (torch.randn(40, 20, 3, 3, 3, generator=g), 1), (torch.randn(32, 64, 3, 3, 3, generator=g), 0)]
+    packs = [be.pack_weight(w, m) for w, m in ws]
+    for pw in packs:
+        pw.f32()
+        pw.bf16(pnum)
+    packs[2].bf16(C.ops.PRECISIONS["bf16x3" if prec != "bf16x3" else "bf16"])      # an older pack of another mode ...
+    packs[2].bf16(pnum)                                                            # ... the mode in use is the last one asked for
+    for w, _ in ws:
+        w.mul_(0.75).add_(-0.125)
+    assert be.repack_batch(packs) == 6
+    assert set(packs[2]._bf16) == {pnum}
+    for pw, (w, m) in zip(packs, ws):
+        fresh = be.pack_weight(w, m)
+        assert torch.equal(pw._f32, fresh.f32()) and torch.equal(pw._bf16[pnum], fresh.bf16(pnum))
+
+
 def test_training_step_repacks_in_one_launch(emu_backend):
     """From the second step on, the packs of a training step are refreshed by ONE mi355_pack_weights_batch launch at the start of the
     forward (engine.py: _repack_stale) and no single-weight pack kernel runs; the step computes what a model with freshly built packs
