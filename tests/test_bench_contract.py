@@ -119,6 +119,44 @@ def test_committed_bench_line_has_the_contract_shape(name):
         assert set(line["precision_modes"]) == {"bf16x6", "bf16x3", "bf16"}
 
 
+@pytest.mark.parametrize("name,dtype", [("r4_bench_fp32.json", "f32"), ("r4_c3_bench.json", "bf16 (mixed)")])
+def test_round4_committed_lines_carry_the_verdict_fixes(name, dtype):
+    """The round-4 lines as produced on the MI355X: contract shape, a roofline whose traffic ratio a reader can redo in one division from
+    the committed PMC summary, per-instantiation rows, both roofline fractions, and (headline only) a cpu_baseline of the REAL shape."""
+    import csv
+    line = json.load(open(os.path.join(ROOT, "profiles", name)))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "communicator"):
+        assert k in line, k
+    assert line["dtype"] == dtype and line["n_gpus"] == 1 and line["communicator"]["world_size"] == 1 and len(line["communicator"]["rank_devices"]) == 1
+    assert abs(line["value"] - line["config"]["global_batch"] * 1e3 / line["ms_per_step"]) / line["value"] < 1e-3
+    roof = line["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 2e-3
+    assert roof["frac"] == (roof["mfma_pipe_frac"] if roof["bound"] == "mfma" else roof["hbm_frac"])
+    assert (roof["mfma_pipe_frac"] >= roof["hbm_frac"]) == (roof["bound"] == "mfma")           # the binding roofline is the one that needs more time
+    assert roof["algorithmic_bytes_per_launch"] >= roof["unfused_compulsory_bytes_per_launch"]
+    assert abs(roof["traffic_over_algorithmic"] - roof["traffic"] / roof["algorithmic_bytes_per_launch"]) < 2e-3
+    # the call-weighted family traffic, recomputed from the CSV the line names
+    rel = roof["traffic_source"].split(" ")[0]
+    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, rel)).read().splitlines()[1:])]
+    keys = _bench().PMC_FAMILY[roof["kernel"]]
+    hit = [(int(r["Calls"]), (float(r["fetch_x2_MiB_per_launch"]) + float(r["WRITE_SIZE_MiB_per_launch"])) * 1048576) for r in rows
+           if any(k in r["Kernel"] for k in keys)]
+    assert abs(sum(c * b for c, b in hit) / sum(c for c, _ in hit) - roof["traffic"]) < 1.0
+    inst = roof["instantiations"]
+    assert len(inst) >= 3 and sum(i["launches_per_step"] for i in inst) == roof["launches_per_step"]
+    assert all("traffic_over_algorithmic" in i for i in inst)
+    if name == "r4_bench_fp32.json":
+        assert "Winograd" in line["config"]["conv_arithmetic"] and roof["kernel"] == "conv3d_wino2d" and roof["bound"] == "mfma"
+        cpu = line["cpu_baseline"]
+        assert cpu["extrapolated"] is False and "128^3 patch" in cpu["sample"] and "scaled" not in cpu["sample"]
+        assert len(cpu["per_iteration_s"]) == 3 and cpu["optimizer_s"] < 0.2 and 5.0 < cpu["seconds_per_step"] < 20.0
+    else:
+        assert "configs[2]" in line["config"]["workload"] and "batch 4" in line["config"]["workload"] and roof["mfma_peak_tflops"] == 2500.0
+        ring = [i for i in inst if "zring" in i["kernel"]]
+        assert ring and all(i["traffic_over_algorithmic"] < 1.5 for i in ring)           # the plane-ring kernels fetch every input voxel once
+
+
 def test_bench_needs_a_gpu():
     import torch
     if torch.cuda.is_available():
