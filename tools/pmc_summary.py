@@ -3,8 +3,9 @@
     python tools/pmc_summary.py gpurun_out/<tag>/pmc_fetch/bench_counter_collection.csv gpurun_out/<tag>/pmc_write/bench_counter_collection.csv
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB per dispatch. Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on
-gfx950 counts 128-B requests as 64 B for wide coalesced reads: the `fetch_x2` column applies that correction; WRITE_SIZE is
-uncalibrated and reported as is.
+gfx950 counts 128-B requests as 64 B for wide coalesced reads: the `fetch_x2` column applies that correction. Both counters were
+calibrated against 1 GiB moved in this library's access patterns (tools/micro/pmc_calibrate.hip, profiles/r4_pmc_calibration.txt):
+FETCH_SIZE x 2 is exact for 16-byte and 4-byte-per-lane reads, WRITE_SIZE is exact.
 """
 import csv
 import hashlib
