@@ -291,14 +291,16 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring(Conv
 // step consumes ONE input plane p: every A fragment (tile, dy, dx, k-step) is read once and multiplies the three z-taps into the three
 // output planes that see plane p -- p + 1 (dz = 0), p (dz = 1), p - 1 (dz = 2) -- so the LDS delivers one fragment per THREE MFMAs,
 // consecutive MFMAs never share an accumulator, and the ring shrinks to two slots (the plane being read, the plane being written).
-// Plane p - 1 is complete after step p; its epilogue rides under the MFMAs of step p + 1.
+// Plane p - 1 is complete after step p: its accumulators go to a 4 KB-per-tile LDS result buffer (double-buffered by step parity) and
+// its epilogue rides under the MFMAs of step p + 1, reading the values back four at a time (no register copy of the finished tile).
 //
 // Layers wider than 32 input channels do not fit the weights-stationary scheme with every wave holding the whole filter (27 taps x
 // Cin / 16 fragments of 4 registers: 432 registers at 64 channels). KS = 2 splits the channels over wave PAIRS instead: wave (ks, mg)
 // holds the 27 x 2 fragments of channels [32 ks, 32 ks + 32) (216 AGPRs, as the 32-channel form) and accumulates the two M tiles of
-// its pair over that half of K; after a plane's last MFMA the partners swap one partial tile each through LDS (16 registers out, 16 in,
-// same lane map on both sides) and each finishes one tile. Per wave and step 108 MFMAs (3.5 us of matrix time) against 36 A-fragment
-// reads, 6 staged units and one 16-value epilogue.
+// its pair over that half of K; both partial tiles of a finished plane go to the result buffer (same lane map on both sides: no shuffle)
+// and each partner finishes ONE tile: its own partial plus the partner's. Per wave and step 108 MFMAs (3456 matrix cycles) against 36
+// A-fragment reads, 6 staged units and one 16-value epilogue. Measured (profiles/r4_bf16_zring2.txt, r4_mfma_valu_overlap.txt): 38-47 %
+// MFMA busy -- with one wave per SIMD the wave's own vector-ALU / LDS / memory instructions add to its MFMA time instead of hiding under it.
 //   J  : k-steps (16 channels) per tap of a wave's channel slice (2)        KS : channel slices = M tiles per wave (1 | 2)
 // Output channels: one 32-channel tile per workgroup (blockIdx carries the tile), Cout a multiple of 32.
 template <int J, int KS, int INMODE, int FUSE, bool F16>

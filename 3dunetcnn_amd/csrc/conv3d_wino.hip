@@ -64,7 +64,11 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(Wi
   static_assert(2 * (XSF + VSF) <= PF, "the main loop's buffers live inside the exchange area");
   DYN_LDS(lds);
   float* xs = lds;                                         // 2 staged planes [halo voxel][8 + 4 pad]
-  float* vs = lds + 2 * XSF;                               // 2 transformed planes [point][tile][channel]
+  // 2 transformed planes [point][tile][channel]. (A lane's A fragment = 4 channels of a tile, tiles 32 bytes apart: every ds_read_b128 of
+  // them is a 2-way bank conflict, the 15 % SQ_LDS_BANK_CONFLICT of profiles/r3_sq_counters_wino.txt. Round 4 measured the conflict-free
+  // [point][channel half][tile][4] layout: plain form unchanged, fused forms 2-5 % slower (two more spilled registers): LDS is ~40 %
+  // utilised, the conflicts are not on the critical path -- profiles/r4_ab_experiments.txt. Do not repeat.)
+  float* vs = lds + 2 * XSF;
   float* P = lds;                                          // epilogue: output-transform exchange [wave][b][tile][co]
   float* prm = lds + PF;                                   // norm prologue of this sample: scale | shift | slope, CinP each
   const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6), half = lane >> 5, li = lane & 31;
@@ -585,22 +589,34 @@ extern "C" int mi355_wino_pack_weight(const float* w, float* up, int32_t cout, i
 
 // x, y: NDHWC activations of the same extent; up: mi355_wino_pack_weight of the [y->c][x->c] (mode 0) weights; desc: kd 3, stride 1, pad 1,
 // plain / norm-prologue input, plain un-windowed output; bias, residual, out_chscale as in mi355_conv3d_fwd.
-extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
-  if (!x || !y || !up || !d || !x->p || !y->p) return MI355_EINVAL;
+// 0 = this call is one mi355_conv3d_wino_fwd accepts, else the status it would return (shape / mode / alignment): the caller routes a
+// call that is not eligible to mi355_conv3d_fwd instead of failing (ops.Backend.conv_fwd).
+static int wino_check(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d) {
+  if (!x || !y || !d || !x->p || !y->p) return MI355_EINVAL;
   if (d->kd != 3 || d->stride != 1 || d->pad != 1 || d->out_mode != MI355_OUT_PLAIN) return MI355_EUNSUPPORTED;
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
   if (d->off_z || d->off_y || d->off_x || d->out_d != y->d || d->out_h != y->h || d->out_w != y->w) return MI355_EUNSUPPORTED;
   if (x->d != y->d || x->h != y->h || x->w != y->w || x->n != y->n) return MI355_EINVAL;
-  if (x->c % 4 || x->ld % 4 || x->ld < x->c || y->ld < y->c || ((uintptr_t)x->p & 15) || ((uintptr_t)up & 15)) return MI355_EINVAL;
+  if (x->c % 4 || x->ld % 4 || x->ld < x->c || y->ld < y->c || ((uintptr_t)x->p & 15)) return MI355_EINVAL;
   if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift || !(d->act_slope >= 0.f && d->act_slope <= 1.f))) return MI355_EINVAL;
   if (d->residual && d->residual_ld < y->c) return MI355_EINVAL;
+  if (d->moments_out && d->gn_bwd) return MI355_EUNSUPPORTED;
+  if (d->gn_bwd && d->in_mode != MI355_IN_PLAIN) return MI355_EUNSUPPORTED;
+  return MI355_OK;
+}
+
+extern "C" int mi355_conv3d_wino_supported(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d) {
+  return wino_check(x, y, d) == MI355_OK;
+}
+
+extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
+  if (!up || ((uintptr_t)up & 15)) return MI355_EINVAL;
+  { const int rc = wino_check(x, y, d); if (rc) return rc; }
   WinoArgs a;
   memset(&a.g, 0, sizeof(a.g));
-  if (d->moments_out && d->gn_bwd) return MI355_EUNSUPPORTED;
   a.g.mom = d->moments_out;
   if (d->gn_bwd) {
     const mi355_gn_bwd_fuse* f = d->gn_bwd;
-    if (d->in_mode != MI355_IN_PLAIN) return MI355_EUNSUPPORTED;
     if (!f->gx || !f->scale || !f->shift || !f->mean_rstd || !f->partials_out || f->groups <= 0 || y->c % f->groups || f->gx_ld < y->c) return MI355_EINVAL;
     a.g.gnb = f->partials_out; a.g.gx = f->gx; a.g.gxld = f->gx_ld; a.g.gscale = f->scale; a.g.gshift = f->shift; a.g.gmr = f->mean_rstd;
     a.g.ggroups = f->groups; a.g.gslope = f->act_slope;

@@ -285,8 +285,13 @@ class Backend:
                 and out_mode == OUT_PLAIN and tuple(off) == (0, 0, 0) and tuple(out_dhw) == tuple(y.shape[1:4]) and wp.mode in (0, 1)
                 and wp.cin >= 8 and wp.cout >= 8 and x.shape[1:4] == y.shape[1:4]
                 and x.shape[1] * x.shape[2] * x.shape[3] >= self.WINO_MIN_VOXELS):
-            return self.conv_fwd_wino(x, wp.wino(), y, in_mode=in_mode, slope=slope, scale=scale, shift=shift, bias=bias, residual=residual,
-                                      chscale=chscale, in_slope=in_slope, moments=moments, gnb=gnb)
+            # the size thresholds are this layer's routing POLICY; whether the Winograd kernel can take the call at all (strides,
+            # alignment of x / y / residual, modes) is the library's answer -- a call it refuses runs on the direct kernel below
+            probe = self._desc(3, 1, 1, in_mode, slope, scale, shift, bias, residual, chscale, (0, 0, 0), y.shape[1:4], [], in_slope, OUT_PLAIN)
+            xd_, yd_ = x.desc(), y.desc()
+            if self.lib.mi355_conv3d_wino_supported(ctypes.byref(xd_), ctypes.byref(yd_), ctypes.byref(probe)):
+                return self.conv_fwd_wino(x, wp.wino(), y, in_mode=in_mode, slope=slope, scale=scale, shift=shift, bias=bias, residual=residual,
+                                          chscale=chscale, in_slope=in_slope, moments=moments, gnb=gnb)
         keep = []
         d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep, in_slope, out_mode)
         xd, yd = x.desc(), y.desc()

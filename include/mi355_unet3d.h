@@ -311,6 +311,9 @@ int mi355_resample_affine(const float* src, float* dst, int32_t c, int32_t sd, i
 size_t mi355_wino_weight_elems(int32_t cout, int32_t cin);
 int mi355_wino_pack_weight(const float* w, float* up, int32_t cout, int32_t cin, int32_t mode, void* stream);
 int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const mi355_act* y, const mi355_conv_desc* desc, void* stream);
+/* 1 when mi355_conv3d_wino_fwd accepts this call (shape, mode, strides, alignment of x / y / the fused operands), else 0: a caller that
+ * routes by size thresholds asks here and falls back to mi355_conv3d_fwd instead of failing. */
+int mi355_conv3d_wino_supported(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* desc);
 /* records per sample its fused-statistics epilogues (desc->moments_out / desc->gn_bwd, formats of gn_fuse.h) write: 2 x 8 x 16 voxel tiles */
 int32_t mi355_conv3d_wino_stats_blocks(const mi355_act* y);
 /* weight gradient in the same domain, F(3x3, 2x2) x direct z (csrc/conv3d_wgrad_wino.hip; replaces the ATen weight-gradient call behind

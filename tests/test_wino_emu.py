@@ -181,3 +181,34 @@ def test_wgrad_wino_ring_matches_autograd(emu_backend, kw):
         be.wgrad_form = old[0]
         del be.WINO_MIN_VOXELS
     assert calls["n"] == 1
+
+
+def test_ineligible_call_falls_back_to_the_direct_kernel(emu_backend):
+    """Routing policy (size, channels) lives in ops.Backend.conv_fwd; ELIGIBILITY is the library's answer (mi355_conv3d_wino_supported).
+    A call the Winograd kernel cannot take -- here an input view whose leading dimension is not a multiple of 4 channels is not
+    constructible, so: an input Act at a 8-byte-aligned (not 16-byte) channel offset is refused by Act itself; the reachable case is a
+    residual narrower than the output -- must run (on the direct kernel) and give the direct kernel's result, not raise."""
+    import ctypes
+    be = emu_backend
+    assert be.winograd
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 16, 16, 16, 16, generator=g)
+    w = torch.randn(16, 16, 3, 3, 3, generator=g) * 0.1
+    xa, ya = C.to_act(be, x), C.to_act(be, torch.zeros(1, 16, 16, 16, 16))
+    d = be._desc(3, 1, 1, 0, 0.0, None, None, None, None, None, (0, 0, 0), (16, 16, 16), [])
+    xd, yd = xa.desc(), ya.desc()
+    assert be.lib.mi355_conv3d_wino_supported(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d)) == 1
+    d.off_x = 1                                              # a windowed output: not a Winograd call
+    assert be.lib.mi355_conv3d_wino_supported(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d)) == 0
+    d.off_x = 0
+    d.stride = 2
+    assert be.lib.mi355_conv3d_wino_supported(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d)) == 0
+    # end to end: the library refuses -> conv_fwd runs the direct kernel and returns its result
+    calls = []
+    real = be.lib.mi355_conv3d_wino_supported
+    try:
+        be.lib.mi355_conv3d_wino_supported = lambda *a: (calls.append(1), 0)[1]
+        be.conv_fwd(xa, be.pack_weight(w, 0), ya, 3, 1)
+    finally:
+        be.lib.mi355_conv3d_wino_supported = real
+    assert calls and C.rel_err(C.from_act(ya), torch.nn.functional.conv3d(x, w, padding=1)) < 1e-5
