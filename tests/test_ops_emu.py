@@ -296,10 +296,18 @@ def test_conv_dgrad_bf16_paths(prec_backend, kw):
     dict(n=1, cin=4, cout=64, dhw=(4, 4, 16)),
     dict(n=1, cin=40, cout=96, dhw=(5, 3, 7), norm=True, slope=0.01),
     dict(n=2, cin=32, cout=32, dhw=(5, 8, 32), norm=True),      # 40 tiles in 5 splits: workgroups start mid-column and cross columns
+    dict(n=1, cin=32, cout=32, dhw=(13, 6, 20), norm=True),     # long columns, ragged y / x tiles
 ])
 def test_conv_wgrad_bf16_paths(prec_backend, kw):
     be, tol = prec_backend
     assert C.case_conv_wgrad(be, **kw) < tol
+
+
+def test_conv_cat_slope_bf16_paths(prec_backend):
+    # per-channel slope table (MONAI DynUNet concat) through the 16-bit kernels; forward (tile form) and weight gradient
+    be, tol = prec_backend
+    r = C.case_conv_cat_slope(be, 1, 32, 32, 32, (9, 6, 17))
+    assert r["fwd"] < tol and r["wgrad"] < tol, r
 
 
 @pytest.mark.parametrize("kw", [

@@ -294,6 +294,13 @@ def test_conv_wgrad_bf16_paths(prec_backend, kw):
     assert C.case_conv_wgrad(be, **kw) < tol
 
 
+def test_conv_cat_slope_bf16_paths(prec_backend):
+    # per-channel slope table (MONAI DynUNet concat) through the 16-bit kernels; forward (tile form) and weight gradient
+    be, tol = prec_backend
+    r = C.case_conv_cat_slope(be, 1, 32, 32, 32, (9, 6, 17))
+    assert r["fwd"] < tol and r["wgrad"] < tol, r
+
+
 # ---- plane-ring forms of the 16-bit forward / dgrad kernel (csrc/conv3d_bf16_zring.hip; MI355_BF16_FORM=zring: conv3d_k3_lp_zring2,
 #      =zring1: the round-3 kernel): GPU twins of the emulator cases in tests/test_ops_emu.py ----
 @pytest.fixture(params=[("bf16", "", "zring"), ("fp16", "", "zring"), ("bf16", "2", "zring"), ("bf16", "5", "zring"), ("bf16", "", "zring1")],
