@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 class MiAct(Structure):
     _fields_ = [("p", c_void_p), ("n", c_int32), ("d", c_int32), ("h", c_int32), ("w", c_int32),
-                ("c", c_int32), ("ld", c_int32)]
+                ("c", c_int32), ("ld", c_int32), ("dtype", c_int32)]
 
 
 class MiGnBwdFuse(Structure):
@@ -46,6 +46,7 @@ IN_PLAIN, IN_AFFINE_ACT, IN_ZERO_INSERT, IN_S2D = 0, 1, 2, 3
 OUT_PLAIN, OUT_D2S = 0, 1
 W_PACKED, W_OIDHW4, W_PACKED_F32_NARROW = 0, 1, 2
 PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_BF16, PREC_F16 = 0, 1, 2, 3, 4
+ACT_F32, ACT_BF16 = 0, 1      # mi355_act.dtype
 PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "bf16": PREC_BF16, "fp16": PREC_F16}
 
 STATUS = {0: "ok", -1: "invalid argument (shape/alignment/null)", -2: "unsupported combination",
@@ -82,6 +83,7 @@ SIGNATURES = {
     "mi355_ndhwc_to_ncdhw": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p]),
     "mi355_add": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), POINTER(MiAct), c_void_p]),
     "mi355_chscale": (ctypes.c_int, [POINTER(MiAct), c_void_p, POINTER(MiAct), c_void_p]),
+    "mi355_cast": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), c_void_p]),
     "mi355_proj_fwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "mi355_proj_workspace": (c_size_t, [POINTER(MiAct), c_int32]),
     "mi355_proj_bwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, c_void_p, c_float, c_void_p, c_void_p, POINTER(MiAct), c_void_p, c_void_p, c_int32,

@@ -1,0 +1,49 @@
+// Typed access to activation tensors (mi355_act.dtype, include/mi355_unet3d.h): fp32 or bf16 STORAGE. Arithmetic is fp32 in every
+// kernel; a bf16 tensor is converted on load (a shift) and rounded to nearest-even on store (v_cvt_pk_bf16_f32). The kernels are
+// templates over the element type of each tensor they touch and address it in elements, so a typed pointer does the byte arithmetic.
+// Reference: unet3d/models/pytorch/segmentation/unet.py:53-58 (AutocastUNet: conv outputs are 16-bit tensors under torch autocast).
+#pragma once
+#include "hipcompat.h"
+#include "../../include/mi355_unet3d.h"
+
+typedef unsigned short bf16_t;      // storage only: never an arithmetic type
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(bf16lo_to_f32(v.x), bf16hi_to_f32(v.x), bf16lo_to_f32(v.y), bf16hi_to_f32(v.y));
+}
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, const float4& v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = (bf16_t)(pack_bf16x2(v, 0.f) & 0xffffu); }
+// the value a tensor of this type returns for `v` once stored: what statistics of "the tensor as stored" are taken over
+__device__ __forceinline__ float as_stored(const float*, float v) { return v; }
+__device__ __forceinline__ float as_stored(const bf16_t*, float v) { return bf16lo_to_f32(pack_bf16x2(v, 0.f)); }
+// 8 consecutive bf16 (16 bytes) / 8 consecutive floats as 8 floats
+__device__ __forceinline__ void ld8(const float* p, float (&o)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&o)[8]) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  o[0] = bf16lo_to_f32(v.x); o[1] = bf16hi_to_f32(v.x); o[2] = bf16lo_to_f32(v.y); o[3] = bf16hi_to_f32(v.y);
+  o[4] = bf16lo_to_f32(v.z); o[5] = bf16hi_to_f32(v.z); o[6] = bf16lo_to_f32(v.w); o[7] = bf16hi_to_f32(v.w);
+}
+
+static inline size_t act_elem_bytes(int dtype) { return dtype == MI355_ACT_BF16 ? 2 : 4; }
+static inline bool act_dtype_ok(const mi355_act* t) { return t->dtype == MI355_ACT_F32 || t->dtype == MI355_ACT_BF16; }
+// a view the streaming kernels accept: 4-element (float4 / 8-byte) granularity
+static inline int act_view_ok(const mi355_act* t) {
+  return t && t->p && act_dtype_ok(t) && t->c > 0 && t->c % 4 == 0 && t->ld % 4 == 0 && t->ld >= t->c &&
+         !((uintptr_t)t->p & (t->dtype == MI355_ACT_BF16 ? 7 : 15));
+}
+
+// Host-side dispatch: runs the statement list with T = the element type of `dtype`
+#define ACT_TYPED(dtype, T, ...)                                              \
+  do {                                                                        \
+    if ((dtype) == MI355_ACT_BF16) { typedef bf16_t T; __VA_ARGS__; }         \
+    else { typedef float T; __VA_ARGS__; }                                    \
+  } while (0)

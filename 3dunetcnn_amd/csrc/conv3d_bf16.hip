@@ -22,14 +22,23 @@
 // (L2/L1 resident), software-prefetched one k-step ahead.
 #include "conv3d_lp.h"
 #include "pack_values.h"
+#include "act_io.h"
 
 // FUSE: 0 plain epilogue, 1 + moment records of the output, 2 + norm-backward sums (dgrad): as conv3d_fwd.hip
 // F16: MI355_PREC_F16 -- the single operand plane is IEEE fp16 instead of bf16 (same tile, same loop, v_mfma_f32_32x32x16_f16)
-template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT, int INMODE, int FUSE = 0, bool F16 = false>
+// TA: storage type of x, y, the residual and the normalised tensor of the norm-backward sums (act_io.h). bf16 storage (NS == 1 bf16
+// operands only): a plain input goes from global memory to LDS without a conversion, outputs are rounded once on store, statistics are
+// taken over the values as stored.
+template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT, int INMODE, int FUSE = 0, bool F16 = false, typename TA = float>
 // LDS holds 3 workgroups of the largest tile: the register allocator must fit 3 waves per SIMD too (several variants sat one or two
 // registers above), except the 4-tile waves with a norm prologue or the norm-backward epilogue, which would spill.
 __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD((MT * NT >= 4 && (INMODE == MI355_IN_AFFINE_ACT || FUSE == 2)) ? 2 : 3)
 void conv3d_k3_bf16(ConvBArgs a) {
+  const TA* const ax = reinterpret_cast<const TA*>(a.x);
+  TA* const ay = reinterpret_cast<TA*>(a.y);
+  const TA* const ares = reinterpret_cast<const TA*>(a.res);
+  const TA* const agx = reinterpret_cast<const TA*>(a.g.gx);
+  constexpr bool RAW16 = std::is_same<TA, bf16_t>::value && INMODE == MI355_IN_PLAIN && NS == 1 && !F16;      // staged values ARE the stored ones
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TZ * TY / 2 == WM * MT, "M tiles (2 x-rows of 16 voxels) must equal WM*MT");
   constexpr int TX = 16;
@@ -144,9 +153,14 @@ void conv3d_k3_bf16(ConvBArgs a) {
           iz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
           iy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
           ix = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
-          const float* src = a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld;
-          ld0[kk] = *reinterpret_cast<const float4*>(src + c0q);
-          ld1[kk] = *reinterpret_cast<const float4*>(src + c1q);
+          const TA* src = ax + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld;
+          if constexpr (RAW16) {
+            const uint2 r0 = *reinterpret_cast<const uint2*>(src + c0q), r1 = *reinterpret_cast<const uint2*>(src + c1q);
+            ld0[kk] = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r1.x), __uint_as_float(r1.y));      // 8 packed bf16
+          } else {
+            ld0[kk] = ld4(src + c0q);
+            ld1[kk] = ld4(src + c1q);
+          }
         }
 #pragma unroll
         for (int kk = 0; kk < UB; ++kk) {
@@ -156,6 +170,12 @@ void conv3d_k3_bf16(ConvBArgs a) {
           const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
           const int iz = tz0 - a.pad + hz, iy = ty0 - a.pad + hy, ix = tx0 - a.pad + hx;
           const bool inb = iz >= 0 && iy >= 0 && ix >= 0 && iz < a.Di && iy < a.Hi && ix < a.Wi;
+          if constexpr (RAW16) {
+            const bool k0v = inb && v0ok, k1v = inb && v1ok;
+            lds[hv * VSQ + so] = make_uint4(k0v ? __float_as_uint(ld0[kk].x) : 0u, k0v ? __float_as_uint(ld0[kk].y) : 0u,
+                                            k1v ? __float_as_uint(ld0[kk].z) : 0u, k1v ? __float_as_uint(ld0[kk].w) : 0u);
+            continue;
+          }
           float v[8] = {ld0[kk].x, ld0[kk].y, ld0[kk].z, ld0[kk].w, ld1[kk].x, ld1[kk].y, ld1[kk].z, ld1[kk].w};
           if (INMODE == MI355_IN_AFFINE_ACT) {
 #pragma unroll
@@ -244,24 +264,25 @@ void conv3d_k3_bf16(ConvBArgs a) {
         const int mz = m / (TY / 2), my0 = (m % (TY / 2)) * 2;
         const size_t vrow = (((size_t)n * a.Do + tz0 + mz) * a.Ho + ty0 + my0) * a.Wo + tx0;      // x-row 0 of the tile, x = 0
         const size_t vA = vrow + (size_t)half * a.Wo, vB = vrow + (size_t)(half ^ 1) * a.Wo;      // this lane's two x-rows
-        float* yA = a.y + vA * a.yld + coc;
-        float* yB = a.y + vB * a.yld + coc;
+        TA* yA = ay + vA * a.yld + coc;
+        TA* yB = ay + vB * a.yld + coc;
         float gxv[16];
         if constexpr (FUSE == 2) {
-          const float* gA = a.g.gx + vA * a.g.gxld + coc;
-          const float* gB = a.g.gx + vB * a.g.gxld + coc;
+          const TA* gA = agx + vA * a.g.gxld + coc;
+          const TA* gB = agx + vB * a.g.gxld + coc;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) gxv[r] = (((0x6 >> (r >> 2)) & 1) ? gB : gA)[(size_t)r * a.g.gxld];
+          for (int r = 0; r < 16; ++r) gxv[r] = ld1((((0x6 >> (r >> 2)) & 1) ? gB : gA) + (size_t)r * a.g.gxld);
         }
-        const float* rA = a.res ? a.res + vA * a.resld + coc : nullptr;
-        const float* rB = a.res ? a.res + vB * a.resld + coc : nullptr;
+        const TA* rA = a.res ? ares + vA * a.resld + coc : nullptr;
+        const TA* rB = a.res ? ares + vB * a.resld + coc : nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const bool rowb = (0x6 >> (r >> 2)) & 1;
           float v = acc[mt][nt][r] + bs;
-          if (a.res) v += (rowb ? rB : rA)[(size_t)r * a.resld];
+          if (a.res) v += ld1((rowb ? rB : rA) + (size_t)r * a.resld);
           v *= cs;
-          if (cov) (rowb ? yB : yA)[(size_t)r * a.yld] = v;
+          if (cov) st1((rowb ? yB : yA) + (size_t)r * a.yld, v);
+          if constexpr (FUSE != 0) v = as_stored(ay, v);
           if constexpr (FUSE == 1) {
             if (mt == 0 && r == 0) K0 = v;
             const float t = v - K0;
@@ -314,9 +335,9 @@ void conv3d_k3_bf16(ConvBArgs a) {
           if (co >= a.Cout) continue;
           float v = acc[mt][nt][r];
           if (a.bias) v += a.bias[co];
-          if (a.res) v += a.res[ovox * a.resld + co];
+          if (a.res) v += ld1(ares + ovox * a.resld + co);
           if (a.out_chscale) v *= a.out_chscale[(size_t)n * a.Cout + co];
-          a.y[svox * a.yld + co] = v;
+          st1(ay + svox * a.yld + co, v);
         }
       }
     }
@@ -353,7 +374,7 @@ void conv3d_k3_bf16(ConvBArgs a) {
             mtile_lane(row, rr, rtx);
             int oz = tz0 + mz, oy = ty0 + my0 + rr, ox = tx0 + rtx;
             oz = oz < a.Do ? oz : a.Do - 1; oy = oy < a.Ho ? oy : a.Ho - 1; ox = ox < a.Wo ? ox : a.Wo - 1;
-            gxv[r] = a.g.gx[((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.g.gxld + coc];
+            gxv[r] = ld1(agx + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.g.gxld + coc);
           }
         }
 #pragma unroll
@@ -365,9 +386,10 @@ void conv3d_k3_bf16(ConvBArgs a) {
           if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo || !cov) continue;
           const size_t ovox = (((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
           float v = acc[mt][nt][r] + bs;
-          if (a.res) v += a.res[ovox * a.resld + co];
+          if (a.res) v += ld1(ares + ovox * a.resld + co);
           v *= cs;
-          a.y[ovox * a.yld + co] = v;
+          st1(ay + ovox * a.yld + co, v);
+          v = as_stored(ay, v);
           if constexpr (FUSE == 1) {
             if (cnt == 0) K0 = v;
             const float t = v - K0;
@@ -401,8 +423,9 @@ void conv3d_k3_bf16(ConvBArgs a) {
 // shape: tests), zring1 (the round-3 kernel where it applies: the A/B switch), tile (never).
 // Measured: profiles/r3_bf16_zring.txt (zring1), profiles/r4_bf16_zring2.txt (zring2).
 struct LpZPlan { int tilesY, tilesX, zsplits, zper, use, ks, coTiles; };
-static LpZPlan plan_lp_zring(int n, int cin, int cout, int d, int h, int w, int precision, const mi355_conv_desc* desc) {
+static LpZPlan plan_lp_zring(int n, int cin, int cout, int d, int h, int w, int precision, const mi355_conv_desc* desc, int act_dtype = MI355_ACT_F32) {
   LpZPlan p; memset(&p, 0, sizeof(p));
+  if (act_dtype != MI355_ACT_F32) return p;                 // 16-bit activation storage: the tile form (the plane rings read fp32 tensors)
   const char* fe = getenv("MI355_BF16_FORM");
   const bool v1 = fe && !strncmp(fe, "zring1", 6);
   const char form = fe && fe[0] ? fe[0] : 'a';
@@ -494,7 +517,7 @@ extern "C" int mi355_pack_conv_weight_bf16(const float* w, void* wp, int32_t cou
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------------------------
-template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT, bool F16>
+template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT, bool F16, typename TA = float>
 static int launch_b(ConvBArgs& a, int in_mode, void* stream) {
   constexpr int HV = (TZ + 2) * (TY + 2) * 18;
   constexpr int VSQ = NS * 2 * J + 1;
@@ -508,31 +531,31 @@ static int launch_b(ConvBArgs& a, int in_mode, void* stream) {
   if (a.g.mom && a.g.gnb) return MI355_EUNSUPPORTED;
   if (a.g.mom) {
     if (in_mode == MI355_IN_PLAIN)
-      LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 1, F16>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+      LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 1, F16, TA>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
     else
-      LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT, 1, F16>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+      LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT, 1, F16, TA>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   } else if (a.g.gnb) {
     if (in_mode != MI355_IN_PLAIN) return MI355_EUNSUPPORTED;
-    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 2, F16>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 2, F16, TA>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   } else if (in_mode == MI355_IN_PLAIN)
-    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 0, F16>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 0, F16, TA>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   else
-    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT, 0, F16>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT, 0, F16, TA>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   return LAUNCH_CHECK();
 }
 
-template <int NS, bool F16 = false>
+template <int NS, bool F16 = false, typename TA = float>
 static int dispatch_ns(ConvBArgs& a, int in_mode, long long vox, void* stream) {
   // big volumes: 4x4x16 tiles (256 voxels), 4 waves along M; small: 2x4x16 tiles (128 voxels) so the grid still fills the chip
   constexpr int J = NS == 1 ? 2 : 1;      // (one 16-channel k-step per chunk for NS = 1 too: more workgroups per CU, measured 10 % slower)
   if constexpr (NS < 3) {     // the 3-plane tile of the big configuration would exceed the 64 KiB LDS window
     if (vox >= 256LL * 512) {
-      if (a.Cout > 32) return launch_b<4, 4, J, NS, 4, 1, 2, 2, F16>(a, in_mode, stream);
-      return launch_b<4, 4, J, NS, 4, 1, 2, 1, F16>(a, in_mode, stream);
+      if (a.Cout > 32) return launch_b<4, 4, J, NS, 4, 1, 2, 2, F16, TA>(a, in_mode, stream);
+      return launch_b<4, 4, J, NS, 4, 1, 2, 1, F16, TA>(a, in_mode, stream);
     }
   }
-  if (a.Cout > 32) return launch_b<2, 4, J, NS, 2, 2, 2, 1, F16>(a, in_mode, stream);
-  return launch_b<2, 4, J, NS, 4, 1, 1, 1, F16>(a, in_mode, stream);
+  if (a.Cout > 32) return launch_b<2, 4, J, NS, 2, 2, 2, 1, F16, TA>(a, in_mode, stream);
+  return launch_b<2, 4, J, NS, 4, 1, 1, 1, F16, TA>(a, in_mode, stream);
 }
 
 // spatial tiles (= epilogue records per sample) of the configuration dispatch_ns picks; 0: this call cannot fuse statistics
@@ -540,7 +563,7 @@ int32_t mi355_conv3d_bf16_stats_blocks(const mi355_act* x, const mi355_act* y, c
   const int ns = nsplit_of(d->precision);
   if (!ns || d->kd != 3 || d->stride != 1 || d->out_mode != MI355_OUT_PLAIN) return 0;
   if (d->off_z || d->off_y || d->off_x || d->out_d != y->d || d->out_h != y->h || d->out_w != y->w) return 0;
-  const LpZPlan zp = plan_lp_zring(x->n, x->c, y->c, y->d, y->h, y->w, d->precision, d);
+  const LpZPlan zp = plan_lp_zring(x->n, x->c, y->c, y->d, y->h, y->w, d->precision, d, x->dtype);
   // plane-ring kernels: one record per (z range, column); zring2 leaves one per wave and half-wave of the column's workgroup (x 8)
   if (zp.use && x->d == y->d && x->h == y->h && x->w == y->w) {
     if (zp.use == 2 && d->gn_bwd) return 0;                  // zring2 has no norm-backward form (plan_lp_zring): unfused sums
@@ -560,7 +583,7 @@ int mi355_conv3d_bf16_kernel_name(const mi355_act* x, const mi355_act* y, const 
   if (!ns || !out || n < 8) return MI355_EINVAL;
   const int fuse = d->moments_out ? 1 : (d->gn_bwd ? 2 : 0);
   const char* f16 = d->precision == MI355_PREC_F16 ? "true" : "false";
-  const LpZPlan zp = plan_lp_zring(x->n, x->c, y->c, d->out_d, d->out_h, d->out_w, d->precision, d);
+  const LpZPlan zp = plan_lp_zring(x->n, x->c, y->c, d->out_d, d->out_h, d->out_w, d->precision, d, x->dtype);
   if (zp.use && y->d == d->out_d && y->h == d->out_h && y->w == d->out_w && x->d == d->out_d && x->h == d->out_h && x->w == d->out_w) {
     if (zp.use == 1) snprintf(out, n, "conv3d_k3_lp_zring<2, %d, %d, %s>", d->in_mode, fuse, f16);
     else snprintf(out, n, "conv3d_k3_lp_zring2<2, %d, %d, %d, %s>", zp.ks, d->in_mode, fuse, f16);
@@ -572,7 +595,7 @@ int mi355_conv3d_bf16_kernel_name(const mi355_act* x, const mi355_act* y, const 
   const char* tile = big ? (wide ? "4, 4, %d, %d, 4, 1, 2, 2" : "4, 4, %d, %d, 4, 1, 2, 1") : (wide ? "2, 4, %d, %d, 2, 2, 2, 1" : "2, 4, %d, %d, 4, 1, 1, 1");
   char t[64];
   snprintf(t, sizeof(t), tile, J, ns);
-  snprintf(out, n, "conv3d_k3_bf16<%s, %d, %d, %s>", t, d->in_mode, fuse, f16);
+  snprintf(out, n, "conv3d_k3_bf16<%s, %d, %d, %s, %s>", t, d->in_mode, fuse, f16, x->dtype == MI355_ACT_BF16 ? "unsigned short" : "float");
   return 0;
 }
 
@@ -581,6 +604,10 @@ int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_a
   const int ns = nsplit_of(d->precision);
   if (!ns || d->kd != 3 || d->stride != 1) return MI355_EUNSUPPORTED;
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
+  if (x->dtype != y->dtype) return MI355_EUNSUPPORTED;
+  const bool lp = x->dtype == MI355_ACT_BF16;
+  if (lp && d->precision != MI355_PREC_BF16) return MI355_EUNSUPPORTED;      // bf16 storage goes with bf16 operands
+  if (lp && (((uintptr_t)y->p & 1) || ((uintptr_t)x->p & 7))) return MI355_EINVAL;
   ConvBArgs a;
   memset(&a.g, 0, sizeof(a.g));
   if (d->moments_out || d->gn_bwd) {
@@ -589,12 +616,12 @@ int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_a
     if (d->gn_bwd) {
       const mi355_gn_bwd_fuse* f = d->gn_bwd;
       if (!f->gx || !f->scale || !f->shift || !f->mean_rstd || !f->partials_out || f->groups <= 0 || y->c % f->groups || f->gx_ld < y->c) return MI355_EINVAL;
-      a.g.gnb = f->partials_out; a.g.gx = f->gx; a.g.gxld = f->gx_ld; a.g.gscale = f->scale; a.g.gshift = f->shift; a.g.gmr = f->mean_rstd;
+      a.g.gnb = f->partials_out; a.g.gx = (const float*)f->gx; a.g.gxld = f->gx_ld; a.g.gscale = f->scale; a.g.gshift = f->shift; a.g.gmr = f->mean_rstd;
       a.g.ggroups = f->groups; a.g.gslope = f->act_slope;
     }
   }
   a.x = (const float*)x->p; a.xld = x->ld; a.wp = (const uint4*)wp; a.y = (float*)y->p; a.yld = y->ld;
-  a.res = d->residual; a.resld = d->residual_ld;
+  a.res = (const float*)d->residual; a.resld = d->residual_ld;
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope;
   a.out_chscale = d->out_chscale; a.bias = d->bias;
   a.N = x->n; a.Di = x->d; a.Hi = x->h; a.Wi = x->w; a.Cin = x->c; a.CinP = (x->c + 15) / 16 * 16;
@@ -603,7 +630,7 @@ int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_a
   a.pad = d->pad;
   if (a.res && a.resld < a.Cout) return MI355_EINVAL;
   const long long vox = (long long)a.Do * a.Ho * a.Wo * a.N;
-  const LpZPlan zp = plan_lp_zring(a.N, a.Cin, a.Cout, a.Do, a.Ho, a.Wo, d->precision, d);
+  const LpZPlan zp = plan_lp_zring(a.N, a.Cin, a.Cout, a.Do, a.Ho, a.Wo, d->precision, d, x->dtype);
   if (zp.use && a.yD == a.Do && a.yH == a.Ho && a.yW == a.Wo && a.Di == a.Do && a.Hi == a.Ho && a.Wi == a.Wo) {
     if (a.g.mom && a.g.gnb) return MI355_EUNSUPPORTED;
     if (a.g.gnb && d->in_mode != MI355_IN_PLAIN) return MI355_EUNSUPPORTED;
@@ -620,6 +647,7 @@ int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_a
     }
     return mi355_lp_zring_launch(a, d->in_mode, fuse, f16, blocks, stream);
   }
+  if (lp) return dispatch_ns<1, false, bf16_t>(a, d->in_mode, vox, stream);
   if (d->precision == MI355_PREC_F16) return dispatch_ns<1, true>(a, d->in_mode, vox, stream);
   if (ns == 1) return dispatch_ns<1>(a, d->in_mode, vox, stream);
   if (ns == 2) return dispatch_ns<2>(a, d->in_mode, vox, stream);

@@ -14,6 +14,7 @@
 #include "hipcompat.h"
 #include "../../include/mi355_unet3d.h"
 #include "gn_fuse.h"
+#include "act_io.h"
 
 struct C4Args {
   const float* x; int xld;
@@ -73,14 +74,15 @@ __device__ __forceinline__ void c4_stage_x(const C4Args& a, float4* lds_x, int n
 // two strides, so a store costs two integer operations instead of the ~40 of the general index arithmetic -- in these kernels
 // (54 or 7*P MFMAs per tile) the 32 stores per lane are a visible share of the tile, unlike in the big convolutions.
 // Returns false when the tile needs the general path (ragged edge, window shift, destination of another extent).
-template <int MT>
+// YT: storage type of y and of the residual (act_io.h). Statistics are taken over the values as stored.
+template <int MT, typename YT = float>
 __device__ __forceinline__ bool c4_store_fast(const C4Args& a, const f32x16 (&acc)[MT], int n, int tz0, int ty0, int tx0, int wave, int half, int co,
                                               bool fuse, float& mK, float& ms0, float& ms1) {
   if (tz0 + 4 > a.D || ty0 + 8 > a.H || tx0 + 8 > a.W || a.offz || a.offy || a.offx || a.yD != a.D || a.yH != a.H || a.yW != a.W) return false;
   if (co >= a.Cout) return true;
   const size_t vox0 = (((size_t)n * a.D + tz0 + wave) * a.H + ty0) * a.W + tx0 + 4 * half;
-  float* yp = a.y + vox0 * a.yld + co;
-  const float* rp = a.res ? a.res + vox0 * a.resld + co : nullptr;
+  YT* yp = reinterpret_cast<YT*>(a.y) + vox0 * a.yld + co;
+  const YT* rp = a.res ? reinterpret_cast<const YT*>(a.res) + vox0 * a.resld + co : nullptr;
   const size_t yrow = (size_t)a.W * a.yld, rrow = (size_t)a.W * a.resld;
   const float bs = a.bias ? a.bias[co] : 0.f, cs = a.out_chscale ? a.out_chscale[(size_t)n * a.Cout + co] : 1.f;
   bool first = true;
@@ -90,9 +92,10 @@ __device__ __forceinline__ bool c4_store_fast(const C4Args& a, const f32x16 (&ac
     for (int r = 0; r < 16; ++r) {
       const int yy = 4 * mt + (r >> 2), xx = r & 3;
       float v = acc[mt][r] + bs;
-      if (rp) v += rp[yy * rrow + (size_t)xx * a.resld];
+      if (rp) v += ld1(rp + yy * rrow + (size_t)xx * a.resld);
       v *= cs;
-      yp[yy * yrow + (size_t)xx * a.yld] = v;
+      st1(yp + yy * yrow + (size_t)xx * a.yld, v);
+      v = as_stored(yp, v);
       if (fuse) {
         if (first) { mK = v; first = false; }
         const float t = v - mK;
@@ -203,8 +206,10 @@ template <> struct C4Prod<1> { static constexpr int P = 1; static constexpr int 
 template <> struct C4Prod<2> { static constexpr int P = 3; static constexpr int pa[3] = {1, 0, 0}; static constexpr int pb[3] = {0, 1, 0}; };
 template <> struct C4Prod<3> { static constexpr int P = 6; static constexpr int pa[6] = {2, 1, 0, 1, 0, 0}; static constexpr int pb[6] = {0, 1, 2, 0, 1, 0}; };   // smallest terms first
 
-template <int NS, int INMODE, bool FUSE, bool F16 = false>      // F16: MI355_PREC_F16, the single plane is fp16
+template <int NS, int INMODE, bool FUSE, bool F16 = false, typename YT = float>      // F16: MI355_PREC_F16, the single plane is fp16
 __global__ __launch_bounds__(256) void conv3d_c4_fwd_bf16(C4Args a) {
+  YT* const ay = reinterpret_cast<YT*>(a.y);
+  const YT* const ares = reinterpret_cast<const YT*>(a.res);
   constexpr int TZ = 4, TY = 8, TX = 8, HZ = 6, HY = 10, HX = 10, HV = HZ * HY * HX, MT = 2, KS = 7;
   constexpr int P = C4Prod<NS>::P;
   __shared__ uint2 lds_x[HV * NS];                 // [halo voxel][plane]: 4 bf16 (the 4 input channels)
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256) void conv3d_c4_fwd_bf16(C4Args a) {
     // ---- epilogue (as conv3d_c4_fwd) ----
     unsigned vmask = 0;
     float mK = 0.f, ms0 = 0.f, ms1 = 0.f;
-    const bool fast = c4_store_fast<MT>(a, acc, n, tz0, ty0, tx0, wave, half, co, FUSE, mK, ms0, ms1);
+    const bool fast = c4_store_fast<MT, YT>(a, acc, n, tz0, ty0, tx0, wave, half, co, FUSE, mK, ms0, ms1);
     if (fast) vmask = 0xffffffffu;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -339,9 +344,10 @@ __global__ __launch_bounds__(256) void conv3d_c4_fwd_bf16(C4Args a) {
         const size_t svox = (((size_t)n * a.yD + sz) * a.yH + sy) * a.yW + sx;
         float v = acc[mt][r];
         if (a.bias) v += a.bias[co];
-        if (a.res) v += a.res[ovox * a.resld + co];
+        if (a.res) v += ld1(ares + ovox * a.resld + co);
         if (a.out_chscale) v *= a.out_chscale[(size_t)n * a.Cout + co];
-        a.y[svox * a.yld + co] = v;
+        st1(ay + svox * a.yld + co, v);
+        v = as_stored(ay, v);
         if constexpr (FUSE) {
           if (first) mK = v;
           const float t = v - mK;
@@ -362,8 +368,9 @@ __global__ __launch_bounds__(256) void conv3d_c4_fwd_bf16(C4Args a) {
 }
 
 // ---- wgrad: one 32-output-channel tile per workgroup column; wave w owns (tap, ci) columns 32w .. 32w+31 ----
-template <int INMODE>
+template <int INMODE, typename TD = float>      // TD: storage type of dy (x, the network input, is fp32)
 __global__ __launch_bounds__(256) void conv3d_c4_wgrad(C4Args a) {
+  const TD* const ady = reinterpret_cast<const TD*>(a.dy);
   constexpr int TZ = 4, TY = 4, TX = 8, TV = TZ * TY * TX, HZ = 6, HY = 6, HX = 10, HV = HZ * HY * HX;
   __shared__ float4 lds_x[HV];            // 5760 B
   __shared__ float lds_dy[TV * 32];       // 16384 B
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(256) void conv3d_c4_wgrad(C4Args a) {
         const int v = sv0 + k * 32;
         int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
         oz = oz < a.D ? oz : a.D - 1; oy = oy < a.H ? oy : a.H - 1; ox = ox < a.W ? ox : a.W - 1;
-        ld[k] = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.D + oz) * a.H + oy) * a.W + ox) * a.dyld + (dyvalid ? cdy : 0));
+        ld[k] = ld4(ady + ((((size_t)n * a.D + oz) * a.H + oy) * a.W + ox) * a.dyld + (dyvalid ? cdy : 0));
       }
 #pragma unroll
       for (int k = 0; k < TV / 32; ++k) {
@@ -465,8 +472,9 @@ struct NarrowArgs {
   int tilesZ, tilesY, tilesX, spatialTiles;
 };
 
-template <int CQ>
+template <int CQ, typename XT = float, typename YT = float>      // storage types of the input (a gradient tensor) and of the <= 4-channel output
 __global__ __launch_bounds__(256) void conv3d_c4_dgrad(NarrowArgs a) {
+  const XT* const ax = reinterpret_cast<const XT*>(a.x);
   constexpr int TZ = 4, TY = 8, TX = 8, HZ = 6, HY = 10, HX = 10, HV = HZ * HY * HX;
   DYN_LDS(lds_f);                           // float4 [HV][CQ], quad q of haloed voxel (hz,hy,hx) at slot q ^ ((hx + hy) & (CQ - 1))
   float4* lds = reinterpret_cast<float4*>(lds_f);
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(256) void conv3d_c4_dgrad(NarrowArgs a) {
         iz = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1);
         iy = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1);
         ix = ix < 0 ? 0 : (ix < a.W ? ix : a.W - 1);
-        ld[k] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + 4 * (c0 + q));
+        ld[k] = ld4(ax + ((((size_t)n * a.D + iz) * a.H + iy) * a.W + ix) * a.xld + 4 * (c0 + q));
       }
 #pragma unroll
       for (int k = 0; k < UP; ++k) {
@@ -536,10 +544,10 @@ __global__ __launch_bounds__(256) void conv3d_c4_dgrad(NarrowArgs a) {
   }
   const int oz = tz0 + lz, oy = ty0 + ly, ox = tx0 + lx;
   if (oz < a.D && oy < a.H && ox < a.W) {
-    float* dst = a.y + ((((size_t)n * a.D + oz) * a.H + oy) * a.W + ox) * a.yld;
+    YT* dst = reinterpret_cast<YT*>(a.y) + ((((size_t)n * a.D + oz) * a.H + oy) * a.W + ox) * a.yld;
 #pragma unroll
     for (int o = 0; o < 4; ++o)
-      if (o < a.Cout) dst[o] = (acc[o][0].x + acc[o][0].y) + (acc[o][1].x + acc[o][1].y);
+      if (o < a.Cout) st1(dst + o, (acc[o][0].x + acc[o][0].y) + (acc[o][1].x + acc[o][1].y));
   }
 }
 
@@ -558,8 +566,10 @@ int mi355_conv3d_c4_ok(const mi355_act* x, const mi355_conv_desc* d) {
 // wp = the UNPACKED OIDHW weight
 int mi355_conv3d_c4_fwd_impl(const mi355_act* x, const float* w, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
   if (!mi355_conv3d_c4_ok(x, d) || d->out_d != x->d || d->out_h != x->h || d->out_w != x->w) return MI355_EUNSUPPORTED;
+  // the 4-channel input is the network's input volume: fp32. A 16-bit output is written by the 16-bit-precision kernels only.
+  if (x->dtype != MI355_ACT_F32 || !act_dtype_ok(y) || (y->dtype != MI355_ACT_F32 && d->precision == MI355_PREC_F32)) return MI355_EUNSUPPORTED;
   C4Args a; c4_fill(a, x, d);
-  a.w = w; a.y = (float*)y->p; a.yld = y->ld; a.res = d->residual; a.resld = d->residual_ld;
+  a.w = w; a.y = (float*)y->p; a.yld = y->ld; a.res = (const float*)d->residual; a.resld = d->residual_ld;
   a.out_chscale = d->out_chscale; a.bias = d->bias; a.Cout = y->c;
   a.yD = y->d; a.yH = y->h; a.yW = y->w; a.offz = d->off_z; a.offy = d->off_y; a.offx = d->off_x;
   if (a.res && a.resld < a.Cout) return MI355_EINVAL;
@@ -577,8 +587,10 @@ int mi355_conv3d_c4_fwd_impl(const mi355_act* x, const float* w, const mi355_act
     const long long wg = cols * a.splits;
     if (wg > 0x7fffffffLL) return MI355_EINVAL;
     const int ns = d->precision == MI355_PREC_BF16X3 ? 2 : (d->precision == MI355_PREC_BF16X6 ? 3 : 1);
+    if (y->dtype == MI355_ACT_BF16 && d->precision != MI355_PREC_BF16) return MI355_EUNSUPPORTED;      // bf16 storage goes with bf16 operands
 #define MI355_C4B(NSV, IM, FU) \
     do { if (d->precision == MI355_PREC_F16) LAUNCH((conv3d_c4_fwd_bf16<NSV == 1 ? 1 : NSV, IM, FU, NSV == 1>), dim3((unsigned)wg), dim3(256), 0, stream, a); \
+         else if (y->dtype == MI355_ACT_BF16) LAUNCH((conv3d_c4_fwd_bf16<1, IM, FU, false, bf16_t>), dim3((unsigned)wg), dim3(256), 0, stream, a); \
          else LAUNCH((conv3d_c4_fwd_bf16<NSV, IM, FU>), dim3((unsigned)wg), dim3(256), 0, stream, a); } while (0)
 #define MI355_C4B_NS(NSV)                                                                                  \
     do {                                                                                                   \
@@ -622,13 +634,15 @@ size_t mi355_conv3d_c4_wgrad_workspace(const mi355_act* x, const mi355_act* dy, 
 int mi355_conv3d_c4_wgrad_impl(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d,
                                void* ws, size_t ws_bytes, void* stream) {
   if (!mi355_conv3d_c4_ok(x, d) || x->d != dy->d || x->h != dy->h || x->w != dy->w) return MI355_EUNSUPPORTED;
+  if (x->dtype != MI355_ACT_F32 || !act_dtype_ok(dy)) return MI355_EUNSUPPORTED;
   C4Args a; c4_fill(a, x, d);
   if (!c4_wgrad_plan(x, dy, a)) return MI355_EINVAL;
   if (ws_bytes < (size_t)a.coTiles * a.splits * 4096 * sizeof(float)) return MI355_EWORKSPACE;
   a.dy = (const float*)dy->p; a.dyld = dy->ld; a.ws = (float*)ws; a.Cout = dy->c;
   dim3 grid(a.splits, a.coTiles);
-  if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_c4_wgrad<MI355_IN_PLAIN>), grid, dim3(256), 0, stream, a);
-  else LAUNCH((conv3d_c4_wgrad<MI355_IN_AFFINE_ACT>), grid, dim3(256), 0, stream, a);
+  ACT_TYPED(dy->dtype, TD,
+            if (d->in_mode == MI355_IN_PLAIN) LAUNCH((conv3d_c4_wgrad<MI355_IN_PLAIN, TD>), grid, dim3(256), 0, stream, a);
+            else LAUNCH((conv3d_c4_wgrad<MI355_IN_AFFINE_ACT, TD>), grid, dim3(256), 0, stream, a));
   int rc = LAUNCH_CHECK(); if (rc) return rc;
   LAUNCH(conv3d_c4_wgrad_reduce, dim3(a.coTiles * 128), dim3(256), 0, stream, (const float*)ws, dw, a.Cout, a.splits);
   return LAUNCH_CHECK();
@@ -654,6 +668,7 @@ int mi355_conv3d_narrow_impl(const mi355_act* x, const float* wp, const mi355_ac
   // 16 input channels per LDS chunk: 38.4 KB and 103 VGPRs -> four workgroups per CU (measured on the 128^3 batch-2 layer: 0.53 ms;
   // 32-channel chunks, two workgroups per CU: 0.67 ms; 8-channel chunks: 0.96 ms)
   constexpr size_t lds = (size_t)6 * 10 * 10 * 4 * 16;
-  LAUNCH(conv3d_c4_dgrad<4>, dim3((unsigned)sp), dim3(256), lds, stream, a);
+  if (!act_dtype_ok(x) || !act_dtype_ok(y)) return MI355_EINVAL;
+  ACT_TYPED(x->dtype, XT, ACT_TYPED(y->dtype, YT, LAUNCH((conv3d_c4_dgrad<4, XT, YT>), dim3((unsigned)sp), dim3(256), lds, stream, a)));
   return LAUNCH_CHECK();
 }

@@ -16,6 +16,7 @@
 #include "../../include/mi355_unet3d.h"
 #include "gn_fuse.h"
 #include "pack_values.h"
+#include "act_io.h"
 
 struct ConvArgs {
   const float* x; int xld;
@@ -50,9 +51,17 @@ constexpr int conv_min_waves(int tiles, bool tl, int wn, bool fullj) {
   return tiles == 1 ? 4 : tiles == 2 ? (wn == 2 ? 4 : fullj ? 3 : 2) : 2;
 }
 
-template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT, int INMODE, bool TL = false, bool FULLJ = false, int FUSE = 0>
+// TA: storage type of x, y, the residual and the normalised tensor of the norm-backward sums (act_io.h: float, or bf16_t for the
+// HBM-bound forms a network with 16-bit activation storage runs here: 1x1x1, stride 2, zero-insert). The 16-bit forms keep fp32 MFMA
+// operands -- the staged values are widened on load -- and round once, on store; statistics are taken over the values as stored.
+template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT, int INMODE, bool TL = false, bool FULLJ = false, int FUSE = 0,
+          typename TA = float>
 __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(conv_min_waves(MT * NT, TL, WN, FULLJ))
 void conv3d_mfma(ConvArgs a) {
+  const TA* const ax = reinterpret_cast<const TA*>(a.x);
+  TA* const ay = reinterpret_cast<TA*>(a.y);
+  const TA* const ares = reinterpret_cast<const TA*>(a.res);
+  const TA* const agx = reinterpret_cast<const TA*>(a.g.gx);
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TZ * TY * TX == 32 * WM * MT, "tile voxels must equal 32*WM*MT");
   static_assert(KC % 8 == 0, "channel chunk is a multiple of 8");
@@ -165,7 +174,7 @@ void conv3d_mfma(ConvArgs a) {
           if (cvalid && v < a.Wi) {
             const int xx = v % a.cW, yy = (v / a.cW) % a.cH, zz = v / (a.cW * a.cH);
             const size_t fv = (((size_t)n * (2 * a.cD) + 2 * zz + pa) * (2 * a.cH) + 2 * yy + pb) * (2 * a.cW) + 2 * xx + pe;
-            val = *reinterpret_cast<const float4*>(a.x + fv * a.xld + k);
+            val = ld4(ax + fv * a.xld + k);
           }
           *reinterpret_cast<float4*>(lds + hv * VS + 4 * sq) = val;
         }
@@ -179,7 +188,7 @@ void conv3d_mfma(ConvArgs a) {
           if (hv >= ZHV) hv = ZHV - 1;
           int iz = tz0 / 2 + hv / (ZCY * ZCX), iy = ty0 / 2 + (hv / ZCX) % ZCY, ix = tx0 / 2 + hv % ZCX;
           iz = iz < a.Di ? iz : a.Di - 1; iy = iy < a.Hi ? iy : a.Hi - 1; ix = ix < a.Wi ? ix : a.Wi - 1;
-          ld[k] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (cvalid ? c : 0));
+          ld[k] = ld4(ax + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (cvalid ? c : 0));
         }
 #pragma unroll
         for (int k = 0; k < UP; ++k) {
@@ -213,7 +222,7 @@ void conv3d_mfma(ConvArgs a) {
         const int ix = tx0 * STRIDE - a.pad + hx;
         const bool xok = tact && crv && ix >= 0 && ix < a.Wi;
         const int ixc = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
-        const float* colp = a.x + (size_t)ixc * a.xld + (crv ? cr : 0);      // this thread's column: row offset added per unit
+        const TA* colp = ax + (size_t)ixc * a.xld + (crv ? cr : 0);      // this thread's column: row offset added per unit
         const unsigned rowpitch = (unsigned)a.Wi * (unsigned)a.xld;           // floats per (z, y) row
         const int hz0 = rt / HY, hy0 = rt % HY;
         float* ldst = lds + ((rt * HX + hx) * VS + 4 * q4);                  // + k * RP * HX * VS per unit: an immediate
@@ -231,7 +240,7 @@ void conv3d_mfma(ConvArgs a) {
             const int iz = tz0 * STRIDE - a.pad + hz, iy = ty0 * STRIDE - a.pad + hy;
             const int izc = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1), iyc = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
             ok[kk] = xok && iz >= 0 && iz < a.Di && iy >= 0 && iy < a.Hi;
-            ld[kk] = *reinterpret_cast<const float4*>(colp + (size_t)(unsigned)((n * a.Di + izc) * a.Hi + iyc) * rowpitch);
+            ld[kk] = ld4(colp + (size_t)(unsigned)((n * a.Di + izc) * a.Hi + iyc) * rowpitch);
           }
 #pragma unroll
           for (int kk = 0; kk < UB; ++kk) {
@@ -266,7 +275,7 @@ void conv3d_mfma(ConvArgs a) {
             iz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
             iy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
             ix = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
-            ld[kk] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (cvalid ? c : 0));
+            ld[kk] = ld4(ax + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (cvalid ? c : 0));
           }
 #pragma unroll
           for (int kk = 0; kk < UB; ++kk) {
@@ -433,25 +442,26 @@ void conv3d_mfma(ConvArgs a) {
         for (int mt = 0; mt < MT; ++mt) {
           const int tv0 = (wm * MT + mt) * 32 + 4 * half;      // this lane's voxel for r = 0
           const size_t v0 = (((size_t)n * a.Do + tz0 + tv0 / (TY * TX)) * a.Ho + ty0 + (tv0 / TX) % TY) * a.Wo + tx0 + tv0 % TX;
-          float* yp = a.y + v0 * a.yld + coc;
-          const float* rp = a.res ? a.res + v0 * a.resld + coc : nullptr;
+          TA* yp = ay + v0 * a.yld + coc;
+          const TA* rp = a.res ? ares + v0 * a.resld + coc : nullptr;
           // FUSE 2: the 16 reads of the normalised tensor of this tile go out ahead of their use
           constexpr int GB = 16;
-          const float* gp = FUSE == 2 ? a.g.gx + v0 * a.g.gxld + coc : nullptr;
+          const TA* gp = FUSE == 2 ? agx + v0 * a.g.gxld + coc : nullptr;
 #pragma unroll
           for (int r0 = 0; r0 < 16; r0 += GB) {
             float gxv[GB];
             if constexpr (FUSE == 2) {
 #pragma unroll
-              for (int r = r0; r < r0 + GB; ++r) gxv[r - r0] = gp[((size_t)(r >> 2) * rowstep + (r & 3)) * a.g.gxld];
+              for (int r = r0; r < r0 + GB; ++r) gxv[r - r0] = ld1(gp + ((size_t)(r >> 2) * rowstep + (r & 3)) * a.g.gxld);
             }
 #pragma unroll
             for (int r = r0; r < r0 + GB; ++r) {
               const size_t eo = (size_t)(r >> 2) * rowstep + (r & 3);      // wave-uniform
               float v = acc[mt][nt][r] + bs;
-              if (a.res) v += rp[eo * a.resld];
+              if (a.res) v += ld1(rp + eo * a.resld);
               v *= cs;
-              if (cov) yp[eo * a.yld] = v;
+              if (cov) st1(yp + eo * a.yld, v);
+              if constexpr (FUSE != 0) v = as_stored(yp, v);
               if constexpr (FUSE == 1) {
                 if (mt == 0 && r == 0) K0 = v;
                 const float t = v - K0;
@@ -505,7 +515,7 @@ void conv3d_mfma(ConvArgs a) {
             const size_t fv = (((size_t)n * (2 * a.cD) + 2 * zz + (p >> 2)) * (2 * a.cH) + 2 * yy + ((p >> 1) & 1)) * (2 * a.cW) + 2 * xx + (p & 1);
             float v = acc[mt][nt][r];
             if (a.bias) v += a.bias[k];
-            a.y[fv * a.yld + k] = v;
+            st1(ay + fv * a.yld + k, v);
           }
           continue;
         }
@@ -519,9 +529,9 @@ void conv3d_mfma(ConvArgs a) {
           if (co >= a.Cout) continue;
           float v = acc[mt][nt][r];
           if (a.bias) v += a.bias[co];
-          if (a.res) v += a.res[ovox * a.resld + co];
+          if (a.res) v += ld1(ares + ovox * a.resld + co);
           if (a.out_chscale) v *= a.out_chscale[(size_t)n * a.Cout + co];
-          a.y[svox * a.yld + co] = v;
+          st1(ay + svox * a.yld + co, v);
         }
       }
     }
@@ -560,7 +570,7 @@ void conv3d_mfma(ConvArgs a) {
             const int tv = (wm * MT + mt) * 32 + row;
             int oz = tz0 + tv / (TY * TX), oy = ty0 + (tv / TX) % TY, ox = tx0 + tv % TX;
             oz = oz < a.Do ? oz : a.Do - 1; oy = oy < a.Ho ? oy : a.Ho - 1; ox = ox < a.Wo ? ox : a.Wo - 1;
-            gxv[r] = a.g.gx[((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.g.gxld + coc];
+            gxv[r] = ld1(agx + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.g.gxld + coc);
           }
         }
 #pragma unroll
@@ -571,9 +581,10 @@ void conv3d_mfma(ConvArgs a) {
           if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo || !cov) continue;
           const size_t ovox = (((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
           float v = acc[mt][nt][r] + bs;
-          if (a.res) v += a.res[ovox * a.resld + co];
+          if (a.res) v += ld1(ares + ovox * a.resld + co);
           v *= cs;
-          a.y[ovox * a.yld + co] = v;
+          st1(ay + ovox * a.yld + co, v);
+          v = as_stored(ay, v);
           if constexpr (FUSE == 1) {
             if (cnt == 0) K0 = v;
             const float t = v - K0;
@@ -671,7 +682,15 @@ extern "C" int mi355_pack_conv_weight(const float* w, float* wp, int32_t cout, i
 }
 
 // ---- dispatch ---------------------------------------------------------------------------------
-template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT>
+// the forms that exist for 16-bit activation storage: what a UNet3D with activation_storage="bf16" sends here (the 3x3x3 stride-1
+// convolutions of that network run on the 16-bit-operand kernels of conv3d_bf16*.hip): 1x1x1 on a plain input, 3x3x3 stride 2 on a plain
+// input (with or without the moments epilogue), and the zero-insert form (stride-2 dgrad, ConvTranspose3d(k3, s2))
+template <typename TA> constexpr bool act_form_exists(int kd, int stride, int im, int fuse) {
+  return std::is_same<TA, float>::value || (kd == 1 && im == MI355_IN_PLAIN && fuse == 0) ||
+         (kd == 3 && stride == 2 && im == MI355_IN_PLAIN && fuse <= 1) || (kd == 3 && im == MI355_IN_ZERO_INSERT && fuse == 0);
+}
+
+template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT, typename TA = float>
 static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
   constexpr int HZ = (TZ - 1) * STRIDE + KD, HY = (TY - 1) * STRIDE + KD, HX = (TX - 1) * STRIDE + KD;
   constexpr size_t lds = (size_t)HZ * HY * HX * (KC + PADV) * sizeof(float);
@@ -690,10 +709,11 @@ static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
   if (fuse && (KD != 3 || (in_mode != MI355_IN_PLAIN && in_mode != MI355_IN_AFFINE_ACT))) return MI355_EUNSUPPORTED;
 #define MI355_LAUNCH_CONV4(SS, IM, LDSB, FU)                                                                                         \
   do {                                                                                                                         \
-    if (tl && fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, true, FU>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);  \
-    else if (tl) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, false, FU>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);      \
-    else if (fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, true, FU>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);       \
-    else LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, false, FU>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);                 \
+    if constexpr (!act_form_exists<TA>(KD, STRIDE, IM, FU)) return MI355_EUNSUPPORTED;                                          \
+    else if (tl && fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, true, FU, TA>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);  \
+    else if (tl) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, false, FU, TA>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);      \
+    else if (fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, true, FU, TA>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);       \
+    else LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, false, FU, TA>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);                 \
   } while (0)
 #define MI355_LAUNCH_CONV(SS, IM, LDSB)                                                                                              \
   do {                                                                                                                         \
@@ -800,7 +820,7 @@ static int fill_gn_fuse(GnFuseArgs& g, const mi355_act* x, const mi355_act* y, c
     const mi355_gn_bwd_fuse* f = d->gn_bwd;
     if (!f->gx || !f->scale || !f->shift || !f->mean_rstd || !f->partials_out || f->groups <= 0 || y->c % f->groups || f->gx_ld < y->c)
       return MI355_EINVAL;
-    g.gnb = f->partials_out; g.gx = f->gx; g.gxld = f->gx_ld; g.gscale = f->scale; g.gshift = f->shift; g.gmr = f->mean_rstd;
+    g.gnb = f->partials_out; g.gx = (const float*)f->gx; g.gxld = f->gx_ld; g.gscale = f->scale; g.gshift = f->shift; g.gmr = f->mean_rstd;
     g.ggroups = f->groups; g.gslope = f->act_slope;
   }
   return 0;
@@ -809,8 +829,8 @@ static int fill_gn_fuse(GnFuseArgs& g, const mi355_act* x, const mi355_act* y, c
 extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
   if (!x || !y || !wp || !d || !x->p || !y->p) return MI355_EINVAL;
   if ((d->kd != 1 && d->kd != 3) || (d->stride != 1 && d->stride != 2)) return MI355_EUNSUPPORTED;
-  if (x->c % 4 || x->ld % 4 || x->ld < x->c || y->ld < y->c || x->n != y->n) return MI355_EINVAL;
-  if (((uintptr_t)x->p & 15) || ((uintptr_t)wp & 15)) return MI355_EINVAL;
+  if (x->c % 4 || x->ld % 4 || x->ld < x->c || y->ld < y->c || x->n != y->n || !act_dtype_ok(x) || !act_dtype_ok(y)) return MI355_EINVAL;
+  if (((uintptr_t)x->p & (x->dtype == MI355_ACT_BF16 ? 7 : 15)) || ((uintptr_t)wp & 15)) return MI355_EINVAL;
   if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift)) return MI355_EINVAL;
   if (d->in_mode == MI355_IN_AFFINE_ACT && !(d->act_slope >= 0.f && d->act_slope <= 1.f)) return MI355_EINVAL;   // act(u) = max(u, slope*u)
   if (d->in_mode < 0 || d->in_mode > 3) return MI355_EINVAL;
@@ -829,9 +849,12 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
     return mi355_conv3d_fwd_bf16_impl(x, wp, y, d, stream);
   }
   if (d->in_mode == MI355_IN_ZERO_INSERT && (d->stride != 1 || d->kd != 3 || d->pad != 1)) return MI355_EINVAL;
+  if (x->dtype != y->dtype) return MI355_EUNSUPPORTED;      // one storage type per call here (the first-layer kernels above take fp32 x with either y)
+  const bool lp = x->dtype == MI355_ACT_BF16;
+  if (lp && (y->c % 4 || y->ld % 4 || ((uintptr_t)y->p & 7))) return MI355_EINVAL;
   ConvArgs a;
   a.x = (const float*)x->p; a.xld = x->ld; a.wp = wp; a.y = (float*)y->p; a.yld = y->ld;
-  a.res = d->residual; a.resld = d->residual_ld;
+  a.res = (const float*)d->residual; a.resld = d->residual_ld;
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope;
   a.out_chscale = d->out_chscale; a.bias = d->bias;
   a.N = x->n; a.Di = x->d; a.Hi = x->h; a.Wi = x->w; a.Cin = x->c; a.CinP = (x->c + 7) / 8 * 8;
@@ -866,8 +889,21 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
     }
     if (vin != vout || vy != vout || a.offz || a.offy || a.offx || vin > 0x7fffffffLL) return MI355_EUNSUPPORTED;
     f.Di = f.Hi = 1; f.Wi = (int)vin; f.Do = f.Ho = 1; f.Wo = (int)vout; f.yD = f.yH = 1; f.yW = (int)vy; f.pad = 0;
+    if (lp) {
+      if (cfg1 == 0) return launch_cfg<1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 2, bf16_t>(f, im, stream);
+      return launch_cfg<1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 1, bf16_t>(f, im, stream);
+    }
     if (cfg1 == 0) return launch_cfg<1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 2>(f, im, stream);
     return launch_cfg<1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 1>(f, im, stream);
+  }
+  if (lp) {
+    switch (cfg) {      // (16-bit storage with exact-fp32 3x3x3 stride-1 arithmetic: no such kernel, act_form_exists)
+      case 2: return launch_cfg<3, 2, 4, 4, 8, 8, 0, 4, 1, 1, 2, bf16_t>(a, im, stream);
+      case 3: return launch_cfg<3, 2, 4, 4, 8, 8, 0, 4, 1, 1, 1, bf16_t>(a, im, stream);
+      case 4: return launch_cfg<3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 2, bf16_t>(a, im, stream);
+      case 5: return launch_cfg<3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 1, bf16_t>(a, im, stream);
+      default: return MI355_EUNSUPPORTED;
+    }
   }
   switch (cfg) {
     case 2: return launch_cfg<3, 2, 4, 4, 8, 8, 0, 4, 1, 1, 2>(a, im, stream);

@@ -17,6 +17,7 @@
 //                       whole in LDS, register-prefetch software pipeline.
 #include "hipcompat.h"
 #include "../../include/mi355_unet3d.h"
+#include "act_io.h"
 
 struct WgradArgs {
   const float* x; int xld;
@@ -33,8 +34,11 @@ struct WgradArgs {
   int cD, cH, cW, fC;
 };
 
-template <int KD, int STRIDE, int TZ, int TY, int TX, int INMODE>
+// TA: storage type of x and dy (act_io.h); the struct carries them as float pointers whatever the type
+template <int KD, int STRIDE, int TZ, int TY, int TX, int INMODE, typename TA = float>
 __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
+  const TA* const ax = reinterpret_cast<const TA*>(a.x);
+  const TA* const ady = reinterpret_cast<const TA*>(a.dy);
   constexpr int T = KD * KD * KD;
   constexpr int TV = TZ * TY * TX;
   constexpr int HZ = (TZ - 1) * STRIDE + KD, HY = (TY - 1) * STRIDE + KD, HX = (TX - 1) * STRIDE + KD;
@@ -98,11 +102,11 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
         int ox = tx0 + v; if (ox >= a.Wo) ox = a.Wo - 1;
         const int xx = ox % a.cW, yy = (ox / a.cW) % a.cH, zz = ox / (a.cW * a.cH);
         const size_t fv = (((size_t)n * (2 * a.cD) + 2 * zz + (d2s_p >> 2)) * (2 * a.cH) + 2 * yy + ((d2s_p >> 1) & 1)) * (2 * a.cW) + 2 * xx + (d2s_p & 1);
-        pdy[k] = *reinterpret_cast<const float4*>(a.dy + fv * a.dyld + (dyvalid ? d2s_k : 0));
+        pdy[k] = ld4(ady + fv * a.dyld + (dyvalid ? d2s_k : 0));
       } else {
         int oz = tz0 + v / (TY * TX), oy = ty0 + (v / TX) % TY, ox = tx0 + v % TX;
         oz = oz < a.Do ? oz : a.Do - 1; oy = oy < a.Ho ? oy : a.Ho - 1; ox = ox < a.Wo ? ox : a.Wo - 1;
-        pdy[k] = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.dyld + (dyvalid ? cdy : 0));
+        pdy[k] = ld4(ady + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.dyld + (dyvalid ? cdy : 0));
       }
     }
 #pragma unroll
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma(WgradArgs a) {
       iz = iz < 0 ? 0 : (iz < a.Di ? iz : a.Di - 1);
       iy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1);
       ix = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
-      px[k] = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (xvalid ? cx : 0));
+      px[k] = ld4(ax + ((((size_t)n * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.xld + (xvalid ? cx : 0));
     }
   };
   // mask / transform the prefetched registers of `tile` and write them to LDS
@@ -516,31 +520,33 @@ extern "C" size_t mi355_conv3d_wgrad_workspace(const mi355_act* x, const mi355_a
   return p.ok ? p.ws_bytes : 0;
 }
 
-template <int KD, int STRIDE, int TZ, int TY, int TX>
+template <int KD, int STRIDE, int TZ, int TY, int TX, typename TA>
 static int launch_wgrad(WgradArgs& a, int in_mode, void* stream) {
   constexpr int HZ = (TZ - 1) * STRIDE + KD, HY = (TY - 1) * STRIDE + KD, HX = (TX - 1) * STRIDE + KD;
   constexpr size_t lds = (size_t)(TZ * TY * TX + HZ * HY * HX) * 32 * sizeof(float);
   static_assert(lds <= 64 * 1024, "LDS tile must fit the default 64 KiB dynamic window");
   dim3 grid(a.splits, a.ciTiles, a.coTiles);
   if (in_mode == MI355_IN_PLAIN)
-    LAUNCH((conv3d_wgrad_mfma<KD, STRIDE, TZ, TY, TX, MI355_IN_PLAIN>), grid, dim3(256), lds, stream, a);
+    LAUNCH((conv3d_wgrad_mfma<KD, STRIDE, TZ, TY, TX, MI355_IN_PLAIN, TA>), grid, dim3(256), lds, stream, a);
   else
-    LAUNCH((conv3d_wgrad_mfma<KD, STRIDE, TZ, TY, TX, MI355_IN_AFFINE_ACT>), grid, dim3(256), lds, stream, a);
+    LAUNCH((conv3d_wgrad_mfma<KD, STRIDE, TZ, TY, TX, MI355_IN_AFFINE_ACT, TA>), grid, dim3(256), lds, stream, a);
   return LAUNCH_CHECK();
 }
 
 extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d,
                                   void* ws, size_t ws_bytes, void* stream) {
   if (!x || !dy || !dw || !d || !ws || !x->p || !dy->p) return MI355_EINVAL;
-  if (x->c % 4 || x->ld % 4 || dy->c % 4 || dy->ld % 4 || x->n != dy->n) return MI355_EINVAL;
-  if (((uintptr_t)x->p & 15) || ((uintptr_t)dy->p & 15)) return MI355_EINVAL;
+  if (x->c % 4 || x->ld % 4 || dy->c % 4 || dy->ld % 4 || x->n != dy->n || !act_dtype_ok(x) || !act_dtype_ok(dy)) return MI355_EINVAL;
+  if (((uintptr_t)x->p & (x->dtype == MI355_ACT_BF16 ? 7 : 15)) || ((uintptr_t)dy->p & (dy->dtype == MI355_ACT_BF16 ? 7 : 15))) return MI355_EINVAL;
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
   if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift)) return MI355_EINVAL;
   if (d->in_mode == MI355_IN_AFFINE_ACT && !(d->act_slope >= 0.f && d->act_slope <= 1.f)) return MI355_EINVAL;
   if (d->precision < MI355_PREC_F32 || d->precision > MI355_PREC_F16) return MI355_EINVAL;
   if (mi355_conv3d_c4_ok(x, d)) return mi355_conv3d_c4_wgrad_impl(x, dy, dw, d, ws, ws_bytes, stream);
   if (wgrad_uses_bf16(d)) return mi355_conv3d_wgrad_bf16_impl(x, dy, dw, d, ws, ws_bytes, stream);
+  if (x->dtype != dy->dtype) return MI355_EUNSUPPORTED;       // (the first-layer kernel above takes fp32 x with either dy)
   if (wgrad_uses_ring(d)) {
+    if (x->dtype != MI355_ACT_F32) return MI355_EUNSUPPORTED;   // exact-fp32 3x3x3 arithmetic on 16-bit tensors: no kernel (and no caller)
     RingPlan r = plan_wgrad_ring(x, dy);
     if (!r.ok) return MI355_EUNSUPPORTED;
     if (ws_bytes < r.ws_bytes) return MI355_EWORKSPACE;
@@ -581,9 +587,9 @@ extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float
     const long long vo = d->out_mode == MI355_OUT_D2S ? vi : (long long)dy->d * dy->h * dy->w;
     if (vi != vo) return MI355_EINVAL;
     a.Di = a.Hi = 1; a.Wi = (int)vi; a.Do = a.Ho = 1; a.Wo = (int)vo; a.pad = 0;
-    rc = launch_wgrad<1, 1, 1, 1, 256>(a, d->in_mode, stream);
+    ACT_TYPED(x->dtype, TA, rc = (launch_wgrad<1, 1, 1, 1, 256, TA>(a, d->in_mode, stream)));
   } else if (d->stride == 2) {
-    rc = launch_wgrad<3, 2, 2, 2, 8>(a, d->in_mode, stream);
+    ACT_TYPED(x->dtype, TA, rc = (launch_wgrad<3, 2, 2, 2, 8, TA>(a, d->in_mode, stream)));
   } else {
     return MI355_EUNSUPPORTED;       // 3x3x3 stride 1 with pad != 1 (pad 1 runs on conv3d_wgrad_ring above)
   }

@@ -19,6 +19,7 @@
 #include "hipcompat.h"
 #include <cstdlib>
 #include "../../include/mi355_unet3d.h"
+#include "act_io.h"
 
 int mi355_wgrad_reduce_launch(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles, void* stream);
 
@@ -68,7 +69,8 @@ __device__ __forceinline__ uint4 shift_run(const uint4& b0, const uint4& b1) {
 // global memory -- every load of the tile issued before the first use, from clamped always-valid addresses (a branch around a
 // load would serialise the round trips) --, transform/split/transpose it and write it to the other dy buffer / the free slot
 // of a 4-plane ring. One barrier per tile; global-memory latency is never on the consumers' path.
-template <int NS, int MT, int NLW, int INMODE, bool F16 = false>      // F16: MI355_PREC_F16, the single plane is fp16
+// TA: storage type of x and dy (act_io.h; bf16 storage halves the bytes this kernel is bound by, profiles/r4_ab_experiments.txt section 6)
+template <int NS, int MT, int NLW, int INMODE, bool F16 = false, typename TA = float>      // F16: MI355_PREC_F16, the single plane is fp16
 __global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArgs a) {
   constexpr int TY = 4, ROWS = 4, HY = 6, XO = 3, RING = 4;
   constexpr int COT = 32 * MT;
@@ -107,23 +109,23 @@ __global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArg
         for (int k = 0; k < UPT; ++k) {
           const int u = u0 + k * NLOAD;
           const bool isx = u < nx;
-          int c, iz, iy, ix0, ld; const float* base;
+          int c, iz, iy, ix0, ld; const TA* base;
           if (isx) {
             const int ro = u >> 3, oct = ro % XO, hy = (ro / XO) % HY;
             c = ci0 + 4 * (u & 7); if (c >= a.Cin) c = 0;
-            iz = z_lo + ro / (XO * HY); iy = ty0 - 1 + hy; ix0 = tx0 - 1 + 8 * oct; ld = a.xld; base = a.x;
+            iz = z_lo + ro / (XO * HY); iy = ty0 - 1 + hy; ix0 = tx0 - 1 + 8 * oct; ld = a.xld; base = reinterpret_cast<const TA*>(a.x);
           } else {
             const int v = u - nx, qq = v % (8 * MT), ro = v / (8 * MT);
             c = co0 + 4 * qq; if (c >= a.Cout) c = 0;
-            iz = z; iy = ty0 + (ro >> 1); ix0 = tx0 + 8 * (ro & 1); ld = a.dyld; base = a.dy;
+            iz = z; iy = ty0 + (ro >> 1); ix0 = tx0 + 8 * (ro & 1); ld = a.dyld; base = reinterpret_cast<const TA*>(a.dy);
           }
           const int izc = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1), iyc = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1);
-          const float* rowp = base + (((size_t)n * a.D + izc) * a.H + iyc) * (size_t)a.W * ld + c;
+          const TA* rowp = base + (((size_t)n * a.D + izc) * a.H + iyc) * (size_t)a.W * ld + c;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int ix = ix0 + e;
             const int ixc = ix < 0 ? 0 : (ix < a.W ? ix : a.W - 1);
-            t8[k][e] = *reinterpret_cast<const float4*>(rowp + (size_t)ixc * ld);
+            t8[k][e] = ld4(rowp + (size_t)ixc * ld);
           }
         }
         // ---- transform, split, transpose, write ----
@@ -282,6 +284,7 @@ static WBPlan plan_wb(const mi355_act* x, const mi355_act* dy, const mi355_conv_
   WBPlan p; memset(&p, 0, sizeof(p));
   if (!x || !dy || !d || !nsplit_of_w(d->precision)) return p;
   if (d->kd != 3 || d->stride != 1 || d->pad != 1) return p;
+  if (x->dtype != dy->dtype || (x->dtype == MI355_ACT_BF16 && d->precision != MI355_PREC_BF16)) return p;      // bf16 storage goes with bf16 operands
   if (x->d != dy->d || x->h != dy->h || x->w != dy->w) return p;
   p.tilesY = ceil_div(dy->h, 4); p.tilesX = ceil_div(dy->w, 16);
   const long long nt = (long long)dy->n * p.tilesY * p.tilesX * dy->d;
@@ -307,18 +310,18 @@ size_t mi355_conv3d_wgrad_bf16_workspace(const mi355_act* x, const mi355_act* dy
   return p.ok ? p.ws_bytes : 0;
 }
 
-template <int NS, int MT, bool F16 = false>
+template <int NS, int MT, bool F16 = false, typename TA = float>
 static int launch_wb(WgradBArgs& a, const WBPlan& p, int in_mode, void* stream) {
   constexpr int NLW = MT == 1 ? 4 : 3;     // producer waves: 4 cover a tile's 208 staging units in one round; MT = 2 is VGPR-limited to 12 waves
   constexpr size_t lds = ((size_t)2 * NS * 32 * MT * 9 + (size_t)NS * 32 * 73) * 16;
   static_assert(lds <= 160 * 1024, "LDS");
   dim3 grid(p.splits, p.ciTiles, p.coTilesWG);
   if (in_mode == MI355_IN_PLAIN) {
-    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_PLAIN, F16>), lds);
-    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_PLAIN, F16>), grid, dim3(576 + 64 * NLW), lds, stream, a);
+    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_PLAIN, F16, TA>), lds);
+    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_PLAIN, F16, TA>), grid, dim3(576 + 64 * NLW), lds, stream, a);
   } else {
-    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_AFFINE_ACT, F16>), lds);
-    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_AFFINE_ACT, F16>), grid, dim3(576 + 64 * NLW), lds, stream, a);
+    SET_MAX_DYN_LDS((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_AFFINE_ACT, F16, TA>), lds);
+    LAUNCH((conv3d_wgrad_k3_bf16<NS, MT, NLW, MI355_IN_AFFINE_ACT, F16, TA>), grid, dim3(576 + 64 * NLW), lds, stream, a);
   }
   return LAUNCH_CHECK();
 }
@@ -337,7 +340,8 @@ int mi355_conv3d_wgrad_bf16_impl(const mi355_act* x, const mi355_act* dy, float*
   a.splits = p.splits; a.ciTiles = p.ciTiles; a.coTiles32 = p.coTiles32;
   const int ns = nsplit_of_w(d->precision);
   int rc;
-  if (d->precision == MI355_PREC_F16) rc = p.mt == 2 ? launch_wb<1, 2, true>(a, p, d->in_mode, stream) : launch_wb<1, 1, true>(a, p, d->in_mode, stream);
+  if (x->dtype == MI355_ACT_BF16) rc = p.mt == 2 ? launch_wb<1, 2, false, bf16_t>(a, p, d->in_mode, stream) : launch_wb<1, 1, false, bf16_t>(a, p, d->in_mode, stream);
+  else if (d->precision == MI355_PREC_F16) rc = p.mt == 2 ? launch_wb<1, 2, true>(a, p, d->in_mode, stream) : launch_wb<1, 1, true>(a, p, d->in_mode, stream);
   else if (p.mt == 2) rc = ns == 1 ? launch_wb<1, 2>(a, p, d->in_mode, stream) : launch_wb<2, 2>(a, p, d->in_mode, stream);
   else rc = ns == 1 ? launch_wb<1, 1>(a, p, d->in_mode, stream) : ns == 2 ? launch_wb<2, 1>(a, p, d->in_mode, stream) : launch_wb<3, 1>(a, p, d->in_mode, stream);
   if (rc) return rc;

@@ -284,6 +284,7 @@ static WWRPlan plan_wwr(const mi355_act* x, const mi355_act* dy, const mi355_con
   if (!x || !dy || !d || d->kd != 3 || d->stride != 1 || d->pad != 1 || d->out_mode != MI355_OUT_PLAIN) return p;
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return p;
   if (x->d != dy->d || x->h != dy->h || x->w != dy->w || x->n != dy->n) return p;
+  if (x->dtype != MI355_ACT_F32 || dy->dtype != MI355_ACT_F32) return p;      // the fp32 path
   if (x->c % 4 || x->ld % 4 || dy->c % 4 || dy->ld % 4 || ((uintptr_t)x->p & 15) || ((uintptr_t)dy->p & 15)) return p;
   p.tilesY = ceil_div(dy->h, 4); p.tilesX = ceil_div(dy->w, 8);
   const long long nc = (long long)dy->n * p.tilesY * p.tilesX;

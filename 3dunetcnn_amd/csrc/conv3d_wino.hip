@@ -593,6 +593,7 @@ extern "C" int mi355_wino_pack_weight(const float* w, float* up, int32_t cout, i
 // call that is not eligible to mi355_conv3d_fwd instead of failing (ops.Backend.conv_fwd).
 static int wino_check(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d) {
   if (!x || !y || !d || !x->p || !y->p) return MI355_EINVAL;
+  if (x->dtype != MI355_ACT_F32 || y->dtype != MI355_ACT_F32) return MI355_EUNSUPPORTED;      // the Winograd kernels are the fp32 path
   if (d->kd != 3 || d->stride != 1 || d->pad != 1 || d->out_mode != MI355_OUT_PLAIN) return MI355_EUNSUPPORTED;
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
   if (d->off_z || d->off_y || d->off_x || d->out_d != y->d || d->out_h != y->h || d->out_w != y->w) return MI355_EUNSUPPORTED;
@@ -618,11 +619,11 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   if (d->gn_bwd) {
     const mi355_gn_bwd_fuse* f = d->gn_bwd;
     if (!f->gx || !f->scale || !f->shift || !f->mean_rstd || !f->partials_out || f->groups <= 0 || y->c % f->groups || f->gx_ld < y->c) return MI355_EINVAL;
-    a.g.gnb = f->partials_out; a.g.gx = f->gx; a.g.gxld = f->gx_ld; a.g.gscale = f->scale; a.g.gshift = f->shift; a.g.gmr = f->mean_rstd;
+    a.g.gnb = f->partials_out; a.g.gx = (const float*)f->gx; a.g.gxld = f->gx_ld; a.g.gscale = f->scale; a.g.gshift = f->shift; a.g.gmr = f->mean_rstd;
     a.g.ggroups = f->groups; a.g.gslope = f->act_slope;
   }
   a.x = (const float*)x->p; a.xld = x->ld; a.up = up; a.y = (float*)y->p; a.yld = y->ld;
-  a.res = d->residual; a.resld = d->residual_ld;
+  a.res = (const float*)d->residual; a.resld = d->residual_ld;
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope;
   a.out_chscale = d->out_chscale; a.bias = d->bias;
   a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cin = x->c; a.CinP = (x->c + 7) / 8 * 8;

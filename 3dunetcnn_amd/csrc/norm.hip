@@ -12,12 +12,14 @@
 #include "hipcompat.h"
 #include <cstdlib>
 #include "../../include/mi355_unet3d.h"
+#include "act_io.h"
 
 #define GN_MAX_BLOCKS_PER_SAMPLE 256
 
 // per-(n, block, c) partial sums (sum du, sum du*xhat), du = dA * act'(scale*x+shift), xhat = (x-mean)*rstd: the first pass of the
 // backward when the dgrad conv that produced dA could not emit them from its epilogue (gn_fuse.h)
-__global__ void gn_bwd_partial_kernel(const float* x, int xld, const float* dA, int dald, long long V, int C, int Q, int R,
+template <typename T>
+__global__ void gn_bwd_partial_kernel(const T* x, int xld, const T* dA, int dald, long long V, int C, int Q, int R,
                                       int G, float slope, const float* mean_rstd, const float* scale, const float* shift,
                                       float* ws) {
   DYN_LDS(lds);  // [R][Q][8]
@@ -38,12 +40,12 @@ __global__ void gn_bwd_partial_kernel(const float* x, int xld, const float* dA, 
     sc[e] = scale[(size_t)n * C + c];
     sh[e] = shift[(size_t)n * C + c];
   }
-  const float* xn = x + (size_t)n * V * xld + 4 * q;
-  const float* dn = dA + (size_t)n * V * dald + 4 * q;
+  const T* xn = x + (size_t)n * V * xld + 4 * q;
+  const T* dn = dA + (size_t)n * V * dald + 4 * q;
   for (long long v = vb + r; v < ve; v += R) {
-    const float4 xv = *reinterpret_cast<const float4*>(xn + (size_t)v * xld);
+    const float4 xv = ld4(xn + (size_t)v * xld);
     const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
-    const float4 dv = *reinterpret_cast<const float4*>(dn + (size_t)v * dald);
+    const float4 dv = ld4(dn + (size_t)v * dald);
     const float de[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -146,8 +148,9 @@ __global__ void gn_bwd_param_kernel(const float* nc_sums, int N, int C, float* d
   if (dgamma) dgamma[c] = (float)s2;
 }
 
-__global__ void gn_bwd_apply_kernel(const float* x, int xld, const float* dA, int dald, float* dx, int dxld,
-                                    const float* addend, int addld, long long V, int C, int N, float slope,
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const T* x, int xld, const T* dA, int dald, T* dx, int dxld,
+                                    const T* addend, int addld, long long V, int C, int N, float slope,
                                     const float* scale, const float* shift, const float* coef) {
   const int Q = C / 4;
   const long long total = (long long)N * V * Q;
@@ -156,8 +159,8 @@ __global__ void gn_bwd_apply_kernel(const float* x, int xld, const float* dA, in
     const long long nv = idx / Q;
     const int n = (int)(nv / V);
     const int c = 4 * q;
-    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)nv * xld + c);
-    const float4 dv = *reinterpret_cast<const float4*>(dA + (size_t)nv * dald + c);
+    const float4 xv = ld4(x + (size_t)nv * xld + c);
+    const float4 dv = ld4(dA + (size_t)nv * dald + c);
     const float4 sc = *reinterpret_cast<const float4*>(scale + (size_t)n * C + c);
     const float4 sh = *reinterpret_cast<const float4*>(shift + (size_t)n * C + c);
     const float xe[4] = {xv.x, xv.y, xv.z, xv.w}, de[4] = {dv.x, dv.y, dv.z, dv.w};
@@ -171,17 +174,18 @@ __global__ void gn_bwd_apply_kernel(const float* x, int xld, const float* dA, in
       o[e] = k[0] * du + k[1] + k[2] * (xe[e] - k[3]);
     }
     if (addend) {
-      const float4 av = *reinterpret_cast<const float4*>(addend + (size_t)nv * addld + c);
+      const float4 av = ld4(addend + (size_t)nv * addld + c);
       o[0] += av.x; o[1] += av.y; o[2] += av.z; o[3] += av.w;
     }
-    *reinterpret_cast<float4*>(dx + (size_t)nv * dxld + c) = make_float4(o[0], o[1], o[2], o[3]);
+    st4(dx + (size_t)nv * dxld + c, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
 // ---- statistics from partial moments (gn_fuse.h record format: (count, sum, M2) per (sample, block, channel)) ----
 // Standalone producer of the records: one streaming read of x. Inside a block the sums are taken about K_c = the block's first
 // voxel of that channel (a sample of the data, so they do not cancel when |mean| >> std) and converted to (count, sum, M2) once.
-__global__ void gn_moments_kernel(const float* x, int xld, long long V, int C, int Q, int R, float* out) {
+template <typename T>
+__global__ void gn_moments_kernel(const T* x, int xld, long long V, int C, int Q, int R, float* out) {
   DYN_LDS(lds);  // [R][Q][8]
   const int tid = threadIdx.x;
   const int q = tid % Q, r = tid / Q;
@@ -189,15 +193,15 @@ __global__ void gn_moments_kernel(const float* x, int xld, long long V, int C, i
   const long long per = (V + B - 1) / B;
   const long long vb = (long long)blk * per;
   const long long ve = vb + per < V ? vb + per : V;
-  const float* xn = x + (size_t)n * V * xld + 4 * q;
+  const T* xn = x + (size_t)n * V * xld + 4 * q;
   float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
   float kc[4] = {0.f, 0.f, 0.f, 0.f};
   if (vb < ve) {
-    const float4 k4 = *reinterpret_cast<const float4*>(xn + (size_t)vb * xld);
+    const float4 k4 = ld4(xn + (size_t)vb * xld);
     kc[0] = k4.x; kc[1] = k4.y; kc[2] = k4.z; kc[3] = k4.w;
   }
   for (long long v = vb + r; v < ve; v += R) {
-    const float4 xv = *reinterpret_cast<const float4*>(xn + (size_t)v * xld);
+    const float4 xv = ld4(xn + (size_t)v * xld);
     const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const float t = xe[e] - kc[e]; s0[e] += t; s1[e] += t * t; }
@@ -378,9 +382,9 @@ extern "C" size_t mi355_gn_workspace(const mi355_act* x) {
 }
 
 static int gn_check(const mi355_act* x, int groups) {
-  if (!x || !x->p || x->c % 4 || x->ld % 4 || x->ld < x->c || groups <= 0 || x->c % groups) return MI355_EINVAL;
+  if (!x || !x->p || x->c % 4 || x->ld % 4 || x->ld < x->c || groups <= 0 || x->c % groups || !act_dtype_ok(x)) return MI355_EINVAL;
   if (x->c / 4 > 256 || x->c / groups > 1024) return MI355_EUNSUPPORTED;
-  if ((uintptr_t)x->p & 15) return MI355_EINVAL;
+  if ((uintptr_t)x->p & (x->dtype == MI355_ACT_BF16 ? 7 : 15)) return MI355_EINVAL;
   return 0;
 }
 
@@ -395,7 +399,7 @@ extern "C" int mi355_gn_moments(const mi355_act* x, float* out, void* stream) {
   if (!out) return MI355_EINVAL;
   const long long V = (long long)x->d * x->h * x->w;
   const int B = gn_blocks_per_sample(V), C = x->c, Q = C / 4, R = 256 / Q > 0 ? 256 / Q : 1;
-  LAUNCH(gn_moments_kernel, dim3(B, x->n), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream, (const float*)x->p, x->ld, V, C, Q, R, out);
+  ACT_TYPED(x->dtype, T, LAUNCH(gn_moments_kernel<T>, dim3(B, x->n), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream, (const T*)x->p, x->ld, V, C, Q, R, out));
   return LAUNCH_CHECK();
 }
 
@@ -433,15 +437,17 @@ extern "C" int mi355_gn_stats(const mi355_act* x, int32_t groups, float eps, con
                            mean_rstd, scale, shift, stream);
 }
 
-static int gn_act_bwd_impl(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const float* addend, int32_t addend_ld,
+static int gn_act_bwd_impl(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const void* addend, int32_t addend_ld,
                            int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
                            const float* scale, const float* shift, float* dgamma, float* dbeta,
                            const float* partials, int32_t blocks, void* ws, size_t ws_bytes, void* stream) {
   int rc = gn_check(x, groups);
   if (rc) return rc;
   if (!dA || !dx || !dA->p || !dx->p || !mean_rstd || !scale || !shift || !ws) return MI355_EINVAL;
-  if (dA->c != x->c || dx->c != x->c || dA->ld % 4 || dx->ld % 4 || ((uintptr_t)dA->p & 15) || ((uintptr_t)dx->p & 15)) return MI355_EINVAL;
-  if (addend && (addend_ld % 4 || ((uintptr_t)addend & 15))) return MI355_EINVAL;
+  const uintptr_t amask = x->dtype == MI355_ACT_BF16 ? 7 : 15;
+  if (dA->c != x->c || dx->c != x->c || dA->ld % 4 || dx->ld % 4 || ((uintptr_t)dA->p & amask) || ((uintptr_t)dx->p & amask)) return MI355_EINVAL;
+  if (dA->dtype != x->dtype || dx->dtype != x->dtype) return MI355_EUNSUPPORTED;      // a tensor's gradient has the tensor's storage type
+  if (addend && (addend_ld % 4 || ((uintptr_t)addend & amask))) return MI355_EINVAL;
   if (ws_bytes < mi355_gn_workspace(x)) return MI355_EWORKSPACE;
   if (partials && blocks <= 0) return MI355_EINVAL;
   const long long V = (long long)x->d * x->h * x->w;
@@ -453,8 +459,8 @@ static int gn_act_bwd_impl(const mi355_act* x, const mi355_act* dA, const mi355_
   if (partials) {
     B = blocks;                                   // first pass already done by the dgrad conv's epilogue (gn_fuse.h)
   } else {
-    LAUNCH(gn_bwd_partial_kernel, dim3(B, N), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream,
-           (const float*)x->p, x->ld, (const float*)dA->p, dA->ld, V, C, Q, R, groups, act_slope, mean_rstd, scale, shift, part);
+    ACT_TYPED(x->dtype, T, LAUNCH(gn_bwd_partial_kernel<T>, dim3(B, N), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream,
+                                  (const T*)x->p, x->ld, (const T*)dA->p, dA->ld, V, C, Q, R, groups, act_slope, mean_rstd, scale, shift, part));
     rc = LAUNCH_CHECK(); if (rc) return rc;
     partials = part;
   }
@@ -466,12 +472,12 @@ static int gn_act_bwd_impl(const mi355_act* x, const mi355_act* dA, const mi355_
   }
   const long long total = (long long)N * V * Q;
   long long grid = (total + 255) / 256; if (grid > 8192) grid = 8192;
-  LAUNCH(gn_bwd_apply_kernel, dim3((unsigned)grid), dim3(256), 0, stream, (const float*)x->p, x->ld, (const float*)dA->p, dA->ld,
-         (float*)dx->p, dx->ld, addend, addend_ld, V, C, N, act_slope, scale, shift, (const float*)coef);
+  ACT_TYPED(x->dtype, T, LAUNCH(gn_bwd_apply_kernel<T>, dim3((unsigned)grid), dim3(256), 0, stream, (const T*)x->p, x->ld, (const T*)dA->p, dA->ld,
+                                (T*)dx->p, dx->ld, (const T*)addend, addend_ld, V, C, N, act_slope, scale, shift, (const float*)coef));
   return LAUNCH_CHECK();
 }
 
-extern "C" int mi355_gn_act_bwd(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const float* addend, int32_t addend_ld,
+extern "C" int mi355_gn_act_bwd(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const void* addend, int32_t addend_ld,
                                 int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
                                 const float* scale, const float* shift, float* dgamma, float* dbeta,
                                 void* ws, size_t ws_bytes, void* stream) {
@@ -479,7 +485,7 @@ extern "C" int mi355_gn_act_bwd(const mi355_act* x, const mi355_act* dA, const m
                          ws, ws_bytes, stream);
 }
 
-extern "C" int mi355_gn_act_bwd_fused(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const float* addend, int32_t addend_ld,
+extern "C" int mi355_gn_act_bwd_fused(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const void* addend, int32_t addend_ld,
                                       int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
                                       const float* scale, const float* shift, float* dgamma, float* dbeta,
                                       const float* partials, int32_t blocks, void* ws, size_t ws_bytes, void* stream) {

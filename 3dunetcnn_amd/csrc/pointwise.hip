@@ -6,6 +6,7 @@
 // segmentation/unet.py:50 (final 1x1x1 conv), classification/myronenko.py:70-79 (Dropout3d).
 #include "hipcompat.h"
 #include "../../include/mi355_unet3d.h"
+#include "act_io.h"
 
 __device__ __forceinline__ void tri_src(int u, int n, int& i0, int& i1, float& l0, float& l1) {
   // PyTorch area_pixel_compute_source_index(scale=0.5, align_corners=False): src = max(0.5*(u+0.5)-0.5, 0)
@@ -17,8 +18,9 @@ __device__ __forceinline__ void tri_src(int u, int n, int& i0, int& i1, float& l
   l0 = 1.f - l1;
 }
 
-__global__ void upsample2x_fwd_kernel(const float* lo, int lold, int N, int Dl, int Hl, int Wl, int C,
-                                      float* cat, int catld, int Dc, int Hc, int Wc, int offz, int offy, int offx) {
+template <typename T>
+__global__ void upsample2x_fwd_kernel(const T* lo, int lold, int N, int Dl, int Hl, int Wl, int C,
+                                      T* cat, int catld, int Dc, int Hc, int Wc, int offz, int offy, int offx) {
   const int Q = C / 4;
   const long long total = (long long)N * Dc * Hc * Wc * Q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -40,11 +42,11 @@ __global__ void upsample2x_fwd_kernel(const float* lo, int lold, int N, int Dl, 
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const float w = wz[a] * wy[b] * wx[c];
-            const float4 v = *reinterpret_cast<const float4*>(lo + ((((size_t)n * Dl + zs[a]) * Hl + ys[b]) * Wl + xs[c]) * lold + 4 * q);
+            const float4 v = ld4(lo + ((((size_t)n * Dl + zs[a]) * Hl + ys[b]) * Wl + xs[c]) * lold + 4 * q);
             o.x += w * v.x; o.y += w * v.y; o.z += w * v.z; o.w += w * v.w;
           }
     }
-    *reinterpret_cast<float4*>(cat + ((((size_t)n * Dc + z) * Hc + y) * Wc + x) * catld + 4 * q) = o;
+    st4(cat + ((((size_t)n * Dc + z) * Hc + y) * Wc + x) * catld + 4 * q, o);
   }
 }
 
@@ -55,8 +57,9 @@ __device__ __forceinline__ float tri_weight(int u, int n, int d) {
   return (i0 == d ? l0 : 0.f) + (i1 == d ? l1 : 0.f);
 }
 
-__global__ void upsample2x_bwd_kernel(const float* dcat, int catld, int N, int Dc, int Hc, int Wc, int C,
-                                      float* dlo, int lold, int Dl, int Hl, int Wl, int offz, int offy, int offx) {
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const T* dcat, int catld, int N, int Dc, int Hc, int Wc, int C,
+                                      T* dlo, int lold, int Dl, int Hl, int Wl, int offz, int offy, int offx) {
   const int Q = C / 4;
   const long long total = (long long)N * Dl * Hl * Wl * Q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -75,12 +78,12 @@ __global__ void upsample2x_bwd_kernel(const float* dcat, int catld, int N, int D
           const int ux = 2 * x + c; const float wx = tri_weight(ux, Wl, x); const int cx = ux + offx;
           if (wx == 0.f || cx < 0 || cx >= Wc) continue;
           const float w = wz * wy * wx;
-          const float4 v = *reinterpret_cast<const float4*>(dcat + ((((size_t)n * Dc + cz) * Hc + cy) * Wc + cx) * catld + 4 * q);
+          const float4 v = ld4(dcat + ((((size_t)n * Dc + cz) * Hc + cy) * Wc + cx) * catld + 4 * q);
           o.x += w * v.x; o.y += w * v.y; o.z += w * v.z; o.w += w * v.w;
         }
       }
     }
-    *reinterpret_cast<float4*>(dlo + ((((size_t)n * Dl + z) * Hl + y) * Wl + x) * lold + 4 * q) = o;
+    st4(dlo + ((((size_t)n * Dl + z) * Hl + y) * Wl + x) * lold + 4 * q, o);
   }
 }
 
@@ -91,77 +94,93 @@ static inline unsigned grid_for(long long total) {
   return (unsigned)g;
 }
 
-static int act_ok(const mi355_act* t) {
-  return t && t->p && t->c > 0 && t->c % 4 == 0 && t->ld % 4 == 0 && t->ld >= t->c && !((uintptr_t)t->p & 15);
-}
+static int act_ok(const mi355_act* t) { return act_view_ok(t); }
 
 extern "C" int mi355_upsample2x_fwd(const mi355_act* lo, const mi355_act* cat, int32_t offz, int32_t offy, int32_t offx, void* stream) {
   if (!act_ok(lo) || !act_ok(cat) || lo->c != cat->c || lo->n != cat->n) return MI355_EINVAL;
+  if (lo->dtype != cat->dtype) return MI355_EUNSUPPORTED;
   const long long total = (long long)cat->n * cat->d * cat->h * cat->w * (cat->c / 4);
-  LAUNCH(upsample2x_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)lo->p, lo->ld, lo->n, lo->d, lo->h, lo->w, lo->c,
-         (float*)cat->p, cat->ld, cat->d, cat->h, cat->w, offz, offy, offx);
+  ACT_TYPED(lo->dtype, T, LAUNCH(upsample2x_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, stream, (const T*)lo->p, lo->ld, lo->n, lo->d, lo->h,
+                                 lo->w, lo->c, (T*)cat->p, cat->ld, cat->d, cat->h, cat->w, offz, offy, offx));
   return LAUNCH_CHECK();
 }
 
 extern "C" int mi355_upsample2x_bwd(const mi355_act* dcat, const mi355_act* dlo, int32_t offz, int32_t offy, int32_t offx, void* stream) {
   if (!act_ok(dlo) || !act_ok(dcat) || dlo->c != dcat->c || dlo->n != dcat->n) return MI355_EINVAL;
+  if (dlo->dtype != dcat->dtype) return MI355_EUNSUPPORTED;
   const long long total = (long long)dlo->n * dlo->d * dlo->h * dlo->w * (dlo->c / 4);
-  LAUNCH(upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)dcat->p, dcat->ld, dcat->n, dcat->d, dcat->h, dcat->w,
-         dcat->c, (float*)dlo->p, dlo->ld, dlo->d, dlo->h, dlo->w, offz, offy, offx);
+  ACT_TYPED(dlo->dtype, T, LAUNCH(upsample2x_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, stream, (const T*)dcat->p, dcat->ld, dcat->n, dcat->d,
+                                  dcat->h, dcat->w, dcat->c, (T*)dlo->p, dlo->ld, dlo->d, dlo->h, dlo->w, offz, offy, offx));
   return LAUNCH_CHECK();
 }
 
 // ---- layout ------------------------------------------------------------------------------------
-__global__ void ncdhw_to_ndhwc_kernel(const float* src, float* dst, int dld, int N, int C, long long V) {
+template <typename T>
+__global__ void ncdhw_to_ndhwc_kernel(const float* src, T* dst, int dld, int N, int C, long long V) {
   const long long total = (long long)N * V * C;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     // read-coalesced over v for small C: idx = (n*C + c)*V + v
     const long long v = idx % V; const long long nc = idx / V;
     const int c = (int)(nc % C); const long long n = nc / C;
-    dst[((size_t)n * V + v) * dld + c] = src[idx];
+    st1(dst + ((size_t)n * V + v) * dld + c, src[idx]);
   }
 }
-__global__ void ndhwc_to_ncdhw_kernel(const float* src, int sld, float* dst, int N, int C, long long V) {
+template <typename T>
+__global__ void ndhwc_to_ncdhw_kernel(const T* src, int sld, float* dst, int N, int C, long long V) {
   const long long total = (long long)N * V * C;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long v = idx % V; const long long nc = idx / V;
     const int c = (int)(nc % C); const long long n = nc / C;
-    dst[idx] = src[((size_t)n * V + v) * sld + c];
+    dst[idx] = ld1(src + ((size_t)n * V + v) * sld + c);
   }
 }
 
 extern "C" int mi355_ncdhw_to_ndhwc(const float* src, const mi355_act* dst, void* stream) {
-  if (!src || !dst || !dst->p || dst->ld < dst->c) return MI355_EINVAL;
+  if (!src || !dst || !dst->p || dst->ld < dst->c || !act_dtype_ok(dst)) return MI355_EINVAL;
   const long long V = (long long)dst->d * dst->h * dst->w;
-  LAUNCH(ncdhw_to_ndhwc_kernel, dim3(grid_for((long long)dst->n * V * dst->c)), dim3(256), 0, stream, src, (float*)dst->p, dst->ld, dst->n, dst->c, V);
+  ACT_TYPED(dst->dtype, T, LAUNCH(ncdhw_to_ndhwc_kernel<T>, dim3(grid_for((long long)dst->n * V * dst->c)), dim3(256), 0, stream, src, (T*)dst->p, dst->ld,
+                                  dst->n, dst->c, V));
   return LAUNCH_CHECK();
 }
 extern "C" int mi355_ndhwc_to_ncdhw(const mi355_act* src, float* dst, void* stream) {
-  if (!dst || !src || !src->p || src->ld < src->c) return MI355_EINVAL;
+  if (!dst || !src || !src->p || src->ld < src->c || !act_dtype_ok(src)) return MI355_EINVAL;
   const long long V = (long long)src->d * src->h * src->w;
-  LAUNCH(ndhwc_to_ncdhw_kernel, dim3(grid_for((long long)src->n * V * src->c)), dim3(256), 0, stream, (const float*)src->p, src->ld, dst, src->n, src->c, V);
+  ACT_TYPED(src->dtype, T, LAUNCH(ndhwc_to_ncdhw_kernel<T>, dim3(grid_for((long long)src->n * V * src->c)), dim3(256), 0, stream, (const T*)src->p, src->ld,
+                                  dst, src->n, src->c, V));
   return LAUNCH_CHECK();
 }
 
 // ---- add / channel scale ---------------------------------------------------------------------------
-__global__ void add_kernel(const float* a, int ald, const float* b, int bld, float* y, int yld, long long NV, int C) {
+template <typename T>
+__global__ void add_kernel(const T* a, int ald, const T* b, int bld, T* y, int yld, long long NV, int C) {
   const int Q = C / 4;
   const long long total = NV * Q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int q = (int)(idx % Q); const long long v = idx / Q;
-    const float4 av = *reinterpret_cast<const float4*>(a + (size_t)v * ald + 4 * q);
-    const float4 bv = *reinterpret_cast<const float4*>(b + (size_t)v * bld + 4 * q);
-    *reinterpret_cast<float4*>(y + (size_t)v * yld + 4 * q) = make_float4(av.x + bv.x, av.y + bv.y, av.z + bv.z, av.w + bv.w);
+    const float4 av = ld4(a + (size_t)v * ald + 4 * q);
+    const float4 bv = ld4(b + (size_t)v * bld + 4 * q);
+    st4(y + (size_t)v * yld + 4 * q, make_float4(av.x + bv.x, av.y + bv.y, av.z + bv.z, av.w + bv.w));
   }
 }
-__global__ void chscale_kernel(const float* x, int xld, const float* s, float* y, int yld, long long V, int N, int C) {
+template <typename T>
+__global__ void chscale_kernel(const T* x, int xld, const float* s, T* y, int yld, long long V, int N, int C) {
   const int Q = C / 4;
   const long long total = (long long)N * V * Q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int q = (int)(idx % Q); const long long nv = idx / Q; const int n = (int)(nv / V);
-    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)nv * xld + 4 * q);
+    const float4 xv = ld4(x + (size_t)nv * xld + 4 * q);
     const float4 sv = *reinterpret_cast<const float4*>(s + (size_t)n * C + 4 * q);
-    *reinterpret_cast<float4*>(y + (size_t)nv * yld + 4 * q) = make_float4(xv.x * sv.x, xv.y * sv.y, xv.z * sv.z, xv.w * sv.w);
+    st4(y + (size_t)nv * yld + 4 * q, make_float4(xv.x * sv.x, xv.y * sv.y, xv.z * sv.z, xv.w * sv.w));
+  }
+}
+// change of storage type (fp32 <-> bf16, or a copy): the bridge to a kernel that has no bf16 form, and the 16-bit copy of the network input
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* x, int xld, TD* y, int yld, long long NV, int C) {
+  const int Q = C / 4;
+  const long long total = NV * Q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % Q); const long long v = idx / Q;
+    st4(y + (size_t)v * yld + 4 * q, ld4(x + (size_t)v * xld + 4 * q));
   }
 }
 
@@ -171,14 +190,25 @@ static int same_shape(const mi355_act* a, const mi355_act* b) {
 
 extern "C" int mi355_add(const mi355_act* a, const mi355_act* b, const mi355_act* y, void* stream) {
   if (!act_ok(a) || !act_ok(b) || !act_ok(y) || !same_shape(a, b) || !same_shape(a, y)) return MI355_EINVAL;
+  if (a->dtype != b->dtype || a->dtype != y->dtype) return MI355_EUNSUPPORTED;
   const long long NV = (long long)a->n * a->d * a->h * a->w;
-  LAUNCH(add_kernel, dim3(grid_for(NV * (a->c / 4))), dim3(256), 0, stream, (const float*)a->p, a->ld, (const float*)b->p, b->ld, (float*)y->p, y->ld, NV, a->c);
+  ACT_TYPED(a->dtype, T, LAUNCH(add_kernel<T>, dim3(grid_for(NV * (a->c / 4))), dim3(256), 0, stream, (const T*)a->p, a->ld, (const T*)b->p, b->ld, (T*)y->p,
+                                y->ld, NV, a->c));
+  return LAUNCH_CHECK();
+}
+extern "C" int mi355_cast(const mi355_act* x, const mi355_act* y, void* stream) {
+  if (!act_ok(x) || !act_ok(y) || !same_shape(x, y)) return MI355_EINVAL;
+  const long long NV = (long long)x->n * x->d * x->h * x->w;
+  const dim3 grid(grid_for(NV * (x->c / 4)));
+  ACT_TYPED(x->dtype, TS, ACT_TYPED(y->dtype, TD, LAUNCH((cast_kernel<TS, TD>), grid, dim3(256), 0, stream, (const TS*)x->p, x->ld, (TD*)y->p, y->ld, NV, x->c)));
   return LAUNCH_CHECK();
 }
 extern "C" int mi355_chscale(const mi355_act* x, const float* chscale, const mi355_act* y, void* stream) {
   if (!act_ok(x) || !act_ok(y) || !same_shape(x, y) || !chscale) return MI355_EINVAL;
+  if (x->dtype != y->dtype) return MI355_EUNSUPPORTED;
   const long long V = (long long)x->d * x->h * x->w;
-  LAUNCH(chscale_kernel, dim3(grid_for((long long)x->n * V * (x->c / 4))), dim3(256), 0, stream, (const float*)x->p, x->ld, chscale, (float*)y->p, y->ld, V, x->n, x->c);
+  ACT_TYPED(x->dtype, T, LAUNCH(chscale_kernel<T>, dim3(grid_for((long long)x->n * V * (x->c / 4))), dim3(256), 0, stream, (const T*)x->p, x->ld, chscale,
+                                (T*)y->p, y->ld, V, x->n, x->c));
   return LAUNCH_CHECK();
 }
 
@@ -197,7 +227,8 @@ __device__ __forceinline__ float4 proj_prologue(float4 v, const float* sc, const
   return v;
 }
 
-__global__ void proj_fwd_kernel(const float* x, int xld, const float* sc, const float* sh, float slope, const float* w, const float* bias,
+template <typename T>
+__global__ void proj_fwd_kernel(const T* x, int xld, const float* sc, const float* sh, float slope, const float* w, const float* bias,
                                 float* out, int N, long long V, int Cin, int Cout) {
   DYN_LDS(lds);                    // x tile [PROJ_TV][Cin+1] | w [Cout][Cin]
   const int XS = Cin + 1;
@@ -212,7 +243,7 @@ __global__ void proj_fwd_kernel(const float* x, int xld, const float* sc, const 
     for (int i = tid; i < PROJ_TV * Q; i += 256) {
       const int v = i / Q, q = i % Q;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v0 + v < V) val = proj_prologue(*reinterpret_cast<const float4*>(x + ((size_t)n * V + v0 + v) * xld + 4 * q), sc, sh, slope, n, Cin, 4 * q);
+      if (v0 + v < V) val = proj_prologue(ld4(x + ((size_t)n * V + v0 + v) * xld + 4 * q), sc, sh, slope, n, Cin, 4 * q);
       float* d = lx + v * XS + 4 * q; d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
     }
     __syncthreads();
@@ -235,8 +266,9 @@ __global__ void proj_fwd_kernel(const float* x, int xld, const float* sc, const 
 }
 
 // dx tile + per-block partial dw/dbias
-__global__ void proj_bwd_kernel(const float* x, int xld, const float* sc, const float* sh, float slope, const float* w, const float* dz,
-                                float* dx, int dxld, float* ws, int N, long long V, int Cin, int Cout) {
+template <typename T>
+__global__ void proj_bwd_kernel(const T* x, int xld, const float* sc, const float* sh, float slope, const float* w, const float* dz,
+                                T* dx, int dxld, float* ws, int N, long long V, int Cin, int Cout) {
   DYN_LDS(lds);                    // x tile [TV][Cin+1] | dz tile [Cout][TV] | w [Cout][Cin]
   const int XS = Cin + 1;
   float* lx = lds; float* lz = lx + PROJ_TV * XS; float* lw = lz + PROJ_MAX_COUT * PROJ_TV;
@@ -254,7 +286,7 @@ __global__ void proj_bwd_kernel(const float* x, int xld, const float* sc, const 
     for (int i = tid; i < PROJ_TV * Q; i += 256) {
       const int v = i / Q, q = i % Q;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v0 + v < V) val = proj_prologue(*reinterpret_cast<const float4*>(x + ((size_t)n * V + v0 + v) * xld + 4 * q), sc, sh, slope, n, Cin, 4 * q);
+      if (v0 + v < V) val = proj_prologue(ld4(x + ((size_t)n * V + v0 + v) * xld + 4 * q), sc, sh, slope, n, Cin, 4 * q);
       float* d = lx + v * XS + 4 * q; d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
     }
     for (int i = tid; i < Cout * PROJ_TV; i += 256) {
@@ -289,7 +321,7 @@ __global__ void proj_bwd_kernel(const float* x, int xld, const float* sc, const 
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] += g * lw[co * Cin + 4 * q + e];
         }
-        *reinterpret_cast<float4*>(dx + ((size_t)n * V + v0 + v) * dxld + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+        st4(dx + ((size_t)n * V + v0 + v) * dxld + 4 * q, make_float4(o[0], o[1], o[2], o[3]));
       }
     }
   }
@@ -340,7 +372,8 @@ extern "C" int mi355_proj_fwd(const mi355_act* x, const float* in_scale, const f
   const size_t lds = ((size_t)PROJ_TV * (x->c + 1) + (size_t)cout * x->c) * sizeof(float);
   if (lds > 64 * 1024) return MI355_EUNSUPPORTED;
   int grid = proj_blocks(x) * 8; long long t = (long long)x->n * ((V + PROJ_TV - 1) / PROJ_TV); if (grid > t) grid = (int)t;
-  LAUNCH(proj_fwd_kernel, dim3(grid), dim3(256), lds, stream, (const float*)x->p, x->ld, in_scale, in_shift, act_slope, w, bias, logits, x->n, V, x->c, cout);
+  ACT_TYPED(x->dtype, T, LAUNCH(proj_fwd_kernel<T>, dim3(grid), dim3(256), lds, stream, (const T*)x->p, x->ld, in_scale, in_shift, act_slope, w, bias, logits,
+                                x->n, V, x->c, cout));
   return LAUNCH_CHECK();
 }
 
@@ -351,14 +384,15 @@ extern "C" int mi355_proj_bwd(const mi355_act* x, const float* in_scale, const f
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MI355_EINVAL;
   if (in_scale && !(act_slope >= 0.f && act_slope <= 1.f)) return MI355_EINVAL;
   if (dx && (!act_ok(dx) || !same_shape(x, dx))) return MI355_EINVAL;
+  if (dx && dx->dtype != x->dtype) return MI355_EUNSUPPORTED;
   if (ws_bytes < mi355_proj_workspace(x, cout)) return MI355_EWORKSPACE;
   const long long V = (long long)x->d * x->h * x->w;
   const size_t lds = ((size_t)PROJ_TV * (x->c + 1) + (size_t)PROJ_MAX_COUT * PROJ_TV + (size_t)cout * x->c) * sizeof(float);
   if (lds > 64 * 1024) return MI355_EUNSUPPORTED;
   const int nb = proj_blocks(x);
   const int npairs = cout * x->c + cout;
-  LAUNCH(proj_bwd_kernel, dim3(nb), dim3(256), lds, stream, (const float*)x->p, x->ld, in_scale, in_shift, act_slope, w, dlogits, dx ? (float*)dx->p : (float*)nullptr,
-         dx ? dx->ld : 0, (float*)ws, x->n, V, x->c, cout);
+  ACT_TYPED(x->dtype, T, LAUNCH(proj_bwd_kernel<T>, dim3(nb), dim3(256), lds, stream, (const T*)x->p, x->ld, in_scale, in_shift, act_slope, w, dlogits,
+                                dx ? (T*)dx->p : (T*)nullptr, dx ? dx->ld : 0, (float*)ws, x->n, V, x->c, cout));
   int rc = LAUNCH_CHECK(); if (rc) return rc;
   LAUNCH(proj_reduce_kernel, dim3(ceil_div(npairs, 8)), dim3(256), 0, stream, (const float*)ws, nb, npairs, cout * x->c, dw, dbias);
   return LAUNCH_CHECK();

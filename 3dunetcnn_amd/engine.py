@@ -42,6 +42,7 @@ class HipNetBase(nn.Module):
     def _init_engine(self):
         self._be = None
         self.conv_precision = None   # None: the backend's setting; "fp32" | "bf16x6" | "bf16x3" | "bf16" | "fp16": per-module override
+        self.act_storage = None      # None: fp32 tensors; torch.bfloat16: activations and their gradients live in HBM as bf16 (ops.Act.dtype)
         self._flat = None          # flat parameter buffer (views are the nn.Parameters)
         self._flat_grad = None
         self._packed = {}          # id(param) -> [version, {mode: packed tensor}, data_ptr]
@@ -175,14 +176,17 @@ class HipNetBase(nn.Module):
             self._packs_dirty = False                      # entries dropped there are rebuilt on first use (their entry is gone)
         self._packs_dirty_local = self._packs_dirty
         self._saved_precision = be.precision
+        self._saved_act_dtype = be.act_dtype
         if self.conv_precision is not None:
             be.set_precision(self.conv_precision)
+        be.act_dtype = self.act_storage or torch.float32
         return be
 
     def _end_forward(self):
         self._packs_dirty = False
         self._packs_dirty_local = False
         self._be.precision = self._saved_precision
+        self._be.act_dtype = self._saved_act_dtype
 
     def _gslice(self, p):
         o = self._goff[id(p)]
@@ -244,9 +248,10 @@ class HipNetBase(nn.Module):
             self.backward_start_callback(gbuf)
         self._goff = {id(p): o for p, o in zip(ps, self._offsets)}
         self._packs_dirty_local = False
-        saved_precision = be.precision
+        saved_precision, saved_act_dtype = be.precision, be.act_dtype
         if self.conv_precision is not None:
             be.set_precision(self.conv_precision)
+        be.act_dtype = self.act_storage or torch.float32
         self._s2_active = None
         if self.backward_side_stream and dlogits.device.type == "cuda":
             if self._s2 is None:
@@ -257,6 +262,7 @@ class HipNetBase(nn.Module):
             self._flush_ready()
         finally:
             be.precision = saved_precision
+            be.act_dtype = saved_act_dtype
             if self._s2_active is not None:
                 torch.cuda.current_stream().wait_stream(self._s2_active)     # join: the optimizer reads every gradient
                 self._s2_active = None

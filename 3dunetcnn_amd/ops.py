@@ -21,11 +21,12 @@ from ._lib import (IN_AFFINE_ACT, IN_PLAIN, IN_S2D, IN_ZERO_INSERT, OUT_D2S, OUT
 class Act:
     """`mom`: None, or the partial-moment records of this view's channels as a list of (records [N, B, c, 3], B, c) sources in
     channel order -- written by the epilogue of the conv that produced the tensor (Backend.conv_fwd(moments=True)) or by
-    Backend.moments(); Backend.gn_stats finalises them instead of reading the tensor again."""
+    Backend.moments(); Backend.gn_stats finalises them instead of reading the tensor again.
+    Storage type: the buffer's dtype, torch.float32 or torch.bfloat16 (mi355_act.dtype; HipAutocastUNet(activation_storage="bf16"))."""
     __slots__ = ("buf", "c0", "c", "mom")
 
     def __init__(self, buf, c0=0, c=None):
-        assert buf.dim() == 5 and buf.is_contiguous() and buf.dtype == torch.float32
+        assert buf.dim() == 5 and buf.is_contiguous() and buf.dtype in (torch.float32, torch.bfloat16)
         self.buf = buf
         self.c0 = c0
         self.c = buf.shape[-1] - c0 if c is None else c
@@ -41,12 +42,16 @@ class Act:
     def ld(self):
         return self.buf.shape[-1]
 
+    @property
+    def dtype(self):
+        return self.buf.dtype
+
     def ptr(self):
-        return self.buf.data_ptr() + 4 * self.c0
+        return self.buf.data_ptr() + self.buf.element_size() * self.c0
 
     def desc(self):
         n, d, h, w, ld = self.buf.shape
-        return MiAct(self.ptr(), n, d, h, w, self.c, ld)
+        return MiAct(self.ptr(), n, d, h, w, self.c, ld, _lib.ACT_BF16 if self.buf.dtype == torch.bfloat16 else _lib.ACT_F32)
 
     def slice(self, c0, c):
         return Act(self.buf, self.c0 + c0, c)
@@ -142,6 +147,7 @@ class Backend:
         self.device = torch.device(device)
         self._ws_by_stream = {}     # launch stream handle -> workspace tensor: kernels of different streams must not share scratch
         self.precision = PREC_F32   # arithmetic of the 3x3x3 stride-1 convs: see set_precision()
+        self.act_dtype = torch.float32   # storage type of the activations empty_act() makes (engine.HipNetBase sets it per network)
         # The eligible fp32 3x3x3 stride-1 forward / dgrad convolutions (>= WINO_MIN_VOXELS voxels, >= 8 channels either side) run on the
         # Winograd F(2x2, 3x3) x direct-z kernel (csrc/conv3d_wino.hip): 12 instead of 27 multiplications per output and (ci, co), fp32
         # error equal to the direct kernel's. Measured on MI355X (round 3, profiles/r3_winograd_landing.txt): layer set 21.96 -> 15.28 ms,
@@ -190,11 +196,20 @@ class Backend:
         return cur
 
 
-    def empty_act(self, n, d, h, w, c, ld=None):
-        return Act(torch.empty(n, d, h, w, ld or c, dtype=torch.float32, device=self.device), 0, c)
+    def empty_act(self, n, d, h, w, c, ld=None, dtype=None):
+        """dtype None: the backend's activation storage type (self.act_dtype: fp32, or bf16 inside a network that stores 16-bit activations)."""
+        return Act(torch.empty(n, d, h, w, ld or c, dtype=dtype or self.act_dtype, device=self.device), 0, c)
 
-    def zeros_act(self, n, d, h, w, c, ld=None):
-        return Act(torch.zeros(n, d, h, w, ld or c, dtype=torch.float32, device=self.device), 0, c)
+    def zeros_act(self, n, d, h, w, c, ld=None, dtype=None):
+        return Act(torch.zeros(n, d, h, w, ld or c, dtype=dtype or self.act_dtype, device=self.device), 0, c)
+
+    def cast(self, x, dtype=None, out=None):
+        """x in another storage type (mi355_cast): a new Act of `dtype`, or into `out`."""
+        if out is None:
+            out = self.empty_act(*x.shape, dtype=dtype)
+        xd, yd = x.desc(), out.desc()
+        check(self.lib.mi355_cast(ctypes.byref(xd), ctypes.byref(yd), self.stream()), "cast")
+        return out
 
     # -- weights -------------------------------------------------------------------------------------------------
     def pack_weight(self, w, mode):
@@ -336,12 +351,13 @@ class Backend:
         flops = 2.0 * nvox * x.c * y.c * kd ** 3 * (8 if (in_mode == IN_S2D or out_mode == OUT_D2S) else 1)
         if in_mode == IN_ZERO_INSERT:
             flops /= 8.0   # algorithmic work of a stride-2 transposed conv: 27/8 taps per output voxel on average
-        byts = 4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * x.c + nvox * y.c + kd ** 3 * x.c * y.c)
+        xb, yb = x.buf.element_size(), y.buf.element_size()          # algorithmic bytes follow the storage types
+        byts = xb * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * x.c) + yb * nvox * y.c + 4.0 * kd ** 3 * x.c * y.c
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(self.lib.mi355_conv3d_fwd(ctypes.byref(xd), wptr, ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_fwd")
         e1.record()
-        fused = 4.0 * nvox * y.c * ((residual is not None) + (gparts is not None))
+        fused = float(yb) * nvox * y.c * ((residual is not None) + (gparts is not None))
         self._prof_add(name.value.decode(), flops, byts, e0, e1, variant, fused)
         return self._fold_after(y, gparts)
 
@@ -441,7 +457,8 @@ class Backend:
             e1.record()
             nvox = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3]
             flops = 2.0 * nvox * x.c * dy.c * kd ** 3
-            byts = 4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * x.c + nvox * dy.c + kd ** 3 * x.c * dy.c)
+            byts = (x.buf.element_size() * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * x.c) + dy.buf.element_size() * nvox * dy.c +
+                    4.0 * kd ** 3 * x.c * dy.c)
             bf = self.precision != PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT) and out_mode == OUT_PLAIN
             c4 = x.c == 4 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT) and out_mode == OUT_PLAIN
             self._prof_add("conv3d_c4_wgrad (+reduce)" if c4 else "conv3d_wgrad_k3_bf16<...> (+reduce)" if bf

@@ -108,7 +108,7 @@ class _Decoder(nn.Module):
 
 class _Saved:
     """Activations and statistics a residual block keeps for its backward."""
-    __slots__ = ("x", "h1", "st1", "st2", "out", "chscale")
+    __slots__ = ("x", "h1", "st1", "st2", "out", "chscale", "x_lp")
 
 
 class HipUNet3D(HipNetBase):
@@ -175,7 +175,7 @@ class HipUNet3D(HipNetBase):
             y = self.activation(y)
         return y
 
-    def _block_fwd(self, be, blk, x, out, chscale, keep, out_moments=True):
+    def _block_fwd(self, be, blk, x, out, chscale, keep, out_moments=True, x_lp=None):
         """One residual block. x: Act input; out: Act destination (maybe a concat slice). Norm statistics are not passes over the
         tensors: each conv's epilogue leaves the moment records of what it wrote (x.mom / h1.mom, csrc/gn_fuse.h) and gn_stats
         finalises those; `out_moments`: whether `out` is normalised by whoever consumes it."""
@@ -191,14 +191,15 @@ class HipUNet3D(HipNetBase):
         h1.mom = None
         if blk.sample is not None:
             idn = be.empty_act(n, d, h, w, cout)
-            be.conv_fwd(x, self._packed_weight(blk.sample.weight, 0, padw), idn, 1)
+            # x_lp: the 16-bit copy of an fp32 block input (the network input under 16-bit activation storage): what a conv reads of it
+            be.conv_fwd(x if x_lp is None else x_lp, self._packed_weight(blk.sample.weight, 0, padw), idn, 1)
         else:
             idn = x
         be.conv_fwd(h1, self._packed_weight(c2.conv.weight, 0), out, 3, 1, in_mode=IN_AFFINE_ACT, scale=st2[1], shift=st2[2],
                     residual=idn, chscale=chscale, moments=out_moments)
         if keep:
             s = _Saved()
-            s.x, s.h1, s.st1, s.st2, s.out, s.chscale = x, h1, st1, st2, out, chscale
+            s.x, s.h1, s.st1, s.st2, s.out, s.chscale, s.x_lp = x, h1, st1, st2, out, chscale, x_lp
             return s
         return None
 
@@ -225,7 +226,7 @@ class HipUNet3D(HipNetBase):
         if t.shape != p.shape:
             self._gslice(p).copy_(t[:, :p.shape[1]])
 
-    def _layer_fwd(self, be, layer, x, out_last, keep, out_moments=True):
+    def _layer_fwd(self, be, layer, x, out_last, keep, out_moments=True, x_lp=None):
         """All blocks of a layer; the last block writes into out_last (`out_moments`: a norm reads it next). Returns list of saved blocks."""
         saved = []
         nb = len(layer.blocks)
@@ -240,7 +241,7 @@ class HipUNet3D(HipNetBase):
                 keepmask = torch.rand(n, cout, device=be.device, generator=self.dropout_generator) >= p
                 chscale = keepmask.float() / (1.0 - p)
                 self.last_dropout_scale = chscale        # [N, C] keep mask / (1 - p) the forward drew (what parity tests hand the oracle)
-            saved.append(self._block_fwd(be, blk, x, out, chscale, keep, out_moments or j < nb - 1))
+            saved.append(self._block_fwd(be, blk, x, out, chscale, keep, out_moments or j < nb - 1, x_lp if j == 0 else None))
             x = out
         return saved
 
@@ -253,12 +254,17 @@ class HipUNet3D(HipNetBase):
         sizes = [(D, H, W)]
         for _ in range(L - 1):
             sizes.append(tuple((s - 1) // 2 + 1 for s in sizes[-1]))
+        # The network input stays fp32 when it has the first-layer kernels' 4 channels (its norm statistics, the normalising conv and that
+        # conv's weight gradient read it as the reference's GroupNorm does: fp32); under 16-bit activation storage the 1x1x1 shortcut of the
+        # first block reads a 16-bit copy (what autocast's conv does with an fp32 input). Wider inputs are stored like every other activation.
+        xa_dtype = torch.float32 if self._cin_pad == 4 else be.act_dtype
         if self._cin_pad == self.n_features:
-            xa = be.empty_act(n, D, H, W, self.n_features)
+            xa = be.empty_act(n, D, H, W, self.n_features, dtype=xa_dtype)
             be.ncdhw_to_ndhwc(x, xa)
         else:
-            xa = be.zeros_act(n, D, H, W, self._cin_pad)
+            xa = be.zeros_act(n, D, H, W, self._cin_pad, dtype=xa_dtype)
             be.ncdhw_to_ndhwc(x, xa.slice(0, self.n_features))
+        xa_lp = be.cast(xa, be.act_dtype) if xa.dtype != be.act_dtype else None
         # concat buffers for decoder levels: level i (resolution of encoder level i, i < L-1) holds [up | skip]
         cats = []
         for i in range(L - 1):
@@ -276,7 +282,7 @@ class HipUNet3D(HipNetBase):
                 out = cat.slice(up_c, skip_c)
             else:
                 out = be.empty_act(n, d_, h_, w_, enc.widths[i])
-            saved["enc"].append(self._layer_fwd(be, layer, cur, out, keep))
+            saved["enc"].append(self._layer_fwd(be, layer, cur, out, keep, x_lp=xa_lp if i == 0 else None))
             enc_out.append(out)
             if i < L - 1:
                 dn = sizes[i + 1]
@@ -351,17 +357,20 @@ class HipUNet3D(HipNetBase):
             tw = self._wgrad_target(c1.conv.weight, cin)
             be.conv_wgrad(s.x, dh1, tw, 3, 1, in_mode=IN_AFFINE_ACT, scale=st1[1], shift=st1[2])
             self._wgrad_commit(c1.conv.weight, tw)
-        dA1 = be.empty_act(n, d, h, w, cin)
+        dA1 = be.empty_act(n, d, h, w, cin, dtype=s.x.dtype)          # a tensor's gradient is stored like the tensor
         p1 = be.conv_fwd(dh1, self._packed_weight(c1.conv.weight, 1, padw), dA1, 3, 1, gnb=(s.x, st1, groups1, 0.0))
         if blk.sample is not None:
-            with self._wgrad_stream(be, s.x, d_out):
+            xs = s.x if s.x_lp is None else s.x_lp
+            with self._wgrad_stream(be, xs, d_out):
                 ts = self._wgrad_target(blk.sample.weight, cin)
-                be.conv_wgrad(s.x, d_out, ts, 1)
+                be.conv_wgrad(xs, d_out, ts, 1)
                 self._wgrad_commit(blk.sample.weight, ts)
             d_id = None
             if need_dx:
                 d_id = be.empty_act(n, d, h, w, cin)
                 be.conv_fwd(d_out, self._packed_weight(blk.sample.weight, 1, padw), d_id, 1)
+                if d_id.dtype != s.x.dtype:
+                    d_id = be.cast(d_id, s.x.dtype)
         else:
             d_id = d_out
         dx = None
@@ -412,7 +421,7 @@ class HipUNet3D(HipNetBase):
                 dyw, dshape = self._window(be, d_up, off, tuple(2 * s - 1 for s in lay_out.shape[1:4]))
                 be.conv_fwd(dyw, self._packed_weight(up.weight, 3), d_lay, 3, 2, pad=1)
                 be.conv_wgrad(dyw, lay_out, self._gslice(up.weight), 3, 2, pad=1)
-                self._gslice(up.bias).copy_(dyw.tensor().sum(dim=(0, 1, 2, 3)))
+                self._gslice(up.bias).copy_(dyw.tensor().sum(dim=(0, 1, 2, 3), dtype=torch.float32))
             else:
                 pre = dec.pre_upsampling_blocks[k]
                 d_pre = be.empty_act(lay_out.shape[0], lay_out.shape[1], lay_out.shape[2], lay_out.shape[3], out_w)
@@ -463,18 +472,30 @@ class HipUNet3D(HipNetBase):
 class HipAutocastUNet(HipUNet3D):
     """Drop-in for the reference's AutocastUNet (unet3d/models/pytorch/segmentation/unet.py:53-58), which runs UNet3D.forward
     under torch.cuda.amp.autocast (fp16 convolutions with fp32 accumulate, norms in fp32). MI355X equivalent: the 3x3x3
-    convolutions take the 16-bit matrix path (operands rounded while staged, fp32 accumulate, fp32 tensors), everything else stays fp32.
+    convolutions take the 16-bit matrix path (operands rounded while staged, fp32 accumulate); norm statistics, weights, weight
+    gradients, logits and the loss stay fp32.
       autocast_dtype="bf16" (default): BASELINE configs[2]'s "bf16 mixed precision"; bf16 has fp32's exponent range, no GradScaler needed.
       autocast_dtype="fp16": the reference class's own arithmetic (CUDA autocast defaults to fp16; v_mfma_f32_32x32x16_f16): 8x smaller
         rounding error than bf16, fp16's range -- train it with torch's GradScaler as the reference's `training.amp` path does
-        (train/training_utils.py:60-69, 93-96), which this module's backward supports (tests/test_boundary.py)."""
+        (train/training_utils.py:60-69, 93-96), which this module's backward supports (tests/test_boundary.py).
+      activation_storage: "fp32" -- every activation tensor in HBM is fp32 and only the MFMA operands are rounded (the round-2..4 form;
+        the only one for fp16) | "bf16" -- conv outputs, block outputs, concat buffers and all their gradients are STORED as bf16, as
+        the reference's autocast keeps conv outputs: half the bytes of every HBM-bound kernel of the step and of
+        the saved-for-backward set; the network input (4 channels) stays fp32, values are rounded once, when stored. Default: "bf16"
+        with autocast_dtype="bf16", "fp32" with "fp16"."""
 
-    def __init__(self, *args, autocast_dtype="bf16", **kwargs):
+    def __init__(self, *args, autocast_dtype="bf16", activation_storage=None, **kwargs):
         super().__init__(*args, **kwargs)
         name = {torch.bfloat16: "bf16", torch.float16: "fp16", torch.half: "fp16"}.get(autocast_dtype, autocast_dtype)
         if name not in ("bf16", "fp16"):
             raise ValueError(f"autocast_dtype must be 'bf16' / torch.bfloat16 or 'fp16' / torch.float16, got {autocast_dtype!r}")
         self.conv_precision = name
+        st = {torch.bfloat16: "bf16", torch.float32: "fp32", None: ("bf16" if name == "bf16" else "fp32")}.get(activation_storage, activation_storage)
+        if st not in ("bf16", "fp32"):
+            raise ValueError(f"activation_storage must be 'bf16' or 'fp32', got {activation_storage!r}")
+        if st == "bf16" and name != "bf16":
+            raise ValueError("activation_storage='bf16' goes with autocast_dtype='bf16' (16-bit storage of fp16-rounded operands has no kernel)")
+        self.act_storage = torch.bfloat16 if st == "bf16" else None
 
 
 class HipAutoImplantUNet(HipUNet3D):

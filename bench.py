@@ -46,7 +46,8 @@ ARITH = {"fp32": "3x3x3 stride-1 convs with >= 8 channels and >= 16^3 voxels: Wi
                    "(product error <= 2^-16); everything else fp32",
          "bf16x6": "3x3x3 stride-1 convs: fp32 operands split into 3 bf16 planes, 6 bf16 MFMA products per MAC, fp32 accumulate "
                    "(product error ~2^-23, fp32-class); everything else fp32",
-         "bf16": "3x3x3 stride-1 convs: operands rounded to bf16, fp32 accumulate (autocast-style mixed precision); everything else fp32",
+         "bf16": "3x3x3 stride-1 convs: operands rounded to bf16, fp32 accumulate (autocast-style mixed precision); every other conv, the norms, "
+                 "the loss and the optimizer in fp32 arithmetic",
          "fp16": "3x3x3 stride-1 convs: operands rounded to IEEE fp16 (v_mfma_f32_32x32x16_f16), fp32 accumulate -- the arithmetic of the "
                  "reference's AutocastUNet under CUDA autocast; everything else fp32"}
 
@@ -58,6 +59,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=2, help="volumes per GPU (BASELINE configs[1]: 2)")
     ap.add_argument("--size", type=int, default=128, help="cubic patch edge (BASELINE configs[1]: 128)")
+    ap.add_argument("--storage", default=None, choices=["fp32", "bf16"],
+                    help="activation storage type (HipAutocastUNet(activation_storage=...)): default bf16 with --precision bf16 on a UNet3D "
+                         "(conv outputs, block outputs, concat buffers and their gradients live in HBM as bf16, as under the reference's "
+                         "autocast), fp32 otherwise")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x6", "bf16", "fp16"],
                     help="arithmetic of the 3x3x3 stride-1 convs: exact f32 MFMA (default) | split-bf16 fp32 emulation | bf16")
     ap.add_argument("--model", default="unet3d", choices=["unet3d", "dynunet"])
@@ -313,6 +318,12 @@ def main():
     else:
         model = unet.HipUNet3D(n_features=4, n_outputs=3).to(dev)
         model_desc = "UNet3D 4ch->3cls (23970216 params)"
+    if args.storage is None:
+        args.storage = "bf16" if (args.precision == "bf16" and args.model != "dynunet") else "fp32"
+    if args.storage == "bf16":
+        if args.precision != "bf16" or args.model == "dynunet":
+            raise SystemExit("--storage bf16 goes with --precision bf16 on a UNet3D")
+        model.act_storage = torch.bfloat16
     model.train()                                                 # Dropout3d active, as in the reference's training loop
     model.flatten_parameters()
     criterion = losses.HipDiceLoss(sigmoid=True)
@@ -540,7 +551,10 @@ def main():
                "data": "synthetic" if not emu else "synthetic -- CPU-EMULATOR PLUMBING TEST, NOT A MEASUREMENT",
                "config": {"workload": f"BASELINE configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.config] }]: {model_desc}, {'x'.join(str(v) for v in dhw)} patch, batch {B}/GPU, fp32 tensors, "
                                       f"fwd + sigmoid-Dice + bwd + Adam" + (", Dropout3d on" if args.model == "unet3d" else ""),
-                          "conv_arithmetic": ARITH[args.precision], "global_batch": world * B, "parallelism": f"dp{world}"},
+                          "conv_arithmetic": ARITH[args.precision],
+                          "activation_storage": "bf16 (activations and their gradients between the fp32 input volume and the fp32 logits; statistics, "
+                                                "weights, weight gradients and the loss fp32)" if args.storage == "bf16" else "fp32",
+                          "global_batch": world * B, "parallelism": f"dp{world}"},
                "final_loss": round(loss_val, 6), "roofline": roofline, "first_layer": first_layer}
         if world == 1 and args.precision == "fp32" and not args.no_precision_modes and args.config == "c2":
             # informational: the same step with the opt-in arithmetic modes of the 3x3x3 stride-1 convs;
@@ -557,6 +571,20 @@ def main():
                 torch.cuda.synchronize()
                 dtm = (time.perf_counter() - t1) / 3
                 modes[pm] = {"volumes_per_s": round(B / dtm, 3), "ms_per_step": round(dtm * 1e3, 2), "conv_arithmetic": ARITH[pm]}
+                if pm == "bf16" and args.model != "dynunet":
+                    # ... and with 16-bit activation storage on top (what `--precision bf16` and `--config c3` run)
+                    model.act_storage = torch.bfloat16
+                    for _ in range(2):
+                        step()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        step()
+                    torch.cuda.synchronize()
+                    dtm = (time.perf_counter() - t1) / 3
+                    model.act_storage = None
+                    modes["bf16 + bf16 activation storage"] = {"volumes_per_s": round(B / dtm, 3), "ms_per_step": round(dtm * 1e3, 2),
+                                                               "conv_arithmetic": ARITH[pm]}
             be.set_precision("fp32")
             out["precision_modes"] = modes
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":

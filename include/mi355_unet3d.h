@@ -9,7 +9,7 @@
  * Each entry point below names the ATen call(s) it replaces. SURVEY.md section 8(b) is the contract.
  *
  * Conventions
- *  - All activations are fp32, NDHWC ("channels last 3d") views: element (n,z,y,x,c) lives at
+ *  - All activations are NDHWC ("channels last 3d") views, fp32 by default (mi355_act.dtype): element (n,z,y,x,c) lives at
  *    p[(((n*D+z)*H+y)*W+x)*ld + c], ld >= C, ld % 4 == 0, p 16-byte aligned. ld > C is how the
  *    skip-concat is expressed: producers write straight into a channel slice of the concat buffer.
  *  - Ownership: the caller owns every buffer including workspaces; the library never allocates
@@ -33,10 +33,22 @@ extern "C" {
 #define MI355_STATUS_ELAUNCH (-3)      /* hipGetLastError() != hipSuccess after launch */
 #define MI355_STATUS_EWORKSPACE (-4)   /* workspace too small */
 
-/* NDHWC fp32 activation view. */
+/* Storage type of an activation tensor. fp32 is the reference's own; bf16 is what its AutocastUNet (segmentation/unet.py:53-58) keeps
+ * conv outputs in under torch autocast: HipAutocastUNet(activation_storage="bf16") stores every activation and activation gradient
+ * between the input volume and the logits that way (statistics, weights, weight gradients, logits and the loss stay fp32). A bf16 view
+ * has the same (n, d, h, w, c, ld) meaning in ELEMENTS; p must be 8-byte aligned (16-byte for the 16-bit convolution kernels, which also
+ * want ld % 8 == 0). Where an entry point takes a raw tensor pointer beside the views (mi355_conv_desc.residual, mi355_gn_bwd_fuse.gx:
+ * the type of y; the `addend` of mi355_gn_act_bwd: the type of dx) the pointer has the type named there. Every entry point checks the
+ * types it is given: MI355_STATUS_EUNSUPPORTED for a combination it has no kernel for (the Winograd fp32 kernels, mixed-type operands of
+ * one call other than those listed at the entry point), never a silent reinterpretation. */
+#define MI355_ACT_F32 0
+#define MI355_ACT_BF16 1
+
+/* NDHWC activation view (fp32 unless dtype says otherwise; a caller that zero-initialises the struct gets fp32). */
 typedef struct mi355_act {
   void* p;
   int32_t n, d, h, w, c, ld;
+  int32_t dtype; /* MI355_ACT_* */
 } mi355_act;
 
 /* Input-side fusion of the conv kernels. */
@@ -75,7 +87,7 @@ typedef struct mi355_conv_desc {
   const float* in_scale; /* [n][cin]  IN_AFFINE_ACT */
   const float* in_shift; /* [n][cin]  IN_AFFINE_ACT */
   const float* bias;     /* [cout] or NULL (ConvTranspose3d / DynUNet output block keep a bias) */
-  const float* residual; /* NULL or NDHWC tensor with the logical output shape, added in the epilogue (myronenko.py:56) */
+  const void* residual;  /* NULL or NDHWC tensor with the logical output shape AND y's storage type, added in the epilogue (myronenko.py:56) */
   int32_t residual_ld;
   const float* out_chscale; /* NULL or [n][cout]: per-(n,channel) scale after the residual add = Dropout3d mask/(1-p) (myronenko.py:78-79) */
   /* output window: logical output voxel (z,y,x) is stored at (z+off_z, y+off_y, x+off_x) of y when that
@@ -101,7 +113,7 @@ typedef struct mi355_conv_desc {
  * xhat = (gx - mean)*rstd the epilogue writes partials_out[n][B][c][2] = (sum du, sum du*xhat) over each spatial tile -- the
  * first of the two passes of mi355_gn_act_bwd, with dA still in registers. gx has the logical shape of y. */
 typedef struct mi355_gn_bwd_fuse {
-  const float* gx; int32_t gx_ld;
+  const void* gx; int32_t gx_ld;          /* the normalised tensor, in the storage type of y (its gradient) */
   const float* scale; const float* shift; /* [n][c] (mi355_gn_stats / mi355_gn_finalize) */
   const float* mean_rstd;                 /* [n][groups][2] */
   int32_t groups; float act_slope;
@@ -208,12 +220,12 @@ int mi355_gn_finalize(const float* part_a, int32_t blocks_a, int32_t c_a, const 
  *   du = dA * act'(u), dgamma[c] = sum du*xhat, dbeta[c] = sum du,
  *   dx = rstd*(gamma*du - mean_g(gamma*du) - xhat*mean_g(gamma*du*xhat)) (+ addend if not NULL)
  * dgamma/dbeta are written (not accumulated). dx may alias dA. */
-int mi355_gn_act_bwd(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const float* addend, int32_t addend_ld,
+int mi355_gn_act_bwd(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const void* addend, int32_t addend_ld,
                      int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
                      const float* scale, const float* shift, float* dgamma, float* dbeta,
                      void* ws, size_t ws_bytes, void* stream);
 /* The same with the first pass already done by the dgrad conv that produced dA (mi355_gn_bwd_fuse): partials[n][blocks][c][2]. */
-int mi355_gn_act_bwd_fused(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const float* addend, int32_t addend_ld,
+int mi355_gn_act_bwd_fused(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const void* addend, int32_t addend_ld,
                            int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
                            const float* scale, const float* shift, float* dgamma, float* dbeta,
                            const float* partials, int32_t blocks, void* ws, size_t ws_bytes, void* stream);
@@ -235,6 +247,10 @@ int mi355_ndhwc_to_ncdhw(const mi355_act* src, float* dst, void* stream);
 int mi355_add(const mi355_act* a, const mi355_act* b, const mi355_act* y, void* stream);
 /* y[n,v,c] = x[n,v,c] * chscale[n][c]  (Dropout3d backward / standalone forward). y may alias x. */
 int mi355_chscale(const mi355_act* x, const float* chscale, const mi355_act* y, void* stream);
+/* y = x in y's storage type (fp32 <-> bf16, round to nearest even; same types: a strided copy). Same logical shape. Replaces
+ * tensor.to(dtype): the 16-bit copy of the network input the first block's 1x1x1 shortcut reads under activation_storage="bf16", and the
+ * bridge around an entry point that has no kernel for a storage type. */
+int mi355_cast(const mi355_act* x, const mi355_act* y, void* stream);
 
 /* ---- 1x1x1 projection to a few classes -------------------------------------------------------- */
 /* final_convolution (variational.py:59-60; unet.py:50) and DynUNet's output block: Conv3d(cin -> cout<=8, k=1),

@@ -53,6 +53,22 @@ def rel_err(a, b):
     return float((a - b).abs().max()) / (den if den > 0 else 1.0)
 
 
+def store_err(got, ref, dtype):
+    """Error of a launch OUTPUT against its fp64 recomputation, relative to the block's largest value. fp32 tensors: rel_err. A tensor
+    STORED as bf16 (ops.Act.dtype, HipAutocastUNet(activation_storage="bf16")) holds the fp32 result rounded once, to nearest even: the
+    rounding itself (up to half a bf16 ulp of each value) is the storage format, not an error of the launch -- what is left after it is
+    taken out must meet the same bound as an fp32 output. A value the fp32 arithmetic puts on the other side of a rounding boundary
+    differs by a whole ulp from round(ref): the half-ulp allowance around `ref` covers exactly the two candidates next to it."""
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    den = float(ref.abs().max())
+    den = den if den > 0 else 1.0
+    if dtype != torch.bfloat16:
+        return float((got - ref).abs().max()) / den
+    a = ref.abs().clamp(min=2.0 ** -126)
+    ulp = torch.exp2(torch.floor(torch.log2(a)) - 7.0)           # spacing of bf16 (8 significand bits) at |ref|
+    return float(((got - ref).abs() - 0.5 * ulp).clamp(min=0.0).max()) / den
+
+
 def _nc(t5):
     """[N, D, H, W, C] (any device) -> NCDHW fp64 on the CPU."""
     return t5.detach().cpu().double().permute(0, 4, 1, 2, 3).contiguous()
@@ -72,7 +88,7 @@ class LaunchAudit:
     """with LaunchAudit(be) as au: <run a step through modules bound to `be`>;  au.records = [dict(kind, desc, err), ...]"""
 
     WRAPPED = ("conv_fwd", "conv_wgrad", "gn_stats", "gn_act_bwd", "upsample2x_fwd", "upsample2x_bwd", "chscale", "proj_fwd", "proj_bwd",
-               "dice", "adam_step", "ncdhw_to_ndhwc", "ndhwc_to_ncdhw", "add")
+               "dice", "adam_step", "ncdhw_to_ndhwc", "ndhwc_to_ncdhw", "add", "cast")
 
     def __init__(self, be, block_macs=1.5e8, n_blocks=4, wgrad_channels=4, full_macs=4e8, seed=0, verbose=False):
         self.be = be
@@ -292,9 +308,10 @@ class LaunchAudit:
                 if p["chscale"] is not None:
                     ref = ref * p["chscale"].detach().cpu().double()[:, :, None, None, None]
                 # error of the block relative to the magnitude of the block itself (a stricter denominator than the tensor's maximum)
-                worst[form] = max(worst[form], rel_err(got, ref))
+                worst[form] = max(worst[form], store_err(got, ref, y.dtype))
         form = min(worst, key=worst.get)
-        self._rec(kind, desc + (f" [{lp} operands, prologue {form}]" if lp is not None else ""), worst[form])
+        self._rec(kind, desc + (f" [{lp} operands, prologue {form}]" if lp is not None else "") + (" [bf16 storage]" if y.dtype == torch.bfloat16 else ""),
+                  worst[form])
         return ret
 
     def _conv_d2s(self, x, W, y, p):
@@ -433,7 +450,7 @@ class LaunchAudit:
         dxr, dgr, dbr = torch.autograd.grad(out, (xin, g, b), dAi * mask)
         if add is not None:
             dxr = dxr + add
-        e_dx = rel_err(_nc(dx.tensor()[..., sel]), dxr)
+        e_dx = store_err(_nc(dx.tensor()[..., sel]), dxr, dx.dtype)
         # gamma / beta gradients relative to the largest gradient of the whole vector (a channel's own value can cancel to ~0)
         dgk, dbk = p["dgamma"].detach().cpu().double(), p["dbeta"].detach().cpu().double()
         e_g = float((dgk[ch] - dgr).abs().max()) / max(float(dgk.abs().max()), 1e-300)
@@ -448,7 +465,7 @@ class LaunchAudit:
         ch = _subset(lo.c, 4, self.rng)
         sel = torch.as_tensor(ch, device=lo.buf.device)
         ref = O.upsample_pad(_nc(lo.tensor()[..., sel]), cat.shape[1:4])
-        self._rec("upsample_fwd", f"C={lo.c} @{tuple(cat.shape[1:4])}", rel_err(_nc(cat.tensor()[..., sel]), ref))
+        self._rec("upsample_fwd", f"C={lo.c} @{tuple(cat.shape[1:4])}", store_err(_nc(cat.tensor()[..., sel]), ref, cat.dtype))
         return ret
 
     @torch.enable_grad()
@@ -459,7 +476,7 @@ class LaunchAudit:
         sel = torch.as_tensor(ch, device=dlo.buf.device)
         lo = torch.zeros(dlo.shape[0], len(ch), *dlo.shape[1:4], dtype=torch.float64, requires_grad=True)
         (ref,) = torch.autograd.grad(O.upsample_pad(lo, dcat.shape[1:4]), lo, _nc(dcat.tensor()[..., sel]))
-        self._rec("upsample_bwd", f"C={dlo.c} @{tuple(dcat.shape[1:4])}", rel_err(_nc(dlo.tensor()[..., sel]), ref))
+        self._rec("upsample_bwd", f"C={dlo.c} @{tuple(dcat.shape[1:4])}", store_err(_nc(dlo.tensor()[..., sel]), ref, dlo.dtype))
         return ret
 
     def _a_chscale(self, orig, args, kw, p):
@@ -469,7 +486,7 @@ class LaunchAudit:
         before = _nc(x.tensor()[..., sel])                   # in place in the Dropout3d backward
         ret = orig(*args, **kw)
         ref = before * s.detach().cpu().double()[:, ch][:, :, None, None, None]
-        self._rec("chscale", f"C={x.c} @{tuple(x.shape[1:4])}", rel_err(_nc(y.tensor()[..., sel]), ref))
+        self._rec("chscale", f"C={x.c} @{tuple(x.shape[1:4])}", store_err(_nc(y.tensor()[..., sel]), ref, y.dtype))
         return ret
 
     def _a_add(self, orig, args, kw, p):
@@ -478,18 +495,24 @@ class LaunchAudit:
         sel = torch.as_tensor(ch, device=a.buf.device)
         ref = _nc(a.tensor()[..., sel]) + _nc(b.tensor()[..., sel])
         ret = orig(*args, **kw)
-        self._rec("add", f"C={a.c}", rel_err(_nc(y.tensor()[..., sel]), ref))
+        self._rec("add", f"C={a.c}", store_err(_nc(y.tensor()[..., sel]), ref, y.dtype))
+        return ret
+
+    def _a_cast(self, orig, args, kw, p):
+        ret = orig(*args, **kw)
+        ok = torch.equal(ret.tensor(), p["x"].tensor().to(ret.dtype))        # bit-exact: torch rounds to nearest even as v_cvt_pk_bf16_f32 does
+        self._rec("layout", f"cast {p['x'].dtype} -> {ret.dtype}", 0.0 if ok else 1.0)
         return ret
 
     def _a_ncdhw_to_ndhwc(self, orig, args, kw, p):
         ret = orig(*args, **kw)
-        ok = torch.equal(p["dst"].tensor().permute(0, 4, 1, 2, 3), p["src"])
+        ok = torch.equal(p["dst"].tensor().permute(0, 4, 1, 2, 3), p["src"].to(p["dst"].dtype))      # (a 16-bit destination: rounded once)
         self._rec("layout", "ncdhw->ndhwc", 0.0 if ok else 1.0)
         return ret
 
     def _a_ndhwc_to_ncdhw(self, orig, args, kw, p):
         ret = orig(*args, **kw)
-        ok = torch.equal(p["src"].tensor().permute(0, 4, 1, 2, 3), p["dst"])
+        ok = torch.equal(p["src"].tensor().permute(0, 4, 1, 2, 3).float(), p["dst"])
         self._rec("layout", "ndhwc->ncdhw", 0.0 if ok else 1.0)
         return ret
 
@@ -516,7 +539,7 @@ class LaunchAudit:
         dz = p["dlogits"].detach().cpu().double()
         e = [rel_err(p["dw"], torch.einsum("nkdhw,ncdhw->kc", dz, t))]
         if p["dx"] is not None and p["scale"] is None:
-            e.append(rel_err(_nc(p["dx"].tensor()), torch.einsum("nkdhw,kc->ncdhw", dz, p["w"].detach().cpu().double())))
+            e.append(store_err(_nc(p["dx"].tensor()), torch.einsum("nkdhw,kc->ncdhw", dz, p["w"].detach().cpu().double()), p["dx"].dtype))
         if p["dbias"] is not None:
             e.append(rel_err(p["dbias"], dz.sum(dim=(0, 2, 3, 4))))
         self._rec("proj_bwd", f"{p['x'].c}->{p['w'].shape[0]} @{tuple(p['x'].shape[1:4])}", max(e))

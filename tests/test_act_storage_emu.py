@@ -1,0 +1,100 @@
+"""16-bit activation storage (mi355_act.dtype = MI355_ACT_BF16) at op level on the CPU emulator build of the kernel sources (index logic,
+type dispatch, rounding points); tests/act_storage_cases.py states the property. GPU twins: tests/test_act_storage_gpu.py."""
+import importlib
+
+import pytest
+import torch
+
+import act_storage_cases as S
+
+ops = importlib.import_module("3dunetcnn_amd.ops")
+TOL = S.TOL
+
+
+@pytest.fixture
+def bf16_backend(emu_backend):
+    saved = emu_backend.precision
+    emu_backend.set_precision("bf16")
+    yield emu_backend
+    emu_backend.precision = saved
+
+
+def _all_below(errs, tol=TOL, **special):
+    bad = {k: v for k, v in errs.items() if not isinstance(v, bool) and v > special.get(k, tol)}
+    assert not bad, (bad, errs)
+
+
+def test_cast(emu_backend):
+    S.case_cast(emu_backend)
+
+
+def test_pointwise_ops(emu_backend):
+    _all_below(S.case_pointwise(emu_backend))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n=1, c=4, dhw=(4, 4, 6), groups=4), dict(c=24, groups=24, slope=0.01)])
+def test_norm_statistics_and_backward(emu_backend, kw):
+    _all_below(S.case_norm(emu_backend, **kw), dgamma=1e-5, dbeta=1e-5)
+
+
+def test_projection(emu_backend):
+    _all_below(S.case_proj(emu_backend), dw=1e-5)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(cin=32, cout=64)])
+def test_conv_1x1x1(emu_backend, kw):
+    _all_below(S.case_conv_k1(emu_backend, **kw))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(cin=64, cout=32, moments=False)])
+def test_conv_stride2(emu_backend, kw):
+    _all_below(S.case_conv_s2(emu_backend, **kw), moments=2e-5)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(window=True), dict(cin=32, cout=64)])
+def test_conv_zero_insert(emu_backend, kw):
+    _all_below(S.case_conv_zero_insert(emu_backend, **kw))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(cin=32, cout=32, dhw=(4, 4, 16)),                                             # plain input: staged without a conversion
+    dict(cin=32, cout=32, dhw=(5, 6, 18), norm=True, moments=True),                    # ragged tiles, norm prologue, moment records
+    dict(cin=64, cout=32, dhw=(4, 8, 16), norm=True, residual=True, drop=True, moments=True, n=2),
+    dict(cin=32, cout=64, dhw=(4, 5, 17), gnb=True, mode=1),                           # dgrad with the norm-backward sums, ragged
+    dict(cin=40, cout=24, dhw=(3, 4, 9), norm=True),                                   # channel counts that are not tile multiples
+])
+def test_conv_3x3x3_on_16bit_operands(bf16_backend, kw):
+    r = S.case_conv_k3_tile(bf16_backend, **kw)
+    if kw.get("gnb"):
+        assert r["gnb_fused"]
+    _all_below(r, moments=2e-5, gnb=1e-5)
+
+
+def test_first_layer(bf16_backend):
+    _all_below(S.case_first_layer(bf16_backend), moments=2e-5, wgrad=1e-5)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(kd=1, stride=1, cin=64, cout=32, dhw=(4, 5, 7)),
+    dict(kd=3, stride=2, cin=32, cout=32, dhw=(9, 8, 11), n=2),
+    dict(kd=3, stride=1, cin=32, cout=32, dhw=(5, 6, 18), norm=True),                  # 16-bit-operand weight gradient
+    dict(kd=3, stride=1, cin=32, cout=96, dhw=(3, 4, 17), norm=True),                  # ... its 64-channel workgroup form
+])
+def test_weight_gradients(bf16_backend, kw):
+    _all_below(S.case_wgrad(bf16_backend, **kw), dw=1e-5)
+
+
+def test_mixed_storage_types_are_refused(emu_backend):
+    """One storage type per call (except the first-layer kernels): the library answers MI355_STATUS_EUNSUPPORTED, never reinterprets."""
+    be = emu_backend
+    a = be.empty_act(1, 4, 4, 8, 32)
+    b = be.empty_act(1, 4, 4, 8, 32, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        be.add(a, b, a)
+    w = be.pack_weight(torch.randn(32, 32, 1, 1, 1), 0)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        be.conv_fwd(a, w, b, 1)
+    w3 = be.pack_weight(torch.randn(32, 32, 3, 3, 3), 0)
+    y = be.empty_act(1, 4, 4, 8, 32, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        be.conv_fwd(b, w3, y, 3)          # fp32 arithmetic (the backend's default precision) on 16-bit tensors: no such 3x3x3 kernel

@@ -1,0 +1,130 @@
+"""GPU twins of tests/test_act_storage_emu.py: 16-bit activation storage at op level on the MI355X (the HIP library through the C ABI),
+at sizes that take the kernels' interior fast paths, several workgroups per CU and ragged edges. tests/act_storage_cases.py states the
+property (stored == the fp32-tensor result rounded once)."""
+import importlib
+
+import pytest
+import torch
+
+import act_storage_cases as S
+
+pytestmark = pytest.mark.gpu
+ops = importlib.import_module("3dunetcnn_amd.ops")
+TOL = S.TOL
+
+
+@pytest.fixture
+def bf16_backend(hip_backend):
+    saved = hip_backend.precision
+    hip_backend.set_precision("bf16")
+    yield hip_backend
+    hip_backend.precision = saved
+
+
+def _all_below(errs, tol=TOL, **special):
+    bad = {k: v for k, v in errs.items() if not isinstance(v, bool) and v > special.get(k, tol)}
+    assert not bad, (bad, errs)
+
+
+def test_cast(hip_backend):
+    S.case_cast(hip_backend)
+
+
+def test_pointwise_ops(hip_backend):
+    _all_below(S.case_pointwise(hip_backend))
+
+
+@pytest.mark.parametrize("kw", [dict(n=2, c=32, dhw=(32, 32, 32)), dict(n=1, c=4, dhw=(16, 16, 24), groups=4), dict(c=96, groups=96, slope=0.01, dhw=(8, 8, 8)),
+                                dict(n=2, c=256, dhw=(8, 8, 8))])
+def test_norm_statistics_and_backward(hip_backend, kw):
+    _all_below(S.case_norm(hip_backend, **kw), dgamma=1e-5, dbeta=1e-5)
+
+
+def test_projection(hip_backend):
+    _all_below(S.case_proj(hip_backend), dw=1e-5)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(cin=32, cout=64), dict(cin=256, cout=128)])
+def test_conv_1x1x1(hip_backend, kw):
+    _all_below(S.case_conv_k1(hip_backend, **kw))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(cin=64, cout=32, moments=False), dict(cin=128, cout=128)])
+def test_conv_stride2(hip_backend, kw):
+    _all_below(S.case_conv_s2(hip_backend, **kw), moments=2e-5)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(window=True), dict(cin=32, cout=64), dict(cin=256, cout=128)])
+def test_conv_zero_insert(hip_backend, kw):
+    _all_below(S.case_conv_zero_insert(hip_backend, **kw))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(cin=32, cout=32, dhw=(16, 32, 32), n=2),                                      # interior tiles, plain input staged without a conversion
+    dict(cin=32, cout=32, dhw=(17, 30, 35), norm=True, moments=True),                  # ragged tiles, norm prologue, moment records
+    dict(cin=64, cout=32, dhw=(16, 16, 32), norm=True, residual=True, drop=True, moments=True, n=2),
+    dict(cin=32, cout=64, dhw=(16, 17, 33), gnb=True, mode=1),                         # dgrad with the norm-backward sums, ragged
+    dict(cin=128, cout=128, dhw=(8, 8, 16), norm=True, residual=True, moments=True, n=2),
+    dict(cin=256, cout=256, dhw=(8, 8, 16), gnb=True, mode=1),
+    dict(cin=40, cout=24, dhw=(7, 9, 19), norm=True),                                  # channel counts that are not tile multiples
+])
+def test_conv_3x3x3_on_16bit_operands(bf16_backend, kw):
+    r = S.case_conv_k3_tile(bf16_backend, **kw)
+    if kw.get("gnb"):
+        assert r["gnb_fused"]
+    _all_below(r, moments=2e-5, gnb=1e-5)
+
+
+@pytest.mark.parametrize("dhw", [(6, 9, 10), (32, 32, 32)])
+def test_first_layer(bf16_backend, dhw):
+    _all_below(S.case_first_layer(bf16_backend, dhw=dhw), moments=2e-5, wgrad=1e-5)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(kd=1, stride=1, cin=64, cout=32, dhw=(16, 16, 16), n=2),
+    dict(kd=3, stride=2, cin=32, cout=32, dhw=(17, 16, 19), n=2),
+    dict(kd=3, stride=1, cin=32, cout=32, dhw=(16, 32, 32), norm=True, n=2),           # 16-bit-operand weight gradient
+    dict(kd=3, stride=1, cin=64, cout=96, dhw=(9, 15, 19), norm=True),                 # ... its 64-channel workgroup form, ragged
+    dict(kd=3, stride=1, cin=256, cout=256, dhw=(8, 8, 16)),
+])
+def test_weight_gradients(bf16_backend, kw):
+    _all_below(S.case_wgrad(bf16_backend, **kw), dw=1e-5)
+
+
+def test_mixed_storage_types_are_refused(hip_backend):
+    be = hip_backend
+    a = be.empty_act(1, 4, 4, 8, 32)
+    b = be.empty_act(1, 4, 4, 8, 32, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        be.add(a, b, a)
+    w = be.pack_weight(torch.randn(32, 32, 1, 1, 1, device=be.device), 0)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        be.conv_fwd(a, w, b, 1)
+
+
+def test_bf16_storage_train_steps_track_the_fp32_storage_run():
+    """HipAutocastUNet(bf16), 64^3 batch 2: five optimizer steps with activation_storage="bf16" next to the same steps with fp32 tensors
+    (same seed, same Dropout3d masks): losses within 2e-3 of each other at every step, and the saved-activation memory about half."""
+    unet = importlib.import_module("3dunetcnn_amd.unet"); losses = importlib.import_module("3dunetcnn_amd.losses")
+    optim = importlib.import_module("3dunetcnn_amd.optim"); syn = importlib.import_module("3dunetcnn_amd.synthetic")
+    x, y = syn.synthetic_case(2, 4, (64, 64, 64))
+    x, y = x.cuda(), y.cuda()
+    hist, peak = {}, {}
+    for st in ("fp32", "bf16"):
+        torch.manual_seed(3)
+        m = unet.HipAutocastUNet(n_features=4, n_outputs=3, activation_storage=st).cuda().train()
+        m.dropout_generator = torch.Generator(device="cuda").manual_seed(11)
+        crit = losses.HipDiceLoss(sigmoid=True); opt = optim.HipAdam(m.parameters(), lr=1e-3)
+        torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        ls = []
+        for _ in range(5):
+            opt.zero_grad(set_to_none=True)
+            l = crit(m(x), y); l.backward(); opt.step()
+            ls.append(float(l))
+        torch.cuda.synchronize()
+        hist[st], peak[st] = ls, torch.cuda.max_memory_allocated() - base
+        del m, opt
+    print(hist, {k: round(v / 2 ** 20) for k, v in peak.items()})
+    assert all(abs(a - b) < 2e-3 for a, b in zip(hist["fp32"], hist["bf16"])), hist
+    assert peak["bf16"] < 0.7 * peak["fp32"], peak

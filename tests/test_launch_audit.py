@@ -122,18 +122,24 @@ def test_audit_dynunet_train_step_emulator(emu_backend):
     _check(au, {"conv_fwd": 10, "conv_d2s": 4, "conv_wgrad": 8, "gn_act_bwd": 4})
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "bf16-fp32-tensors"])
 def test_audit_16bit_train_step_emulator(emu_backend, mode):
     """The mixed-precision step (HipAutocastUNet: the 3x3x3 stride-1 convs and their weight gradients on 16-bit operands) audited
     with the 16-bit operand model: every such launch agrees to 1e-5 with fp64 of operands rounded as the mode rounds them, every
     other launch (first-layer gradients, stride-2 / 1x1x1 convs, norms, loss, Adam) with plain fp64 as in the fp32 step."""
     torch.manual_seed(5)
-    m = unet.HipAutocastUNet(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1, 2], autocast_dtype=mode).train()
+    storage = "fp32" if mode != "bf16" else "bf16"      # "bf16": the default of the mode -- activations STORED as bf16 (output-storage model)
+    m = unet.HipAutocastUNet(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1, 2], autocast_dtype=mode.split("-")[0],
+                             activation_storage=storage).train()
+    assert (m.act_storage == torch.bfloat16) == (mode == "bf16")
     m.backward_side_stream = False
     x, y = R.synthetic_case(2, 4, (16, 16, 16), 3)
     au, loss = _step(emu_backend, m, x, y, "cpu", block_macs=2e5, full_macs=1e6, wgrad_channels=3)
     assert 0.0 < loss <= 1.0
     counts = au.counts()
+    if mode == "bf16":
+        stored = [r for r in au.records if "[bf16 storage]" in r["desc"]]
+        assert len(stored) >= 30, len(stored)           # every conv output of the step but the first layer's input gradient is a 16-bit tensor
     # 8 residual-block convs + 1 first-layer forward on 16-bit operands + their dgrads; the first layer's dgrad / wgrad and the stride-2
     # / 1x1x1 / up-sampling convs stay fp32
     _check(au, {"conv_fwd_lp": 15, "conv_wgrad_lp": 7, "conv_fwd": 8, "conv_wgrad": 5, "gn_act_bwd": 8, "gn_stats": 8})
@@ -147,7 +153,7 @@ def test_audit_16bit_model_is_the_rounding_of_the_mode(emu_backend, monkeypatch)
     x, y = R.synthetic_case(1, 4, (16, 16, 16), 3)
 
     def run(mode, claim):
-        m = unet.HipAutocastUNet(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1], autocast_dtype=mode).eval()
+        m = unet.HipAutocastUNet(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1], autocast_dtype=mode, activation_storage="fp32").eval()
         m.backward_side_stream = False
         if claim is not None:
             monkeypatch.setattr(A.LaunchAudit, "_fwd_precision", lambda self, *a: claim)
@@ -166,6 +172,32 @@ def test_audit_16bit_model_is_the_rounding_of_the_mode(emu_backend, monkeypatch)
     as_f16 = run("bf16", A.PREC_F16)
     errs = [r["err"] for r in as_f16.records if r["kind"] in ("conv_fwd_lp", "conv_wgrad_lp") and k3(r)]
     assert len(errs) >= 8 and min(errs) > 1e-4, errs
+
+
+def test_audit_bf16_storage_transposed_conv_emulator(emu_backend):
+    """activation_storage="bf16" through the ConvTranspose3d(k3, s2) decoder (decoder.py:96-102): zero-insert forward into a windowed concat
+    slice, its stride-2 dgrad and weight gradient on 16-bit tensors."""
+    torch.manual_seed(6)
+    m = unet.HipAutocastUNet(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1, 1], use_transposed_convolutions=True).train()
+    assert m.act_storage == torch.bfloat16
+    m.backward_side_stream = False
+    x, y = R.synthetic_case(1, 4, (16, 16, 16), 3)
+    au, loss = _step(emu_backend, m, x, y, "cpu", block_macs=2e5, full_macs=1e6, wgrad_channels=3)
+    assert 0.0 < loss <= 1.0
+    _check(au, {"conv_fwd_lp": 10, "conv_wgrad_lp": 5, "conv_fwd": 6, "gn_act_bwd": 6})
+
+
+def test_audit_storage_model_allows_the_rounding_and_nothing_else():
+    """store_err: half a bf16 ulp of every value is the storage format; one more ulp anywhere is an error of the launch."""
+    g = torch.Generator().manual_seed(0)
+    ref = torch.randn(4, 8, 5, 6, 7, generator=g, dtype=torch.float64) * 3.0
+    stored = ref.float().bfloat16().double()
+    assert A.store_err(stored, ref, torch.bfloat16) < 1e-7                     # (the fp64 -> fp32 step of this emulation)
+    assert A.store_err(stored, ref, torch.float32) > 1e-3                      # as an fp32 tensor the same values are far off
+    bad = stored.clone()
+    i = (1, 2, 3, 4, 5)
+    bad[i] = torch.nextafter(stored[i].float().bfloat16(), torch.tensor(float("inf")).bfloat16()).double()      # one ulp up
+    assert A.store_err(bad, ref, torch.bfloat16) > 1e-4
 
 
 @pytest.mark.gpu
@@ -233,12 +265,13 @@ def test_audit_c3_bf16_train_step_gpu(hip_backend):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "bf16-fp32-tensors"])
 def test_audit_16bit_train_step_gpu(hip_backend, mode):
     """The 16-bit operand model on the product kernels at a size every routing of the mode takes part in (64^3, batch 2: plane-ring
     form on the 32-channel level, tile forms below, first-layer forward on the 16-bit pipe)."""
     torch.manual_seed(7)
-    m = unet.HipAutocastUNet(n_features=4, n_outputs=3, autocast_dtype=mode).cuda().train()
+    m = unet.HipAutocastUNet(n_features=4, n_outputs=3, autocast_dtype=mode.split("-")[0],
+                             activation_storage="bf16" if mode == "bf16" else "fp32").cuda().train()
     x, y = R.synthetic_case(2, 4, (64, 64, 64), 3)
     # fp16 is trained with a loss scale, as the reference does (GradScaler, initial scale 2^16): unscaled, the Dice gradients (1e-6 ..
     # 1e-9) sit in fp16's SUBNORMAL range, where the matrix pipe and tensor.half() need not agree (measured on MI355X without the

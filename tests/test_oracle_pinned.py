@@ -109,14 +109,17 @@ def test_emulated_kernels_reproduce_golden(emu_backend, name):
 def _autocast_golden(be, dev):
     """HipAutocastUNet against the REFERENCE graph run under torch.autocast (tests/golden/unet3d_small_autocast.pt, generated by
     oracle/make_golden.py from the imported reference; AutocastUNet = UNet3D.forward under autocast, unet.py:53-58). Two 16-bit
-    roundings of the same fp32 network are compared, so the bound is the sum of both errors; the HIP modes keep fp32 tensors between
-    the convolutions (the reference rounds every conv OUTPUT to 16 bits too), so they must also be at least as close to the fp32
+    roundings of the same fp32 network are compared, so the bound is the sum of both errors. The reference rounds every conv OUTPUT to
+    16 bits; so does the bf16 mode's default activation_storage="bf16" (values rounded once, on store), while activation_storage="fp32"
+    (and the fp16 mode) keeps fp32 tensors between the convolutions: either way the HIP result must be at least as close to the fp32
     logits as the reference's own autocast result is."""
     a = torch.load(os.path.join(GOLD, "unet3d_small_autocast.pt"))
     g = torch.load(os.path.join(GOLD, a["bundle"]))
     res = {}
-    for mode, tol in (("fp16", 4e-3), ("bf16", 3e-2)):
-        m = unet.HipAutocastUNet(autocast_dtype=mode, **g["kwargs"]).to(dev).eval()
+    for mode, storage, tol in (("fp16", "fp32", 4e-3), ("bf16", "bf16", 3e-2), ("bf16", "fp32", 3e-2)):
+        m = unet.HipAutocastUNet(autocast_dtype=mode, activation_storage=storage, **g["kwargs"]).to(dev).eval()
+        assert (m.act_storage == torch.bfloat16) == (storage == "bf16") and unet.HipAutocastUNet(autocast_dtype=mode, **g["kwargs"]).act_storage == \
+            (torch.bfloat16 if mode == "bf16" else None)
         if be is not None:
             m._be = be
         m.load_state_dict(g["state_dict"])
@@ -126,8 +129,9 @@ def _autocast_golden(be, dev):
         e_ref = C.rel_err(ref16, ref32)                      # the reference's own autocast error
         e_hip = C.rel_err(out, ref32)
         assert C.rel_err(out, ref16) < tol, (mode, C.rel_err(out, ref16))
-        assert 1e-6 < e_hip <= e_ref, (mode, e_hip, e_ref)  # really the 16-bit path, and no worse than the reference's
-        res[mode] = e_hip
+        assert 1e-6 < e_hip <= e_ref, (mode, storage, e_hip, e_ref)  # really the 16-bit path, and no worse than the reference's
+        res[mode] = max(res.get(mode, 0.0), e_hip)
+        res[mode + "/" + storage] = e_hip
     assert res["fp16"] < 0.25 * res["bf16"]                  # 11 vs 8 significand bits
     return res
 
@@ -148,8 +152,8 @@ def test_mixed_precision_gradients_against_the_reference_gradients(emu_backend):
     bf16 6.1e-2 / 1 - 1.8e-3."""
     g = torch.load(os.path.join(GOLD, "unet3d_small.pt"))
     res = {}
-    for mode, tol, cos_min in (("fp16", 5e-2, 0.999), ("bf16", 1.5e-1, 0.99)):
-        m = unet.HipAutocastUNet(autocast_dtype=mode, **g["kwargs"]).eval()
+    for mode, storage, tol, cos_min in (("fp16", "fp32", 5e-2, 0.999), ("bf16", "fp32", 1.5e-1, 0.99), ("bf16", "bf16", 1.5e-1, 0.99)):
+        m = unet.HipAutocastUNet(autocast_dtype=mode, activation_storage=storage, **g["kwargs"]).eval()
         m._be = emu_backend
         m.load_state_dict(g["state_dict"])
         crit = losses.HipDiceLoss(sigmoid=True)
@@ -161,9 +165,10 @@ def test_mixed_precision_gradients_against_the_reference_gradients(emu_backend):
         rel = float((a - b).norm() / b.norm())
         cos = float((a * b).sum() / a.norm() / b.norm())
         assert abs(float(loss.detach()) - float(g["loss"])) / float(g["loss"]) < 1e-4
-        assert rel < tol and cos > cos_min, (mode, rel, cos)
-        res[mode] = rel
-    assert res["fp16"] < 0.5 * res["bf16"]
+        assert rel < tol and cos > cos_min, (mode, storage, rel, cos)
+        res[mode + "/" + storage] = rel
+    print(res)
+    assert res["fp16/fp32"] < 0.5 * min(res["bf16/fp32"], res["bf16/bf16"])
 
 
 def test_fp16_mode_rounds_operands_like_tensor_half(emu_backend):
