@@ -425,7 +425,7 @@ void conv3d_k3_bf16(ConvBArgs a) {
 struct LpZPlan { int tilesY, tilesX, zsplits, zper, use, ks, coTiles; };
 static LpZPlan plan_lp_zring(int n, int cin, int cout, int d, int h, int w, int precision, const mi355_conv_desc* desc, int act_dtype = MI355_ACT_F32) {
   LpZPlan p; memset(&p, 0, sizeof(p));
-  if (act_dtype != MI355_ACT_F32) return p;                 // 16-bit activation storage: the tile form (the plane rings read fp32 tensors)
+  if (act_dtype != MI355_ACT_F32 && precision != MI355_PREC_BF16) return p;      // bf16 storage goes with bf16 operands
   const char* fe = getenv("MI355_BF16_FORM");
   const bool v1 = fe && !strncmp(fe, "zring1", 6);
   const char form = fe && fe[0] ? fe[0] : 'a';
@@ -585,8 +585,9 @@ int mi355_conv3d_bf16_kernel_name(const mi355_act* x, const mi355_act* y, const 
   const char* f16 = d->precision == MI355_PREC_F16 ? "true" : "false";
   const LpZPlan zp = plan_lp_zring(x->n, x->c, y->c, d->out_d, d->out_h, d->out_w, d->precision, d, x->dtype);
   if (zp.use && y->d == d->out_d && y->h == d->out_h && y->w == d->out_w && x->d == d->out_d && x->h == d->out_h && x->w == d->out_w) {
-    if (zp.use == 1) snprintf(out, n, "conv3d_k3_lp_zring<2, %d, %d, %s>", d->in_mode, fuse, f16);
-    else snprintf(out, n, "conv3d_k3_lp_zring2<2, %d, %d, %d, %s>", zp.ks, d->in_mode, fuse, f16);
+    const char* st = x->dtype == MI355_ACT_BF16 ? "unsigned short" : "float";
+    if (zp.use == 1) snprintf(out, n, "conv3d_k3_lp_zring<2, %d, %d, %s, %s>", d->in_mode, fuse, f16, st);
+    else snprintf(out, n, "conv3d_k3_lp_zring2<2, %d, %d, %d, %s, %s>", zp.ks, d->in_mode, fuse, f16, st);
     return 0;
   }
   const long long vox = (long long)d->out_d * d->out_h * d->out_w * x->n;
@@ -643,9 +644,9 @@ int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_a
       a.coTiles = zp.coTiles;
       const long long wgs = blocks * zp.coTiles;
       if (wgs > 0x7fffffffLL) return MI355_EINVAL;
-      return mi355_lp_zring2_launch(a, zp.ks, d->in_mode, fuse, f16, wgs, stream);
+      return mi355_lp_zring2_launch(a, zp.ks, d->in_mode, fuse, f16, lp, wgs, stream);
     }
-    return mi355_lp_zring_launch(a, d->in_mode, fuse, f16, blocks, stream);
+    return mi355_lp_zring_launch(a, d->in_mode, fuse, f16, lp, blocks, stream);
   }
   if (lp) return dispatch_ns<1, false, bf16_t>(a, d->in_mode, vox, stream);
   if (d->precision == MI355_PREC_F16) return dispatch_ns<1, true>(a, d->in_mode, vox, stream);

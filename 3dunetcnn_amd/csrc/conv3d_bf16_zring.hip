@@ -2,6 +2,7 @@
 // MI355_PREC_F16; reference op: unet3d/models/pytorch/classification/resnet.py:12-22 called from myronenko.py:17-21, same fusions as
 // conv3d_bf16.hip). Own translation unit: the kernels are long unrolled instruction streams (minutes of compile time).
 #include "conv3d_lp.h"
+#include "act_io.h"
 
 // =====================================================================================================================================
 // Plane-ring (z-marching), WEIGHTS-STATIONARY form for the 16-bit single-product modes (MI355_PREC_BF16 / MI355_PREC_F16) with <= 32
@@ -23,8 +24,11 @@
 //     registers over the whole z range: one record per (z range, column).
 // Wave w owns the M tile of rows 2 w, 2 w + 1 (32 voxels, the conflict-free lane -> voxel map of mtile_lane). Interior columns only
 // (H % 8 == 0, W % 16 == 0, plain un-windowed output): the dispatcher keeps the tile kernel for everything else.
-template <int J, int INMODE, int FUSE, bool F16>
+// TA: storage type of x, y, the residual and the normalised tensor of the norm-backward sums (act_io.h; bf16 storage with bf16 operands only).
+template <int J, int INMODE, int FUSE, bool F16, typename TA = float>
 __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring(ConvBArgs a) {
+  constexpr bool LPS = std::is_same<TA, bf16_t>::value;      // 16-bit storage: a staging unit is one 16-byte run of 8 channels
+  static_assert(!LPS || !F16, "bf16 storage goes with bf16 operands");
   constexpr int TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HVP = HY * HX;      // haloed plane: 180 voxels
   constexpr int OCT = 2 * J;                 // channel octets of the (padded) input: 2 (16 channels) or 4 (32)
   constexpr int VSQ = OCT + 1;               // voxel stride in 16-byte units (odd)
@@ -93,22 +97,34 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring(Conv
     }
   }
   const size_t xplane = (size_t)a.Hi * a.Wi * a.xld;
-  const float* xn = a.x + (size_t)n * a.Di * xplane;
+  const TA* xn = reinterpret_cast<const TA*>(a.x) + (size_t)n * a.Di * xplane;
   // plane p (may lie outside the volume: clamped address, zeroed at the conversion) -> register set
   auto loads = [&](float4 (&ld)[UP][2], int p) {
     const int pc = p < 0 ? 0 : (p < a.Di ? p : a.Di - 1);
-    const float* base = xn + (size_t)pc * xplane;             // workgroup-uniform
+    const TA* base = xn + (size_t)pc * xplane;                // workgroup-uniform
 #pragma unroll
     for (int k = 0; k < UP; ++k) {
-      ld[k][0] = *reinterpret_cast<const float4*>(base + uoff[k] + c0q);
-      ld[k][1] = *reinterpret_cast<const float4*>(base + uoff[k] + c1q);
+      if constexpr (LPS) {                                   // 8 packed bf16 in set element 0 (element 1 stays unused)
+        const uint2 r0 = *reinterpret_cast<const uint2*>(base + uoff[k] + c0q), r1 = *reinterpret_cast<const uint2*>(base + uoff[k] + c1q);
+        ld[k][0] = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r1.x), __uint_as_float(r1.y));
+      } else {
+        ld[k][0] = *reinterpret_cast<const float4*>(base + uoff[k] + c0q);
+        ld[k][1] = *reinterpret_cast<const float4*>(base + uoff[k] + c1q);
+      }
     }
   };
   // conversion of one staged element (norm + activation, mask) / of a unit's eight elements into its ring slot. The step below
   // spreads these over the MFMAs of a plane one element at a time; the prologue runs a whole plane at once (`commit`).
   auto conv_elem = [&](const float4 (&ld)[UP][2], int k, int e, bool pin) -> float {
-    const float4 q = ld[k][e >> 2];
-    float v = (e & 3) == 0 ? q.x : (e & 3) == 1 ? q.y : (e & 3) == 2 ? q.z : q.w;
+    float v;
+    if constexpr (LPS) {
+      const float4 q = ld[k][0];
+      const unsigned w = __float_as_uint((e >> 1) == 0 ? q.x : (e >> 1) == 1 ? q.y : (e >> 1) == 2 ? q.z : q.w);
+      v = (e & 1) ? bf16hi_to_f32(w) : bf16lo_to_f32(w);
+    } else {
+      const float4 q = ld[k][e >> 2];
+      v = (e & 3) == 0 ? q.x : (e & 3) == 1 ? q.y : (e & 3) == 2 ? q.z : q.w;
+    }
     if (INMODE == MI355_IN_AFFINE_ACT) {
       const float u = v * sc[e] + sh[e];
       v = fmaxf(u, u * sl[e]);
@@ -161,22 +177,23 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring(Conv
   auto side_loads = [&](Side& sd, int z) {
     const size_t v0 = vrow0 + (size_t)z * oplane;             // wave-uniform
     if constexpr (FUSE == 2) {
-      const float* gb = a.g.gx + v0 * a.g.gxld;
+      const TA* gb = reinterpret_cast<const TA*>(a.g.gx) + v0 * a.g.gxld;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sd.gx[r] = (gb + (size_t)r * a.g.gxld)[((0x6 >> (r >> 2)) & 1) ? goB : goA];
+      for (int r = 0; r < 16; ++r) sd.gx[r] = ld1(gb + (size_t)r * a.g.gxld + (((0x6 >> (r >> 2)) & 1) ? goB : goA));
     }
     if (a.res) {                                             // workgroup-uniform
-      const float* rb = a.res + v0 * a.resld;
+      const TA* rb = reinterpret_cast<const TA*>(a.res) + v0 * a.resld;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sd.rs[r] = (rb + (size_t)r * a.resld)[((0x6 >> (r >> 2)) & 1) ? roB : roA];
+      for (int r = 0; r < 16; ++r) sd.rs[r] = ld1(rb + (size_t)r * a.resld + (((0x6 >> (r >> 2)) & 1) ? roB : roA));
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sd.rs[r] = 0.f;
     }
   };
-  auto epilogue_value = [&](const f32x16& acc, const Side& sd, float* yb, int r) {      // yb: wave-uniform base of the plane
-    const float v = (acc[r] + bs + sd.rs[r]) * cs;
-    (yb + (size_t)r * a.yld)[((0x6 >> (r >> 2)) & 1) ? yoB : yoA] = v;
+  auto epilogue_value = [&](const f32x16& acc, const Side& sd, TA* yb, int r) {      // yb: wave-uniform base of the plane
+    float v = (acc[r] + bs + sd.rs[r]) * cs;
+    st1(yb + (size_t)r * a.yld + (((0x6 >> (r >> 2)) & 1) ? yoB : yoA), v);
+    if constexpr (FUSE != 0) v = as_stored(yb, v);
     if constexpr (FUSE == 1) {
       if (first && r == 0) K0 = v;
       const float t = v - K0;
@@ -189,7 +206,7 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring(Conv
     }
   };
   auto epilogue = [&](const f32x16& acc, const Side& sd, int z) {
-    float* yb = a.y + (vrow0 + (size_t)z * oplane) * a.yld;
+    TA* yb = reinterpret_cast<TA*>(a.y) + (vrow0 + (size_t)z * oplane) * a.yld;
 #pragma unroll
     for (int r = 0; r < 16; ++r) epilogue_value(acc, sd, yb, r);
     first = false;
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring(Conv
     Side sd;
     if constexpr (HASPREV) side_loads(sd, z - 1);
     const bool pin = z + 2 >= 0 && z + 2 < a.Di;             // plane z + 2 (in `cur`) exists; workgroup-uniform
-    float* yb = a.y + (vrow0 + (size_t)(z - 1) * oplane) * a.yld;
+    TA* yb = reinterpret_cast<TA*>(a.y) + (vrow0 + (size_t)(z - 1) * oplane) * a.yld;
     SCHED_BARRIER();
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -303,8 +320,12 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring(Conv
 // MFMA busy -- with one wave per SIMD the wave's own vector-ALU / LDS / memory instructions add to its MFMA time instead of hiding under it.
 //   J  : k-steps (16 channels) per tap of a wave's channel slice (2)        KS : channel slices = M tiles per wave (1 | 2)
 // Output channels: one 32-channel tile per workgroup (blockIdx carries the tile), Cout a multiple of 32.
-template <int J, int KS, int INMODE, int FUSE, bool F16>
+// TA: storage type of x, y and the residual (act_io.h). bf16 storage (bf16 operands only): a staging unit is ONE 16-byte run of 8 channels
+// (a plain input goes to the ring as loaded, no conversion), outputs are rounded once on store, moments are taken over the values as stored.
+template <int J, int KS, int INMODE, int FUSE, bool F16, typename TA = float>
 __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring2(ConvBArgs a) {
+  constexpr bool LPS = std::is_same<TA, bf16_t>::value;      // 16-bit storage
+  static_assert(!LPS || !F16, "bf16 storage goes with bf16 operands");
   constexpr int TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HVP = HY * HX;      // haloed plane: 180 voxels
   constexpr int MT = KS;                     // M tiles (two x-rows of 16 voxels) per wave
   constexpr int CT = KS * 16 * J;            // channels of a staged plane (the padded input)
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring2(Con
     }
   }
   const size_t xplane = (size_t)a.Hi * a.Wi * a.xld;
-  const float* xn = a.x + (size_t)n * a.Di * xplane;
+  const TA* xn = reinterpret_cast<const TA*>(a.x) + (size_t)n * a.Di * xplane;
   // Input planes in flight. One wave per SIMD and one workgroup per CU: nothing but the distance between a request and its first use
   // hides the HBM latency (~2 us under load, a step is 2-4 us). KS = 2 has registers for ONE set: requested mid-step, consumed in the
   // first half of the next step (half a step of lead). KS = 1 has 100 registers to spare: a second set `ldn` holds the plane after
@@ -423,18 +444,23 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring2(Con
   float4 ld[UP][2], ldn[TWOSETS ? UP : 1][2];
   auto loads_into = [&](float4 (&dst)[UP][2], int p) {        // plane p (may lie outside the volume: clamped address, zeroed at the conversion)
     const int pc = p < 0 ? 0 : (p < a.Di ? p : a.Di - 1);
-    const float* base = xn + (size_t)pc * xplane;             // workgroup-uniform
+    const TA* base = xn + (size_t)pc * xplane;                // workgroup-uniform
 #pragma unroll
     for (int k = 0; k < UP; ++k) {
-      dst[k][0] = *reinterpret_cast<const float4*>(base + uoff[k] + c0q);
-      dst[k][1] = *reinterpret_cast<const float4*>(base + uoff[k] + c1q);
+      if constexpr (LPS) {                                   // 8 packed bf16 in set element 0 (element 1 stays unused)
+        const uint2 r0 = *reinterpret_cast<const uint2*>(base + uoff[k] + c0q), r1 = *reinterpret_cast<const uint2*>(base + uoff[k] + c1q);
+        dst[k][0] = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r1.x), __uint_as_float(r1.y));
+      } else {
+        dst[k][0] = *reinterpret_cast<const float4*>(base + uoff[k] + c0q);
+        dst[k][1] = *reinterpret_cast<const float4*>(base + uoff[k] + c1q);
+      }
     }
   };
   auto loads = [&](int p) { loads_into(ld, p); };
   auto loads_mid_step = [&](int p) {                          // after plane p + 1's conversions: `ld` is free
     if constexpr (TWOSETS) {
 #pragma unroll
-      for (int k = 0; k < UP; ++k) { ld[k][0] = ldn[k][0]; ld[k][1] = ldn[k][1]; }      // plane p + 2 (requested a step ago)
+      for (int k = 0; k < UP; ++k) { ld[k][0] = ldn[k][0]; if constexpr (!LPS) ld[k][1] = ldn[k][1]; }      // plane p + 2 (requested a step ago)
       loads_into(ldn, p + 3);
     } else {
       loads_into(ld, p + 2);
@@ -452,8 +478,18 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring2(Con
     }
   };
   auto conv_pair = [&](int k, int e2, bool pin, int set) -> unsigned {
-    const float4 q = ld[k][e2 >> 1];
-    float v0 = (e2 & 1) ? q.z : q.x, v1 = (e2 & 1) ? q.w : q.y;
+    float v0, v1;
+    if constexpr (LPS) {
+      const float4 q = ld[k][0];
+      const unsigned w = __float_as_uint(e2 == 0 ? q.x : e2 == 1 ? q.y : e2 == 2 ? q.z : q.w);      // channels 2 e2, 2 e2 + 1 as stored
+      if constexpr (INMODE == MI355_IN_PLAIN) {              // the operand IS the stored value
+        return (pin && uin[k] && (e2 < 2 ? v0ok : v1ok)) ? w : 0u;
+      }
+      v0 = bf16lo_to_f32(w); v1 = bf16hi_to_f32(w);
+    } else {
+      const float4 q = ld[k][e2 >> 1];
+      v0 = (e2 & 1) ? q.z : q.x; v1 = (e2 & 1) ? q.w : q.y;
+    }
     if (INMODE == MI355_IN_AFFINE_ACT) {
       float s0, s1, h0, h1, l0, l1;
       if constexpr (KS == 1) {
@@ -492,18 +528,19 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring2(Con
   auto side_loads = [&](Side& sd, int z) {
     const size_t v0 = vrow0 + (size_t)z * oplane;             // wave-uniform
     if (a.res) {                                             // workgroup-uniform
-      const float* rb = a.res + v0 * a.resld;
+      const TA* rb = reinterpret_cast<const TA*>(a.res) + v0 * a.resld;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sd.rs[r] = (rb + (size_t)r * a.resld)[((0x6 >> (r >> 2)) & 1) ? roB : roA];
+      for (int r = 0; r < 16; ++r) sd.rs[r] = ld1(rb + (size_t)r * a.resld + (((0x6 >> (r >> 2)) & 1) ? roB : roA));
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sd.rs[r] = 0.f;
     }
   };
-  auto epilogue_value = [&](float accv, const Side& sd, float* yb, int r, float K0, float& ps0, float& ps1) {      // yb: wave-uniform base of the plane
-    const float v = (accv + bs + sd.rs[r]) * cs;
-    (yb + (size_t)r * a.yld)[((0x6 >> (r >> 2)) & 1) ? yoB : yoA] = v;
+  auto epilogue_value = [&](float accv, const Side& sd, TA* yb, int r, float K0, float& ps0, float& ps1) {      // yb: wave-uniform base of the plane
+    float v = (accv + bs + sd.rs[r]) * cs;
+    st1(yb + (size_t)r * a.yld + (((0x6 >> (r >> 2)) & 1) ? yoB : yoA), v);
     if constexpr (FUSE == 1) {
+      v = as_stored(yb, v);
       const float t = v - K0;                                // K0: this lane's shift (set once when the first plane completes)
       ps0 += t; ps1 += t * t;
     }
@@ -540,7 +577,7 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring2(Con
     const uint4* cur = lds + (q & 1) * PLANE;
     uint4* nxt = lds + ((q + 1) & 1) * PLANE;
     Side sd;
-    float* yb = a.y + (vrow0 + (size_t)(p - 2) * oplane) * a.yld;
+    TA* yb = reinterpret_cast<TA*>(a.y) + (vrow0 + (size_t)(p - 2) * oplane) * a.yld;
     float K0 = 0.f, ps0 = 0.f, ps1 = 0.f;                 // the plane's partial sums (step-local)
     if constexpr (HASPREV) {
       side_loads(sd, p - 2);
@@ -626,7 +663,7 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring2(Con
     // serves -- the first accumulator value of the first finished plane, straight from the register (no residual, for KS = 2 this wave's
     // partial only). Set in the one step that completes the first plane: no run-time flag, no branch in the epilogue pieces.
     if constexpr (FUSE != 0 && HASPREV) { stat[0] += ps0; stat[1] += ps1; }
-    if constexpr (FUSE == 1 && MASK == 7 && !HASPREV) stat[2] = (X[0][0] + bs) * cs;
+    if constexpr (FUSE == 1 && MASK == 7 && !HASPREV) stat[2] = as_stored(reinterpret_cast<TA*>(a.y), (X[0][0] + bs) * cs);
     if constexpr (MASK & 4) {                                // output plane p - 1 is complete: its accumulators -> this step's result buffer
       uint4* px = xch + (q & 1) * XCH + ((wave * MT) * 4) * 64 + lane;
 #pragma unroll
@@ -662,7 +699,7 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring2(Con
     side_loads(sd, ze - 1);
     const uint4* rown = xch + ((nq - 1) & 1) * XCH + ((wave * MT) * 4) * 64 + lane;
     const uint4* rpar = xch + ((nq - 1) & 1) * XCH + (((wave ^ (KS - 1)) * MT + (MT - 1)) * 4) * 64 + lane;
-    float* yb = a.y + (vrow0 + (size_t)(ze - 1) * oplane) * a.yld;
+    TA* yb = reinterpret_cast<TA*>(a.y) + (vrow0 + (size_t)(ze - 1) * oplane) * a.yld;
     const float K0 = FUSE == 1 ? stat[2] : 0.f;
     float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
@@ -695,43 +732,53 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring2(Con
 #ifndef LPZ_NO_LAUNCH      // (developer builds of single instantiations: tools/lpz_one.sh)
 #ifndef LPZ_NO_LAUNCH      // (developer builds of single instantiations: tools/lpz_one.sh)
 // ---- launches (called by mi355_conv3d_fwd_bf16_impl, conv3d_bf16.hip) ----
-int mi355_lp_zring_launch(ConvBArgs& a, int in_mode, int fuse, bool f16, long long blocks, void* stream) {
+int mi355_lp_zring_launch(ConvBArgs& a, int in_mode, int fuse, bool f16, bool lps, long long blocks, void* stream) {
   const bool norm = in_mode == MI355_IN_AFFINE_ACT;
   const int lds_bytes = 4 * 180 * 5 * 16;                   // ring of 4 planes, 180 voxels, 5 x 16 bytes per voxel (32 channels + pad)
   const dim3 grid((unsigned)blocks), blk(256);
+#define LPZ_LAUNCH_T(JJ, IM, FU, HF, TT)                                                                    \
+  do { SET_MAX_DYN_LDS((conv3d_k3_lp_zring<JJ, IM, FU, HF, TT>), lds_bytes);                              \
+       LAUNCH((conv3d_k3_lp_zring<JJ, IM, FU, HF, TT>), grid, blk, lds_bytes, stream, a); } while (0)
 #define LPZ_LAUNCH(JJ, IM, FU, HF)                                                                          \
-  do { SET_MAX_DYN_LDS((conv3d_k3_lp_zring<JJ, IM, FU, HF>), lds_bytes);                                  \
-       LAUNCH((conv3d_k3_lp_zring<JJ, IM, FU, HF>), grid, blk, lds_bytes, stream, a); } while (0)
+  do { if constexpr (!(HF)) { if (lps) { LPZ_LAUNCH_T(JJ, IM, FU, false, bf16_t); break; } }                \
+       LPZ_LAUNCH_T(JJ, IM, FU, HF, float); } while (0)
 #define LPZ_FUSE(JJ, HF)                                                                                    \
   do { if (fuse == 1) { if (norm) LPZ_LAUNCH(JJ, MI355_IN_AFFINE_ACT, 1, HF); else LPZ_LAUNCH(JJ, MI355_IN_PLAIN, 1, HF); } \
        else if (fuse == 2) LPZ_LAUNCH(JJ, MI355_IN_PLAIN, 2, HF);                                         \
        else if (norm) LPZ_LAUNCH(JJ, MI355_IN_AFFINE_ACT, 0, HF); else LPZ_LAUNCH(JJ, MI355_IN_PLAIN, 0, HF); } while (0)
+  if (lps && f16) return MI355_EUNSUPPORTED;
   if (f16) LPZ_FUSE(2, true); else LPZ_FUSE(2, false);
 #undef LPZ_FUSE
 #undef LPZ_LAUNCH
+#undef LPZ_LAUNCH_T
   return LAUNCH_CHECK();
 }
 
-int mi355_lp_zring2_launch(ConvBArgs& a, int ks, int in_mode, int fuse, bool f16, long long wgs, void* stream) {
+int mi355_lp_zring2_launch(ConvBArgs& a, int ks, int in_mode, int fuse, bool f16, bool lps, long long wgs, void* stream) {
   const bool norm = in_mode == MI355_IN_AFFINE_ACT;
   const dim3 grid2((unsigned)wgs), blk2(256);
   // ring of 2 planes (180 voxels x (channels / 8 + 1) x 16 bytes) + two result buffers (4 waves x KS tiles x 4 KB) + KS = 2: the norm prologue
   const int lds1 = 2 * 180 * 5 * 16 + 2 * 4 * 1 * 64 * 4 * 16 + (3 * 32 + 3 * 256) * 4;      // ... + norm prologue slots + per-thread statistics
   const int lds2 = 2 * 180 * 9 * 16 + 2 * 4 * 2 * 64 * 4 * 16 + (3 * 64 + 3 * 256) * 4;
-#define LPZ2_LAUNCH(KSV, IM, FU, HF)                                                                          \
+#define LPZ2_LAUNCH_T(KSV, IM, FU, HF, TT)                                                                    \
   do { const int lb = (KSV) == 1 ? lds1 : lds2;                                                            \
-       SET_MAX_DYN_LDS((conv3d_k3_lp_zring2<2, KSV, IM, FU, HF>), lb);                                     \
-       LAUNCH((conv3d_k3_lp_zring2<2, KSV, IM, FU, HF>), grid2, blk2, lb, stream, a); } while (0)
+       SET_MAX_DYN_LDS((conv3d_k3_lp_zring2<2, KSV, IM, FU, HF, TT>), lb);                                 \
+       LAUNCH((conv3d_k3_lp_zring2<2, KSV, IM, FU, HF, TT>), grid2, blk2, lb, stream, a); } while (0)
+#define LPZ2_LAUNCH(KSV, IM, FU, HF)                                                                          \
+  do { if constexpr (!(HF)) { if (lps) { LPZ2_LAUNCH_T(KSV, IM, FU, false, bf16_t); break; } }                \
+       LPZ2_LAUNCH_T(KSV, IM, FU, HF, float); } while (0)
 #define LPZ2_FUSE(KSV, HF)                                                                                    \
   do { if (fuse == 1) { if (norm) LPZ2_LAUNCH(KSV, MI355_IN_AFFINE_ACT, 1, HF); else LPZ2_LAUNCH(KSV, MI355_IN_PLAIN, 1, HF); } \
        else if (fuse == 2) return MI355_EUNSUPPORTED;                                                      \
        else if (norm) LPZ2_LAUNCH(KSV, MI355_IN_AFFINE_ACT, 0, HF); else LPZ2_LAUNCH(KSV, MI355_IN_PLAIN, 0, HF); } while (0)
   // (no norm-backward form: plan_lp_zring routes those calls to conv3d_k3_lp_zring where it applies and answers the statistics query
   // with 0 otherwise -- the sums then take their own pass and the conv runs here with the plain epilogue)
+  if (lps && f16) return MI355_EUNSUPPORTED;
   if (ks == 1) { if (f16) LPZ2_FUSE(1, true); else LPZ2_FUSE(1, false); }
   else { if (f16) LPZ2_FUSE(2, true); else LPZ2_FUSE(2, false); }
 #undef LPZ2_FUSE
 #undef LPZ2_LAUNCH
+#undef LPZ2_LAUNCH_T
   return LAUNCH_CHECK();
 }
 #endif

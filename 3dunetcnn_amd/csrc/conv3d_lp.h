@@ -60,5 +60,5 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[NS]) {
 
 
 // plane-ring launches (conv3d_bf16_zring.hip); the planner and the dispatcher live in conv3d_bf16.hip
-int mi355_lp_zring_launch(ConvBArgs& a, int in_mode, int fuse, bool f16, long long blocks, void* stream);
-int mi355_lp_zring2_launch(ConvBArgs& a, int ks, int in_mode, int fuse, bool f16, long long wgs, void* stream);
+int mi355_lp_zring_launch(ConvBArgs& a, int in_mode, int fuse, bool f16, bool lps, long long blocks, void* stream);      // lps: bf16 storage
+int mi355_lp_zring2_launch(ConvBArgs& a, int ks, int in_mode, int fuse, bool f16, bool lps, long long wgs, void* stream);

@@ -474,6 +474,8 @@ def main():
         hbm_frac = hbm_gbps / HBM_PEAK_GBPS
         # HBM traffic of the SAME launches: call-weighted over every instantiation of the family in the PMC summary of this command
         rows, traffic_src = pmc_rows(args.config, args.precision)
+        if rows is not None and args.precision == "bf16" and args.storage != "bf16":
+            rows, traffic_src = None, "the committed bf16 PMC summaries were collected with the default 16-bit activation storage"
         traffic, inst_rows, hit = None, [], []
         if rows is not None:
             traffic, hit = family_traffic(rows, name)

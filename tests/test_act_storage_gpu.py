@@ -75,6 +75,24 @@ def test_conv_3x3x3_on_16bit_operands(bf16_backend, kw):
     _all_below(r, moments=2e-5, gnb=1e-5)
 
 
+@pytest.mark.parametrize("form,kw", [
+    ("zring", dict(cin=32, cout=32, dhw=(16, 32, 32), norm=True, moments=True, n=2)),
+    ("zring", dict(cin=64, cout=32, dhw=(16, 16, 32), norm=True, residual=True, drop=True, moments=True, n=2)),
+    ("zring", dict(cin=32, cout=64, dhw=(9, 16, 32), mode=1)),                                  # plain input (a dgrad): staged as loaded
+    ("zring", dict(cin=64, cout=64, dhw=(12, 8, 16), norm=True, residual=True)),
+    ("zring1", dict(cin=32, cout=32, dhw=(16, 16, 32), gnb=True, mode=1)),                      # the round-3 ring: norm-backward sums
+    ("zring1", dict(cin=24, cout=32, dhw=(5, 8, 16), norm=True, moments=True, residual=True)),
+])
+def test_conv_3x3x3_plane_ring_forms(bf16_backend, monkeypatch, form, kw):
+    """The plane-ring kernels (csrc/conv3d_bf16_zring.hip) on 16-bit tensors: MI355_BF16_FORM=zring forces conv3d_k3_lp_zring2 on every
+    eligible shape, zring1 the round-3 kernel."""
+    monkeypatch.setenv("MI355_BF16_FORM", form)
+    r = S.case_conv_k3_tile(bf16_backend, **kw)
+    if kw.get("gnb"):
+        assert r["gnb_fused"]
+    _all_below(r, moments=2e-5, gnb=1e-5)
+
+
 @pytest.mark.parametrize("dhw", [(6, 9, 10), (32, 32, 32)])
 def test_first_layer(bf16_backend, dhw):
     _all_below(S.case_first_layer(bf16_backend, dhw=dhw), moments=2e-5, wgrad=1e-5)

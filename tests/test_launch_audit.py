@@ -245,7 +245,7 @@ def test_audit_c3_bf16_train_step_gpu(hip_backend):
     assert m.last_dropout_scale is not None and 0.0 < loss < 1.0
     _check(au, {"conv_fwd_lp": 26 + 25, "conv_wgrad_lp": 25, "conv_fwd": 22, "conv_wgrad": 12, "gn_act_bwd": 26, "gn_stats": 26, "chscale": 1,
                 "upsample_fwd": 3, "upsample_bwd": 3, "proj_fwd": 1, "proj_bwd": 1, "dice": 1, "adam": 1})
-    forms = {r["desc"].rsplit("prologue ", 1)[1].rstrip("]") for r in au.records if "prologue " in r["desc"]}
+    forms = {r["desc"].rsplit("prologue ", 1)[1].split("]")[0] for r in au.records if "prologue " in r["desc"]}
     print("prologue forms matched:", forms, {k: f"{v['err']:.1e}" for k, v in au.worst().items() if k.endswith("_lp")})
     # (b) against the fp32 oracle, sample by sample (the CPU oracle holds one 128^3 sample at a time comfortably)
     sd = keep["state_dict"]
