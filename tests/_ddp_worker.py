@@ -39,7 +39,8 @@ def main(out_dir, device="cpu", mode="step"):
 
     torch.manual_seed(100 + rank)                  # ranks start from DIFFERENT weights: broadcast must fix that
     kw = dict(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1, 1])
-    m = unet.HipUNet3D(**kw).eval()
+    # "lpstep": BASELINE configs[2]'s network -- bf16 operands, activations stored as bf16 (HipAutocastUNet's default) -- under the same reducer
+    m = (unet.HipAutocastUNet(**kw) if mode == "lpstep" else unet.HipUNet3D(**kw)).eval()
     if on_gpu:
         m = m.cuda()
     m._be = be
@@ -56,6 +57,26 @@ def main(out_dir, device="cpu", mode="step"):
     if on_gpu:
         x, y = x.cuda(), y.cuda()
     rec = {"sd0": sd0, "losses": [], "n_buckets": None}
+    if mode == "lpstep":
+        assert m.act_storage == torch.bfloat16 and m.conv_precision == "bf16"
+        opt.zero_grad(set_to_none=True)
+        with red.no_sync():                                  # this rank's own gradient, not exchanged
+            crit(m(x), y).backward()
+        rec["local"] = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            loss = crit(m(x), y)
+            loss.backward()
+            if "grads" not in rec:
+                rec["grads"] = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+                rec["n_buckets"] = len(red.buckets)
+            opt.step()
+            m.mark_parameters_updated()
+            rec["losses"].append(float(loss))
+        rec["sd2"] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        torch.save(rec, os.path.join(out_dir, f"rank{rank}.pt"))
+        dist.destroy_process_group()
+        return
     if mode == "accum":
         # two micro-batches per optimizer step: the first accumulates locally (reducer.no_sync()), the second reduces the accumulated sum
         x2, y2 = R.synthetic_case(1, 4, (16, 16, 16), 3, seed=rank + 10)

@@ -85,6 +85,27 @@ def test_two_rank_graphed_step_on_hip_kernels(tmp_path, hip_backend):
     _two_rank_step(tmp_path, "cuda", "graphstep")
 
 
+def test_two_rank_mixed_precision_step_with_16bit_activation_storage(tmp_path, emu_backend):
+    """BASELINE configs[2]'s form of the step under the reducer: HipAutocastUNet (bf16 operands, activations stored as bf16). What is
+    exchanged are the fp32 weight gradients, bucket by bucket from inside backward, exactly as in the fp32 step: the averaged gradient
+    on every rank is the mean of the two ranks' own gradients (taken under no_sync() before) to summation order, and both ranks hold
+    bit-identical weights after two optimizer steps; the loss is within the mode's tolerance of the fp32 oracle."""
+    recs = _run_workers(tmp_path, "cpu", "lpstep")
+    assert recs[0]["n_buckets"] >= 3
+    for k in recs[0]["grads"]:
+        want = (recs[0]["local"][k] + recs[1]["local"][k]) / 2
+        for r in range(2):
+            assert C.rel_err(recs[r]["grads"][k], want) < 1e-6, (r, k)
+    for k in recs[0]["sd2"]:
+        assert torch.equal(recs[0]["sd2"][k], recs[1]["sd2"][k]), k
+    for r in range(2):
+        sd = {k: v.clone() for k, v in recs[0]["sd0"].items()}
+        x, y = R.synthetic_case(1, 4, (16, 16, 16), 3, seed=r)
+        with torch.no_grad():
+            lref = float(O.dice_loss(R.unet3d_forward(sd, x, (1, 1, 1)), y))
+        assert abs(lref - recs[r]["losses"][0]) / lref < 1e-2, (r, lref, recs[r]["losses"])
+
+
 def _two_rank_step(tmp_path, device, mode="step"):
     recs = _run_workers(tmp_path, device, mode)
     # broadcast: both ranks start from rank 0's weights
