@@ -109,6 +109,31 @@ def _tiny(be, seed):
     return m, crit, opt
 
 
+def test_uncaptured_graphed_step_with_16bit_activation_storage(emu_backend):
+    """HipGraphedTrainStep's host logic (capture=False on the CPU emulator) around a HipAutocastUNet that stores activations as bf16: the
+    stepper's step equals the eager step bit for bit (same kernels, same order), storage type restored on the backend afterwards."""
+    x, y = R.synthetic_case(1, 4, (16, 16, 16), 3, seed=0)
+    res = []
+    for stepper_kind in ("eager", "graphed"):
+        torch.manual_seed(3)
+        m = unet.HipAutocastUNet(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1]).eval()
+        crit, opt = losses.HipDiceLoss(sigmoid=True), optim.HipAdam(m.parameters(), lr=1e-3)
+        m._be = crit._be = opt._be = emu_backend
+        if stepper_kind == "eager":
+            opt.zero_grad(set_to_none=True)
+            loss = crit(m(x), y)
+            loss.backward()
+            opt.step()
+        else:
+            step = graph.HipGraphedTrainStep(m, crit, opt, x, y, capture=False)
+            loss = step(x, y)
+        res.append((float(loss.detach()), {k: v.detach().clone() for k, v in m.state_dict().items()}))
+        assert emu_backend.act_dtype == torch.float32 and emu_backend.precision == 0
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
 def test_pack_tables_are_per_network(emu_backend):
     """Two networks on ONE backend (training model + validation / EMA twin): each keeps the device task table of its one-launch weight
     repack across the other's steps -- the table a captured graph has baked in is never replaced or freed (round-3 advisor finding:
