@@ -175,7 +175,8 @@ class Backend:
 
     def set_precision(self, name):
         """"fp32" (exact f32 MFMA, default) | "bf16x3" | "bf16x6" (split-bf16 fp32 emulation) | "bf16" | "fp16" (mixed precision: operands
-        rounded to bf16 / IEEE fp16 while staged, fp32 accumulate and fp32 tensors; "fp16" is the arithmetic of torch's CUDA autocast)."""
+        rounded to bf16 / IEEE fp16 while staged, fp32 accumulate; "fp16" is the arithmetic of torch's CUDA autocast). The tensors' storage
+        type is a separate choice: `act_dtype` (fp32, or bf16 with the "bf16" mode -- HipAutocastUNet(activation_storage=...))."""
         self.precision = PRECISIONS[name] if isinstance(name, str) else int(name)
 
     # -- plumbing ------------------------------------------------------------------------------------------------

@@ -551,7 +551,7 @@ def main():
                "step_form": "hip-graph replay + one flat all-reduce" if graphed is not None else "eager launches, bucketed all-reduce inside backward",
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision],
                "data": "synthetic" if not emu else "synthetic -- CPU-EMULATOR PLUMBING TEST, NOT A MEASUREMENT",
-               "config": {"workload": f"BASELINE configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.config] }]: {model_desc}, {'x'.join(str(v) for v in dhw)} patch, batch {B}/GPU, fp32 tensors, "
+               "config": {"workload": f"BASELINE configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.config] }]: {model_desc}, {'x'.join(str(v) for v in dhw)} patch, batch {B}/GPU, {'bf16 activation tensors' if args.storage == 'bf16' else 'fp32 tensors'}, "
                                       f"fwd + sigmoid-Dice + bwd + Adam" + (", Dropout3d on" if args.model == "unet3d" else ""),
                           "conv_arithmetic": ARITH[args.precision],
                           "activation_storage": "bf16 (activations and their gradients between the fp32 input volume and the fp32 logits; statistics, "

@@ -59,8 +59,9 @@ typedef struct mi355_act {
                                   (d,h,w,8c), logical channel p*c + k with p = 4a+2b+e  <->  x[2z+a,2y+b,2x+e,k].
                                   dgrad of ConvTranspose3d(k2,s2) (MONAI DynUNet up block). x->d/h/w are the FINE extents. */
 
-/* Arithmetic of the 3x3x3 stride-1 conv kernels (forward, dgrad and wgrad). Inputs, outputs and accumulation are fp32 in every
- * mode; the modes differ in how the fp32 x fp32 products are formed on the matrix pipe. */
+/* Arithmetic of the 3x3x3 stride-1 conv kernels (forward, dgrad and wgrad). Accumulation is fp32 in every mode; the modes differ in how
+ * the products are formed on the matrix pipe. The tensors a call reads and writes are fp32 unless their views say MI355_ACT_BF16, which
+ * goes with MI355_PREC_BF16 only (the operands are then the stored values; outputs are rounded once, on store). */
 #define MI355_PREC_F32 0     /* v_mfma_f32_32x32x2_f32: exact fp32 products (bitwise a k-ordered fmaf chain). 157 TFLOP/s peak. */
 #define MI355_PREC_BF16X3 1  /* each operand split into 2 bf16 planes (hi + lo), 3 bf16-MFMA products hi*hi + hi*lo + lo*hi:
                                 product error <= ~2^-16 relative ("3xBF16 fp32 emulation"). 2.5 PFLOP/s / 3 peak. */
@@ -68,7 +69,7 @@ typedef struct mi355_act {
 #define MI355_PREC_BF16 3    /* operands rounded to bf16, one product: autocast-style mixed precision. 2.5 PFLOP/s peak. */
 #define MI355_PREC_F16 4     /* operands rounded to IEEE fp16 (round to nearest even), one v_mfma_f32_32x32x16_f16 product, fp32 accumulate:
                                 the arithmetic of torch.cuda.amp.autocast (fp16) around the reference's AutocastUNet
-                                (models/pytorch/segmentation/unet.py:53-58); outputs stay fp32. 2.5 PFLOP/s peak. */
+                                (models/pytorch/segmentation/unet.py:53-58); fp32 tensors only. 2.5 PFLOP/s peak. */
 
 /* Output-side layout of the conv kernels. */
 #define MI355_OUT_PLAIN 0
