@@ -116,3 +116,41 @@ def test_mixed_storage_types_are_refused(emu_backend):
     y = be.empty_act(1, 4, 4, 8, 32, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="unsupported"):
         be.conv_fwd(b, w3, y, 3)          # fp32 arithmetic (the backend's default precision) on 16-bit tensors: no such 3x3x3 kernel
+
+
+def test_randomized_shapes(bf16_backend, monkeypatch):
+    """A fixed-seed sample of the developer fuzz over the storage cases: random channel counts (incl. non-multiples of the tiles), ragged
+    extents, fusion combinations and kernel forms (160 cases of it ran clean when the storage landed)."""
+    import random
+    rng = random.Random(4)
+    be = bf16_backend
+    for _ in range(18):
+        kind = rng.choice(["tile", "ring", "ring1", "k1", "s2", "zi", "wgrad", "norm"])
+        if kind in ("tile", "ring", "ring1"):
+            monkeypatch.setenv("MI355_BF16_FORM", {"tile": "tile", "ring": "zring", "ring1": "zring1"}[kind])
+            if kind == "tile":
+                kw = dict(cin=rng.choice([8, 24, 32, 40, 64]), cout=rng.choice([8, 32, 48, 64]), dhw=(rng.randint(1, 5), rng.randint(1, 9), rng.randint(1, 19)))
+            else:
+                kw = dict(cin=rng.choice([20, 24, 32]) if kind == "ring1" else rng.choice([20, 32, 48, 64]), cout=32 if kind == "ring1" else rng.choice([32, 64]),
+                          dhw=(rng.randint(4, 8), 8, 16 * rng.randint(1, 2)))
+            kw.update(norm=rng.random() < 0.5, residual=rng.random() < 0.5, drop=rng.random() < 0.3, moments=rng.random() < 0.5, n=rng.choice([1, 2]))
+            if kind != "ring" and rng.random() < 0.3:
+                kw.update(gnb=True, mode=1, norm=False, moments=False)
+            r = S.case_conv_k3_tile(be, **kw)
+        elif kind == "k1":
+            kw = dict(cin=rng.choice([8, 32, 128]), cout=rng.choice([8, 32, 64])); r = S.case_conv_k1(be, **kw)
+        elif kind == "s2":
+            kw = dict(cin=rng.choice([8, 32, 64]), cout=rng.choice([16, 64]), moments=rng.random() < 0.5); r = S.case_conv_s2(be, **kw)
+        elif kind == "zi":
+            kw = dict(cin=rng.choice([32, 64]), cout=rng.choice([16, 32]), window=rng.random() < 0.5); r = S.case_conv_zero_insert(be, **kw)
+        elif kind == "wgrad":
+            kd = rng.choice([1, 3, 3]); stride = 1 if kd == 1 else rng.choice([1, 2])
+            kw = dict(kd=kd, stride=stride, cin=rng.choice([8, 32, 40]), cout=rng.choice([16, 32, 96]), dhw=(rng.randint(2, 6), rng.randint(2, 8), rng.randint(3, 19)),
+                      norm=rng.random() < 0.5 and kd == 3 and stride == 1)
+            r = S.case_wgrad(be, **kw)
+        else:
+            c = rng.choice([4, 8, 16, 24])
+            kw = dict(n=rng.choice([1, 2]), c=c, dhw=(rng.randint(1, 4), rng.randint(1, 6), rng.randint(1, 9)), groups=rng.choice([g for g in (1, 2, 4, c) if c % g == 0]))
+            r = S.case_norm(be, **kw)
+        bad = {k: v for k, v in r.items() if not isinstance(v, bool) and v > {"moments": 3e-5, "gnb": 2e-5, "dw": 1e-5, "dgamma": 1e-5, "dbeta": 1e-5, "stats": 1e-5}.get(k, TOL)}
+        assert not bad, (kind, kw, bad)
