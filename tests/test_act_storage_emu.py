@@ -124,8 +124,8 @@ def test_randomized_shapes(bf16_backend, monkeypatch):
     import random
     rng = random.Random(4)
     be = bf16_backend
-    for _ in range(18):
-        kind = rng.choice(["tile", "ring", "ring1", "k1", "s2", "zi", "wgrad", "norm"])
+    for _ in range(10):                                  # (the plane-ring forms have their own cases above: minutes each on the emulator)
+        kind = rng.choice(["tile", "tile", "k1", "s2", "zi", "wgrad", "norm"])
         if kind in ("tile", "ring", "ring1"):
             monkeypatch.setenv("MI355_BF16_FORM", {"tile": "tile", "ring": "zring", "ring1": "zring1"}[kind])
             if kind == "tile":
