@@ -18,7 +18,11 @@ class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, *params):
         need_grad = any(ctx.needs_input_grad)   # False under torch.no_grad() / for frozen inference
-        logits, saved = model._forward_impl(x, need_grad)
+        try:
+            logits, saved = model._forward_impl(x, need_grad)
+        except BaseException:
+            model._abort_forward()              # an exception inside the forward (an OOM the caller catches, a refused shape) must not
+            raise                               # leave the shared backend in this network's precision / storage type
         ctx.model = model
         ctx.saved = saved
         ctx.x_requires_grad = x.requires_grad
@@ -180,6 +184,7 @@ class HipNetBase(nn.Module):
         if self.conv_precision is not None:
             be.set_precision(self.conv_precision)
         be.act_dtype = self.act_storage or torch.float32
+        self._forward_open = True
         return be
 
     def _end_forward(self):
@@ -187,6 +192,14 @@ class HipNetBase(nn.Module):
         self._packs_dirty_local = False
         self._be.precision = self._saved_precision
         self._be.act_dtype = self._saved_act_dtype
+        self._forward_open = False
+
+    def _abort_forward(self):
+        """Undo _begin_forward's changes to the backend after a forward that raised (the packs stay marked dirty)."""
+        if getattr(self, "_forward_open", False) and self._be is not None:
+            self._be.precision = self._saved_precision
+            self._be.act_dtype = self._saved_act_dtype
+        self._forward_open = False
 
     def _gslice(self, p):
         o = self._goff[id(p)]

@@ -121,6 +121,25 @@ def test_frozen_parameters_get_no_gradient_and_do_not_move(emu_backend):
     assert any(not torch.equal(before[k], after[k]) for k in before if k.startswith("decoder."))
 
 
+def test_a_forward_that_raises_leaves_the_shared_backend_as_it_found_it(emu_backend, monkeypatch):
+    """HipAutocastUNet switches the backend to its precision and its 16-bit activation storage for the duration of a forward. A forward that
+    raises half-way (an OOM the caller catches, a refused call) must undo that: the next fp32 network on the same backend would otherwise
+    allocate bf16 tensors and be refused by the fp32 kernels."""
+    be = emu_backend
+    m = unet.HipAutocastUNet(**KW).eval()
+    m._be = be
+    x, _ = R.synthetic_case(1, 4, (8, 8, 8), 3)
+    real = be.upsample2x_fwd
+    monkeypatch.setattr(be, "upsample2x_fwd", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("injected failure in the decoder")))
+    with pytest.raises(RuntimeError, match="injected failure"):
+        m(x)
+    assert be.act_dtype == torch.float32 and be.precision == 0
+    monkeypatch.setattr(be, "upsample2x_fwd", real)
+    out = _model(be)(x)                                    # an fp32 network right after it runs as if nothing had happened
+    assert out.dtype == torch.float32 and torch.isfinite(out).all()
+    assert torch.isfinite(m(x)).all() and be.act_dtype == torch.float32      # and so does the mixed-precision one
+
+
 def test_second_backward_raises_a_clear_error(emu_backend):
     m = _model(emu_backend)
     x, y = R.synthetic_case(1, 4, (8, 8, 8), 3)
