@@ -138,28 +138,38 @@ def test_four_ranks_mixed_exchange_forms_with_skewed_ranks(tmp_path, emu_backend
     that their collectives are launched at different moments. Every eager backward launches each bucket exactly once, the accumulation
     and the graphed step launch none (one flat all-reduce instead), the averaged gradients are the mean over the FOUR ranks' oracle
     gradients, and after the four optimizer steps all ranks hold bit-identical weights."""
-    recs = _run_workers(tmp_path, "cpu", "mix4", world=4)
+    _mixed_exchange_forms(tmp_path, 4)
+
+
+@pytest.mark.skipif(os.environ.get("MI355_SKIP_WORLD8") == "1", reason="8 emulator ranks: 2 min of wall clock on 64 cores, 11 min of CPU")
+def test_eight_ranks_mixed_exchange_forms_with_skewed_ranks(tmp_path, emu_backend):
+    """The same at the world size of the node BASELINE configs[2] names (8 ranks; gloo on the CPU emulator stands in for RCCL on 8 MI355X)."""
+    _mixed_exchange_forms(tmp_path, 8)
+
+
+def _mixed_exchange_forms(tmp_path, W):
+    recs = _run_workers(tmp_path, "cpu", "mix4", world=W)
     nb = recs[0]["n_buckets"]
     assert nb >= 3
-    for r in range(4):
+    for r in range(W):
         # A: (launched, buckets); B: two backwards without a bucket launch; D: all buckets again
         assert recs[r]["launched"] == [(nb, nb), (0, 0), (0, 0), (nb, nb)], (r, recs[r]["launched"])
         for k in recs[0]["sd0"]:
             assert torch.equal(recs[0]["sd0"][k], recs[r]["sd0"][k]), k
     want, want_acc = None, None
-    for r in range(4):
+    for r in range(W):
         sd = {k: v.clone().requires_grad_(True) for k, v in recs[0]["sd0"].items()}
         x, y = R.synthetic_case(1, 4, (16, 16, 16), 3, seed=r)
         O.dice_loss(R.unet3d_forward(sd, x, (1, 1, 1)), y).backward()
-        g = {k: v.grad / 4 for k, v in sd.items()}
+        g = {k: v.grad / W for k, v in sd.items()}
         want = g if want is None else {k: want[k] + g[k] for k in g}
         sda = {k: v.clone().requires_grad_(True) for k, v in recs[0]["sd_before_accum_step"].items()}
         for seed in (r, r + 10):
             x, y = R.synthetic_case(1, 4, (16, 16, 16), 3, seed=seed)
             O.dice_loss(R.unet3d_forward(sda, x, (1, 1, 1)), y).backward()
-        ga = {k: v.grad / 4 for k, v in sda.items()}
+        ga = {k: v.grad / W for k, v in sda.items()}
         want_acc = ga if want_acc is None else {k: want_acc[k] + ga[k] for k in ga}
-    for r in range(4):
+    for r in range(W):
         for k in want:
             assert C.rel_err(recs[r]["grads"][k], want[k]) < 1e-3, (r, k)
             assert C.rel_err(recs[r]["grads_accum"][k], want_acc[k]) < 2e-3, (r, k)
