@@ -198,15 +198,15 @@ def test_launcher_environment_wins_over_self_launch(emu_backend):
 
 
 def test_bf16_line_says_how_activations_are_stored(emu_backend):
-    """`--precision bf16` runs the mode's default 16-bit activation storage and says so in `config.activation_storage`; `--storage fp32`
-    selects the fp32-tensor form; `--storage bf16` without bf16 operands is refused (emulator plumbing run)."""
+    """`--precision bf16` runs the mode's default 16-bit activation storage and says so in `config.activation_storage` and in the workload
+    string; `--storage bf16` without bf16 operands is refused (emulator plumbing run)."""
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--size", "8", "--batch", "1", "--steps", "1", "--warmup", "1",
             "--emulator-plumbing-test"]
-    for extra, want in ((["--precision", "bf16"], "bf16"), (["--precision", "bf16", "--storage", "fp32"], "fp32")):
-        p = subprocess.run(base + extra, capture_output=True, text=True, env=env, timeout=900)
-        assert p.returncode == 0, p.stderr[-2000:]
-        line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
-        assert line["config"]["activation_storage"].startswith(want) and line["dtype"] == "bf16 (mixed)", line["config"]
+    p = subprocess.run(base + ["--precision", "bf16"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["config"]["activation_storage"].startswith("bf16") and line["dtype"] == "bf16 (mixed)", line["config"]
+    assert "bf16 activation tensors" in line["config"]["workload"]
     p = subprocess.run(base + ["--storage", "bf16"], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode != 0 and "--storage bf16 goes with --precision bf16" in (p.stderr + p.stdout)

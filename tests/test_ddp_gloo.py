@@ -141,7 +141,8 @@ def test_four_ranks_mixed_exchange_forms_with_skewed_ranks(tmp_path, emu_backend
     _mixed_exchange_forms(tmp_path, 4)
 
 
-@pytest.mark.skipif(os.environ.get("MI355_SKIP_WORLD8") == "1", reason="8 emulator ranks: 2 min of wall clock on 64 cores, 11 min of CPU")
+@pytest.mark.skipif(os.environ.get("MI355_TEST_WORLD8") != "1", reason="8 emulator ranks: 2 min of wall clock on 64 idle cores, 11 min of CPU -- opt in with "
+                    "MI355_TEST_WORLD8=1 (last run: profiles/r4_gloo_world8.txt)")
 def test_eight_ranks_mixed_exchange_forms_with_skewed_ranks(tmp_path, emu_backend):
     """The same at the world size of the node BASELINE configs[2] names (8 ranks; gloo on the CPU emulator stands in for RCCL on 8 MI355X)."""
     _mixed_exchange_forms(tmp_path, 8)
