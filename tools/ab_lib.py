@@ -27,6 +27,8 @@ def one(path, size, batch):
     x, y = x.cuda(), y.cuda()
     torch.manual_seed(0)
     m = unet.HipUNet3D(n_features=4, n_outputs=3).cuda().train()
+    if os.environ.get("MI355_STORAGE") == "bf16":           # with MI355_PRECISION=bf16: the 16-bit activation storage of HipAutocastUNet
+        m.act_storage = torch.bfloat16
     crit = losses.HipDiceLoss(sigmoid=True)
     opt = optim.HipAdam(m.parameters(), lr=1e-3)
 
