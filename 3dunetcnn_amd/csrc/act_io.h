@@ -33,6 +33,27 @@ __device__ __forceinline__ void ld8(const bf16_t* p, float (&o)[8]) {
   o[4] = bf16lo_to_f32(v.z); o[5] = bf16hi_to_f32(v.z); o[6] = bf16lo_to_f32(v.w); o[7] = bf16hi_to_f32(v.w);
 }
 
+// VW consecutive channels (VW = 4: the float4 / 8-byte granularity of every view; VW = 8: one 16-byte access per lane for bf16 tensors whose
+// channel count, leading dimension and base address allow it -- an 8-byte access per lane leaves the streaming kernels at ~70 % of what
+// 16 bytes per lane reach)
+template <int VW, typename T> __device__ __forceinline__ void ldv(const T* p, float (&o)[VW]) {
+  if constexpr (VW == 8) ld8(p, o);
+  else { const float4 v = ld4(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+}
+template <int VW> __device__ __forceinline__ void stv(float* p, const float (&v)[VW]) {
+  st4(p, make_float4(v[0], v[1], v[2], v[3]));
+  if constexpr (VW == 8) st4(p + 4, make_float4(v[4], v[5], v[6], v[7]));
+}
+template <int VW> __device__ __forceinline__ void stv(bf16_t* p, const float (&v)[VW]) {
+  if constexpr (VW == 8)
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+  else st4(p, make_float4(v[0], v[1], v[2], v[3]));
+}
+// can every one of these bf16 views be walked 8 channels at a time?
+static inline bool act_vw8(const mi355_act* t) {
+  return t->dtype == MI355_ACT_BF16 && t->c % 8 == 0 && t->ld % 8 == 0 && !((uintptr_t)t->p & 15);
+}
+
 static inline size_t act_elem_bytes(int dtype) { return dtype == MI355_ACT_BF16 ? 2 : 4; }
 static inline bool act_dtype_ok(const mi355_act* t) { return t->dtype == MI355_ACT_F32 || t->dtype == MI355_ACT_BF16; }
 // a view the streaming kernels accept: 4-element (float4 / 8-byte) granularity

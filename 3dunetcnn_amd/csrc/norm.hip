@@ -18,59 +18,58 @@
 
 // per-(n, block, c) partial sums (sum du, sum du*xhat), du = dA * act'(scale*x+shift), xhat = (x-mean)*rstd: the first pass of the
 // backward when the dgrad conv that produced dA could not emit them from its epilogue (gn_fuse.h)
-template <typename T>
+template <typename T, int VW>
 __global__ void gn_bwd_partial_kernel(const T* x, int xld, const T* dA, int dald, long long V, int C, int Q, int R,
                                       int G, float slope, const float* mean_rstd, const float* scale, const float* shift,
                                       float* ws) {
-  DYN_LDS(lds);  // [R][Q][8]
+  DYN_LDS(lds);  // [R][Q][2 VW]
   const int tid = threadIdx.x;
   const int q = tid % Q, r = tid / Q;
   const int n = blockIdx.y, blk = blockIdx.x, B = gridDim.x;
   const long long per = (V + B - 1) / B;
   const long long vb = (long long)blk * per;
   const long long ve = vb + per < V ? vb + per : V;
-  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-  float mean[4], rstd[4], sc[4], sh[4];
+  float s0[VW], s1[VW], mean[VW], rstd[VW], sc[VW], sh[VW];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int c = 4 * q + e;
+  for (int e = 0; e < VW; ++e) {
+    const int c = VW * q + e;
     const int g = c / (C / G);
+    s0[e] = 0.f; s1[e] = 0.f;
     mean[e] = mean_rstd[((size_t)n * G + g) * 2];
     rstd[e] = mean_rstd[((size_t)n * G + g) * 2 + 1];
     sc[e] = scale[(size_t)n * C + c];
     sh[e] = shift[(size_t)n * C + c];
   }
-  const T* xn = x + (size_t)n * V * xld + 4 * q;
-  const T* dn = dA + (size_t)n * V * dald + 4 * q;
+  const T* xn = x + (size_t)n * V * xld + VW * q;
+  const T* dn = dA + (size_t)n * V * dald + VW * q;
   for (long long v = vb + r; v < ve; v += R) {
-    const float4 xv = ld4(xn + (size_t)v * xld);
-    const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
-    const float4 dv = ld4(dn + (size_t)v * dald);
-    const float de[4] = {dv.x, dv.y, dv.z, dv.w};
+    float xe[VW], de[VW];
+    ldv<VW>(xn + (size_t)v * xld, xe);
+    ldv<VW>(dn + (size_t)v * dald, de);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < VW; ++e) {
       const float u = xe[e] * sc[e] + sh[e];
       const float du = u > 0.f ? de[e] : de[e] * slope;
       const float xh = (xe[e] - mean[e]) * rstd[e];
       s0[e] += du; s1[e] += du * xh;
     }
   }
-  float* my = lds + (size_t)tid * 8;
+  float* my = lds + (size_t)tid * (2 * VW);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { my[e] = s0[e]; my[4 + e] = s1[e]; }
+  for (int e = 0; e < VW; ++e) { my[e] = s0[e]; my[VW + e] = s1[e]; }
   __syncthreads();
   if (r == 0) {
-    float t[8];
+    float t[2 * VW];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) t[e] = 0.f;
+    for (int e = 0; e < 2 * VW; ++e) t[e] = 0.f;
     for (int rr = 0; rr < R; ++rr) {
-      const float* o = lds + (size_t)(rr * Q + q) * 8;
+      const float* o = lds + (size_t)(rr * Q + q) * (2 * VW);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) t[e] += o[e];
+      for (int e = 0; e < 2 * VW; ++e) t[e] += o[e];
     }
-    float* dst = ws + (((size_t)n * B + blk) * C + 4 * q) * 2;
+    float* dst = ws + (((size_t)n * B + blk) * C + VW * q) * 2;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { dst[2 * e] = t[e]; dst[2 * e + 1] = t[4 + e]; }
+    for (int e = 0; e < VW; ++e) { dst[2 * e] = t[e]; dst[2 * e + 1] = t[VW + e]; }
   }
 }
 
@@ -148,82 +147,80 @@ __global__ void gn_bwd_param_kernel(const float* nc_sums, int N, int C, float* d
   if (dgamma) dgamma[c] = (float)s2;
 }
 
-template <typename T>
+template <typename T, int VW>
 __global__ void gn_bwd_apply_kernel(const T* x, int xld, const T* dA, int dald, T* dx, int dxld,
                                     const T* addend, int addld, long long V, int C, int N, float slope,
                                     const float* scale, const float* shift, const float* coef) {
-  const int Q = C / 4;
+  const int Q = C / VW;
   const long long total = (long long)N * V * Q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int q = (int)(idx % Q);
     const long long nv = idx / Q;
     const int n = (int)(nv / V);
-    const int c = 4 * q;
-    const float4 xv = ld4(x + (size_t)nv * xld + c);
-    const float4 dv = ld4(dA + (size_t)nv * dald + c);
-    const float4 sc = *reinterpret_cast<const float4*>(scale + (size_t)n * C + c);
-    const float4 sh = *reinterpret_cast<const float4*>(shift + (size_t)n * C + c);
-    const float xe[4] = {xv.x, xv.y, xv.z, xv.w}, de[4] = {dv.x, dv.y, dv.z, dv.w};
-    const float se[4] = {sc.x, sc.y, sc.z, sc.w}, he[4] = {sh.x, sh.y, sh.z, sh.w};
-    float o[4];
+    const int c = VW * q;
+    float xe[VW], de[VW], o[VW], se[VW], he[VW];
+    ldv<VW>(x + (size_t)nv * xld + c, xe);
+    ldv<VW>(dA + (size_t)nv * dald + c, de);
+    ldv<VW>(scale + (size_t)n * C + c, se);
+    ldv<VW>(shift + (size_t)n * C + c, he);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < VW; ++e) {
       const float* k = coef + ((size_t)n * C + c + e) * 4;
       const float u = xe[e] * se[e] + he[e];
       const float du = u > 0.f ? de[e] : de[e] * slope;
       o[e] = k[0] * du + k[1] + k[2] * (xe[e] - k[3]);
     }
     if (addend) {
-      const float4 av = ld4(addend + (size_t)nv * addld + c);
-      o[0] += av.x; o[1] += av.y; o[2] += av.z; o[3] += av.w;
+      float av[VW];
+      ldv<VW>(addend + (size_t)nv * addld + c, av);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) o[e] += av[e];
     }
-    st4(dx + (size_t)nv * dxld + c, make_float4(o[0], o[1], o[2], o[3]));
+    stv<VW>(dx + (size_t)nv * dxld + c, o);
   }
 }
 
 // ---- statistics from partial moments (gn_fuse.h record format: (count, sum, M2) per (sample, block, channel)) ----
 // Standalone producer of the records: one streaming read of x. Inside a block the sums are taken about K_c = the block's first
 // voxel of that channel (a sample of the data, so they do not cancel when |mean| >> std) and converted to (count, sum, M2) once.
-template <typename T>
+template <typename T, int VW>
 __global__ void gn_moments_kernel(const T* x, int xld, long long V, int C, int Q, int R, float* out) {
-  DYN_LDS(lds);  // [R][Q][8]
+  DYN_LDS(lds);  // [R][Q][2 VW]
   const int tid = threadIdx.x;
   const int q = tid % Q, r = tid / Q;
   const int n = blockIdx.y, blk = blockIdx.x, B = gridDim.x;
   const long long per = (V + B - 1) / B;
   const long long vb = (long long)blk * per;
   const long long ve = vb + per < V ? vb + per : V;
-  const T* xn = x + (size_t)n * V * xld + 4 * q;
-  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-  float kc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (vb < ve) {
-    const float4 k4 = ld4(xn + (size_t)vb * xld);
-    kc[0] = k4.x; kc[1] = k4.y; kc[2] = k4.z; kc[3] = k4.w;
-  }
+  const T* xn = x + (size_t)n * V * xld + VW * q;
+  float s0[VW], s1[VW], kc[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) { s0[e] = 0.f; s1[e] = 0.f; kc[e] = 0.f; }
+  if (vb < ve) ldv<VW>(xn + (size_t)vb * xld, kc);
   for (long long v = vb + r; v < ve; v += R) {
-    const float4 xv = ld4(xn + (size_t)v * xld);
-    const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+    float xe[VW];
+    ldv<VW>(xn + (size_t)v * xld, xe);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const float t = xe[e] - kc[e]; s0[e] += t; s1[e] += t * t; }
+    for (int e = 0; e < VW; ++e) { const float t = xe[e] - kc[e]; s0[e] += t; s1[e] += t * t; }
   }
-  float* my = lds + (size_t)tid * 8;
+  float* my = lds + (size_t)tid * (2 * VW);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { my[e] = s0[e]; my[4 + e] = s1[e]; }
+  for (int e = 0; e < VW; ++e) { my[e] = s0[e]; my[VW + e] = s1[e]; }
   __syncthreads();
   if (r == 0) {
-    float t[8];
+    float t[2 * VW];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) t[e] = 0.f;
+    for (int e = 0; e < 2 * VW; ++e) t[e] = 0.f;
     for (int rr = 0; rr < R; ++rr) {
-      const float* o = lds + (size_t)(rr * Q + q) * 8;
+      const float* o = lds + (size_t)(rr * Q + q) * (2 * VW);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) t[e] += o[e];
+      for (int e = 0; e < 2 * VW; ++e) t[e] += o[e];
     }
     const float cnt = (float)(ve > vb ? ve - vb : 0);
-    float* dst = out + (((size_t)n * B + blk) * C + 4 * q) * 3;
+    float* dst = out + (((size_t)n * B + blk) * C + VW * q) * 3;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float m2 = cnt > 0.f ? t[4 + e] - t[e] * t[e] / cnt : 0.f;
+    for (int e = 0; e < VW; ++e) {
+      float m2 = cnt > 0.f ? t[VW + e] - t[e] * t[e] / cnt : 0.f;
       dst[3 * e] = cnt; dst[3 * e + 1] = t[e] + cnt * kc[e]; dst[3 * e + 2] = m2 > 0.f ? m2 : 0.f;
     }
   }
@@ -398,8 +395,14 @@ extern "C" int mi355_gn_moments(const mi355_act* x, float* out, void* stream) {
   if (rc) return rc;
   if (!out) return MI355_EINVAL;
   const long long V = (long long)x->d * x->h * x->w;
-  const int B = gn_blocks_per_sample(V), C = x->c, Q = C / 4, R = 256 / Q > 0 ? 256 / Q : 1;
-  ACT_TYPED(x->dtype, T, LAUNCH(gn_moments_kernel<T>, dim3(B, x->n), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream, (const T*)x->p, x->ld, V, C, Q, R, out));
+  const int B = gn_blocks_per_sample(V), C = x->c;
+  if (act_vw8(x)) {
+    const int Q = C / 8, R = 256 / Q > 0 ? 256 / Q : 1;
+    LAUNCH((gn_moments_kernel<bf16_t, 8>), dim3(B, x->n), dim3(Q * R), (size_t)Q * R * 16 * sizeof(float), stream, (const bf16_t*)x->p, x->ld, V, C, Q, R, out);
+  } else {
+    const int Q = C / 4, R = 256 / Q > 0 ? 256 / Q : 1;
+    ACT_TYPED(x->dtype, T, LAUNCH((gn_moments_kernel<T, 4>), dim3(B, x->n), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream, (const T*)x->p, x->ld, V, C, Q, R, out));
+  }
   return LAUNCH_CHECK();
 }
 
@@ -459,8 +462,14 @@ static int gn_act_bwd_impl(const mi355_act* x, const mi355_act* dA, const mi355_
   if (partials) {
     B = blocks;                                   // first pass already done by the dgrad conv's epilogue (gn_fuse.h)
   } else {
-    ACT_TYPED(x->dtype, T, LAUNCH(gn_bwd_partial_kernel<T>, dim3(B, N), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream,
-                                  (const T*)x->p, x->ld, (const T*)dA->p, dA->ld, V, C, Q, R, groups, act_slope, mean_rstd, scale, shift, part));
+    if (act_vw8(x) && act_vw8(dA)) {
+      const int Q8 = C / 8, R8 = 256 / Q8 > 0 ? 256 / Q8 : 1;
+      LAUNCH((gn_bwd_partial_kernel<bf16_t, 8>), dim3(B, N), dim3(Q8 * R8), (size_t)Q8 * R8 * 16 * sizeof(float), stream,
+             (const bf16_t*)x->p, x->ld, (const bf16_t*)dA->p, dA->ld, V, C, Q8, R8, groups, act_slope, mean_rstd, scale, shift, part);
+    } else {
+      ACT_TYPED(x->dtype, T, LAUNCH((gn_bwd_partial_kernel<T, 4>), dim3(B, N), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream,
+                                    (const T*)x->p, x->ld, (const T*)dA->p, dA->ld, V, C, Q, R, groups, act_slope, mean_rstd, scale, shift, part));
+    }
     rc = LAUNCH_CHECK(); if (rc) return rc;
     partials = part;
   }
@@ -472,8 +481,16 @@ static int gn_act_bwd_impl(const mi355_act* x, const mi355_act* dA, const mi355_
   }
   const long long total = (long long)N * V * Q;
   long long grid = (total + 255) / 256; if (grid > 8192) grid = 8192;
-  ACT_TYPED(x->dtype, T, LAUNCH(gn_bwd_apply_kernel<T>, dim3((unsigned)grid), dim3(256), 0, stream, (const T*)x->p, x->ld, (const T*)dA->p, dA->ld,
-                                (T*)dx->p, dx->ld, (const T*)addend, addend_ld, V, C, N, act_slope, scale, shift, (const float*)coef));
+  const bool vw8 = act_vw8(x) && act_vw8(dA) && act_vw8(dx) && (!addend || (addend_ld % 8 == 0 && !((uintptr_t)addend & 15)));
+  if (vw8) {
+    const long long total8 = (long long)N * V * (C / 8);
+    long long grid8 = (total8 + 255) / 256; if (grid8 > 8192) grid8 = 8192;
+    LAUNCH((gn_bwd_apply_kernel<bf16_t, 8>), dim3((unsigned)grid8), dim3(256), 0, stream, (const bf16_t*)x->p, x->ld, (const bf16_t*)dA->p, dA->ld,
+           (bf16_t*)dx->p, dx->ld, (const bf16_t*)addend, addend_ld, V, C, N, act_slope, scale, shift, (const float*)coef);
+  } else {
+    ACT_TYPED(x->dtype, T, LAUNCH((gn_bwd_apply_kernel<T, 4>), dim3((unsigned)grid), dim3(256), 0, stream, (const T*)x->p, x->ld, (const T*)dA->p, dA->ld,
+                                  (T*)dx->p, dx->ld, (const T*)addend, addend_ld, V, C, N, act_slope, scale, shift, (const float*)coef));
+  }
   return LAUNCH_CHECK();
 }
 

@@ -18,10 +18,10 @@ __device__ __forceinline__ void tri_src(int u, int n, int& i0, int& i1, float& l
   l0 = 1.f - l1;
 }
 
-template <typename T>
+template <typename T, int VW>
 __global__ void upsample2x_fwd_kernel(const T* lo, int lold, int N, int Dl, int Hl, int Wl, int C,
                                       T* cat, int catld, int Dc, int Hc, int Wc, int offz, int offy, int offx) {
-  const int Q = C / 4;
+  const int Q = C / VW;
   const long long total = (long long)N * Dc * Hc * Wc * Q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int q = (int)(idx % Q); long long r = idx / Q;
@@ -29,7 +29,9 @@ __global__ void upsample2x_fwd_kernel(const T* lo, int lold, int N, int Dl, int 
     const int y = (int)(r % Hc); r /= Hc;
     const int z = (int)(r % Dc); const int n = (int)(r / Dc);
     const int uz = z - offz, uy = y - offy, ux = x - offx;
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    float o[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) o[e] = 0.f;
     if (uz >= 0 && uy >= 0 && ux >= 0 && uz < 2 * Dl && uy < 2 * Hl && ux < 2 * Wl) {
       int z0, z1, y0, y1, x0, x1; float lz0, lz1, ly0, ly1, lx0, lx1;
       tri_src(uz, Dl, z0, z1, lz0, lz1); tri_src(uy, Hl, y0, y1, ly0, ly1); tri_src(ux, Wl, x0, x1, lx0, lx1);
@@ -42,11 +44,13 @@ __global__ void upsample2x_fwd_kernel(const T* lo, int lold, int N, int Dl, int 
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const float w = wz[a] * wy[b] * wx[c];
-            const float4 v = ld4(lo + ((((size_t)n * Dl + zs[a]) * Hl + ys[b]) * Wl + xs[c]) * lold + 4 * q);
-            o.x += w * v.x; o.y += w * v.y; o.z += w * v.z; o.w += w * v.w;
+            float v[VW];
+            ldv<VW>(lo + ((((size_t)n * Dl + zs[a]) * Hl + ys[b]) * Wl + xs[c]) * lold + VW * q, v);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) o[e] += w * v[e];
           }
     }
-    st4(cat + ((((size_t)n * Dc + z) * Hc + y) * Wc + x) * catld + 4 * q, o);
+    stv<VW>(cat + ((((size_t)n * Dc + z) * Hc + y) * Wc + x) * catld + VW * q, o);
   }
 }
 
@@ -57,17 +61,19 @@ __device__ __forceinline__ float tri_weight(int u, int n, int d) {
   return (i0 == d ? l0 : 0.f) + (i1 == d ? l1 : 0.f);
 }
 
-template <typename T>
+template <typename T, int VW>
 __global__ void upsample2x_bwd_kernel(const T* dcat, int catld, int N, int Dc, int Hc, int Wc, int C,
                                       T* dlo, int lold, int Dl, int Hl, int Wl, int offz, int offy, int offx) {
-  const int Q = C / 4;
+  const int Q = C / VW;
   const long long total = (long long)N * Dl * Hl * Wl * Q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int q = (int)(idx % Q); long long r = idx / Q;
     const int x = (int)(r % Wl); r /= Wl;
     const int y = (int)(r % Hl); r /= Hl;
     const int z = (int)(r % Dl); const int n = (int)(r / Dl);
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    float o[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) o[e] = 0.f;
     for (int a = -1; a <= 2; ++a) {
       const int uz = 2 * z + a; const float wz = tri_weight(uz, Dl, z); const int cz = uz + offz;
       if (wz == 0.f || cz < 0 || cz >= Dc) continue;
@@ -78,12 +84,14 @@ __global__ void upsample2x_bwd_kernel(const T* dcat, int catld, int N, int Dc, i
           const int ux = 2 * x + c; const float wx = tri_weight(ux, Wl, x); const int cx = ux + offx;
           if (wx == 0.f || cx < 0 || cx >= Wc) continue;
           const float w = wz * wy * wx;
-          const float4 v = ld4(dcat + ((((size_t)n * Dc + cz) * Hc + cy) * Wc + cx) * catld + 4 * q);
-          o.x += w * v.x; o.y += w * v.y; o.z += w * v.z; o.w += w * v.w;
+          float v[VW];
+          ldv<VW>(dcat + ((((size_t)n * Dc + cz) * Hc + cy) * Wc + cx) * catld + VW * q, v);
+#pragma unroll
+          for (int e = 0; e < VW; ++e) o[e] += w * v[e];
         }
       }
     }
-    st4(dlo + ((((size_t)n * Dl + z) * Hl + y) * Wl + x) * lold + 4 * q, o);
+    stv<VW>(dlo + ((((size_t)n * Dl + z) * Hl + y) * Wl + x) * lold + VW * q, o);
   }
 }
 
@@ -100,8 +108,12 @@ extern "C" int mi355_upsample2x_fwd(const mi355_act* lo, const mi355_act* cat, i
   if (!act_ok(lo) || !act_ok(cat) || lo->c != cat->c || lo->n != cat->n) return MI355_EINVAL;
   if (lo->dtype != cat->dtype) return MI355_EUNSUPPORTED;
   const long long total = (long long)cat->n * cat->d * cat->h * cat->w * (cat->c / 4);
-  ACT_TYPED(lo->dtype, T, LAUNCH(upsample2x_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, stream, (const T*)lo->p, lo->ld, lo->n, lo->d, lo->h,
-                                 lo->w, lo->c, (T*)cat->p, cat->ld, cat->d, cat->h, cat->w, offz, offy, offx));
+  if (act_vw8(lo) && act_vw8(cat))
+    LAUNCH((upsample2x_fwd_kernel<bf16_t, 8>), dim3(grid_for(total / 2)), dim3(256), 0, stream, (const bf16_t*)lo->p, lo->ld, lo->n, lo->d, lo->h,
+           lo->w, lo->c, (bf16_t*)cat->p, cat->ld, cat->d, cat->h, cat->w, offz, offy, offx);
+  else
+    ACT_TYPED(lo->dtype, T, LAUNCH((upsample2x_fwd_kernel<T, 4>), dim3(grid_for(total)), dim3(256), 0, stream, (const T*)lo->p, lo->ld, lo->n, lo->d, lo->h,
+                                   lo->w, lo->c, (T*)cat->p, cat->ld, cat->d, cat->h, cat->w, offz, offy, offx));
   return LAUNCH_CHECK();
 }
 
@@ -109,8 +121,12 @@ extern "C" int mi355_upsample2x_bwd(const mi355_act* dcat, const mi355_act* dlo,
   if (!act_ok(dlo) || !act_ok(dcat) || dlo->c != dcat->c || dlo->n != dcat->n) return MI355_EINVAL;
   if (dlo->dtype != dcat->dtype) return MI355_EUNSUPPORTED;
   const long long total = (long long)dlo->n * dlo->d * dlo->h * dlo->w * (dlo->c / 4);
-  ACT_TYPED(dlo->dtype, T, LAUNCH(upsample2x_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, stream, (const T*)dcat->p, dcat->ld, dcat->n, dcat->d,
-                                  dcat->h, dcat->w, dcat->c, (T*)dlo->p, dlo->ld, dlo->d, dlo->h, dlo->w, offz, offy, offx));
+  if (act_vw8(dlo) && act_vw8(dcat))
+    LAUNCH((upsample2x_bwd_kernel<bf16_t, 8>), dim3(grid_for(total / 2)), dim3(256), 0, stream, (const bf16_t*)dcat->p, dcat->ld, dcat->n, dcat->d,
+           dcat->h, dcat->w, dcat->c, (bf16_t*)dlo->p, dlo->ld, dlo->d, dlo->h, dlo->w, offz, offy, offx);
+  else
+    ACT_TYPED(dlo->dtype, T, LAUNCH((upsample2x_bwd_kernel<T, 4>), dim3(grid_for(total)), dim3(256), 0, stream, (const T*)dcat->p, dcat->ld, dcat->n, dcat->d,
+                                    dcat->h, dcat->w, dcat->c, (T*)dlo->p, dlo->ld, dlo->d, dlo->h, dlo->w, offz, offy, offx));
   return LAUNCH_CHECK();
 }
 
@@ -162,15 +178,18 @@ __global__ void add_kernel(const T* a, int ald, const T* b, int bld, T* y, int y
     st4(y + (size_t)v * yld + 4 * q, make_float4(av.x + bv.x, av.y + bv.y, av.z + bv.z, av.w + bv.w));
   }
 }
-template <typename T>
+template <typename T, int VW>
 __global__ void chscale_kernel(const T* x, int xld, const float* s, T* y, int yld, long long V, int N, int C) {
-  const int Q = C / 4;
+  const int Q = C / VW;
   const long long total = (long long)N * V * Q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int q = (int)(idx % Q); const long long nv = idx / Q; const int n = (int)(nv / V);
-    const float4 xv = ld4(x + (size_t)nv * xld + 4 * q);
-    const float4 sv = *reinterpret_cast<const float4*>(s + (size_t)n * C + 4 * q);
-    st4(y + (size_t)nv * yld + 4 * q, make_float4(xv.x * sv.x, xv.y * sv.y, xv.z * sv.z, xv.w * sv.w));
+    float xv[VW], sv[VW];
+    ldv<VW>(x + (size_t)nv * xld + VW * q, xv);
+    ldv<VW>(s + (size_t)n * C + VW * q, sv);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) xv[e] *= sv[e];
+    stv<VW>(y + (size_t)nv * yld + VW * q, xv);
   }
 }
 // change of storage type (fp32 <-> bf16, or a copy): the bridge to a kernel that has no bf16 form, and the 16-bit copy of the network input
@@ -207,8 +226,12 @@ extern "C" int mi355_chscale(const mi355_act* x, const float* chscale, const mi3
   if (!act_ok(x) || !act_ok(y) || !same_shape(x, y) || !chscale) return MI355_EINVAL;
   if (x->dtype != y->dtype) return MI355_EUNSUPPORTED;
   const long long V = (long long)x->d * x->h * x->w;
-  ACT_TYPED(x->dtype, T, LAUNCH(chscale_kernel<T>, dim3(grid_for((long long)x->n * V * (x->c / 4))), dim3(256), 0, stream, (const T*)x->p, x->ld, chscale,
-                                (T*)y->p, y->ld, V, x->n, x->c));
+  if (act_vw8(x) && act_vw8(y))
+    LAUNCH((chscale_kernel<bf16_t, 8>), dim3(grid_for((long long)x->n * V * (x->c / 8))), dim3(256), 0, stream, (const bf16_t*)x->p, x->ld, chscale,
+           (bf16_t*)y->p, y->ld, V, x->n, x->c);
+  else
+    ACT_TYPED(x->dtype, T, LAUNCH((chscale_kernel<T, 4>), dim3(grid_for((long long)x->n * V * (x->c / 4))), dim3(256), 0, stream, (const T*)x->p, x->ld, chscale,
+                                  (T*)y->p, y->ld, V, x->n, x->c));
   return LAUNCH_CHECK();
 }
 
