@@ -71,7 +71,14 @@ __device__ __forceinline__ uint4 shift_run(const uint4& b0, const uint4& b1) {
 // of a 4-plane ring. One barrier per tile; global-memory latency is never on the consumers' path.
 // TA: storage type of x and dy (act_io.h; bf16 storage halves the bytes this kernel is bound by, profiles/r4_ab_experiments.txt section 6)
 template <int NS, int MT, int NLW, int INMODE, bool F16 = false, typename TA = float>      // F16: MI355_PREC_F16, the single plane is fp16
-__global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArgs a) {
+// Register budget of the single-product, 32-output-channel form: 13 waves per workgroup over 4 SIMDs = 4 + 3 + 3 + 3; at the 79 - 88 registers
+// hipcc takes when left alone a SIMD holds 5 waves, i.e. ONE workgroup per CU -- producers and consumers of one workgroup in lock step through
+// a barrier per 64-voxel step, nothing to fill the waits. 72 registers (7 waves per SIMD) let TWO workgroups (26 waves) share the CU.
+// UNMEASURED (round-5 candidate): A/B with tools/build_variant.sh <tag> conv3d_wgrad_bf16.hip -DWGRAD_LP_WAVES=1 (= hipcc's own allocation).
+#ifndef WGRAD_LP_WAVES
+#define WGRAD_LP_WAVES 7
+#endif
+__global__ __launch_bounds__(576 + 64 * NLW) MIN_WAVES_PER_SIMD((NS == 1 && MT == 1) ? WGRAD_LP_WAVES : 1) void conv3d_wgrad_k3_bf16(WgradBArgs a) {
   constexpr int TY = 4, ROWS = 4, HY = 6, XO = 3, RING = 4;
   constexpr int COT = 32 * MT;
   constexpr int CSA = ROWS * 2 + 1;            // 9
@@ -147,6 +154,33 @@ __global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArg
               sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
               if (a.in_slope) { const float4 l4 = *reinterpret_cast<const float4*>(a.in_slope + c); sl[0] = l4.x; sl[1] = l4.y; sl[2] = l4.z; sl[3] = l4.w; }
             }
+            const int slot = iz & 3;                          // iz >= -1: (-1 & 3) == 3
+            if constexpr (NS == 1) {
+              // single-plane operands: two voxels become one packed dword per channel as soon as both are transformed -- no 8 x 4 float
+              // block between the loads and the four LDS writes (the kernel's register count decides how many workgroups share a CU)
+              unsigned wq[4][4];
+#pragma unroll
+              for (int pr = 0; pr < 4; ++pr) {
+                float4 tt[2];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                  const int e = 2 * pr + h2, ix = ix0 + e;
+                  float4 t = t8[k][e];
+                  if (INMODE == MI355_IN_AFFINE_ACT) {
+                    t.x = t.x * sc[0] + sh[0]; t.y = t.y * sc[1] + sh[1]; t.z = t.z * sc[2] + sh[2]; t.w = t.w * sc[3] + sh[3];
+                    t.x = fmaxf(t.x, t.x * sl[0]); t.y = fmaxf(t.y, t.y * sl[1]); t.z = fmaxf(t.z, t.z * sl[2]); t.w = fmaxf(t.w, t.w * sl[3]);
+                  }
+                  const bool ok = rowok && ix >= 0 && ix < a.W && 8 * oct + e < 18;
+                  tt[h2] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                wq[0][pr] = pack_lp2<F16>(tt[0].x, tt[1].x); wq[1][pr] = pack_lp2<F16>(tt[0].y, tt[1].y);
+                wq[2][pr] = pack_lp2<F16>(tt[0].z, tt[1].z); wq[3][pr] = pack_lp2<F16>(tt[0].w, tt[1].w);
+              }
+#pragma unroll
+              for (int cc = 0; cc < 4; ++cc)
+                ldsB[(4 * q + cc) * CSB + (slot * HY + hy) * XO + oct] = make_uint4(wq[cc][0], wq[cc][1], wq[cc][2], wq[cc][3]);
+              continue;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const int ix = ix0 + e;
@@ -158,7 +192,6 @@ __global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArg
               const bool ok = rowok && ix >= 0 && ix < a.W && 8 * oct + e < 18;
               v[e][0] = ok ? t.x : 0.f; v[e][1] = ok ? t.y : 0.f; v[e][2] = ok ? t.z : 0.f; v[e][3] = ok ? t.w : 0.f;
             }
-            const int slot = iz & 3;                          // iz >= -1: (-1 & 3) == 3
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
               uint4 pl[NS];
@@ -169,6 +202,21 @@ __global__ __launch_bounds__(576 + 64 * NLW) void conv3d_wgrad_k3_bf16(WgradBArg
           } else {
             const int w = u - nx, qq = w % (8 * MT), ro = w / (8 * MT), row = ro >> 1, oct = ro & 1;
             const int co = co0 + 4 * qq, y = ty0 + row, x0 = tx0 + 8 * oct;
+            if constexpr (NS == 1) {
+              unsigned wq[4][4];
+#pragma unroll
+              for (int pr = 0; pr < 4; ++pr) {
+                const bool ok0 = co < a.Cout && y < a.H && x0 + 2 * pr < a.W, ok1 = co < a.Cout && y < a.H && x0 + 2 * pr + 1 < a.W;
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 t0 = ok0 ? t8[k][2 * pr] : z4, t1 = ok1 ? t8[k][2 * pr + 1] : z4;
+                wq[0][pr] = pack_lp2<F16>(t0.x, t1.x); wq[1][pr] = pack_lp2<F16>(t0.y, t1.y);
+                wq[2][pr] = pack_lp2<F16>(t0.z, t1.z); wq[3][pr] = pack_lp2<F16>(t0.w, t1.w);
+              }
+#pragma unroll
+              for (int cc = 0; cc < 4; ++cc)
+                ldsA[(buf * COT + 4 * qq + cc) * CSA + row * 2 + oct] = make_uint4(wq[cc][0], wq[cc][1], wq[cc][2], wq[cc][3]);
+              continue;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const bool ok = co < a.Cout && y < a.H && x0 + e < a.W;
