@@ -64,6 +64,102 @@ __device__ __forceinline__ uint4 shift_run(const uint4& b0, const uint4& b1) {
   return make_uint4(b0.y, b0.z, b0.w, b1.x);
 }
 
+// Steady-state producer of the single-product 32-output-channel form (UNMEASURED, round-5 candidate; tools/NEXT.md). Inside a column of tiles
+// (fixed sample, y and x origin; only z moves) a producer thread stages the SAME unit of every tile: everything but z is a per-column
+// constant -- 8-voxel base offset, validity bits, LDS slot, the unit's norm parameters. The generic staging code of the kernel below spends
+// ~650 instructions per unit re-deriving them every step (unit decomposition, eight clamps, eight 64-bit addresses, eight predicates).
+template <int INMODE, bool F16, typename TA>
+struct WgradLpLean {
+  static constexpr int TY = 4, HY = 6, XO = 3, CSA = 9, CSB = 73, NXU = HY * XO * 8, NDYU = 4 * 2 * 8;
+  const WgradBArgs& a;
+  uint4* ldsA; uint4* ldsB;
+  int ci0, co0, ltid;
+  struct Col {
+    const TA* base;                 // tensor + sample + channel of this thread's unit (input or dy)
+    unsigned rowoff; int ix0, ld;   // element offset of voxel e inside a z plane = rowoff + clamp(ix0 + e) * ld
+    unsigned plane;                 // elements per z plane of that tensor
+    unsigned ok;                    // bit e: voxel e exists (row, column and channel inside the tensor)
+    int lds;                        // uint4 index of the unit's channel-0 write, without the ring-slot (input) / buffer (dy) term
+    float4 sc, sh;                  // fused norm of the unit's 4 channels (input units)
+    int ch;
+    bool isx;
+  };
+  __device__ __forceinline__ void col_setup(Col& c, int tile) const {
+    const int col = tile / a.D;
+    const int tx0 = (col % a.tilesX) * 16, ty0 = ((col / a.tilesX) % a.tilesY) * TY, n = col / (a.tilesX * a.tilesY);
+    const int u = ltid < NXU + NDYU ? ltid : NXU + NDYU - 1;        // (threads past the last unit shadow it; they never write)
+    c.isx = u < NXU;
+    int ch, iy, ix0, ld; bool chok;
+    c.ok = 0;
+    if (c.isx) {
+      const int ro = u >> 3, oct = ro % XO, hy = ro / XO, q = u & 7;
+      ch = ci0 + 4 * q; chok = ch < a.Cin; iy = ty0 - 1 + hy; ix0 = tx0 - 1 + 8 * oct; ld = a.xld;
+      c.lds = (4 * q) * CSB + hy * XO + oct;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) c.ok |= (unsigned)(chok && iy >= 0 && iy < a.H && ix0 + e >= 0 && ix0 + e < a.W && 8 * oct + e < 18) << e;
+    } else {
+      const int v = u - NXU, qq = v % 8, ro = v / 8, row = ro >> 1, oct = ro & 1;
+      ch = co0 + 4 * qq; chok = ch < a.Cout; iy = ty0 + row; ix0 = tx0 + 8 * oct; ld = a.dyld;
+      c.lds = (4 * qq) * CSA + row * 2 + oct;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) c.ok |= (unsigned)(chok && iy < a.H && ix0 + e < a.W) << e;
+    }
+    if (!chok) ch = 0;
+    c.ch = ch;
+    const int iyc = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1);
+    c.plane = (unsigned)a.H * (unsigned)a.W * (unsigned)ld;
+    c.base = reinterpret_cast<const TA*>(c.isx ? a.x : a.dy) + (size_t)n * a.D * c.plane + ch;
+    c.rowoff = (unsigned)iyc * (unsigned)a.W * (unsigned)ld; c.ix0 = ix0; c.ld = ld;
+    c.sc = make_float4(1.f, 1.f, 1.f, 1.f); c.sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (INMODE == MI355_IN_AFFINE_ACT && c.isx && chok) {
+      c.sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + ch);
+      c.sh = *reinterpret_cast<const float4*>(a.in_shift + (size_t)n * a.Cin + ch);
+    }
+  }
+  // the unit of the tile at depth z: input units read plane z + 1 (the one new plane of that tile), dy units plane z
+  __device__ __forceinline__ void issue(float4 (&t8)[8], const Col& c, int z) const {
+    int iz = c.isx ? z + 1 : z;
+    iz = iz < a.D ? iz : a.D - 1;
+    const TA* p = c.base + (size_t)iz * c.plane;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ix = c.ix0 + e;
+      const int ixc = ix < 0 ? 0 : (ix < a.W ? ix : a.W - 1);
+      t8[e] = ld4(p + (c.rowoff + (unsigned)ixc * (unsigned)c.ld));
+    }
+  }
+  __device__ __forceinline__ void commit(const float4 (&t8)[8], const Col& c, int z, int buf) const {
+    if (ltid >= NXU + NDYU) return;
+    const unsigned ok = (c.isx && z + 1 >= a.D) ? 0u : c.ok;          // the plane past the volume is the zero halo
+    float4 sl = make_float4(a.slope, a.slope, a.slope, a.slope);
+    if (INMODE == MI355_IN_AFFINE_ACT && a.in_slope && c.isx) sl = *reinterpret_cast<const float4*>(a.in_slope + c.ch);      // (rare: DynUNet concat)
+    unsigned w[4][4];                                                  // [channel][voxel pair]
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      float4 t[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = 2 * pr + h;
+        t[h] = t8[e];
+        if (INMODE == MI355_IN_AFFINE_ACT) {
+          if (c.isx) {                                                 // (dy units are not normalised / activated)
+            t[h].x = t[h].x * c.sc.x + c.sh.x; t[h].y = t[h].y * c.sc.y + c.sh.y; t[h].z = t[h].z * c.sc.z + c.sh.z; t[h].w = t[h].w * c.sc.w + c.sh.w;
+            t[h].x = fmaxf(t[h].x, t[h].x * sl.x); t[h].y = fmaxf(t[h].y, t[h].y * sl.y);
+            t[h].z = fmaxf(t[h].z, t[h].z * sl.z); t[h].w = fmaxf(t[h].w, t[h].w * sl.w);
+          }
+        }
+        if (!((ok >> e) & 1u)) { t[h].x = 0.f; t[h].y = 0.f; t[h].z = 0.f; t[h].w = 0.f; }
+      }
+      w[0][pr] = pack_lp2<F16>(t[0].x, t[1].x); w[1][pr] = pack_lp2<F16>(t[0].y, t[1].y);
+      w[2][pr] = pack_lp2<F16>(t[0].z, t[1].z); w[3][pr] = pack_lp2<F16>(t[0].w, t[1].w);
+    }
+    uint4* dst = c.isx ? ldsB + c.lds + ((z + 1) & 3) * (HY * XO) : ldsA + c.lds + buf * (32 * CSA);
+    const int cs = c.isx ? CSB : CSA;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) dst[cc * cs] = make_uint4(w[cc][0], w[cc][1], w[cc][2], w[cc][3]);
+  }
+};
+
 // Producer / consumer workgroup: waves 0..8 are the 9 (dz,dy) tap rows and only read LDS + issue MFMAs; the NLW producer
 // waves only stage: while the consumers work on tile t they load tile t+1 (its dy tile and the one new input plane) from
 // global memory -- every load of the tile issued before the first use, from clamped always-valid addresses (a branch around a
@@ -235,6 +331,31 @@ __global__ __launch_bounds__(576 + 64 * NLW) MIN_WAVES_PER_SIMD((NS == 1 && MT =
     };
     if (t_begin < t_end) stage(t_begin, 0, t_begin % a.D - 1, 3, true);       // prologue: everything tile t_begin needs
     __syncthreads();
+#ifndef WGRAD_LP_NO_LEAN      // A/B switch (tools/build_variant.sh ... -DWGRAD_LP_NO_LEAN): the generic staging code in the steady state too
+    if constexpr (NS == 1 && MT == 1) {
+      using Lean = WgradLpLean<INMODE, F16, TA>;
+      const Lean lean{a, ldsA, ldsB, ci0, co0, ltid};
+      typename Lean::Col c;
+      if (t_begin < t_end) lean.col_setup(c, t_begin);
+      for (int tile = t_begin; tile < t_end; ++tile) {
+        const int z = tile % a.D, buf = (tile - t_begin) & 1;
+        const bool has_next = tile + 1 < t_end;
+        const bool next_same_col = has_next && z + 1 < a.D;
+        if (next_same_col) {
+          float4 t8[8];
+          lean.issue(t8, c, z + 1);
+          lean.commit(t8, c, z + 1, buf ^ 1);
+        }
+        __syncthreads();
+        if (has_next && !next_same_col) {
+          stage(tile + 1, buf ^ 1, -1, 3, true);
+          __syncthreads();
+          lean.col_setup(c, tile + 1);
+        }
+      }
+      return;
+    }
+#endif
     for (int tile = t_begin; tile < t_end; ++tile) {
       const int z = tile % a.D, buf = (tile - t_begin) & 1;
       const bool has_next = tile + 1 < t_end;
