@@ -461,6 +461,7 @@ static WBPlan plan_wb(const mi355_act* x, const mi355_act* dy, const mi355_conv_
   p.ntiles = (int)nt;
   p.ciTiles = ceil_div(x->c, 32); p.coTiles32 = ceil_div(dy->c, 32);
   p.mt = (dy->c > 32 && nsplit_of_w(d->precision) < 3) ? 2 : 1;     // 3 planes x 64 co would not fit the 160 KiB LDS
+  { const char* e = getenv("MI355_WGRAD_LP_MT"); if (e && atoi(e) == 1) p.mt = 1; }      // A/B switch (tools/r5_prep_ab.sh): 32-channel workgroups everywhere
   p.coTilesWG = ceil_div(p.coTiles32, p.mt);
   const int wgs = p.ciTiles * p.coTilesWG;
   int splits = ceil_div(512, wgs);
