@@ -37,6 +37,35 @@ def newer(a, b):
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
+_PROBED = {}
+
+
+def flags_supported(cc, flags):
+    """Does this hipcc accept `flags`? Compiles an empty translation unit once per flag set. -amdgpu-mfma-vgpr-form is an internal LLVM
+    option: a ROCm whose LLVM does not know it aborts with 'Unknown command line argument', and the whole library -- including the fp32
+    path, which does not need that file's kernels -- would fail to build."""
+    key = tuple(flags)
+    if key not in _PROBED:
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            src = os.path.join(td, "probe.hip")
+            open(src, "w").write("// empty\n")
+            r = subprocess.run([cc, "--offload-arch=gfx950", "-c", src, "-o", os.path.join(td, "probe.o")] + list(flags),
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            _PROBED[key] = r.returncode == 0
+    return _PROBED[key]
+
+
+def flags_for(cc, name, verbose=True):
+    extra = EXTRA_FLAGS.get(name, [])
+    if extra and not flags_supported(cc, extra):
+        if verbose:
+            print(f"build.py: WARNING: this hipcc does not accept {' '.join(extra)}; building {name} without it (the 16-bit plane-ring kernels "
+                  "then copy weight fragments between register halves: slower, same results)", file=sys.stderr, flush=True)
+        extra = []
+    return FLAGS + extra
+
+
 def build(force=False, verbose=True):
     srcs = sources()
     # every header a kernel source may include: editing any of them rebuilds all objects
@@ -49,13 +78,22 @@ def build(force=False, verbose=True):
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or newer(s, o) or any(newer(d, o) for d in deps):
-            jobs.append([cc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o])
+        # the flag set is part of an object's identity: recorded beside it, a change rebuilds (mtimes alone would keep the old object)
+        fl = flags_for(cc, os.path.basename(s), verbose)
+        stamp = o + ".flags"
+        same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(fl)
+        if force or not same_flags or newer(s, o) or any(newer(d, o) for d in deps):
+            jobs.append(([cc] + fl + ["-c", s, "-o", o], stamp, " ".join(fl)))
 
-    def run(cmd):
+    def run(job):
+        cmd, stamp, text = job if isinstance(job, tuple) else (job, None, None)
         if verbose:
             print(" ".join(cmd), flush=True)
+        if stamp and os.path.exists(stamp):
+            os.remove(stamp)
         subprocess.check_call(cmd)
+        if stamp:
+            open(stamp, "w").write(text)
 
     with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))

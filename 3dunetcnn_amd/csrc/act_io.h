@@ -3,7 +3,7 @@
 // templates over the element type of each tensor they touch and address it in elements, so a typed pointer does the byte arithmetic.
 // Reference: unet3d/models/pytorch/segmentation/unet.py:53-58 (AutocastUNet: conv outputs are 16-bit tensors under torch autocast).
 #pragma once
-#include "hipcompat.h"
+#include "gfx950_dialect.h"
 #include "../../include/mi355_unet3d.h"
 
 typedef unsigned short bf16_t;      // storage only: never an arithmetic type

@@ -730,7 +730,6 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring2(Con
 }
 
 #ifndef LPZ_NO_LAUNCH      // (developer builds of single instantiations: tools/lpz_one.sh)
-#ifndef LPZ_NO_LAUNCH      // (developer builds of single instantiations: tools/lpz_one.sh)
 // ---- launches (called by mi355_conv3d_fwd_bf16_impl, conv3d_bf16.hip) ----
 int mi355_lp_zring_launch(ConvBArgs& a, int in_mode, int fuse, bool f16, bool lps, long long blocks, void* stream) {
   const bool norm = in_mode == MI355_IN_AFFINE_ACT;
@@ -781,5 +780,4 @@ int mi355_lp_zring2_launch(ConvBArgs& a, int ks, int in_mode, int fuse, bool f16
 #undef LPZ2_LAUNCH_T
   return LAUNCH_CHECK();
 }
-#endif
 #endif

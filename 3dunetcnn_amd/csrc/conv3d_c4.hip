@@ -11,7 +11,7 @@
 // operand is ONE float per lane, so the per-lane (tap, ci) gather is a plain ds_read_b32 whose tap offset is an instruction
 // immediate (forward) or a per-lane constant (wgrad) -- no address arithmetic in the inner loops.
 // The forward reads the UNPACKED OIDHW weight (3456 floats per 32 output channels, staged to LDS in [(tap,ci)][co] order).
-#include "hipcompat.h"
+#include "gfx950_dialect.h"
 #include "../../include/mi355_unet3d.h"
 #include "gn_fuse.h"
 #include "act_io.h"

@@ -12,7 +12,7 @@
 // MFMA k-steps with one 16-byte global load (L2 resident, software-prefetched one tap ahead).
 // K ordering inside an 8-channel group: lanes 0-31 own channels 0..3, lanes 32-63 channels 4..7, k-step s uses
 // (s, 4+s); A and B use the same permutation so the sum is unchanged.
-#include "hipcompat.h"
+#include "gfx950_dialect.h"
 #include "../../include/mi355_unet3d.h"
 #include "gn_fuse.h"
 #include "pack_values.h"

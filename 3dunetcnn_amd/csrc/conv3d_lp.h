@@ -1,7 +1,7 @@
 // Shared declarations of the 16-bit-operand 3x3x3 convolution kernels: the tile forms (conv3d_bf16.hip) and the plane-ring forms
 // (conv3d_bf16_zring.hip). Reference op: unet3d/models/pytorch/classification/resnet.py:12-22 (conv3x3x3).
 #pragma once
-#include "hipcompat.h"
+#include "gfx950_dialect.h"
 #include <type_traits>
 #include <cstdlib>
 #include "../../include/mi355_unet3d.h"

@@ -15,7 +15,7 @@
 //                       of input planes, global loads overlapped with the MFMA loop (below).
 //   conv3d_wgrad_mfma : 3x3x3 stride 2 and 1x1x1 (incl. the depth-to-space transposed-conv form): split-K over voxel tiles staged
 //                       whole in LDS, register-prefetch software pipeline.
-#include "hipcompat.h"
+#include "gfx950_dialect.h"
 #include "../../include/mi355_unet3d.h"
 #include "act_io.h"
 

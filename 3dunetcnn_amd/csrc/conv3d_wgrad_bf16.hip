@@ -16,7 +16,7 @@
 // and keeps a ring of four input z-planes in LDS, so each step stages ONE new plane (x halo re-read factor 1.7 instead of 5)
 // while the consumers compute on the other three. Partial sums go to the same
 // workspace slabs as the f32 kernel and are reduced by the same deterministic second pass.
-#include "hipcompat.h"
+#include "gfx950_dialect.h"
 #include <cstdlib>
 #include "../../include/mi355_unet3d.h"
 #include "act_io.h"

@@ -21,7 +21,7 @@
 // LDS: 2 x 3 x 16 KB rings + 2 x (6x10 + 4x8) voxels x 128 B staging = 119 KB -> one 512-thread workgroup per CU, 2 waves per SIMD.
 // Partial 27-tap tiles go to the slab workspace of conv3d_wgrad.hip ([pair][slab][tap][32 co][32 ci]) and are reduced by its
 // deterministic second pass.
-#include "hipcompat.h"
+#include "gfx950_dialect.h"
 #include <type_traits>
 #include "../../include/mi355_unet3d.h"
 

@@ -21,7 +21,7 @@
 // History of the forms (all measured on MI355X, profiles/r3_wino_forms.txt; the losers were deleted): a 4-wave workgroup with 8
 // accumulator tiles per wave (three weight-prefetch orders; layer set 33.3 ms), a z-marching 8-wave workgroup with three output planes
 // in registers (36.9 ms: one workgroup per CU in lock step), and the 8-wave tile kernel below (28.7 ms).
-#include "hipcompat.h"
+#include "gfx950_dialect.h"
 #include <type_traits>
 #include <cstdlib>
 #include "../../include/mi355_unet3d.h"

@@ -6,7 +6,7 @@
 //   p = sigmoid(z); per (n,c): I = sum p*y, D = sum p + sum y (sum p^2 + sum y^2 if squared_pred);
 //   f = 1 - (2I + smooth_nr)/(D + smooth_dr); loss = mean f   (batch=True sums I, D over n first).
 // Adam: torch.optim.Adam defaults (script_utils.py:80-81), single flat parameter buffer.
-#include "hipcompat.h"
+#include "gfx950_dialect.h"
 #include "../../include/mi355_unet3d.h"
 
 #define DICE_MAX_BLOCKS 128

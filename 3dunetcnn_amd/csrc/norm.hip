@@ -9,7 +9,7 @@
 // Algorithmic traffic: stats = 1 read of x; backward = reads of (x, dA) twice + 1 write of dx. When the tensor (forward) or its
 // gradient (backward) leaves a conv, that conv's epilogue emits the per-tile partial records instead (gn_fuse.h) and the first
 // read disappears: 0 extra bytes for the forward statistics, 1 pass fewer in the backward.
-#include "hipcompat.h"
+#include "gfx950_dialect.h"
 #include <cstdlib>
 #include "../../include/mi355_unet3d.h"
 #include "act_io.h"

@@ -4,7 +4,7 @@
 // Reference call sites: unet3d/models/pytorch/classification/decoder.py:105-106 (F.interpolate trilinear x2,
 // align_corners=False), segmentation/unet.py:34-42 (F.pad + torch.cat), autoencoder/variational.py:59-60 and
 // segmentation/unet.py:50 (final 1x1x1 conv), classification/myronenko.py:70-79 (Dropout3d).
-#include "hipcompat.h"
+#include "gfx950_dialect.h"
 #include "../../include/mi355_unet3d.h"
 #include "act_io.h"
 

@@ -6,7 +6,7 @@
 //  pre:  unet3d/utils/one_hot.py:7-37 (compile_one_hot_encoding: round, isclose against label values or label groups -> uint8
 //        channels; used by transforms/one_hot.py:7-16) and MONAI NormalizeIntensityD(channel_wise=True, nonzero=False)
 //        (datasets/segmentation.py:77-86): per-channel (x - mean) / std, population std, std == 0 -> 1.
-#include "hipcompat.h"
+#include "gfx950_dialect.h"
 #include "../../include/mi355_unet3d.h"
 
 #define PP_MAX_C 16

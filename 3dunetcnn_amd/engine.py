@@ -130,7 +130,10 @@ class HipNetBase(nn.Module):
             ent[0] = p._version
             batch.extend(ent[1].values())
         if batch:
-            be.repack_batch(batch, self._pack_tables)
+            be.repack_batch(batch, self._pack_tables, precision=self.conv_precision)      # the mode THIS network's forward runs in
+            # the device task table this network's repack used (None: the per-weight launches ran). graph.HipGraphedTrainStep pins
+            # exactly this one -- `be.last_pack_table` is shared by every model on the backend
+            self._last_pack_table = be.last_pack_table
 
     # ---- forward / backward bridge -------------------------------------------------------------------------------
     def _check_input(self, x):

@@ -76,12 +76,26 @@ class HipGraphedTrainStep:
         self._ws_refs = None if be is None else [t for t in be._ws_by_stream.values() if t is not None]
         # the same holds for the device task table of the one-launch weight repack (Backend.repack_batch): its address is in the graph.
         # Keep it alive and mark it so the owner's cache never drops it while this graph exists.
-        self._pack_table = getattr(be, "last_pack_table", None)
+        # (the table of THIS model's repack, recorded by engine._repack_stale -- the backend-global attribute may belong to another model)
+        self._pack_table = getattr(model, "_last_pack_table", None)
         if self._pack_table is not None:
-            self._pack_table._mi355_pinned = True
+            self._pack_table._mi355_pinned = getattr(self._pack_table, "_mi355_pinned", 0) + 1      # a count: several graphs may share it
         self.logits = logits.detach()                # static outputs, refreshed by every replay
         self.loss = loss.detach()
         self._grads = [(p, p.grad) for p in model.parameters() if p.grad is not None]
+
+    def close(self):
+        """Release the graph and unpin the repack task table it held (the owner's 8-entry table cache may evict it again)."""
+        t, self._pack_table = getattr(self, "_pack_table", None), None
+        if t is not None:
+            t._mi355_pinned = max(0, getattr(t, "_mi355_pinned", 1) - 1)
+        self.graph = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _exchange(self):
         if self.reducer is not None:

@@ -217,7 +217,7 @@ class Backend:
         """w: Conv3d weight [O, I, k, k, k] (modes 0, 1) or ConvTranspose3d weight [I, O, k, k, k] (modes 2, 3)."""
         return PackedWeight(self, w, mode)
 
-    def repack_batch(self, packed, cache=None):
+    def repack_batch(self, packed, cache=None, precision=None):
         """Refresh the fp32, Winograd and 16-bit packs that the PackedWeights in `packed` hold from their (updated) weight tensors in ONE
         launch (mi355_pack_weights_batch; round 4: the 16-bit packs too -- dropped and rebuilt on first use they were 50 launches of 6 us
         per bf16 step). The device task table is cached in `cache`
@@ -227,6 +227,8 @@ class Backend:
         never replaced or freed while its owner lives: a captured HIP graph has the table's ADDRESS baked in (graph.py also holds a
         reference of its own)."""
         import numpy as np
+        # precision: the mode of the forward that is about to run (engine passes its network's conv_precision); None: the backend's
+        active = self.precision if precision is None else (PRECISIONS[precision] if isinstance(precision, str) else int(precision))
         CHUNK = 1024                                       # MI355_PACK_CHUNK work items (fp32: elements; Winograd: (dz, ci, co) triples)
         tasks, chunks = [], 0
         for pw in packed:
@@ -237,8 +239,10 @@ class Backend:
             if getattr(pw, "_wino", None) is not None:
                 tasks.append((pw.w.data_ptr(), pw._wino.data_ptr(), pw.cout, pw.cin, pw.kd, pw.mode, 1, chunks))
                 chunks += (3 * cinP * coutP + CHUNK - 1) // CHUNK
-            last = getattr(pw, "_bf16_last", None)             # only the 16-bit pack in use is refreshed; packs of other precision modes
-            pw._bf16 = {k: v for k, v in pw._bf16.items() if k == last}      # (a mode switch) are dropped and rebuilt on first use
+            # only the 16-bit pack of the precision mode the NEXT forward runs in (this backend's current mode) is refreshed: packs of
+            # other modes -- every 16-bit pack once the backend is back in fp32, the other network's after two networks alternated
+            # modes on one PackedWeight -- are dropped and rebuilt on first use instead of being rewritten every step for nobody
+            pw._bf16 = {k: v for k, v in pw._bf16.items() if k == active}
             for prec, buf in pw._bf16.items():             # kind = MI355_PACK_LP + precision
                 tasks.append((pw.w.data_ptr(), buf.data_ptr(), pw.cout, pw.cin, pw.kd, pw.mode, 16 + int(prec), chunks))
                 chunks += (pw.kd ** 3 * ((pw.cin + 15) // 16 * 16) * coutP + CHUNK - 1) // CHUNK
@@ -257,6 +261,7 @@ class Backend:
                     check(self.lib.mi355_wino_pack_weight(w, out, cout, cin, mode, self.stream()), "wino_pack_weight")
                 else:
                     check(self.lib.mi355_pack_conv_weight_bf16(w, out, cout, cin, kd, mode, kind - 16, self.stream()), "pack_conv_weight_bf16")
+            self.last_pack_table = None                    # no table was used: nothing for a capture to pin
             return len(tasks)
         if table is None:
             rec = np.array(tasks, dtype=[("w", "<u8"), ("out", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("kd", "<i4"), ("mode", "<i4"),
@@ -264,15 +269,24 @@ class Backend:
             assert rec.itemsize == 40                      # sizeof(mi355_pack_task)
             if len(cache) >= 8:                            # routing changed 8 times (precision / shape switches): drop the oldest unpinned
                 for k in list(cache):
-                    if not getattr(cache[k], "_mi355_pinned", False):
+                    if not getattr(cache[k], "_mi355_pinned", 0):
                         del cache[k]
                         break
             table = cache[key] = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
-        self.last_pack_table = table                       # graph.py pins the table its capture used
+        self.last_pack_table = table                       # the table THIS call used (engine.HipNetBase records it per network)
         check(self.lib.mi355_pack_weights_batch(table.data_ptr(), len(tasks), chunks, self.stream()), "pack_weights_batch")
         return len(tasks)
 
     # -- conv ----------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _same_storage(what, t, ref, ref_name):
+        """Operands handed to the library as RAW pointers (a conv's residual, the normalised tensor of the norm-backward sums, the addend
+        of gn_act_bwd) carry no type on the C side: the header promises they have the storage type of y / dx, and nothing there can
+        check it. A mismatch would be reinterpreted silently -- refuse it here."""
+        if t is not None and t.dtype != ref.dtype:
+            raise TypeError(f"{what} is stored as {t.dtype} but {ref_name} as {ref.dtype}: operands passed by pointer must share the "
+                            "output's storage type (mi355_unet3d.h); cast first (Backend.cast)")
+
     def _desc(self, kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep, in_slope=None,
               out_mode=OUT_PLAIN):
         d = MiConvDesc()
@@ -295,6 +309,9 @@ class Backend:
         (mean_rstd, scale, shift) of gx: have the epilogue emit the first pass of gn_act_bwd. Returns None, or (records, B) to
         hand to gn_act_bwd(partials=...)."""
         pad = kd // 2 if pad is None else pad
+        self._same_storage("conv_fwd: residual", residual, y, "y")
+        if gnb is not None:
+            self._same_storage("conv_fwd: normalised tensor of the norm-backward sums", gnb[0], y, "y")
         if out_dhw is None:
             out_dhw = x.shape[1:4] if out_mode == OUT_D2S else y.shape[1:4]
         if (self.winograd and self.precision == PREC_F32 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT)
@@ -379,6 +396,9 @@ class Backend:
     def conv_fwd_wino(self, x, up, y, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, bias=None, residual=None, chscale=None,
                       in_slope=None, moments=False, gnb=None):
         """Same contract as conv_fwd for a 3x3x3 stride-1 conv (moments / gnb: the fused statistics of the epilogue)."""
+        self._same_storage("conv_fwd_wino: residual", residual, y, "y")
+        if gnb is not None:
+            self._same_storage("conv_fwd_wino: normalised tensor of the norm-backward sums", gnb[0], y, "y")
         keep = []
         d = self._desc(3, 1, 1, in_mode, slope, scale, shift, bias, residual, chscale, (0, 0, 0), y.shape[1:4], keep, in_slope, OUT_PLAIN)
         xd, yd = x.desc(), y.desc()
@@ -512,6 +532,7 @@ class Backend:
 
     def gn_act_bwd(self, x, dA, dx, groups, slope, gamma, mean_rstd, scale, shift, dgamma, dbeta, addend=None, partials=None):
         """partials: None, or what conv_fwd(gnb=...) returned for the dgrad that produced dA (its epilogue did the first pass)."""
+        self._same_storage("gn_act_bwd: addend", addend, dx, "dx")
         xd, dad, dxd = x.desc(), dA.desc(), dx.desc()
         ws = self.ws(self.lib.mi355_gn_workspace(ctypes.byref(xd)))
         common = (ctypes.byref(xd), ctypes.byref(dad), ctypes.byref(dxd),

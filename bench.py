@@ -77,6 +77,9 @@ def parse():
                          "backward. ~600 host launches per step become 3 (many ranks on one host, short steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="disable the per-launch HIP events (roofline -> null)")
+    ap.add_argument("--no-c3", action="store_true",
+                    help="skip the short run of BASELINE configs[2]'s per-GPU shape (bf16 mixed, batch 4, 16-bit activation storage) that the "
+                         "default N=1 line carries under `c3` (a child process: python bench.py --config c3 --steps 5 --warmup 2)")
     ap.add_argument("--no-precision-modes", action="store_true",
                     help="skip the short extra runs of the opt-in conv arithmetic modes (reported under precision_modes, N=1 only)")
     # TEST INFRASTRUCTURE (tests/test_bench_contract.py): run the launch / rank / reduce plumbing of this script on the CPU emulator
@@ -216,7 +219,11 @@ def cpu_baseline(size, model="unet3d"):
     try:
         step((edge,) * 3)                                        # the warm-up iteration of the protocol
         runs = [step((edge,) * 3) for _ in range(3)]
-    except (MemoryError, RuntimeError):                          # host RAM too small for the full patch: the only case that is scaled
+    except (MemoryError, RuntimeError) as e:                     # host RAM too small for the full patch: the only case that is scaled
+        # torch reports a failed host allocation as a RuntimeError ("DefaultCPUAllocator: not enough memory", "can't allocate memory");
+        # any OTHER RuntimeError is a bug in the baseline and must not turn into a silent half-size run
+        if not isinstance(e, MemoryError) and not any(t in str(e).lower() for t in ("not enough memory", "allocate memory", "out of memory")):
+            raise
         edge = max(smallest, size // 2)
         mult = (size / edge) ** 3
         step((edge,) * 3)
@@ -232,6 +239,36 @@ def cpu_baseline(size, model="unet3d"):
     if mult != 1.0:
         out["sample"] += f" -- EXTRAPOLATED: the host could not hold the {size}^3 step; forward / backward of the {edge}^3 patch x {mult:.0f}"
     return out
+
+
+C3_KEYS = ("volumes_per_s_per_gpu", "ms_per_step", "workload", "activation_storage", "dtype", "steps", "warmup", "bound", "frac", "kernel",
+           "mfma_pipe_frac", "hbm_frac", "traffic_over_algorithmic", "share_of_step", "per_rank_host_enqueue_ms_per_step", "command")
+
+
+def c3_block(steps=5, warmup=2, timeout=600):
+    """BASELINE configs[2] per GPU (the same model in bf16 mixed precision, batch 4 per GPU, 16-bit activation storage: the configuration
+    the 8-GPU DDP run is quoted on, reference: AutocastUNet, segmentation/unet.py:53-58) measured by a CHILD process on this GPU after the
+    headline's timed region: `python bench.py --config c3 --steps 5 --warmup 2 --no-cpu-baseline`. A separate process because the step
+    allocates the batch-4 activations of another network; its own line is what `--config c3` prints, this block keeps the figures a
+    reader of the driver's line needs. Informational: never `value`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", "c3", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"))
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"child exited {r.returncode}: {(r.stderr or r.stdout)[-300:]}", "command": " ".join(cmd[1:])}
+        c = json.loads(line[-1])
+    except Exception as e:                                       # a failing extra must not take the headline line down; it says so
+        return {"error": f"{type(e).__name__}: {e}", "command": " ".join(cmd[1:])}
+    roof = c.get("roofline") or {}
+    return {"volumes_per_s_per_gpu": c["value"], "ms_per_step": c["ms_per_step"], "workload": c["config"]["workload"],
+            "activation_storage": c["config"]["activation_storage"], "dtype": c["dtype"], "steps": c["steps"], "warmup": c["warmup"],
+            "bound": roof.get("bound"), "frac": roof.get("frac"), "kernel": roof.get("kernel"),
+            "mfma_pipe_frac": roof.get("mfma_pipe_frac"), "hbm_frac": roof.get("hbm_frac"),
+            "traffic_over_algorithmic": roof.get("traffic_over_algorithmic"), "share_of_step": roof.get("share_of_step"),
+            "per_rank_host_enqueue_ms_per_step": c.get("per_rank_host_enqueue_ms_per_step"),
+            "command": "python bench.py --config c3 --steps %d --warmup %d --no-cpu-baseline (child process, same GPU, after the timed region)" % (steps, warmup)}
 
 
 def bench_c5(args, unet, inferer_mod, dev):
@@ -358,9 +395,11 @@ def main():
         return loss
 
     graphed = None
-    if args.graph and dev.type == "cuda":
+    if args.graph:
         graph_mod = importlib.import_module("3dunetcnn_amd.graph")
-        graphed = graph_mod.HipGraphedTrainStep(model, criterion, optimizer, x, y)      # one flat all-reduce per step when N > 1
+        # one flat all-reduce per step when N > 1. On the CPU emulator (plumbing test) the same step runs uncaptured: the host logic of
+        # the graphed form -- callbacks detached, one exchange of the flat buffer between backward and Adam -- without a HIP graph
+        graphed = graph_mod.HipGraphedTrainStep(model, criterion, optimizer, x, y, capture=dev.type == "cuda")
         args.no_kernel_events = True                              # a replayed graph has no per-launch events
 
     def step():
@@ -548,7 +587,8 @@ def main():
                # with --graph; two extra steps after the timed region); the step is GPU-bound while this stays below ms_per_step
                "per_rank_host_enqueue_ms_per_step": [round(t, 3) for t in per_rank_host],
                "communicator": {"backend": comm_backend, "world_size": comm_world, "rank_devices": rank_devices},
-               "step_form": "hip-graph replay + one flat all-reduce" if graphed is not None else "eager launches, bucketed all-reduce inside backward",
+               "step_form": ("hip-graph replay + one flat all-reduce" + (" (uncaptured: emulator plumbing test)" if emu else "")) if graphed is not None
+                            else "eager launches, bucketed all-reduce inside backward",
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision],
                "data": "synthetic" if not emu else "synthetic -- CPU-EMULATOR PLUMBING TEST, NOT A MEASUREMENT",
                "config": {"workload": f"BASELINE configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.config] }]: {model_desc}, {'x'.join(str(v) for v in dhw)} patch, batch {B}/GPU, {'bf16 activation tensors' if args.storage == 'bf16' else 'fp32 tensors'}, "
@@ -589,6 +629,8 @@ def main():
                                                                "conv_arithmetic": ARITH[pm]}
             be.set_precision("fp32")
             out["precision_modes"] = modes
+        if world == 1 and args.precision == "fp32" and args.config == "c2" and args.model == "unet3d" and not args.no_c3 and not emu:
+            out["c3"] = c3_block()
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             out["cpu_baseline"] = cpu_baseline(S, args.model)
         print(json.dumps(out), flush=True)

@@ -210,3 +210,52 @@ def test_bf16_line_says_how_activations_are_stored(emu_backend):
     assert "bf16 activation tensors" in line["config"]["workload"]
     p = subprocess.run(base + ["--storage", "bf16"], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode != 0 and "--storage bf16 goes with --precision bf16" in (p.stderr + p.stdout)
+
+
+@pytest.mark.parametrize("extra,form,dtype", [(["--config", "c3"], "eager launches", "bf16 (mixed)"), (["--graph"], "hip-graph replay + one flat all-reduce", "f32")])
+def test_two_ranks_in_the_c3_and_the_graphed_form(emu_backend, extra, form, dtype):
+    """8-rank readiness without hardware (round 5): the two other forms the driver may launch -- `--gpus N --config c3` (BASELINE configs[2]:
+    bf16 operands, batch 4 per GPU, 16-bit activation storage, bucketed exchange inside backward) and `--gpus N --graph` (one exchange of
+    the flat gradient buffer per step) -- through the script's own launch / rendezvous / reduce / timing plumbing at world size 2 on the
+    CPU emulator over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "8", "--batch", "1", "--steps", "2",
+                        "--warmup", "1", "--emulator-plumbing-test"] + extra, capture_output=True, text=True, env=env, timeout=1800)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    per_gpu = 4 if "c3" in extra else 1                 # --config c3 fixes the batch at BASELINE configs[2]'s 4 per GPU
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 2 * per_gpu
+    assert line["step_form"].startswith(form) and line["dtype"] == dtype
+    assert line["communicator"]["world_size"] == 2 and len(line["per_rank_ms_per_step"]) == 2
+    assert abs(line["value"] - 2 * per_gpu * 1e3 / line["ms_per_step"]) / line["value"] < 1e-2
+    if "c3" in extra:
+        assert "configs[2]" in line["config"]["workload"] and line["config"]["activation_storage"].startswith("bf16")
+    assert line["final_loss"] == line["final_loss"] and 0.0 < line["final_loss"] < 2.0      # a finite Dice loss on both forms
+
+
+def test_c3_block_keeps_the_figures_of_the_child_line(monkeypatch):
+    """The default N = 1 line carries BASELINE configs[2]'s per-GPU shape under `c3` (verdict round 4, item 5): a child `bench.py --config c3`
+    whose line is reduced to the keys below; a failing child yields an `error` entry instead of taking the headline line down."""
+    b = _bench()
+    child = {"value": 84.0, "ms_per_step": 47.6, "steps": 5, "warmup": 2, "dtype": "bf16 (mixed)", "per_rank_host_enqueue_ms_per_step": [9.0],
+             "config": {"workload": "BASELINE configs[2]: ...", "activation_storage": "bf16 (...)"},
+             "roofline": {"bound": "mfma", "frac": 0.3, "kernel": "conv3d_k3_bf16<...>", "mfma_pipe_frac": 0.3, "hbm_frac": 0.12,
+                          "traffic_over_algorithmic": 1.4, "share_of_step": 0.36}}
+    seen = {}
+
+    class R:
+        returncode, stderr = 0, ""
+        stdout = "noise\n" + json.dumps(child) + "\n"
+
+    def run(cmd, **kw):
+        seen["cmd"] = cmd
+        return R
+    monkeypatch.setattr(subprocess, "run", run)
+    blk = b.c3_block()
+    assert set(blk) == set(b.C3_KEYS) and blk["volumes_per_s_per_gpu"] == 84.0 and blk["mfma_pipe_frac"] == 0.3 and blk["hbm_frac"] == 0.12
+    assert seen["cmd"][2:5] == ["--config", "c3", "--steps"] and "--no-cpu-baseline" in seen["cmd"]
+    R.returncode = 3
+    blk = b.c3_block()
+    assert "error" in blk and "exited 3" in blk["error"]

@@ -235,7 +235,7 @@ def test_audit_c3_bf16_train_step_gpu(hip_backend):
     and weight gradients with the 16-bit operand model at the SAME 1e-5 as an fp32 launch, everything else against plain fp64;
     (b) logits and loss against the fp32 CPU oracle (oracle/unet3d_ref.py, the device-drawn Dropout3d mask shared with it) at the
     tolerance of the mode: bf16 operands carry 2^-9 relative rounding, measured network-level error ~7e-3 (tests/test_model_gpu.py
-    test_autocast_unet_mixed_precision at 32^3); bound 3e-2 on logits, 1e-2 on the Dice loss."""
+    test_autocast_unet_mixed_precision at 32^3); bound 1.5e-2 on logits (1.5x the 1.0e-2 measured on MI355X in round 4: a regression by a factor of two fails), 1e-2 on the Dice loss."""
     from oracle import torch_ops as O
     torch.manual_seed(1234)
     m = unet.HipAutocastUNet(n_features=4, n_outputs=3, autocast_dtype="bf16").cuda().train()
@@ -260,7 +260,7 @@ def test_audit_c3_bf16_train_step_gpu(hip_backend):
             worst = max(worst, A.rel_err(keep["logits"][i:i + 1], ref))
         lref = float(O.dice_loss(torch.cat(ref_all), y))
     print(f"c3 logits vs fp32 oracle {worst:.2e}; loss {loss:.6f} vs {lref:.6f}")
-    assert worst < 3e-2, worst
+    assert worst < 1.5e-2, worst
     assert abs(loss - lref) / lref < 1e-2, (loss, lref)
 
 

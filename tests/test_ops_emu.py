@@ -517,15 +517,24 @@ def test_batched_repack_refreshes_the_16bit_packs(emu_backend, prec):
     packs[2].bf16(pnum)                                                            # ... the mode in use is the last one asked for
     for w, _ in ws:
         w.mul_(0.75).add_(-0.125)
-    assert be.repack_batch(packs) == 6
-    assert set(packs[2]._bf16) == {pnum}
-    for pw, (w, m) in zip(packs, ws):
-        fresh = be.pack_weight(w, m)
-        assert torch.equal(pw._f32, fresh.f32()) and torch.equal(pw._bf16[pnum], fresh.bf16(pnum))
+    be.set_precision(prec)                            # the mode the next forward runs in decides which 16-bit pack is refreshed
+    try:
+        assert be.repack_batch(packs) == 6
+        assert set(packs[2]._bf16) == {pnum}
+        for pw, (w, m) in zip(packs, ws):
+            fresh = be.pack_weight(w, m)
+            assert torch.equal(pw._f32, fresh.f32()) and torch.equal(pw._bf16[pnum], fresh.bf16(pnum))
+    finally:
+        be.set_precision("fp32")
+    # back in fp32 nobody reads the 16-bit packs: they are dropped (3 fp32 tasks left), not rewritten every step
+    assert be.repack_batch(packs) == 3 and all(not pw._bf16 for pw in packs)
 
 
-def test_training_step_repacks_in_one_launch(emu_backend):
-    """From the second step on, the packs of a training step are refreshed by ONE mi355_pack_weights_batch launch at the start of the
+@pytest.mark.parametrize("conv_precision", [None, "bf16"])
+def test_training_step_repacks_in_one_launch(emu_backend, conv_precision):
+    """(conv_precision "bf16": a network with its own mode on a backend that is in fp32 between forwards -- the 16-bit packs of THAT
+    mode ride in the batch, they are not dropped and rebuilt by single launches every step.)
+    From the second step on, the packs of a training step are refreshed by ONE mi355_pack_weights_batch launch at the start of the
     forward (engine.py: _repack_stale) and no single-weight pack kernel runs; the step computes what a model with freshly built packs
     computes from the same weights."""
     import importlib
@@ -538,11 +547,13 @@ def test_training_step_repacks_in_one_launch(emu_backend):
     kw = dict(n_features=4, n_outputs=3, base_width=8, encoder_blocks=[1, 1])
     m = unet.HipUNet3D(**kw).eval()
     m._be = be
+    m.conv_precision = conv_precision
     crit, opt = losses.HipDiceLoss(sigmoid=True), optim.HipAdam(m.parameters(), lr=1e-2)
     crit._be = opt._be = be
     x, y = R.synthetic_case(1, 4, (16, 16, 16), 3)
     counts = {"single": 0, "batch": 0}
-    orig = {n: getattr(be.lib, n) for n in ("mi355_pack_conv_weight", "mi355_wino_pack_weight", "mi355_pack_weights_batch")}
+    orig = {n: getattr(be.lib, n) for n in ("mi355_pack_conv_weight", "mi355_wino_pack_weight", "mi355_pack_weights_batch",
+                                            "mi355_pack_conv_weight_bf16")}
 
     def counted(name, key):
         def f(*a):
@@ -552,6 +563,7 @@ def test_training_step_repacks_in_one_launch(emu_backend):
     be.lib.mi355_pack_conv_weight = counted("mi355_pack_conv_weight", "single")
     be.lib.mi355_wino_pack_weight = counted("mi355_wino_pack_weight", "single")
     be.lib.mi355_pack_weights_batch = counted("mi355_pack_weights_batch", "batch")
+    be.lib.mi355_pack_conv_weight_bf16 = counted("mi355_pack_conv_weight_bf16", "single")
     try:
         for _ in range(2):
             opt.zero_grad(set_to_none=True)
@@ -568,6 +580,7 @@ def test_training_step_repacks_in_one_launch(emu_backend):
             setattr(be.lib, n, f)
     m2 = unet.HipUNet3D(**kw).eval()                   # the same weights through freshly built packs
     m2._be = be
+    m2.conv_precision = conv_precision
     m2.load_state_dict(m.state_dict())
     out2 = m2(x)
     crit(out2, y).backward()
