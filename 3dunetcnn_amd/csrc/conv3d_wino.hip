@@ -53,9 +53,6 @@ struct WinoArgs {
 #ifndef WINO_ZBRICK
 #define WINO_ZBRICK 8             // z tiles per brick of the workgroup order (A/B: -DWINO_ZBRICK=1 = x fastest)
 #endif
-#ifndef WINO_R8
-#define WINO_R8 1             // 1: conv3d_wino2d_r8 (A fragments generated in registers, round 5); 0: conv3d_wino2d_w8 (A/B: -DWINO_R8=0)
-#endif
 #ifndef WINO_ABL
 #define WINO_ABL 0            // developer ablations of conv3d_wino2d_w8 (tools/build_variant.sh ... -DWINO_ABL=mask): 1 no input loads, 2 no weight loads, 4 no transform, 8 no stores
 #endif
@@ -568,485 +565,6 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(Wi
 #undef W8_PATTERN_ONE_USE
 #undef W8_PATTERN_TWO_USE
 
-// The statistics tail of a fused epilogue (FUSE 1: moments of the stored output, FUSE 2: norm-backward sums): per-lane partials of 4 channels
-// -> one record per (tile, channel); the code of conv3d_wino2d_w8's tail as a function (conv3d_wino2d_r8 calls it).
-template <int FUSE>
-__device__ __forceinline__ void wino_fuse_records(const WinoArgs& a, float* P, int tid, int lane, int wave, int coq, int co_base, int n, int tz0, int ty0,
-                                                  int tx0, int cnt, float (&K0)[4], float (&s0)[4], float (&s1)[4]) {
-  constexpr int TZ = 2, TY = 8, TX = 16;
-
-    // Per-lane partials of 4 channels -> one record per (tile, channel). Lanes coq + 8 m (m = 0..7) of a wave hold the same channels:
-    // three xor-shuffle steps of PLAIN sums (fixed order: the lane with the lower m first), then the eight waves through LDS in wave
-    // order (Chan's merge, as everywhere). Moments: a lane's sums are about its own first value K0; before the shuffles they are moved
-    // to the wave's common shift Kc = K0 of lane m = 0 (sum (v - Kc) = s0 + c d, sum (v - Kc)^2 = s1 + d (2 s0 + c d), d = K0 - Kc: no
-    // division, no E[x^2] - E[x]^2 of raw values), and M2 = s1 - s0^2 / c is formed once per wave and channel.
-    constexpr int KK = FUSE == 1 ? 3 : 2;
-    float vals[4][KK];
-    float cw = (float)cnt;                                  // FUSE 1: stored voxels of this lane (the same for its four channels)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if constexpr (FUSE == 1) {
-        const float Kc = __shfl(K0[e], coq);
-        const float d = K0[e] - Kc;
-        vals[e][0] = Kc;
-        vals[e][2] = s1[e] + d * (2.f * s0[e] + cw * d);
-        vals[e][1] = s0[e] + cw * d;
-      } else {
-        vals[e][0] = s0[e]; vals[e][1] = s1[e];
-      }
-    }
-#pragma unroll
-    for (int step = 8; step < 64; step <<= 1) {
-      const bool upper = lane & step;
-      if constexpr (FUSE == 1) { const float oc = __shfl_xor(cw, step); cw = upper ? oc + cw : cw + oc; }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int k = (FUSE == 1 ? 1 : 0); k < KK; ++k) {
-          const float o = __shfl_xor(vals[e][k], step);
-          vals[e][k] = upper ? o + vals[e][k] : vals[e][k] + o;
-        }
-    }
-    // the eight waves through LDS: moments as (count, sum about Kc, sum of squares about Kc, Kc) per wave, moved to wave 0's shift by
-    // the same identity and added in wave order; M2 = s1 - s0^2 / c once per channel
-    constexpr int KW = FUSE == 1 ? 4 : 2;
-    __syncthreads();                                       // every wave is done with the exchange
-    if (lane < 8) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float* pr = P + ((wave * 32) + 4 * coq + e) * KW;
-        if constexpr (FUSE == 1) { pr[0] = cw; pr[1] = vals[e][1]; pr[2] = vals[e][2]; pr[3] = vals[e][0]; }
-        else { pr[0] = vals[e][0]; pr[1] = vals[e][1]; }
-      }
-    }
-    __syncthreads();
-    if (tid < 32) {
-      float r[KK];
-      if constexpr (FUSE == 1) {
-        const float K = P[tid * KW + 3];
-        float c = P[tid * KW], t0 = P[tid * KW + 1], t1 = P[tid * KW + 2];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) {
-          const float* pr = P + (w * 32 + tid) * KW;
-          const float cwv = pr[0], d = pr[3] - K;
-          t1 += pr[2] + d * (2.f * pr[1] + cwv * d);
-          t0 += pr[1] + cwv * d;
-          c += cwv;
-        }
-        const float m2 = c > 0.f ? t1 - t0 * t0 / c : 0.f;
-        r[0] = c; r[1] = t0 + c * K; r[2] = m2 > 0.f ? m2 : 0.f;
-      } else {
-#pragma unroll
-        for (int k = 0; k < KK; ++k) r[k] = P[tid * KW + k];
-#pragma unroll
-        for (int w = 1; w < 8; ++w)
-#pragma unroll
-          for (int k = 0; k < KK; ++k) r[k] += P[(w * 32 + tid) * KW + k];
-      }
-      const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
-      const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
-      float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * KK;
-      const int co = co_base + tid;
-      if (co < a.Cout) {
-#pragma unroll
-        for (int k = 0; k < KK; ++k) dst[(size_t)co * KK + k] = r[k];
-      }
-    }
-  }
-
-// =====================================================================================================================================
-// conv3d_wino2d_r8 (round 5): the same tile, the same 8 waves and the same weight pack as conv3d_wino2d_w8, WITHOUT the transformed
-// planes in LDS. What the SQ counters and the ablations of rounds 3 / 4 say about the w8 form (profiles/r3_wino_forms.txt section 4,
-// r4_mfma_valu_overlap.txt, r5_sq_counters_wino.txt): nothing but the instruction count per MFMA is left to take -- per phase and lane 12
-// ds_read_b32 + 16 adds + 8 ds_write_b32 of the shared transform, 2 ds_read_b128 of the A fragments, and on the 32-channel layers
-// an epilogue / prologue as long as the main loop. Here:
-//  * a wave GENERATES its A fragments in registers straight from the staged plane: its two points share the point row i (two window
-//    rows ra, rb: R = d[ra] + beta d[rb]) and use three adjacent window columns X0 X1 X2 (q0 = R[X0] - R[X2], q1 = R[X1] + eps R[X2]),
-//    so a lane reads 6 x 16 bytes (4 channels each) and issues 10 packed fp32 instructions per phase -- 6 LDS instructions instead of
-//    22, 10 vector instructions instead of 20, no second LDS hop between the input and the MFMA, and the 32 KB of transformed planes
-//    are gone. beta / eps / the rows / the column order are wave constants, so the body is branch-free:
-//        i = 0: d0 - d2   i = 1: d1 + d2   i = 2: d2 - d1   i = 3: d1 - d3                  (ra, rb, beta) = (0,2,-) (1,2,+) (2,1,-) (1,3,-)
-//        j half 0 (j = 0, 1): X = columns (0, 1, 2): q0 = X0 - X2 = V[i][0], q1 = X1 + X2 = V[i][1]
-//        j half 1 (j = 3, 2): X = columns (3, 2, 1): q0 = X0 - X2 = -V[i][3], q1 = X1 - X2 = V[i][2]
-//    (the accumulator of q0 holds -M[i][3] in the second half; the in-wave part of the output transform takes the sign for free:
-//    b0 = a1, b1 = a0 - a1 instead of b0 = a0 + a1, b1 = a1);
-//  * the staged plane is laid out for those reads: [channel quad][row][even columns | odd columns] in 16-byte groups, row stride 20
-//    groups, so the 16 lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, ...; MI355X_MICROARCH.md, LDS) hit 16 different
-//    16-byte bank groups (tile (ty, tx) of column class c sits at group tx + 40 ty + const), and the 8-lane groups of the staging
-//    ds_write_b128 (4 consecutive voxels x 2 quads) hit 8 different ones;
-//  * the MFMA operands are swapped (A = weights, B = input): a lane holds 4 CONSECUTIVE output channels of one tile per accumulator
-//    quad, so the output-transform exchange is written with 8 ds_write_b128 per plane instead of 32 ds_write_b32 (rows padded to 36
-//    floats: conflict-free), and the in-wave half of the transform is a scalar branch on the wave's j half instead of two selects
-//    per value.
-template <int INMODE, int FUSE>
-__global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_r8(WinoArgs a) {
-  constexpr int TZ = 2, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HV = HY * HX;
-  constexpr int KC = 8;
-  constexpr int RS = 20;                                   // 16-byte groups per staged row: even columns 0..8 | pad | odd columns 10..18 | pad
-  constexpr int QS = HY * RS + 4;                          // groups per channel quad (+ 4: the two quads of a voxel land on different banks)
-  constexpr int XSF = 2 * QS * 4;                          // floats of one staged plane chunk
-  constexpr int PS = 36, PW = 2 * 32 * PS, PF = 8 * PW;    // exchange: [wave][b][tile][32 channels + 4 pad]
-  static_assert(2 * XSF + (512 - 2 * HV) * 4 <= PF, "the main loop's buffers live inside the exchange area");
-  DYN_LDS(lds);
-  float* xs = lds;                                         // 2 staged plane chunks
-  float* P = lds;                                          // epilogue: output-transform exchange
-  float* prm = lds + PF;                                   // norm prologue of this sample: scale | shift | slope, CinP each
-  const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6), half = lane >> 5, li = lane & 31;
-  // workgroup -> (channel tile, spatial tile): as conv3d_wino2d_w8 (an XCD gets a contiguous range of spatial tiles of one channel tile,
-  // walked in bricks of WINO_ZBRICK z tiles, then x, y)
-  int b = blockIdx.x, cot;
-  {
-    const int nct = a.coTiles, S = gridDim.x / nct, ng = nct < 8 && 8 % nct == 0 ? 8 / nct : 0;
-    if (ng > 0 && S % ng == 0) {
-      const int x = b & 7;
-      cot = x % nct;
-      b = (x / nct) * (S / ng) + (b >> 3);
-    } else {
-      cot = b % nct; b /= nct;
-    }
-  }
-  int tz;
-  if (a.tilesZ % WINO_ZBRICK == 0) {
-    const int zi = b % WINO_ZBRICK; b /= WINO_ZBRICK;
-    const int txi = b % a.tilesX; b /= a.tilesX;
-    const int tyi = b % a.tilesY; b /= a.tilesY;
-    const int zbk = b % (a.tilesZ / WINO_ZBRICK); b /= (a.tilesZ / WINO_ZBRICK);
-    tz = zbk * WINO_ZBRICK + zi;
-    b = (b * a.tilesY + tyi) * a.tilesX + txi;
-  } else {
-    const int txi = b % a.tilesX, r1 = b / a.tilesX;
-    const int tyi = r1 % a.tilesY, r2 = r1 / a.tilesY;
-    tz = r2 % a.tilesZ;
-    b = ((r2 / a.tilesZ) * a.tilesY + tyi) * a.tilesX + txi;
-  }
-  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
-  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
-  const int tz0 = tz * TZ;
-  const int n = b;
-  const int co_base = cot * 32;
-
-  f32x16 acc[TZ][2];                                       // [output plane][q]
-#pragma unroll
-  for (int oz = 0; oz < TZ; ++oz)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[oz][q][r] = 0.f;
-
-  // Staging unit of this thread: (halo voxel sv, channel quad sq) of the 180 x 2 units of a plane chunk, fixed for the whole kernel.
-  // EVERY lane stages (threads 360..511 re-read unit 0 and write zeros to a pad slot of their own): no lane-divergent control flow in the
-  // main loop, a chunk is straight-line code between its barriers. What a lane keeps of the value it loaded is a uniform choice between
-  // loop-invariant LANE MASKS held in scalar registers (image-inside lanes; of those the first quad), applied as one select per register.
-  const bool sunit = tid < HV * 2;
-  const int sv = sunit ? tid >> 1 : 0, sq = sunit ? tid & 1 : 0;
-  const int srow = sv / HX, scol = sv % HX;
-  const int siy = ty0 - 1 + srow, six = tx0 - 1 + scol;
-  const bool sin = sunit && siy >= 0 && siy < a.H && six >= 0 && six < a.W;
-  const size_t xplane = (size_t)a.H * a.W * a.xld;
-  const float* xn = a.x + (size_t)n * a.D * xplane;        // sample n
-  // BYTE offset inside the plane, 32 bits: uniform 64-bit base + lane offset = the scalar-base form of global_load. A channel count that
-  // is not a multiple of 8 has a last chunk without a second quad: its lanes read the 16 bytes behind the voxel's channels (never kept,
-  // see `keep`), which exist for every voxel but the last of a plane -- that one re-reads its first quad.
-  const int cyx = (siy < 0 ? 0 : (siy < a.H ? siy : a.H - 1)) * a.W + (six < 0 ? 0 : (six < a.W ? six : a.W - 1));
-  const bool back = sq == 1 && a.Cin % 8 != 0 && cyx == a.H * a.W - 1;
-  const unsigned xoff = (unsigned)(cyx * a.xld + (back ? 0 : 4 * sq)) * 4u;
-  const unsigned soff = sunit ? (unsigned)((sq * QS + srow * RS + (scol >> 1) + 10 * (scol & 1)) * 4)      // staged position (floats)
-                              : (unsigned)(2 * XSF + (tid - HV * 2) * 4);
-  const LaneMask m_in = LANE_MASK(sin), m_in0 = LANE_MASK(sin && sq == 0);
-  const float4* up4 = reinterpret_cast<const float4*>(a.up);
-  const int CQ = a.CinP / 4;
-
-  float4 ld = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto loads = [&](int c0_, int pz_) {
-    const int iz = tz0 - 1 + pz_;
-    const int izc = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1);
-    ld = ldg16_uniform_base(xn + (size_t)izc * xplane + c0_, xoff);
-  };
-  auto commit = [&](float* xsb, int c0_, int pz_) {
-    const int iz = tz0 - 1 + pz_;
-    const LaneMask km = iz >= 0 && iz < a.D ? (c0_ + 8 <= a.Cin ? m_in : m_in0) : (LaneMask)0;      // uniform
-    float4 v = ld;
-    if (INMODE == MI355_IN_AFFINE_ACT) {
-      const int c = c0_ + 4 * sq;
-      const float4 sc = *reinterpret_cast<const float4*>(prm + c), sh = *reinterpret_cast<const float4*>(prm + a.CinP + c);
-      const float4 sl = *reinterpret_cast<const float4*>(prm + 2 * a.CinP + c);
-      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-      v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
-    }
-    if (!LANE_IN_MASK(km)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(xsb + soff) = v;
-  };
-  // A-fragment generation: wave constants (point row i, j half jh); the lane's two row addresses (window rows ra, rb at window column
-  // 0); the column offsets are immediates once the j half is a compile-time constant (the main loop exists twice, `run` below)
-  const int pi = wave >> 1, jh = wave & 1;
-  const int ra = pi == 0 ? 0 : (pi == 2 ? 2 : 1), rb = pi == 2 ? 1 : (pi == 3 ? 3 : 2);
-  const float beta = pi == 1 ? 1.f : -1.f;
-  const int tty = li >> 3, ttx = li & 7;
-  const unsigned ga = (unsigned)((half * QS + (2 * tty + ra) * RS + ttx) * 4);      // floats
-  const unsigned gb = (unsigned)((half * QS + (2 * tty + rb) * RS + ttx) * 4);
-  struct AF { pkf2 v[2][2]; };                             // [q][channel pair]: 4 channels = two register pairs
-  // weight fragments of one use: the wave's two points p0 = 4 i + 3 jh, p1 = 4 i + 1 + jh, z-tap dz, channels [c0_, c0_ + 8)
-  const unsigned boff = (unsigned)(half * a.CoutP + co_base + li) * 16u;    // bytes
-  const size_t bstep = (size_t)CQ * a.CoutP;               // float4s between consecutive (point, dz) slabs
-  const int p0 = 4 * pi + 3 * jh, p1 = 4 * pi + 1 + jh;
-  auto b_use = [&](float4 (&bu)[2], int c0_, int dz) {
-    const float4* qb = up4 + (size_t)(c0_ / 4) * a.CoutP;  // uniform
-    bu[0] = ldg16_uniform_base(qb + (size_t)(p0 * 3 + dz) * bstep, boff);
-    bu[1] = ldg16_uniform_base(qb + (size_t)(p1 * 3 + dz) * bstep, boff);
-  };
-  auto mfma_use = [&](const AF& f, const float4 (&bu)[2], f32x16 (&ac)[2]) {
-    ac[0] = MFMA_32x32x2(bu[0].x, f.v[0][0].x, ac[0]);
-    ac[1] = MFMA_32x32x2(bu[1].x, f.v[1][0].x, ac[1]);
-    ac[0] = MFMA_32x32x2(bu[0].y, f.v[0][0].y, ac[0]);
-    ac[1] = MFMA_32x32x2(bu[1].y, f.v[1][0].y, ac[1]);
-    ac[0] = MFMA_32x32x2(bu[0].z, f.v[0][1].x, ac[0]);
-    ac[1] = MFMA_32x32x2(bu[1].z, f.v[1][1].x, ac[1]);
-    ac[0] = MFMA_32x32x2(bu[0].w, f.v[0][1].y, ac[0]);
-    ac[1] = MFMA_32x32x2(bu[1].w, f.v[1][1].y, ac[1]);
-  };
-#ifdef MI355_EMU
-#define R8_PATTERN_ONE_USE()
-#define R8_PATTERN_TWO_USE()
-#else
-#define R8_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-  // One basic block per phase. The four LDS reads of X0 / X2 go out first, their row sums and q0 (12 instructions) follow two MFMAs later,
-  // then the two reads of X1 (at most 16 registers of window values in flight), its row sum and q1 (8) behind two more MFMAs; the weight request of a two-use
-  // phase is issued once the first use's MFMAs (which read the registers it overwrites) are out.
-#define R8_PATTERN_ONE_USE() do {                                                            \
-    R8_SGB(0x100, 4); R8_SGB(0x008, 2); R8_SGB(0x002, 12); R8_SGB(0x100, 2);                 \
-    R8_SGB(0x008, 2); R8_SGB(0x002, 8); R8_SGB(0x008, 4); } while (0)
-#define R8_PATTERN_TWO_USE() do {                                                            \
-    R8_SGB(0x100, 4); R8_SGB(0x008, 2); R8_SGB(0x002, 12); R8_SGB(0x100, 2);                 \
-    R8_SGB(0x008, 2); R8_SGB(0x002, 8); R8_SGB(0x008, 4); R8_SGB(0x020, 2); R8_SGB(0x008, 8); } while (0)
-#endif
-  // The main loop, once per j half (a scalar branch around it): JH is a compile-time constant inside, so the three window columns of
-  // a fragment generation are immediate offsets from the lane's two row addresses.
-  //   JH = 0: X = columns (0, 1, 2): q0 = X0 - X2 = V[i][0], q1 = X1 + X2 = V[i][1]
-  //   JH = 1: X = columns (3, 2, 1): q0 = X0 - X2 = -V[i][3], q1 = X1 - X2 = V[i][2]
-  float4 bA[2], bB[2];
-  auto run = [&](auto jhc) {
-    constexpr int JH = decltype(jhc)::value;
-    auto gen = [&](AF& f, const float* xsb) {
-      constexpr int c0_ = JH ? 3 : 0, c1_ = JH ? 2 : 1, c2_ = JH ? 1 : 2;
-      constexpr int o0 = ((c0_ >> 1) + 10 * (c0_ & 1)) * 4, o1 = ((c1_ >> 1) + 10 * (c1_ & 1)) * 4, o2 = ((c2_ >> 1) + 10 * (c2_ & 1)) * 4;
-      const float4 a0 = *reinterpret_cast<const float4*>(xsb + ga + o0), b0 = *reinterpret_cast<const float4*>(xsb + gb + o0);
-      const float4 a2 = *reinterpret_cast<const float4*>(xsb + ga + o2), b2 = *reinterpret_cast<const float4*>(xsb + gb + o2);
-      // (written per element: hipcc unpacks v_pk_* fp32 instructions that sit in the shadow of an MFMA anyway, and a scalar beta stays in
-      // an SGPR)
-      const float s00 = fmaf(b0.x, beta, a0.x), s01 = fmaf(b0.y, beta, a0.y), s02 = fmaf(b0.z, beta, a0.z), s03 = fmaf(b0.w, beta, a0.w);
-      const float s20 = fmaf(b2.x, beta, a2.x), s21 = fmaf(b2.y, beta, a2.y), s22 = fmaf(b2.z, beta, a2.z), s23 = fmaf(b2.w, beta, a2.w);
-      const float4 a1 = *reinterpret_cast<const float4*>(xsb + ga + o1), b1 = *reinterpret_cast<const float4*>(xsb + gb + o1);
-      f.v[0][0] = make_pkf2(s00 - s20, s01 - s21); f.v[0][1] = make_pkf2(s02 - s22, s03 - s23);
-      const float s10 = fmaf(b1.x, beta, a1.x), s11 = fmaf(b1.y, beta, a1.y), s12 = fmaf(b1.z, beta, a1.z), s13 = fmaf(b1.w, beta, a1.w);
-      f.v[1][0] = JH ? make_pkf2(s10 - s20, s11 - s21) : make_pkf2(s10 + s20, s11 + s21);
-      f.v[1][1] = JH ? make_pkf2(s12 - s22, s13 - s23) : make_pkf2(s12 + s22, s13 + s23);
-      // the fragments are used by the NEXT phase only: without the pins hipcc sinks the ten instructions behind the barrier, in front of
-      // the MFMAs that wait for them, and carries the 24 window registers across it
-      PIN_IN_VGPR(f.v[0][0]); PIN_IN_VGPR(f.v[0][1]); PIN_IN_VGPR(f.v[1][0]); PIN_IN_VGPR(f.v[1][1]);
-    };
-    // One channel chunk = 4 phases (input planes pz = 0..3 of the tile), weights W[dz] of a chunk loaded once into two rotating sets as
-    // in conv3d_wino2d_w8. Phase pz: MFMAs with the fragments f(pz) generated in phase pz - 1 | fragments of plane pz + 1 from the
-    // buffer staged in phase pz - 1 | loads of plane pz + 2 at the top, staged at the bottom into the buffer f(pz) was generated from.
-    auto chunk = [&](int c0, float4 (&S0)[2], float4 (&S1)[2], AF& fa, AF& fb) {
-      const bool more = c0 + KC < a.CinP;                  // another chunk follows (workgroup-uniform)
-      const int cn = more ? c0 + KC : c0;                  // the requests of phases 2 / 3 are unconditional: after the last chunk they repeat it
-      // phase 0: plane 0 x W0 -> output plane 0 | fragments of plane 1 | loads of plane 2
-      b_use(S1, c0, 1);
-      loads(c0, 2);
-      SCHED_BARRIER();
-      gen(fb, xs + XSF);
-      mfma_use(fa, S0, acc[0]);
-      R8_PATTERN_ONE_USE();
-      SCHED_BARRIER();
-      commit(xs, c0, 2);
-      __syncthreads();
-      // phase 1: plane 1 x W0 -> output plane 1, x W1 -> output plane 0 | fragments of plane 2 | loads of plane 3
-      loads(c0, 3);
-      SCHED_BARRIER();
-      gen(fa, xs);
-      mfma_use(fb, S0, acc[1]);
-      b_use(S0, c0, 2);
-      mfma_use(fb, S1, acc[0]);
-      R8_PATTERN_TWO_USE();
-      SCHED_BARRIER();
-      commit(xs + XSF, c0, 3);
-      __syncthreads();
-      // phase 2: plane 2 x W1 -> output plane 1, x W2 -> output plane 0 | fragments of plane 3 | loads of the next chunk's plane 0
-      loads(cn, 0);
-      SCHED_BARRIER();
-      gen(fb, xs + XSF);
-      mfma_use(fa, S1, acc[1]);
-      b_use(S1, cn, 0);
-      mfma_use(fa, S0, acc[0]);
-      R8_PATTERN_TWO_USE();
-      SCHED_BARRIER();
-      commit(xs, cn, 0);
-      __syncthreads();
-      // phase 3: plane 3 x W2 -> output plane 1 | fragments of the next chunk's plane 0 (after the last chunk: never used) | loads of
-      // its plane 1
-      loads(cn, 1);
-      SCHED_BARRIER();
-      gen(fa, xs);
-      mfma_use(fb, S0, acc[1]);
-      R8_PATTERN_ONE_USE();
-      SCHED_BARRIER();
-      commit(xs + XSF, cn, 1);
-      __syncthreads();
-    };
-    AF fA, fB;
-    gen(fA, xs);
-    __syncthreads();                                       // phase 0 stages plane 2 over plane 0
-    for (int c0 = 0; c0 < a.CinP; c0 += KC) {
-      chunk(c0, bA, bB, fA, fB);
-      bA[0] = bB[0]; bA[1] = bB[1];                        // the next chunk's W0 (8 register moves per 4 phases keep ONE loop body)
-    }
-  };
-
-  // prologue: planes 0 and 1 of the first chunk requested together, W0 requested, the norm-prologue parameters fetched after those
-  // requests; plane 0 staged | barrier | plane 1 staged, fragments of plane 0 generated | barrier
-  b_use(bA, 0, 0);
-  loads(0, 0);
-  const float4 ld0 = ld;
-  loads(0, 1);
-  if (INMODE == MI355_IN_AFFINE_ACT) {
-    for (int c = tid; c < a.CinP; c += 512) {
-      const bool in = c < a.Cin;
-      prm[c] = in ? a.in_scale[(size_t)n * a.Cin + c] : 0.f;
-      prm[a.CinP + c] = in ? a.in_shift[(size_t)n * a.Cin + c] : 0.f;
-      prm[2 * a.CinP + c] = in ? (a.in_slope ? a.in_slope[c] : a.slope) : 0.f;
-    }
-    __syncthreads();
-  }
-  { const float4 ld1 = ld; ld = ld0; commit(xs, 0, 0); ld = ld1; }
-  __syncthreads();
-  commit(xs + XSF, 0, 1);
-  if (jh) run(std::integral_constant<int, 1>()); else run(std::integral_constant<int, 0>());
-
-  // ---- output transform Y = A^T M A, bias / residual / dropout scale, store ----
-  // In-wave over the wave's two j (scalar branch on the j half), written to the exchange P[wave][b][tile][co] as 16-byte runs of the 4
-  // consecutive channels an accumulator quad holds; across the waves over i on the way out, voxel-major as in conv3d_wino2d_w8.
-  const int coq = tid & 7, ea = (wave >> 1) & 1;           // voxel rows: y = (tid >> 7) + 4 s -> a = y & 1 is wave-uniform
-  const int co4 = co_base + 4 * coq;
-  float bs[4], cs[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const bool cv = co4 + e < a.Cout;
-    bs[e] = cv && a.bias ? a.bias[co4 + e] : 0.f;
-    cs[e] = cv && a.out_chscale ? a.out_chscale[(size_t)n * a.Cout + co4 + e] : 1.f;
-  }
-  const bool q_in = co4 < a.Cout, q_full = co4 + 4 <= a.Cout;      // any / all four channels of the quad exist
-  float K0[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-  float gsc[4], gsh[4], gmean[4], grstd[4];
-  int cnt = 0;
-  if constexpr (FUSE == 2) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int coc = co4 + e < a.Cout ? co4 + e : a.Cout - 1;
-      const int grp = coc / (a.Cout / a.g.ggroups);
-      gsc[e] = a.g.gscale[(size_t)n * a.Cout + coc]; gsh[e] = a.g.gshift[(size_t)n * a.Cout + coc];
-      gmean[e] = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd[e] = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
-    }
-  }
-  float* pw = P + wave * PW + li * PS + 4 * half;          // this lane's partials: + b * 32 * PS + 8 * g for accumulator quad g
-  auto ld4 = [&](const float* base, size_t off, float (&v)[4]) {          // 4 channels of a voxel; scalar where 16-byte access is not legal
-    if (a.vec4) {
-      const float4 t = *reinterpret_cast<const float4*>(base + off);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = co4 + e < a.Cout ? base[off + e] : 0.f;
-    }
-  };
-#pragma unroll
-  for (int oz = 0; oz < TZ; ++oz) {
-    if (oz > 0) __syncthreads();                           // the previous plane's exchange has been read (the main loop ends on a barrier)
-    if (jh) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x16& m0 = acc[oz][0]; const f32x16& m1 = acc[oz][1];
-        *reinterpret_cast<float4*>(pw + 8 * g) = make_float4(m1[4 * g], m1[4 * g + 1], m1[4 * g + 2], m1[4 * g + 3]);
-        *reinterpret_cast<float4*>(pw + 32 * PS + 8 * g) =
-            make_float4(m0[4 * g] - m1[4 * g], m0[4 * g + 1] - m1[4 * g + 1], m0[4 * g + 2] - m1[4 * g + 2], m0[4 * g + 3] - m1[4 * g + 3]);
-      }
-    } else {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x16& m0 = acc[oz][0]; const f32x16& m1 = acc[oz][1];
-        *reinterpret_cast<float4*>(pw + 8 * g) =
-            make_float4(m0[4 * g] + m1[4 * g], m0[4 * g + 1] + m1[4 * g + 1], m0[4 * g + 2] + m1[4 * g + 2], m0[4 * g + 3] + m1[4 * g + 3]);
-        *reinterpret_cast<float4*>(pw + 32 * PS + 8 * g) = make_float4(m1[4 * g], m1[4 * g + 1], m1[4 * g + 2], m1[4 * g + 3]);
-      }
-    }
-    // reads that do not depend on the exchange go out before the barrier: the normalised tensor (FUSE 2) and the residual
-    const int z = tz0 + oz, zc = z < a.D ? z : a.D - 1;
-    float gxv[2][4], rsv[2][4];
-    size_t vox[2];
-    bool vin[2];
-#pragma unroll
-    for (int sI = 0; sI < 2; ++sI) {
-      const int v = (tid >> 3) + 64 * sI;
-      const int yy = ty0 + (v >> 4), xx = tx0 + (v & 15);
-      vin[sI] = q_in && z < a.D && yy < a.H && xx < a.W;
-      const int yc = yy < a.H ? yy : a.H - 1, xc = xx < a.W ? xx : a.W - 1;
-      vox[sI] = (((size_t)n * a.D + zc) * a.H + yc) * a.W + xc;
-      const int cq = q_in ? co4 : 0;                       // a quad beyond Cout reads (and drops) the first one
-      if constexpr (FUSE == 2) ld4(a.g.gx, vox[sI] * a.g.gxld + cq, gxv[sI]);
-      if (a.res) ld4(a.res, vox[sI] * a.resld + cq, rsv[sI]);
-      else { rsv[sI][0] = rsv[sI][1] = rsv[sI][2] = rsv[sI][3] = 0.f; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int sI = 0; sI < 2; ++sI) {
-      const int v = (tid >> 3) + 64 * sI;
-      const int tile = ((v >> 5) << 3) + ((v & 15) >> 1), eb = v & 1;      // (y >> 1) * 8 + (x >> 1); b = x & 1
-      const float* pz = P + (eb * 32 + tile) * PS + 4 * coq;      // wave w at + w * PW floats
-      auto rd = [&](int w) { return *reinterpret_cast<const float4*>(pz + w * PW); };
-      // across the waves: row i of the point grid = waves 2 i, 2 i + 1; A^T rows over i: (1, 1, 1, 0) and (0, 1, -1, -1)
-      float4 o;
-      if (ea == 0) {
-        const float4 q0 = rd(0), q1 = rd(1), q2 = rd(2), q3 = rd(3), q4 = rd(4), q5 = rd(5);
-        o.x = (q0.x + q1.x) + (q2.x + q3.x) + (q4.x + q5.x); o.y = (q0.y + q1.y) + (q2.y + q3.y) + (q4.y + q5.y);
-        o.z = (q0.z + q1.z) + (q2.z + q3.z) + (q4.z + q5.z); o.w = (q0.w + q1.w) + (q2.w + q3.w) + (q4.w + q5.w);
-      } else {
-        const float4 q2 = rd(2), q3 = rd(3), q4 = rd(4), q5 = rd(5), q6 = rd(6), q7 = rd(7);
-        o.x = (q2.x + q3.x) - (q4.x + q5.x) - (q6.x + q7.x); o.y = (q2.y + q3.y) - (q4.y + q5.y) - (q6.y + q7.y);
-        o.z = (q2.z + q3.z) - (q4.z + q5.z) - (q6.z + q7.z); o.w = (q2.w + q3.w) - (q4.w + q5.w) - (q6.w + q7.w);
-      }
-      if (!vin[sI]) continue;
-      float ov[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ov[e] = (ov[e] + bs[e] + rsv[sI][e]) * cs[e];
-      float* yp = a.y + vox[sI] * a.yld + co4;
-      if (a.vec4 && q_full) *reinterpret_cast<float4*>(yp) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-      else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (co4 + e < a.Cout) yp[e] = ov[e];
-      }
-      if constexpr (FUSE == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (cnt == 0) K0[e] = ov[e];
-          const float t = ov[e] - K0[e];
-          s0[e] += t; s1[e] += t * t;
-        }
-        ++cnt;
-      } else if constexpr (FUSE == 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xv = gxv[sI][e];
-          const float u = xv * gsc[e] + gsh[e];
-          const float du = u > 0.f ? ov[e] : ov[e] * a.g.gslope;
-          s0[e] += du; s1[e] += du * ((xv - gmean[e]) * grstd[e]);
-        }
-      }
-    }
-  }
-  if constexpr (FUSE != 0) wino_fuse_records<FUSE>(a, P, tid, lane, wave, coq, co_base, n, tz0, ty0, tx0, cnt, K0, s0, s1);
-}
-#undef R8_SGB
-#undef R8_PATTERN_ONE_USE
-#undef R8_PATTERN_TWO_USE
-
 // ---- filter transform: U[(i,j)][dz][ci][co] = sum_{dy,dx} G[i][dy] G[j][dx] w[...] (pack_values.h: pack_wino_item) ----
 __global__ void wino_pack_weight_kernel(const float* w, float* up, int cout, int cin, int coutP, int cinP, int mode) {
   const size_t items = (size_t)3 * (cinP / 4) * coutP * 4;          // one per (dz, ci, co): 16 points each
@@ -1115,17 +633,11 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
            (!a.g.gnb || (a.g.gxld % 4 == 0 && !((uintptr_t)a.g.gx & 15)));
   const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
-  // exchange area (the main loop's buffers live inside it; r8: rows padded to 36 floats) + norm prologue
-  const int lds_bytes = (8 * 2 * 32 * (WINO_R8 ? 36 : 32) + 3 * a.CinP) * (int)sizeof(float);
+  const int lds_bytes = (8 * 2 * 32 * 32 + 3 * a.CinP) * (int)sizeof(float);      // exchange area (the main loop's buffers live inside it) + norm prologue
   const dim3 grid((unsigned)blocks), blk(512);
-#if WINO_R8
-#define WINO_KERNEL conv3d_wino2d_r8
-#else
-#define WINO_KERNEL conv3d_wino2d_w8
-#endif
 #define WINO_LAUNCH(IM, FU)                                                                          \
-  do { SET_MAX_DYN_LDS((WINO_KERNEL<IM, FU>), lds_bytes);                                         \
-       LAUNCH((WINO_KERNEL<IM, FU>), grid, blk, lds_bytes, stream, a); } while (0)
+  do { SET_MAX_DYN_LDS((conv3d_wino2d_w8<IM, FU>), lds_bytes);                                         \
+       LAUNCH((conv3d_wino2d_w8<IM, FU>), grid, blk, lds_bytes, stream, a); } while (0)
   if (a.g.mom) {
     if (d->in_mode == MI355_IN_PLAIN) WINO_LAUNCH(MI355_IN_PLAIN, 1); else WINO_LAUNCH(MI355_IN_AFFINE_ACT, 1);
   } else if (a.g.gnb) {
@@ -1133,7 +645,6 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   } else if (d->in_mode == MI355_IN_PLAIN) WINO_LAUNCH(MI355_IN_PLAIN, 0);
   else WINO_LAUNCH(MI355_IN_AFFINE_ACT, 0);
 #undef WINO_LAUNCH
-#undef WINO_KERNEL
   return LAUNCH_CHECK();
 }
 

@@ -29,25 +29,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ... and in the architectural half: accumulators of a kernel whose AGPRs are full of pinned operands (left to itself hipcc may put the
 // MFMA results there too and then spills the operands)
 #define PIN_IN_VGPR(v) asm volatile("" : "+v"(v))
-// a per-lane condition as a 64-bit wave mask in scalar registers, and back: `LANE_IN_MASK(m)` is this lane's bit of a UNIFORM mask, used
-// directly as the select / branch condition (no vector instruction tests it)
-typedef unsigned long long LaneMask;
-#define LANE_MASK(cond) __builtin_amdgcn_ballot_w64(cond)
-#define LANE_IN_MASK(m) __builtin_amdgcn_inverse_ballot_w64(m)
-// a wave-uniform value (pointer, offset) kept in scalar registers from here on: what is added to it afterwards stays a lane offset
-#define PIN_IN_SGPR(v) asm volatile("" : "+s"(v))
-// 16 bytes from (uniform base in scalar registers) + (32-bit lane byte offset): global_load_dwordx4 v, v_off, s[base:base+1]. Left to
-// itself hipcc folds the loop-invariant lane part into a 64-bit register pair per lane and adds the uniform rest with vector instructions
-// before every load. The pin hides the pointer's origin, so the global address space is stated (a generic pointer would be a flat_load,
-// which also counts on the LDS counter).
-__device__ __forceinline__ float4 ldg16_uniform_base(const void* ubase, unsigned lane_off) {
-  unsigned long long b = reinterpret_cast<unsigned long long>(ubase);
-  PIN_IN_SGPR(b);
-  PIN_IN_VGPR(lane_off);      // ... and keeps the 32-bit offset's zero extension in the block of the load (instruction selection works per block)
-  const __attribute__((address_space(1))) char* g = reinterpret_cast<const __attribute__((address_space(1))) char*>(b);
-  const f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(g + lane_off);
-  return make_float4(v[0], v[1], v[2], v[3]);
-}
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+0..7] and B[k=8*(l>>5)+0..7][j=l&31] as 8 packed bf16
 // (16 bytes, carried here as uint4); same C/D map as the f32 form. 32 cycles per SIMD = 16x the f32 MFMA rate.
@@ -75,8 +56,6 @@ __device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
 typedef f32x2_t pkf2;
 __device__ __forceinline__ pkf2 make_pkf2(float x, float y) { pkf2 v = {x, y}; return v; }
 __device__ __forceinline__ pkf2 pk_fma(pkf2 a, pkf2 b, pkf2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ pkf2 pk_add(pkf2 a, pkf2 b) { return a + b; }      // v_pk_add_f32
-__device__ __forceinline__ pkf2 pk_sub(pkf2 a, pkf2 b) { return a - b; }      // v_pk_add_f32 with the neg modifier
 #define LAUNCH(kernel, grid, block, lds, stream, ...) \
   hipLaunchKernelGGL(kernel, (grid), (block), (lds), (hipStream_t)(stream), __VA_ARGS__)
 #define LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? 0 : -3)

@@ -197,8 +197,6 @@ static inline f32x16 emu_mfma_32x32x2(float a, float b, f32x16 c) {
 struct pkf2 { float x, y; };
 static inline pkf2 make_pkf2(float x, float y) { return pkf2{x, y}; }
 static inline pkf2 pk_fma(pkf2 a, pkf2 b, pkf2 c) { return pkf2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
-static inline pkf2 pk_add(pkf2 a, pkf2 b) { return pkf2{a.x + b.x, a.y + b.y}; }
-static inline pkf2 pk_sub(pkf2 a, pkf2 b) { return pkf2{a.x - b.x, a.y - b.y}; }
 
 // bf16 helpers (round to nearest even, as v_cvt_pk_bf16_f32)
 static inline unsigned emu_f2bf(float f) {
@@ -309,11 +307,5 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetc
 #define ONE_WAVE_PER_SIMD
 #define PIN_IN_AGPR(v) ((void)0)
 #define PIN_IN_VGPR(v) ((void)0)
-#define PIN_IN_SGPR(v) ((void)0)
-static inline float4 ldg16_uniform_base(const void* ubase, unsigned lane_off) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ubase) + lane_off); }
-typedef unsigned long long LaneMask;
-static inline LaneMask emu_lane_mask(bool c) { LaneMask m = 0; for (int l = 0; l < 64; ++l) m |= (LaneMask)(emu_shfl((int)c, l) & 1) << l; return m; }
-#define LANE_MASK(cond) emu_lane_mask(cond)
-#define LANE_IN_MASK(m) ((((m) >> (emu::flat_tid() % 64)) & 1ull) != 0)
 typedef uint4 u32x4_t;
 #define SLEEP_64CLK(n) do {} while (0)
