@@ -19,7 +19,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # there as well, runs out of AGPRs, keeps the remaining weights in VGPRs and copies each into place before the MFMA that reads it (two
 # v_mov_b64 + s_nop per MFMA on a third of the MFMAs of the 64-channel form). -amdgpu-mfma-vgpr-form selects the VGPR-destination MFMA
 # forms: accumulators in the architectural half, every weight fragment in an AGPR, no copies, no spills (tools/lpz_one.sh).
-EXTRA_FLAGS = {"conv3d_bf16_zring.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# conv3d_wino.hip: without SLP vectorisation. The fragment generation of conv3d_wino2d_d8 is written per element with a scalar sign; the SLP
+# vectoriser packs part of it into v_pk_* (the sign then needs a register pair per lane) and hipcc unpacks some of that again in the shadow of
+# the MFMAs -- a mix whose instruction count per phase the scheduler directives cannot name.
+EXTRA_FLAGS = {"conv3d_bf16_zring.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "conv3d_wino.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():

@@ -53,6 +53,9 @@ struct WinoArgs {
 #ifndef WINO_ZBRICK
 #define WINO_ZBRICK 8             // z tiles per brick of the workgroup order (A/B: -DWINO_ZBRICK=1 = x fastest)
 #endif
+#ifndef WINO_D8
+#define WINO_D8 1             // 1: plain-input launches on conv3d_wino2d_d8 (LDS-DMA staging, round 5); 0: everything on conv3d_wino2d_w8
+#endif
 #ifndef WINO_ABL
 #define WINO_ABL 0            // developer ablations of conv3d_wino2d_w8 (tools/build_variant.sh ... -DWINO_ABL=mask): 1 no input loads, 2 no weight loads, 4 no transform, 8 no stores
 #endif
@@ -565,6 +568,457 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(Wi
 #undef W8_PATTERN_ONE_USE
 #undef W8_PATTERN_TWO_USE
 
+// The statistics tail of a fused epilogue (FUSE 1: moments of the stored output, FUSE 2: norm-backward sums): per-lane partials of 4 channels
+// -> one record per (tile, channel); the code of conv3d_wino2d_w8's tail as a function (conv3d_wino2d_d8 calls it).
+template <int FUSE>
+__device__ __forceinline__ void wino_fuse_records(const WinoArgs& a, float* P, int tid, int lane, int wave, int coq, int co_base, int n, int tz0, int ty0,
+                                                  int tx0, int cnt, float (&K0)[4], float (&s0)[4], float (&s1)[4]) {
+  constexpr int TZ = 2, TY = 8, TX = 16;
+
+    // Per-lane partials of 4 channels -> one record per (tile, channel). Lanes coq + 8 m (m = 0..7) of a wave hold the same channels:
+    // three xor-shuffle steps of PLAIN sums (fixed order: the lane with the lower m first), then the eight waves through LDS in wave
+    // order (Chan's merge, as everywhere). Moments: a lane's sums are about its own first value K0; before the shuffles they are moved
+    // to the wave's common shift Kc = K0 of lane m = 0 (sum (v - Kc) = s0 + c d, sum (v - Kc)^2 = s1 + d (2 s0 + c d), d = K0 - Kc: no
+    // division, no E[x^2] - E[x]^2 of raw values), and M2 = s1 - s0^2 / c is formed once per wave and channel.
+    constexpr int KK = FUSE == 1 ? 3 : 2;
+    float vals[4][KK];
+    float cw = (float)cnt;                                  // FUSE 1: stored voxels of this lane (the same for its four channels)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if constexpr (FUSE == 1) {
+        const float Kc = __shfl(K0[e], coq);
+        const float d = K0[e] - Kc;
+        vals[e][0] = Kc;
+        vals[e][2] = s1[e] + d * (2.f * s0[e] + cw * d);
+        vals[e][1] = s0[e] + cw * d;
+      } else {
+        vals[e][0] = s0[e]; vals[e][1] = s1[e];
+      }
+    }
+#pragma unroll
+    for (int step = 8; step < 64; step <<= 1) {
+      const bool upper = lane & step;
+      if constexpr (FUSE == 1) { const float oc = __shfl_xor(cw, step); cw = upper ? oc + cw : cw + oc; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = (FUSE == 1 ? 1 : 0); k < KK; ++k) {
+          const float o = __shfl_xor(vals[e][k], step);
+          vals[e][k] = upper ? o + vals[e][k] : vals[e][k] + o;
+        }
+    }
+    // the eight waves through LDS: moments as (count, sum about Kc, sum of squares about Kc, Kc) per wave, moved to wave 0's shift by
+    // the same identity and added in wave order; M2 = s1 - s0^2 / c once per channel
+    constexpr int KW = FUSE == 1 ? 4 : 2;
+    __syncthreads();                                       // every wave is done with the exchange
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float* pr = P + ((wave * 32) + 4 * coq + e) * KW;
+        if constexpr (FUSE == 1) { pr[0] = cw; pr[1] = vals[e][1]; pr[2] = vals[e][2]; pr[3] = vals[e][0]; }
+        else { pr[0] = vals[e][0]; pr[1] = vals[e][1]; }
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float r[KK];
+      if constexpr (FUSE == 1) {
+        const float K = P[tid * KW + 3];
+        float c = P[tid * KW], t0 = P[tid * KW + 1], t1 = P[tid * KW + 2];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) {
+          const float* pr = P + (w * 32 + tid) * KW;
+          const float cwv = pr[0], d = pr[3] - K;
+          t1 += pr[2] + d * (2.f * pr[1] + cwv * d);
+          t0 += pr[1] + cwv * d;
+          c += cwv;
+        }
+        const float m2 = c > 0.f ? t1 - t0 * t0 / c : 0.f;
+        r[0] = c; r[1] = t0 + c * K; r[2] = m2 > 0.f ? m2 : 0.f;
+      } else {
+#pragma unroll
+        for (int k = 0; k < KK; ++k) r[k] = P[tid * KW + k];
+#pragma unroll
+        for (int w = 1; w < 8; ++w)
+#pragma unroll
+          for (int k = 0; k < KK; ++k) r[k] += P[(w * 32 + tid) * KW + k];
+      }
+      const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
+      const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
+      float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * KK;
+      const int co = co_base + tid;
+      if (co < a.Cout) {
+#pragma unroll
+        for (int k = 0; k < KK; ++k) dst[(size_t)co * KK + k] = r[k];
+      }
+    }
+  }
+
+// =====================================================================================================================================
+// conv3d_wino2d_d8 (round 5): the PLAIN-input forms (every dgrad, the plain forward) with NO register-staged global load in the main loop.
+// What bounds conv3d_wino2d_w8 is not its instruction count (profiles/r5_wino_r8_experiment.txt: a quarter fewer vector and half the
+// LDS instructions per MFMA changed nothing) but memory latency on a one-phase lead: removing the input and weight loads from the
+// main loop (wrong results, timing only) returns 11 % on w8 and 20 % on the register-generation form below (profiles/r5_wino_d8.txt).
+// A phase is 8-16 MFMAs per wave; the value a phase needs was requested one phase earlier, and the in-order VMEM counter ties the
+// L2-hit weight request to the HBM-latency input request issued before it. More lead needs registers the kernel does not have
+// (128 per wave, four waves per SIMD) -- unless the loads never touch registers:
+//  * input planes AND weights travel by LDS-DMA (global_load_lds_dwordx4), requested TWO phases before the phase that reads them:
+//    a ring of 4 staged plane chunks (6.5 KB each) and 3 weight slabs W[dz] (16 points x 8 input x 32 output channels = 16 KB each);
+//    the waits are counted (`s_waitcnt vmcnt(N)` with N = the DMA instructions of the current phase: everything older has landed),
+//    the barriers raw s_barrier (a __syncthreads() would drain the queue);
+//  * A fragments generated in registers from the staged plane (the r8 scheme: a wave's two points share the point row i and three
+//    adjacent window columns: 6 ds_read_b128 + 20 fp32 instructions per phase and lane, no transformed planes in LDS -- which is what
+//    makes room for the weight slabs); the staged layout [quad][row][even columns | odd columns] is conflict-free for those reads and
+//    is filled in lane order, as the DMA requires (slot = 51 x wave + lane; the slot picks the voxel);
+//  * weight fragments read from the slab right before their use (2 ds_read_b128 per use, consecutive lanes = consecutive 16 bytes);
+//  * MFMA operands swapped (A = weights, B = input) and the 16-byte output-transform exchange of r8.
+// The norm-prologue forms stay on conv3d_wino2d_w8 (a DMA cannot apply act(scale x + shift) on the way).
+__device__ const float wino_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+template <int FUSE>
+__global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_d8(WinoArgs a) {
+  constexpr int INMODE = MI355_IN_PLAIN;
+  constexpr int TZ = 2, TY = 8, TX = 16, HY = TY + 2;
+  constexpr int KC = 8;
+  constexpr int RS = 20;                                   // 16-byte groups per staged row: even columns 0..8 | pad | odd columns 10..18 | pad
+  constexpr int QS = HY * RS + 4;                          // groups per channel quad (+ 4: the two quads of a voxel land on different banks)
+  constexpr int XSF = 2 * QS * 4;                          // floats of one staged plane chunk (408 slots of 16 bytes = 8 waves x 51 lanes)
+  constexpr int WSF = 16 * 2 * 32 * 4;                     // floats of one weight slab
+  constexpr int PS = 36, PW = 2 * 32 * PS;                 // exchange: [wave][b][tile][32 channels + 4 pad]
+  static_assert(2 * QS == 8 * 51, "one DMA instruction per wave fills a staged plane chunk");
+  DYN_LDS(lds);
+  float* xs = lds;                                         // ring of 4 staged plane chunks
+  float* ws = lds + 4 * XSF;                               // 3 weight slabs
+  float* P = lds;                                          // epilogue: output-transform exchange (reuses everything)
+  (void)INMODE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6), half = lane >> 5, li = lane & 31;
+  // workgroup -> (channel tile, spatial tile): as conv3d_wino2d_w8 (an XCD gets a contiguous range of spatial tiles of one channel tile,
+  // walked in bricks of WINO_ZBRICK z tiles, then x, y)
+  int b = blockIdx.x, cot;
+  {
+    const int nct = a.coTiles, S = gridDim.x / nct, ng = nct < 8 && 8 % nct == 0 ? 8 / nct : 0;
+    if (ng > 0 && S % ng == 0) {
+      const int x = b & 7;
+      cot = x % nct;
+      b = (x / nct) * (S / ng) + (b >> 3);
+    } else {
+      cot = b % nct; b /= nct;
+    }
+  }
+  int tz;
+  if (a.tilesZ % WINO_ZBRICK == 0) {
+    const int zi = b % WINO_ZBRICK; b /= WINO_ZBRICK;
+    const int txi = b % a.tilesX; b /= a.tilesX;
+    const int tyi = b % a.tilesY; b /= a.tilesY;
+    const int zbk = b % (a.tilesZ / WINO_ZBRICK); b /= (a.tilesZ / WINO_ZBRICK);
+    tz = zbk * WINO_ZBRICK + zi;
+    b = (b * a.tilesY + tyi) * a.tilesX + txi;
+  } else {
+    const int txi = b % a.tilesX, r1 = b / a.tilesX;
+    const int tyi = r1 % a.tilesY, r2 = r1 / a.tilesY;
+    tz = r2 % a.tilesZ;
+    b = ((r2 / a.tilesZ) * a.tilesY + tyi) * a.tilesX + txi;
+  }
+  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+  const int tz0 = tz * TZ;
+  const int n = b;
+  const int co_base = cot * 32;
+
+  f32x16 acc[TZ][2];                                       // [output plane][q]
+#pragma unroll
+  for (int oz = 0; oz < TZ; ++oz)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[oz][q][r] = 0.f;
+
+  // ---- staging by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, LDS destination = wave base + 16 x lane) ----
+  // Input: slot s = 51 wave + lane (lane < 51) of a staged plane chunk [quad kq][row][20 positions]; the slot decides which (voxel, quad)
+  // the lane fetches. EVERY slot is written by every request: a pad, a voxel outside the image, the missing second quad of a last
+  // chunk (Cin % 8 == 4) and every slot of a plane outside the volume fetch 16 zero bytes (`wino_zero16`) -- the number of DMA
+  // instructions a wave issues per phase is a constant, which is what the counted waits below rely on.
+  const int slot = wave * 51 + lane;
+  const int skq = slot / QS, sr = slot % QS, srow = sr / RS, spos = sr % RS;
+  const int scol = spos < 9 ? 2 * spos : 2 * (spos - 10) + 1;
+  const bool sunit = lane < 51 && srow < HY && spos != 9 && spos != 19;
+  const int siy = ty0 - 1 + srow, six = tx0 - 1 + scol;
+  const bool sin = sunit && siy >= 0 && siy < a.H && six >= 0 && six < a.W;
+  const size_t xplane = (size_t)a.H * a.W * a.xld;
+  const float* xn = a.x + (size_t)n * a.D * xplane;        // sample n
+  const unsigned xoff = sin ? (unsigned)((siy * a.W + six) * a.xld + 4 * skq) * 4u : 0u;      // bytes inside the plane
+  const LaneMask m_in = LANE_MASK(sin), m_in0 = LANE_MASK(sin && skq == 0);
+  const float4* up4 = reinterpret_cast<const float4*>(a.up);
+  const int CQ = a.CinP / 4;
+  const size_t bstep = (size_t)CQ * a.CoutP;               // float4s between consecutive (point, dz) slabs of the weight pack
+  const unsigned boff = (unsigned)(half * a.CoutP + co_base + li) * 16u;    // bytes: this lane's (channel quad half, output channel)
+  // plane pz_ of the chunk at channel c0_ -> ring buffer pz_
+  auto dma_in = [&](int c0_, int pz_) {
+    const int iz = tz0 - 1 + pz_;
+    const int izc = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1);
+    const LaneMask m = iz >= 0 && iz < a.D ? (c0_ + 8 <= a.Cin ? m_in : m_in0) : (LaneMask)0;      // uniform
+    const char* real = reinterpret_cast<const char*>(xn + (size_t)izc * xplane + c0_) + xoff;
+    const char* src = LANE_IN_MASK(m) ? real : reinterpret_cast<const char*>(wino_zero16);
+    if (lane < 51) glds16(src, xs + pz_ * XSF + wave * (51 * 4));
+  };
+  // weights W[dz] of the chunk at c0_ -> slab dz: [point 16][quad half 2][output channel 32] x 16 bytes, unit u = 512 j + tid
+  auto dma_w = [&](int c0_, int dz) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float4* src = up4 + (size_t)(c0_ / 4) * a.CoutP + (size_t)((8 * j + wave) * 3 + dz) * bstep;      // uniform
+      glds16_uniform_base(src, boff, ws + dz * WSF + j * 2048 + wave * 256);
+    }
+  };
+  // A-fragment generation (as conv3d_wino2d_r8): wave constants (point row i, j half jh), the lane's two row addresses
+  const int pi = wave >> 1, jh = wave & 1;
+  const int ra = pi == 0 ? 0 : (pi == 2 ? 2 : 1), rb = pi == 2 ? 1 : (pi == 3 ? 3 : 2);
+  const float beta = pi == 1 ? 1.f : -1.f;
+  const int tty = li >> 3, ttx = li & 7;
+  const unsigned ga = (unsigned)((half * QS + (2 * tty + ra) * RS + ttx) * 4);      // floats
+  const unsigned gb = (unsigned)((half * QS + (2 * tty + rb) * RS + ttx) * 4);
+  struct AF { pkf2 v[2][2]; };                             // [q][channel pair]: 4 channels = two register pairs
+  // weight fragments from the slab: points p0 = 4 i + 3 jh (q = 0), p1 = 4 i + 1 + jh (q = 1); the lower of the two + this lane
+  const unsigned bfa = (unsigned)((4 * pi + 2 * jh) * 256 + lane * 4);      // floats
+  auto mfma_use = [&](const AF& f, const float4 (&bu)[2], f32x16 (&ac)[2]) {
+    ac[0] = MFMA_32x32x2(bu[0].x, f.v[0][0].x, ac[0]);
+    ac[1] = MFMA_32x32x2(bu[1].x, f.v[1][0].x, ac[1]);
+    ac[0] = MFMA_32x32x2(bu[0].y, f.v[0][0].y, ac[0]);
+    ac[1] = MFMA_32x32x2(bu[1].y, f.v[1][0].y, ac[1]);
+    ac[0] = MFMA_32x32x2(bu[0].z, f.v[0][1].x, ac[0]);
+    ac[1] = MFMA_32x32x2(bu[1].z, f.v[1][1].x, ac[1]);
+    ac[0] = MFMA_32x32x2(bu[0].w, f.v[0][1].y, ac[0]);
+    ac[1] = MFMA_32x32x2(bu[1].w, f.v[1][1].y, ac[1]);
+  };
+#ifdef MI355_EMU
+#define D8_PATTERN_ONE_USE()
+#define D8_PATTERN_TWO_USE()
+#else
+#define D8_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+  // One basic block per phase: the weight fragments and the four window reads of X0 / X2 first, their row sums and q0 (12 instructions)
+  // two MFMAs later, then the two reads of X1 (at most 16 registers of window values in flight), its row sum and q1 (8); in a two-use
+  // phase the second use's weight fragments are read behind the first use's MFMAs.
+#define D8_PATTERN_ONE_USE() do {                                                            \
+    D8_SGB(0x100, 6); D8_SGB(0x008, 2); D8_SGB(0x002, 12); D8_SGB(0x100, 2);                 \
+    D8_SGB(0x008, 2); D8_SGB(0x002, 8); D8_SGB(0x008, 4); } while (0)
+#define D8_PATTERN_TWO_USE() do {                                                            \
+    D8_SGB(0x100, 6); D8_SGB(0x008, 2); D8_SGB(0x002, 12); D8_SGB(0x100, 2);                 \
+    D8_SGB(0x008, 2); D8_SGB(0x002, 8); D8_SGB(0x100, 2); D8_SGB(0x008, 4); D8_SGB(0x008, 8); } while (0)
+#endif
+  // End of a phase that issued N DMA instructions per wave: everything issued in EARLIER phases has landed (the counter retires in
+  // order), this wave's LDS reads are done, barrier. A raw s_barrier: __syncthreads() would drain the DMA queue (vmcnt(0)).
+#define D8_PHASE_END(N) do { WAIT_VMCNT_LGKM0(N); RAW_BARRIER(); } while (0)
+  // The main loop, once per j half (a scalar branch around it), as in conv3d_wino2d_r8.
+  auto run = [&](auto jhc) {
+    constexpr int JH = decltype(jhc)::value;
+    auto gen = [&](AF& f, const float* xsb) {
+      constexpr int c0_ = JH ? 3 : 0, c1_ = JH ? 2 : 1, c2_ = JH ? 1 : 2;
+      constexpr int o0 = ((c0_ >> 1) + 10 * (c0_ & 1)) * 4, o1 = ((c1_ >> 1) + 10 * (c1_ & 1)) * 4, o2 = ((c2_ >> 1) + 10 * (c2_ & 1)) * 4;
+      const float4 a0 = *reinterpret_cast<const float4*>(xsb + ga + o0), b0 = *reinterpret_cast<const float4*>(xsb + gb + o0);
+      const float4 a2 = *reinterpret_cast<const float4*>(xsb + ga + o2), b2 = *reinterpret_cast<const float4*>(xsb + gb + o2);
+      const float s00 = fmaf(b0.x, beta, a0.x), s01 = fmaf(b0.y, beta, a0.y), s02 = fmaf(b0.z, beta, a0.z), s03 = fmaf(b0.w, beta, a0.w);
+      const float s20 = fmaf(b2.x, beta, a2.x), s21 = fmaf(b2.y, beta, a2.y), s22 = fmaf(b2.z, beta, a2.z), s23 = fmaf(b2.w, beta, a2.w);
+      const float4 a1 = *reinterpret_cast<const float4*>(xsb + ga + o1), b1 = *reinterpret_cast<const float4*>(xsb + gb + o1);
+      f.v[0][0] = make_pkf2(s00 - s20, s01 - s21); f.v[0][1] = make_pkf2(s02 - s22, s03 - s23);
+      const float s10 = fmaf(b1.x, beta, a1.x), s11 = fmaf(b1.y, beta, a1.y), s12 = fmaf(b1.z, beta, a1.z), s13 = fmaf(b1.w, beta, a1.w);
+      f.v[1][0] = JH ? make_pkf2(s10 - s20, s11 - s21) : make_pkf2(s10 + s20, s11 + s21);
+      f.v[1][1] = JH ? make_pkf2(s12 - s22, s13 - s23) : make_pkf2(s12 + s22, s13 + s23);
+      // the fragments are used by the NEXT phase only: without the pins hipcc sinks the arithmetic behind the barrier
+      PIN_IN_VGPR(f.v[0][0]); PIN_IN_VGPR(f.v[0][1]); PIN_IN_VGPR(f.v[1][0]); PIN_IN_VGPR(f.v[1][1]);
+    };
+    auto b_lds = [&](float4 (&bu)[2], int dz) {
+      const float* s = ws + dz * WSF + bfa;
+      bu[0] = *reinterpret_cast<const float4*>(s + (JH ? 256 : 0));
+      bu[1] = *reinterpret_cast<const float4*>(s + (JH ? 0 : 256));
+    };
+    // One channel chunk = 4 phases (input planes pz = 0..3 of the tile). Phase pz: MFMAs with the fragments f(pz) generated in phase
+    // pz - 1 | fragments of plane pz + 1 | DMA requests at the top: input plane pz + 3 (into the buffer whose plane was consumed in
+    // phase pz - 2) and the weights whose slab was last read in phase pz - 1 -- everything a phase reads was requested two phases
+    // earlier and is waited for at the end of the phase before (`D8_PHASE_END`).
+    auto chunk = [&](int c0, AF& fa, AF& fb) {
+      const bool more = c0 + KC < a.CinP;                  // another chunk follows (workgroup-uniform)
+      const int cn = more ? c0 + KC : c0;                  // after the last chunk the requests repeat it (never read)
+      float4 bu[2], bv[2];
+      // phase 0: plane 0 x W0 -> output plane 0 | fragments of plane 1 | requests: plane 3, W2
+      dma_in(c0, 3);
+      dma_w(c0, 2);
+      SCHED_BARRIER();
+      b_lds(bu, 0);
+      gen(fb, xs + XSF);
+      mfma_use(fa, bu, acc[0]);
+      D8_PATTERN_ONE_USE();
+      SCHED_BARRIER();
+      D8_PHASE_END(3);
+      // phase 1: plane 1 x W0 -> output plane 1, x W1 -> output plane 0 | fragments of plane 2 | requests: the next chunk's plane 0
+      dma_in(cn, 0);
+      SCHED_BARRIER();
+      b_lds(bu, 0);
+      gen(fa, xs + 2 * XSF);
+      mfma_use(fb, bu, acc[1]);
+      b_lds(bv, 1);
+      mfma_use(fb, bv, acc[0]);
+      D8_PATTERN_TWO_USE();
+      SCHED_BARRIER();
+      D8_PHASE_END(1);
+      // phase 2: plane 2 x W1 -> output plane 1, x W2 -> output plane 0 | fragments of plane 3 | requests: its plane 1, its W0
+      dma_in(cn, 1);
+      dma_w(cn, 0);
+      SCHED_BARRIER();
+      b_lds(bu, 1);
+      gen(fb, xs + 3 * XSF);
+      mfma_use(fa, bu, acc[1]);
+      b_lds(bv, 2);
+      mfma_use(fa, bv, acc[0]);
+      D8_PATTERN_TWO_USE();
+      SCHED_BARRIER();
+      D8_PHASE_END(3);
+      // phase 3: plane 3 x W2 -> output plane 1 | fragments of the next chunk's plane 0 | requests: its plane 2, its W1
+      dma_in(cn, 2);
+      dma_w(cn, 1);
+      SCHED_BARRIER();
+      b_lds(bu, 2);
+      gen(fa, xs);
+      mfma_use(fb, bu, acc[1]);
+      D8_PATTERN_ONE_USE();
+      SCHED_BARRIER();
+      D8_PHASE_END(3);
+    };
+    AF fA, fB;
+    gen(fA, xs);
+    for (int c0 = 0; c0 < a.CinP; c0 += KC) chunk(c0, fA, fB);
+  };
+
+  // prologue: planes 0, 1, 2 and W0, W1 of the first chunk requested together and waited for
+  dma_in(0, 0); dma_in(0, 1); dma_in(0, 2);
+  dma_w(0, 0); dma_w(0, 1);
+  D8_PHASE_END(0);
+  if (jh) run(std::integral_constant<int, 1>()); else run(std::integral_constant<int, 0>());
+  D8_PHASE_END(0);                                         // the requests of the last phases (never read) have landed: the exchange reuses the LDS
+
+  // ---- output transform Y = A^T M A, bias / residual / dropout scale, store ----
+  // In-wave over the wave's two j (scalar branch on the j half), written to the exchange P[wave][b][tile][co] as 16-byte runs of the 4
+  // consecutive channels an accumulator quad holds; across the waves over i on the way out, voxel-major as in conv3d_wino2d_w8.
+  const int coq = tid & 7, ea = (wave >> 1) & 1;           // voxel rows: y = (tid >> 7) + 4 s -> a = y & 1 is wave-uniform
+  const int co4 = co_base + 4 * coq;
+  float bs[4], cs[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool cv = co4 + e < a.Cout;
+    bs[e] = cv && a.bias ? a.bias[co4 + e] : 0.f;
+    cs[e] = cv && a.out_chscale ? a.out_chscale[(size_t)n * a.Cout + co4 + e] : 1.f;
+  }
+  const bool q_in = co4 < a.Cout, q_full = co4 + 4 <= a.Cout;      // any / all four channels of the quad exist
+  float K0[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  float gsc[4], gsh[4], gmean[4], grstd[4];
+  int cnt = 0;
+  if constexpr (FUSE == 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int coc = co4 + e < a.Cout ? co4 + e : a.Cout - 1;
+      const int grp = coc / (a.Cout / a.g.ggroups);
+      gsc[e] = a.g.gscale[(size_t)n * a.Cout + coc]; gsh[e] = a.g.gshift[(size_t)n * a.Cout + coc];
+      gmean[e] = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd[e] = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
+    }
+  }
+  float* pw = P + wave * PW + li * PS + 4 * half;          // this lane's partials: + b * 32 * PS + 8 * g for accumulator quad g
+  auto ld4 = [&](const float* base, size_t off, float (&v)[4]) {          // 4 channels of a voxel; scalar where 16-byte access is not legal
+    if (a.vec4) {
+      const float4 t = *reinterpret_cast<const float4*>(base + off);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = co4 + e < a.Cout ? base[off + e] : 0.f;
+    }
+  };
+#pragma unroll
+  for (int oz = 0; oz < TZ; ++oz) {
+    if (oz > 0) __syncthreads();                           // the previous plane's exchange has been read (the main loop ends on a barrier)
+    if (jh) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x16& m0 = acc[oz][0]; const f32x16& m1 = acc[oz][1];
+        *reinterpret_cast<float4*>(pw + 8 * g) = make_float4(m1[4 * g], m1[4 * g + 1], m1[4 * g + 2], m1[4 * g + 3]);
+        *reinterpret_cast<float4*>(pw + 32 * PS + 8 * g) =
+            make_float4(m0[4 * g] - m1[4 * g], m0[4 * g + 1] - m1[4 * g + 1], m0[4 * g + 2] - m1[4 * g + 2], m0[4 * g + 3] - m1[4 * g + 3]);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x16& m0 = acc[oz][0]; const f32x16& m1 = acc[oz][1];
+        *reinterpret_cast<float4*>(pw + 8 * g) =
+            make_float4(m0[4 * g] + m1[4 * g], m0[4 * g + 1] + m1[4 * g + 1], m0[4 * g + 2] + m1[4 * g + 2], m0[4 * g + 3] + m1[4 * g + 3]);
+        *reinterpret_cast<float4*>(pw + 32 * PS + 8 * g) = make_float4(m1[4 * g], m1[4 * g + 1], m1[4 * g + 2], m1[4 * g + 3]);
+      }
+    }
+    // reads that do not depend on the exchange go out before the barrier: the normalised tensor (FUSE 2) and the residual
+    const int z = tz0 + oz, zc = z < a.D ? z : a.D - 1;
+    float gxv[2][4], rsv[2][4];
+    size_t vox[2];
+    bool vin[2];
+#pragma unroll
+    for (int sI = 0; sI < 2; ++sI) {
+      const int v = (tid >> 3) + 64 * sI;
+      const int yy = ty0 + (v >> 4), xx = tx0 + (v & 15);
+      vin[sI] = q_in && z < a.D && yy < a.H && xx < a.W;
+      const int yc = yy < a.H ? yy : a.H - 1, xc = xx < a.W ? xx : a.W - 1;
+      vox[sI] = (((size_t)n * a.D + zc) * a.H + yc) * a.W + xc;
+      const int cq = q_in ? co4 : 0;                       // a quad beyond Cout reads (and drops) the first one
+      if constexpr (FUSE == 2) ld4(a.g.gx, vox[sI] * a.g.gxld + cq, gxv[sI]);
+      if (a.res) ld4(a.res, vox[sI] * a.resld + cq, rsv[sI]);
+      else { rsv[sI][0] = rsv[sI][1] = rsv[sI][2] = rsv[sI][3] = 0.f; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sI = 0; sI < 2; ++sI) {
+      const int v = (tid >> 3) + 64 * sI;
+      const int tile = ((v >> 5) << 3) + ((v & 15) >> 1), eb = v & 1;      // (y >> 1) * 8 + (x >> 1); b = x & 1
+      const float* pz = P + (eb * 32 + tile) * PS + 4 * coq;      // wave w at + w * PW floats
+      auto rd = [&](int w) { return *reinterpret_cast<const float4*>(pz + w * PW); };
+      // across the waves: row i of the point grid = waves 2 i, 2 i + 1; A^T rows over i: (1, 1, 1, 0) and (0, 1, -1, -1)
+      float4 o;
+      if (ea == 0) {
+        const float4 q0 = rd(0), q1 = rd(1), q2 = rd(2), q3 = rd(3), q4 = rd(4), q5 = rd(5);
+        o.x = (q0.x + q1.x) + (q2.x + q3.x) + (q4.x + q5.x); o.y = (q0.y + q1.y) + (q2.y + q3.y) + (q4.y + q5.y);
+        o.z = (q0.z + q1.z) + (q2.z + q3.z) + (q4.z + q5.z); o.w = (q0.w + q1.w) + (q2.w + q3.w) + (q4.w + q5.w);
+      } else {
+        const float4 q2 = rd(2), q3 = rd(3), q4 = rd(4), q5 = rd(5), q6 = rd(6), q7 = rd(7);
+        o.x = (q2.x + q3.x) - (q4.x + q5.x) - (q6.x + q7.x); o.y = (q2.y + q3.y) - (q4.y + q5.y) - (q6.y + q7.y);
+        o.z = (q2.z + q3.z) - (q4.z + q5.z) - (q6.z + q7.z); o.w = (q2.w + q3.w) - (q4.w + q5.w) - (q6.w + q7.w);
+      }
+      if (!vin[sI]) continue;
+      float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = (ov[e] + bs[e] + rsv[sI][e]) * cs[e];
+      float* yp = a.y + vox[sI] * a.yld + co4;
+      if (a.vec4 && q_full) *reinterpret_cast<float4*>(yp) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (co4 + e < a.Cout) yp[e] = ov[e];
+      }
+      if constexpr (FUSE == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (cnt == 0) K0[e] = ov[e];
+          const float t = ov[e] - K0[e];
+          s0[e] += t; s1[e] += t * t;
+        }
+        ++cnt;
+      } else if constexpr (FUSE == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xv = gxv[sI][e];
+          const float u = xv * gsc[e] + gsh[e];
+          const float du = u > 0.f ? ov[e] : ov[e] * a.g.gslope;
+          s0[e] += du; s1[e] += du * ((xv - gmean[e]) * grstd[e]);
+        }
+      }
+    }
+  }
+  if constexpr (FUSE != 0) wino_fuse_records<FUSE>(a, P, tid, lane, wave, coq, co_base, n, tz0, ty0, tx0, cnt, K0, s0, s1);
+}
+#undef D8_SGB
+#undef D8_PATTERN_ONE_USE
+#undef D8_PATTERN_TWO_USE
+#undef D8_PHASE_END
+
 // ---- filter transform: U[(i,j)][dz][ci][co] = sum_{dy,dx} G[i][dy] G[j][dx] w[...] (pack_values.h: pack_wino_item) ----
 __global__ void wino_pack_weight_kernel(const float* w, float* up, int cout, int cin, int coutP, int cinP, int mode) {
   const size_t items = (size_t)3 * (cinP / 4) * coutP * 4;          // one per (dz, ci, co): 16 points each
@@ -635,6 +1089,16 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
   const int lds_bytes = (8 * 2 * 32 * 32 + 3 * a.CinP) * (int)sizeof(float);      // exchange area (the main loop's buffers live inside it) + norm prologue
   const dim3 grid((unsigned)blocks), blk(512);
+#if WINO_D8
+  if (d->in_mode == MI355_IN_PLAIN) {
+    // conv3d_wino2d_d8: 4 staged plane chunks + 3 weight slabs (75 264 bytes) | the padded exchange (73 728)
+    const int lds_d8 = (4 * 1632 + 3 * 4096) * (int)sizeof(float);
+#define D8_LAUNCH(FU) do { SET_MAX_DYN_LDS((conv3d_wino2d_d8<FU>), lds_d8); LAUNCH((conv3d_wino2d_d8<FU>), grid, blk, lds_d8, stream, a); } while (0)
+    if (a.g.mom) D8_LAUNCH(1); else if (a.g.gnb) D8_LAUNCH(2); else D8_LAUNCH(0);
+#undef D8_LAUNCH
+    return LAUNCH_CHECK();
+  }
+#endif
 #define WINO_LAUNCH(IM, FU)                                                                          \
   do { SET_MAX_DYN_LDS((conv3d_wino2d_w8<IM, FU>), lds_bytes);                                         \
        LAUNCH((conv3d_wino2d_w8<IM, FU>), grid, blk, lds_bytes, stream, a); } while (0)

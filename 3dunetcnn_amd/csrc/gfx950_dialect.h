@@ -29,6 +29,35 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ... and in the architectural half: accumulators of a kernel whose AGPRs are full of pinned operands (left to itself hipcc may put the
 // MFMA results there too and then spills the operands)
 #define PIN_IN_VGPR(v) asm volatile("" : "+v"(v))
+// a per-lane condition as a 64-bit wave mask in scalar registers, and back: `LANE_IN_MASK(m)` is this lane's bit of a UNIFORM mask, used
+// directly as the select / branch condition (no vector instruction tests it)
+typedef unsigned long long LaneMask;
+#define LANE_MASK(cond) __builtin_amdgcn_ballot_w64(cond)
+#define LANE_IN_MASK(m) __builtin_amdgcn_inverse_ballot_w64(m)
+// a wave-uniform value (pointer, offset) kept in scalar registers from here on: what is added to it afterwards stays a lane offset
+#define PIN_IN_SGPR(v) asm volatile("" : "+s"(v))
+// LDS-DMA, 16 bytes per lane: LDS[lds_wave_base + 16 * lane] = *(16 bytes at this lane's global address); no register is written, the
+// instruction counts on the VM counter like a load (global_load_lds_dwordx4, LDS base in M0, wave-uniform). Issued from inline asm ON
+// PURPOSE: hipcc cannot tell which LDS bytes a DMA writes once the addresses are computed (one dynamic array, run-time offsets) and puts
+// `s_waitcnt vmcnt(0)` in front of the next ds_read of ANY address -- every request would be waited for at once. Hidden from the
+// compiler, the requests are ordered by the counted waits the kernel writes itself (WAIT_VMCNT_LGKM0) -- which therefore must also
+// cover the compiler's own view: no ordinary global load may be outstanding across such a DMA's lifetime that hipcc waits for by count.
+__device__ __forceinline__ unsigned lds_byte_address(const float* p) {
+  return (unsigned)reinterpret_cast<unsigned long long>((const __attribute__((address_space(3))) float*)p);
+}
+__device__ __forceinline__ void glds16(const void* src, float* lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte_address(lds_wave_base));
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(m0v) : "memory");
+}
+// ... from (uniform base in scalar registers) + (32-bit lane byte offset)
+__device__ __forceinline__ void glds16_uniform_base(const void* ubase, unsigned lane_off, float* lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte_address(lds_wave_base));
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_off), "s"(ubase), "s"(m0v) : "memory");
+}
+// s_waitcnt vmcnt(n) lgkmcnt(0): at most n of this wave's VMEM instructions (loads, LDS-DMA) outstanding -- they retire in order -- and
+// its LDS instructions done; s_barrier without the fence of __syncthreads() (which waits vmcnt(0) while a DMA is in flight)
+#define WAIT_VMCNT_LGKM0(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x0070)
+#define RAW_BARRIER() __builtin_amdgcn_s_barrier()
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+0..7] and B[k=8*(l>>5)+0..7][j=l&31] as 8 packed bf16
 // (16 bytes, carried here as uint4); same C/D map as the f32 form. 32 cycles per SIMD = 16x the f32 MFMA rate.

@@ -307,5 +307,16 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetc
 #define ONE_WAVE_PER_SIMD
 #define PIN_IN_AGPR(v) ((void)0)
 #define PIN_IN_VGPR(v) ((void)0)
+#define PIN_IN_SGPR(v) ((void)0)
+typedef unsigned long long LaneMask;
+static inline LaneMask emu_lane_mask(bool c) { LaneMask m = 0; for (int l = 0; l < 64; ++l) m |= (LaneMask)(emu_shfl((int)c, l) & 1) << l; return m; }
+#define LANE_MASK(cond) emu_lane_mask(cond)
+#define LANE_IN_MASK(m) ((((m) >> (emu::flat_tid() % 64)) & 1ull) != 0)
+// LDS-DMA: synchronous here (the data lands at once: a buffer restaged while another fiber still reads it shows up as a wrong result; a
+// read BEFORE the counted wait does not -- that half of the protocol is checked on the GPU only)
+static inline void glds16(const void* src, float* lds_wave_base) { memcpy(lds_wave_base + 4 * (emu::flat_tid() % 64), src, 16); }
+static inline void glds16_uniform_base(const void* ubase, unsigned lane_off, float* lds_wave_base) { glds16(reinterpret_cast<const char*>(ubase) + lane_off, lds_wave_base); }
+#define WAIT_VMCNT_LGKM0(n) ((void)0)
+#define RAW_BARRIER() __syncthreads()
 typedef uint4 u32x4_t;
 #define SLEEP_64CLK(n) do {} while (0)
