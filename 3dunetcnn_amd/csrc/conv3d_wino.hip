@@ -674,9 +674,8 @@ __device__ __forceinline__ void wino_fuse_records(const WinoArgs& a, float* P, i
 //  * MFMA operands swapped (A = weights, B = input) and the 16-byte output-transform exchange of r8.
 // The norm-prologue forms stay on conv3d_wino2d_w8 (a DMA cannot apply act(scale x + shift) on the way).
 __device__ const float wino_zero16[4] = {0.f, 0.f, 0.f, 0.f};
-template <int FUSE>
+template <int INMODE, int FUSE>
 __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_d8(WinoArgs a) {
-  constexpr int INMODE = MI355_IN_PLAIN;
   constexpr int TZ = 2, TY = 8, TX = 16, HY = TY + 2;
   constexpr int KC = 8;
   constexpr int RS = 20;                                   // 16-byte groups per staged row: even columns 0..8 | pad | odd columns 10..18 | pad
@@ -689,7 +688,7 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_d8(Wi
   float* xs = lds;                                         // ring of 4 staged plane chunks
   float* ws = lds + 4 * XSF;                               // 3 weight slabs
   float* P = lds;                                          // epilogue: output-transform exchange (reuses everything)
-  (void)INMODE;
+  float* prm = lds + 4 * XSF + 3 * WSF;                    // norm prologue of this sample: scale | shift | slope, CinP each
   const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6), half = lane >> 5, li = lane & 31;
   // workgroup -> (channel tile, spatial tile): as conv3d_wino2d_w8 (an XCD gets a contiguous range of spatial tiles of one channel tile,
   // walked in bricks of WINO_ZBRICK z tiles, then x, y)
@@ -737,7 +736,7 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_d8(Wi
   // the lane fetches. EVERY slot is written by every request: a pad, a voxel outside the image, the missing second quad of a last
   // chunk (Cin % 8 == 4) and every slot of a plane outside the volume fetch 16 zero bytes (`wino_zero16`) -- the number of DMA
   // instructions a wave issues per phase is a constant, which is what the counted waits below rely on.
-  const int slot = wave * 51 + lane;
+  const int slot = wave * 51 + (lane < 50 ? lane : 50);     // lanes 51..63 of a wave request nothing
   const int skq = slot / QS, sr = slot % QS, srow = sr / RS, spos = sr % RS;
   const int scol = spos < 9 ? 2 * spos : 2 * (spos - 10) + 1;
   const bool sunit = lane < 51 && srow < HY && spos != 9 && spos != 19;
@@ -757,15 +756,50 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_d8(Wi
     const int izc = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1);
     const LaneMask m = iz >= 0 && iz < a.D ? (c0_ + 8 <= a.Cin ? m_in : m_in0) : (LaneMask)0;      // uniform
     const char* real = reinterpret_cast<const char*>(xn + (size_t)izc * xplane + c0_) + xoff;
+#if WINO_ABL & 64
+    const char* src = reinterpret_cast<const char*>(wino_zero16); (void)real; (void)m;      // timing only: every lane fetches the same 16 bytes
+#else
     const char* src = LANE_IN_MASK(m) ? real : reinterpret_cast<const char*>(wino_zero16);
+#endif
+#if !(WINO_ABL & 1)
     if (lane < 51) glds16(src, xs + pz_ * XSF + wave * (51 * 4));
+#else
+    (void)src;
+#endif
+  };
+  // Norm prologue (INMODE = MI355_IN_AFFINE_ACT): a DMA cannot apply act(scale x + shift) on the way, so the lane that requested a slot
+  // rewrites it in place once its request has landed (its own counted wait at the end of the previous phase: no barrier needed for its
+  // own slot), at the bottom of the phase before the one whose fragment generation reads the plane -- behind the wave's last MFMA,
+  // while the matrix pipe drains and the wave's requests of this phase are still on their way; the barrier at the end of the phase
+  // publishes the result. Slots that
+  // fetched zeros (pads, halo outside the image) are left alone: the padding of the ACTIVATED tensor is zero.
+  auto activate = [&](int c0_, int pz_) {
+    if (INMODE != MI355_IN_AFFINE_ACT) return;
+    const int iz = tz0 - 1 + pz_;
+    const LaneMask m = iz >= 0 && iz < a.D ? (c0_ + 8 <= a.Cin ? m_in : m_in0) : (LaneMask)0;      // as in dma_in
+    if (LANE_IN_MASK(m)) {                                 // (m has no bit for lanes 51..63)
+      const int c = c0_ + 4 * skq;
+      float* p = xs + pz_ * XSF + slot * 4;
+      float4 v = *reinterpret_cast<const float4*>(p);
+      const float4 sc = *reinterpret_cast<const float4*>(prm + c), sh = *reinterpret_cast<const float4*>(prm + a.CinP + c);
+      const float4 sl = *reinterpret_cast<const float4*>(prm + 2 * a.CinP + c);
+      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+      v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
+      *reinterpret_cast<float4*>(p) = v;
+    }
   };
   // weights W[dz] of the chunk at c0_ -> slab dz: [point 16][quad half 2][output channel 32] x 16 bytes, unit u = 512 j + tid
   auto dma_w = [&](int c0_, int dz) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const float4* src = up4 + (size_t)(c0_ / 4) * a.CoutP + (size_t)((8 * j + wave) * 3 + dz) * bstep;      // uniform
+#if WINO_ABL & 128
+      glds16_uniform_base(wino_zero16, 0u, ws + dz * WSF + j * 2048 + wave * 256); (void)src;      // timing only
+#elif !(WINO_ABL & 2)
       glds16_uniform_base(src, boff, ws + dz * WSF + j * 2048 + wave * 256);
+#else
+      (void)src;
+#endif
     }
   };
   // A-fragment generation (as conv3d_wino2d_r8): wave constants (point row i, j half jh), the lane's two row addresses
@@ -776,119 +810,169 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_d8(Wi
   const unsigned ga = (unsigned)((half * QS + (2 * tty + ra) * RS + ttx) * 4);      // floats
   const unsigned gb = (unsigned)((half * QS + (2 * tty + rb) * RS + ttx) * 4);
   struct AF { pkf2 v[2][2]; };                             // [q][channel pair]: 4 channels = two register pairs
-  // weight fragments from the slab: points p0 = 4 i + 3 jh (q = 0), p1 = 4 i + 1 + jh (q = 1); the lower of the two + this lane
+  // weight fragments from the slab: points p0 = 4 i + 3 jh (q = 0), p1 = 4 i + 1 + jh (q = 1); `bfa` = the lower of the two + this lane
   const unsigned bfa = (unsigned)((4 * pi + 2 * jh) * 256 + lane * 4);      // floats
-  auto mfma_use = [&](const AF& f, const float4 (&bu)[2], f32x16 (&ac)[2]) {
-    ac[0] = MFMA_32x32x2(bu[0].x, f.v[0][0].x, ac[0]);
-    ac[1] = MFMA_32x32x2(bu[1].x, f.v[1][0].x, ac[1]);
-    ac[0] = MFMA_32x32x2(bu[0].y, f.v[0][0].y, ac[0]);
-    ac[1] = MFMA_32x32x2(bu[1].y, f.v[1][0].y, ac[1]);
-    ac[0] = MFMA_32x32x2(bu[0].z, f.v[0][1].x, ac[0]);
-    ac[1] = MFMA_32x32x2(bu[1].z, f.v[1][1].x, ac[1]);
-    ac[0] = MFMA_32x32x2(bu[0].w, f.v[0][1].y, ac[0]);
-    ac[1] = MFMA_32x32x2(bu[1].w, f.v[1][1].y, ac[1]);
-  };
+  // MFMA pair e of a use: the wave's two points x input channels (e, e + 4 by lane half) -- independent accumulators, issued back to back
+#define D8_MF0(f, b, ac) do { ac[0] = MFMA_32x32x2(b[0].x, f.v[0][0].x, ac[0]); ac[1] = MFMA_32x32x2(b[1].x, f.v[1][0].x, ac[1]); } while (0)
+#define D8_MF1(f, b, ac) do { ac[0] = MFMA_32x32x2(b[0].y, f.v[0][0].y, ac[0]); ac[1] = MFMA_32x32x2(b[1].y, f.v[1][0].y, ac[1]); } while (0)
+#define D8_MF2(f, b, ac) do { ac[0] = MFMA_32x32x2(b[0].z, f.v[0][1].x, ac[0]); ac[1] = MFMA_32x32x2(b[1].z, f.v[1][1].x, ac[1]); } while (0)
+#define D8_MF3(f, b, ac) do { ac[0] = MFMA_32x32x2(b[0].w, f.v[0][1].y, ac[0]); ac[1] = MFMA_32x32x2(b[1].w, f.v[1][1].y, ac[1]); } while (0)
 #ifdef MI355_EMU
-#define D8_PATTERN_ONE_USE()
-#define D8_PATTERN_TWO_USE()
+#define D8_SGB(mask, n)
 #else
 #define D8_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-  // One basic block per phase: the weight fragments and the four window reads of X0 / X2 first, their row sums and q0 (12 instructions)
-  // two MFMAs later, then the two reads of X1 (at most 16 registers of window values in flight), its row sum and q1 (8); in a two-use
-  // phase the second use's weight fragments are read behind the first use's MFMAs.
-#define D8_PATTERN_ONE_USE() do {                                                            \
-    D8_SGB(0x100, 6); D8_SGB(0x008, 2); D8_SGB(0x002, 12); D8_SGB(0x100, 2);                 \
-    D8_SGB(0x008, 2); D8_SGB(0x002, 8); D8_SGB(0x008, 4); } while (0)
-#define D8_PATTERN_TWO_USE() do {                                                            \
-    D8_SGB(0x100, 6); D8_SGB(0x008, 2); D8_SGB(0x002, 12); D8_SGB(0x100, 2);                 \
-    D8_SGB(0x008, 2); D8_SGB(0x002, 8); D8_SGB(0x100, 2); D8_SGB(0x008, 4); D8_SGB(0x008, 8); } while (0)
 #endif
   // End of a phase that issued N DMA instructions per wave: everything issued in EARLIER phases has landed (the counter retires in
-  // order), this wave's LDS reads are done, barrier. A raw s_barrier: __syncthreads() would drain the DMA queue (vmcnt(0)).
+  // order), this wave's LDS accesses are done, barrier. A raw s_barrier: __syncthreads() would drain the DMA queue (vmcnt(0)).
+#if WINO_ABL & 32
+#define D8_PHASE_END(N) do { WAIT_VMCNT_LGKM0((N) ? 63 : 0); RAW_BARRIER(); } while (0)      // timing only: never waits for a DMA inside the loop
+#else
 #define D8_PHASE_END(N) do { WAIT_VMCNT_LGKM0(N); RAW_BARRIER(); } while (0)
+#endif
   // The main loop, once per j half (a scalar branch around it), as in conv3d_wino2d_r8.
   auto run = [&](auto jhc) {
     constexpr int JH = decltype(jhc)::value;
-    auto gen = [&](AF& f, const float* xsb) {
-      constexpr int c0_ = JH ? 3 : 0, c1_ = JH ? 2 : 1, c2_ = JH ? 1 : 2;
-      constexpr int o0 = ((c0_ >> 1) + 10 * (c0_ & 1)) * 4, o1 = ((c1_ >> 1) + 10 * (c1_ & 1)) * 4, o2 = ((c2_ >> 1) + 10 * (c2_ & 1)) * 4;
-      const float4 a0 = *reinterpret_cast<const float4*>(xsb + ga + o0), b0 = *reinterpret_cast<const float4*>(xsb + gb + o0);
-      const float4 a2 = *reinterpret_cast<const float4*>(xsb + ga + o2), b2 = *reinterpret_cast<const float4*>(xsb + gb + o2);
-      const float s00 = fmaf(b0.x, beta, a0.x), s01 = fmaf(b0.y, beta, a0.y), s02 = fmaf(b0.z, beta, a0.z), s03 = fmaf(b0.w, beta, a0.w);
-      const float s20 = fmaf(b2.x, beta, a2.x), s21 = fmaf(b2.y, beta, a2.y), s22 = fmaf(b2.z, beta, a2.z), s23 = fmaf(b2.w, beta, a2.w);
-      const float4 a1 = *reinterpret_cast<const float4*>(xsb + ga + o1), b1 = *reinterpret_cast<const float4*>(xsb + gb + o1);
-      f.v[0][0] = make_pkf2(s00 - s20, s01 - s21); f.v[0][1] = make_pkf2(s02 - s22, s03 - s23);
-      const float s10 = fmaf(b1.x, beta, a1.x), s11 = fmaf(b1.y, beta, a1.y), s12 = fmaf(b1.z, beta, a1.z), s13 = fmaf(b1.w, beta, a1.w);
-      f.v[1][0] = JH ? make_pkf2(s10 - s20, s11 - s21) : make_pkf2(s10 + s20, s11 + s21);
-      f.v[1][1] = JH ? make_pkf2(s12 - s22, s13 - s23) : make_pkf2(s12 + s22, s13 + s23);
-      // the fragments are used by the NEXT phase only: without the pins hipcc sinks the arithmetic behind the barrier
-      PIN_IN_VGPR(f.v[0][0]); PIN_IN_VGPR(f.v[0][1]); PIN_IN_VGPR(f.v[1][0]); PIN_IN_VGPR(f.v[1][1]);
-    };
     auto b_lds = [&](float4 (&bu)[2], int dz) {
-      const float* s = ws + dz * WSF + bfa;
-      bu[0] = *reinterpret_cast<const float4*>(s + (JH ? 256 : 0));
-      bu[1] = *reinterpret_cast<const float4*>(s + (JH ? 0 : 256));
+#if WINO_ABL & 4
+      bu[0] = make_float4((float)dz, 0.5f, 0.25f, 1.f); bu[1] = make_float4(0.25f, (float)dz, 0.5f, 2.f);
+#else
+      const float* sp = ws + dz * WSF + bfa;
+      bu[JH ? 1 : 0] = *reinterpret_cast<const float4*>(sp);
+      bu[JH ? 0 : 1] = *reinterpret_cast<const float4*>(sp + 256);
+#endif
     };
-    // One channel chunk = 4 phases (input planes pz = 0..3 of the tile). Phase pz: MFMAs with the fragments f(pz) generated in phase
-    // pz - 1 | fragments of plane pz + 1 | DMA requests at the top: input plane pz + 3 (into the buffer whose plane was consumed in
-    // phase pz - 2) and the weights whose slab was last read in phase pz - 1 -- everything a phase reads was requested two phases
-    // earlier and is waited for at the end of the phase before (`D8_PHASE_END`).
-    auto chunk = [&](int c0, AF& fa, AF& fb) {
+    // Fragments of the next plane, interleaved with the first two MFMA pairs of the phase (one scheduling region): the four window reads of
+    // X0 / X2 go out first, their row sums and q0 (12 instructions) behind the first pair, then the two reads of X1 (at most 16
+    // registers of window values in flight), its row sum and q1 (8) behind the second pair.
+#define D8_GEN_WITH_PAIRS_01(fnext, xsb, fcur, b, ac) do {                                                                         \
+      constexpr int c0_ = JH ? 3 : 0, c1_ = JH ? 2 : 1, c2_ = JH ? 1 : 2;                                                            \
+      constexpr int o0 = ((c0_ >> 1) + 10 * (c0_ & 1)) * 4, o1 = ((c1_ >> 1) + 10 * (c1_ & 1)) * 4, o2 = ((c2_ >> 1) + 10 * (c2_ & 1)) * 4;  \
+      const float* xb_ = (xsb);                                                                                                      \
+      const float4 a0 = *reinterpret_cast<const float4*>(xb_ + ga + o0), b0 = *reinterpret_cast<const float4*>(xb_ + gb + o0);       \
+      const float4 a2 = *reinterpret_cast<const float4*>(xb_ + ga + o2), b2 = *reinterpret_cast<const float4*>(xb_ + gb + o2);       \
+      D8_MF0(fcur, b, ac);                                                                                                           \
+      const float s00 = fmaf(b0.x, beta, a0.x), s01 = fmaf(b0.y, beta, a0.y), s02 = fmaf(b0.z, beta, a0.z), s03 = fmaf(b0.w, beta, a0.w);  \
+      const float s20 = fmaf(b2.x, beta, a2.x), s21 = fmaf(b2.y, beta, a2.y), s22 = fmaf(b2.z, beta, a2.z), s23 = fmaf(b2.w, beta, a2.w);  \
+      fnext.v[0][0] = make_pkf2(s00 - s20, s01 - s21); fnext.v[0][1] = make_pkf2(s02 - s22, s03 - s23);                              \
+      const float4 a1 = *reinterpret_cast<const float4*>(xb_ + ga + o1), b1 = *reinterpret_cast<const float4*>(xb_ + gb + o1);       \
+      D8_MF1(fcur, b, ac);                                                                                                           \
+      const float s10 = fmaf(b1.x, beta, a1.x), s11 = fmaf(b1.y, beta, a1.y), s12 = fmaf(b1.z, beta, a1.z), s13 = fmaf(b1.w, beta, a1.w);  \
+      fnext.v[1][0] = JH ? make_pkf2(s10 - s20, s11 - s21) : make_pkf2(s10 + s20, s11 + s21);                                        \
+      fnext.v[1][1] = JH ? make_pkf2(s12 - s22, s13 - s23) : make_pkf2(s12 + s22, s13 + s23);                                        \
+      /* the fragments are used by the NEXT phase only: without the pins hipcc sinks the arithmetic behind the barrier */            \
+      PIN_IN_VGPR(fnext.v[0][0]); PIN_IN_VGPR(fnext.v[0][1]); PIN_IN_VGPR(fnext.v[1][0]); PIN_IN_VGPR(fnext.v[1][1]);                \
+      D8_SGB(0x100, 4); D8_SGB(0x008, 2); D8_SGB(0x002, 12); D8_SGB(0x100, 2); D8_SGB(0x008, 2); D8_SGB(0x002, 8);                   \
+      SCHED_BARRIER();                                                                                                               \
+    } while (0)
+    // One channel chunk = 4 phases (input planes pz = 0..3 of the tile). Phase pz:
+    //   MFMAs with the fragments f(pz) generated in phase pz - 1 | fragments of plane pz + 1 | the DMA requests BETWEEN the MFMA pairs
+    //   (issuing one occupies the wave for 60-190 cycles: in front of the MFMAs, as the first version had them, that was 16 % of the
+    //   kernel -- profiles/r5_wino_d8.txt; behind a pair it overlaps with the 128 cycles the matrix pipe spends on that pair) |
+    //   [plane pz + 2 activated in place] | the weight fragments of the next phase's first use read at the bottom (`bu`: in registers when
+    //   the phase opens), those of a second use (`bv`) behind the first use's MFMAs.
+    // Requests: input plane pz of the NEXT chunk (into the buffer whose plane was consumed in phase pz - 1); its W0 in phase 0, W1
+    // in phase 2, W2 in phase 3 (the slab's fragments were last read one phase earlier) -- everything a phase reads from LDS was
+    // requested at least two phases earlier and waited for at the end of the phase before.
+    auto chunk = [&](int c0, float4 (&bu)[2], AF& fa, AF& fb) {
       const bool more = c0 + KC < a.CinP;                  // another chunk follows (workgroup-uniform)
       const int cn = more ? c0 + KC : c0;                  // after the last chunk the requests repeat it (never read)
-      float4 bu[2], bv[2];
-      // phase 0: plane 0 x W0 -> output plane 0 | fragments of plane 1 | requests: plane 3, W2
-      dma_in(c0, 3);
-      dma_w(c0, 2);
-      SCHED_BARRIER();
-      b_lds(bu, 0);
-      gen(fb, xs + XSF);
-      mfma_use(fa, bu, acc[0]);
-      D8_PATTERN_ONE_USE();
-      SCHED_BARRIER();
-      D8_PHASE_END(3);
-      // phase 1: plane 1 x W0 -> output plane 1, x W1 -> output plane 0 | fragments of plane 2 | requests: the next chunk's plane 0
+      float4 bv[2];
+      // phase 0: plane 0 x W0 -> output plane 0 | fragments of plane 1 | requests: next plane 0, next W0 | activate plane 2
+      D8_GEN_WITH_PAIRS_01(fb, xs + XSF, fa, bu, acc[0]);
       dma_in(cn, 0);
       SCHED_BARRIER();
-      b_lds(bu, 0);
-      gen(fa, xs + 2 * XSF);
-      mfma_use(fb, bu, acc[1]);
-      b_lds(bv, 1);
-      mfma_use(fb, bv, acc[0]);
-      D8_PATTERN_TWO_USE();
+      D8_MF2(fa, bu, acc[0]);
       SCHED_BARRIER();
-      D8_PHASE_END(1);
-      // phase 2: plane 2 x W1 -> output plane 1, x W2 -> output plane 0 | fragments of plane 3 | requests: its plane 1, its W0
-      dma_in(cn, 1);
       dma_w(cn, 0);
       SCHED_BARRIER();
-      b_lds(bu, 1);
-      gen(fb, xs + 3 * XSF);
-      mfma_use(fa, bu, acc[1]);
-      b_lds(bv, 2);
-      mfma_use(fa, bv, acc[0]);
-      D8_PATTERN_TWO_USE();
+      D8_MF3(fa, bu, acc[0]);
       SCHED_BARRIER();
-      D8_PHASE_END(3);
-      // phase 3: plane 3 x W2 -> output plane 1 | fragments of the next chunk's plane 0 | requests: its plane 2, its W1
+      activate(c0, 2);
+      D8_PHASE_END(3);                                     // (bu = W0 again for the first use of phase 1)
+      // phase 1: plane 1 x W0 -> output plane 1, x W1 -> output plane 0 | fragments of plane 2 | requests: next plane 1 | activate plane 3
+      D8_GEN_WITH_PAIRS_01(fa, xs + 2 * XSF, fb, bu, acc[1]);
+      b_lds(bv, 1);
+      D8_MF2(fb, bu, acc[1]);
+      D8_MF3(fb, bu, acc[1]);
+      D8_SGB(0x100, 2); D8_SGB(0x008, 4);
+      SCHED_BARRIER();
+      dma_in(cn, 1);
+      SCHED_BARRIER();
+      D8_MF0(fb, bv, acc[0]); D8_MF1(fb, bv, acc[0]); D8_MF2(fb, bv, acc[0]); D8_MF3(fb, bv, acc[0]);
+      SCHED_BARRIER();
+      activate(c0, 3);
+      bu[0] = bv[0]; bu[1] = bv[1];                        // W1: first use of phase 2
+      D8_PHASE_END(1);
+      // phase 2: plane 2 x W1 -> output plane 1, x W2 -> output plane 0 | fragments of plane 3 | requests: next plane 2, next W1 |
+      // activate the next chunk's plane 0
+      D8_GEN_WITH_PAIRS_01(fb, xs + 3 * XSF, fa, bu, acc[1]);
+      b_lds(bv, 2);
+      D8_MF2(fa, bu, acc[1]);
+      D8_MF3(fa, bu, acc[1]);
+      D8_SGB(0x100, 2); D8_SGB(0x008, 4);
+      SCHED_BARRIER();
       dma_in(cn, 2);
+      SCHED_BARRIER();
+      D8_MF0(fa, bv, acc[0]); D8_MF1(fa, bv, acc[0]);
+      SCHED_BARRIER();
       dma_w(cn, 1);
       SCHED_BARRIER();
-      b_lds(bu, 2);
-      gen(fa, xs);
-      mfma_use(fb, bu, acc[1]);
-      D8_PATTERN_ONE_USE();
+      D8_MF2(fa, bv, acc[0]); D8_MF3(fa, bv, acc[0]);
       SCHED_BARRIER();
+      activate(cn, 0);
+      bu[0] = bv[0]; bu[1] = bv[1];                        // W2: first use of phase 3
+      D8_PHASE_END(3);
+      // phase 3: plane 3 x W2 -> output plane 1 | fragments of the next chunk's plane 0 | requests: its plane 3, its W2 | activate its
+      // plane 1 | read its W0
+      D8_GEN_WITH_PAIRS_01(fa, xs, fb, bu, acc[1]);
+      dma_in(cn, 3);
+      SCHED_BARRIER();
+      D8_MF2(fb, bu, acc[1]);
+      SCHED_BARRIER();
+      dma_w(cn, 2);
+      SCHED_BARRIER();
+      D8_MF3(fb, bu, acc[1]);
+      SCHED_BARRIER();
+      activate(cn, 1);
+      b_lds(bu, 0);
       D8_PHASE_END(3);
     };
+    float4 bA[2];
     AF fA, fB;
-    gen(fA, xs);
-    for (int c0 = 0; c0 < a.CinP; c0 += KC) chunk(c0, fA, fB);
+    b_lds(bA, 0);
+    {
+      AF& f = fA;                                          // fragments of plane 0 (no MFMA to ride behind yet)
+      constexpr int c0_ = JH ? 3 : 0, c1_ = JH ? 2 : 1, c2_ = JH ? 1 : 2;
+      constexpr int o0 = ((c0_ >> 1) + 10 * (c0_ & 1)) * 4, o1 = ((c1_ >> 1) + 10 * (c1_ & 1)) * 4, o2 = ((c2_ >> 1) + 10 * (c2_ & 1)) * 4;
+      const float4 a0 = *reinterpret_cast<const float4*>(xs + ga + o0), b0 = *reinterpret_cast<const float4*>(xs + gb + o0);
+      const float4 a2 = *reinterpret_cast<const float4*>(xs + ga + o2), b2 = *reinterpret_cast<const float4*>(xs + gb + o2);
+      const float4 a1 = *reinterpret_cast<const float4*>(xs + ga + o1), b1 = *reinterpret_cast<const float4*>(xs + gb + o1);
+      const float s00 = fmaf(b0.x, beta, a0.x), s01 = fmaf(b0.y, beta, a0.y), s02 = fmaf(b0.z, beta, a0.z), s03 = fmaf(b0.w, beta, a0.w);
+      const float s20 = fmaf(b2.x, beta, a2.x), s21 = fmaf(b2.y, beta, a2.y), s22 = fmaf(b2.z, beta, a2.z), s23 = fmaf(b2.w, beta, a2.w);
+      const float s10 = fmaf(b1.x, beta, a1.x), s11 = fmaf(b1.y, beta, a1.y), s12 = fmaf(b1.z, beta, a1.z), s13 = fmaf(b1.w, beta, a1.w);
+      f.v[0][0] = make_pkf2(s00 - s20, s01 - s21); f.v[0][1] = make_pkf2(s02 - s22, s03 - s23);
+      f.v[1][0] = JH ? make_pkf2(s10 - s20, s11 - s21) : make_pkf2(s10 + s20, s11 + s21);
+      f.v[1][1] = JH ? make_pkf2(s12 - s22, s13 - s23) : make_pkf2(s12 + s22, s13 + s23);
+    }
+    D8_PHASE_END(0);                                       // plane 0 and W0 have been read: phase 0 requests into their buffer / slab
+    for (int c0 = 0; c0 < a.CinP; c0 += KC) chunk(c0, bA, fA, fB);
   };
+#undef D8_GEN_WITH_PAIRS_01
 
-  // prologue: planes 0, 1, 2 and W0, W1 of the first chunk requested together and waited for
-  dma_in(0, 0); dma_in(0, 1); dma_in(0, 2);
-  dma_w(0, 0); dma_w(0, 1);
+  // prologue: the four planes and the three weight slabs of the first chunk requested together and waited for [; parameters to LDS,
+  // planes 0 and 1 activated]
+  dma_in(0, 0); dma_in(0, 1); dma_in(0, 2); dma_in(0, 3);
+  dma_w(0, 0); dma_w(0, 1); dma_w(0, 2);
+  if (INMODE == MI355_IN_AFFINE_ACT) {
+    for (int c = tid; c < a.CinP; c += 512) {
+      const bool in = c < a.Cin;
+      prm[c] = in ? a.in_scale[(size_t)n * a.Cin + c] : 0.f;
+      prm[a.CinP + c] = in ? a.in_shift[(size_t)n * a.Cin + c] : 0.f;
+      prm[2 * a.CinP + c] = in ? (a.in_slope ? a.in_slope[c] : a.slope) : 0.f;
+    }
+    D8_PHASE_END(0);                                       // the parameters are in LDS, every request of this wave has landed
+    activate(0, 0); activate(0, 1);                        // (planes 2 and 3 in phases 0 and 1, where the loop activates them in every chunk)
+  }
   D8_PHASE_END(0);
   if (jh) run(std::integral_constant<int, 1>()); else run(std::integral_constant<int, 0>());
   D8_PHASE_END(0);                                         // the requests of the last phases (never read) have landed: the exchange reuses the LDS
@@ -1015,9 +1099,11 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_d8(Wi
   if constexpr (FUSE != 0) wino_fuse_records<FUSE>(a, P, tid, lane, wave, coq, co_base, n, tz0, ty0, tx0, cnt, K0, s0, s1);
 }
 #undef D8_SGB
-#undef D8_PATTERN_ONE_USE
-#undef D8_PATTERN_TWO_USE
 #undef D8_PHASE_END
+#undef D8_MF0
+#undef D8_MF1
+#undef D8_MF2
+#undef D8_MF3
 
 // ---- filter transform: U[(i,j)][dz][ci][co] = sum_{dy,dx} G[i][dy] G[j][dx] w[...] (pack_values.h: pack_wino_item) ----
 __global__ void wino_pack_weight_kernel(const float* w, float* up, int cout, int cin, int coutP, int cinP, int mode) {
@@ -1090,11 +1176,14 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
   const int lds_bytes = (8 * 2 * 32 * 32 + 3 * a.CinP) * (int)sizeof(float);      // exchange area (the main loop's buffers live inside it) + norm prologue
   const dim3 grid((unsigned)blocks), blk(512);
 #if WINO_D8
-  if (d->in_mode == MI355_IN_PLAIN) {
-    // conv3d_wino2d_d8: 4 staged plane chunks + 3 weight slabs (75 264 bytes) | the padded exchange (73 728)
-    const int lds_d8 = (4 * 1632 + 3 * 4096) * (int)sizeof(float);
-#define D8_LAUNCH(FU) do { SET_MAX_DYN_LDS((conv3d_wino2d_d8<FU>), lds_d8); LAUNCH((conv3d_wino2d_d8<FU>), grid, blk, lds_d8, stream, a); } while (0)
-    if (a.g.mom) D8_LAUNCH(1); else if (a.g.gnb) D8_LAUNCH(2); else D8_LAUNCH(0);
+  {
+    // conv3d_wino2d_d8: 4 staged plane chunks + 3 weight slabs (75 264 bytes; the padded exchange of the epilogue, 73 728, lives inside) + norm prologue
+    const int lds_d8 = (4 * 1632 + 3 * 4096 + 3 * a.CinP) * (int)sizeof(float);
+#define D8_LAUNCH(IM, FU) do { SET_MAX_DYN_LDS((conv3d_wino2d_d8<IM, FU>), lds_d8); LAUNCH((conv3d_wino2d_d8<IM, FU>), grid, blk, lds_d8, stream, a); } while (0)
+    if (a.g.mom) { if (d->in_mode == MI355_IN_PLAIN) D8_LAUNCH(MI355_IN_PLAIN, 1); else D8_LAUNCH(MI355_IN_AFFINE_ACT, 1); }
+    else if (a.g.gnb) D8_LAUNCH(MI355_IN_PLAIN, 2);
+    else if (d->in_mode == MI355_IN_PLAIN) D8_LAUNCH(MI355_IN_PLAIN, 0);
+    else D8_LAUNCH(MI355_IN_AFFINE_ACT, 0);
 #undef D8_LAUNCH
     return LAUNCH_CHECK();
   }
