@@ -12,15 +12,17 @@
 //   point-wise        M[p] = sum_{ci, dz} V[p][plane z + dz - 1][ci] * U[p][dz][ci][co]          <- the MFMA work, p = 0..15
 //   output transform  Y = A^T M A    (2x2 outputs, A^T rows: m0+m1+m2, m1-m2-m3)
 //
-// Output tile of a workgroup = 2 z-planes x 8 (y) x 16 (x) voxels = per plane 4 x 8 = 32 Winograd tiles of 2x2 = the M dimension of one
-// 32x32 MFMA tile; N = 32 output channels; K = 8 input channels per LDS chunk (lane l supplies A[tile = l & 31][k = l >> 5] as one
-// float4 per k-half: four MFMAs per 16-byte operand, the operand scheme of conv3d_mfma). A workgroup walks the 4 input planes its 2
-// output planes see; every plane is staged (haloed 10 x 18 voxels, normalised + activated on the way in), transformed ONCE into the 16
-// points and used by the 1-2 (output plane, dz) pairs that see it.
+// Output tile of a workgroup = 2 z-planes x 8 (y) x 16 (x) voxels = per plane 4 x 8 = 32 Winograd tiles of 2x2 = one dimension of a
+// 32x32 MFMA tile; the other = 32 output channels; K = 8 input channels per chunk (a lane supplies 4 of them as one 16-byte operand
+// per MFMA quadruple, lane half = the other 4). A workgroup walks the 4 input planes its 2 output planes see; every plane chunk is staged
+// once (haloed 10 x 18 voxels) and used by the 1-2 (output plane, dz) pairs that see it.
 //
-// History of the forms (all measured on MI355X, profiles/r3_wino_forms.txt; the losers were deleted): a 4-wave workgroup with 8
-// accumulator tiles per wave (three weight-prefetch orders; layer set 33.3 ms), a z-marching 8-wave workgroup with three output planes
-// in registers (36.9 ms: one workgroup per CU in lock step), and the 8-wave tile kernel below (28.7 ms).
+// History of the forms (all measured on MI355X; the losers were deleted): round 3 (profiles/r3_wino_forms.txt) a 4-wave workgroup with 8
+// accumulator tiles per wave (layer set 33.3 ms), a z-marching 8-wave workgroup with three output planes in registers (36.9 ms: one
+// workgroup per CU in lock step), the 8-wave tile kernel conv3d_wino2d_w8 with the transformed planes in LDS (28.7 ms; rounds 3-4);
+// round 5 (profiles/r5_wino_r8_experiment.txt, r5_wino_d8.txt): conv3d_wino2d_r8, the same with register-generated fragments (a quarter
+// fewer vector and half the LDS instructions per MFMA, 3 % SLOWER: the kernel is not bound by its instruction count), and
+// conv3d_wino2d_d8 below, r8 with every global load of the main loop replaced by an LDS-DMA requested two phases ahead.
 #include "gfx950_dialect.h"
 #include <type_traits>
 #include <cstdlib>
@@ -41,535 +43,18 @@ struct WinoArgs {
   GnFuseArgs g;                          // norm statistics fused into the epilogue (gn_fuse.h), as in conv3d_mfma
 };
 
-// =====================================================================================================================================
-// EIGHT waves per workgroup. The SQ counters of the first, 4-wave form (profiles/r3_sq_counters_wino.txt) showed a latency-bound
-// kernel, not a busy one: matrix pipe 51 %, vector ALU 22 % of the SIMD cycles, the waves half of their resident time in s_waitcnt -- at
-// 256 registers per wave only two waves share a SIMD, and both run the same barrier-separated phases. Here the 2 x 8 x 16 voxel x 32
-// channel tile is computed by 512 threads: wave w owns the two points p = 2 w, 2 w + 1 of both output planes = 4 accumulator tiles =
-// 64 registers, the kernel fits 128 registers, and FOUR waves (two workgroups) share a SIMD. Per phase a wave reads its two A fragments
-// once (both uses of a two-use phase share them), a thread stages one float4 and transforms half a (tile, channel) window (two point
-// rows), the norm prologue comes from LDS. Weight fragments: two rotating register sets, each weight loaded once per chunk.
-// Output transform: in-wave over the wave's two j, across the waves through a 64 KB exchange (the main loop's LDS, reused).
 #ifndef WINO_ZBRICK
 #define WINO_ZBRICK 8             // z tiles per brick of the workgroup order (A/B: -DWINO_ZBRICK=1 = x fastest)
 #endif
-#ifndef WINO_D8
-#define WINO_D8 1             // 1: plain-input launches on conv3d_wino2d_d8 (LDS-DMA staging, round 5); 0: everything on conv3d_wino2d_w8
-#endif
 #ifndef WINO_ABL
-#define WINO_ABL 0            // developer ablations of conv3d_wino2d_w8 (tools/build_variant.sh ... -DWINO_ABL=mask): 1 no input loads, 2 no weight loads, 4 no transform, 8 no stores
+// developer ablations of conv3d_wino2d_d8 (tools/build_variant.sh ... -DWINO_ABL=mask; results wrong by construction, timing only):
+// 1 no input requests, 2 no weight requests, 4 weight fragments from constants instead of the slab, 32 the loop never waits for a request,
+// 64 / 128 every input / weight lane fetches the same 16 bytes
+#define WINO_ABL 0
 #endif
-template <int INMODE, int FUSE>
-__global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_w8(WinoArgs a) {
-  constexpr int TZ = 2, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HV = HY * HX;
-  constexpr int KC = 8, XS = 12, NT = 32;
-  constexpr int XSF = HV * XS + 16, VSF = 16 * NT * KC, PF = 8 * 2 * 32 * 32;
-  static_assert(2 * (XSF + VSF) <= PF, "the main loop's buffers live inside the exchange area");
-  DYN_LDS(lds);
-  float* xs = lds;                                         // 2 staged planes [halo voxel][8 + 4 pad]
-  // 2 transformed planes [point][tile][channel]. (A lane's A fragment = 4 channels of a tile, tiles 32 bytes apart: every ds_read_b128 of
-  // them is a 2-way bank conflict, the 15 % SQ_LDS_BANK_CONFLICT of profiles/r3_sq_counters_wino.txt. Round 4 measured the conflict-free
-  // [point][channel half][tile][4] layout: plain form unchanged, fused forms 2-5 % slower (two more spilled registers): LDS is ~40 %
-  // utilised, the conflicts are not on the critical path -- profiles/r4_ab_experiments.txt. Do not repeat.)
-  float* vs = lds + 2 * XSF;
-  float* P = lds;                                          // epilogue: output-transform exchange [wave][b][tile][co]
-  float* prm = lds + PF;                                   // norm prologue of this sample: scale | shift | slope, CinP each
-  const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6), half = lane >> 5, li = lane & 31;
-  // Workgroup -> (channel tile, spatial tile). The hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own
-  // L2), so the plain order b = spatial * coTiles + cot gives XCD x the channel tiles cot = x mod coTiles (their weights stay in that
-  // L2: good) but every (8 / coTiles)-th spatial tile (the halo and the z overlap of neighbouring tiles are fetched once per XCD).
-  // Where the numbers divide, XCD x = (cot, group g) takes a CONTIGUOUS range of spatial tiles instead.
-  int b = blockIdx.x, cot;
-  {
-    const int nct = a.coTiles, S = gridDim.x / nct, ng = nct < 8 && 8 % nct == 0 ? 8 / nct : 0;
-    if (ng > 0 && S % ng == 0) {
-      const int x = b & 7;
-      cot = x % nct;
-      b = (x / nct) * (S / ng) + (b >> 3);
-    } else {
-      cot = b % nct; b /= nct;
-    }
-  }
-  // Spatial order inside an XCD's range: bricks of WINO_ZBRICK z tiles, then x, y, z bricks. The ~64 workgroups resident on an XCD then
-  // cover 8 z tiles x 8 x tiles of one tile row: z neighbours (which share two of their four input planes) and x neighbours (the halo)
-  // are resident together and ~3 MB of input sit in the 4 MB L2; with x fastest (the first order) a z neighbour ran 128 workgroups
-  // later and every plane was fetched twice. Stated per launch in profiles/r3_bench_fp32_hbm_traffic_pmc.csv.
-  int tz;
-  if (a.tilesZ % WINO_ZBRICK == 0) {
-    const int zi = b % WINO_ZBRICK; b /= WINO_ZBRICK;
-    const int txi = b % a.tilesX; b /= a.tilesX;
-    const int tyi = b % a.tilesY; b /= a.tilesY;
-    const int zbk = b % (a.tilesZ / WINO_ZBRICK); b /= (a.tilesZ / WINO_ZBRICK);
-    tz = zbk * WINO_ZBRICK + zi;
-    b = (b * a.tilesY + tyi) * a.tilesX + txi;              // (n, ty, tx) for the common decode below
-  } else {
-    const int txi = b % a.tilesX, r1 = b / a.tilesX;
-    const int tyi = r1 % a.tilesY, r2 = r1 / a.tilesY;
-    tz = r2 % a.tilesZ;
-    b = ((r2 / a.tilesZ) * a.tilesY + tyi) * a.tilesX + txi;
-  }
-  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
-  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
-  const int tz0 = tz * TZ;
-  const int n = b;
-  const int co_base = cot * 32;
-
-  f32x16 acc[TZ][2];                                       // [output plane][point q: p = 2 * wave + q]
-#pragma unroll
-  for (int oz = 0; oz < TZ; ++oz)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[oz][q][r] = 0.f;
-
-  // staging unit of this thread: (halo voxel sv, channel quad sq) of the 180 x 2 units of a plane chunk; fixed for the whole kernel.
-  // Addresses are a workgroup-uniform base (scalar registers) plus one 32-bit lane offset inside the plane.
-  const bool sunit = tid < HV * 2;
-  const int sv = sunit ? tid >> 1 : 0, sq = tid & 1;
-  const int siy = ty0 - 1 + sv / HX, six = tx0 - 1 + sv % HX;
-  const bool sin = sunit && siy >= 0 && siy < a.H && six >= 0 && six < a.W;
-  const size_t xplane = (size_t)a.H * a.W * a.xld;
-  const float* xn = a.x + (size_t)n * a.D * xplane;        // sample n
-  const unsigned xoff = (unsigned)(((siy < 0 ? 0 : (siy < a.H ? siy : a.H - 1)) * a.W + (six < 0 ? 0 : (six < a.W ? six : a.W - 1))) * a.xld + 4 * sq);
-  const unsigned soff = (unsigned)(sv * XS + 4 * sq);      // staged position
-  const bool sq0 = sq == 0;
-  // transform unit: (channel tc, tile tt) and the row half th (wave-uniform): point rows i = 2 th, 2 th + 1
-  const int tc = tid & 7, tt = (tid >> 3) & 31, th = wave >> 2;
-  const int tty = tt >> 3, ttx = tt & 7;
-  const float4* up4 = reinterpret_cast<const float4*>(a.up);
-  const int CQ = a.CinP / 4;
-
-  float4 ld = make_float4(0.f, 0.f, 0.f, 0.f);
-  bool lok = false;
-  auto loads = [&](int c0_, int pz_) {
-    if (!sunit) return;
-    const int iz = tz0 - 1 + pz_;
-    const bool call = c0_ + 8 <= a.Cin;                    // both quads of the chunk exist (Cin is a multiple of 4)
-    lok = sin && iz >= 0 && iz < a.D && (call || sq0);
-    const int izc = iz < 0 ? 0 : (iz < a.D ? iz : a.D - 1);
-    const float* base = xn + (size_t)izc * xplane + c0_;  // uniform
-#if WINO_ABL & 1
-    ld = make_float4((float)izc, (float)c0_, 1.f, 2.f); (void)base;
-#else
-    ld = *reinterpret_cast<const float4*>(base + (call ? xoff : xoff - 4u * sq));      // a missing quad re-reads the first one (zeroed by lok)
-#endif
-  };
-  auto commit = [&](float* xsb, int c0_) {
-    if (!sunit) return;
-    float4 v = ld;
-    if (INMODE == MI355_IN_AFFINE_ACT) {
-      const int c = c0_ + 4 * sq;
-      const float4 sc = *reinterpret_cast<const float4*>(prm + c), sh = *reinterpret_cast<const float4*>(prm + a.CinP + c);
-      const float4 sl = *reinterpret_cast<const float4*>(prm + 2 * a.CinP + c);
-      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-      v.x = fmaxf(v.x, v.x * sl.x); v.y = fmaxf(v.y, v.y * sl.y); v.z = fmaxf(v.z, v.z * sl.z); v.w = fmaxf(v.w, v.w * sl.w);
-    }
-    if (!lok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(xsb + soff) = v;
-  };
-  // Input transform of this thread's (tile, channel), two of the four point rows. `th` (waves 0-3: 0, waves 4-7: 1) selects them WITHOUT
-  // a branch, so that a phase is one basic block and its transform can be spread between the MFMAs (scheduler directives in `chunk`):
-  //   th = 0 (window rows d0 d1 d2): u = d0 - d2 -> point row 0, o = d1 + d2 -> point row 1
-  //   th = 1 (window rows d1 d2 d3): u = d1 - d3 -> point row 3, o = d2 - d1 -> point row 2        (r0 r1 r2 = the rows read, base contains th)
-  //   u = r0 - r2,  o = r1 + sg * (th ? r0 : r2),  sg = th ? -1 : +1       (x * (+-1) + y is exact)
-  const float sg = th ? -1.f : 1.f;
-  const int toff = ((2 * tty + th) * HX + 2 * ttx) * XS + tc;                 // first window value read in a staged plane
-  const int uoff = ((th ? 12 : 0) * NT + tt) * KC + tc, ooff = ((th ? 8 : 4) * NT + tt) * KC + tc;      // point (4 i + j) at ((4 i + j) * NT + tt) * KC + tc
-  struct TIn { float d[3][4]; };
-  auto transform_reads = [&](TIn& t, const float* xsb) {
-#if WINO_ABL & 4
-    return;
-#endif
-    const float* col = xsb + toff;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) t.d[r][s2] = col[(r * HX + s2) * XS];
-  };
-  auto transform_math = [&](const TIn& t, float* vsb) {
-#if WINO_ABL & 4
-    return;
-#endif
-    float u[4], o[4];
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      u[s2] = t.d[0][s2] - t.d[2][s2];
-      o[s2] = fmaf(th ? t.d[0][s2] : t.d[2][s2], sg, t.d[1][s2]);
-    }
-    float* vu = vsb + uoff;
-    float* vo = vsb + ooff;
-    vu[(0 * NT) * KC] = u[0] - u[2]; vu[(1 * NT) * KC] = u[1] + u[2]; vu[(2 * NT) * KC] = u[2] - u[1]; vu[(3 * NT) * KC] = u[1] - u[3];
-    vo[(0 * NT) * KC] = o[0] - o[2]; vo[(1 * NT) * KC] = o[1] + o[2]; vo[(2 * NT) * KC] = o[2] - o[1]; vo[(3 * NT) * KC] = o[1] - o[3];
-  };
-  auto transform = [&](const float* xsb, float* vsb) { TIn t; transform_reads(t, xsb); transform_math(t, vsb); };
-  // weight fragments of one use: the wave's two points, z-tap dz, channels [c0_, c0_ + 8): uniform base + one 32-bit lane offset
-  const unsigned boff = (unsigned)(half * a.CoutP + co_base + li);          // in float4s
-  const size_t bstep = (size_t)CQ * a.CoutP;               // float4s between consecutive (point, dz) slabs
-  auto b_use = [&](float4 (&bu)[2], int c0_, int dz) {
-    const float4* q0 = up4 + (size_t)(c0_ / 4) * a.CoutP + (size_t)((2 * wave) * 3 + dz) * bstep;      // uniform
-#if WINO_ABL & 2
-    bu[0] = make_float4((float)c0_, (float)dz, 0.5f, 0.25f); bu[1] = make_float4((float)dz, (float)c0_, 0.25f, 0.5f); (void)q0;
-#else
-    bu[0] = q0[boff];
-    bu[1] = (q0 + 3 * bstep)[boff];
-#endif
-  };
-  auto mfma_use = [&](const float4 (&af)[2], const float4 (&bu)[2], f32x16 (&ac)[2]) {
-    ac[0] = MFMA_32x32x2(af[0].x, bu[0].x, ac[0]);
-    ac[1] = MFMA_32x32x2(af[1].x, bu[1].x, ac[1]);
-    ac[0] = MFMA_32x32x2(af[0].y, bu[0].y, ac[0]);
-    ac[1] = MFMA_32x32x2(af[1].y, bu[1].y, ac[1]);
-    ac[0] = MFMA_32x32x2(af[0].z, bu[0].z, ac[0]);
-    ac[1] = MFMA_32x32x2(af[1].z, bu[1].z, ac[1]);
-    ac[0] = MFMA_32x32x2(af[0].w, bu[0].w, ac[0]);
-    ac[1] = MFMA_32x32x2(af[1].w, bu[1].w, ac[1]);
-  };
-  // One channel chunk = 4 phases (input planes pz = 0..3 of the tile). The weights W[dz] of a chunk are loaded ONCE: input plane pz
-  // multiplies W[pz] into output plane 0 and W[pz - 1] into output plane 1, so W[dz] serves two consecutive phases from the same
-  // registers (the ablation run profiles/r3_wino_w8_ablation.txt prices the weight stream from L2 at 12-20 % of the kernel when every
-  // use re-requests it). Two fragment sets rotate: on entry S0 holds W0 and S1 is free; phase 0 requests W1 into S1; phase 1 runs
-  // (plane 1, W0), then requests W2 into S0, then (plane 0, W1); phase 2 runs (plane 1, W1), requests the NEXT chunk's W0 into S1, then
-  // (plane 0, W2); phase 3 runs (plane 1, W2). On exit S1 holds the next W0 (moved to S0 by the caller). Every request has at
-  // least one phase of lead, and a phase-opening request precedes the phase's input-plane loads in program order (vmcnt retires in
-  // order: a weight wait must never include a younger HBM load).
-  auto a_frags = [&](float4 (&af)[2], const float* vcur) {
-    const float* vb = vcur + ((2 * wave) * NT + li) * KC + 4 * half;
-    af[0] = *reinterpret_cast<const float4*>(vb);
-    af[1] = *reinterpret_cast<const float4*>(vb + NT * KC);
-  };
-  // Scheduler directives of a phase body (one basic block: A fragments, transform reads, MFMAs, weight request, transform arithmetic
-  // and writes): the transform's LDS reads go out behind the first MFMAs, its arithmetic and writes ride in the shadow of the others
-  // (a 32x32x2 fp32 MFMA holds the pipe for 64 cycles), the weight request of a two-use phase is issued once the first use's MFMAs
-  // (which read the registers it overwrites) are out.
-#ifdef MI355_EMU
-#define W8_PATTERN_ONE_USE()
-#define W8_PATTERN_TWO_USE()
-#else
-#define W8_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-#define W8_PATTERN_ONE_USE() do {                                                            \
-    W8_SGB(0x100, 2);                                                                        \
-    W8_SGB(0x008, 1); W8_SGB(0x100, 3); W8_SGB(0x008, 1); W8_SGB(0x100, 3);                  \
-    W8_SGB(0x008, 1); W8_SGB(0x002, 4); W8_SGB(0x008, 1); W8_SGB(0x002, 4);                  \
-    W8_SGB(0x008, 1); W8_SGB(0x002, 4);                                                      \
-    W8_SGB(0x008, 1); W8_SGB(0x002, 3); W8_SGB(0x200, 2);                                    \
-    W8_SGB(0x008, 1); W8_SGB(0x002, 3); W8_SGB(0x200, 2);                                    \
-    W8_SGB(0x008, 1); W8_SGB(0x002, 3); W8_SGB(0x200, 2); } while (0)
-#define W8_PATTERN_TWO_USE() do {                                                            \
-    W8_SGB(0x100, 2);                                                                        \
-    W8_SGB(0x008, 1); W8_SGB(0x100, 2); W8_SGB(0x008, 1); W8_SGB(0x100, 2);                  \
-    W8_SGB(0x008, 1); W8_SGB(0x100, 2);                                                      \
-    W8_SGB(0x008, 1); W8_SGB(0x002, 3); W8_SGB(0x008, 1); W8_SGB(0x002, 3);                  \
-    W8_SGB(0x008, 1); W8_SGB(0x002, 3); W8_SGB(0x008, 1); W8_SGB(0x002, 3);                  \
-    W8_SGB(0x008, 1); W8_SGB(0x020, 2);                                                      \
-    W8_SGB(0x008, 1); W8_SGB(0x002, 2); W8_SGB(0x200, 1);                                    \
-    W8_SGB(0x008, 1); W8_SGB(0x002, 2); W8_SGB(0x200, 1);                                    \
-    W8_SGB(0x008, 1); W8_SGB(0x002, 2); W8_SGB(0x200, 1);                                    \
-    W8_SGB(0x008, 1); W8_SGB(0x002, 2); W8_SGB(0x200, 1);                                    \
-    W8_SGB(0x008, 4); } while (0)
-#endif
-  auto chunk = [&](int c0, float4 (&S0)[2], float4 (&S1)[2]) {
-    const bool more = c0 + KC < a.CinP;                    // another chunk follows (workgroup-uniform)
-    const int cn = more ? c0 + KC : c0;                    // the weight request of phase 2 is unconditional (no branch inside a phase body)
-    float4 af[2];
-    TIn t;
-    // phase 0: plane 0 x W0 -> output plane 0 | transform plane 1 | loads of plane 2
-    b_use(S1, c0, 1);
-    loads(c0, 2);
-    SCHED_BARRIER();
-    a_frags(af, vs);
-    transform_reads(t, xs + XSF);
-    mfma_use(af, S0, acc[0]);
-    transform_math(t, vs + VSF);
-    W8_PATTERN_ONE_USE();
-    SCHED_BARRIER();
-    commit(xs, c0);
-    __syncthreads();
-    // phase 1: plane 1 x W0 -> output plane 1, x W1 -> output plane 0 | transform plane 2 | loads of plane 3
-    loads(c0, 3);
-    SCHED_BARRIER();
-    a_frags(af, vs + VSF);
-    transform_reads(t, xs);
-    mfma_use(af, S0, acc[1]);
-    b_use(S0, c0, 2);
-    transform_math(t, vs);
-    mfma_use(af, S1, acc[0]);
-    W8_PATTERN_TWO_USE();
-    SCHED_BARRIER();
-    commit(xs + XSF, c0);
-    __syncthreads();
-    // phase 2: plane 2 x W1 -> output plane 1, x W2 -> output plane 0 | transform plane 3 | loads of the next chunk's plane 0
-    if (more) loads(c0 + KC, 0);
-    SCHED_BARRIER();
-    a_frags(af, vs);
-    transform_reads(t, xs + XSF);
-    mfma_use(af, S1, acc[1]);
-    b_use(S1, cn, 0);
-    transform_math(t, vs + VSF);
-    mfma_use(af, S0, acc[0]);
-    W8_PATTERN_TWO_USE();
-    SCHED_BARRIER();
-    if (more) commit(xs, c0 + KC);
-    __syncthreads();
-    // phase 3: plane 3 x W2 -> output plane 1 | transform of the next chunk's plane 0 (after the last chunk: of a stale buffer, into a
-    // buffer nobody reads) | loads of its plane 1
-    if (more) loads(c0 + KC, 1);
-    SCHED_BARRIER();
-    a_frags(af, vs + VSF);
-    transform_reads(t, xs);
-    mfma_use(af, S0, acc[1]);
-    transform_math(t, vs);
-    W8_PATTERN_ONE_USE();
-    SCHED_BARRIER();
-    if (more) commit(xs + XSF, c0 + KC);
-    __syncthreads();
-  };
-
-  // prologue: planes 0 and 1 of the first chunk requested together, W0 requested; plane 0 staged and transformed, plane 1 staged. The
-  // norm-prologue parameters are fetched AFTER those requests (they are a global round trip of their own: in front of them, as in the
-  // first version, the workgroup's first input plane left one memory latency later) and are in LDS before the first staging write.
-  float4 bA[2], bB[2];
-  b_use(bA, 0, 0);
-  loads(0, 0);
-  const float4 ld0 = ld;
-  const bool lok0 = lok;
-  loads(0, 1);
-  if (INMODE == MI355_IN_AFFINE_ACT) {
-    for (int c = tid; c < a.CinP; c += 512) {
-      const bool in = c < a.Cin;
-      prm[c] = in ? a.in_scale[(size_t)n * a.Cin + c] : 0.f;
-      prm[a.CinP + c] = in ? a.in_shift[(size_t)n * a.Cin + c] : 0.f;
-      prm[2 * a.CinP + c] = in ? (a.in_slope ? a.in_slope[c] : a.slope) : 0.f;
-    }
-    __syncthreads();
-  }
-  { const float4 ld1 = ld; const bool lok1 = lok; ld = ld0; lok = lok0; commit(xs, 0); ld = ld1; lok = lok1; }
-  commit(xs + XSF, 0);
-  __syncthreads();
-  transform(xs, vs);
-  __syncthreads();
-  for (int c0 = 0; c0 < a.CinP; c0 += KC) {
-    chunk(c0, bA, bB);
-    bA[0] = bB[0]; bA[1] = bB[1];                          // the next chunk's W0 (8 register moves per 4 phases keep ONE loop body)
-  }
-
-  // ---- output transform Y = A^T M A, bias / residual / dropout scale, store ----
-  // wave w = (i = w >> 1, j half = w & 1). In-wave over its two j: A^T rows (1, 1, 1, 0) and (0, 1, -1, -1), written to the exchange
-  // P[wave][b][tile][co]; across the waves over i on the way out. The read side is VOXEL-major: a thread owns 4 consecutive channels
-  // (quad coq = tid & 7) of two output voxels per plane, so the exchange is read with ds_read_b128, residual / normalised tensor come
-  // in and the result goes out as 16-byte accesses (8 lanes = the 32 channels of a voxel, a wave = 8 consecutive voxels of a row; the
-  // ablation run priced the first, channel-per-lane epilogue -- 48 ds_read_b32 and 8 dword stores per lane and plane -- at 10 % of
-  // the layer set, profiles/r3_wino_w8_ablation.txt). `a.vec4` == 0 (an output, residual or normalised tensor that is not 16-byte
-  // aligned per voxel, or a channel count that is not a multiple of 4) takes the same path with scalar accesses.
-  const bool jh = wave & 1;
-  const int coq = tid & 7, ea = (wave >> 1) & 1;           // voxel rows: y = (tid >> 7) + 4 s -> a = y & 1 is wave-uniform
-  const int co4 = co_base + 4 * coq;
-  float bs[4], cs[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const bool cv = co4 + e < a.Cout;
-    bs[e] = cv && a.bias ? a.bias[co4 + e] : 0.f;
-    cs[e] = cv && a.out_chscale ? a.out_chscale[(size_t)n * a.Cout + co4 + e] : 1.f;
-  }
-  const bool q_in = co4 < a.Cout, q_full = co4 + 4 <= a.Cout;      // any / all four channels of the quad exist
-  float K0[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-  float gsc[4], gsh[4], gmean[4], grstd[4];
-  int cnt = 0;
-  if constexpr (FUSE == 2) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int coc = co4 + e < a.Cout ? co4 + e : a.Cout - 1;
-      const int grp = coc / (a.Cout / a.g.ggroups);
-      gsc[e] = a.g.gscale[(size_t)n * a.Cout + coc]; gsh[e] = a.g.gshift[(size_t)n * a.Cout + coc];
-      gmean[e] = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2]; grstd[e] = a.g.gmr[((size_t)n * a.g.ggroups + grp) * 2 + 1];
-    }
-  }
-  float* pw = P + ((wave * 2) * 32 + 4 * half) * 32 + li;  // this lane's partial rows: + (b * 32 + (r & 3) + 8 * (r >> 2)) * 32
-  auto ld4 = [&](const float* base, size_t off, float (&v)[4]) {          // 4 channels of a voxel; scalar where 16-byte access is not legal
-    if (a.vec4) {
-      const float4 t = *reinterpret_cast<const float4*>(base + off);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = co4 + e < a.Cout ? base[off + e] : 0.f;
-    }
-  };
-#if WINO_ABL & 16
-  {
-    float sacc = 0.f;
-#pragma unroll
-    for (int oz = 0; oz < TZ; ++oz)
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc += acc[oz][q][r];
-    if (sacc == 12345.678f) a.y[tid] = sacc + bs[0] + cs[0];
-    return;
-  }
-#endif
-#pragma unroll
-  for (int oz = 0; oz < TZ; ++oz) {
-    if (oz > 0) __syncthreads();                           // the previous plane's exchange has been read (the main loop ends on a barrier)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rowoff = (r & 3) + 8 * (r >> 2);           // tile index of accumulator register r, less 4 * half
-      const float m0 = acc[oz][0][r], m1 = acc[oz][1][r], sm = m0 + m1;
-      pw[rowoff * 32] = jh ? m0 : sm;
-      pw[(32 + rowoff) * 32] = jh ? -sm : m1;
-    }
-    // reads that do not depend on the exchange go out before the barrier: the normalised tensor (FUSE 2) and the residual. Measured and
-    // reverted (profiles/r3_wino_forms.txt): both planes' requests at the top of the epilogue (27 spilled registers, the norm-backward
-    // form 16 % slower) and plane 1's requests right after plane 0's barrier (23 spills, some reloaded inside the main loop: +12 %)
-    const int z = tz0 + oz, zc = z < a.D ? z : a.D - 1;
-    float gxv[2][4], rsv[2][4];
-    size_t vox[2];
-    bool vin[2];
-#pragma unroll
-    for (int sI = 0; sI < 2; ++sI) {
-      const int v = (tid >> 3) + 64 * sI;
-      const int yy = ty0 + (v >> 4), xx = tx0 + (v & 15);
-      vin[sI] = q_in && z < a.D && yy < a.H && xx < a.W;
-      const int yc = yy < a.H ? yy : a.H - 1, xc = xx < a.W ? xx : a.W - 1;
-      vox[sI] = (((size_t)n * a.D + zc) * a.H + yc) * a.W + xc;
-      const int cq = q_in ? co4 : 0;                       // a quad beyond Cout reads (and drops) the first one
-      if constexpr (FUSE == 2) ld4(a.g.gx, vox[sI] * a.g.gxld + cq, gxv[sI]);
-      if (a.res) ld4(a.res, vox[sI] * a.resld + cq, rsv[sI]);
-      else { rsv[sI][0] = rsv[sI][1] = rsv[sI][2] = rsv[sI][3] = 0.f; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int sI = 0; sI < 2; ++sI) {
-      const int v = (tid >> 3) + 64 * sI;
-      const int tile = ((v >> 5) << 3) + ((v & 15) >> 1), eb = v & 1;      // (y >> 1) * 8 + (x >> 1); b = x & 1
-      const float4* pz = reinterpret_cast<const float4*>(P + (eb * 32 + tile) * 32 + 4 * coq);      // wave w at + w * 2048 floats
-      // across the waves: row i of the point grid = waves 2 i, 2 i + 1; A^T rows over i: (1, 1, 1, 0) and (0, 1, -1, -1)
-      float4 o;
-      if (ea == 0) {
-        const float4 p0 = pz[0 * 512], p1 = pz[1 * 512], p2 = pz[2 * 512], p3 = pz[3 * 512], p4 = pz[4 * 512], p5 = pz[5 * 512];
-        o.x = (p0.x + p1.x) + (p2.x + p3.x) + (p4.x + p5.x); o.y = (p0.y + p1.y) + (p2.y + p3.y) + (p4.y + p5.y);
-        o.z = (p0.z + p1.z) + (p2.z + p3.z) + (p4.z + p5.z); o.w = (p0.w + p1.w) + (p2.w + p3.w) + (p4.w + p5.w);
-      } else {
-        const float4 p2 = pz[2 * 512], p3 = pz[3 * 512], p4 = pz[4 * 512], p5 = pz[5 * 512], p6 = pz[6 * 512], p7 = pz[7 * 512];
-        o.x = (p2.x + p3.x) - (p4.x + p5.x) - (p6.x + p7.x); o.y = (p2.y + p3.y) - (p4.y + p5.y) - (p6.y + p7.y);
-        o.z = (p2.z + p3.z) - (p4.z + p5.z) - (p6.z + p7.z); o.w = (p2.w + p3.w) - (p4.w + p5.w) - (p6.w + p7.w);
-      }
-      if (!vin[sI]) continue;
-      float ov[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ov[e] = (ov[e] + bs[e] + rsv[sI][e]) * cs[e];
-      float* yp = a.y + vox[sI] * a.yld + co4;
-#if WINO_ABL & 8
-      if (ov[0] == 12345.678f)
-#endif
-      if (a.vec4 && q_full) *reinterpret_cast<float4*>(yp) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-      else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (co4 + e < a.Cout) yp[e] = ov[e];
-      }
-      if constexpr (FUSE == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (cnt == 0) K0[e] = ov[e];
-          const float t = ov[e] - K0[e];
-          s0[e] += t; s1[e] += t * t;
-        }
-        ++cnt;
-      } else if constexpr (FUSE == 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xv = gxv[sI][e];
-          const float u = xv * gsc[e] + gsh[e];
-          const float du = u > 0.f ? ov[e] : ov[e] * a.g.gslope;
-          s0[e] += du; s1[e] += du * ((xv - gmean[e]) * grstd[e]);
-        }
-      }
-    }
-  }
-  if constexpr (FUSE != 0) {
-    // Per-lane partials of 4 channels -> one record per (tile, channel). Lanes coq + 8 m (m = 0..7) of a wave hold the same channels:
-    // three xor-shuffle steps of PLAIN sums (fixed order: the lane with the lower m first), then the eight waves through LDS in wave
-    // order (Chan's merge, as everywhere). Moments: a lane's sums are about its own first value K0; before the shuffles they are moved
-    // to the wave's common shift Kc = K0 of lane m = 0 (sum (v - Kc) = s0 + c d, sum (v - Kc)^2 = s1 + d (2 s0 + c d), d = K0 - Kc: no
-    // division, no E[x^2] - E[x]^2 of raw values), and M2 = s1 - s0^2 / c is formed once per wave and channel.
-    constexpr int KK = FUSE == 1 ? 3 : 2;
-    float vals[4][KK];
-    float cw = (float)cnt;                                  // FUSE 1: stored voxels of this lane (the same for its four channels)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if constexpr (FUSE == 1) {
-        const float Kc = __shfl(K0[e], coq);
-        const float d = K0[e] - Kc;
-        vals[e][0] = Kc;
-        vals[e][2] = s1[e] + d * (2.f * s0[e] + cw * d);
-        vals[e][1] = s0[e] + cw * d;
-      } else {
-        vals[e][0] = s0[e]; vals[e][1] = s1[e];
-      }
-    }
-#pragma unroll
-    for (int step = 8; step < 64; step <<= 1) {
-      const bool upper = lane & step;
-      if constexpr (FUSE == 1) { const float oc = __shfl_xor(cw, step); cw = upper ? oc + cw : cw + oc; }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int k = (FUSE == 1 ? 1 : 0); k < KK; ++k) {
-          const float o = __shfl_xor(vals[e][k], step);
-          vals[e][k] = upper ? o + vals[e][k] : vals[e][k] + o;
-        }
-    }
-    // the eight waves through LDS: moments as (count, sum about Kc, sum of squares about Kc, Kc) per wave, moved to wave 0's shift by
-    // the same identity and added in wave order; M2 = s1 - s0^2 / c once per channel
-    constexpr int KW = FUSE == 1 ? 4 : 2;
-    __syncthreads();                                       // every wave is done with the exchange
-    if (lane < 8) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float* pr = P + ((wave * 32) + 4 * coq + e) * KW;
-        if constexpr (FUSE == 1) { pr[0] = cw; pr[1] = vals[e][1]; pr[2] = vals[e][2]; pr[3] = vals[e][0]; }
-        else { pr[0] = vals[e][0]; pr[1] = vals[e][1]; }
-      }
-    }
-    __syncthreads();
-    if (tid < 32) {
-      float r[KK];
-      if constexpr (FUSE == 1) {
-        const float K = P[tid * KW + 3];
-        float c = P[tid * KW], t0 = P[tid * KW + 1], t1 = P[tid * KW + 2];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) {
-          const float* pr = P + (w * 32 + tid) * KW;
-          const float cwv = pr[0], d = pr[3] - K;
-          t1 += pr[2] + d * (2.f * pr[1] + cwv * d);
-          t0 += pr[1] + cwv * d;
-          c += cwv;
-        }
-        const float m2 = c > 0.f ? t1 - t0 * t0 / c : 0.f;
-        r[0] = c; r[1] = t0 + c * K; r[2] = m2 > 0.f ? m2 : 0.f;
-      } else {
-#pragma unroll
-        for (int k = 0; k < KK; ++k) r[k] = P[tid * KW + k];
-#pragma unroll
-        for (int w = 1; w < 8; ++w)
-#pragma unroll
-          for (int k = 0; k < KK; ++k) r[k] += P[(w * 32 + tid) * KW + k];
-      }
-      const int tile = ((tz0 / TZ) * a.tilesY + ty0 / TY) * a.tilesX + tx0 / TX;
-      const size_t rec = (size_t)n * ((size_t)a.tilesZ * a.tilesY * a.tilesX) + tile;
-      float* dst = (FUSE == 1 ? a.g.mom : a.g.gnb) + rec * a.Cout * KK;
-      const int co = co_base + tid;
-      if (co < a.Cout) {
-#pragma unroll
-        for (int k = 0; k < KK; ++k) dst[(size_t)co * KK + k] = r[k];
-      }
-    }
-  }
-}
-#undef W8_SGB
-#undef W8_PATTERN_ONE_USE
-#undef W8_PATTERN_TWO_USE
 
 // The statistics tail of a fused epilogue (FUSE 1: moments of the stored output, FUSE 2: norm-backward sums): per-lane partials of 4 channels
-// -> one record per (tile, channel); the code of conv3d_wino2d_w8's tail as a function (conv3d_wino2d_d8 calls it).
+// -> one record per (tile, channel).
 template <int FUSE>
 __device__ __forceinline__ void wino_fuse_records(const WinoArgs& a, float* P, int tid, int lane, int wave, int coq, int co_base, int n, int tz0, int ty0,
                                                   int tx0, int cnt, float (&K0)[4], float (&s0)[4], float (&s1)[4]) {
@@ -655,42 +140,62 @@ __device__ __forceinline__ void wino_fuse_records(const WinoArgs& a, float* P, i
   }
 
 // =====================================================================================================================================
-// conv3d_wino2d_d8 (round 5): the PLAIN-input forms (every dgrad, the plain forward) with NO register-staged global load in the main loop.
-// What bounds conv3d_wino2d_w8 is not its instruction count (profiles/r5_wino_r8_experiment.txt: a quarter fewer vector and half the
-// LDS instructions per MFMA changed nothing) but memory latency on a one-phase lead: removing the input and weight loads from the
-// main loop (wrong results, timing only) returns 11 % on w8 and 20 % on the register-generation form below (profiles/r5_wino_d8.txt).
-// A phase is 8-16 MFMAs per wave; the value a phase needs was requested one phase earlier, and the in-order VMEM counter ties the
-// L2-hit weight request to the HBM-latency input request issued before it. More lead needs registers the kernel does not have
-// (128 per wave, four waves per SIMD) -- unless the loads never touch registers:
-//  * input planes AND weights travel by LDS-DMA (global_load_lds_dwordx4), requested TWO phases before the phase that reads them:
-//    a ring of 4 staged plane chunks (6.5 KB each) and 3 weight slabs W[dz] (16 points x 8 input x 32 output channels = 16 KB each);
-//    the waits are counted (`s_waitcnt vmcnt(N)` with N = the DMA instructions of the current phase: everything older has landed),
-//    the barriers raw s_barrier (a __syncthreads() would drain the queue);
-//  * A fragments generated in registers from the staged plane (the r8 scheme: a wave's two points share the point row i and three
-//    adjacent window columns: 6 ds_read_b128 + 20 fp32 instructions per phase and lane, no transformed planes in LDS -- which is what
-//    makes room for the weight slabs); the staged layout [quad][row][even columns | odd columns] is conflict-free for those reads and
-//    is filled in lane order, as the DMA requires (slot = 51 x wave + lane; the slot picks the voxel);
-//  * weight fragments read from the slab right before their use (2 ds_read_b128 per use, consecutive lanes = consecutive 16 bytes);
-//  * MFMA operands swapped (A = weights, B = input) and the 16-byte output-transform exchange of r8.
-// The norm-prologue forms stay on conv3d_wino2d_w8 (a DMA cannot apply act(scale x + shift) on the way).
+// conv3d_wino2d_d8 (round 5): 512 threads = 8 waves on a 2 (z) x 8 x 16 voxel x 32 channel tile, wave w = (point row i = w >> 1, j half
+// jh = w & 1) owns two of the 16 transform points for both output planes (4 accumulator tiles = 64 registers; 128 per wave, four waves
+// per SIMD, two workgroups per CU). What bounded its predecessor conv3d_wino2d_w8 (transformed planes in LDS, register-staged loads one
+// phase ahead) was not the instruction count -- a quarter fewer vector and half the LDS instructions per MFMA changed nothing
+// (profiles/r5_wino_r8_experiment.txt) -- but the global loads on a one-phase lead: a phase is 8-16 MFMAs per wave, the in-order VMEM
+// counter ties the L2-hit weight request to the HBM-latency input request issued before it, and more lead needs registers the kernel
+// does not have. So here NO global load of the main loop touches a register (profiles/r5_wino_d8.txt):
+//  * input planes AND weights travel by LDS-DMA (global_load_lds_dwordx4, 16 bytes per lane, destination = wave base + 16 x lane):
+//    a ring of 4 staged plane chunks (6.5 KB each; a request goes out four phases before the plane's fragments are generated) and 3
+//    weight slabs W[dz] (16 points x 8 input x 32 output channels = 16 KB each); the waits are counted -- `s_waitcnt vmcnt(N)`, N = the
+//    DMA instructions this wave issued in the current phase, everything older has landed: the counter retires in order, so every
+//    wave issues the SAME number of requests per phase, whatever its lanes fetch -- and the barriers raw s_barrier (__syncthreads()
+//    would drain the queue). The requests sit BETWEEN the MFMA pairs: issuing one occupies the wave for 60-190 cycles;
+//  * the staged layout [quad][row][even columns | odd columns] is filled in lane order, as the DMA requires (slot = 51 x wave + lane, the
+//    slot picks the voxel), and is conflict-free for the reads below: the 16 lanes of every ds_read_b128 lane group hit 16 different
+//    16-byte bank groups (tile (ty, tx), column class c -> group tx + 40 ty + const);
+//  * A fragments generated in registers straight from the staged plane: a wave's two points share the point row i (window rows ra,
+//    rb: R = d[ra] + beta d[rb]) and three adjacent window columns X0 X1 X2 (q0 = R[X0] - R[X2], q1 = R[X1] +- R[X2]): 6
+//    ds_read_b128 + 20 fp32 instructions per phase and lane, one phase ahead of the MFMAs that use them. No transformed planes in
+//    LDS -- which is what makes room for the weight slabs. beta, the rows and the column order are wave constants:
+//        i = 0: d0 - d2   i = 1: d1 + d2   i = 2: d2 - d1   i = 3: d1 - d3                  (ra, rb, beta) = (0,2,-) (1,2,+) (2,1,-) (1,3,-)
+//        jh = 0 (j = 0, 1): X = columns (0, 1, 2): q0 = X0 - X2 = V[i][0], q1 = X1 + X2 = V[i][1]
+//        jh = 1 (j = 3, 2): X = columns (3, 2, 1): q0 = X0 - X2 = -V[i][3], q1 = X1 - X2 = V[i][2]
+//    (the accumulator of q0 holds -M[i][3] in the second half; the in-wave part of the output transform takes the sign for free:
+//    b0 = a1, b1 = a0 - a1 instead of b0 = a0 + a1, b1 = a1); the main loop exists once per j half, so the column offsets are immediates;
+//  * weight fragments read from the slab (2 ds_read_b128 per use, consecutive lanes = consecutive 16 bytes): those of a phase's first
+//    use at the bottom of the phase before, those of a second use behind the first use's MFMAs;
+//  * the norm prologue act(scale x + shift), which a DMA cannot apply on the way: the lane that requested a slot rewrites it in place
+//    once its own counted wait says the slot has landed, at the bottom of the phase before the plane is first read;
+//  * MFMA operands swapped (A = weights, B = input): a lane holds 4 CONSECUTIVE output channels of one tile per accumulator quad, so
+//    the output-transform exchange is written with 8 ds_write_b128 per plane (rows padded to 36 floats: conflict-free) and read
+//    voxel-major with ds_read_b128; residual, normalised tensor (dgrad) and output move as 16-byte accesses; fused norm statistics as
+//    plain sums about a common shift, the 8 waves merged by Chan's formula once (`wino_fuse_records`);
+//  * workgroups are dealt so that an XCD gets a contiguous range of spatial tiles of one channel tile, walked in bricks of 8 z tiles,
+//    then x, then y (z neighbours share two of their four input planes, x neighbours the halo, in that XCD's L2).
 __device__ const float wino_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 template <int INMODE, int FUSE>
 __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_d8(WinoArgs a) {
   constexpr int TZ = 2, TY = 8, TX = 16, HY = TY + 2;
   constexpr int KC = 8;
+  // staged plane chunk: [channel quad][row][even columns | odd columns] in 16-byte groups. (Measured and not kept: [row][position][quad],
+  // the two quads of a voxel in adjacent request lanes = one cache line per lane pair, 2-way bank conflicts of the fragment reads:
+  // layer set -0.7 %, profiles/r5_wino_d8.txt.)
   constexpr int RS = 20;                                   // 16-byte groups per staged row: even columns 0..8 | pad | odd columns 10..18 | pad
   constexpr int QS = HY * RS + 4;                          // groups per channel quad (+ 4: the two quads of a voxel land on different banks)
   constexpr int XSF = 2 * QS * 4;                          // floats of one staged plane chunk (408 slots of 16 bytes = 8 waves x 51 lanes)
   constexpr int WSF = 16 * 2 * 32 * 4;                     // floats of one weight slab
   constexpr int PS = 36, PW = 2 * 32 * PS;                 // exchange: [wave][b][tile][32 channels + 4 pad]
-  static_assert(2 * QS == 8 * 51, "one DMA instruction per wave fills a staged plane chunk");
+  static_assert(XSF == 8 * 51 * 4, "one DMA instruction per wave fills a staged plane chunk");
   DYN_LDS(lds);
   float* xs = lds;                                         // ring of 4 staged plane chunks
   float* ws = lds + 4 * XSF;                               // 3 weight slabs
   float* P = lds;                                          // epilogue: output-transform exchange (reuses everything)
   float* prm = lds + 4 * XSF + 3 * WSF;                    // norm prologue of this sample: scale | shift | slope, CinP each
   const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6), half = lane >> 5, li = lane & 31;
-  // workgroup -> (channel tile, spatial tile): as conv3d_wino2d_w8 (an XCD gets a contiguous range of spatial tiles of one channel tile,
+  // workgroup -> (channel tile, spatial tile): an XCD (consecutive workgroup ids go round-robin to the 8 XCDs) gets a contiguous range of spatial tiles of one channel tile,
   // walked in bricks of WINO_ZBRICK z tiles, then x, y)
   int b = blockIdx.x, cot;
   {
@@ -829,7 +334,7 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_d8(Wi
 #else
 #define D8_PHASE_END(N) do { WAIT_VMCNT_LGKM0(N); RAW_BARRIER(); } while (0)
 #endif
-  // The main loop, once per j half (a scalar branch around it), as in conv3d_wino2d_r8.
+  // The main loop, once per j half (a scalar branch around it): JH is a compile-time constant inside.
   auto run = [&](auto jhc) {
     constexpr int JH = decltype(jhc)::value;
     auto b_lds = [&](float4 (&bu)[2], int dz) {
@@ -979,7 +484,7 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(4) void conv3d_wino2d_d8(Wi
 
   // ---- output transform Y = A^T M A, bias / residual / dropout scale, store ----
   // In-wave over the wave's two j (scalar branch on the j half), written to the exchange P[wave][b][tile][co] as 16-byte runs of the 4
-  // consecutive channels an accumulator quad holds; across the waves over i on the way out, voxel-major as in conv3d_wino2d_w8.
+  // consecutive channels an accumulator quad holds; across the waves over i on the way out, voxel-major.
   const int coq = tid & 7, ea = (wave >> 1) & 1;           // voxel rows: y = (tid >> 7) + 4 s -> a = y & 1 is wave-uniform
   const int co4 = co_base + 4 * coq;
   float bs[4], cs[4];
@@ -1173,24 +678,13 @@ extern "C" int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const 
            (!a.g.gnb || (a.g.gxld % 4 == 0 && !((uintptr_t)a.g.gx & 15)));
   const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return MI355_EINVAL;
-  const int lds_bytes = (8 * 2 * 32 * 32 + 3 * a.CinP) * (int)sizeof(float);      // exchange area (the main loop's buffers live inside it) + norm prologue
   const dim3 grid((unsigned)blocks), blk(512);
-#if WINO_D8
-  {
-    // conv3d_wino2d_d8: 4 staged plane chunks + 3 weight slabs (75 264 bytes; the padded exchange of the epilogue, 73 728, lives inside) + norm prologue
-    const int lds_d8 = (4 * 1632 + 3 * 4096 + 3 * a.CinP) * (int)sizeof(float);
-#define D8_LAUNCH(IM, FU) do { SET_MAX_DYN_LDS((conv3d_wino2d_d8<IM, FU>), lds_d8); LAUNCH((conv3d_wino2d_d8<IM, FU>), grid, blk, lds_d8, stream, a); } while (0)
-    if (a.g.mom) { if (d->in_mode == MI355_IN_PLAIN) D8_LAUNCH(MI355_IN_PLAIN, 1); else D8_LAUNCH(MI355_IN_AFFINE_ACT, 1); }
-    else if (a.g.gnb) D8_LAUNCH(MI355_IN_PLAIN, 2);
-    else if (d->in_mode == MI355_IN_PLAIN) D8_LAUNCH(MI355_IN_PLAIN, 0);
-    else D8_LAUNCH(MI355_IN_AFFINE_ACT, 0);
-#undef D8_LAUNCH
-    return LAUNCH_CHECK();
-  }
-#endif
+  // 4 staged plane chunks + 3 weight slabs (75 264 bytes; the padded exchange of the epilogue, 73 728, lives inside) + norm prologue: two
+  // workgroups per CU
+  const int lds_bytes = (4 * 1632 + 3 * 4096 + 3 * a.CinP) * (int)sizeof(float);
 #define WINO_LAUNCH(IM, FU)                                                                          \
-  do { SET_MAX_DYN_LDS((conv3d_wino2d_w8<IM, FU>), lds_bytes);                                         \
-       LAUNCH((conv3d_wino2d_w8<IM, FU>), grid, blk, lds_bytes, stream, a); } while (0)
+  do { SET_MAX_DYN_LDS((conv3d_wino2d_d8<IM, FU>), lds_bytes);                                         \
+       LAUNCH((conv3d_wino2d_d8<IM, FU>), grid, blk, lds_bytes, stream, a); } while (0)
   if (a.g.mom) {
     if (d->in_mode == MI355_IN_PLAIN) WINO_LAUNCH(MI355_IN_PLAIN, 1); else WINO_LAUNCH(MI355_IN_AFFINE_ACT, 1);
   } else if (a.g.gnb) {

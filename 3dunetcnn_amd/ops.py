@@ -426,7 +426,7 @@ class Backend:
             nvox = y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3]
             fuse = 1 if d.moments_out else (2 if gparts is not None else 0)
             self._prof_add("conv3d_wino2d", 2.0 * nvox * x.c * y.c * 27, 4.0 * (nvox * (x.c + y.c) + 27 * x.c * y.c), e0, e1,
-                           f"conv3d_wino2d_w8<{1 if in_mode == IN_AFFINE_ACT else 0}, {fuse}>",
+                           f"conv3d_wino2d_d8<{1 if in_mode == IN_AFFINE_ACT else 0}, {fuse}>",
                            4.0 * nvox * y.c * ((residual is not None) + (gparts is not None)))
         return self._fold_after(y, gparts)
 

@@ -66,9 +66,9 @@ def test_pmc_traffic_lookup_checks_provenance(tmp_path, monkeypatch):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from pmc_summary import kernel_source_hash
     body = ('Kernel,Calls,FETCH_SIZE_MiB_per_launch,WRITE_SIZE_MiB_per_launch,fetch_x2_MiB_per_launch,avg_ms_under_pmc\n'
-            '"void conv3d_wino2d_w8<0, 2>(WinoArgs)",100,348.84,183.80,697.69,0.6220\n'
-            '"void conv3d_wino2d_w8<1, 1>(WinoArgs)",84,279.22,135.53,558.45,0.5320\n'
-            '"void conv3d_wino2d_w8<1, 0>(WinoArgs)",16,592.89,275.63,1185.78,1.1347\n'
+            '"void conv3d_wino2d_d8<0, 2>(WinoArgs)",100,348.84,183.80,697.69,0.6220\n'
+            '"void conv3d_wino2d_d8<1, 1>(WinoArgs)",84,279.22,135.53,558.45,0.5320\n'
+            '"void conv3d_wino2d_d8<1, 0>(WinoArgs)",16,592.89,275.63,1185.78,1.1347\n'
             '"void conv3d_wgrad_wino_ring<1>(WWRArgs)",100,149.41,27.00,298.81,0.5333\n')
     good = tmp_path / "good.csv"
     good.write_text(f"# provenance: git_sha=abc kernel_source_sha256={kernel_source_hash()}\n" + body)
