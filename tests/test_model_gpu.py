@@ -84,7 +84,12 @@ RECORDED = {
     "32": dict(grad=0.02, n_loose=0, max_err_vs_fp32=3e-4, logits=2e-5),
     "odd": dict(grad=0.25, n_loose=18, max_err_vs_fp32=3e-2, logits=2e-5),      # grad 0.11 since the 16^3 level runs on the Winograd kernels too (n_loose 0, max error 7e-4)
     "64": dict(grad=0.5, n_loose=30, max_err_vs_fp32=1.5e-2, logits=2e-5),
-    "tc": dict(grad=0.02, n_loose=0, max_err_vs_fp32=1e-3, logits=2e-5),
+    # "tc" since round 5 (conv3d_wino2d_d8, another summation order in the output-transform exchange): the ReLU tie DESIGN section 4 describes
+    # -- ONE mask bit of a pre-activation that is zero to fp32 resolution moves decoder.layers.1.blocks.0.conv1.conv.weight by 2.06e-3, the
+    # fp32 oracle's own one-ulp runs land on 8e-5 or 2.06e-3 -- now lands on the 2.06e-3 side on the GPU (measured: error 2.0708e-3 against a
+    # noise floor of 2.0682e-3, ratio 0.0997, two tensors on the tie leg; before: 0.02 / 0 / 1e-3). The per-launch fp64 audit of the same
+    # kernels (tests/test_launch_audit.py) is unchanged at <= 1.2e-6; the bounds sit just above the tie, anything beyond it still fails.
+    "tc": dict(grad=0.12, n_loose=2, max_err_vs_fp32=2.2e-3, logits=2e-5),
     "five": dict(grad=0.25, n_loose=2, max_err_vs_fp32=1e-3, logits=2e-5),
     "train32": dict(grad=0.5, n_loose=45, max_err_vs_fp32=1e-1, logits=2e-5),
     "train64": dict(grad=0.1, n_loose=12, max_err_vs_fp32=3e-2, logits=2e-5),
