@@ -79,7 +79,7 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="disable the per-launch HIP events (roofline -> null)")
     ap.add_argument("--no-c3", action="store_true",
                     help="skip the short run of BASELINE configs[2]'s per-GPU shape (bf16 mixed, batch 4, 16-bit activation storage) that the "
-                         "default N=1 line carries under `c3` (a child process: python bench.py --config c3 --steps 5 --warmup 2)")
+                         "default N=1 line carries under `c3` (a child process: python bench.py --config c3 --steps 20 --warmup 5)")
     ap.add_argument("--no-precision-modes", action="store_true",
                     help="skip the short extra runs of the opt-in conv arithmetic modes (reported under precision_modes, N=1 only)")
     # TEST INFRASTRUCTURE (tests/test_bench_contract.py): run the launch / rank / reduce plumbing of this script on the CPU emulator
@@ -245,10 +245,11 @@ C3_KEYS = ("volumes_per_s_per_gpu", "ms_per_step", "workload", "activation_stora
            "mfma_pipe_frac", "hbm_frac", "traffic_over_algorithmic", "share_of_step", "per_rank_host_enqueue_ms_per_step", "command")
 
 
-def c3_block(steps=5, warmup=2, timeout=600):
+def c3_block(steps=20, warmup=5, timeout=600):
     """BASELINE configs[2] per GPU (the same model in bf16 mixed precision, batch 4 per GPU, 16-bit activation storage: the configuration
     the 8-GPU DDP run is quoted on, reference: AutocastUNet, segmentation/unet.py:53-58) measured by a CHILD process on this GPU after the
-    headline's timed region: `python bench.py --config c3 --steps 5 --warmup 2 --no-cpu-baseline`. A separate process because the step
+    headline's timed region: `python bench.py --config c3 --steps 20 --warmup 5 --no-cpu-baseline` (5 + 2 steps were measured 16 % slow: the
+    first steps of a fresh process run before the allocator and the clocks have settled, profiles/r5_c3_warmup.txt). A separate process because the step
     allocates the batch-4 activations of another network; its own line is what `--config c3` prints, this block keeps the figures a
     reader of the driver's line needs. Informational: never `value`."""
     import subprocess
@@ -604,26 +605,26 @@ def main():
             modes = {}
             for pm in ("bf16x6", "bf16x3", "bf16"):
                 be.set_precision(pm)
-                for _ in range(2):
-                    step()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
                 for _ in range(3):
                     step()
                 torch.cuda.synchronize()
-                dtm = (time.perf_counter() - t1) / 3
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    step()
+                torch.cuda.synchronize()
+                dtm = (time.perf_counter() - t1) / 5
                 modes[pm] = {"volumes_per_s": round(B / dtm, 3), "ms_per_step": round(dtm * 1e3, 2), "conv_arithmetic": ARITH[pm]}
                 if pm == "bf16" and args.model != "dynunet":
                     # ... and with 16-bit activation storage on top (what `--precision bf16` and `--config c3` run)
                     model.act_storage = torch.bfloat16
-                    for _ in range(2):
-                        step()
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
                     for _ in range(3):
                         step()
                     torch.cuda.synchronize()
-                    dtm = (time.perf_counter() - t1) / 3
+                    t1 = time.perf_counter()
+                    for _ in range(5):
+                        step()
+                    torch.cuda.synchronize()
+                    dtm = (time.perf_counter() - t1) / 5
                     model.act_storage = None
                     modes["bf16 + bf16 activation storage"] = {"volumes_per_s": round(B / dtm, 3), "ms_per_step": round(dtm * 1e3, 2),
                                                                "conv_arithmetic": ARITH[pm]}
