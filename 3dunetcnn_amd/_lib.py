@@ -46,7 +46,7 @@ IN_PLAIN, IN_AFFINE_ACT, IN_ZERO_INSERT, IN_S2D = 0, 1, 2, 3
 OUT_PLAIN, OUT_D2S = 0, 1
 W_PACKED, W_OIDHW4, W_PACKED_F32_NARROW = 0, 1, 2
 PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_BF16, PREC_F16 = 0, 1, 2, 3, 4
-ACT_F32, ACT_BF16 = 0, 1      # mi355_act.dtype
+ACT_F32, ACT_BF16, ACT_F16 = 0, 1, 2      # mi355_act.dtype
 PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "bf16": PREC_BF16, "fp16": PREC_F16}
 
 STATUS = {0: "ok", -1: "invalid argument (shape/alignment/null)", -2: "unsupported combination",

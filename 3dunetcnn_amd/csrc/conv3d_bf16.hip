@@ -38,7 +38,7 @@ void conv3d_k3_bf16(ConvBArgs a) {
   TA* const ay = reinterpret_cast<TA*>(a.y);
   const TA* const ares = reinterpret_cast<const TA*>(a.res);
   const TA* const agx = reinterpret_cast<const TA*>(a.g.gx);
-  constexpr bool RAW16 = std::is_same<TA, bf16_t>::value && INMODE == MI355_IN_PLAIN && NS == 1 && !F16;      // staged values ARE the stored ones
+  constexpr bool RAW16 = lp_storage_is_operand<TA, F16>::value && INMODE == MI355_IN_PLAIN && NS == 1;      // staged values ARE the stored ones
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TZ * TY / 2 == WM * MT, "M tiles (2 x-rows of 16 voxels) must equal WM*MT");
   constexpr int TX = 16;
@@ -585,7 +585,7 @@ int mi355_conv3d_bf16_kernel_name(const mi355_act* x, const mi355_act* y, const 
   const char* f16 = d->precision == MI355_PREC_F16 ? "true" : "false";
   const LpZPlan zp = plan_lp_zring(x->n, x->c, y->c, d->out_d, d->out_h, d->out_w, d->precision, d, x->dtype);
   if (zp.use && y->d == d->out_d && y->h == d->out_h && y->w == d->out_w && x->d == d->out_d && x->h == d->out_h && x->w == d->out_w) {
-    const char* st = x->dtype == MI355_ACT_BF16 ? "unsigned short" : "float";
+    const char* st = x->dtype == MI355_ACT_BF16 ? "unsigned short" : (x->dtype == MI355_ACT_F16 ? "f16_t" : "float");
     if (zp.use == 1) snprintf(out, n, "conv3d_k3_lp_zring<2, %d, %d, %s, %s>", d->in_mode, fuse, f16, st);
     else snprintf(out, n, "conv3d_k3_lp_zring2<2, %d, %d, %d, %s, %s>", zp.ks, d->in_mode, fuse, f16, st);
     return 0;
@@ -596,7 +596,7 @@ int mi355_conv3d_bf16_kernel_name(const mi355_act* x, const mi355_act* y, const 
   const char* tile = big ? (wide ? "4, 4, %d, %d, 4, 1, 2, 2" : "4, 4, %d, %d, 4, 1, 2, 1") : (wide ? "2, 4, %d, %d, 2, 2, 2, 1" : "2, 4, %d, %d, 4, 1, 1, 1");
   char t[64];
   snprintf(t, sizeof(t), tile, J, ns);
-  snprintf(out, n, "conv3d_k3_bf16<%s, %d, %d, %s, %s>", t, d->in_mode, fuse, f16, x->dtype == MI355_ACT_BF16 ? "unsigned short" : "float");
+  snprintf(out, n, "conv3d_k3_bf16<%s, %d, %d, %s, %s>", t, d->in_mode, fuse, f16, x->dtype == MI355_ACT_BF16 ? "unsigned short" : (x->dtype == MI355_ACT_F16 ? "f16_t" : "float"));
   return 0;
 }
 
@@ -606,8 +606,8 @@ int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_a
   if (!ns || d->kd != 3 || d->stride != 1) return MI355_EUNSUPPORTED;
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
   if (x->dtype != y->dtype) return MI355_EUNSUPPORTED;
-  const bool lp = x->dtype == MI355_ACT_BF16;
-  if (lp && d->precision != MI355_PREC_BF16) return MI355_EUNSUPPORTED;      // bf16 storage goes with bf16 operands
+  const bool lp = act_is_lp16(x->dtype);
+  if (!act_matches_precision(x->dtype, d->precision)) return MI355_EUNSUPPORTED;      // 16-bit storage goes with operands of its own type
   if (lp && (((uintptr_t)y->p & 1) || ((uintptr_t)x->p & 7))) return MI355_EINVAL;
   ConvBArgs a;
   memset(&a.g, 0, sizeof(a.g));
@@ -648,7 +648,8 @@ int mi355_conv3d_fwd_bf16_impl(const mi355_act* x, const void* wp, const mi355_a
     }
     return mi355_lp_zring_launch(a, d->in_mode, fuse, f16, lp, blocks, stream);
   }
-  if (lp) return dispatch_ns<1, false, bf16_t>(a, d->in_mode, vox, stream);
+  if (x->dtype == MI355_ACT_BF16) return dispatch_ns<1, false, bf16_t>(a, d->in_mode, vox, stream);
+  if (x->dtype == MI355_ACT_F16) return dispatch_ns<1, true, f16_t>(a, d->in_mode, vox, stream);
   if (d->precision == MI355_PREC_F16) return dispatch_ns<1, true>(a, d->in_mode, vox, stream);
   if (ns == 1) return dispatch_ns<1>(a, d->in_mode, vox, stream);
   if (ns == 2) return dispatch_ns<2>(a, d->in_mode, vox, stream);

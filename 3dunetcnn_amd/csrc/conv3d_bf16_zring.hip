@@ -27,8 +27,8 @@
 // TA: storage type of x, y, the residual and the normalised tensor of the norm-backward sums (act_io.h; bf16 storage with bf16 operands only).
 template <int J, int INMODE, int FUSE, bool F16, typename TA = float>
 __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring(ConvBArgs a) {
-  constexpr bool LPS = std::is_same<TA, bf16_t>::value;      // 16-bit storage: a staging unit is one 16-byte run of 8 channels
-  static_assert(!LPS || !F16, "bf16 storage goes with bf16 operands");
+  constexpr bool LPS = is_lp16<TA>::value;      // 16-bit storage: a staging unit is one 16-byte run of 8 channels
+  static_assert(!LPS || lp_storage_is_operand<TA, F16>::value, "16-bit storage goes with operands of its own type");
   constexpr int TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HVP = HY * HX;      // haloed plane: 180 voxels
   constexpr int OCT = 2 * J;                 // channel octets of the (padded) input: 2 (16 channels) or 4 (32)
   constexpr int VSQ = OCT + 1;               // voxel stride in 16-byte units (odd)
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring(Conv
     if constexpr (LPS) {
       const float4 q = ld[k][0];
       const unsigned w = __float_as_uint((e >> 1) == 0 ? q.x : (e >> 1) == 1 ? q.y : (e >> 1) == 2 ? q.z : q.w);
-      v = (e & 1) ? bf16hi_to_f32(w) : bf16lo_to_f32(w);
+      v = (e & 1) ? lp_hi<TA>(w) : lp_lo<TA>(w);
     } else {
       const float4 q = ld[k][e >> 2];
       v = (e & 3) == 0 ? q.x : (e & 3) == 1 ? q.y : (e & 3) == 2 ? q.z : q.w;
@@ -324,8 +324,8 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring(Conv
 // (a plain input goes to the ring as loaded, no conversion), outputs are rounded once on store, moments are taken over the values as stored.
 template <int J, int KS, int INMODE, int FUSE, bool F16, typename TA = float>
 __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring2(ConvBArgs a) {
-  constexpr bool LPS = std::is_same<TA, bf16_t>::value;      // 16-bit storage
-  static_assert(!LPS || !F16, "bf16 storage goes with bf16 operands");
+  constexpr bool LPS = is_lp16<TA>::value;      // 16-bit storage
+  static_assert(!LPS || lp_storage_is_operand<TA, F16>::value, "16-bit storage goes with operands of its own type");
   constexpr int TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HVP = HY * HX;      // haloed plane: 180 voxels
   constexpr int MT = KS;                     // M tiles (two x-rows of 16 voxels) per wave
   constexpr int CT = KS * 16 * J;            // channels of a staged plane (the padded input)
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void conv3d_k3_lp_zring2(Con
       if constexpr (INMODE == MI355_IN_PLAIN) {              // the operand IS the stored value
         return (pin && uin[k] && (e2 < 2 ? v0ok : v1ok)) ? w : 0u;
       }
-      v0 = bf16lo_to_f32(w); v1 = bf16hi_to_f32(w);
+      v0 = lp_lo<TA>(w); v1 = lp_hi<TA>(w);
     } else {
       const float4 q = ld[k][e2 >> 1];
       v0 = (e2 & 1) ? q.z : q.x; v1 = (e2 & 1) ? q.w : q.y;
@@ -739,13 +739,12 @@ int mi355_lp_zring_launch(ConvBArgs& a, int in_mode, int fuse, bool f16, bool lp
   do { SET_MAX_DYN_LDS((conv3d_k3_lp_zring<JJ, IM, FU, HF, TT>), lds_bytes);                              \
        LAUNCH((conv3d_k3_lp_zring<JJ, IM, FU, HF, TT>), grid, blk, lds_bytes, stream, a); } while (0)
 #define LPZ_LAUNCH(JJ, IM, FU, HF)                                                                          \
-  do { if constexpr (!(HF)) { if (lps) { LPZ_LAUNCH_T(JJ, IM, FU, false, bf16_t); break; } }                \
+  do { if (lps) { if constexpr (HF) LPZ_LAUNCH_T(JJ, IM, FU, true, f16_t); else LPZ_LAUNCH_T(JJ, IM, FU, false, bf16_t); break; } \
        LPZ_LAUNCH_T(JJ, IM, FU, HF, float); } while (0)
 #define LPZ_FUSE(JJ, HF)                                                                                    \
   do { if (fuse == 1) { if (norm) LPZ_LAUNCH(JJ, MI355_IN_AFFINE_ACT, 1, HF); else LPZ_LAUNCH(JJ, MI355_IN_PLAIN, 1, HF); } \
        else if (fuse == 2) LPZ_LAUNCH(JJ, MI355_IN_PLAIN, 2, HF);                                         \
        else if (norm) LPZ_LAUNCH(JJ, MI355_IN_AFFINE_ACT, 0, HF); else LPZ_LAUNCH(JJ, MI355_IN_PLAIN, 0, HF); } while (0)
-  if (lps && f16) return MI355_EUNSUPPORTED;
   if (f16) LPZ_FUSE(2, true); else LPZ_FUSE(2, false);
 #undef LPZ_FUSE
 #undef LPZ_LAUNCH
@@ -764,7 +763,7 @@ int mi355_lp_zring2_launch(ConvBArgs& a, int ks, int in_mode, int fuse, bool f16
        SET_MAX_DYN_LDS((conv3d_k3_lp_zring2<2, KSV, IM, FU, HF, TT>), lb);                                 \
        LAUNCH((conv3d_k3_lp_zring2<2, KSV, IM, FU, HF, TT>), grid2, blk2, lb, stream, a); } while (0)
 #define LPZ2_LAUNCH(KSV, IM, FU, HF)                                                                          \
-  do { if constexpr (!(HF)) { if (lps) { LPZ2_LAUNCH_T(KSV, IM, FU, false, bf16_t); break; } }                \
+  do { if (lps) { if constexpr (HF) LPZ2_LAUNCH_T(KSV, IM, FU, true, f16_t); else LPZ2_LAUNCH_T(KSV, IM, FU, false, bf16_t); break; } \
        LPZ2_LAUNCH_T(KSV, IM, FU, HF, float); } while (0)
 #define LPZ2_FUSE(KSV, HF)                                                                                    \
   do { if (fuse == 1) { if (norm) LPZ2_LAUNCH(KSV, MI355_IN_AFFINE_ACT, 1, HF); else LPZ2_LAUNCH(KSV, MI355_IN_PLAIN, 1, HF); } \
@@ -772,7 +771,6 @@ int mi355_lp_zring2_launch(ConvBArgs& a, int ks, int in_mode, int fuse, bool f16
        else if (norm) LPZ2_LAUNCH(KSV, MI355_IN_AFFINE_ACT, 0, HF); else LPZ2_LAUNCH(KSV, MI355_IN_PLAIN, 0, HF); } while (0)
   // (no norm-backward form: plan_lp_zring routes those calls to conv3d_k3_lp_zring where it applies and answers the statistics query
   // with 0 otherwise -- the sums then take their own pass and the conv runs here with the plain epilogue)
-  if (lps && f16) return MI355_EUNSUPPORTED;
   if (ks == 1) { if (f16) LPZ2_FUSE(1, true); else LPZ2_FUSE(1, false); }
   else { if (f16) LPZ2_FUSE(2, true); else LPZ2_FUSE(2, false); }
 #undef LPZ2_FUSE

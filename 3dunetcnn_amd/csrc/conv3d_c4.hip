@@ -587,9 +587,10 @@ int mi355_conv3d_c4_fwd_impl(const mi355_act* x, const float* w, const mi355_act
     const long long wg = cols * a.splits;
     if (wg > 0x7fffffffLL) return MI355_EINVAL;
     const int ns = d->precision == MI355_PREC_BF16X3 ? 2 : (d->precision == MI355_PREC_BF16X6 ? 3 : 1);
-    if (y->dtype == MI355_ACT_BF16 && d->precision != MI355_PREC_BF16) return MI355_EUNSUPPORTED;      // bf16 storage goes with bf16 operands
+    if (!act_matches_precision(y->dtype, d->precision)) return MI355_EUNSUPPORTED;      // 16-bit storage goes with operands of its own type
 #define MI355_C4B(NSV, IM, FU) \
-    do { if (d->precision == MI355_PREC_F16) LAUNCH((conv3d_c4_fwd_bf16<NSV == 1 ? 1 : NSV, IM, FU, NSV == 1>), dim3((unsigned)wg), dim3(256), 0, stream, a); \
+    do { if (y->dtype == MI355_ACT_F16) LAUNCH((conv3d_c4_fwd_bf16<1, IM, FU, true, f16_t>), dim3((unsigned)wg), dim3(256), 0, stream, a); \
+         else if (d->precision == MI355_PREC_F16) LAUNCH((conv3d_c4_fwd_bf16<NSV == 1 ? 1 : NSV, IM, FU, NSV == 1>), dim3((unsigned)wg), dim3(256), 0, stream, a); \
          else if (y->dtype == MI355_ACT_BF16) LAUNCH((conv3d_c4_fwd_bf16<1, IM, FU, false, bf16_t>), dim3((unsigned)wg), dim3(256), 0, stream, a); \
          else LAUNCH((conv3d_c4_fwd_bf16<NSV, IM, FU>), dim3((unsigned)wg), dim3(256), 0, stream, a); } while (0)
 #define MI355_C4B_NS(NSV)                                                                                  \

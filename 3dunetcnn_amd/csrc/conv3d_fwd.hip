@@ -51,7 +51,7 @@ constexpr int conv_min_waves(int tiles, bool tl, int wn, bool fullj) {
   return tiles == 1 ? 4 : tiles == 2 ? (wn == 2 ? 4 : fullj ? 3 : 2) : 2;
 }
 
-// TA: storage type of x, y, the residual and the normalised tensor of the norm-backward sums (act_io.h: float, or bf16_t for the
+// TA: storage type of x, y, the residual and the normalised tensor of the norm-backward sums (act_io.h: float, or bf16_t / f16_t for the
 // HBM-bound forms a network with 16-bit activation storage runs here: 1x1x1, stride 2, zero-insert). The 16-bit forms keep fp32 MFMA
 // operands -- the staged values are widened on load -- and round once, on store; statistics are taken over the values as stored.
 template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, int WN, int MT, int NT, int INMODE, bool TL = false, bool FULLJ = false, int FUSE = 0,
@@ -830,7 +830,7 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
   if (!x || !y || !wp || !d || !x->p || !y->p) return MI355_EINVAL;
   if ((d->kd != 1 && d->kd != 3) || (d->stride != 1 && d->stride != 2)) return MI355_EUNSUPPORTED;
   if (x->c % 4 || x->ld % 4 || x->ld < x->c || y->ld < y->c || x->n != y->n || !act_dtype_ok(x) || !act_dtype_ok(y)) return MI355_EINVAL;
-  if (((uintptr_t)x->p & (x->dtype == MI355_ACT_BF16 ? 7 : 15)) || ((uintptr_t)wp & 15)) return MI355_EINVAL;
+  if (((uintptr_t)x->p & act_align_mask(x->dtype)) || ((uintptr_t)wp & 15)) return MI355_EINVAL;
   if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift)) return MI355_EINVAL;
   if (d->in_mode == MI355_IN_AFFINE_ACT && !(d->act_slope >= 0.f && d->act_slope <= 1.f)) return MI355_EINVAL;   // act(u) = max(u, slope*u)
   if (d->in_mode < 0 || d->in_mode > 3) return MI355_EINVAL;
@@ -850,7 +850,7 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
   }
   if (d->in_mode == MI355_IN_ZERO_INSERT && (d->stride != 1 || d->kd != 3 || d->pad != 1)) return MI355_EINVAL;
   if (x->dtype != y->dtype) return MI355_EUNSUPPORTED;      // one storage type per call here (the first-layer kernels above take fp32 x with either y)
-  const bool lp = x->dtype == MI355_ACT_BF16;
+  const bool lp = act_is_lp16(x->dtype);
   if (lp && (y->c % 4 || y->ld % 4 || ((uintptr_t)y->p & 7))) return MI355_EINVAL;
   ConvArgs a;
   a.x = (const float*)x->p; a.xld = x->ld; a.wp = wp; a.y = (float*)y->p; a.yld = y->ld;
@@ -890,20 +890,25 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
     if (vin != vout || vy != vout || a.offz || a.offy || a.offx || vin > 0x7fffffffLL) return MI355_EUNSUPPORTED;
     f.Di = f.Hi = 1; f.Wi = (int)vin; f.Do = f.Ho = 1; f.Wo = (int)vout; f.yD = f.yH = 1; f.yW = (int)vy; f.pad = 0;
     if (lp) {
-      if (cfg1 == 0) return launch_cfg<1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 2, bf16_t>(f, im, stream);
-      return launch_cfg<1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 1, bf16_t>(f, im, stream);
+      int rc1 = MI355_EUNSUPPORTED;
+      ACT_TYPED_LP16(x->dtype, T16, rc1 = cfg1 == 0 ? (launch_cfg<1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 2, T16>(f, im, stream))
+                                                     : (launch_cfg<1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 1, T16>(f, im, stream)));
+      return rc1;
     }
     if (cfg1 == 0) return launch_cfg<1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 2>(f, im, stream);
     return launch_cfg<1, 1, 1, 1, 256, 32, 4, 4, 1, 2, 1>(f, im, stream);
   }
   if (lp) {
-    switch (cfg) {      // (16-bit storage with exact-fp32 3x3x3 stride-1 arithmetic: no such kernel, act_form_exists)
-      case 2: return launch_cfg<3, 2, 4, 4, 8, 8, 0, 4, 1, 1, 2, bf16_t>(a, im, stream);
-      case 3: return launch_cfg<3, 2, 4, 4, 8, 8, 0, 4, 1, 1, 1, bf16_t>(a, im, stream);
-      case 4: return launch_cfg<3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 2, bf16_t>(a, im, stream);
-      case 5: return launch_cfg<3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 1, bf16_t>(a, im, stream);
-      default: return MI355_EUNSUPPORTED;
-    }
+    int rcl = MI355_EUNSUPPORTED;      // (16-bit storage with exact-fp32 3x3x3 stride-1 arithmetic: no such kernel, act_form_exists)
+    ACT_TYPED_LP16(x->dtype, T16,
+      switch (cfg) {
+        case 2: rcl = (launch_cfg<3, 2, 4, 4, 8, 8, 0, 4, 1, 1, 2, T16>(a, im, stream)); break;
+        case 3: rcl = (launch_cfg<3, 2, 4, 4, 8, 8, 0, 4, 1, 1, 1, T16>(a, im, stream)); break;
+        case 4: rcl = (launch_cfg<3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 2, T16>(a, im, stream)); break;
+        case 5: rcl = (launch_cfg<3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 1, T16>(a, im, stream)); break;
+        default: break;
+      });
+    return rcl;
   }
   switch (cfg) {
     case 2: return launch_cfg<3, 2, 4, 4, 8, 8, 0, 4, 1, 1, 2>(a, im, stream);

@@ -537,7 +537,7 @@ extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float
                                   void* ws, size_t ws_bytes, void* stream) {
   if (!x || !dy || !dw || !d || !ws || !x->p || !dy->p) return MI355_EINVAL;
   if (x->c % 4 || x->ld % 4 || dy->c % 4 || dy->ld % 4 || x->n != dy->n || !act_dtype_ok(x) || !act_dtype_ok(dy)) return MI355_EINVAL;
-  if (((uintptr_t)x->p & (x->dtype == MI355_ACT_BF16 ? 7 : 15)) || ((uintptr_t)dy->p & (dy->dtype == MI355_ACT_BF16 ? 7 : 15))) return MI355_EINVAL;
+  if (((uintptr_t)x->p & act_align_mask(x->dtype)) || ((uintptr_t)dy->p & act_align_mask(dy->dtype))) return MI355_EINVAL;
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
   if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift)) return MI355_EINVAL;
   if (d->in_mode == MI355_IN_AFFINE_ACT && !(d->act_slope >= 0.f && d->act_slope <= 1.f)) return MI355_EINVAL;

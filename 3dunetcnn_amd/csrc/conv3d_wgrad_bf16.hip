@@ -453,7 +453,7 @@ static WBPlan plan_wb(const mi355_act* x, const mi355_act* dy, const mi355_conv_
   WBPlan p; memset(&p, 0, sizeof(p));
   if (!x || !dy || !d || !nsplit_of_w(d->precision)) return p;
   if (d->kd != 3 || d->stride != 1 || d->pad != 1) return p;
-  if (x->dtype != dy->dtype || (x->dtype == MI355_ACT_BF16 && d->precision != MI355_PREC_BF16)) return p;      // bf16 storage goes with bf16 operands
+  if (x->dtype != dy->dtype || !act_matches_precision(x->dtype, d->precision)) return p;      // 16-bit storage goes with operands of its own type
   if (x->d != dy->d || x->h != dy->h || x->w != dy->w) return p;
   p.tilesY = ceil_div(dy->h, 4); p.tilesX = ceil_div(dy->w, 16);
   const long long nt = (long long)dy->n * p.tilesY * p.tilesX * dy->d;
@@ -511,6 +511,7 @@ int mi355_conv3d_wgrad_bf16_impl(const mi355_act* x, const mi355_act* dy, float*
   const int ns = nsplit_of_w(d->precision);
   int rc;
   if (x->dtype == MI355_ACT_BF16) rc = p.mt == 2 ? launch_wb<1, 2, false, bf16_t>(a, p, d->in_mode, stream) : launch_wb<1, 1, false, bf16_t>(a, p, d->in_mode, stream);
+  else if (x->dtype == MI355_ACT_F16) rc = p.mt == 2 ? launch_wb<1, 2, true, f16_t>(a, p, d->in_mode, stream) : launch_wb<1, 1, true, f16_t>(a, p, d->in_mode, stream);
   else if (d->precision == MI355_PREC_F16) rc = p.mt == 2 ? launch_wb<1, 2, true>(a, p, d->in_mode, stream) : launch_wb<1, 1, true>(a, p, d->in_mode, stream);
   else if (p.mt == 2) rc = ns == 1 ? launch_wb<1, 2>(a, p, d->in_mode, stream) : launch_wb<2, 2>(a, p, d->in_mode, stream);
   else rc = ns == 1 ? launch_wb<1, 1>(a, p, d->in_mode, stream) : ns == 2 ? launch_wb<2, 1>(a, p, d->in_mode, stream) : launch_wb<3, 1>(a, p, d->in_mode, stream);

@@ -128,3 +128,11 @@ template <bool F16> __device__ __forceinline__ f32x16 mfma_lp(const uint4& a, co
 // value of the bf16 stored in the low / high half of a packed dword
 __device__ __forceinline__ float bf16lo_to_f32(unsigned p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+// value of the IEEE fp16 stored in the low / high half of a packed dword (v_cvt_f32_f16)
+#ifdef MI355_EMU
+static inline float f16lo_to_f32(unsigned p) { return emu_h2f(p & 0xffffu); }
+static inline float f16hi_to_f32(unsigned p) { return emu_h2f(p >> 16); }
+#else
+__device__ __forceinline__ float f16lo_to_f32(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
+__device__ __forceinline__ float f16hi_to_f32(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
+#endif

@@ -381,7 +381,7 @@ extern "C" size_t mi355_gn_workspace(const mi355_act* x) {
 static int gn_check(const mi355_act* x, int groups) {
   if (!x || !x->p || x->c % 4 || x->ld % 4 || x->ld < x->c || groups <= 0 || x->c % groups || !act_dtype_ok(x)) return MI355_EINVAL;
   if (x->c / 4 > 256 || x->c / groups > 1024) return MI355_EUNSUPPORTED;
-  if ((uintptr_t)x->p & (x->dtype == MI355_ACT_BF16 ? 7 : 15)) return MI355_EINVAL;
+  if ((uintptr_t)x->p & act_align_mask(x->dtype)) return MI355_EINVAL;
   return 0;
 }
 
@@ -398,7 +398,7 @@ extern "C" int mi355_gn_moments(const mi355_act* x, float* out, void* stream) {
   const int B = gn_blocks_per_sample(V), C = x->c;
   if (act_vw8(x)) {
     const int Q = C / 8, R = 256 / Q > 0 ? 256 / Q : 1;
-    LAUNCH((gn_moments_kernel<bf16_t, 8>), dim3(B, x->n), dim3(Q * R), (size_t)Q * R * 16 * sizeof(float), stream, (const bf16_t*)x->p, x->ld, V, C, Q, R, out);
+    ACT_TYPED_LP16(x->dtype, T, LAUNCH((gn_moments_kernel<T, 8>), dim3(B, x->n), dim3(Q * R), (size_t)Q * R * 16 * sizeof(float), stream, (const T*)x->p, x->ld, V, C, Q, R, out));
   } else {
     const int Q = C / 4, R = 256 / Q > 0 ? 256 / Q : 1;
     ACT_TYPED(x->dtype, T, LAUNCH((gn_moments_kernel<T, 4>), dim3(B, x->n), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream, (const T*)x->p, x->ld, V, C, Q, R, out));
@@ -447,7 +447,7 @@ static int gn_act_bwd_impl(const mi355_act* x, const mi355_act* dA, const mi355_
   int rc = gn_check(x, groups);
   if (rc) return rc;
   if (!dA || !dx || !dA->p || !dx->p || !mean_rstd || !scale || !shift || !ws) return MI355_EINVAL;
-  const uintptr_t amask = x->dtype == MI355_ACT_BF16 ? 7 : 15;
+  const uintptr_t amask = act_align_mask(x->dtype);
   if (dA->c != x->c || dx->c != x->c || dA->ld % 4 || dx->ld % 4 || ((uintptr_t)dA->p & amask) || ((uintptr_t)dx->p & amask)) return MI355_EINVAL;
   if (dA->dtype != x->dtype || dx->dtype != x->dtype) return MI355_EUNSUPPORTED;      // a tensor's gradient has the tensor's storage type
   if (addend && (addend_ld % 4 || ((uintptr_t)addend & amask))) return MI355_EINVAL;
@@ -464,8 +464,8 @@ static int gn_act_bwd_impl(const mi355_act* x, const mi355_act* dA, const mi355_
   } else {
     if (act_vw8(x) && act_vw8(dA)) {
       const int Q8 = C / 8, R8 = 256 / Q8 > 0 ? 256 / Q8 : 1;
-      LAUNCH((gn_bwd_partial_kernel<bf16_t, 8>), dim3(B, N), dim3(Q8 * R8), (size_t)Q8 * R8 * 16 * sizeof(float), stream,
-             (const bf16_t*)x->p, x->ld, (const bf16_t*)dA->p, dA->ld, V, C, Q8, R8, groups, act_slope, mean_rstd, scale, shift, part);
+      ACT_TYPED_LP16(x->dtype, T, LAUNCH((gn_bwd_partial_kernel<T, 8>), dim3(B, N), dim3(Q8 * R8), (size_t)Q8 * R8 * 16 * sizeof(float), stream,
+             (const T*)x->p, x->ld, (const T*)dA->p, dA->ld, V, C, Q8, R8, groups, act_slope, mean_rstd, scale, shift, part));
     } else {
       ACT_TYPED(x->dtype, T, LAUNCH((gn_bwd_partial_kernel<T, 4>), dim3(B, N), dim3(Q * R), (size_t)Q * R * 8 * sizeof(float), stream,
                                     (const T*)x->p, x->ld, (const T*)dA->p, dA->ld, V, C, Q, R, groups, act_slope, mean_rstd, scale, shift, part));
@@ -485,8 +485,8 @@ static int gn_act_bwd_impl(const mi355_act* x, const mi355_act* dA, const mi355_
   if (vw8) {
     const long long total8 = (long long)N * V * (C / 8);
     long long grid8 = (total8 + 255) / 256; if (grid8 > 8192) grid8 = 8192;
-    LAUNCH((gn_bwd_apply_kernel<bf16_t, 8>), dim3((unsigned)grid8), dim3(256), 0, stream, (const bf16_t*)x->p, x->ld, (const bf16_t*)dA->p, dA->ld,
-           (bf16_t*)dx->p, dx->ld, (const bf16_t*)addend, addend_ld, V, C, N, act_slope, scale, shift, (const float*)coef);
+    ACT_TYPED_LP16(x->dtype, T, LAUNCH((gn_bwd_apply_kernel<T, 8>), dim3((unsigned)grid8), dim3(256), 0, stream, (const T*)x->p, x->ld, (const T*)dA->p, dA->ld,
+           (T*)dx->p, dx->ld, (const T*)addend, addend_ld, V, C, N, act_slope, scale, shift, (const float*)coef));
   } else {
     ACT_TYPED(x->dtype, T, LAUNCH((gn_bwd_apply_kernel<T, 4>), dim3((unsigned)grid), dim3(256), 0, stream, (const T*)x->p, x->ld, (const T*)dA->p, dA->ld,
                                   (T*)dx->p, dx->ld, (const T*)addend, addend_ld, V, C, N, act_slope, scale, shift, (const float*)coef));

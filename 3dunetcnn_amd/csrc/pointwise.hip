@@ -109,8 +109,8 @@ extern "C" int mi355_upsample2x_fwd(const mi355_act* lo, const mi355_act* cat, i
   if (lo->dtype != cat->dtype) return MI355_EUNSUPPORTED;
   const long long total = (long long)cat->n * cat->d * cat->h * cat->w * (cat->c / 4);
   if (act_vw8(lo) && act_vw8(cat))
-    LAUNCH((upsample2x_fwd_kernel<bf16_t, 8>), dim3(grid_for(total / 2)), dim3(256), 0, stream, (const bf16_t*)lo->p, lo->ld, lo->n, lo->d, lo->h,
-           lo->w, lo->c, (bf16_t*)cat->p, cat->ld, cat->d, cat->h, cat->w, offz, offy, offx);
+    ACT_TYPED_LP16(lo->dtype, T, LAUNCH((upsample2x_fwd_kernel<T, 8>), dim3(grid_for(total / 2)), dim3(256), 0, stream, (const T*)lo->p, lo->ld, lo->n, lo->d, lo->h,
+           lo->w, lo->c, (T*)cat->p, cat->ld, cat->d, cat->h, cat->w, offz, offy, offx));
   else
     ACT_TYPED(lo->dtype, T, LAUNCH((upsample2x_fwd_kernel<T, 4>), dim3(grid_for(total)), dim3(256), 0, stream, (const T*)lo->p, lo->ld, lo->n, lo->d, lo->h,
                                    lo->w, lo->c, (T*)cat->p, cat->ld, cat->d, cat->h, cat->w, offz, offy, offx));
@@ -122,8 +122,8 @@ extern "C" int mi355_upsample2x_bwd(const mi355_act* dcat, const mi355_act* dlo,
   if (dlo->dtype != dcat->dtype) return MI355_EUNSUPPORTED;
   const long long total = (long long)dlo->n * dlo->d * dlo->h * dlo->w * (dlo->c / 4);
   if (act_vw8(dlo) && act_vw8(dcat))
-    LAUNCH((upsample2x_bwd_kernel<bf16_t, 8>), dim3(grid_for(total / 2)), dim3(256), 0, stream, (const bf16_t*)dcat->p, dcat->ld, dcat->n, dcat->d,
-           dcat->h, dcat->w, dcat->c, (bf16_t*)dlo->p, dlo->ld, dlo->d, dlo->h, dlo->w, offz, offy, offx);
+    ACT_TYPED_LP16(dlo->dtype, T, LAUNCH((upsample2x_bwd_kernel<T, 8>), dim3(grid_for(total / 2)), dim3(256), 0, stream, (const T*)dcat->p, dcat->ld, dcat->n, dcat->d,
+           dcat->h, dcat->w, dcat->c, (T*)dlo->p, dlo->ld, dlo->d, dlo->h, dlo->w, offz, offy, offx));
   else
     ACT_TYPED(dlo->dtype, T, LAUNCH((upsample2x_bwd_kernel<T, 4>), dim3(grid_for(total)), dim3(256), 0, stream, (const T*)dcat->p, dcat->ld, dcat->n, dcat->d,
                                     dcat->h, dcat->w, dcat->c, (T*)dlo->p, dlo->ld, dlo->d, dlo->h, dlo->w, offz, offy, offx));
@@ -227,8 +227,8 @@ extern "C" int mi355_chscale(const mi355_act* x, const float* chscale, const mi3
   if (x->dtype != y->dtype) return MI355_EUNSUPPORTED;
   const long long V = (long long)x->d * x->h * x->w;
   if (act_vw8(x) && act_vw8(y))
-    LAUNCH((chscale_kernel<bf16_t, 8>), dim3(grid_for((long long)x->n * V * (x->c / 8))), dim3(256), 0, stream, (const bf16_t*)x->p, x->ld, chscale,
-           (bf16_t*)y->p, y->ld, V, x->n, x->c);
+    ACT_TYPED_LP16(x->dtype, T, LAUNCH((chscale_kernel<T, 8>), dim3(grid_for((long long)x->n * V * (x->c / 8))), dim3(256), 0, stream, (const T*)x->p, x->ld, chscale,
+           (T*)y->p, y->ld, V, x->n, x->c));
   else
     ACT_TYPED(x->dtype, T, LAUNCH((chscale_kernel<T, 4>), dim3(grid_for((long long)x->n * V * (x->c / 4))), dim3(256), 0, stream, (const T*)x->p, x->ld, chscale,
                                   (T*)y->p, y->ld, V, x->n, x->c));

@@ -18,15 +18,18 @@ from ._lib import (IN_AFFINE_ACT, IN_PLAIN, IN_S2D, IN_ZERO_INSERT, OUT_D2S, OUT
                    W_PACKED, W_PACKED_F32_NARROW, MiAct, MiConvDesc, MiDiceOpts, MiGnBwdFuse, check)
 
 
+ACT_DTYPES = {torch.float32: _lib.ACT_F32, torch.bfloat16: _lib.ACT_BF16, torch.float16: _lib.ACT_F16}      # storage types of an activation view
+
+
 class Act:
     """`mom`: None, or the partial-moment records of this view's channels as a list of (records [N, B, c, 3], B, c) sources in
     channel order -- written by the epilogue of the conv that produced the tensor (Backend.conv_fwd(moments=True)) or by
     Backend.moments(); Backend.gn_stats finalises them instead of reading the tensor again.
-    Storage type: the buffer's dtype, torch.float32 or torch.bfloat16 (mi355_act.dtype; HipAutocastUNet(activation_storage="bf16"))."""
+    Storage type: the buffer's dtype, torch.float32, torch.bfloat16 or torch.float16 (mi355_act.dtype; HipAutocastUNet(activation_storage=...))."""
     __slots__ = ("buf", "c0", "c", "mom")
 
     def __init__(self, buf, c0=0, c=None):
-        assert buf.dim() == 5 and buf.is_contiguous() and buf.dtype in (torch.float32, torch.bfloat16)
+        assert buf.dim() == 5 and buf.is_contiguous() and buf.dtype in ACT_DTYPES
         self.buf = buf
         self.c0 = c0
         self.c = buf.shape[-1] - c0 if c is None else c
@@ -51,7 +54,7 @@ class Act:
 
     def desc(self):
         n, d, h, w, ld = self.buf.shape
-        return MiAct(self.ptr(), n, d, h, w, self.c, ld, _lib.ACT_BF16 if self.buf.dtype == torch.bfloat16 else _lib.ACT_F32)
+        return MiAct(self.ptr(), n, d, h, w, self.c, ld, ACT_DTYPES[self.buf.dtype])
 
     def slice(self, c0, c):
         return Act(self.buf, self.c0 + c0, c)

@@ -478,11 +478,13 @@ class HipAutocastUNet(HipUNet3D):
       autocast_dtype="fp16": the reference class's own arithmetic (CUDA autocast defaults to fp16; v_mfma_f32_32x32x16_f16): 8x smaller
         rounding error than bf16, fp16's range -- train it with torch's GradScaler as the reference's `training.amp` path does
         (train/training_utils.py:60-69, 93-96), which this module's backward supports (tests/test_boundary.py).
-      activation_storage: "fp32" -- every activation tensor in HBM is fp32 and only the MFMA operands are rounded (the round-2..4 form;
-        the only one for fp16) | "bf16" -- conv outputs, block outputs, concat buffers and all their gradients are STORED as bf16, as
-        the reference's autocast keeps conv outputs: half the bytes of every HBM-bound kernel of the step and of
-        the saved-for-backward set; the network input (4 channels) stays fp32, values are rounded once, when stored. Default: "bf16"
-        with autocast_dtype="bf16", "fp32" with "fp16"."""
+      activation_storage: "fp32" -- every activation tensor in HBM is fp32 and only the MFMA operands are rounded (the round-2..4 form) |
+        "bf16" (with autocast_dtype="bf16") / "fp16" (with "fp16") -- conv outputs, block outputs, concat buffers and all their gradients
+        are STORED in the 16-bit type of the mode, as the reference's autocast keeps conv outputs: half the bytes of
+        every HBM-bound kernel of the step and of the saved-for-backward set; the network input (4 channels) stays fp32, values are
+        rounded once, when stored. "fp16" is the reference's own amp form (fp16 tensors, train/train.py:33-37): like there, gradients
+        stored as fp16 need the loss scale of torch's GradScaler (training_utils.py:60-69) -- unscaled Dice gradients sit in fp16's
+        subnormal range. Default: "bf16" with autocast_dtype="bf16"; "fp32" with "fp16" (opt in to "fp16" together with a GradScaler)."""
 
     def __init__(self, *args, autocast_dtype="bf16", activation_storage=None, **kwargs):
         super().__init__(*args, **kwargs)
@@ -490,12 +492,13 @@ class HipAutocastUNet(HipUNet3D):
         if name not in ("bf16", "fp16"):
             raise ValueError(f"autocast_dtype must be 'bf16' / torch.bfloat16 or 'fp16' / torch.float16, got {autocast_dtype!r}")
         self.conv_precision = name
-        st = {torch.bfloat16: "bf16", torch.float32: "fp32", None: ("bf16" if name == "bf16" else "fp32")}.get(activation_storage, activation_storage)
-        if st not in ("bf16", "fp32"):
-            raise ValueError(f"activation_storage must be 'bf16' or 'fp32', got {activation_storage!r}")
-        if st == "bf16" and name != "bf16":
-            raise ValueError("activation_storage='bf16' goes with autocast_dtype='bf16' (16-bit storage of fp16-rounded operands has no kernel)")
-        self.act_storage = torch.bfloat16 if st == "bf16" else None
+        st = {torch.bfloat16: "bf16", torch.float16: "fp16", torch.float32: "fp32", None: ("bf16" if name == "bf16" else "fp32")}.get(activation_storage, activation_storage)
+        if st not in ("bf16", "fp16", "fp32"):
+            raise ValueError(f"activation_storage must be 'bf16', 'fp16' or 'fp32', got {activation_storage!r}")
+        if st != "fp32" and st != name:
+            raise ValueError(f"activation_storage={st!r} goes with autocast_dtype={st!r}: a 16-bit tensor is stored in the type its convolutions "
+                             "round their operands to (a plain input is the matrix operand as stored)")
+        self.act_storage = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(st)
 
 
 class HipAutoImplantUNet(HipUNet3D):

@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=2, help="volumes per GPU (BASELINE configs[1]: 2)")
     ap.add_argument("--size", type=int, default=128, help="cubic patch edge (BASELINE configs[1]: 128)")
-    ap.add_argument("--storage", default=None, choices=["fp32", "bf16"],
+    ap.add_argument("--storage", default=None, choices=["fp32", "bf16", "fp16"],
                     help="activation storage type (HipAutocastUNet(activation_storage=...)): default bf16 with --precision bf16 on a UNet3D "
                          "(conv outputs, block outputs, concat buffers and their gradients live in HBM as bf16, as under the reference's "
                          "autocast), fp32 otherwise")
@@ -357,11 +357,11 @@ def main():
         model = unet.HipUNet3D(n_features=4, n_outputs=3).to(dev)
         model_desc = "UNet3D 4ch->3cls (23970216 params)"
     if args.storage is None:
-        args.storage = "bf16" if (args.precision == "bf16" and args.model != "dynunet") else "fp32"
-    if args.storage == "bf16":
-        if args.precision != "bf16" or args.model == "dynunet":
-            raise SystemExit("--storage bf16 goes with --precision bf16 on a UNet3D")
-        model.act_storage = torch.bfloat16
+        args.storage = args.precision if (args.precision in ("bf16", "fp16") and args.model != "dynunet") else "fp32"
+    if args.storage in ("bf16", "fp16"):
+        if args.precision != args.storage or args.model == "dynunet":
+            raise SystemExit(f"--storage {args.storage} goes with --precision {args.storage} on a UNet3D")
+        model.act_storage = torch.bfloat16 if args.storage == "bf16" else torch.float16
     model.train()                                                 # Dropout3d active, as in the reference's training loop
     model.flatten_parameters()
     criterion = losses.HipDiceLoss(sigmoid=True)
@@ -387,15 +387,26 @@ def main():
 
     host_s = [0.0, 0]                                             # host time spent enqueueing steps (no device sync inside), step count
 
+    # fp16 activation storage = the reference's amp form: gradients stored as fp16 need its loss scale (train/train.py:33-37,
+    # training_utils.py:60-69: scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update())
+    scaler = torch.amp.GradScaler(dev.type) if args.storage == "fp16" else None
+
     def eager_step():
         optimizer.zero_grad(set_to_none=True)
         out = model(x)
         loss = criterion(out, y)
+        if scaler is not None:
+            scaler.scale(loss).backward()
+            scaler.step(optimizer)
+            scaler.update()
+            return loss
         loss.backward()                                           # the reducer's bucket all-reduces are launched from inside backward
         optimizer.step()                                          # and joined at its end (engine.py: grad_sync_callback)
         return loss
 
     graphed = None
+    if args.graph and scaler is not None:
+        raise SystemExit("--graph with fp16 activation storage: the captured step has no GradScaler; use --storage fp32 or the eager step")
     if args.graph:
         graph_mod = importlib.import_module("3dunetcnn_amd.graph")
         # one flat all-reduce per step when N > 1. On the CPU emulator (plumbing test) the same step runs uncaptured: the host logic of
@@ -592,11 +603,11 @@ def main():
                             else "eager launches, bucketed all-reduce inside backward",
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision],
                "data": "synthetic" if not emu else "synthetic -- CPU-EMULATOR PLUMBING TEST, NOT A MEASUREMENT",
-               "config": {"workload": f"BASELINE configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.config] }]: {model_desc}, {'x'.join(str(v) for v in dhw)} patch, batch {B}/GPU, {'bf16 activation tensors' if args.storage == 'bf16' else 'fp32 tensors'}, "
+               "config": {"workload": f"BASELINE configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.config] }]: {model_desc}, {'x'.join(str(v) for v in dhw)} patch, batch {B}/GPU, {args.storage + ' activation tensors' if args.storage != 'fp32' else 'fp32 tensors'}, "
                                       f"fwd + sigmoid-Dice + bwd + Adam" + (", Dropout3d on" if args.model == "unet3d" else ""),
                           "conv_arithmetic": ARITH[args.precision],
-                          "activation_storage": "bf16 (activations and their gradients between the fp32 input volume and the fp32 logits; statistics, "
-                                                "weights, weight gradients and the loss fp32)" if args.storage == "bf16" else "fp32",
+                          "activation_storage": args.storage + " (activations and their gradients between the fp32 input volume and the fp32 logits; statistics, "
+                                                "weights, weight gradients and the loss fp32)" if args.storage != "fp32" else "fp32",
                           "global_batch": world * B, "parallelism": f"dp{world}"},
                "final_loss": round(loss_val, 6), "roofline": roofline, "first_layer": first_layer}
         if world == 1 and args.precision == "fp32" and not args.no_precision_modes and args.config == "c2":

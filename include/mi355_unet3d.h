@@ -43,6 +43,7 @@ extern "C" {
  * one call other than those listed at the entry point), never a silent reinterpretation. */
 #define MI355_ACT_F32 0
 #define MI355_ACT_BF16 1
+#define MI355_ACT_F16 2 /* IEEE fp16 storage: the tensors of the reference's own amp mode (fp16 autocast, train/train.py:33-37) */
 
 /* NDHWC activation view (fp32 unless dtype says otherwise; a caller that zero-initialises the struct gets fp32). */
 typedef struct mi355_act {

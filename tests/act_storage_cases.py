@@ -17,8 +17,24 @@ import launch_audit as A
 import op_cases as C
 
 ops = importlib.import_module("3dunetcnn_amd.ops")
-BF = torch.bfloat16
+BF = torch.bfloat16          # the 16-bit storage type under test: `storage_type(torch.float16)` switches the cases to MI355_ACT_F16
 TOL = 1e-6
+
+
+class storage_type:
+    """with storage_type(torch.float16): ... -- runs the cases on IEEE fp16 tensors (the reference's own amp tensors, train/train.py:33-37);
+    the backend precision must be the matching one ("fp16")."""
+
+    def __init__(self, dt):
+        self.dt = dt
+
+    def __enter__(self):
+        global BF
+        self.saved, BF = BF, self.dt
+
+    def __exit__(self, *a):
+        global BF
+        BF = self.saved
 
 
 def bf16_values(shape, g, scale=1.0, shift=0.0):

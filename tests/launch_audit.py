@@ -55,17 +55,21 @@ def rel_err(a, b):
 
 def store_err(got, ref, dtype):
     """Error of a launch OUTPUT against its fp64 recomputation, relative to the block's largest value. fp32 tensors: rel_err. A tensor
-    STORED as bf16 (ops.Act.dtype, HipAutocastUNet(activation_storage="bf16")) holds the fp32 result rounded once, to nearest even: the
+    STORED as bf16 / fp16 (ops.Act.dtype, HipAutocastUNet(activation_storage=...)) holds the fp32 result rounded once, to nearest even: the
     rounding itself (up to half a bf16 ulp of each value) is the storage format, not an error of the launch -- what is left after it is
     taken out must meet the same bound as an fp32 output. A value the fp32 arithmetic puts on the other side of a rounding boundary
     differs by a whole ulp from round(ref): the half-ulp allowance around `ref` covers exactly the two candidates next to it."""
     got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
     den = float(ref.abs().max())
     den = den if den > 0 else 1.0
-    if dtype != torch.bfloat16:
+    if dtype not in (torch.bfloat16, torch.float16):
         return float((got - ref).abs().max()) / den
-    a = ref.abs().clamp(min=2.0 ** -126)
-    ulp = torch.exp2(torch.floor(torch.log2(a)) - 7.0)           # spacing of bf16 (8 significand bits) at |ref|
+    if dtype == torch.bfloat16:
+        a = ref.abs().clamp(min=2.0 ** -126)
+        ulp = torch.exp2(torch.floor(torch.log2(a)) - 7.0)       # spacing of bf16 (8 significand bits) at |ref|
+    else:
+        a = ref.abs().clamp(min=2.0 ** -14)                      # fp16: 11 significand bits, subnormal spacing 2^-24 below 2^-14
+        ulp = torch.exp2(torch.floor(torch.log2(a)) - 10.0)
     return float(((got - ref).abs() - 0.5 * ulp).clamp(min=0.0).max()) / den
 
 
@@ -310,7 +314,7 @@ class LaunchAudit:
                 # error of the block relative to the magnitude of the block itself (a stricter denominator than the tensor's maximum)
                 worst[form] = max(worst[form], store_err(got, ref, y.dtype))
         form = min(worst, key=worst.get)
-        self._rec(kind, desc + (f" [{lp} operands, prologue {form}]" if lp is not None else "") + (" [bf16 storage]" if y.dtype == torch.bfloat16 else ""),
+        self._rec(kind, desc + (f" [{lp} operands, prologue {form}]" if lp is not None else "") + (f" [{'bf16' if y.dtype == torch.bfloat16 else 'fp16'} storage]" if y.dtype in (torch.bfloat16, torch.float16) else ""),
                   worst[form])
         return ret
 

@@ -1,4 +1,4 @@
-"""16-bit activation storage (mi355_act.dtype = MI355_ACT_BF16) at op level on the CPU emulator build of the kernel sources (index logic,
+"""16-bit activation storage (mi355_act.dtype = MI355_ACT_BF16 / MI355_ACT_F16) at op level on the CPU emulator build of the kernel sources (index logic,
 type dispatch, rounding points); tests/act_storage_cases.py states the property. GPU twins: tests/test_act_storage_gpu.py."""
 import importlib
 
@@ -116,6 +116,81 @@ def test_mixed_storage_types_are_refused(emu_backend):
     y = be.empty_act(1, 4, 4, 8, 32, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="unsupported"):
         be.conv_fwd(b, w3, y, 3)          # fp32 arithmetic (the backend's default precision) on 16-bit tensors: no such 3x3x3 kernel
+
+
+# ---- IEEE fp16 storage (MI355_ACT_F16: the tensors of the reference's own amp mode, train/train.py:33-37) with fp16 operands: the same
+# ---- property on the other 16-bit type. A subset of the cases above per kernel family (every typed kernel has an f16_t instantiation).
+@pytest.fixture
+def fp16_backend(emu_backend):
+    saved = emu_backend.precision
+    emu_backend.set_precision("fp16")
+    with S.storage_type(torch.float16):
+        yield emu_backend
+    emu_backend.precision = saved
+
+
+def test_fp16_cast_pointwise_norm_projection(fp16_backend):
+    S.case_cast(fp16_backend)
+    _all_below(S.case_pointwise(fp16_backend))
+    _all_below(S.case_norm(fp16_backend), dgamma=1e-5, dbeta=1e-5)
+    _all_below(S.case_norm(fp16_backend, c=24, groups=24, slope=0.01), dgamma=1e-5, dbeta=1e-5)
+    _all_below(S.case_proj(fp16_backend), dw=1e-5)
+
+
+def test_fp16_conv_1x1x1_stride2_zero_insert(fp16_backend):
+    _all_below(S.case_conv_k1(fp16_backend))
+    _all_below(S.case_conv_s2(fp16_backend), moments=2e-5)
+    _all_below(S.case_conv_zero_insert(fp16_backend, window=True))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(cin=32, cout=32, dhw=(4, 4, 16)),                                             # plain input: staged without a conversion
+    dict(cin=64, cout=32, dhw=(4, 8, 16), norm=True, residual=True, drop=True, moments=True, n=2),
+    dict(cin=32, cout=64, dhw=(4, 5, 17), gnb=True, mode=1),                           # dgrad with the norm-backward sums, ragged
+])
+def test_fp16_conv_3x3x3_on_16bit_operands(fp16_backend, kw):
+    r = S.case_conv_k3_tile(fp16_backend, **kw)
+    if kw.get("gnb"):
+        assert r["gnb_fused"]
+    _all_below(r, moments=2e-5, gnb=1e-5)
+
+
+@pytest.mark.parametrize("form,kw", [
+    ("zring", dict(cin=32, cout=64, dhw=(4, 16, 16), mode=1)),                                  # plain input (a dgrad): staged as loaded
+    ("zring", dict(cin=64, cout=32, dhw=(5, 8, 32), norm=True, residual=True, drop=True, moments=True, n=2)),
+    ("zring1", dict(cin=32, cout=32, dhw=(5, 8, 16), gnb=True, mode=1)),                        # the round-3 ring: norm-backward sums
+])
+def test_fp16_conv_3x3x3_plane_ring_forms(fp16_backend, monkeypatch, form, kw):
+    monkeypatch.setenv("MI355_BF16_FORM", form)
+    r = S.case_conv_k3_tile(fp16_backend, **kw)
+    if kw.get("gnb"):
+        assert r["gnb_fused"]
+    _all_below(r, moments=2e-5, gnb=1e-5)
+
+
+def test_fp16_first_layer_and_weight_gradients(fp16_backend):
+    _all_below(S.case_first_layer(fp16_backend), moments=2e-5, wgrad=1e-5)
+    _all_below(S.case_wgrad(fp16_backend, kd=1, stride=1, cin=64, cout=32, dhw=(4, 5, 7)), dw=1e-5)
+    _all_below(S.case_wgrad(fp16_backend, kd=3, stride=2, cin=32, cout=32, dhw=(9, 8, 11), n=2), dw=1e-5)
+    _all_below(S.case_wgrad(fp16_backend, kd=3, stride=1, cin=32, cout=32, dhw=(5, 6, 18), norm=True), dw=1e-5)
+    _all_below(S.case_wgrad(fp16_backend, kd=3, stride=1, cin=32, cout=96, dhw=(3, 4, 17), norm=True), dw=1e-5)
+
+
+def test_fp16_storage_goes_with_fp16_operands_only(emu_backend):
+    """A 16-bit tensor is stored in the type its convolutions round their operands to: fp16 tensors under bf16 arithmetic (and the reverse)
+    are refused, never reinterpreted."""
+    be = emu_backend
+    saved = be.precision
+    try:
+        w3 = be.pack_weight(torch.randn(32, 32, 3, 3, 3), 0)
+        for prec, dt in (("bf16", torch.float16), ("fp16", torch.bfloat16)):
+            be.set_precision(prec)
+            x = be.empty_act(1, 4, 4, 16, 32, dtype=dt); x.buf.zero_()
+            y = be.empty_act(1, 4, 4, 16, 32, dtype=dt)
+            with pytest.raises(RuntimeError, match="unsupported"):
+                be.conv_fwd(x, w3, y, 3)
+    finally:
+        be.precision = saved
 
 
 def test_randomized_shapes(bf16_backend, monkeypatch):

@@ -120,6 +120,82 @@ def test_mixed_storage_types_are_refused(hip_backend):
         be.conv_fwd(a, w, b, 1)
 
 
+# ---- IEEE fp16 storage (MI355_ACT_F16, the tensors of the reference's own amp mode) with fp16 operands: GPU twins of the emulator cases ----
+@pytest.fixture
+def fp16_backend(hip_backend):
+    saved = hip_backend.precision
+    hip_backend.set_precision("fp16")
+    with S.storage_type(torch.float16):
+        yield hip_backend
+    hip_backend.precision = saved
+
+
+def test_fp16_cast_pointwise_norm_projection(fp16_backend):
+    S.case_cast(fp16_backend)
+    _all_below(S.case_pointwise(fp16_backend))
+    _all_below(S.case_norm(fp16_backend, n=2, c=32, dhw=(32, 32, 32)), dgamma=1e-5, dbeta=1e-5)
+    _all_below(S.case_norm(fp16_backend, c=96, groups=96, slope=0.01, dhw=(8, 8, 8)), dgamma=1e-5, dbeta=1e-5)
+    _all_below(S.case_proj(fp16_backend), dw=1e-5)
+
+
+def test_fp16_conv_1x1x1_stride2_zero_insert(fp16_backend):
+    _all_below(S.case_conv_k1(fp16_backend, cin=256, cout=128))
+    _all_below(S.case_conv_s2(fp16_backend, cin=128, cout=128), moments=2e-5)
+    _all_below(S.case_conv_zero_insert(fp16_backend, window=True))
+    _all_below(S.case_conv_zero_insert(fp16_backend, cin=256, cout=128))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(cin=32, cout=32, dhw=(16, 16, 32)),
+    dict(cin=64, cout=32, dhw=(8, 8, 32), norm=True, residual=True, drop=True, moments=True, n=2),
+    dict(cin=32, cout=64, dhw=(8, 9, 33), gnb=True, mode=1),
+    dict(cin=256, cout=256, dhw=(8, 8, 16), norm=True, moments=True),
+])
+def test_fp16_conv_3x3x3_on_16bit_operands(fp16_backend, kw):
+    r = S.case_conv_k3_tile(fp16_backend, **kw)
+    if kw.get("gnb"):
+        assert r["gnb_fused"]
+    _all_below(r, moments=2e-5, gnb=1e-5)
+
+
+@pytest.mark.parametrize("form,kw", [
+    ("zring", dict(cin=32, cout=64, dhw=(16, 32, 32), mode=1)),
+    ("zring", dict(cin=64, cout=32, dhw=(12, 16, 32), norm=True, residual=True, drop=True, moments=True, n=2)),
+    ("zring", dict(cin=64, cout=64, dhw=(9, 16, 32), norm=True, residual=True)),
+    ("zring1", dict(cin=32, cout=32, dhw=(16, 16, 32), gnb=True, mode=1)),
+    ("zring1", dict(cin=32, cout=32, dhw=(12, 16, 32), norm=True, moments=True, residual=True)),
+])
+def test_fp16_conv_3x3x3_plane_ring_forms(fp16_backend, monkeypatch, form, kw):
+    monkeypatch.setenv("MI355_BF16_FORM", form)
+    r = S.case_conv_k3_tile(fp16_backend, **kw)
+    if kw.get("gnb"):
+        assert r["gnb_fused"]
+    _all_below(r, moments=2e-5, gnb=1e-5)
+
+
+def test_fp16_first_layer_and_weight_gradients(fp16_backend):
+    _all_below(S.case_first_layer(fp16_backend, dhw=(32, 32, 32)), moments=2e-5, wgrad=1e-5)
+    _all_below(S.case_wgrad(fp16_backend, kd=1, stride=1, cin=64, cout=32, dhw=(16, 16, 16)), dw=1e-5)
+    _all_below(S.case_wgrad(fp16_backend, kd=3, stride=2, cin=32, cout=32, dhw=(17, 16, 19), n=2), dw=1e-5)
+    _all_below(S.case_wgrad(fp16_backend, kd=3, stride=1, cin=32, cout=32, dhw=(9, 10, 34), norm=True), dw=1e-5)
+    _all_below(S.case_wgrad(fp16_backend, kd=3, stride=1, cin=64, cout=96, dhw=(6, 8, 33), norm=True), dw=1e-5)
+
+
+def test_fp16_storage_goes_with_fp16_operands_only(hip_backend):
+    be = hip_backend
+    saved = be.precision
+    try:
+        w3 = be.pack_weight(torch.randn(32, 32, 3, 3, 3, device=be.device), 0)
+        for prec, dt in (("bf16", torch.float16), ("fp16", torch.bfloat16)):
+            be.set_precision(prec)
+            x = be.empty_act(1, 4, 4, 16, 32, dtype=dt); x.buf.zero_()
+            y = be.empty_act(1, 4, 4, 16, 32, dtype=dt)
+            with pytest.raises(RuntimeError, match="unsupported"):
+                be.conv_fwd(x, w3, y, 3)
+    finally:
+        be.precision = saved
+
+
 def test_bf16_storage_train_steps_track_the_fp32_storage_run():
     """HipAutocastUNet(bf16), 64^3 batch 2: five optimizer steps with activation_storage="bf16" next to the same steps with fp32 tensors
     (same seed, same Dropout3d masks): losses within 2e-3 of each other at every step, and the saved-activation memory about half."""

@@ -122,23 +122,25 @@ def test_audit_dynunet_train_step_emulator(emu_backend):
     _check(au, {"conv_fwd": 10, "conv_d2s": 4, "conv_wgrad": 8, "gn_act_bwd": 4})
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp16", "bf16-fp32-tensors"])
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "bf16-fp32-tensors", "fp16-stored"])
 def test_audit_16bit_train_step_emulator(emu_backend, mode):
     """The mixed-precision step (HipAutocastUNet: the 3x3x3 stride-1 convs and their weight gradients on 16-bit operands) audited
     with the 16-bit operand model: every such launch agrees to 1e-5 with fp64 of operands rounded as the mode rounds them, every
     other launch (first-layer gradients, stride-2 / 1x1x1 convs, norms, loss, Adam) with plain fp64 as in the fp32 step."""
     torch.manual_seed(5)
-    storage = "fp32" if mode != "bf16" else "bf16"      # "bf16": the default of the mode -- activations STORED as bf16 (output-storage model)
+    # "bf16": the default of the mode -- activations STORED as bf16 (output-storage model); "fp16-stored": the reference's own amp form,
+    # fp16 tensors (activation_storage="fp16"), audited with its loss scale (GradScaler's 2^16) like the GPU twin
+    storage = {"bf16": "bf16", "fp16-stored": "fp16"}.get(mode, "fp32")
     m = unet.HipAutocastUNet(n_features=4, n_outputs=3, base_width=16, encoder_blocks=[1, 1, 2], autocast_dtype=mode.split("-")[0],
                              activation_storage=storage).train()
-    assert (m.act_storage == torch.bfloat16) == (mode == "bf16")
+    assert m.act_storage == {"bf16": torch.bfloat16, "fp16": torch.float16}.get(storage)
     m.backward_side_stream = False
     x, y = R.synthetic_case(2, 4, (16, 16, 16), 3)
-    au, loss = _step(emu_backend, m, x, y, "cpu", block_macs=2e5, full_macs=1e6, wgrad_channels=3)
+    au, loss = _step(emu_backend, m, x, y, "cpu", block_macs=2e5, full_macs=1e6, wgrad_channels=3, loss_scale=65536.0 if mode == "fp16-stored" else 1.0)
     assert 0.0 < loss <= 1.0
     counts = au.counts()
-    if mode == "bf16":
-        stored = [r for r in au.records if "[bf16 storage]" in r["desc"]]
+    if storage != "fp32":
+        stored = [r for r in au.records if f"[{storage} storage]" in r["desc"]]
         assert len(stored) >= 30, len(stored)           # every conv output of the step but the first layer's input gradient is a 16-bit tensor
     # 8 residual-block convs + 1 first-layer forward on 16-bit operands + their dgrads; the first layer's dgrad / wgrad and the stride-2
     # / 1x1x1 / up-sampling convs stay fp32
@@ -265,17 +267,17 @@ def test_audit_c3_bf16_train_step_gpu(hip_backend):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["bf16", "fp16", "bf16-fp32-tensors"])
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "bf16-fp32-tensors", "fp16-stored"])
 def test_audit_16bit_train_step_gpu(hip_backend, mode):
     """The 16-bit operand model on the product kernels at a size every routing of the mode takes part in (64^3, batch 2: plane-ring
     form on the 32-channel level, tile forms below, first-layer forward on the 16-bit pipe)."""
     torch.manual_seed(7)
     m = unet.HipAutocastUNet(n_features=4, n_outputs=3, autocast_dtype=mode.split("-")[0],
-                             activation_storage="bf16" if mode == "bf16" else "fp32").cuda().train()
+                             activation_storage={"bf16": "bf16", "fp16-stored": "fp16"}.get(mode, "fp32")).cuda().train()
     x, y = R.synthetic_case(2, 4, (64, 64, 64), 3)
     # fp16 is trained with a loss scale, as the reference does (GradScaler, initial scale 2^16): unscaled, the Dice gradients (1e-6 ..
     # 1e-9) sit in fp16's SUBNORMAL range, where the matrix pipe and tensor.half() need not agree (measured on MI355X without the
     # scale: dgrad launches 1.2e-5 instead of 1.4e-6 -- operands of a few subnormal bits). bf16 has fp32's range: no scale.
-    au, loss = _step(hip_backend, m, x, y, "cuda", loss_scale=65536.0 if mode == "fp16" else 1.0)
+    au, loss = _step(hip_backend, m, x, y, "cuda", loss_scale=65536.0 if mode.startswith("fp16") else 1.0)
     assert 0.0 < loss < 1.0
     _check(au, {"conv_fwd_lp": 51, "conv_wgrad_lp": 25, "gn_act_bwd": 26, "gn_stats": 26})

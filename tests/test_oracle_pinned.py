@@ -110,16 +110,16 @@ def _autocast_golden(be, dev):
     """HipAutocastUNet against the REFERENCE graph run under torch.autocast (tests/golden/unet3d_small_autocast.pt, generated by
     oracle/make_golden.py from the imported reference; AutocastUNet = UNet3D.forward under autocast, unet.py:53-58). Two 16-bit
     roundings of the same fp32 network are compared, so the bound is the sum of both errors. The reference rounds every conv OUTPUT to
-    16 bits; so does the bf16 mode's default activation_storage="bf16" (values rounded once, on store), while activation_storage="fp32"
-    (and the fp16 mode) keeps fp32 tensors between the convolutions: either way the HIP result must be at least as close to the fp32
-    logits as the reference's own autocast result is."""
+    16 bits; so do activation_storage="bf16" (the bf16 mode's default) and "fp16" (the reference's own amp form; values rounded once, on
+    store), while activation_storage="fp32" keeps fp32 tensors between the convolutions: either way the HIP result must be at least as
+    close to the fp32 logits as the reference's own autocast result is."""
     a = torch.load(os.path.join(GOLD, "unet3d_small_autocast.pt"))
     g = torch.load(os.path.join(GOLD, a["bundle"]))
     res = {}
-    for mode, storage, tol in (("fp16", "fp32", 4e-3), ("bf16", "bf16", 3e-2), ("bf16", "fp32", 3e-2)):
+    for mode, storage, tol in (("fp16", "fp32", 4e-3), ("fp16", "fp16", 4e-3), ("bf16", "bf16", 3e-2), ("bf16", "fp32", 3e-2)):
         m = unet.HipAutocastUNet(autocast_dtype=mode, activation_storage=storage, **g["kwargs"]).to(dev).eval()
-        assert (m.act_storage == torch.bfloat16) == (storage == "bf16") and unet.HipAutocastUNet(autocast_dtype=mode, **g["kwargs"]).act_storage == \
-            (torch.bfloat16 if mode == "bf16" else None)
+        assert m.act_storage == {"bf16": torch.bfloat16, "fp16": torch.float16}.get(storage) and \
+            unet.HipAutocastUNet(autocast_dtype=mode, **g["kwargs"]).act_storage == (torch.bfloat16 if mode == "bf16" else None)
         if be is not None:
             m._be = be
         m.load_state_dict(g["state_dict"])
