@@ -127,9 +127,9 @@ def self_launch(n):
 
 
 # HBM-traffic summaries (tools/pmc_summary.py) of the rocprofv3 PMC passes of THIS command, per (config, precision)
-PMC_FILES = {("c2", "fp32"): os.path.join("profiles", "r4_bench_fp32_hbm_traffic_pmc.csv"),
-             ("c2", "bf16"): os.path.join("profiles", "r4_bf16_hbm_traffic_pmc.csv"),
-             ("c3", "bf16"): os.path.join("profiles", "r4_c3_hbm_traffic_pmc.csv")}
+PMC_FILES = {("c2", "fp32"): os.path.join("profiles", "r5_bench_fp32_hbm_traffic_pmc.csv"),
+             ("c2", "bf16"): os.path.join("profiles", "r5_bf16_hbm_traffic_pmc.csv"),
+             ("c3", "bf16"): os.path.join("profiles", "r5_c3_hbm_traffic_pmc.csv")}
 # kernel family (ops.Backend prof name) -> substrings of the trace names of its instantiations
 PMC_FAMILY = {"conv3d_wino2d": ("conv3d_wino2d",), "conv3d_k3_bf16<...>": ("conv3d_k3_bf16", "conv3d_k3_lp_zring"),
               "conv3d_wgrad_wino_ring (+reduce)": ("conv3d_wgrad_wino_ring",), "conv3d_wgrad_k3_bf16<...> (+reduce)": ("conv3d_wgrad_k3_bf16", "conv3d_wgrad_lp_ring"),
