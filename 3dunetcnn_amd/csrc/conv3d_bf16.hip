@@ -425,7 +425,7 @@ void conv3d_k3_bf16(ConvBArgs a) {
 struct LpZPlan { int tilesY, tilesX, zsplits, zper, use, ks, coTiles; };
 static LpZPlan plan_lp_zring(int n, int cin, int cout, int d, int h, int w, int precision, const mi355_conv_desc* desc, int act_dtype = MI355_ACT_F32) {
   LpZPlan p; memset(&p, 0, sizeof(p));
-  if (act_dtype != MI355_ACT_F32 && precision != MI355_PREC_BF16) return p;      // bf16 storage goes with bf16 operands
+  if (!act_matches_precision(act_dtype, precision)) return p;      // 16-bit storage goes with operands of its own type
   const char* fe = getenv("MI355_BF16_FORM");
   const bool v1 = fe && !strncmp(fe, "zring1", 6);
   const char form = fe && fe[0] ? fe[0] : 'a';

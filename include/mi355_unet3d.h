@@ -33,9 +33,12 @@ extern "C" {
 #define MI355_STATUS_ELAUNCH (-3)      /* hipGetLastError() != hipSuccess after launch */
 #define MI355_STATUS_EWORKSPACE (-4)   /* workspace too small */
 
-/* Storage type of an activation tensor. fp32 is the reference's own; bf16 is what its AutocastUNet (segmentation/unet.py:53-58) keeps
- * conv outputs in under torch autocast: HipAutocastUNet(activation_storage="bf16") stores every activation and activation gradient
- * between the input volume and the logits that way (statistics, weights, weight gradients, logits and the loss stay fp32). A bf16 view
+/* Storage type of an activation tensor. fp32 is the reference's own; a 16-bit type is what its AutocastUNet (segmentation/unet.py:53-58)
+ * keeps conv outputs in under torch autocast -- fp16 in the reference's amp mode (train/train.py:33-37), bf16 in BASELINE configs[2]:
+ * HipAutocastUNet(activation_storage="bf16" | "fp16") stores every activation and activation gradient between the input volume and the
+ * logits that way (statistics, weights, weight gradients, logits and the loss stay fp32). A 16-bit tensor goes with the operand precision
+ * of its own type (MI355_ACT_BF16 with MI355_PREC_BF16, MI355_ACT_F16 with MI355_PREC_F16: a plain input of the 16-bit convolution kernels
+ * IS the matrix operand as stored). A 16-bit view
  * has the same (n, d, h, w, c, ld) meaning in ELEMENTS; p must be 8-byte aligned (16-byte for the 16-bit convolution kernels, which also
  * want ld % 8 == 0). Where an entry point takes a raw tensor pointer beside the views (mi355_conv_desc.residual, mi355_gn_bwd_fuse.gx:
  * the type of y; the `addend` of mi355_gn_act_bwd: the type of dx) the pointer has the type named there. Every entry point checks the
@@ -61,8 +64,9 @@ typedef struct mi355_act {
                                   dgrad of ConvTranspose3d(k2,s2) (MONAI DynUNet up block). x->d/h/w are the FINE extents. */
 
 /* Arithmetic of the 3x3x3 stride-1 conv kernels (forward, dgrad and wgrad). Accumulation is fp32 in every mode; the modes differ in how
- * the products are formed on the matrix pipe. The tensors a call reads and writes are fp32 unless their views say MI355_ACT_BF16, which
- * goes with MI355_PREC_BF16 only (the operands are then the stored values; outputs are rounded once, on store). */
+ * the products are formed on the matrix pipe. The tensors a call reads and writes are fp32 unless their views say MI355_ACT_BF16 (goes
+ * with MI355_PREC_BF16 only) or MI355_ACT_F16 (with MI355_PREC_F16 only): the operands are then the stored values; outputs are rounded
+ * once, on store. */
 #define MI355_PREC_F32 0     /* v_mfma_f32_32x32x2_f32: exact fp32 products (bitwise a k-ordered fmaf chain). 157 TFLOP/s peak. */
 #define MI355_PREC_BF16X3 1  /* each operand split into 2 bf16 planes (hi + lo), 3 bf16-MFMA products hi*hi + hi*lo + lo*hi:
                                 product error <= ~2^-16 relative ("3xBF16 fp32 emulation"). 2.5 PFLOP/s / 3 peak. */
