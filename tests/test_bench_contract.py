@@ -119,10 +119,11 @@ def test_committed_bench_line_has_the_contract_shape(name):
         assert set(line["precision_modes"]) == {"bf16x6", "bf16x3", "bf16"}
 
 
-@pytest.mark.parametrize("name,dtype", [("r4_bench_fp32.json", "f32"), ("r4_c3_bench.json", "bf16 (mixed)")])
-def test_round4_committed_lines_carry_the_verdict_fixes(name, dtype):
-    """The round-4 lines as produced on the MI355X: contract shape, a roofline whose traffic ratio a reader can redo in one division from
-    the committed PMC summary, per-instantiation rows, both roofline fractions, and (headline only) a cpu_baseline of the REAL shape."""
+@pytest.mark.parametrize("name,dtype", [("r5_bench_fp32.json", "f32"), ("r5_c3_bench.json", "bf16 (mixed)")])
+def test_committed_lines_carry_the_verdict_fixes(name, dtype):
+    """The round-5 lines as produced on the MI355X (tools/r5_final.sh): contract shape, a roofline whose traffic ratio a reader can redo in
+    one division from the committed PMC summary, per-instantiation rows, both roofline fractions, (headline only) a cpu_baseline of the REAL
+    shape and the `c3` block = BASELINE configs[2] per GPU measured warm."""
     import csv
     line = json.load(open(os.path.join(ROOT, "profiles", name)))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
@@ -146,8 +147,12 @@ def test_round4_committed_lines_carry_the_verdict_fixes(name, dtype):
     inst = roof["instantiations"]
     assert len(inst) >= 3 and sum(i["launches_per_step"] for i in inst) == roof["launches_per_step"]
     assert all("traffic_over_algorithmic" in i for i in inst)
-    if name == "r4_bench_fp32.json":
+    if name == "r5_bench_fp32.json":
         assert "Winograd" in line["config"]["conv_arithmetic"] and roof["kernel"] == "conv3d_wino2d" and roof["bound"] == "mfma"
+        assert all("conv3d_wino2d_d8<" in i["kernel"] for i in inst) and roof["frac"] > 0.62           # round 4: conv3d_wino2d_w8, 0.60
+        c3 = line["c3"]
+        assert set(_bench().C3_KEYS) <= set(c3) and c3["steps"] >= 20 and c3["warmup"] >= 5 and "configs[2]" in c3["workload"]
+        assert abs(c3["volumes_per_s_per_gpu"] - 4e3 / c3["ms_per_step"]) / c3["volumes_per_s_per_gpu"] < 1e-3 and c3["volumes_per_s_per_gpu"] > 80.0
         cpu = line["cpu_baseline"]
         assert cpu["extrapolated"] is False and "128^3 patch" in cpu["sample"] and "scaled" not in cpu["sample"]
         assert len(cpu["per_iteration_s"]) == 3 and cpu["optimizer_s"] < 0.2 and 5.0 < cpu["seconds_per_step"] < 20.0
