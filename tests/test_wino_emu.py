@@ -19,6 +19,13 @@ ops = C.ops
     dict(n=2, cin=8, cout=32, dhw=(8, 8, 16), bias=True),                        # 8 workgroups: the XCD-contiguous workgroup order
     dict(n=1, cin=16, cout=64, dhw=(8, 8, 16), norm=True),                       # the same with two channel tiles (4 spatial groups)
     dict(n=1, cin=8, cout=32, dhw=(16, 16, 32), bias=True),                      # 8 z tiles: the z-brick workgroup order (32 workgroups)
+    # round 5 (conv3d_wino2d_d8: every staged slot is a DMA request): a single plane (three of the four requested planes lie outside the
+    # volume: zeros from the device constant), an image smaller than the tile (whole request waves fetch zeros), three samples with a
+    # partial channel chunk, and a plain input with every epilogue operand
+    dict(n=1, cin=8, cout=8, dhw=(1, 3, 5), bias=True),
+    dict(n=1, cin=16, cout=32, dhw=(2, 2, 3), norm=True),
+    dict(n=3, cin=20, cout=32, dhw=(3, 4, 33), norm=True, residual=True, bias=True),
+    dict(n=2, cin=40, cout=72, dhw=(5, 8, 16), residual=True, chscale=True, bias=True),
 ])
 def test_wino_forward_matches_conv3d(emu_backend, kw):
     be = emu_backend
