@@ -16,6 +16,9 @@ void fiber_entry() {
 
 void run_block(BlockState& bs) {
   bs.bar_count = 0; bs.bar_gen = 0;
+  const unsigned nwaves = (bs.nthreads + 63) / 64;
+  bs.dma_log.assign(nwaves, {}); bs.dma_wait_log.assign(nwaves, {});
+  bs.dma_pending.assign(bs.nthreads, {}); bs.dma_cursor.assign(bs.nthreads, 0); bs.dma_waits.assign(bs.nthreads, 0);
   memset(bs.wbar_count, 0, sizeof(bs.wbar_count));
   memset(bs.wbar_gen, 0, sizeof(bs.wbar_gen));
   for (unsigned i = 0; i < bs.nthreads; ++i) {

@@ -72,6 +72,13 @@ struct BlockState {
   uint4  mfma_a4[1024]; uint4 mfma_b4[1024];
   std::function<void()> body;
   char* dyn_lds = nullptr;
+  // LDS-DMA model (glds16 / WAIT_VMCNT_LGKM0 below): per wave the log of DMA instructions (their wave-uniform LDS base) and of the
+  // instruction count at each counted wait, both written by the wave's lane 0; per lane the requests not yet landed
+  struct DmaReq { unsigned tag; float* dst; float v[4]; };
+  std::vector<std::vector<float*>> dma_log;          // [wave] -> LDS base of instruction 1, 2, ...
+  std::vector<std::vector<unsigned>> dma_wait_log;   // [wave] -> instructions issued when lane 0 reached its k-th wait
+  std::vector<std::vector<DmaReq>> dma_pending;      // [thread], in issue order
+  std::vector<unsigned> dma_cursor, dma_waits;       // [thread]: next log entry to match / waits executed
 };
 
 extern thread_local BlockState* g_bs;
@@ -115,6 +122,10 @@ void run_block(BlockState& bs);
 
 template <class F>
 void launch(emu_dim3 grid, emu_dim3 block, size_t lds_bytes, F body) {
+  // MI355_EMU_NOEXEC=1: a launch returns at once (tools/host_enqueue.py times the host side of a step -- Python, ctypes, the C dispatch --
+  // at the real shapes without a GPU; outputs are garbage, nothing may check them)
+  static const bool noexec = [] { const char* v = getenv("MI355_EMU_NOEXEC"); return v && v[0] == '1'; }();
+  if (noexec) return;
   size_t nblocks = (size_t)grid.x * grid.y * grid.z;
   unsigned nthr = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), nblocks);
   const char* env = getenv("MI355_EMU_THREADS");
@@ -312,11 +323,55 @@ typedef unsigned long long LaneMask;
 static inline LaneMask emu_lane_mask(bool c) { LaneMask m = 0; for (int l = 0; l < 64; ++l) m |= (LaneMask)(emu_shfl((int)c, l) & 1) << l; return m; }
 #define LANE_MASK(cond) emu_lane_mask(cond)
 #define LANE_IN_MASK(m) ((((m) >> (emu::flat_tid() % 64)) & 1ull) != 0)
-// LDS-DMA: synchronous here (the data lands at once: a buffer restaged while another fiber still reads it shows up as a wrong result; a
-// read BEFORE the counted wait does not -- that half of the protocol is checked on the GPU only)
-static inline void glds16(const void* src, float* lds_wave_base) { memcpy(lds_wave_base + 4 * (emu::flat_tid() % 64), src, 16); }
+// LDS-DMA (global_load_lds_dwordx4 + counted s_waitcnt vmcnt(n)). Two models, MI355_EMU_DMA=late (default) | early:
+//   late : a request lands as LATE as the protocol allows -- only when a counted wait of its wave retires it (the wave's VM counter
+//          retires in order: vmcnt(n) leaves the n most recent INSTRUCTIONS of the wave outstanding, whichever lanes took part in them).
+//          A fragment read before the wait + barrier that publish its plane sees stale data: the RAW half of the protocol, including the
+//          immediates of the waits, is checked here and not only on the GPU.
+//   early: a request lands at once: a buffer restaged while another fiber still reads it shows up as a wrong result (the WAR half).
+// Wave-level instruction counting with per-lane fibers: lane 0 of a wave takes part in every DMA instruction and every wait of the
+// kernels that use this (it runs first between two barriers); it logs each instruction's wave-uniform LDS base and, at each wait, how
+// many instructions the wave has issued. Another lane finds the instruction it is executing by that base (forward from its last match).
+static inline bool emu_dma_early() { static const bool e = [] { const char* v = getenv("MI355_EMU_DMA"); return v && !strcmp(v, "early"); }(); return e; }
+static inline void glds16(const void* src, float* lds_wave_base) {
+  const int t = emu::flat_tid(), l = t % 64, w = t / 64;
+  if (emu_dma_early()) { memcpy(lds_wave_base + 4 * l, src, 16); return; }
+  emu::BlockState* bs = emu::g_bs;
+  auto& log = bs->dma_log[w];
+  unsigned tag;
+  if (l == 0) { log.push_back(lds_wave_base); tag = (unsigned)log.size(); bs->dma_cursor[t] = tag; }
+  else {
+    unsigned c = bs->dma_cursor[t];
+    for (int spins = 0;; ++spins) {                          // (the last fiber to reach a barrier runs on before the wave's lane 0: let that one catch up)
+      while (c < log.size() && log[c] != lds_wave_base) ++c;
+      if (c < log.size()) break;
+      if (spins > 1000000) { fprintf(stderr, "emu: LDS-DMA by lane %d of wave %d has no matching instruction of lane 0\n", l, w); abort(); }
+      emu::yield();
+    }
+    tag = c + 1; bs->dma_cursor[t] = tag;
+  }
+  emu::BlockState::DmaReq r; r.tag = tag; r.dst = lds_wave_base + 4 * l; memcpy(r.v, src, 16);
+  bs->dma_pending[t].push_back(r);
+}
 static inline void glds16_uniform_base(const void* ubase, unsigned lane_off, float* lds_wave_base) { glds16(reinterpret_cast<const char*>(ubase) + lane_off, lds_wave_base); }
-#define WAIT_VMCNT_LGKM0(n) ((void)0)
+static inline void emu_wait_vmcnt(unsigned n) {
+  if (emu_dma_early()) return;
+  emu::BlockState* bs = emu::g_bs;
+  const int t = emu::flat_tid(), l = t % 64, w = t / 64;
+  auto& wl = bs->dma_wait_log[w];
+  const unsigned k = bs->dma_waits[t]++;
+  if (l == 0) wl.push_back((unsigned)bs->dma_log[w].size());
+  for (int spins = 0; k >= wl.size(); ++spins) {
+    if (spins > 1000000) { fprintf(stderr, "emu: counted wait %u of lane %d, wave %d: lane 0 never executed it\n", k, l, w); abort(); }
+    emu::yield();
+  }
+  const unsigned issued = wl[k], retire = issued > n ? issued - n : 0;      // instructions 1 .. retire have landed
+  auto& q = bs->dma_pending[t];
+  size_t i = 0;
+  for (; i < q.size() && q[i].tag <= retire; ++i) memcpy(q[i].dst, q[i].v, 16);
+  q.erase(q.begin(), q.begin() + i);
+}
+#define WAIT_VMCNT_LGKM0(n) emu_wait_vmcnt(n)
 #define RAW_BARRIER() __syncthreads()
 typedef uint4 u32x4_t;
 #define SLEEP_64CLK(n) do {} while (0)
