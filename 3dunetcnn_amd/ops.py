@@ -18,6 +18,10 @@ from ._lib import (IN_AFFINE_ACT, IN_PLAIN, IN_S2D, IN_ZERO_INSERT, OUT_D2S, OUT
                    W_PACKED, W_PACKED_F32_NARROW, MiAct, MiConvDesc, MiDiceOpts, MiGnBwdFuse, check)
 
 
+# MI355_HOST_CACHES=0: the per-call forms of round 4 (descriptors, the Winograd routing query, the engine's parameter list and gradient
+# views rebuilt every time) -- the A/B switch of the host-enqueue measurement (tools/host_enqueue.py, profiles/r5_host_enqueue.txt)
+HOST_CACHES = os.environ.get("MI355_HOST_CACHES", "1") != "0"
+
 ACT_DTYPES = {torch.float32: _lib.ACT_F32, torch.bfloat16: _lib.ACT_BF16, torch.float16: _lib.ACT_F16}      # storage types of an activation view
 
 
@@ -26,7 +30,7 @@ class Act:
     channel order -- written by the epilogue of the conv that produced the tensor (Backend.conv_fwd(moments=True)) or by
     Backend.moments(); Backend.gn_stats finalises them instead of reading the tensor again.
     Storage type: the buffer's dtype, torch.float32, torch.bfloat16 or torch.float16 (mi355_act.dtype; HipAutocastUNet(activation_storage=...))."""
-    __slots__ = ("buf", "c0", "c", "mom")
+    __slots__ = ("buf", "c0", "c", "mom", "_d")
 
     def __init__(self, buf, c0=0, c=None):
         assert buf.dim() == 5 and buf.is_contiguous() and buf.dtype in ACT_DTYPES
@@ -34,6 +38,7 @@ class Act:
         self.c0 = c0
         self.c = buf.shape[-1] - c0 if c is None else c
         self.mom = None
+        self._d = None
         assert self.c0 % 4 == 0 and self.c0 + self.c <= buf.shape[-1]
 
     @property
@@ -53,8 +58,12 @@ class Act:
         return self.buf.data_ptr() + self.buf.element_size() * self.c0
 
     def desc(self):
-        n, d, h, w, ld = self.buf.shape
-        return MiAct(self.ptr(), n, d, h, w, self.c, ld, ACT_DTYPES[self.buf.dtype])
+        """The view's mi355_act, built once (buf / c0 / c are fixed at construction; the library only reads the struct)."""
+        d_ = self._d
+        if d_ is None or not HOST_CACHES:
+            n, d, h, w, ld = self.buf.shape
+            d_ = self._d = MiAct(self.ptr(), n, d, h, w, self.c, ld, ACT_DTYPES[self.buf.dtype])
+        return d_
 
     def slice(self, c0, c):
         return Act(self.buf, self.c0 + c0, c)
@@ -69,6 +78,9 @@ class Act:
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+_current_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
 
 
 class PackedWeight:
@@ -148,6 +160,10 @@ class Backend:
                 raise RuntimeError("3dunetcnn_amd needs an MI355X (no HIP device visible); there is no CPU fallback")
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
+        self._dev_index = None
+        if self.device.type == "cuda":
+            self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._wino_ok = {}          # call signature -> mi355_conv3d_wino_supported's answer (conv_fwd)
         self._ws_by_stream = {}     # launch stream handle -> workspace tensor: kernels of different streams must not share scratch
         self.precision = PREC_F32   # arithmetic of the 3x3x3 stride-1 convs: see set_precision()
         self.act_dtype = torch.float32   # storage type of the activations empty_act() makes (engine.HipNetBase sets it per network)
@@ -184,8 +200,10 @@ class Backend:
 
     # -- plumbing ------------------------------------------------------------------------------------------------
     def stream(self):
-        if self.device.type == "cuda":
-            return torch.cuda.current_stream(self.device).cuda_stream
+        """Raw handle of the device's CURRENT stream (what torch.cuda.current_stream(device).cuda_stream returns, without building a
+        Stream object per launch: ~600 launches per step ask)."""
+        if self._dev_index is not None:
+            return _current_raw_stream(self._dev_index)
         return 0
 
     def ws(self, nbytes):
@@ -322,12 +340,18 @@ class Backend:
                 and wp.cin >= 8 and wp.cout >= 8 and x.shape[1:4] == y.shape[1:4]
                 and x.shape[1] * x.shape[2] * x.shape[3] >= self.WINO_MIN_VOXELS):
             # the size thresholds are this layer's routing POLICY; whether the Winograd kernel can take the call at all (strides,
-            # alignment of x / y / residual, modes) is the library's answer -- a call it refuses runs on the direct kernel below
-            probe = self._desc(3, 1, 1, in_mode, slope, scale, shift, bias, residual, chscale, (0, 0, 0), y.shape[1:4], [], in_slope, OUT_PLAIN)
-            xd_, yd_ = x.desc(), y.desc()
-            if self.lib.mi355_conv3d_wino_supported(ctypes.byref(xd_), ctypes.byref(yd_), ctypes.byref(probe)):
-                return self.conv_fwd_wino(x, wp.wino(), y, in_mode=in_mode, slope=slope, scale=scale, shift=shift, bias=bias, residual=residual,
-                                          chscale=chscale, in_slope=in_slope, moments=moments, gnb=gnb)
+            # alignment of x / y / residual, modes) is the library's answer -- a call it refuses runs on the direct kernel below.
+            # The answer is asked once per call signature (everything mi355_conv3d_wino_supported reads except the pointers' upper
+            # bits); mi355_conv3d_wino_fwd checks the same conditions again on every call, so a stale entry fails loudly there
+            key = (x.shape, x.ld, x.dtype, x.ptr() & 15, y.c, y.ld, y.dtype, in_mode, slope, scale is None, shift is None,
+                   None if residual is None else residual.ld)
+            ok = self._wino_ok.get(key) if HOST_CACHES else None
+            if ok is None:
+                probe = self._desc(3, 1, 1, in_mode, slope, scale, shift, bias, residual, chscale, (0, 0, 0), y.shape[1:4], [], in_slope, OUT_PLAIN)
+                xd_, yd_ = x.desc(), y.desc()
+                ok = self._wino_ok[key] = bool(self.lib.mi355_conv3d_wino_supported(ctypes.byref(xd_), ctypes.byref(yd_), ctypes.byref(probe)))
+            if ok:
+                return self.conv_fwd_wino(x, wp.wino(), y, in_mode, slope, scale, shift, bias, residual, chscale, in_slope, moments, gnb)
         keep = []
         d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep, in_slope, out_mode)
         xd, yd = x.desc(), y.desc()

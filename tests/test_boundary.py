@@ -121,6 +121,47 @@ def test_frozen_parameters_get_no_gradient_and_do_not_move(emu_backend):
     assert any(not torch.equal(before[k], after[k]) for k in before if k.startswith("decoder."))
 
 
+def test_module_surgery_between_steps_is_seen_by_the_engine(emu_backend):
+    """The engine keeps its parameter list and its gradient views between steps (host time). What the reference's users do to a built
+    model -- swap a Parameter (re-initialised norm), replace a submodule's parameter after a first step, accumulate, zero_grad() either
+    way -- must still behave like torch: new Parameters are the ones that are trained and receive .grad, values match the oracle."""
+    torch.manual_seed(7)
+    m = _model(emu_backend)
+    x, y = R.synthetic_case(1, 4, (8, 8, 8), 3)
+    crit = losses.HipDiceLoss(sigmoid=True)
+    crit._be = emu_backend
+
+    def check(tag):
+        for p in m.parameters():
+            p.grad = None
+        crit(m(x), y).backward()
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+        O.dice_loss(R.unet3d_forward(sd, x, (1, 1, 1)), y).backward()
+        assert [id(p) for p in m._params()] == [id(p) for p in m.parameters()], tag
+        for k, p in m.named_parameters():
+            assert p.grad is not None, (tag, k)
+            assert float((p.grad - sd[k].grad).abs().max() / sd[k].grad.abs().max().clamp_min(1e-30)) < 1e-3, (tag, k)
+
+    check("as built")
+    blk = m.encoder.layers[1].blocks[0]
+    blk.conv1.norm1.weight = torch.nn.Parameter(torch.full_like(blk.conv1.norm1.weight, 1.7))       # a swapped Parameter, deep in the tree
+    check("after swapping a norm weight")
+    m.decoder.layers[-1].blocks[0].conv2.conv.weight = torch.nn.Parameter(torch.randn_like(m.decoder.layers[-1].blocks[0].conv2.conv.weight) * 0.05)
+    check("after swapping a conv weight")
+    # accumulation over two micro-batches, then zero_grad(set_to_none=False) and a plain step: gradients still match
+    crit(m(x), y).backward()
+    g2 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    O.dice_loss(R.unet3d_forward(sd, x, (1, 1, 1)), y).backward()
+    for k in g2:
+        assert float((g2[k] - 2 * sd[k].grad).abs().max() / sd[k].grad.abs().max().clamp_min(1e-30)) < 2e-3, k
+    m.zero_grad(set_to_none=False)
+    assert all(float(p.grad.abs().max()) == 0.0 for p in m.parameters())
+    crit(m(x), y).backward()
+    for k, p in m.named_parameters():
+        assert float((p.grad - sd[k].grad).abs().max() / sd[k].grad.abs().max().clamp_min(1e-30)) < 1e-3, k
+
+
 def test_a_forward_that_raises_leaves_the_shared_backend_as_it_found_it(emu_backend, monkeypatch):
     """HipAutocastUNet switches the backend to its precision and its 16-bit activation storage for the duration of a forward. A forward that
     raises half-way (an OOM the caller catches, a refused call) must undo that: the next fp32 network on the same backend would otherwise

@@ -4,6 +4,10 @@ set -e
 here="$(cd "$(dirname "$0")" && pwd)"
 root="$(cd "$here/../.." && pwd)"
 src="$root/3dunetcnn_amd/csrc"
+# one builder at a time: parallel test workers all call this script; the first rebuilds, the others wait and find everything fresh
+mkdir -p "$here/build"
+exec 9> "$here/build/.lock"
+flock 9
 objs=()
 pids=()
 rebuilt=0

@@ -8,6 +8,8 @@ The tensors are CPU tensors (torch.empty on the CPU allocator instead of the HIP
 garbage. Numbers are relative, for comparing host-side changes.
 
   python tools/host_enqueue.py [--precision fp32|bf16] [--batch 2] [--size 128] [--steps 5] [--profile]
+  python tools/host_enqueue.py --gpu ...      the same loop on the real library and an idle MI355X (synchronised between steps, only the
+                                              enqueue is timed): what bench.py reports, with the cProfile breakdown
 """
 import argparse
 import cProfile
@@ -21,7 +23,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["MI355_EMU_NOEXEC"] = "1"
+if "--gpu" not in sys.argv:
+    os.environ["MI355_EMU_NOEXEC"] = "1"
 
 import torch  # noqa: E402
 
@@ -33,8 +36,10 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--gpu", action="store_true")
     args = ap.parse_args()
-    subprocess.check_call([os.path.join(ROOT, "tools", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if not args.gpu:
+        subprocess.check_call([os.path.join(ROOT, "tools", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     unet = importlib.import_module("3dunetcnn_amd.unet")
     losses = importlib.import_module("3dunetcnn_amd.losses")
     optim = importlib.import_module("3dunetcnn_amd.optim")
@@ -42,21 +47,27 @@ def main():
     lib_mod = importlib.import_module("3dunetcnn_amd._lib")
     # the one torch op of a step that touches a logits-sized tensor (d(loss)/d(logits) times the incoming scalar: an asynchronous
     # elementwise kernel on the GPU, 100 ms of real arithmetic on CPU tensors) is skipped like the launches are
-    losses._scaled = lambda ctx, g: ctx.dlogits
+    if not args.gpu:
+        losses._scaled = lambda ctx, g: ctx.dlogits
+    dev = torch.device("cuda", 0) if args.gpu else torch.device("cpu")
     torch.manual_seed(0)
-    model = unet.HipUNet3D(n_features=4, n_outputs=3)
+    model = unet.HipUNet3D(n_features=4, n_outputs=3).to(dev)
     if args.precision in ("bf16", "fp16"):
         model.act_storage = torch.bfloat16 if args.precision == "bf16" else torch.float16
     model.train()
     model.flatten_parameters()
     criterion = losses.HipDiceLoss(sigmoid=True)
     optimizer = optim.HipAdam(model.parameters(), lr=1e-3)
-    be = ops.Backend(lib=lib_mod.bind(ctypes.CDLL(os.path.join(ROOT, "tools", "emu", "libmi355unet3d_emu.so"))), device="cpu")
-    model._be = criterion._be = optimizer._be = be
+    if args.gpu:
+        be = ops.default_backend()
+    else:
+        be = ops.Backend(lib=lib_mod.bind(ctypes.CDLL(os.path.join(ROOT, "tools", "emu", "libmi355unet3d_emu.so"))), device="cpu")
+        model._be = criterion._be = optimizer._be = be
     be.set_precision(args.precision)
     S = args.size
-    x = torch.empty(args.batch, 4, S, S, S)
-    y = torch.empty(args.batch, 3, S, S, S)
+    x = torch.rand(args.batch, 4, S, S, S, device=dev) if args.gpu else torch.empty(args.batch, 4, S, S, S)
+    y = (torch.rand(args.batch, 3, S, S, S, device=dev) > 0.5).float() if args.gpu else torch.empty(args.batch, 3, S, S, S)
+    sync = torch.cuda.synchronize if args.gpu else (lambda: None)
 
     def step():
         optimizer.zero_grad(set_to_none=True)
@@ -66,18 +77,23 @@ def main():
 
     for _ in range(2):
         step()
+    sync()
     ts = []
     for _ in range(args.steps):
         t = time.perf_counter()
         step()
         ts.append((time.perf_counter() - t) * 1e3)
-    print(f"host side of one step ({args.precision}, batch {args.batch}, {S}^3, launches skipped): "
+        sync()
+    print(f"host side of one step ({args.precision}, batch {args.batch}, {S}^3, {'MI355X, idle device' if args.gpu else 'launches skipped'}): "
           f"min {min(ts):.2f} ms, median {sorted(ts)[len(ts) // 2]:.2f} ms")
     if args.profile:
         pr = cProfile.Profile()
         pr.enable()
         for _ in range(args.steps):
             step()
+            pr.disable()
+            sync()
+            pr.enable()
         pr.disable()
         st = pstats.Stats(pr)
         st.sort_stats("tottime").print_stats(35)
