@@ -80,7 +80,8 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-_current_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
+_current_raw_stream = ((os.environ.get("MI355_RAW_STREAM", "1") != "0" and getattr(torch._C, "_cuda_getCurrentRawStream", None))
+                       or (lambda i: torch.cuda.current_stream(i).cuda_stream))
 
 
 class PackedWeight:
