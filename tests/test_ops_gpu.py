@@ -355,3 +355,23 @@ def test_norm_backward_sums_zring_form(zring_backend, kw):
     fused = os.environ["MI355_BF16_FORM"] != "zring" or (16 < kw["cout"] <= 32 and kw["cin"] == 32)      # as in tests/test_ops_emu.py
     r = C.case_gn_bwd_fused(be, compare_unfused=True, expect_fused=fused, **kw)
     assert all(v < 2e-5 for v in r.values()), r
+
+
+def test_launch_stream_handle_follows_the_current_stream(hip_backend):
+    """Backend.stream() hands the library torch's CURRENT stream of the backend's device (raw handle, no Stream object per launch): the
+    default stream, a side stream inside torch.cuda.stream(...), and the default one again afterwards -- and a kernel launched inside the
+    context is ordered on that stream (its result is visible after synchronising the side stream only)."""
+    import torch
+    be = hip_backend
+    assert be.stream() == torch.cuda.current_stream(be.device).cuda_stream
+    s = torch.cuda.Stream(device=be.device)
+    x = be.empty_act(1, 4, 4, 4, 8)
+    x.buf.fill_(2.0)
+    y = be.empty_act(1, 4, 4, 4, 8)
+    s.wait_stream(torch.cuda.current_stream(be.device))
+    with torch.cuda.stream(s):
+        assert be.stream() == s.cuda_stream != 0
+        be.add(x, x, y)
+    assert be.stream() == torch.cuda.current_stream(be.device).cuda_stream
+    s.synchronize()
+    assert float(y.buf.min()) == float(y.buf.max()) == 4.0
