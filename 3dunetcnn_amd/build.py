@@ -69,11 +69,21 @@ def flags_for(cc, name, verbose=True):
     return FLAGS + extra
 
 
+def local_deps(depfile):
+    """Headers of THIS tree an object was compiled from (its compiler-written depfile, -MD): editing one of them rebuilds the objects that
+    include it and no others. No depfile yet: None (the caller falls back to every header)."""
+    if not os.path.exists(depfile):
+        return None
+    root = os.path.abspath(os.path.join(HERE, ".."))
+    words = open(depfile).read().replace("\\\n", " ").split()
+    return [w for w in words[1:] if os.path.abspath(w).startswith(root) and os.path.exists(w)]
+
+
 def build(force=False, verbose=True):
     srcs = sources()
-    # every header a kernel source may include: editing any of them rebuilds all objects
-    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
-    deps.append(os.path.join(HERE, "..", "include", "mi355_unet3d.h"))
+    # without a depfile: every header a kernel source may include
+    all_headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    all_headers.append(os.path.join(HERE, "..", "include", "mi355_unet3d.h"))
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     jobs = []
@@ -85,8 +95,11 @@ def build(force=False, verbose=True):
         fl = flags_for(cc, os.path.basename(s), verbose)
         stamp = o + ".flags"
         same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(fl)
+        deps = local_deps(o + ".d")
+        if deps is None:
+            deps = all_headers
         if force or not same_flags or newer(s, o) or any(newer(d, o) for d in deps):
-            jobs.append(([cc] + fl + ["-c", s, "-o", o], stamp, " ".join(fl)))
+            jobs.append(([cc] + fl + ["-MD", "-MF", o + ".d", "-c", s, "-o", o], stamp, " ".join(fl)))
 
     def run(job):
         cmd, stamp, text = job if isinstance(job, tuple) else (job, None, None)

@@ -639,10 +639,11 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const mi355_pack_task* 
   }
   const mi355_pack_task t = tasks[lo];
   const bool lp = t.kind >= MI355_PACK_LP;                  // 16-bit operand pack of precision t.kind - MI355_PACK_LP
-  const int coutP = (t.cout + 31) / 32 * 32, cinP = lp ? (t.cin + 15) / 16 * 16 : (t.cin + 7) / 8 * 8;
+  const int coutP = (t.cout + 31) / 32 * 32, cinP = lp ? (t.cin + 15) / 16 * 16 : (t.kind == MI355_PACK_WINO3 ? (t.cin + 3) / 4 * 4 : (t.cin + 7) / 8 * 8);
   const int T = t.kd * t.kd * t.kd;
   // work items: an fp32 / 16-bit pack element, or one (dz, ci, co) of a Winograd pack (16 outputs from 9 weights, pack_values.h)
-  const size_t items = t.kind == MI355_PACK_WINO ? (size_t)3 * cinP * coutP : (size_t)T * cinP * coutP;
+  // ... or one (ci, co) of a 3-D Winograd pack (64 outputs from 27 weights)
+  const size_t items = t.kind == MI355_PACK_WINO ? (size_t)3 * cinP * coutP : (t.kind == MI355_PACK_WINO3 ? (size_t)cinP * coutP : (size_t)T * cinP * coutP);
   const size_t base = (size_t)(chunk - t.first_chunk) * MI355_PACK_CHUNK;
   const int prec = t.kind - MI355_PACK_LP;
   const int ns = prec == MI355_PREC_BF16X3 ? 2 : (prec == MI355_PREC_BF16X6 ? 3 : 1);
@@ -652,6 +653,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const mi355_pack_task* 
     if (idx >= items) break;
     if (lp) pack_lp_item(t.w, reinterpret_cast<unsigned short*>(t.out), idx, t.cout, t.cin, T, coutP, cinP, t.mode, ns, prec == MI355_PREC_F16);
     else if (t.kind == MI355_PACK_WINO) pack_wino_item(t.w, t.out, idx, t.cout, t.cin, coutP, cinP, t.mode);
+    else if (t.kind == MI355_PACK_WINO3) pack_wino3_item(t.w, t.out, idx, t.cout, t.cin, coutP, cinP, t.mode);
     else t.out[idx] = pack_f32_value(t.w, idx, t.cout, t.cin, T, coutP, cinP, t.mode);
   }
 }

@@ -58,6 +58,18 @@ __device__ __forceinline__ void glds16_uniform_base(const void* ubase, unsigned 
 // its LDS instructions done; s_barrier without the fence of __syncthreads() (which waits vmcnt(0) while a DMA is in flight)
 #define WAIT_VMCNT_LGKM0(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x0070)
 #define RAW_BARRIER() __builtin_amdgcn_s_barrier()
+// The waitcnt and barrier builtins carry no memory semantics at IR level, and the DMA they order is hidden in inline asm: this
+// compiler-only fence (no instruction) keeps hipcc from moving an LDS access of the next phase above the wait + barrier that publish
+// its data, or one of this phase below them
+#define COMPILER_FENCE() asm volatile("" ::: "memory")
+// v_permlane32_swap_b32: lanes 32..63 of `upper_from` trade values with lanes 0..31 of `lower_from` (lane 32 + k of the first <-> lane k
+// of the second): two registers of a lane pair (l, l + 32) become a 2 x 2 transpose without touching the LDS
+__device__ __forceinline__ void permlane32_swap(float& upper_from, float& lower_from) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(upper_from), __float_as_uint(lower_from), false, false);
+  upper_from = __uint_as_float(r[0]); lower_from = __uint_as_float(r[1]);
+}
+// s_setprio: issue priority of this wave among the waves of its SIMD (0 lowest .. 3)
+#define SET_PRIO(n) __builtin_amdgcn_s_setprio(n)
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+0..7] and B[k=8*(l>>5)+0..7][j=l&31] as 8 packed bf16
 // (16 bytes, carried here as uint4); same C/D map as the f32 form. 32 cycles per SIMD = 16x the f32 MFMA rate.

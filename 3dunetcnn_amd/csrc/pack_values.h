@@ -63,6 +63,69 @@ __device__ __forceinline__ void pack_wino_item(const float* w, float* up, size_t
     for (int pj = 0; pj < 4; ++pj) dst[(size_t)(pi * 4 + pj) * slab] = u[pi][pj];
 }
 
+// Winograd F(2x2x2, 3x3x3) layout (conv3d_wino3d.hip): U[(zi, i, j)][ci][co] = sum_{dz,dy,dx} G[zi][dz] G[i][dy] G[j][dx] w[...], G as above.
+// Pack layout [point 64][ci / 4][co tile][lane half 2][co 32][2]: element (h, co, e) of a (point, quad, channel tile) is channel 4 q + 2 h + e.
+// mode 0: forward, w OIDHW [cout][cin][3][3][3]; mode 1: dgrad of Conv3d (roles swapped, taps flipped). One WORK ITEM = one (ci, co): its 27
+// weights are read once and all 64 points written; item index r runs over [quad][channel tile][half][co][e], the order inside a point's slab.
+__device__ __forceinline__ void pack_wino3_item(const float* w, float* up, size_t r, int cout, int cin, int coutP, int cinP, int mode) {
+  const int e = r & 1;
+  size_t q = r >> 1;
+  const int col = q & 31; q >>= 5;
+  const int h = q & 1; q >>= 1;
+  const int ct = q % (coutP / 32); q /= (coutP / 32);
+  const int cq = (int)q;
+  const int o = ct * 32 + col, i = cq * 4 + 2 * h + e;
+  const size_t slab = (size_t)cinP * coutP;                // floats between consecutive points
+  float* dst = up + r;
+  float u[4][4][4];
+  if (o < cout && i < cin) {
+    float u2[3][4][4];                                     // the plane transform of every dz slice: the expressions of pack_wino_item
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz) {
+      float g[3][3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+          g[dy][dx] = mode == 0 ? w[((size_t)o * cin + i) * 27 + (dz * 3 + dy) * 3 + dx]
+                                : w[((size_t)i * cout + o) * 27 + ((2 - dz) * 3 + (2 - dy)) * 3 + (2 - dx)];      // w[co = i][ci = o], flipped
+      float t[4][3];
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        t[0][dx] = g[0][dx]; t[1][dx] = 0.5f * (g[0][dx] + g[1][dx] + g[2][dx]); t[2][dx] = 0.5f * (g[0][dx] - g[1][dx] + g[2][dx]); t[3][dx] = g[2][dx];
+      }
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi) {
+        u2[dz][pi][0] = t[pi][0]; u2[dz][pi][1] = 0.5f * (t[pi][0] + t[pi][1] + t[pi][2]); u2[dz][pi][2] = 0.5f * (t[pi][0] - t[pi][1] + t[pi][2]);
+        u2[dz][pi][3] = t[pi][2];
+      }
+    }
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+      for (int pj = 0; pj < 4; ++pj) {
+        u[0][pi][pj] = u2[0][pi][pj];
+        u[1][pi][pj] = 0.5f * (u2[0][pi][pj] + u2[1][pi][pj] + u2[2][pi][pj]);
+        u[2][pi][pj] = 0.5f * (u2[0][pi][pj] - u2[1][pi][pj] + u2[2][pi][pj]);
+        u[3][pi][pj] = u2[2][pi][pj];
+      }
+  } else {
+#pragma unroll
+    for (int pz = 0; pz < 4; ++pz)
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) u[pz][pi][pj] = 0.f;
+  }
+#pragma unroll
+  for (int pz = 0; pz < 4; ++pz)
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+      for (int pj = 0; pj < 4; ++pj) dst[(size_t)((pz * 4 + pi) * 4 + pj) * slab] = u[pz][pi][pj];
+}
+
+
 // 16-bit operand layouts of the bf16 matrix paths [tap][ciP / 8][plane][coP][8] (conv3d_bf16.hip), ciP = roundup(cin, 16): NS planes per
 // element (hi, residual of hi, ...) of bf16, or one plane of IEEE fp16. One WORK ITEM = one (tap, ci, co) element (its NS planes).
 __device__ __forceinline__ void pack_lp_item(const float* w, unsigned short* wp, size_t idx, int cout, int cin, int T, int coutP, int cinP,

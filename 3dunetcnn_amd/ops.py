@@ -124,11 +124,14 @@ class PackedWeight:
         self._bf16_last = precision
         return self._bf16[precision]
 
-    def wino(self):
-        """Winograd-domain weights of a 3x3x3 kernel (csrc/conv3d_wino.hip), packed on first use."""
-        if getattr(self, "_wino", None) is None:
-            self._wino = self.be.wino_pack_weight(self.w, self.mode)
-        return self._wino
+    def wino(self, form=None):
+        """Winograd-domain weights of a 3x3x3 kernel, packed on first use: form "2d" = F(2x2, 3x3) x direct z (csrc/conv3d_wino.hip), "3d" =
+        F(2x2x2, 3x3x3) (csrc/conv3d_wino3d.hip); None = the backend's current form."""
+        form = form or self.be.wino_form
+        attr = "_wino3" if form == "3d" else "_wino"
+        if getattr(self, attr, None) is None:
+            setattr(self, attr, self.be.wino_pack_weight(self.w, self.mode, form))
+        return getattr(self, attr)
 
     def ptr_for(self, desc):
         if (self.mode == 0 and self.cin == 4 and self.kd == 3 and desc.stride == 1 and desc.pad == 1 and desc.out_mode == OUT_PLAIN
@@ -152,7 +155,7 @@ class Backend:
     # 16^3 a launch has fewer workgroups than the chip has CUs: the direct kernels' smaller tiles stay.
     WINO_MIN_VOXELS = 16 ** 3
     # executed / algorithmic multiplications of the Winograd kernels (bench.py reports both rates)
-    WINO_EXECUTED = {"conv3d_wino2d": 12.0 / 27.0, "conv3d_wgrad_wino_ring (+reduce)": 16.0 / 36.0}
+    WINO_EXECUTED = {"conv3d_wino2d": 12.0 / 27.0, "conv3d_wino3d": 8.0 / 27.0, "conv3d_wgrad_wino_ring (+reduce)": 16.0 / 36.0}
 
     def __init__(self, lib=None, device=None):
         self.lib = lib if lib is not None else _lib.load_library()
@@ -173,6 +176,11 @@ class Backend:
         # error equal to the direct kernel's. Measured on MI355X (round 3, profiles/r3_winograd_landing.txt): layer set 21.96 -> 15.28 ms,
         # UNet3D 128^3 batch-2 step 87.1 -> 75.2 ms. MI355_WINOGRAD=0 selects the direct kernels (the A/B and cross-check form).
         self.winograd = os.environ.get("MI355_WINOGRAD", "1") == "1"
+        # ... and which Winograd kernel: "3d" = F(2x2x2, 3x3x3) (csrc/conv3d_wino3d.hip, round 6: 8 multiplications per output and (ci, co)),
+        # "2d" = F(2x2, 3x3) x direct z (csrc/conv3d_wino.hip: 12). MI355_WINO_FORM selects; the A/B is profiles/r6_wino3d.txt.
+        self.wino_form = os.environ.get("MI355_WINO_FORM", "2d")
+        if self.wino_form not in ("2d", "3d"):
+            raise ValueError(f"MI355_WINO_FORM={self.wino_form!r}: '2d' or '3d'")
         # Weight gradients of the same layers: "wino" = the plane-ring Winograd kernel (csrc/conv3d_wgrad_wino.hip: all three dz per
         # workgroup, every plane transformed once), "direct" = conv3d_wgrad_ring. Measured on MI355X (round 3,
         # profiles/r3_wgrad_wino_ring_ab.txt): 32->32 @128^3 1.93 -> 1.21 (-> 1.13) ms, layer set 1.55-1.7x, UNet3D step 74.7 -> 64.1 ms.
@@ -261,6 +269,9 @@ class Backend:
             if getattr(pw, "_wino", None) is not None:
                 tasks.append((pw.w.data_ptr(), pw._wino.data_ptr(), pw.cout, pw.cin, pw.kd, pw.mode, 1, chunks))
                 chunks += (3 * cinP * coutP + CHUNK - 1) // CHUNK
+            if getattr(pw, "_wino3", None) is not None:     # MI355_PACK_WINO3: one work item per (ci, co), input channels padded to 4
+                tasks.append((pw.w.data_ptr(), pw._wino3.data_ptr(), pw.cout, pw.cin, pw.kd, pw.mode, 2, chunks))
+                chunks += ((pw.cin + 3) // 4 * 4 * coutP + CHUNK - 1) // CHUNK
             # only the 16-bit pack of the precision mode the NEXT forward runs in (this backend's current mode) is refreshed: packs of
             # other modes -- every 16-bit pack once the backend is back in fp32, the other network's after two networks alternated
             # modes on one PackedWeight -- are dropped and rebuilt on first use instead of being rewritten every step for nobody
@@ -281,6 +292,8 @@ class Backend:
                     check(self.lib.mi355_pack_conv_weight(w, out, cout, cin, kd, mode, self.stream()), "pack_conv_weight")
                 elif kind == 1:
                     check(self.lib.mi355_wino_pack_weight(w, out, cout, cin, mode, self.stream()), "wino_pack_weight")
+                elif kind == 2:
+                    check(self.lib.mi355_wino3d_pack_weight(w, out, cout, cin, mode, self.stream()), "wino3d_pack_weight")
                 else:
                     check(self.lib.mi355_pack_conv_weight_bf16(w, out, cout, cin, kd, mode, kind - 16, self.stream()), "pack_conv_weight_bf16")
             self.last_pack_table = None                    # no table was used: nothing for a capture to pin
@@ -345,12 +358,13 @@ class Backend:
             # The answer is asked once per call signature (everything mi355_conv3d_wino_supported reads except the pointers' upper
             # bits); mi355_conv3d_wino_fwd checks the same conditions again on every call, so a stale entry fails loudly there
             key = (x.shape, x.ld, x.dtype, x.ptr() & 15, y.c, y.ld, y.dtype, in_mode, slope, scale is None, shift is None,
-                   None if residual is None else residual.ld)
+                   None if residual is None else residual.ld, self.wino_form)
             ok = self._wino_ok.get(key) if HOST_CACHES else None
             if ok is None:
                 probe = self._desc(3, 1, 1, in_mode, slope, scale, shift, bias, residual, chscale, (0, 0, 0), y.shape[1:4], [], in_slope, OUT_PLAIN)
                 xd_, yd_ = x.desc(), y.desc()
-                ok = self._wino_ok[key] = bool(self.lib.mi355_conv3d_wino_supported(ctypes.byref(xd_), ctypes.byref(yd_), ctypes.byref(probe)))
+                supported = self.lib.mi355_conv3d_wino3d_supported if self.wino_form == "3d" else self.lib.mi355_conv3d_wino_supported
+                ok = self._wino_ok[key] = bool(supported(ctypes.byref(xd_), ctypes.byref(yd_), ctypes.byref(probe)))
             if ok:
                 return self.conv_fwd_wino(x, wp.wino(), y, in_mode, slope, scale, shift, bias, residual, chscale, in_slope, moments, gnb)
         keep = []
@@ -408,17 +422,22 @@ class Backend:
         return self._fold_after(y, gparts)
 
     # -- Winograd form of the 3x3x3 stride-1 conv (csrc/conv3d_wino.hip) -------------------------------------------------------------
-    def wino_pack_weight(self, w, mode=0):
+    def wino_pack_weight(self, w, mode=0, form=None):
         """w OIDHW [cout, cin, 3, 3, 3] -> transformed weights for conv_fwd_wino (mode 0: forward; mode 1: dgrad, i.e. a conv from
-        cout to cin channels)."""
+        cout to cin channels). form "2d" / "3d" (None: self.wino_form): which kernel's layout; the returned tensor remembers it
+        (`mi355_form`), conv_fwd_wino launches the kernel that reads it."""
+        form = form or self.wino_form
         cout, cin = (w.shape[0], w.shape[1]) if mode == 0 else (w.shape[1], w.shape[0])
         same = w.device.type == self.device.type and (w.device.type != "cuda" or
                                                      (w.device.index if w.device.index is not None else torch.cuda.current_device()) ==
                                                      (self.device.index if self.device.index is not None else torch.cuda.current_device()))
         if not same or w.dtype != torch.float32:
             raise ValueError(f"wino_pack_weight: weight on {w.device} ({w.dtype}), backend on {self.device}: fp32 on the backend device expected")
-        up = torch.empty(self.lib.mi355_wino_weight_elems(cout, cin), dtype=torch.float32, device=self.device)
-        check(self.lib.mi355_wino_pack_weight(w.contiguous().data_ptr(), up.data_ptr(), cout, cin, mode, self.stream()), "wino_pack_weight")
+        elems, pack = ((self.lib.mi355_wino3d_weight_elems, self.lib.mi355_wino3d_pack_weight) if form == "3d" else
+                       (self.lib.mi355_wino_weight_elems, self.lib.mi355_wino_pack_weight))
+        up = torch.empty(elems(cout, cin), dtype=torch.float32, device=self.device)
+        check(pack(w.contiguous().data_ptr(), up.data_ptr(), cout, cin, mode, self.stream()), "wino_pack_weight")
+        up.mi355_form = form
         return up
 
     def conv_fwd_wino(self, x, up, y, in_mode=IN_PLAIN, slope=0.0, scale=None, shift=None, bias=None, residual=None, chscale=None,
@@ -448,13 +467,16 @@ class Backend:
         if self.prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        check(self.lib.mi355_conv3d_wino_fwd(ctypes.byref(xd), up.data_ptr(), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_wino_fwd")
+        form3 = getattr(up, "mi355_form", "2d") == "3d"
+        fwd = self.lib.mi355_conv3d_wino3d_fwd if form3 else self.lib.mi355_conv3d_wino_fwd
+        check(fwd(ctypes.byref(xd), up.data_ptr(), ctypes.byref(yd), ctypes.byref(d), self.stream()), "conv3d_wino3d_fwd" if form3 else "conv3d_wino_fwd")
         if self.prof is not None:
             e1.record()
             nvox = y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3]
             fuse = 1 if d.moments_out else (2 if gparts is not None else 0)
-            self._prof_add("conv3d_wino2d", 2.0 * nvox * x.c * y.c * 27, 4.0 * (nvox * (x.c + y.c) + 27 * x.c * y.c), e0, e1,
-                           f"conv3d_wino2d_d8<{1 if in_mode == IN_AFFINE_ACT else 0}, {fuse}>",
+            kern = "conv3d_wino3d" if form3 else "conv3d_wino2d_d8"
+            self._prof_add("conv3d_wino3d" if form3 else "conv3d_wino2d", 2.0 * nvox * x.c * y.c * 27, 4.0 * (nvox * (x.c + y.c) + 27 * x.c * y.c), e0, e1,
+                           f"{kern}<{1 if in_mode == IN_AFFINE_ACT else 0}, {fuse}>",
                            4.0 * nvox * y.c * ((residual is not None) + (gparts is not None)))
         return self._fold_after(y, gparts)
 

@@ -157,6 +157,8 @@ int mi355_pack_conv_weight(const float* w, float* wp, int32_t cout, int32_t cin,
  * it, `total_chunks` = the sum over all tasks. */
 #define MI355_PACK_F32 0
 #define MI355_PACK_WINO 1
+#define MI355_PACK_WINO3 2    /* out = mi355_wino3d_pack_weight(w, cout, cin, mode) (kd ignored); work items = roundup(cin, 4) * roundup(cout, 32): one
+                                 (ci, co) pair, 64 outputs from 27 weights */
 #define MI355_PACK_LP 16      /* kind = MI355_PACK_LP + precision (MI355_PREC_BF16X3 .. MI355_PREC_F16): out = mi355_pack_conv_weight_bf16(w, ..., precision),
                                  modes 0 / 1, kd 3; work items = kd^3 * roundup(cin, 16) * roundup(cout, 32) */
 #define MI355_PACK_CHUNK 1024
@@ -338,6 +340,16 @@ int mi355_conv3d_wino_fwd(const mi355_act* x, const float* up, const mi355_act* 
 int mi355_conv3d_wino_supported(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* desc);
 /* records per sample its fused-statistics epilogues (desc->moments_out / desc->gn_bwd, formats of gn_fuse.h) write: 2 x 8 x 16 voxel tiles */
 int32_t mi355_conv3d_wino_stats_blocks(const mi355_act* y);
+/* ---- Winograd F(2x2x2, 3x3x3): the same convolution with the transform along z as well (csrc/conv3d_wino3d.hip, round 6) -----------------
+ * 8 instead of 12 (27) multiplications per output and (ci, co); the contract, the eligible calls (mi355_conv3d_wino3d_supported: those of
+ * mi355_conv3d_wino_supported with at most 1024 input channels) and the statistics records (mi355_conv3d_wino_stats_blocks: one per
+ * 2 x 8 x 16 voxel tile) are those of mi355_conv3d_wino_fwd; the weights are packed by mi355_wino3d_pack_weight (64 transform points,
+ * input channels padded to 4) into mi355_wino3d_weight_elems(cout, cin) floats. Replaces the same ATen / cuDNN call
+ * (unet3d/models/pytorch/classification/resnet.py:12-17). */
+size_t mi355_wino3d_weight_elems(int32_t cout, int32_t cin);
+int mi355_wino3d_pack_weight(const float* w, float* up, int32_t cout, int32_t cin, int32_t mode, void* stream);
+int mi355_conv3d_wino3d_fwd(const mi355_act* x, const float* up, const mi355_act* y, const mi355_conv_desc* desc, void* stream);
+int mi355_conv3d_wino3d_supported(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* desc);
 /* weight gradient in the same domain, F(3x3, 2x2) x direct z (csrc/conv3d_wgrad_wino.hip; replaces the ATen weight-gradient call behind
  * nn.Conv3d.backward for resnet.py:12-17): contract of mi355_conv3d_wgrad for kd 3 / stride 1 / pad 1. A z-marching plane ring: all
  * three dz per workgroup, every plane staged and transformed once. MI355_EUNSUPPORTED for channel counts that are not multiples

@@ -11,6 +11,16 @@ from oracle import torch_ops as O
 ops = C.ops
 
 
+@pytest.fixture(params=["2d", "3d"])
+def wino_form(emu_backend, request):
+    """Both Winograd forward / dgrad kernels take every case of this file: "2d" = conv3d_wino2d_d8 (F(2x2, 3x3) x direct z), "3d" =
+    conv3d_wino3d (F(2x2x2, 3x3x3), round 6). The backend's form decides which pack wino_pack_weight builds and which kernel reads it."""
+    old = emu_backend.wino_form
+    emu_backend.wino_form = request.param
+    yield request.param
+    emu_backend.wino_form = old
+
+
 @pytest.mark.parametrize("kw", [
     dict(n=1, cin=8, cout=32, dhw=(2, 8, 16)),                                   # exactly one tile
     dict(n=2, cin=32, cout=32, dhw=(4, 8, 16), bias=True),                       # two z tiles, four channel chunks
@@ -27,7 +37,7 @@ ops = C.ops
     dict(n=3, cin=20, cout=32, dhw=(3, 4, 33), norm=True, residual=True, bias=True),
     dict(n=2, cin=40, cout=72, dhw=(5, 8, 16), residual=True, chscale=True, bias=True),
 ])
-def test_wino_forward_matches_conv3d(emu_backend, kw):
+def test_wino_forward_matches_conv3d(emu_backend, kw, wino_form):
     be = emu_backend
     n, cin, cout, dhw = kw["n"], kw["cin"], kw["cout"], kw["dhw"]
     g = torch.Generator().manual_seed(3)
@@ -52,7 +62,7 @@ def test_wino_forward_matches_conv3d(emu_backend, kw):
     assert C.rel_err(C.from_act(ya), ref) < 1e-5
 
 
-def test_wino_dgrad_pack_matches_autograd(emu_backend):
+def test_wino_dgrad_pack_matches_autograd(emu_backend, wino_form):
     be = emu_backend
     g = torch.Generator().manual_seed(5)
     x = torch.randn(1, 16, 4, 8, 16, generator=g, requires_grad=True)
@@ -96,14 +106,14 @@ class _WinoBackend:
     dict(n=2, cin=4, cout=32, dhw=(3, 4, 17), bias=True),
     dict(n=1, cin=48, cout=40, dhw=(2, 6, 9), norm=True, slope=0.01),
 ])
-def test_wino_shared_forward_cases(emu_backend, kw):
+def test_wino_shared_forward_cases(emu_backend, kw, wino_form):
     be = _WinoBackend(emu_backend)
     assert C.case_conv_fwd(be, **kw) < 1e-5
     assert be.wino_calls == 1
 
 
 @pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=64, dhw=(3, 4, 18)), dict(n=2, cin=64, cout=32, dhw=(4, 4, 16))])
-def test_wino_shared_dgrad_cases(emu_backend, kw):
+def test_wino_shared_dgrad_cases(emu_backend, kw, wino_form):
     assert C.case_conv_dgrad(_WinoBackend(emu_backend), **kw) < 1e-5
 
 
@@ -112,19 +122,19 @@ def test_wino_shared_dgrad_cases(emu_backend, kw):
     dict(n=1, cin=16, cout=64, dhw=(4, 8, 16), yld=128, yc0=32),
     dict(n=2, cin=16, cout=40, dhw=(2, 6, 9), groups_out=40),
 ])
-def test_wino_epilogue_moments(emu_backend, kw):
+def test_wino_epilogue_moments(emu_backend, kw, wino_form):
     assert C.case_conv_moments(_WinoBackend(emu_backend), **kw) < 2e-5
 
 
 @pytest.mark.parametrize("kw", [dict(n=1, cin=32, cout=32, dhw=(3, 5, 19)), dict(n=2, cin=64, cout=16, dhw=(4, 4, 16), slope=0.01)])
-def test_wino_norm_backward_sums_from_dgrad_epilogue(emu_backend, kw):
+def test_wino_norm_backward_sums_from_dgrad_epilogue(emu_backend, kw, wino_form):
     be = _WinoBackend(emu_backend)
     r = C.case_gn_bwd_fused(be, **kw)
     assert all(v < 2e-4 for v in r.values()), r
     assert be.wino_calls == 1
 
 
-def test_whole_network_step_on_the_winograd_kernels(emu_backend):
+def test_whole_network_step_on_the_winograd_kernels(emu_backend, wino_form):
     """Product routing with the size threshold removed: every eligible 3x3x3 stride-1 forward / dgrad / wgrad conv of a UNet3D step on the
     Winograd kernels, against the golden bundle generated from the reference."""
     import importlib

@@ -1,7 +1,8 @@
 """Developer tool (GPU): launch time of the headline step's conv layers, one kernel at a time, for one or several builds of the
 kernel library on the same box.
 
-    [PREC=bf16] python tools/bench_conv_layers.py [lib.so ...]        (no argument: the in-tree library; "tree" names it in a list)
+    [PREC=bf16] python tools/bench_conv_layers.py [lib.so[@form] ...]  (no argument: the in-tree library; "tree" names it in a list;
+                                                                        "@3d" / "@2d" selects the Winograd forward kernel: MI355_WINO_FORM)
 
 Layers: the 3x3x3 convolutions of UNet3D 4->3 at 128^3, batch 2 (forward with the norm prologue + fused moments, the plain form, and
 the plain form with the norm-backward sums in its epilogue as the data gradients run it) and the 1x1x1 shortcut. PREC selects the
@@ -19,6 +20,8 @@ LAYERS = [(32, 32, 128, 3), (64, 32, 128, 3), (32, 64, 128, 3), (64, 64, 64, 3),
 
 def one(path):
     sys.path.insert(0, ROOT)
+    if "@" in path:
+        path, os.environ["MI355_WINO_FORM"] = path.split("@")
     import torch
     lib = importlib.import_module("3dunetcnn_amd._lib")
     if path != "tree":

@@ -15,11 +15,14 @@ for f in "$src"/*.hip; do
   o="$here/build/$(basename "$f" .hip).o"
   mkdir -p "$here/build"
   stale=0
-  for dep in "$f" "$here/emu.h" "$root/include/mi355_unet3d.h" "$src"/*.h; do      # every header a kernel source may include
-    if [ ! -f "$o" ] || [ "$dep" -nt "$o" ]; then stale=1; fi
+  # dependencies: the headers the object was compiled from (g++ -MD depfile beside it); without one, every header a source may include
+  if [ -f "$o.d" ]; then deps=$(sed -e 's/^[^:]*://' -e 's/\\$//' "$o.d" | tr ' ' '\n' | grep -E "^($root|\.\./|[^/])" | sort -u)
+  else deps="$f $here/emu.h $root/include/mi355_unet3d.h $(ls "$src"/*.h)"; fi
+  for dep in $deps; do
+    if [ ! -f "$o" ] || { [ -f "$dep" ] && [ "$dep" -nt "$o" ]; }; then stale=1; fi
   done
   if [ "$stale" = 1 ]; then
-    g++ -std=c++20 -O2 -g -fPIC -DMI355_EMU -Wno-unknown-pragmas -I"$here" -I"$src" -x c++ -c "$f" -o "$o" &
+    g++ -std=c++20 -O2 -g -fPIC -DMI355_EMU -Wno-unknown-pragmas -I"$here" -I"$src" -MD -MF "$o.d" -x c++ -c "$f" -o "$o" &
     pids+=($!)
     rebuilt=1
   fi

@@ -373,5 +373,15 @@ static inline void emu_wait_vmcnt(unsigned n) {
 }
 #define WAIT_VMCNT_LGKM0(n) emu_wait_vmcnt(n)
 #define RAW_BARRIER() __syncthreads()
+#define COMPILER_FENCE() do {} while (0)
+#define SET_PRIO(n) do {} while (0)
+// v_permlane32_swap_b32: lane 32 + k of the first register <-> lane k of the second
+static inline void permlane32_swap(float& upper_from, float& lower_from) {
+  const int l = emu::flat_tid() % 64;
+  const float got = l < 32 ? emu_shfl(lower_from, l + 32) : emu_shfl(lower_from, l - 32);      // what the partner lane holds in `lower_from`
+  const float got2 = l < 32 ? emu_shfl(upper_from, l + 32) : emu_shfl(upper_from, l - 32);     // ... and in `upper_from`
+  if (l < 32) lower_from = got2;        // lower lane: its `lower_from` <- partner's (lane l + 32) `upper_from`
+  else upper_from = got;                // upper lane: its `upper_from` <- partner's (lane l - 32) `lower_from`
+}
 typedef uint4 u32x4_t;
 #define SLEEP_64CLK(n) do {} while (0)
