@@ -106,6 +106,13 @@ SIGNATURES = {
     "mi355_conv3d_wino_fwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, POINTER(MiAct), POINTER(MiConvDesc), c_void_p]),
     "mi355_conv3d_wino_supported": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), POINTER(MiConvDesc)]),
     "mi355_conv3d_wino_stats_blocks": (c_int32, [POINTER(MiAct)]),
+    "mi355_conv3d_c4_bwd_supported": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), POINTER(MiConvDesc)]),
+    "mi355_conv3d_c4_bwd_blocks": (c_int32, [POINTER(MiAct)]),
+    "mi355_conv3d_c4_bwd_workspace": (c_size_t, [POINTER(MiAct), POINTER(MiAct), POINTER(MiConvDesc)]),
+    "mi355_conv3d_c4_bwd": (ctypes.c_int, [POINTER(MiAct), POINTER(MiAct), c_void_p, c_void_p, POINTER(MiConvDesc), c_void_p, c_int32, c_void_p,
+                                           c_void_p, c_size_t, c_void_p]),
+    "mi355_gn_bwd_params": (ctypes.c_int, [POINTER(MiAct), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t,
+                                           c_void_p]),
     "mi355_wino3d_weight_elems": (c_size_t, [c_int32, c_int32]),
     "mi355_wino3d_pack_weight": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "mi355_conv3d_wino3d_fwd": (ctypes.c_int, [POINTER(MiAct), c_void_p, POINTER(MiAct), POINTER(MiConvDesc), c_void_p]),

@@ -22,7 +22,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # conv3d_wino.hip: without SLP vectorisation. The fragment generation of conv3d_wino2d_d8 is written per element with a scalar sign; the SLP
 # vectoriser packs part of it into v_pk_* (the sign then needs a register pair per lane) and hipcc unpacks some of that again in the shadow of
 # the MFMAs -- a mix whose instruction count per phase the scheduler directives cannot name.
-EXTRA_FLAGS = {"conv3d_bf16_zring.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "conv3d_wino.hip": ["-fno-slp-vectorize"]}
+# conv3d_wino3d.hip: the same (its sched_group_barrier counts name scalar fp32 instructions).
+EXTRA_FLAGS = {"conv3d_bf16_zring.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "conv3d_wino.hip": ["-fno-slp-vectorize"],
+               "conv3d_wino3d.hip": ["-fno-slp-vectorize"]}
+# what building WITHOUT an unsupported flag set costs, per file (printed with the warning)
+EXTRA_FLAGS_LOST = {"conv3d_bf16_zring.hip": "the 16-bit plane-ring kernels then copy weight fragments between register halves: slower, same results",
+                    "conv3d_wino.hip": "the scheduling directives of conv3d_wino2d_d8 assume the non-vectorised instruction mix: performance only",
+                    "conv3d_wino3d.hip": "the scheduling directives of conv3d_wino3d assume the non-vectorised instruction mix: performance only"}
 
 
 def hipcc():
@@ -63,8 +69,8 @@ def flags_for(cc, name, verbose=True):
     extra = EXTRA_FLAGS.get(name, [])
     if extra and not flags_supported(cc, extra):
         if verbose:
-            print(f"build.py: WARNING: this hipcc does not accept {' '.join(extra)}; building {name} without it (the 16-bit plane-ring kernels "
-                  "then copy weight fragments between register halves: slower, same results)", file=sys.stderr, flush=True)
+            print(f"build.py: WARNING: this hipcc does not accept {' '.join(extra)}; building {name} without it ({EXTRA_FLAGS_LOST.get(name, 'performance only')})",
+                  file=sys.stderr, flush=True)
         extra = []
     return FLAGS + extra
 

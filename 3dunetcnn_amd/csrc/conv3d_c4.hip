@@ -456,6 +456,11 @@ __global__ __launch_bounds__(256) void conv3d_c4_wgrad_reduce(const float* ws, f
   }
 }
 
+// the same reduction for the slabs of conv3d_c4_bwd (conv3d_c4_bwd.hip): one channel tile, `splits` slabs
+void conv3d_c4_wgrad_reduce_launch(const float* ws, float* dw, int Cout, int splits, void* stream) {
+  LAUNCH(conv3d_c4_wgrad_reduce, dim3(128), dim3(256), 0, stream, ws, dw, Cout, splits);
+}
+
 // ---- dgrad of the first layer: 3x3x3 stride-1 conv with <= 4 OUTPUT channels on the vector ALU ----
 // The gradient wrt the activated first-layer input (needed for the gamma/beta gradients of the network's first norm) is a
 // conv Cout -> 4. On the 32-wide MFMA N tile 7/8 of the matrix work would be padding (measured: 2.0 ms at 128^3, batch 2 --

@@ -47,11 +47,28 @@
 #endif
 #ifndef WINO3_ABL
 // developer ablations (tools/build_variant.sh ... -DWINO3_ABL=mask; results wrong by construction, timing only):
-// 1 no input requests, 2 no weight requests, 4 no fragment generation (the loop reuses the first fragments), 8 no MFMAs
+// 1 no input requests, 2 no weight requests, 4 no fragment generation (the loop reuses the first fragments), 8 no MFMAs, 16 no epilogue
+// (one store per lane keeps the accumulators alive), 32 no barrier at the end of a phase, 64 no weight-fragment reads in the loop
 #define WINO3_ABL 0
 #endif
 
 __device__ const float wino3_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// glds16 (gfx950_dialect.h) for lanes 0..50 of a wave only, without a branch: `if (lane < 51) glds16(...)` becomes s_and_saveexec +
+// s_cbranch_execz, which cuts the phase into basic blocks the scheduler cannot interleave across; here the lane mask is put into EXEC
+// around the one instruction inside the asm statement.
+#ifdef MI355_EMU
+static inline void glds16_lanes51(const void* src, float* lds_wave_base) { if (emu::flat_tid() % 64 < 51) glds16(src, lds_wave_base); }
+#define W3_SGB(mask, n)
+#else
+__device__ __forceinline__ void glds16_lanes51(const void* src, float* lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte_address(lds_wave_base));
+  unsigned long long saved;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved) : "v"(src), "s"(m0v), "s"(0x0007ffffffffffffull) : "memory");
+}
+#define W3_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#endif
 
 template <int INMODE, int FUSE>
 __global__ __launch_bounds__(1024) void conv3d_wino3d(WinoArgs a) {
@@ -132,7 +149,7 @@ __global__ __launch_bounds__(1024) void conv3d_wino3d(WinoArgs a) {
     const LaneMask m = q_ < NQ ? m_in : (LaneMask)0;       // uniform
     const char* src = LANE_IN_MASK(m) ? real : reinterpret_cast<const char*>(wino3_zero16);
 #if !(WINO3_ABL & 1)
-    if (lane < 51) glds16(src, xs + bx * XSF + wave * (51 * 4));
+    glds16_lanes51(src, xs + bx * XSF + wave * (51 * 4));
 #else
     (void)src;
 #endif
@@ -164,7 +181,7 @@ __global__ __launch_bounds__(1024) void conv3d_wino3d(WinoArgs a) {
     for (int j2 = 0; j2 < 2; ++j2) {
       const float4* src = up4 + ((size_t)(4 * wave + 2 * j2) * NQ + q_) * (a.coTiles * 32) + (size_t)cot * 32;      // uniform
 #if !(WINO3_ABL & 2)
-      glds16_uniform_base(live ? reinterpret_cast<const void*>(src) : reinterpret_cast<const void*>(wino3_zero16), live ? woff : 0u,
+      glds16_uniform_base(live ? reinterpret_cast<const void*>(src) : reinterpret_cast<const void*>(wino3_zero16), woff & (live ? ~0u : 0u),
                           ws + bw * WSF + (4 * wave + 2 * j2) * 128);
 #else
       (void)src; (void)live;
@@ -184,20 +201,22 @@ __global__ __launch_bounds__(1024) void conv3d_wino3d(WinoArgs a) {
   const unsigned g_ba = (unsigned)((zb * PSL + (2 * tty + ra) * RS + ttx + 10 * half) * 4);
   const unsigned g_bb = (unsigned)((zb * PSL + (2 * tty + rb) * RS + ttx + 10 * half) * 4);
   struct AF { float v[4][2]; };                            // [j][channel of the lane's pair]
-  auto gen = [&](const float* xb, AF& f) {
-    float R[4][2];
-#pragma unroll
-    for (int Pc = 0; Pc < 2; ++Pc) {
-      const float4 aa = *reinterpret_cast<const float4*>(xb + g_aa + 4 * Pc), ab = *reinterpret_cast<const float4*>(xb + g_ab + 4 * Pc);
-      const float4 ba = *reinterpret_cast<const float4*>(xb + g_ba + 4 * Pc), bb = *reinterpret_cast<const float4*>(xb + g_bb + 4 * Pc);
-      float r0 = fmaf(ab.x, beta, aa.x), r1 = fmaf(ab.y, beta, aa.y), r2 = fmaf(ab.z, beta, aa.z), r3 = fmaf(ab.w, beta, aa.w);
-      const float t0 = fmaf(bb.x, beta, ba.x), t1 = fmaf(bb.y, beta, ba.y), t2 = fmaf(bb.z, beta, ba.z), t3 = fmaf(bb.w, beta, ba.w);
-      r0 = fmaf(t0, betaz, r0); r1 = fmaf(t1, betaz, r1); r2 = fmaf(t2, betaz, r2); r3 = fmaf(t3, betaz, r3);
-      // lane (t, 0) holds column 2 Pc, lane (t, 1) column 2 Pc + 1, four channels each -> both hold both columns, channels 2 h, 2 h + 1
-      permlane32_swap(r0, r2);
-      permlane32_swap(r1, r3);
-      R[2 * Pc][0] = r0; R[2 * Pc][1] = r1; R[2 * Pc + 1][0] = r2; R[2 * Pc + 1][1] = r3;
-    }
+  struct Win { float4 aa, ab, ba, bb; };                   // the four window values (plane, row) of one column, four channels each
+  auto win_read = [&](const float* xb, int Pc, Win& t) {
+    t.aa = *reinterpret_cast<const float4*>(xb + g_aa + 4 * Pc); t.ab = *reinterpret_cast<const float4*>(xb + g_ab + 4 * Pc);
+    t.ba = *reinterpret_cast<const float4*>(xb + g_ba + 4 * Pc); t.bb = *reinterpret_cast<const float4*>(xb + g_bb + 4 * Pc);
+  };
+  // R = (d[za][ra] + b d[za][rb]) + bz (d[zb][ra] + b d[zb][rb]) of this lane's column (12 fma), then the 2 x 2 transpose of the lane pair:
+  // lane (t, 0) holds column 2 Pc, lane (t, 1) column 2 Pc + 1, four channels each -> both hold both columns, channels 2 h, 2 h + 1
+  auto win_combine = [&](const Win& t, float (&Ra)[2], float (&Rb)[2]) {
+    float r0 = fmaf(t.ab.x, beta, t.aa.x), r1 = fmaf(t.ab.y, beta, t.aa.y), r2 = fmaf(t.ab.z, beta, t.aa.z), r3 = fmaf(t.ab.w, beta, t.aa.w);
+    const float t0 = fmaf(t.bb.x, beta, t.ba.x), t1 = fmaf(t.bb.y, beta, t.ba.y), t2 = fmaf(t.bb.z, beta, t.ba.z), t3 = fmaf(t.bb.w, beta, t.ba.w);
+    r0 = fmaf(t0, betaz, r0); r1 = fmaf(t1, betaz, r1); r2 = fmaf(t2, betaz, r2); r3 = fmaf(t3, betaz, r3);
+    permlane32_swap(r0, r2);
+    permlane32_swap(r1, r3);
+    Ra[0] = r0; Ra[1] = r1; Rb[0] = r2; Rb[1] = r3;
+  };
+  auto gen_finish = [&](const float (&R)[4][2], AF& f) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       f.v[0][e] = R[0][e] - R[2][e];
@@ -205,6 +224,13 @@ __global__ __launch_bounds__(1024) void conv3d_wino3d(WinoArgs a) {
       f.v[2][e] = R[2][e] - R[1][e];
       f.v[3][e] = R[1][e] - R[3][e];
     }
+  };
+  auto gen = [&](const float* xb, AF& f) {                 // (prologue: nothing to interleave with)
+    float R[4][2];
+    Win t;
+    win_read(xb, 0, t); win_combine(t, R[0], R[1]);
+    win_read(xb, 1, t); win_combine(t, R[2], R[3]);
+    gen_finish(R, f);
   };
   // weight fragments of the wave's four points from slab bw: one ds_read_b64 each (lanes of a half read consecutive 8 bytes)
   struct WF { float2 v[4]; };
@@ -214,17 +240,18 @@ __global__ __launch_bounds__(1024) void conv3d_wino3d(WinoArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) w.v[j] = *reinterpret_cast<const float2*>(sp + j * 128);
   };
-  auto mfmas = [&](const AF& f, const WF& w) {
-#if !(WINO3_ABL & 8)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = MFMA_32x32x2(w.v[j].x, f.v[j][0], acc[j]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = MFMA_32x32x2(w.v[j].y, f.v[j][1], acc[j]);
+#if WINO3_ABL & 8
+#define W3_MF(j, e) do { } while (0)
+#else
+#define W3_MF(j, e) acc[j] = MFMA_32x32x2((e) ? wcur.v[j].y : wcur.v[j].x, fcur.v[j][e], acc[j])
 #endif
-  };
   // End of a phase that issued N DMA instructions per wave: everything issued in EARLIER phases has landed (in-order counter), this wave's
   // LDS accesses are done, barrier (raw: __syncthreads() would drain the DMA queue); the compiler may not move LDS accesses across it
+#if WINO3_ABL & 32
+#define W3_PHASE_END(N) do { COMPILER_FENCE(); WAIT_VMCNT_LGKM0(N); if ((N) == 0) RAW_BARRIER(); COMPILER_FENCE(); } while (0)
+#else
 #define W3_PHASE_END(N) do { COMPILER_FENCE(); WAIT_VMCNT_LGKM0(N); RAW_BARRIER(); COMPILER_FENCE(); } while (0)
+#endif
 
   // ---- prologue: the first four input chunks and three weight slabs requested together and waited for ----
   dma_in(0, 0); dma_in(1, 1); dma_in(2, 2); dma_in(3, 3);
@@ -250,16 +277,51 @@ __global__ __launch_bounds__(1024) void conv3d_wino3d(WinoArgs a) {
   // (read at the bottom of phase p - 1) | weight fragments of quad p + 1 read at the bottom. Everything a phase reads from LDS was
   // requested at least two phases earlier and waited for at the end of the phase before. Two phases per trip: the fragment sets swap.
   int bx = 0, bw = 0;                                      // p % 4, p % 3
+  // The order inside a phase (scheduling regions, pinned): the window reads of column pair 0 go out first, two MFMAs behind them cover
+  // the LDS latency; every DMA request sits behind an MFMA (issuing one occupies the wave for 60-190 cycles, the matrix pipe spends
+  // 64 on an MFMA and has three other waves of the SIMD to take from); the 36 fragment instructions ride between the remaining MFMAs.
   auto phase = [&](int p, const AF& fcur, const WF& wcur, AF& fnext, WF& wnext) {
     const int bx1 = (bx + 1) & 3, bx2 = (bx + 2) & 3, bw1 = bw == 2 ? 0 : bw + 1;
-    dma_in(p + 4, bx);
-    dma_w(p + 3, bw);
+    const float* xb = xs + bx1 * XSF;
+    float R[4][2];
+    Win t0, t1;
 #if !(WINO3_ABL & 4)
-    gen(xs + bx1 * XSF, fnext);
+    win_read(xb, 0, t0);
 #endif
-    mfmas(fcur, wcur);
-    if (p + 2 < NQ) activate(p + 2, bx2);              // (uniform)
+    SCHED_BARRIER();
+    W3_MF(0, 0); W3_MF(1, 0);
+    SCHED_BARRIER();
+    dma_in(p + 4, bx);
+    SCHED_BARRIER();
+#if !(WINO3_ABL & 4)
+    win_read(xb, 1, t1);
+    win_combine(t0, R[0], R[1]);
+#endif
+    W3_MF(2, 0); W3_MF(3, 0);
+    W3_SGB(0x100, 4); W3_SGB(0x008, 1); W3_SGB(0x002, 7); W3_SGB(0x008, 1); W3_SGB(0x002, 7);
+    SCHED_BARRIER();
+    dma_w(p + 3, bw);
+    SCHED_BARRIER();
+#if !(WINO3_ABL & 4)
+    win_combine(t1, R[2], R[3]);
+#endif
+    W3_MF(0, 1); W3_MF(1, 1);
+    W3_SGB(0x008, 1); W3_SGB(0x002, 7); W3_SGB(0x008, 1); W3_SGB(0x002, 7);
+    SCHED_BARRIER();
+#if !(WINO3_ABL & 4)
+    gen_finish(R, fnext);
+#endif
+#if !(WINO3_ABL & 64)
     w_lds(bw1, wnext);
+#endif
+    W3_MF(2, 1); W3_MF(3, 1);
+    W3_SGB(0x008, 1); W3_SGB(0x100, 4); W3_SGB(0x002, 4); W3_SGB(0x008, 1); W3_SGB(0x002, 4);
+    SCHED_BARRIER();
+    if (p + 2 < NQ) activate(p + 2, bx2);                  // (uniform)
+    // the fragments are used by the NEXT phase only: without the pins hipcc sinks the arithmetic behind the barrier
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { PIN_IN_VGPR(fnext.v[j][0]); PIN_IN_VGPR(fnext.v[j][1]); }
+    SCHED_BARRIER();
     W3_PHASE_END(3);
     bx = bx1; bw = bw1;
   };
@@ -269,6 +331,14 @@ __global__ __launch_bounds__(1024) void conv3d_wino3d(WinoArgs a) {
   }
   W3_PHASE_END(0);                                         // the requests of the last phases (never read) have landed: the exchange reuses the LDS
 
+#if WINO3_ABL & 16
+  { float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += acc[j][r];
+    a.y[(size_t)blockIdx.x * 1024 % 4096 + tid] = t; return; }
+#endif
   // ---- output transform Y = A^T M A (x) A^T, bias / residual / dropout scale, store ----
   // Columns (j -> b) in registers, written to the exchange P[wave][b][tile][co] as 16-byte runs of the 4 consecutive channels an accumulator
   // quad holds; rows (i -> a) and planes (zi -> oz) across the waves on the way out, voxel-major.
@@ -385,6 +455,8 @@ __global__ __launch_bounds__(1024) void conv3d_wino3d(WinoArgs a) {
   if constexpr (FUSE != 0) wino_fuse_records<FUSE, 16>(a, P, tid, lane, wave, coq, co_base, n, tz0, ty0, tx0, cnt, K0, s0, s1);
 }
 #undef W3_PHASE_END
+#undef W3_MF
+#undef W3_SGB
 
 // ---- filter transform (pack_values.h: pack_wino3_item) ----
 __global__ void wino3_pack_weight_kernel(const float* w, float* up, int cout, int cin, int coutP, int cinP, int mode) {

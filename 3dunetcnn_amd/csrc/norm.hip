@@ -494,6 +494,26 @@ static int gn_act_bwd_impl(const mi355_act* x, const mi355_act* dA, const mi355_
   return LAUNCH_CHECK();
 }
 
+// The parameter gradients alone, from partial records (gn_fuse.h format) a producer left: no data-gradient pass. For the network's FIRST
+// norm (its input needs no gradient): conv3d_c4_bwd.hip leaves the records, nothing reads or writes a tensor here.
+extern "C" int mi355_gn_bwd_params(const mi355_act* x, int32_t groups, const float* gamma, const float* mean_rstd, float* dgamma, float* dbeta,
+                                   const float* partials, int32_t blocks, void* ws, size_t ws_bytes, void* stream) {
+  int rc = gn_check(x, groups);
+  if (rc) return rc;
+  if (!partials || blocks <= 0 || !mean_rstd || !ws || (!dgamma && !dbeta)) return MI355_EINVAL;
+  if (ws_bytes < mi355_gn_workspace(x)) return MI355_EWORKSPACE;
+  const long long V = (long long)x->d * x->h * x->w;
+  const int C = x->c, N = x->n;
+  const int B = gn_blocks_per_sample(V);
+  float* part = (float*)ws;
+  float* coef = part + (size_t)N * B * C * 2;
+  float* ncs = coef + (size_t)N * C * 4;
+  LAUNCH(gn_bwd_finalize_kernel, dim3(groups, N), dim3(256), 0, stream, partials, (int)blocks, C, groups, V, gamma, mean_rstd, coef, ncs);
+  rc = LAUNCH_CHECK(); if (rc) return rc;
+  LAUNCH(gn_bwd_param_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, (const float*)ncs, N, C, dgamma, dbeta);
+  return LAUNCH_CHECK();
+}
+
 extern "C" int mi355_gn_act_bwd(const mi355_act* x, const mi355_act* dA, const mi355_act* dx, const void* addend, int32_t addend_ld,
                                 int32_t groups, float act_slope, const float* gamma, const float* mean_rstd,
                                 const float* scale, const float* shift, float* dgamma, float* dbeta,

@@ -128,6 +128,8 @@ class PackedWeight:
         """Winograd-domain weights of a 3x3x3 kernel, packed on first use: form "2d" = F(2x2, 3x3) x direct z (csrc/conv3d_wino.hip), "3d" =
         F(2x2x2, 3x3x3) (csrc/conv3d_wino3d.hip); None = the backend's current form."""
         form = form or self.be.wino_form
+        if form == "auto":                                  # (resolved per call by Backend.conv_fwd; asked without a call: the 2-D pack)
+            form = "2d"
         attr = "_wino3" if form == "3d" else "_wino"
         if getattr(self, attr, None) is None:
             setattr(self, attr, self.be.wino_pack_weight(self.w, self.mode, form))
@@ -178,9 +180,11 @@ class Backend:
         self.winograd = os.environ.get("MI355_WINOGRAD", "1") == "1"
         # ... and which Winograd kernel: "3d" = F(2x2x2, 3x3x3) (csrc/conv3d_wino3d.hip, round 6: 8 multiplications per output and (ci, co)),
         # "2d" = F(2x2, 3x3) x direct z (csrc/conv3d_wino.hip: 12). MI355_WINO_FORM selects; the A/B is profiles/r6_wino3d.txt.
-        self.wino_form = os.environ.get("MI355_WINO_FORM", "2d")
-        if self.wino_form not in ("2d", "3d"):
-            raise ValueError(f"MI355_WINO_FORM={self.wino_form!r}: '2d' or '3d'")
+        # "auto" = per call: "3d" where it measured faster (profiles/r6_wino3d.txt: >= 256 input channels with a plain input, or at most
+        # 16^3 voxels), "2d" elsewhere.
+        self.wino_form = os.environ.get("MI355_WINO_FORM", "auto")
+        if self.wino_form not in ("2d", "3d", "auto"):
+            raise ValueError(f"MI355_WINO_FORM={self.wino_form!r}: '2d', '3d' or 'auto'")
         # Weight gradients of the same layers: "wino" = the plane-ring Winograd kernel (csrc/conv3d_wgrad_wino.hip: all three dz per
         # workgroup, every plane transformed once), "direct" = conv3d_wgrad_ring. Measured on MI355X (round 3,
         # profiles/r3_wgrad_wino_ring_ab.txt): 32->32 @128^3 1.93 -> 1.21 (-> 1.13) ms, layer set 1.55-1.7x, UNet3D step 74.7 -> 64.1 ms.
@@ -357,16 +361,19 @@ class Backend:
             # alignment of x / y / residual, modes) is the library's answer -- a call it refuses runs on the direct kernel below.
             # The answer is asked once per call signature (everything mi355_conv3d_wino_supported reads except the pointers' upper
             # bits); mi355_conv3d_wino_fwd checks the same conditions again on every call, so a stale entry fails loudly there
+            form = self.wino_form
+            if form == "auto":
+                form = "3d" if x.c >= 256 and (in_mode == IN_PLAIN or x.shape[1] * x.shape[2] * x.shape[3] <= 16 ** 3) else "2d"
             key = (x.shape, x.ld, x.dtype, x.ptr() & 15, y.c, y.ld, y.dtype, in_mode, slope, scale is None, shift is None,
-                   None if residual is None else residual.ld, self.wino_form)
+                   None if residual is None else residual.ld, form)
             ok = self._wino_ok.get(key) if HOST_CACHES else None
             if ok is None:
                 probe = self._desc(3, 1, 1, in_mode, slope, scale, shift, bias, residual, chscale, (0, 0, 0), y.shape[1:4], [], in_slope, OUT_PLAIN)
                 xd_, yd_ = x.desc(), y.desc()
-                supported = self.lib.mi355_conv3d_wino3d_supported if self.wino_form == "3d" else self.lib.mi355_conv3d_wino_supported
+                supported = self.lib.mi355_conv3d_wino3d_supported if form == "3d" else self.lib.mi355_conv3d_wino_supported
                 ok = self._wino_ok[key] = bool(supported(ctypes.byref(xd_), ctypes.byref(yd_), ctypes.byref(probe)))
             if ok:
-                return self.conv_fwd_wino(x, wp.wino(), y, in_mode, slope, scale, shift, bias, residual, chscale, in_slope, moments, gnb)
+                return self.conv_fwd_wino(x, wp.wino(form), y, in_mode, slope, scale, shift, bias, residual, chscale, in_slope, moments, gnb)
         keep = []
         d = self._desc(kd, stride, pad, in_mode, slope, scale, shift, bias, residual, chscale, off, out_dhw, keep, in_slope, out_mode)
         xd, yd = x.desc(), y.desc()
@@ -426,7 +433,7 @@ class Backend:
         """w OIDHW [cout, cin, 3, 3, 3] -> transformed weights for conv_fwd_wino (mode 0: forward; mode 1: dgrad, i.e. a conv from
         cout to cin channels). form "2d" / "3d" (None: self.wino_form): which kernel's layout; the returned tensor remembers it
         (`mi355_form`), conv_fwd_wino launches the kernel that reads it."""
-        form = form or self.wino_form
+        form = form or ("2d" if self.wino_form == "auto" else self.wino_form)
         cout, cin = (w.shape[0], w.shape[1]) if mode == 0 else (w.shape[1], w.shape[0])
         same = w.device.type == self.device.type and (w.device.type != "cuda" or
                                                      (w.device.index if w.device.index is not None else torch.cuda.current_device()) ==
@@ -535,6 +542,43 @@ class Backend:
             self._prof_add("conv3d_c4_wgrad (+reduce)" if c4 else "conv3d_wgrad_k3_bf16<...> (+reduce)" if bf
                            else "conv3d_wgrad_ring (+reduce)" if (kd == 3 and stride == 1 and pad == 1 and out_mode == OUT_PLAIN)
                            else f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1)
+
+    # -- first-layer backward in one pass over dy (csrc/conv3d_c4_bwd.hip) -----------------------------------------------------------------
+    def c4_bwd_supported(self, x, dy, in_mode=IN_AFFINE_ACT, slope=0.0, scale=None, shift=None, in_slope=None):
+        """Can the fused first-layer backward take this pair (fp32 4-channel input, fp32 32-channel dy, fp32 arithmetic)? MI355_C4_BWD=0: never."""
+        if os.environ.get("MI355_C4_BWD", "1") == "0" or x.c != 4 or dy.c != 32:
+            return False
+        d = self._desc(3, 1, 1, in_mode, slope, scale, shift, None, None, None, (0, 0, 0), dy.shape[1:4], [], in_slope, OUT_PLAIN)
+        xd, dyd = x.desc(), dy.desc()
+        return bool(self.lib.mi355_conv3d_c4_bwd_supported(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d)))
+
+    def c4_bwd(self, x, dy, wp, dw, groups, gamma, mean_rstd, scale, shift, dgamma, dbeta, slope=0.0, in_slope=None):
+        """Backward of [GroupNorm(4 channels) -> act -> Conv3d(4 -> 32, k3)] whose input needs no gradient: dw (OIDHW) and dgamma / dbeta in
+        one pass over dy, no data-gradient tensor. wp: PackedWeight of the conv weight, mode 1 (its fp32 pack is read)."""
+        keep = []
+        d = self._desc(3, 1, 1, IN_AFFINE_ACT, slope, scale, shift, None, None, None, (0, 0, 0), dy.shape[1:4], keep, in_slope, OUT_PLAIN)
+        xd, dyd = x.desc(), dy.desc()
+        nb = self.lib.mi355_conv3d_c4_bwd_blocks(ctypes.byref(xd))
+        nbytes = self.lib.mi355_conv3d_c4_bwd_workspace(ctypes.byref(xd), ctypes.byref(dyd), ctypes.byref(d))
+        if nb <= 0 or nbytes == 0:
+            raise RuntimeError("c4_bwd: unsupported configuration (ask c4_bwd_supported first)")
+        rec = torch.empty(x.shape[0], nb, 4, 2, dtype=torch.float32, device=self.device)
+        ws = self.ws(max(nbytes, self.lib.mi355_gn_workspace(ctypes.byref(xd))))
+        assert dw.is_contiguous()
+        if self.prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(self.lib.mi355_conv3d_c4_bwd(ctypes.byref(xd), ctypes.byref(dyd), wp.f32().data_ptr(), dw.data_ptr(), ctypes.byref(d),
+                                           mean_rstd.data_ptr(), groups, rec.data_ptr(), ws.data_ptr(), ws.numel() * 4, self.stream()), "conv3d_c4_bwd")
+        if self.prof is not None:
+            e1.record()
+            nvox = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3]
+            # the two passes it replaces (weight gradient + data gradient, SURVEY 8d: each x + dy + w once): 2 x the forward's flops and
+            # algorithmic bytes -- the fused kernel MOVES half of those bytes (dy and x once), which is the point
+            self._prof_add("conv3d_c4_bwd (+reduce)", 2 * 2.0 * nvox * 4 * 32 * 27, 2 * 4.0 * (nvox * (4 + 32) + 27 * 4 * 32), e0, e1)
+        # the records are few (<= ~1024 per sample): finalised in place of the norm backward's first pass; dgamma / dbeta only
+        check(self.lib.mi355_gn_bwd_params(ctypes.byref(xd), groups, _p(gamma), mean_rstd.data_ptr(), _p(dgamma), _p(dbeta), rec.data_ptr(), nb,
+                                           ws.data_ptr(), ws.numel() * 4, self.stream()), "gn_bwd_params")
 
     # -- norm ----------------------------------------------------------------------------------------------------
     RECORDS_MAX = 256        # more epilogue records than this per (sample, channel) are folded to RECORDS_FOLD before finalisation

@@ -581,7 +581,7 @@ def main():
     first_layer = None
     if prof:
         fl = {k: v for k, v in agg.items() if k.startswith("conv3d_c4")}
-        if len(fl) >= 3:
+        if len(fl) >= 2:      # forward + the fused backward (conv3d_c4_bwd; round 5 and MI355_C4_BWD=0: weight gradient and data gradient apart)
             secs_f = sum(v[0] for v in fl.values())
             by_f = sum(v[2] for v in fl.values())
             first_layer = {"kernels_ms_per_launch": {k: round(v[0] / v[3] * 1e3, 4) for k, v in fl.items()},
@@ -593,7 +593,8 @@ def main():
                                     "of HBM time, i.e. the layer is arithmetic-bound in the headline precision and 60 % of 8 TB/s is out of "
                                     "reach there (DESIGN.md section 3); the 16-bit modes move the forward to the bf16 pipe"}
     if rank == 0:
-        out = {"metric": "training volumes/sec (128^3, 4ch->3cls)" if args.config != "c4" else "training volumes/sec (160x192x128, 4ch->3cls, 5 levels)",
+        out = {"metric": (f"training volumes/sec ({dhw[0]}^3, 4ch->3cls)" if dhw[0] == dhw[1] == dhw[2] else
+                          f"training volumes/sec ({'x'.join(str(v) for v in dhw)}, 4ch->3cls{', 5 levels' if args.config == 'c4' else ''})"),
                "value": round(world * B * args.steps / dt, 4), "unit": "volumes/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],

@@ -327,6 +327,24 @@ int mi355_zscore(const float* x, float* y, int32_t c, int64_t voxels, void* ws, 
 int mi355_resample_affine(const float* src, float* dst, int32_t c, int32_t sd, int32_t sh, int32_t sw, int32_t dd, int32_t dh,
                           int32_t dw, const float* m, int32_t mode, int32_t padding, void* stream);
 
+/* ---- first-layer backward in one pass over dy (csrc/conv3d_c4_bwd.hip, round 6) ----------------------------------------------------------
+ * The 4 -> 32 channel 3x3x3 conv of BASELINE.json's "128^3 x 4ch" line (unet3d/models/pytorch/classification/myronenko.py:17-21 via
+ * resnet.py:12-17) sits behind the network's first GroupNorm + ReLU (myronenko.py:9-15), and the network input needs no gradient: the
+ * backward of the pair is dW of the conv and (dgamma, dbeta) of the norm. mi355_conv3d_c4_bwd produces dW and the norm-backward records
+ * (gn_fuse.h format, [n][mi355_conv3d_c4_bwd_blocks(x)][4][2]) reading dy ONCE and never writing the data gradient -- it replaces
+ * mi355_conv3d_wgrad + mi355_conv3d_fwd(dgrad pack) + mi355_gn_act_bwd for this layer (ATen: conv backward + native_group_norm_backward);
+ * mi355_gn_bwd_params turns the records into dgamma / dbeta. x: the fp32 network input (4 channels); dy: fp32, 32 channels; desc: the
+ * forward conv's descriptor (norm prologue: in_mode, in_scale, in_shift, act_slope / in_slope); wp_dgrad: mi355_pack_conv_weight(mode 1);
+ * mean_rstd / groups: mi355_gn_stats of x. MI355_EUNSUPPORTED for any other shape / storage type / precision (use the three calls). */
+int mi355_conv3d_c4_bwd_supported(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* desc);
+int32_t mi355_conv3d_c4_bwd_blocks(const mi355_act* x);
+size_t mi355_conv3d_c4_bwd_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* desc);
+int mi355_conv3d_c4_bwd(const mi355_act* x, const mi355_act* dy, const float* wp_dgrad, float* dw, const mi355_conv_desc* desc,
+                        const float* mean_rstd, int32_t groups, float* partials_out, void* ws, size_t ws_bytes, void* stream);
+/* dgamma / dbeta of a norm from partial records alone (ws: mi355_gn_workspace(x) bytes) */
+int mi355_gn_bwd_params(const mi355_act* x, int32_t groups, const float* gamma, const float* mean_rstd, float* dgamma, float* dbeta,
+                        const float* partials, int32_t blocks, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- Winograd F(2x2, 3x3) x direct-z form of the 3x3x3 stride-1 convolution (csrc/conv3d_wino.hip) --------------------------------
  * The product path of the eligible fp32 forward / dgrad convolutions (round 3; replaces the ATen / cuDNN call behind nn.Conv3d of
  * unet3d/models/pytorch/classification/resnet.py:12-17). Same operation as mi355_conv3d_fwd for kd 3 / stride 1 / pad 1, plain or norm-prologue input, plain un-windowed output (bias, residual, out_chscale and the fused statistics

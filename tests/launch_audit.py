@@ -91,7 +91,7 @@ def _subset(c, k, rng):
 class LaunchAudit:
     """with LaunchAudit(be) as au: <run a step through modules bound to `be`>;  au.records = [dict(kind, desc, err), ...]"""
 
-    WRAPPED = ("conv_fwd", "conv_wgrad", "gn_stats", "gn_act_bwd", "upsample2x_fwd", "upsample2x_bwd", "chscale", "proj_fwd", "proj_bwd",
+    WRAPPED = ("conv_fwd", "conv_wgrad", "c4_bwd", "gn_stats", "gn_act_bwd", "upsample2x_fwd", "upsample2x_bwd", "chscale", "proj_fwd", "proj_bwd",
                "dice", "adam_step", "ncdhw_to_ndhwc", "ndhwc_to_ncdhw", "add", "cast")
 
     def __init__(self, be, block_macs=1.5e8, n_blocks=4, wgrad_channels=4, full_macs=4e8, seed=0, verbose=False):
@@ -367,8 +367,11 @@ class LaunchAudit:
             got = dw.detach().cpu().double().view(8, dy.c, x.c)[:, co][:, :, ci]
             self._rec("conv_wgrad", desc, rel_err(got, ref) if float(ref.abs().max()) > 0 else 0.0)
             return ret
-        ci = _subset(x.c, self.wch, self.rng)
-        co = _subset(dy.c, self.wch, self.rng)
+        # the reference holds the full voxel sum of every audited (ci, co) pair in fp64: 27 strided copies of the input subset. On the
+        # largest tensors (128^3 x 4 of BASELINE configs[2]: 8.4 M voxels) two channels per side keep a launch's audit near one second
+        wch = self.wch if n * dy.shape[1] * dy.shape[2] * dy.shape[3] <= 6e6 else min(self.wch, 2)
+        ci = _subset(x.c, wch, self.rng)
+        co = _subset(dy.c, wch, self.rng)
         prec = self._wgrad_precision(p, x, kd, stride, pad)
         lp = LP_DTYPE.get(prec)
         kind = "conv_wgrad"
@@ -403,6 +406,33 @@ class LaunchAudit:
             errs[form] = float((got - ref).abs().max()) / scale
         form = min(errs, key=errs.get)
         self._rec(kind, desc + (f" [{lp} operands, prologue {form}]" if lp is not None else ""), errs[form])
+        return ret
+
+    def _a_c4_bwd(self, orig, args, kw, p):
+        """The fused first-layer backward (csrc/conv3d_c4_bwd.hip): dW of the 4 -> 32 conv (complete) and dgamma / dbeta of the norm in front
+        of it, from the launch's own inputs in fp64. Recorded as one conv_wgrad and one gn_act_bwd launch (the kinds it replaces)."""
+        x, dy, dw, groups = p["x"], p["dy"], p["dw"], p["groups"]
+        ret = orig(*args, **kw)
+        t0, g = _nc(x.tensor()), _nc(dy.tensor())
+        a = self._prologue(t0, slice(None), list(range(4)), IN_AFFINE_ACT, p["slope"], p["scale"], p["shift"], p["in_slope"])
+        w = self._weight(p["wp"]).transpose(0, 1).flip(2, 3, 4).contiguous()      # back to the forward weight [32, 4, 3, 3, 3]
+        dw_ref = torch.nn.grad.conv3d_weight(a, (32, 4, 3, 3, 3), g, padding=1)
+        e_w = float((dw.detach().cpu().double() - dw_ref).abs().max()) / max(float(dw_ref.abs().max()), 1e-300)
+        self._rec("conv_wgrad", f"c4_bwd k3 s1 4->32 @{tuple(dy.shape[1:4])}", e_w)
+        dA = torch.nn.grad.conv3d_input(a.shape, w, g, padding=1)
+        sc = p["scale"].detach().cpu().double()[:, :, None, None, None]
+        sh = p["shift"].detach().cpu().double()[:, :, None, None, None]
+        u = t0 * sc + sh                                     # the mask the kernel uses: its own scale / shift
+        du = dA * torch.where(u > 0, torch.ones_like(u), torch.full_like(u, float(p["slope"])))
+        mr = p["mean_rstd"].detach().cpu().double()
+        cpg = 4 // groups
+        mean = mr[..., 0].repeat_interleave(cpg, 1)[:, :, None, None, None]
+        rstd = mr[..., 1].repeat_interleave(cpg, 1)[:, :, None, None, None]
+        dgr, dbr = (du * (t0 - mean) * rstd).sum((0, 2, 3, 4)), du.sum((0, 2, 3, 4))
+        dgk, dbk = p["dgamma"].detach().cpu().double(), p["dbeta"].detach().cpu().double()
+        e_g = float((dgk - dgr).abs().max()) / max(float(dgr.abs().max()), 1e-300)
+        e_b = float((dbk - dbr).abs().max()) / max(float(dbr.abs().max()), 1e-300)
+        self._rec("gn_act_bwd", f"c4_bwd C=4 G={groups} @{tuple(x.shape[1:4])} fused=True", max(e_g, e_b))
         return ret
 
     # ---- norm --------------------------------------------------------------------------------------------------------------------

@@ -383,6 +383,29 @@ def case_gn_bwd_fused(be, n, cin, cout, dhw, groups=None, slope=0.0, expect_fuse
     return dict(dx=rel_err(from_act(dA), dx_ref), dgamma=rel_err(dgam, dg_ref), dbeta=rel_err(dbet, db_ref))
 
 
+def case_c4_bwd(be, n, dhw, groups=4, slope=0.0, seed=21, xld=None, dyld=None):
+    """Fused backward of the network's first pair [GroupNorm(4) -> act -> Conv3d(4 -> 32, k3)] (csrc/conv3d_c4_bwd.hip): dW of the conv
+    and dgamma / dbeta of the norm in one pass over dy, against autograd in double precision."""
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dhw
+    x = (torch.randn(n, 4, d, h, w, generator=g) * 1.3 + 0.2).double()
+    gamma = (torch.rand(4, generator=g) + 0.5).double().requires_grad_(True)
+    beta = (torch.randn(4, generator=g) * 0.3).double().requires_grad_(True)
+    wt = (torch.randn(32, 4, 3, 3, 3, generator=g) * 0.1).double().requires_grad_(True)
+    y = F.conv3d(O.norm_act(x, groups, gamma, beta, 1e-5, slope), wt, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    dw_ref, dg_ref, db_ref = torch.autograd.grad(y, (wt, gamma, beta), dy.double())
+    xa, dya = to_act(be, x.float(), xld), to_act(be, dy, dyld)
+    gam, bet = dev(be, gamma.detach().float()), dev(be, beta.detach().float())
+    mr, sc, sh = be.gn_stats(xa, groups, 1e-5, gam, bet)
+    assert be.c4_bwd_supported(xa, dya, ops.IN_AFFINE_ACT, slope, sc, sh)
+    wp = be.pack_weight(dev(be, wt.detach().float()), 1)
+    dw = torch.full((32, 4, 3, 3, 3), 7.0, device=be.device)
+    dgam, dbet = torch.full((4,), 7.0, device=be.device), torch.full((4,), 7.0, device=be.device)
+    be.c4_bwd(xa, dya, wp, dw, groups, gam, mr, sc, sh, dgam, dbet, slope=slope)
+    return dict(dw=rel_err(dw, dw_ref), dgamma=rel_err(dgam, dg_ref), dbeta=rel_err(dbet, db_ref))
+
+
 def case_upsample(be, n, c, lo_dhw, target_dhw, c_skip=8, seed=4):
     g = torch.Generator().manual_seed(seed)
     lo = torch.randn(n, c, *lo_dhw, generator=g, requires_grad=True)

@@ -92,7 +92,9 @@ def test_headline_config_matches_oracle_directly():
          "dice": float(((_soft_dice_per_class(out_c, y) - _soft_dice_per_class(ref, y)).abs() / _soft_dice_per_class(ref, y)).max())}
     assert e["logits"] < TOL and e["loss"] < TOL and e["dice"] < TOL, e
     del ref
-    floor, perturbed = conditioning.noise_floor(R, lambda: _oracle(sd0, x, y, torch.float32, per_sample=False)[2], return_evals=True)
+    # two perturbed evaluations (one per sub-gradient branch of the ties; rounds 2-5 ran four: 100 s of the suite's 20-minute budget for
+    # floors that differ by a few per cent -- fewer evaluations can only LOWER a floor, i.e. tighten the criterion)
+    floor, perturbed = conditioning.noise_floor(R, lambda: _oracle(sd0, x, y, torch.float32, per_sample=False)[2], seeds=(1, 2), return_evals=True)
     e32 = {k: C.rel_err(grads[k], g32[k]) for k in grads}
     ratio = {}
     for k, v in e32.items():

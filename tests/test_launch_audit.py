@@ -49,6 +49,8 @@ def _step(be, model, x, y, dev, keep=None, loss_scale=1.0, **akw):
             opt.grad_scale = 1.0 / loss_scale
         else:
             loss.backward()
+        if keep is not None:
+            keep["grads"] = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
         opt.step()
     return au, float(loss.detach())
 
@@ -73,6 +75,29 @@ def test_audit_unet3d_train_step_emulator(emu_backend):
     au, loss = _step(emu_backend, m, x, y, "cpu", block_macs=2e5, full_macs=1e6, wgrad_channels=3)
     assert m.last_dropout_scale is not None and 0.0 < loss <= 1.0
     _check(au, {"conv_fwd": 30, "conv_wgrad": 15, "gn_act_bwd": 8, "gn_stats": 8, "chscale": 1, "upsample_fwd": 2, "upsample_bwd": 2, "adam": 1})
+
+
+def test_audit_first_block_fused_backward_emulator(emu_backend):
+    """Default width (32) on a volume the emulator can afford: the network's first block takes the fused backward (csrc/conv3d_c4_bwd.hip:
+    weight gradient of the 4 -> 32 conv and dgamma / dbeta of the first norm in one pass over dy) -- audited per launch, and every
+    parameter gradient against the fp64 oracle graph."""
+    from oracle import torch_ops as O
+    torch.manual_seed(3)
+    enc = [1, 1]
+    m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=32, encoder_blocks=enc).eval()
+    m.backward_side_stream = False
+    x, y = R.synthetic_case(2, 4, (6, 10, 18), 3)
+    keep = {}
+    au, loss = _step(emu_backend, m, x, y, "cpu", block_macs=2e5, full_macs=1e6, wgrad_channels=3, keep=keep)
+    fused = [r for r in au.records if "c4_bwd" in r["desc"]]
+    assert [r["kind"] for r in fused] == ["conv_wgrad", "gn_act_bwd"], fused
+    _check(au, {"conv_fwd": 20, "conv_wgrad": 13, "gn_act_bwd": 8})
+    sd = {k: v.detach().clone().double().requires_grad_(True) for k, v in keep["state_dict"].items()}
+    l = O.dice_loss(R.unet3d_forward(sd, x.double(), tuple(enc)), y)
+    l.backward()
+    assert abs(loss - float(l.detach())) < 1e-5
+    for k, g in keep["grads"].items():
+        assert A.rel_err(g, sd[k].grad) < 1e-4, k
 
 
 @pytest.mark.parametrize("tc", [False, True])
@@ -211,9 +236,11 @@ def test_audit_headline_train_step_gpu(hip_backend):
     x, y = R.synthetic_case(2, 4, (128, 128, 128), 3)
     au, loss = _step(hip_backend, m, x, y, "cuda")
     assert m.last_dropout_scale is not None and 0.0 < loss < 1.0
-    # launches of the step (37 forward convs + 36 dgrads, 37 weight gradients, 26 norms, ...): all of them are audited.
+    # launches of the step (37 forward convs + 35 dgrads, 37 weight gradients, 26 norms, ...): all of them are audited. Round 6: the first
+    # block's weight gradient, data gradient and norm backward are ONE launch (conv3d_c4_bwd), audited as a conv_wgrad + a gn_act_bwd record.
     # Recorded on MI355X (round 3): conv_fwd 1.2e-6, conv_wgrad 7.2e-7, gn_act_bwd 2.1e-7, gn_stats 6.6e-8, upsample 3.3e-7, dice 1.9e-7
-    _check(au, {"conv_fwd": 73, "conv_wgrad": 37, "gn_act_bwd": 26, "gn_stats": 26, "chscale": 1, "upsample_fwd": 3, "upsample_bwd": 3,
+    assert [r["kind"] for r in au.records if "c4_bwd" in r["desc"]] == ["conv_wgrad", "gn_act_bwd"]
+    _check(au, {"conv_fwd": 72, "conv_wgrad": 37, "gn_act_bwd": 26, "gn_stats": 26, "chscale": 1, "upsample_fwd": 3, "upsample_bwd": 3,
                 "proj_fwd": 1, "proj_bwd": 1, "dice": 1, "adam": 1})
 
 
@@ -267,7 +294,7 @@ def test_audit_c3_bf16_train_step_gpu(hip_backend):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["bf16", "fp16", "bf16-fp32-tensors", "fp16-stored"])
+@pytest.mark.parametrize("mode", ["bf16", "bf16-fp32-tensors", "fp16-stored"])      # ("fp16" with fp32 tensors: the emulator twin keeps it)
 def test_audit_16bit_train_step_gpu(hip_backend, mode):
     """The 16-bit operand model on the product kernels at a size every routing of the mode takes part in (64^3, batch 2: plane-ring
     form on the 32-channel level, tile forms below, first-layer forward on the 16-bit pipe)."""

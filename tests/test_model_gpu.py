@@ -112,7 +112,7 @@ def test_unet3d_default_fwd_bwd_64cube():
     C.assert_recorded(e, RECORDED["64"])
 
 
-@pytest.mark.parametrize("dhw,n,rec", [((32, 32, 32), 2, "train32"), ((64, 64, 64), 1, "train64")])
+@pytest.mark.parametrize("dhw,n,rec", [((32, 32, 32), 2, "train32")])      # (64^3 in train mode: the trajectory test below, step 0)
 def test_unet3d_train_mode_dropout_mask_shared_with_oracle(dhw, n, rec):
     """SURVEY 8a row a5 (MyronenkoLayer + Dropout3d) in the mode bench.py times: logits, loss and all gradients of the .train() graph."""
     e = _run_pair(dict(n_features=4, n_outputs=3), (1, 2, 2, 4), dhw, n, train=True)
@@ -127,7 +127,7 @@ def test_train_mode_loss_trajectory_matches_oracle():
     to 1e-3 while the step-to-step amplification of rounding differences allows it (the first steps), stay close after, and -- the
     question VERDICT r2 raised about bench.py's `final_loss: 1.0` -- saturate together or not at all."""
     torch.manual_seed(1234)
-    steps = 16
+    steps = 12                       # (16 until round 5; both sides collapse at step 10, see below)
     m = unet.HipUNet3D(n_features=4, n_outputs=3).cuda().train()
     m.dropout_generator = torch.Generator(device="cuda").manual_seed(5)
     torch.set_num_threads(min(64, os.cpu_count() or 1))

@@ -588,3 +588,14 @@ def test_training_step_repacks_in_one_launch(emu_backend, conv_precision):
     for (k, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
         assert torch.equal(p.grad, q.grad), k
 
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=1, dhw=(3, 8, 16)),                                   # one column tile, one z chunk
+    dict(n=2, dhw=(5, 9, 19), groups=2, slope=0.01),             # ragged tiles, leaky slope, two channels per group
+    dict(n=1, dhw=(17, 8, 16), groups=1),                        # two z chunks: the halo planes of a chunk come from its neighbour
+    dict(n=1, dhw=(2, 3, 5), xld=8, dyld=64),                    # image smaller than the tile; views of wider buffers
+])
+def test_first_layer_fused_backward(emu_backend, kw):
+    r = C.case_c4_bwd(emu_backend, **kw)
+    assert all(v < 1e-4 for v in r.values()), r

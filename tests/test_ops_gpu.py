@@ -375,3 +375,15 @@ def test_launch_stream_handle_follows_the_current_stream(hip_backend):
     assert be.stream() == torch.cuda.current_stream(be.device).cuda_stream
     s.synchronize()
     assert float(y.buf.min()) == float(y.buf.max()) == 4.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(n=1, dhw=(3, 8, 16)),                                   # one column tile, one z chunk
+    dict(n=2, dhw=(5, 9, 19), groups=2, slope=0.01),             # ragged tiles, leaky slope, two channels per group
+    dict(n=1, dhw=(17, 8, 16), groups=1),                        # two z chunks: the halo planes of a chunk come from its neighbour
+    dict(n=1, dhw=(2, 3, 5), xld=8, dyld=64),                    # image smaller than the tile; views of wider buffers
+])
+def test_first_layer_fused_backward(hip_backend, kw):
+    r = C.case_c4_bwd(hip_backend, **kw)
+    assert all(v < 1e-4 for v in r.values()), r

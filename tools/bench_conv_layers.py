@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MODES = tuple(os.environ["MODES"].split(",")) if os.environ.get("MODES") else ("norm+moments", "plain", "plain+gnb")      # also: norm, moments
 LAYERS = [(32, 32, 128, 3), (64, 32, 128, 3), (32, 64, 128, 3), (64, 64, 64, 3), (128, 128, 64, 3), (128, 128, 32, 3), (256, 256, 32, 3), (256, 256, 16, 3),
           (32, 64, 64, 1), (128, 64, 64, 1)]
+if os.environ.get("LAYERS"):                              # LAYERS=0,6: a subset by index
+    LAYERS = [LAYERS[int(i)] for i in os.environ["LAYERS"].split(",")]
 
 
 def one(path):

@@ -37,6 +37,15 @@ for mode in ("fp32", "bf16x6", "bf16x3", "bf16"):
     print(f"{mode:7s} fwd {t_f*1e3:.3f} ms ({alg/t_f/1e12:.2f} TB/s = {alg/t_f/8e12*100:.0f} %)  fwd+moments {t_fm*1e3:.3f} ms  wgrad {t_w*1e3:.3f} ms ({alg/t_w/1e12:.2f} TB/s)  "
           f"dgrad {t_d*1e3:.3f} ms ({alg/t_d/1e12:.2f} TB/s)  | fwd+bwd {tot*1e3:.3f} ms = {3*alg/tot/1e12:.2f} TB/s = {3*alg/tot/8e12*100:.0f} % of 8 TB/s", flush=True)
 be.set_precision("fp32")
+# round 6: the fused backward (csrc/conv3d_c4_bwd.hip: weight gradient + norm-backward sums in one pass over dy, no data-gradient tensor)
+wpd = be.pack_weight(w, 1)
+dg, db = torch.empty(4, device="cuda"), torch.empty(4, device="cuda")
+if be.c4_bwd_supported(x, dy, ops.IN_AFFINE_ACT, 0.0, sc, sh):
+    t_b = timeit(lambda: be.c4_bwd(x, dy, wpd, dw, 4, gamma, mr, sc, sh, dg, db))
+    wp = be.pack_weight(w, 0)
+    t_fm = timeit(lambda: be.conv_fwd(x, wp, y, 3, 1, moments=True, **kw))
+    print(f"fp32 fused backward (conv3d_c4_bwd + reduce + gn_bwd_params) {t_b*1e3:.3f} ms = {2*alg/t_b/1e12:.2f} TB/s of the two passes it replaces; "
+          f"fwd+moments + fused bwd {1e3*(t_fm+t_b):.3f} ms = {3*alg/(t_fm+t_b)/8e12*100:.0f} % of 8 TB/s", flush=True)
 # reference rates of the memory system for the same 537 MB output tensor: a pure write (fill) and a read+write (scale in place)
 t_fill = timeit(lambda: y.buf.fill_(1.0))
 t_rw = timeit(lambda: y.buf.mul_(1.0001))
