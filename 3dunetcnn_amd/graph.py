@@ -80,6 +80,14 @@ class HipGraphedTrainStep:
         self._pack_table = getattr(model, "_last_pack_table", None)
         if self._pack_table is not None:
             self._pack_table._mi355_pinned = getattr(self._pack_table, "_mi355_pinned", 0) + 1      # a count: several graphs may share it
+        # ... and for every packed-weight buffer the captured convolutions read: Backend.repack_batch drops the 16-bit packs of precision
+        # modes other than the one the NEXT eager forward runs in (an eager forward of this model in another precision after the capture
+        # would free a pack the graph still reads). Our references keep the memory; the graph's own pack kernels keep it current.
+        self._pack_refs = []
+        for ent in getattr(model, "_packed", {}).values():
+            for pw in ent[1].values():
+                self._pack_refs.extend(t for t in (pw._f32, getattr(pw, "_wino", None), getattr(pw, "_wino3", None)) if t is not None)
+                self._pack_refs.extend(pw._bf16.values())
         self.logits = logits.detach()                # static outputs, refreshed by every replay
         self.loss = loss.detach()
         self._grads = [(p, p.grad) for p in model.parameters() if p.grad is not None]

@@ -127,11 +127,11 @@ def self_launch(n):
 
 
 # HBM-traffic summaries (tools/pmc_summary.py) of the rocprofv3 PMC passes of THIS command, per (config, precision)
-PMC_FILES = {("c2", "fp32"): os.path.join("profiles", "r5_bench_fp32_hbm_traffic_pmc.csv"),
-             ("c2", "bf16"): os.path.join("profiles", "r5_bf16_hbm_traffic_pmc.csv"),
-             ("c3", "bf16"): os.path.join("profiles", "r5_c3_hbm_traffic_pmc.csv")}
+PMC_FILES = {("c2", "fp32"): os.path.join("profiles", "r6_bench_fp32_hbm_traffic_pmc.csv"),
+             ("c2", "bf16"): os.path.join("profiles", "r6_bf16_hbm_traffic_pmc.csv"),
+             ("c3", "bf16"): os.path.join("profiles", "r6_c3_hbm_traffic_pmc.csv")}
 # kernel family (ops.Backend prof name) -> substrings of the trace names of its instantiations
-PMC_FAMILY = {"conv3d_wino2d": ("conv3d_wino2d",), "conv3d_k3_bf16<...>": ("conv3d_k3_bf16", "conv3d_k3_lp_zring"),
+PMC_FAMILY = {"conv3d_wino2d": ("conv3d_wino2d",), "conv3d_wino3d": ("conv3d_wino3d",), "conv3d_c4_bwd (+reduce)": ("conv3d_c4_bwd",), "conv3d_k3_bf16<...>": ("conv3d_k3_bf16", "conv3d_k3_lp_zring"),
               "conv3d_wgrad_wino_ring (+reduce)": ("conv3d_wgrad_wino_ring",), "conv3d_wgrad_k3_bf16<...> (+reduce)": ("conv3d_wgrad_k3_bf16", "conv3d_wgrad_lp_ring"),
               "conv3d_wgrad_ring (+reduce)": ("conv3d_wgrad_ring",)}
 
@@ -160,6 +160,21 @@ def pmc_rows(config, precision):
     rows = [(r["Kernel"], int(r["Calls"]), (float(r["fetch_x2_MiB_per_launch"]) + float(r["WRITE_SIZE_MiB_per_launch"])) * 1048576.0)
             for r in csv.DictReader(lines)]
     return rows, f"{rel} (FETCH_SIZE x2 + WRITE_SIZE per launch; family figure = call-weighted over the file's rows of the family)"
+
+
+def family_clock(config, precision, family):
+    """Call-weighted shader clock (GHz) of `family`'s launches from the same PMC summary (column shader_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs /
+    duration, a separate rocprofv3 pass), or None when the summary has no such column / is stale."""
+    rows, _ = pmc_rows(config, precision)
+    if rows is None:
+        return None
+    import csv
+    lines = open(os.path.join(ROOT, PMC_FILES[(config, precision)])).read().splitlines()[1:]
+    keys = PMC_FAMILY.get(family, (family.split(" (")[0].split("<")[0],))
+    hit = [(int(r["Calls"]), float(r["shader_clock_ghz"])) for r in csv.DictReader(lines)
+           if r.get("shader_clock_ghz") not in (None, "", "nan") and any(k in r["Kernel"] for k in keys)]
+    calls = sum(c for c, _ in hit)
+    return round(sum(c * g for c, g in hit) / calls, 3) if calls else None
 
 
 def family_traffic(rows, family):
@@ -564,6 +579,9 @@ def main():
                                                "of the norm-backward sums), averaged over the same launches as `traffic`",
                         unfused_compulsory_bytes_per_launch=round(by / cnt),
                         traffic_over_algorithmic=None if traffic is None else round(traffic / alg_bytes, 3),
+                        # the clock the family's launches ran at under the profiler (power-limited: below the 2.4 GHz the peak is quoted at)
+                        shader_clock_ghz=family_clock(args.config, args.precision, name), shader_clock_note="GRBM_GUI_ACTIVE / 8 XCDs / duration, "
+                        "rocprofv3 pass of the same serialized command (profiled runs clock a few per cent below un-profiled ones); peak figures assume 2.4 GHz",
                         instantiations=inst_rows,
                         mfma_products_per_mac=products, mfma_pipe_frac=round(mfma_frac, 4),
                         # Winograd kernels execute fewer multiplications than the algorithmic count `achieved` is quoted in (it can

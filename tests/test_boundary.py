@@ -162,6 +162,31 @@ def test_module_surgery_between_steps_is_seen_by_the_engine(emu_backend):
         assert float((p.grad - sd[k].grad).abs().max() / sd[k].grad.abs().max().clamp_min(1e-30)) < 1e-3, k
 
 
+def test_surgery_the_registration_hooks_do_not_see_and_pickling(emu_backend):
+    """Writes torch's global registration hooks never fire for -- a direct `_parameters[...]` replacement on a CHILD module -- are caught by
+    the engine's once-per-forward walk (engine._check_parameter_cache); a pickled model (torch.save(model)) carries no process-local cache."""
+    import pickle
+    torch.manual_seed(7)
+    m = _model(emu_backend)
+    x, y = R.synthetic_case(1, 4, (8, 8, 8), 3)
+    crit = losses.HipDiceLoss(sigmoid=True)
+    crit._be = emu_backend
+    crit(m(x), y).backward()
+    norm = m.encoder.layers[1].blocks[0].conv1.norm1
+    new = torch.nn.Parameter(torch.full_like(norm.weight, 1.3))
+    norm._parameters["weight"] = new                             # no hook fires
+    for p in m.parameters():
+        p.grad = None
+    crit(m(x), y).backward()
+    assert [id(p) for p in m._params()] == [id(p) for p in m.parameters()]
+    assert new.grad is not None and float(new.grad.abs().max()) > 0.0
+    state = m.__getstate__()
+    assert "_params_cache" not in state and "_gview_cache" not in state
+    assert "_params_cache" in m.__dict__                          # (the live module keeps its caches)
+    m.invalidate_parameter_cache()
+    assert [id(p) for p in m._params()] == [id(p) for p in m.parameters()]
+
+
 def test_a_forward_that_raises_leaves_the_shared_backend_as_it_found_it(emu_backend, monkeypatch):
     """HipAutocastUNet switches the backend to its precision and its 16-bit activation storage for the duration of a forward. A forward that
     raises half-way (an OOM the caller catches, a refused call) must undo that: the next fp32 network on the same backend would otherwise

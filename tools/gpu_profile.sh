@@ -17,9 +17,10 @@ trace) (cd /tmp && MI355_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --st
 pmc)
   (cd /tmp && MI355_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $root/$out/pmc_fetch -o bench -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-precision-modes --no-kernel-events > $root/$out/pmc_fetch.log 2>&1)
   (cd /tmp && MI355_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $root/$out/pmc_write -o bench -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-precision-modes --no-kernel-events > $root/$out/pmc_write.log 2>&1)
-  python tools/pmc_summary.py $out/pmc_fetch/bench_counter_collection.csv $out/pmc_write/bench_counter_collection.csv > $out/hbm_traffic_pmc.csv 2> $out/pmc_summary.err
+  (cd /tmp && MI355_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -f csv -d $root/$out/pmc_clk -o bench -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-precision-modes --no-kernel-events > $root/$out/pmc_clk.log 2>&1)
+  python tools/pmc_summary.py $out/pmc_fetch/bench_counter_collection.csv $out/pmc_write/bench_counter_collection.csv $out/pmc_clk/bench_counter_collection.csv > $out/hbm_traffic_pmc.csv 2> $out/pmc_summary.err
   head -4 $out/hbm_traffic_pmc.csv
-  rm -rf $out/pmc_fetch $out/pmc_write;;
+  rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_clk;;
 esac
 done
 # keep the merge-back small: drop anything above 20 MB

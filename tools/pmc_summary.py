@@ -64,9 +64,12 @@ def main(paths):
     names = set()
     for t in tables.values():
         names |= set(t)
+    # GRBM_GUI_ACTIVE (optional third pass): busy cycles of the kernel summed over the 8 XCDs -> the shader clock the kernel ran at
+    # (MI355X_MICROARCH.md, DVFS: the chip clocks to its power budget; a profiled pass runs a few per cent below an un-profiled one)
+    clk = tables.pop("GRBM_GUI_ACTIVE", None)
     cols = sorted(tables)
     print(f"# provenance: git_sha={tree_sha()} kernel_source_sha256={kernel_source_hash()}")
-    print("Kernel,Calls," + ",".join(f"{c}_MiB_per_launch" for c in cols) + ",fetch_x2_MiB_per_launch,avg_ms_under_pmc")
+    print("Kernel,Calls," + ",".join(f"{c}_MiB_per_launch" for c in cols) + ",fetch_x2_MiB_per_launch,avg_ms_under_pmc" + (",shader_clock_ghz" if clk else ""))
     rows = []
     for n in names:
         calls = max(tables[c][n][0] for c in cols if n in tables[c])
@@ -74,9 +77,10 @@ def main(paths):
         secs = max(tables[c][n][2] / max(tables[c][n][0], 1) for c in cols if n in tables[c])
         fx2 = 2 * vals[cols.index("FETCH_SIZE")] if "FETCH_SIZE" in cols else float("nan")
         tot = sum(tables[c][n][2] for c in cols if n in tables[c])
-        rows.append((tot, n, calls, vals, fx2, secs))
-    for tot, n, calls, vals, fx2, secs in sorted(rows, reverse=True):
-        print(f"\"{n}\",{calls}," + ",".join(f"{v:.2f}" for v in vals) + f",{fx2:.2f},{secs * 1e3:.4f}")
+        ghz = clk[n][1] / 8.0 / clk[n][2] / 1e9 if clk and n in clk and clk[n][2] > 0 else float("nan")
+        rows.append((tot, n, calls, vals, fx2, secs, ghz))
+    for tot, n, calls, vals, fx2, secs, ghz in sorted(rows, reverse=True):
+        print(f"\"{n}\",{calls}," + ",".join(f"{v:.2f}" for v in vals) + f",{fx2:.2f},{secs * 1e3:.4f}" + (f",{ghz:.3f}" if clk else ""))
 
 
 if __name__ == "__main__":
