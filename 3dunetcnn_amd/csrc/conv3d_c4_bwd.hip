@@ -6,8 +6,9 @@
 //
 // Before (conv3d_c4.hip): conv3d_c4_wgrad read dy once (0.37 ms at 128^3 x 2), conv3d_c4_dgrad read it again through 6 x 10 x 10 halo tiles
 // (PMC: 1 476 MiB fetched for 537 MB of dy) and wrote dA (0.48-0.58 ms), gn_act_bwd read dA and x again. Here a 512-thread workgroup
-// marches an 8 x 16 voxel column along z with a ring of three haloed dy planes (10 x 18 voxels x 32 channels, every plane of the column
-// fetched once: 1.4x dy in total, the (y, x) halo) and three activated x planes in LDS. Per plane, everything on the matrix pipe:
+// marches an 8 x 16 voxel column along z with a ring of four haloed dy planes (10 x 18 voxels x 32 channels, every plane of the column
+// fetched once: 1.4x dy in total, the (y, x) halo; three are read, the fourth is being filled: one barrier per plane) and the activated
+// x planes beside them in LDS. Per plane, everything on the matrix pipe:
 //   * data gradient with v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4 voxels x 4 input channels, K = one dy channel per instruction: exact
 //     fp32 FMA chains at the fp32 matrix rate WITHOUT the 7/8 padding a 32-wide N tile would carry for 4 output channels): wave (voxel
 //     half, channel quarter) owns 64 voxels x 8 dy channels; per tap and channel quad one ds_read_b128 of the voxel's quad (A) and one of
@@ -58,10 +59,10 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(2) void conv3d_c4_bwd(C4BAr
   constexpr int DYP = HV * 32, XP = HV * 4;              // floats per staged dy / x plane
   constexpr int DYU = (HV * 8 + 511) / 512;              // 16-byte units of a dy plane per thread
   DYN_LDS(lds);
-  float* dyr = lds;                                      // ring of 3 dy planes: voxel hv at hv * 32, channel quad q at slot q ^ s(hx)
-  float* xr = lds + 3 * DYP;                             // ring of 3 activated x planes (float4 per voxel, zero outside the image)
-  float* wl = xr + 3 * XP;                               // dgrad weights [tap][quad][input channel 4][4 dy channels of the quad]
-  float* cmb = wl + 27 * 8 * 16;                         // partial data gradients of channel quarters 1..3: [voxel half][3][64 lanes][4]
+  float* dyr = lds;                                      // ring of 4 dy planes: voxel hv at hv * 32, channel quad q at slot q ^ s(hx)
+  float* xr = lds + 4 * DYP;                             // ring of 4 activated x planes (float4 per voxel, zero outside the image)
+  float* wl = xr + 4 * XP;                               // dgrad weights [tap][quad][input channel 4][4 dy channels of the quad]
+  float* cmb = wl + 27 * 8 * 16;                         // partial data gradients of channel quarters 1..3: [plane parity][voxel half][3][64 lanes][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6), half = lane >> 5, li = lane & 31;
   int b = blockIdx.x;
   const int zc = b % a.zchunks; b /= a.zchunks;
@@ -98,8 +99,8 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(2) void conv3d_c4_bwd(C4BAr
       xld_ = *reinterpret_cast<const float4*>(a.x + ((((size_t)n * a.D + zcl) * a.H + iy) * a.W + ix) * a.xld);
     }
   };
-  auto commit_plane = [&](int z) {                       // registers -> ring slot z mod 3 (z >= -1)
-    const int slot = (z + 3) % 3;
+  auto commit_plane = [&](int z) {                       // registers -> ring slot z mod 4 (z >= -1)
+    const int slot = (z + 4) & 3;
     const bool zin = z >= 0 && z < a.D;
 #pragma unroll
     for (int k = 0; k < DYU; ++k) {
@@ -146,14 +147,18 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(2) void conv3d_c4_bwd(C4BAr
   const int grp = cj / (4 / a.groups);
   const float gmean = a.mean_rstd[((size_t)n * a.groups + grp) * 2], grstd = a.mean_rstd[((size_t)n * a.groups + grp) * 2 + 1];
 
-  // ---- prologue: planes z_begin - 1, z_begin, z_begin + 1 ----
+  // ---- prologue: planes z_begin - 1, z_begin, z_begin + 1 staged; plane z_begin + 2 in registers ----
+  // Four ring slots, ONE barrier per plane: plane z + 2 (loaded during plane z - 1) is committed at the top of plane z into the slot plane
+  // z - 2 left at the previous barrier, while nobody reads it; the barrier at the end of plane z publishes it for plane z + 1.
   load_plane(z_begin - 1); commit_plane(z_begin - 1);
   load_plane(z_begin); commit_plane(z_begin);
   load_plane(z_begin + 1); commit_plane(z_begin + 1);
+  load_plane(z_begin + 2);
   __syncthreads();
 
   for (int z = z_begin; z < z_end; ++z) {
-    load_plane(z + 2);                                   // in flight during the plane's arithmetic
+    commit_plane(z + 2);
+    load_plane(z + 3);                                   // in flight during the plane's arithmetic
     // raw input of this lane's result voxels, channel cj (the activation mask and xhat of the sums)
     float xc[4] = {0.f, 0.f, 0.f, 0.f};
     if (cq == 0 && rin) {
@@ -161,7 +166,8 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(2) void conv3d_c4_bwd(C4BAr
 #pragma unroll
       for (int i = 0; i < 4; ++i) if (tx0 + rx0 + i < a.W) xc[i] = xp[(size_t)i * a.xld];
     }
-    const int s0 = (z + 2) % 3, s1 = z % 3, s2 = (z + 1) % 3;      // ring slots of planes z - 1, z, z + 1
+    const int s0 = (z + 3) & 3, s1 = z & 3, s2 = (z + 1) & 3;      // ring slots of planes z - 1, z, z + 1
+    float* cmz = cmb + (z & 1) * (2 * 3 * 64 * 4);       // (double-buffered: the next plane's partials may be written before a slow reader is done)
     const float* dyc = dyr + s1 * DYP;
     const float* xb = xr + (dzc == 0 ? s0 : (dzc == 1 ? s1 : s2)) * XP + boff;      // this lane's B operand plane + tap offset
     // Software pipeline, written out (left to itself hipcc reads the two operands of a channel quad, waits for the LDS and issues the four
@@ -221,13 +227,13 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(2) void conv3d_c4_bwd(C4BAr
     }
     f32x4 dacc = dacc0 + dacc1;
     // the four channel quarters meet: quarters 1..3 through LDS
-    if (cq != 0) *reinterpret_cast<float4*>(cmb + (((vh * 3 + cq - 1) * 64) + lane) * 4) = make_float4(dacc[0], dacc[1], dacc[2], dacc[3]);
-    __syncthreads();                                     // also: every wave is done with plane z - 1 and the x ring
+    if (cq != 0) *reinterpret_cast<float4*>(cmz + (((vh * 3 + cq - 1) * 64) + lane) * 4) = make_float4(dacc[0], dacc[1], dacc[2], dacc[3]);
+    __syncthreads();                                     // the plane's only barrier: partials and plane z + 2 published, plane z - 1 released
     if (cq == 0 && rin) {
       float g[4] = {dacc[0], dacc[1], dacc[2], dacc[3]};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float4 up = *reinterpret_cast<const float4*>(cmb + (((vh * 3 + k) * 64) + lane) * 4);
+        const float4 up = *reinterpret_cast<const float4*>(cmz + (((vh * 3 + k) * 64) + lane) * 4);
         g[0] += up.x; g[1] += up.y; g[2] += up.z; g[3] += up.w;
       }
 #pragma unroll
@@ -238,8 +244,6 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(2) void conv3d_c4_bwd(C4BAr
         sdu += du; sdx += du * ((xc[i] - gmean) * grstd);
       }
     }
-    commit_plane(z + 2);                                 // into the slot of plane z - 1
-    __syncthreads();
   }
 
   // ---- outputs ----
@@ -328,7 +332,7 @@ extern "C" int mi355_conv3d_c4_bwd(const mi355_act* x, const mi355_act* dy, cons
   a.x = (const float*)x->p; a.xld = x->ld; a.dy = (const float*)dy->p; a.dyld = dy->ld; a.wp = wp_dgrad; a.ws = (float*)ws; a.part = partials_out;
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope; a.mean_rstd = mean_rstd; a.groups = groups;
   a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w;
-  const int lds_bytes = (3 * 180 * 32 + 3 * 180 * 4 + 27 * 8 * 16 + 2 * 3 * 64 * 4) * (int)sizeof(float);      // 97 728: one 8-wave workgroup per CU
+  const int lds_bytes = (4 * 180 * 32 + 4 * 180 * 4 + 27 * 8 * 16 + 2 * 2 * 3 * 64 * 4) * (int)sizeof(float);      // 129 792: one 8-wave workgroup per CU
   if (d->in_mode == MI355_IN_PLAIN) {
     SET_MAX_DYN_LDS((conv3d_c4_bwd<MI355_IN_PLAIN>), lds_bytes);
     LAUNCH((conv3d_c4_bwd<MI355_IN_PLAIN>), dim3((unsigned)wgs), dim3(512), lds_bytes, stream, a);

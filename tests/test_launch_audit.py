@@ -262,9 +262,9 @@ def test_audit_c3_bf16_train_step_gpu(hip_backend):
     """BASELINE configs[2] at its own size and precision: default UNet3D as HipAutocastUNet(bf16) (reference: AutocastUNet,
     segmentation/unet.py:53-58), 128^3, batch 4 per GPU, train mode. (a) every launch of the step audited -- the 16-bit convolutions
     and weight gradients with the 16-bit operand model at the SAME 1e-5 as an fp32 launch, everything else against plain fp64;
-    (b) logits and loss against the fp32 CPU oracle (oracle/unet3d_ref.py, the device-drawn Dropout3d mask shared with it) at the
+    (b) logits (two of the four samples) against the fp32 CPU oracle (oracle/unet3d_ref.py, the device-drawn Dropout3d mask shared with it) at the
     tolerance of the mode: bf16 operands carry 2^-9 relative rounding, measured network-level error ~7e-3 (tests/test_model_gpu.py
-    test_autocast_unet_mixed_precision at 32^3); bound 1.5e-2 on logits (1.5x the 1.0e-2 measured on MI355X in round 4: a regression by a factor of two fails), 1e-2 on the Dice loss."""
+    test_autocast_unet_mixed_precision at 32^3); bound 1.5e-2 on logits (1.5x the 1.0e-2 measured on MI355X in round 4: a regression by a factor of two fails); the Dice loss kernel against the oracle's formula on the same logits, 1e-4."""
     from oracle import torch_ops as O
     torch.manual_seed(1234)
     m = unet.HipAutocastUNet(n_features=4, n_outputs=3, autocast_dtype="bf16").cuda().train()
@@ -276,21 +276,21 @@ def test_audit_c3_bf16_train_step_gpu(hip_backend):
                 "upsample_fwd": 3, "upsample_bwd": 3, "proj_fwd": 1, "proj_bwd": 1, "dice": 1, "adam": 1})
     forms = {r["desc"].rsplit("prologue ", 1)[1].split("]")[0] for r in au.records if "prologue " in r["desc"]}
     print("prologue forms matched:", forms, {k: f"{v['err']:.1e}" for k, v in au.worst().items() if k.endswith("_lp")})
-    # (b) against the fp32 oracle, sample by sample (the CPU oracle holds one 128^3 sample at a time comfortably)
+    # (b) against the fp32 oracle: the first and the last sample of the batch (the CPU oracle needs ~8 s per 128^3 forward; rounds 4-5 ran all
+    # four -- the samples are independent, a per-sample kernel fault shows on any of them and the per-launch audit above covers all four),
+    # and the batch loss against the oracle's Dice formula evaluated on the kernel's own logits of all four
     sd = keep["state_dict"]
     scale = m.last_dropout_scale.detach().cpu()
     torch.set_num_threads(min(64, torch.get_num_threads() * 2 or 1))
     worst = 0.0
-    ref_all = []
     with torch.no_grad():
-        for i in range(4):
+        for i in (0, 3):
             ref = R.unet3d_forward(sd, x[i:i + 1], dropout_scale=scale[i:i + 1])
-            ref_all.append(ref)
             worst = max(worst, A.rel_err(keep["logits"][i:i + 1], ref))
-        lref = float(O.dice_loss(torch.cat(ref_all), y))
+        lref = float(O.dice_loss(keep["logits"], y))
     print(f"c3 logits vs fp32 oracle {worst:.2e}; loss {loss:.6f} vs {lref:.6f}")
     assert worst < 1.5e-2, worst
-    assert abs(loss - lref) / lref < 1e-2, (loss, lref)
+    assert abs(loss - lref) / lref < 1e-4, (loss, lref)          # the loss kernel on identical logits: fp32 class
 
 
 @pytest.mark.gpu
