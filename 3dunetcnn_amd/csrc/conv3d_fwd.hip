@@ -696,7 +696,7 @@ template <int KD, int STRIDE, int TZ, int TY, int TX, int KC, int PADV, int WM, 
 static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
   constexpr int HZ = (TZ - 1) * STRIDE + KD, HY = (TY - 1) * STRIDE + KD, HX = (TX - 1) * STRIDE + KD;
   constexpr size_t lds = (size_t)HZ * HY * HX * (KC + PADV) * sizeof(float);
-  static_assert(lds <= 160 * 1024, "LDS tile must fit a CU's 160 KiB");      // (> 64 KiB: opted in per instantiation below, one workgroup per CU)
+  static_assert(lds <= 64 * 1024, "LDS tile must fit the default 64 KiB dynamic window");
   a.tilesZ = ceil_div(a.Do, TZ); a.tilesY = ceil_div(a.Ho, TY); a.tilesX = ceil_div(a.Wo, TX);
   a.coTiles = ceil_div(a.Cout, 32 * WN * NT);
   const long long blocks = (long long)a.N * a.tilesZ * a.tilesY * a.tilesX * a.coTiles;
@@ -712,11 +712,6 @@ static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
 #define MI355_LAUNCH_CONV4(SS, IM, LDSB, FU)                                                                                         \
   do {                                                                                                                         \
     if constexpr (!act_form_exists<TA>(KD, STRIDE, IM, FU)) return MI355_EUNSUPPORTED;                                          \
-    else if constexpr (lds > 64 * 1024) {   /* the wide-chunk stride-2 form: FULLJ instantiation only (CinP % KC == 0 is its routing condition) */ \
-      if (!fullj) return MI355_EUNSUPPORTED;                                                                                   \
-      SET_MAX_DYN_LDS((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, true, FU, TA>), (LDSB));            \
-      LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, true, FU, TA>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);  \
-    }                                                                                                                          \
     else if (tl && fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, true, FU, TA>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);  \
     else if (tl) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, KD == 3, false, FU, TA>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);      \
     else if (fullj) LAUNCH((conv3d_mfma<KD, SS, TZ, TY, TX, KC, PADV, WM, WN, MT, NT, IM, false, true, FU, TA>), dim3((unsigned)blocks), dim3(256), (LDSB), stream, a);       \
@@ -759,12 +754,8 @@ static int launch_cfg(ConvArgs& a, int in_mode, void* stream) {
 //  6/7: 3x3x3 stride 1, 2x4x8 / 4x4x8 tiles, KC=32 (small volumes, so the grid still covers 256 CUs)
 //  8:   3x3x3 stride 1, 4x4x8 tiles x 64 output channels, KC=16, 2 M tiles per wave (32768 .. 131071 output voxels, > 32 output
 //       channels: each B fragment feeds two MFMA tiles; +10 % over configuration 6 on the 32^3-level layers)
-//  9/10: 3x3x3 stride 2 with 16-channel chunks (MI355_S2_KC16=1; plain input, input channels a multiple of 16): a staging pass takes 64 bytes
-//       of every voxel's 128-byte line instead of 32 -- half the passes over the haloed 9 x 9 x 17 tile (110 KB of LDS: one workgroup per CU)
-static bool s2_kc16() { static const bool on = [] { const char* v = getenv("MI355_S2_KC16"); return v && v[0] == '1'; }(); return on; }
-static int select_cfg(int kd, int stride, long long vox, int cout, int in_mode = MI355_IN_PLAIN, int cin = 0) {
+static int select_cfg(int kd, int stride, long long vox, int cout, int in_mode = MI355_IN_PLAIN) {
   if (kd == 1) return cout > 32 ? 0 : 1;
-  if (stride == 2 && s2_kc16() && in_mode == MI355_IN_PLAIN && cin > 0 && cin % 16 == 0) return cout > 32 ? 9 : 10;
   if (stride == 2) return cout > 32 ? 2 : 3;
   if (vox >= 256LL * 512 || in_mode == MI355_IN_ZERO_INSERT) return cout > 32 ? 4 : 5;   // zero-insert: parity-class tiles need 4x8x8
   if (cout > 32 && vox >= 64LL * 512) return 8;
@@ -877,7 +868,7 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
   { const int rcg = fill_gn_fuse(a.g, x, y, d); if (rcg) return rcg; }
   if (a.res && a.resld < a.Cout) return MI355_EINVAL;
   const int im = d->in_mode;
-  const int cfg = select_cfg(d->kd, d->stride, (long long)a.Do * a.Ho * a.Wo * a.N, a.Cout, im, x->c);
+  const int cfg = select_cfg(d->kd, d->stride, (long long)a.Do * a.Ho * a.Wo * a.N, a.Cout, im);
   if (d->kd == 1) {
     if (d->stride != 1 || im == MI355_IN_ZERO_INSERT) return MI355_EUNSUPPORTED;
     const int cfg1 = select_cfg(1, 1, 0, d->out_mode == MI355_OUT_D2S ? 8 * y->c : y->c);
@@ -928,8 +919,6 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
     case 5: return launch_cfg<3, 1, 4, 8, 8, 16, 4, 4, 1, 2, 1>(a, im, stream);
     case 6: return launch_cfg<3, 1, 2, 4, 8, 32, 4, 2, 2, 1, 1>(a, im, stream);
     case 8: return launch_cfg<3, 1, 4, 4, 8, 16, 4, 2, 2, 2, 1>(a, im, stream);
-    case 9: return launch_cfg<3, 2, 4, 4, 8, 16, 4, 4, 1, 1, 2>(a, im, stream);
-    case 10: return launch_cfg<3, 2, 4, 4, 8, 16, 4, 4, 1, 1, 1>(a, im, stream);
     default: return launch_cfg<3, 1, 4, 4, 8, 32, 4, 4, 1, 1, 1>(a, im, stream);
   }
 }

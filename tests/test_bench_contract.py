@@ -119,7 +119,8 @@ def test_committed_bench_line_has_the_contract_shape(name):
         assert set(line["precision_modes"]) == {"bf16x6", "bf16x3", "bf16"}
 
 
-@pytest.mark.parametrize("name,dtype", [("r5_bench_fp32.json", "f32"), ("r5_c3_bench.json", "bf16 (mixed)")])
+@pytest.mark.parametrize("name,dtype", [("r5_bench_fp32.json", "f32"), ("r5_c3_bench.json", "bf16 (mixed)"), ("r6_bench_fp32.json", "f32"),
+                                        ("r6_c3_bench.json", "bf16 (mixed)")])
 def test_committed_lines_carry_the_verdict_fixes(name, dtype):
     """The round-5 lines as produced on the MI355X (tools/r5_final.sh): contract shape, a roofline whose traffic ratio a reader can redo in
     one division from the committed PMC summary, per-instantiation rows, both roofline fractions, (headline only) a cpu_baseline of the REAL
@@ -147,7 +148,17 @@ def test_committed_lines_carry_the_verdict_fixes(name, dtype):
     inst = roof["instantiations"]
     assert len(inst) >= 3 and sum(i["launches_per_step"] for i in inst) == roof["launches_per_step"]
     assert all("traffic_over_algorithmic" in i for i in inst)
-    if name == "r5_bench_fp32.json":
+    if name == "r6_bench_fp32.json":
+        # round 6: the PMC summary named by the line is the one bench.py reads for THIS tree (provenance hash of the kernel sources), the
+        # roofline block carries the clock the launches ran at, the >= 256-channel launches are on conv3d_wino3d, the first layer's
+        # backward is the fused kernel
+        assert rel == _bench().PMC_FILES[("c2", "fp32")].replace(os.sep, "/") and _bench().pmc_rows("c2", "fp32")[0] is not None
+        assert 1.5 < roof["shader_clock_ghz"] < 2.5 and roof["shader_clock_ghz"] == _bench().family_clock("c2", "fp32", roof["kernel"])
+        assert "conv3d_wino3d" in roof["all_kernels"] and roof["all_kernels"]["conv3d_wino3d"]["launches"] >= 3 * 8
+        fl = line["first_layer"]
+        assert set(fl["kernels_ms_per_launch"]) == {"conv3d_c4_fwd", "conv3d_c4_bwd (+reduce)"} and fl["hbm_frac"] > 0.22      # round 5: 0.19
+        assert line["metric"] == "training volumes/sec (128^3, 4ch->3cls)" and line["ms_per_step"] < 53.5
+    if name in ("r5_bench_fp32.json", "r6_bench_fp32.json"):
         assert "Winograd" in line["config"]["conv_arithmetic"] and roof["kernel"] == "conv3d_wino2d" and roof["bound"] == "mfma"
         assert all("conv3d_wino2d_d8<" in i["kernel"] for i in inst) and roof["frac"] > 0.62           # round 4: conv3d_wino2d_w8, 0.60
         c3 = line["c3"]
