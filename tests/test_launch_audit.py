@@ -86,7 +86,7 @@ def test_audit_first_block_fused_backward_emulator(emu_backend):
     enc = [1, 1]
     m = unet.HipUNet3D(n_features=4, n_outputs=3, base_width=32, encoder_blocks=enc).eval()
     m.backward_side_stream = False
-    x, y = R.synthetic_case(2, 4, (6, 10, 18), 3)
+    x, y = R.synthetic_case(1, 4, (6, 10, 18), 3)
     keep = {}
     au, loss = _step(emu_backend, m, x, y, "cpu", block_macs=2e5, full_macs=1e6, wgrad_channels=3, keep=keep)
     fused = [r for r in au.records if "c4_bwd" in r["desc"]]
