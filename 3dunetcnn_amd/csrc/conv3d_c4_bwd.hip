@@ -22,6 +22,7 @@
 // (sum du, sum du xhat) record per workgroup and input channel in the format of gn_fuse.h (mi355_gn_bwd_params finalises them).
 #include "gfx950_dialect.h"
 #include "../../include/mi355_unet3d.h"
+#include "act_io.h"
 
 // v_mfma_f32_4x4x1_16b_f32: 16 independent 4 x 4 outer products. Lane l = 4 b + r supplies A[b][row r] and B[b][column r]; it holds
 // D[b][rows 0..3][column r] in its 4 result registers.
@@ -42,7 +43,7 @@ static inline f32x4 emu_mfma_4x4x1(float a, float b, f32x4 c) {
 
 struct C4BArgs {
   const float* x; int xld;               // network input, 4 channels (fp32)
-  const float* dy; int dyld;             // gradient wrt the conv output, 32 channels
+  const float* dy; int dyld;             // gradient wrt the conv output, 32 channels (storage type TD of the kernel: fp32, bf16 or fp16)
   const float* wp;                       // dgrad pack of the conv weight (mi355_pack_conv_weight mode 1: [27][8][32][4], columns 0..3 used)
   float* ws;                             // weight-gradient slabs [2 x workgroup][32 co][128 (tap, ci) columns]
   float* part;                           // norm-backward records [n][B][4][2]
@@ -53,8 +54,11 @@ struct C4BArgs {
 
 void conv3d_c4_wgrad_reduce_launch(const float* ws, float* dw, int Cout, int splits, void* stream);      // conv3d_c4.hip
 
-template <int INMODE>
+// TD: storage type of dy (act_io.h). The arithmetic is exact fp32 on the stored values in every precision mode, as in the kernels this one
+// replaces (the 4-channel first layer's weight gradient and data gradient never ran on the 16-bit pipe).
+template <int INMODE, typename TD = float>
 __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(2) void conv3d_c4_bwd(C4BArgs a) {
+  const TD* const ady = reinterpret_cast<const TD*>(a.dy);
   constexpr int TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, HV = HY * HX;
   constexpr int DYP = HV * 32, XP = HV * 4;              // floats per staged dy / x plane
   constexpr int DYU = (HV * 8 + 511) / 512;              // 16-byte units of a dy plane per thread
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(2) void conv3d_c4_bwd(C4BAr
       const int hv = u >> 3, q = u & 7;
       int iy = ty0 - 1 + hv / HX, ix = tx0 - 1 + hv % HX;
       iy = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1); ix = ix < 0 ? 0 : (ix < a.W ? ix : a.W - 1);
-      dld[k] = *reinterpret_cast<const float4*>(a.dy + ((((size_t)n * a.D + zcl) * a.H + iy) * a.W + ix) * a.dyld + 4 * q);
+      dld[k] = ld4(ady + ((((size_t)n * a.D + zcl) * a.H + iy) * a.W + ix) * a.dyld + 4 * q);
     }
     {
       const int hv = tid < HV ? tid : HV - 1;
@@ -295,9 +299,9 @@ static int c4b_ok(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc
   if (!x || !dy || !d || !x->p || !dy->p) return MI355_EINVAL;
   if (x->c != 4 || dy->c != 32 || d->kd != 3 || d->stride != 1 || d->pad != 1 || d->out_mode != MI355_OUT_PLAIN) return MI355_EUNSUPPORTED;
   if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return MI355_EUNSUPPORTED;
-  if (x->dtype != MI355_ACT_F32 || dy->dtype != MI355_ACT_F32 || d->precision != MI355_PREC_F32) return MI355_EUNSUPPORTED;
+  if (x->dtype != MI355_ACT_F32 || !act_dtype_ok(dy)) return MI355_EUNSUPPORTED;      // (any precision mode: this layer's backward is exact fp32 in all of them)
   if (x->n != dy->n || x->d != dy->d || x->h != dy->h || x->w != dy->w) return MI355_EINVAL;
-  if (x->ld % 4 || dy->ld % 4 || x->ld < 4 || dy->ld < 32 || ((uintptr_t)x->p & 15) || ((uintptr_t)dy->p & 15)) return MI355_EINVAL;
+  if (x->ld % 4 || dy->ld % 4 || x->ld < 4 || dy->ld < 32 || ((uintptr_t)x->p & 15) || ((uintptr_t)dy->p & act_align_mask(dy->dtype))) return MI355_EINVAL;
   if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift || !(d->act_slope >= 0.f && d->act_slope <= 1.f))) return MI355_EINVAL;
   return MI355_OK;
 }
@@ -333,13 +337,14 @@ extern "C" int mi355_conv3d_c4_bwd(const mi355_act* x, const mi355_act* dy, cons
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope; a.mean_rstd = mean_rstd; a.groups = groups;
   a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w;
   const int lds_bytes = (4 * 180 * 32 + 4 * 180 * 4 + 27 * 8 * 16 + 2 * 2 * 3 * 64 * 4) * (int)sizeof(float);      // 129 792: one 8-wave workgroup per CU
-  if (d->in_mode == MI355_IN_PLAIN) {
-    SET_MAX_DYN_LDS((conv3d_c4_bwd<MI355_IN_PLAIN>), lds_bytes);
-    LAUNCH((conv3d_c4_bwd<MI355_IN_PLAIN>), dim3((unsigned)wgs), dim3(512), lds_bytes, stream, a);
-  } else {
-    SET_MAX_DYN_LDS((conv3d_c4_bwd<MI355_IN_AFFINE_ACT>), lds_bytes);
-    LAUNCH((conv3d_c4_bwd<MI355_IN_AFFINE_ACT>), dim3((unsigned)wgs), dim3(512), lds_bytes, stream, a);
-  }
+  ACT_TYPED(dy->dtype, TD,
+            if (d->in_mode == MI355_IN_PLAIN) {
+              SET_MAX_DYN_LDS((conv3d_c4_bwd<MI355_IN_PLAIN, TD>), lds_bytes);
+              LAUNCH((conv3d_c4_bwd<MI355_IN_PLAIN, TD>), dim3((unsigned)wgs), dim3(512), lds_bytes, stream, a);
+            } else {
+              SET_MAX_DYN_LDS((conv3d_c4_bwd<MI355_IN_AFFINE_ACT, TD>), lds_bytes);
+              LAUNCH((conv3d_c4_bwd<MI355_IN_AFFINE_ACT, TD>), dim3((unsigned)wgs), dim3(512), lds_bytes, stream, a);
+            });
   const int rc = LAUNCH_CHECK(); if (rc) return rc;
   conv3d_c4_wgrad_reduce_launch((const float*)ws, dw, 32, (int)wgs * 2, stream);
   return LAUNCH_CHECK();

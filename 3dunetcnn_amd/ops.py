@@ -545,7 +545,7 @@ class Backend:
 
     # -- first-layer backward in one pass over dy (csrc/conv3d_c4_bwd.hip) -----------------------------------------------------------------
     def c4_bwd_supported(self, x, dy, in_mode=IN_AFFINE_ACT, slope=0.0, scale=None, shift=None, in_slope=None):
-        """Can the fused first-layer backward take this pair (fp32 4-channel input, fp32 32-channel dy, fp32 arithmetic)? MI355_C4_BWD=0: never."""
+        """Can the fused first-layer backward take this pair (fp32 4-channel input, 32-channel dy of any storage type; its arithmetic is exact fp32 in every precision mode)? MI355_C4_BWD=0: never."""
         if os.environ.get("MI355_C4_BWD", "1") == "0" or x.c != 4 or dy.c != 32:
             return False
         d = self._desc(3, 1, 1, in_mode, slope, scale, shift, None, None, None, (0, 0, 0), dy.shape[1:4], [], in_slope, OUT_PLAIN)

@@ -353,14 +353,15 @@ class HipUNet3D(HipNetBase):
                       self._gslice(c2.norm1.weight), self._gslice(c2.norm1.bias), partials=p2)
         dh1 = dA2
         g1, _, groups1, padw = self._in_pad(c1, cin)
-        if (not need_dx and padw is None and blk.sample is not None and s.x_lp is None
+        if (not need_dx and padw is None and blk.sample is not None
                 and be.c4_bwd_supported(s.x, dh1, IN_AFFINE_ACT, 0.0, st1[1], st1[2])):
             # the network's first block (4 input channels, no gradient wrt the input): weight gradient of conv1 and dgamma / dbeta of
             # norm1 in ONE pass over dh1 -- no data-gradient tensor, no second read of dh1 (csrc/conv3d_c4_bwd.hip)
             be.c4_bwd(s.x, dh1, self._packed_weight(c1.conv.weight, 1), self._gslice(c1.conv.weight), groups1, g1, st1[0], st1[1], st1[2],
                       self._gslice(c1.norm1.weight), self._gslice(c1.norm1.bias))
-            with self._wgrad_stream(be, s.x, d_out):
-                be.conv_wgrad(s.x, d_out, self._gslice(blk.sample.weight), 1)
+            xs = s.x if s.x_lp is None else s.x_lp         # (16-bit storage: the shortcut conv read a 16-bit copy of the input)
+            with self._wgrad_stream(be, xs, d_out):
+                be.conv_wgrad(xs, d_out, self._gslice(blk.sample.weight), 1)
             self._flush_ready()
             return None
         with self._wgrad_stream(be, s.x, dh1, st1[1], st1[2]):

@@ -333,9 +333,10 @@ int mi355_resample_affine(const float* src, float* dst, int32_t c, int32_t sd, i
  * backward of the pair is dW of the conv and (dgamma, dbeta) of the norm. mi355_conv3d_c4_bwd produces dW and the norm-backward records
  * (gn_fuse.h format, [n][mi355_conv3d_c4_bwd_blocks(x)][4][2]) reading dy ONCE and never writing the data gradient -- it replaces
  * mi355_conv3d_wgrad + mi355_conv3d_fwd(dgrad pack) + mi355_gn_act_bwd for this layer (ATen: conv backward + native_group_norm_backward);
- * mi355_gn_bwd_params turns the records into dgamma / dbeta. x: the fp32 network input (4 channels); dy: fp32, 32 channels; desc: the
+ * mi355_gn_bwd_params turns the records into dgamma / dbeta. x: the fp32 network input (4 channels); dy: 32 channels, fp32 / bf16 / fp16
+ * storage (exact fp32 arithmetic on the stored values in every precision mode, as the calls it replaces); desc: the
  * forward conv's descriptor (norm prologue: in_mode, in_scale, in_shift, act_slope / in_slope); wp_dgrad: mi355_pack_conv_weight(mode 1);
- * mean_rstd / groups: mi355_gn_stats of x. MI355_EUNSUPPORTED for any other shape / storage type / precision (use the three calls). */
+ * mean_rstd / groups: mi355_gn_stats of x. MI355_EUNSUPPORTED for any other shape (use the three calls). */
 int mi355_conv3d_c4_bwd_supported(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* desc);
 int32_t mi355_conv3d_c4_bwd_blocks(const mi355_act* x);
 size_t mi355_conv3d_c4_bwd_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* desc);

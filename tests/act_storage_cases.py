@@ -270,6 +270,19 @@ def case_first_layer(be, dhw=(6, 9, 10), cout=32):
         be.conv_wgrad(x32, dy, dw, 3, 1, in_mode=ops.IN_AFFINE_ACT, scale=st[1], shift=st[2])
         dws.append(dw.cpu())
     out["wgrad"] = C.rel_err(dws[1], dws[0])
+    if cout == 32:
+        # round 6: the fused backward (csrc/conv3d_c4_bwd.hip) reads the upstream gradient in its storage type: the same values as fp32
+        # and as a 16-bit tensor must give the same dW / dgamma / dbeta (exact fp32 arithmetic on the stored values in both)
+        gam = C.dev(be, torch.rand(4, generator=g) + 0.5)
+        res = []
+        for dy in (dy32, dy16):
+            assert be.c4_bwd_supported(x32, dy, ops.IN_AFFINE_ACT, 0.0, st[1], st[2])
+            dw = torch.full((cout, 4, 3, 3, 3), 7.0, device=be.device)
+            dg, db = torch.full((4,), 7.0, device=be.device), torch.full((4,), 7.0, device=be.device)
+            be.c4_bwd(x32, dy, be.pack_weight(C.dev(be, w), 1), dw, 4, gam, st[0], st[1], st[2], dg, db)
+            res.append((dw.cpu(), dg.cpu(), db.cpu()))
+        out["c4bwd_dw"], out["c4bwd_dgamma"], out["c4bwd_dbeta"] = (C.rel_err(a, b) for a, b in zip(res[1], res[0]))
+        out["c4bwd_vs_wgrad"] = C.rel_err(res[0][0], dws[0])          # ... and its dW is the weight-gradient kernel's
     out.update({"dgrad_" + k: v for k, v in _conv_both(be, dy32.tensor().permute(0, 4, 1, 2, 3).cpu(), w, 1, 3, (n, 4, *dhw), {}, y16_is_f32=True).items()})
     return out
 

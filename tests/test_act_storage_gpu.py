@@ -95,7 +95,7 @@ def test_conv_3x3x3_plane_ring_forms(bf16_backend, monkeypatch, form, kw):
 
 @pytest.mark.parametrize("dhw", [(6, 9, 10), (32, 32, 32)])
 def test_first_layer(bf16_backend, dhw):
-    _all_below(S.case_first_layer(bf16_backend, dhw=dhw), moments=2e-5, wgrad=1e-5)
+    _all_below(S.case_first_layer(bf16_backend, dhw=dhw), moments=2e-5, wgrad=1e-5, c4bwd_vs_wgrad=1e-5)
 
 
 @pytest.mark.parametrize("kw", [
@@ -174,7 +174,7 @@ def test_fp16_conv_3x3x3_plane_ring_forms(fp16_backend, monkeypatch, form, kw):
 
 
 def test_fp16_first_layer_and_weight_gradients(fp16_backend):
-    _all_below(S.case_first_layer(fp16_backend, dhw=(32, 32, 32)), moments=2e-5, wgrad=1e-5)
+    _all_below(S.case_first_layer(fp16_backend, dhw=(32, 32, 32)), moments=2e-5, wgrad=1e-5, c4bwd_vs_wgrad=1e-5)
     _all_below(S.case_wgrad(fp16_backend, kd=1, stride=1, cin=64, cout=32, dhw=(16, 16, 16)), dw=1e-5)
     _all_below(S.case_wgrad(fp16_backend, kd=3, stride=2, cin=32, cout=32, dhw=(17, 16, 19), n=2), dw=1e-5)
     _all_below(S.case_wgrad(fp16_backend, kd=3, stride=1, cin=32, cout=32, dhw=(9, 10, 34), norm=True), dw=1e-5)

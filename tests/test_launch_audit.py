@@ -100,6 +100,20 @@ def test_audit_first_block_fused_backward_emulator(emu_backend):
         assert A.rel_err(g, sd[k].grad) < 1e-4, k
 
 
+def test_audit_first_block_fused_backward_16bit_storage_emulator(emu_backend):
+    """The same first block inside a network with bf16 operands and bf16 activation storage (BASELINE configs[2]'s mode): the fused
+    backward reads the bf16 upstream gradient, computes in exact fp32 (as the kernels it replaces did) and the 1x1x1 shortcut's weight
+    gradient reads the 16-bit copy of the input -- every launch audited."""
+    torch.manual_seed(3)
+    m = unet.HipAutocastUNet(n_features=4, n_outputs=3, base_width=32, encoder_blocks=[1, 1], autocast_dtype="bf16").eval()
+    m.backward_side_stream = False
+    assert m.act_storage == torch.bfloat16
+    x, y = R.synthetic_case(1, 4, (6, 10, 18), 3)
+    au, loss = _step(emu_backend, m, x, y, "cpu", block_macs=2e5, full_macs=1e6, wgrad_channels=3)
+    assert [r["kind"] for r in au.records if "c4_bwd" in r["desc"]] == ["conv_wgrad", "gn_act_bwd"]
+    _check(au, {"conv_fwd_lp": 5, "conv_wgrad_lp": 3, "conv_wgrad": 3, "gn_act_bwd": 8})
+
+
 @pytest.mark.parametrize("tc", [False, True])
 def test_audit_odd_sizes_emulator(emu_backend, tc):
     """Ragged sizes: the pad / crop window of the up-sampling path (unet.py:34-40) and, with use_transposed_convolutions, the zero-insert
@@ -272,7 +286,10 @@ def test_audit_c3_bf16_train_step_gpu(hip_backend):
     keep = {}
     au, loss = _step(hip_backend, m, x, y, "cuda", keep=keep)
     assert m.last_dropout_scale is not None and 0.0 < loss < 1.0
-    _check(au, {"conv_fwd_lp": 26 + 25, "conv_wgrad_lp": 25, "conv_fwd": 22, "conv_wgrad": 12, "gn_act_bwd": 26, "gn_stats": 26, "chscale": 1,
+    # (round 6: the first block's backward is the fused conv3d_c4_bwd in the 16-bit modes too -- exact fp32 on the stored bf16 gradient --
+    # audited as a conv_wgrad + a gn_act_bwd record; the narrow data gradient it replaced was one of the 22 fp32-kind conv_fwd launches)
+    assert [r["kind"] for r in au.records if "c4_bwd" in r["desc"]] == ["conv_wgrad", "gn_act_bwd"]
+    _check(au, {"conv_fwd_lp": 26 + 25, "conv_wgrad_lp": 25, "conv_fwd": 21, "conv_wgrad": 12, "gn_act_bwd": 26, "gn_stats": 26, "chscale": 1,
                 "upsample_fwd": 3, "upsample_bwd": 3, "proj_fwd": 1, "proj_bwd": 1, "dice": 1, "adam": 1})
     forms = {r["desc"].rsplit("prologue ", 1)[1].split("]")[0] for r in au.records if "prologue " in r["desc"]}
     print("prologue forms matched:", forms, {k: f"{v['err']:.1e}" for k, v in au.worst().items() if k.endswith("_lp")})
