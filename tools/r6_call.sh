@@ -1,9 +1,23 @@
 #!/bin/bash
-out=gpurun_out/r6k
+out=gpurun_out/r6l
 mkdir -p $out
-python -m pytest tests/test_act_storage_gpu.py tests/test_ops_gpu.py tests/test_launch_audit.py -m gpu -q -x -k "first_layer or 16bit_train_step_gpu or c3" 2>&1 | tail -4
-for f in 0 1; do
-  for cfg in "--config c3" "--precision bf16"; do
-    MI355_C4_BWD=$f python bench.py $cfg --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('c4_bwd=$f $cfg', d['ms_per_step'], d['value'])"
-  done
+root=$(pwd)
+for lib in tree tools/libvar_wgrabl.so; do
+python - "$lib" <<'PY'
+import sys, os, importlib, torch, time
+sys.path.insert(0, os.getcwd())
+lib = importlib.import_module("3dunetcnn_amd._lib")
+if sys.argv[1] != "tree": lib.LIB_PATH = os.path.abspath(sys.argv[1])
+ops = importlib.import_module("3dunetcnn_amd.ops")
+be = ops.default_backend()
+for cin, cout, s in ((32, 32, 128), (64, 64, 64), (128, 128, 32), (256, 256, 16)):
+    x = be.empty_act(2, s, s, s, cin); x.buf.normal_()
+    dy = be.empty_act(2, s, s, s, cout); dy.buf.normal_()
+    dw = torch.empty(cout, cin, 3, 3, 3, device="cuda")
+    f = lambda: be.conv_wgrad(x, dy, dw, 3, 1)
+    for _ in range(3): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): f()
+    torch.cuda.synchronize(); print(sys.argv[1][-16:], cin, cout, s, f"{(time.perf_counter() - t0) / 20 * 1e3:.4f} ms (wgrad + reduce)")
+PY
 done
