@@ -787,6 +787,10 @@ int mi355_conv3d_c4_ok(const mi355_act* x, const mi355_conv_desc* d);
 int mi355_conv3d_c4_fwd_impl(const mi355_act* x, const float* w, const mi355_act* y, const mi355_conv_desc* d, void* stream);
 int mi355_conv3d_narrow_ok(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d);
 int mi355_conv3d_narrow_impl(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream);
+// conv3d_s2.hip: the z-marching 32 -> 32 channel stride-2 forward
+int mi355_conv3d_s2c32_ok(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d);
+int32_t mi355_conv3d_s2c32_stats_blocks(const mi355_act* y);
+int mi355_conv3d_s2c32_fwd_impl(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream);
 
 extern "C" int mi355_conv3d_uses_bf16(const mi355_conv_desc* d) {
   return d && d->precision != MI355_PREC_F32 && d->kd == 3 && d->stride == 1 &&
@@ -803,6 +807,8 @@ extern "C" int32_t mi355_conv3d_stats_blocks(const mi355_act* x, const mi355_act
     b = (long long)ceil_div(y->d, 4) * ceil_div(y->h, 8) * ceil_div(y->w, 8);
   } else if (mi355_conv3d_uses_bf16(d)) {
     return mi355_conv3d_bf16_stats_blocks(x, y, d);
+  } else if (mi355_conv3d_s2c32_ok(x, y, d)) {
+    return mi355_conv3d_s2c32_stats_blocks(y);
   } else if (d->kd == 1 || (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT)) {
     return 0;                 // only the 3x3x3 kernels reading a plain / normalised input carry the fused-statistics epilogue
   } else {
@@ -851,6 +857,7 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
     return mi355_conv3d_fwd_bf16_impl(x, wp, y, d, stream);
   }
   if (d->in_mode == MI355_IN_ZERO_INSERT && (d->stride != 1 || d->kd != 3 || d->pad != 1)) return MI355_EINVAL;
+  if (mi355_conv3d_s2c32_ok(x, y, d)) return mi355_conv3d_s2c32_fwd_impl(x, wp, y, d, stream);
   if (x->dtype != y->dtype) return MI355_EUNSUPPORTED;      // one storage type per call here (the first-layer kernels above take fp32 x with either y)
   const bool lp = act_is_lp16(x->dtype);
   if (lp && (y->c % 4 || y->ld % 4 || ((uintptr_t)y->p & 7))) return MI355_EINVAL;
@@ -932,6 +939,7 @@ extern "C" int mi355_conv3d_fwd_config(const mi355_act* x, const mi355_act* y, c
     return 0;
   }
   if (d->wformat == MI355_W_PACKED && mi355_conv3d_uses_bf16(d)) return mi355_conv3d_bf16_kernel_name(x, y, d, out, n);
+  if (mi355_conv3d_s2c32_ok(x, y, d)) { snprintf(out, n, "conv3d_s2c32_fwd"); return 0; }
   const int cfg = select_cfg(d->kd, d->stride, (long long)d->out_d * d->out_h * d->out_w * x->n,
                              (d->kd == 1 && d->out_mode == MI355_OUT_D2S) ? 8 * y->c : y->c, d->in_mode);
   const int stride_t = d->in_mode == MI355_IN_ZERO_INSERT ? 1 : d->stride;

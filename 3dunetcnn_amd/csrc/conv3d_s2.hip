@@ -1,0 +1,255 @@
+// 3x3x3 stride-2 pad-1 conv3d forward for 32 -> 32 channels (round 6): the first down-sampling convolution of the default UNet3D
+// (unet3d/models/pytorch/classification/myronenko.py:93-101, `downsampling_convolutions[0]`: 128^3 -> 64^3 at the headline size), exact fp32.
+//
+// Why a kernel of its own: the generic conv3d_mfma<3, 2, ...> stages a haloed 9 x 9 x 17 voxel tile 8 channels at a time, i.e. takes 32
+// bytes of every voxel's 128-byte line per pass, four passes per tile -- and 64 resident workgroups x 176 KB of such tiles do not fit an
+// XCD's 4 MB L2: PMC 2.4 GB fetched for 0.6 GB algorithmic, the launch runs at HBM speed (0.43 ms at 128^3 x 2 against 0.18 ms of matrix
+// time). 16-channel chunks in that kernel need 110 KB of LDS (one workgroup per CU) and measured slower.
+// Here a 256-thread workgroup marches a 4 x 8 output-voxel column along z: a ring of three haloed input planes (9 x 17 voxels x ALL 32
+// channels: every 128-byte line is fetched whole and once per column, 1.2x with the (y, x) halo; two new planes per output plane, loaded into
+// registers during the previous plane's MFMAs) and the four waves split K: wave w owns input channels 8 w .. 8 w + 7 of all 27 taps with
+// its 27 weight quads per lane resident in registers for the whole march (108 VGPRs: this is why 32 channels and not more); per tap one
+// ds_read_b128 of the voxel's channel quad feeds 4 MFMAs (read one tap ahead, by hand: hipcc does not pipeline LDS reads into MFMAs); the
+// four partial 32 x 32 accumulators meet in LDS once per plane, where the 256 threads add them, store 16 bytes each (coalesced 128-byte
+// voxel rows) and keep the output's moments for the next norm (one record per workgroup, gn_fuse.h format).
+// TA: storage type of x and y (act_io.h): the 16-bit modes run this layer in exact fp32 on the stored values, like conv3d_mfma.
+#include "gfx950_dialect.h"
+#include "../../include/mi355_unet3d.h"
+#include "act_io.h"
+
+struct S2Args {
+  const float* x; int xld;
+  const float* wp;                       // forward pack [27][8][32][4] (mi355_pack_conv_weight mode 0, cin = cout = 32)
+  float* y; int yld;
+  float* mom;                            // moment records [n][B][32][3] or NULL
+  int N, Di, Hi, Wi, Do, Ho, Wo;
+  int tilesY, tilesX, zchunks, zper;
+};
+
+template <typename TA, bool FUSE>
+__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_s2c32_fwd(S2Args a) {
+  constexpr int TY = 4, TX = 8, HY = 2 * TY + 1, HX = 2 * TX + 1, HV = HY * HX;      // 9 x 17 = 153 input voxels per plane
+  constexpr int PL = HV * 32;                            // floats per staged plane
+  constexpr int UNITS = 2 * HV * 8, UP = (UNITS + 255) / 256;      // 16-byte units of the two planes a step loads, per thread
+  const TA* const ax = reinterpret_cast<const TA*>(a.x);
+  TA* const ay = reinterpret_cast<TA*>(a.y);
+  DYN_LDS(lds);
+  float* xs = lds;                                       // ring of 3 planes: input plane p in slot (p + 3) % 3
+  float* ex = lds + 3 * PL;                              // exchange [wave][voxel 32][co 32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6), half = lane >> 5, li = lane & 31;
+  int b = blockIdx.x;
+  const int zc = b % a.zchunks; b /= a.zchunks;
+  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+  const int n = b;
+  const int z_begin = zc * a.zper, z_end = z_begin + a.zper < a.Do ? z_begin + a.zper : a.Do;
+  const int iy0 = 2 * ty0 - 1, ix0 = 2 * tx0 - 1;        // input origin of the haloed plane tile
+
+  // the wave's weights: 27 quads per lane (quad 2 w + half of the input channels, output channel li), resident for the whole march
+  float4 W[27];
+  {
+    const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
+#pragma unroll
+    for (int t = 0; t < 27; ++t) W[t] = wp4[(size_t)(t * 8 + 2 * wave + half) * 32 + li];
+  }
+
+  // Staging units of a step: two input planes x 153 voxels x 8 channel quads = 2 448 units of 16 bytes, unit u = tid + 256 k. Everything a
+  // unit needs per step is 32 bits wide and computed ONCE: its element offset inside a plane (clamped to the image: the load is always
+  // legal), its LDS offset inside a slot, one validity bit. (The first form kept ten 64-bit addresses per thread, spilled them, and every
+  // scratch reload put an `s_waitcnt vmcnt(0)` between the global loads: 13 us per plane.)
+  float4 st[UP];
+  unsigned goff[UP], loff[UP];
+  unsigned okmask = 0, ppmask = 0;                       // bit k: unit k lies inside the image in (y, x); unit k belongs to the pair's second plane
+#pragma unroll
+  for (int k = 0; k < UP; ++k) {
+    int u = tid + k * 256; const bool live = u < UNITS; if (!live) u = UNITS - 1;
+    const int pp = u / (HV * 8), r = u % (HV * 8), hv = r >> 3, q = r & 7;
+    const int iy = iy0 + hv / HX, ix = ix0 + hv % HX;
+    const bool in = iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+    const int cy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1), cx = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
+    goff[k] = (unsigned)((cy * a.Wi + cx) * a.xld + 4 * q);
+    loff[k] = live ? (unsigned)(hv * 32 + 4 * q) : 0xffffffffu;
+    okmask |= (unsigned)(in && live) << k;
+    ppmask |= (unsigned)pp << k;
+  }
+  const size_t xplane = (size_t)a.Hi * a.Wi * a.xld;
+  const TA* const xn = ax + (size_t)n * a.Di * xplane;
+  auto load_planes = [&](int p0) {                       // input planes p0, p0 + 1 -> registers
+    const int z0 = p0 < 0 ? 0 : (p0 < a.Di ? p0 : a.Di - 1), z1 = p0 + 1 < 0 ? 0 : (p0 + 1 < a.Di ? p0 + 1 : a.Di - 1);
+    const TA* pA = xn + (size_t)z0 * xplane;             // wave-uniform plane bases
+    const TA* pB = xn + (size_t)z1 * xplane;
+#pragma unroll
+    for (int k = 0; k < UP; ++k) st[k] = ld4(((ppmask >> k) & 1u ? pB : pA) + goff[k]);
+  };
+  auto commit_planes = [&](int p0, bool first_only) {
+    const bool zokA = p0 >= 0 && p0 < a.Di, zokB = p0 + 1 >= 0 && p0 + 1 < a.Di;
+    float* sA = xs + ((p0 + 3) % 3) * PL;
+    float* sB = xs + ((p0 + 4) % 3) * PL;
+#pragma unroll
+    for (int k = 0; k < UP; ++k) {
+      const bool second = (ppmask >> k) & 1u;
+      if (loff[k] == 0xffffffffu || (first_only && second)) continue;
+      const bool ok = ((okmask >> k) & 1u) && (second ? zokB : zokA);
+      *reinterpret_cast<float4*>((second ? sB : sA) + loff[k]) = ok ? st[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  // A operand: lane li = output voxel (row li >> 3, column li & 7) of the plane tile, lane half = which of the wave's two channel quads
+  const int abase = ((2 * (li >> 3)) * HX + 2 * (li & 7)) * 32 + (2 * wave + half) * 4;
+  // final stage: thread = (voxel tid >> 3, output-channel quad tid & 7)
+  const int fv = tid >> 3, fq = tid & 7;
+  const int oy = ty0 + (fv >> 3), ox = tx0 + (fv & 7);
+  const bool fin = oy < a.Ho && ox < a.Wo;
+  float K0[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  float cnt = 0.f;
+
+  // ---- prologue: planes 2 z_begin - 1, 2 z_begin, 2 z_begin + 1 (loads come in pairs: the second pair's second plane is dropped --
+  // the loop's first step loads the pair (2 z_begin + 2, 2 z_begin + 3) like every other step: one code path) ----
+  load_planes(2 * z_begin - 1); commit_planes(2 * z_begin - 1, false);
+  load_planes(2 * z_begin + 1); commit_planes(2 * z_begin + 1, true);
+  __syncthreads();
+
+  for (int zo = z_begin; zo < z_end; ++zo) {
+    // planes 2 zo - 1, 2 zo, 2 zo + 1 are staged. The next output plane needs 2 zo + 2, 2 zo + 3: in flight during the MFMAs
+    load_planes(2 * zo + 2);
+    const float* pl[3] = {xs + ((2 * zo - 1 + 3) % 3) * PL, xs + ((2 * zo + 3) % 3) * PL, xs + ((2 * zo + 1 + 3) % 3) * PL};
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 cur = *reinterpret_cast<const float4*>(pl[0] + abase), nxt = cur;
+    static_for<0, 27>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      if constexpr (t + 1 < 27) {
+        constexpr int t1 = t + 1, dz = t1 / 9, dy = (t1 / 3) % 3, dx = t1 % 3;
+        nxt = *reinterpret_cast<const float4*>(pl[dz] + abase + (dy * HX + dx) * 32);
+      }
+      SCHED_BARRIER();
+      acc = MFMA_32x32x2(cur.x, W[t].x, acc); acc = MFMA_32x32x2(cur.y, W[t].y, acc);
+      acc = MFMA_32x32x2(cur.z, W[t].z, acc); acc = MFMA_32x32x2(cur.w, W[t].w, acc);
+      SCHED_BARRIER();
+      cur = nxt;
+    });
+    // partial tile -> exchange [wave][voxel row][co]: accumulator register r is voxel (r & 3) + 8 (r >> 2) + 4 half, lane li = co
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ex[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[r];
+    __syncthreads();                                     // every wave is done with the ring; the partials are visible
+    commit_planes(2 * zo + 2, false);                    // into the slots of planes 2 zo - 1 and 2 zo
+    {
+      const float* e0 = ex + fv * 32 + 4 * fq;
+      const float4 p0 = *reinterpret_cast<const float4*>(e0), p1 = *reinterpret_cast<const float4*>(e0 + 1024);
+      const float4 p2 = *reinterpret_cast<const float4*>(e0 + 2048), p3 = *reinterpret_cast<const float4*>(e0 + 3072);
+      float ov[4] = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w)};
+      if (fin) {
+        TA* yp = ay + ((((size_t)n * a.Do + zo) * a.Ho + oy) * a.Wo + ox) * a.yld + 4 * fq;
+        st4(yp, make_float4(ov[0], ov[1], ov[2], ov[3]));
+        if constexpr (FUSE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = as_stored(yp, ov[e]);
+            if (cnt == 0.f) K0[e] = v;
+            const float d = v - K0[e];
+            s0[e] += d; s1[e] += d * d;
+          }
+          cnt += 1.f;
+        }
+      }
+    }
+    __syncthreads();                                     // the ring is complete for the next plane; the exchange is free
+  }
+
+  if constexpr (FUSE) {
+    // one record per workgroup and channel: lanes fq + 8 m of a wave hold the same channels -> xor-shuffle steps 8, 16, 32 (the lower lane
+    // first), then the four waves through LDS in wave order; partial (c, K, s0, s1) pairs merge by moving the second to the first's shift
+    auto merge = [](float& ca, float& ka, float& a0, float& a1, float cb, float kb, float b0, float b1) {
+      if (ca == 0.f) { ca = cb; ka = kb; a0 = b0; a1 = b1; return; }
+      const float d = kb - ka;
+      a1 += b1 + d * (2.f * b0 + cb * d);
+      a0 += b0 + cb * d;
+      ca += cb;
+    };
+#pragma unroll
+    for (int step = 8; step < 64; step <<= 1) {
+      const bool upper = lane & step;
+      const float oc = __shfl_xor(cnt, step);
+      float nc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ok_ = __shfl_xor(K0[e], step), o0 = __shfl_xor(s0[e], step), o1 = __shfl_xor(s1[e], step);
+        float ca, ka, a0, a1;
+        if (upper) { ca = oc; ka = ok_; a0 = o0; a1 = o1; merge(ca, ka, a0, a1, cnt, K0[e], s0[e], s1[e]); }
+        else { ca = cnt; ka = K0[e]; a0 = s0[e]; a1 = s1[e]; merge(ca, ka, a0, a1, oc, ok_, o0, o1); }
+        K0[e] = ka; s0[e] = a0; s1[e] = a1; nc = ca;
+      }
+      cnt = nc;
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float* pr = ex + ((wave * 32) + 4 * fq + e) * 4;
+        pr[0] = cnt; pr[1] = K0[e]; pr[2] = s0[e]; pr[3] = s1[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float c = ex[tid * 4], k = ex[tid * 4 + 1], t0 = ex[tid * 4 + 2], t1 = ex[tid * 4 + 3];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float* pr = ex + (w * 32 + tid) * 4;
+        merge(c, k, t0, t1, pr[0], pr[1], pr[2], pr[3]);
+      }
+      const float m2 = c > 0.f ? t1 - t0 * t0 / c : 0.f;
+      const size_t B = (size_t)a.tilesY * a.tilesX * a.zchunks;
+      float* dst = a.mom + (((size_t)n * B + (blockIdx.x % B)) * 32 + tid) * 3;
+      dst[0] = c; dst[1] = t0 + c * k; dst[2] = m2 > 0.f ? m2 : 0.f;
+    }
+  }
+}
+
+static int s2_plan(const mi355_act* y, S2Args& a) {
+  a.tilesY = ceil_div(y->h, 4); a.tilesX = ceil_div(y->w, 8);
+  const long long cols = (long long)y->n * a.tilesY * a.tilesX;
+  if (cols <= 0 || cols > 0x7fffffffLL) return 0;
+  int zch = (int)((512 + cols - 1) / cols);              // ~512 workgroups: two per CU, one round (1024: 0.332 -> measured below)
+  const int maxch = y->d >= 8 ? y->d / 8 : 1;            // >= 8 output planes per chunk (a chunk stages 3 planes before its first MFMA)
+  if (zch > maxch) zch = maxch;
+  if (zch < 1) zch = 1;
+  a.zper = ceil_div(y->d, zch);
+  a.zchunks = ceil_div(y->d, a.zper);
+  return cols * a.zchunks <= 0x7fffffffLL;
+}
+
+// the calls this kernel takes: 3x3x3 stride 2 pad 1, 32 -> 32 channels, plain input, plain un-windowed output, no bias / residual / channel
+// scale, exact-fp32 arithmetic (every precision mode runs the stride-2 convolutions so), x and y of one storage type; optional moments.
+// MI355_S2_KERNEL=0 (read once): never -- the A/B switch.
+int mi355_conv3d_s2c32_ok(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d) {
+  static const bool off = [] { const char* v = getenv("MI355_S2_KERNEL"); return v && v[0] == '0'; }();
+  if (off || !x || !y || !d) return 0;
+  if (d->kd != 3 || d->stride != 2 || d->pad != 1 || x->c != 32 || y->c != 32 || d->in_mode != MI355_IN_PLAIN || d->out_mode != MI355_OUT_PLAIN) return 0;
+  if (d->bias || d->residual || d->out_chscale || d->gn_bwd || d->off_z || d->off_y || d->off_x) return 0;
+  if (d->wformat != MI355_W_PACKED || x->dtype != y->dtype || !act_dtype_ok(x)) return 0;
+  if (y->d != (x->d - 1) / 2 + 1 || y->h != (x->h - 1) / 2 + 1 || y->w != (x->w - 1) / 2 + 1 || d->out_d != y->d || d->out_h != y->h || d->out_w != y->w) return 0;
+  if (x->ld % 4 || y->ld % 4 || ((uintptr_t)x->p & act_align_mask(x->dtype)) || ((uintptr_t)y->p & act_align_mask(y->dtype))) return 0;
+  return 1;
+}
+
+int32_t mi355_conv3d_s2c32_stats_blocks(const mi355_act* y) {
+  S2Args a; memset(&a, 0, sizeof(a));
+  if (!y || !s2_plan(y, a)) return 0;
+  return a.tilesY * a.tilesX * a.zchunks;
+}
+
+int mi355_conv3d_s2c32_fwd_impl(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
+  if (!mi355_conv3d_s2c32_ok(x, y, d)) return MI355_EUNSUPPORTED;
+  S2Args a; memset(&a, 0, sizeof(a));
+  if (!s2_plan(y, a)) return MI355_EINVAL;
+  a.x = (const float*)x->p; a.xld = x->ld; a.wp = wp; a.y = (float*)y->p; a.yld = y->ld; a.mom = d->moments_out;
+  a.N = x->n; a.Di = x->d; a.Hi = x->h; a.Wi = x->w; a.Do = y->d; a.Ho = y->h; a.Wo = y->w;
+  const long long wgs = (long long)x->n * a.tilesY * a.tilesX * a.zchunks;
+  const int lds_bytes = (3 * 153 * 32 + 4 * 32 * 32) * (int)sizeof(float);      // 75 136: two workgroups per CU
+  ACT_TYPED(x->dtype, TA,
+            if (a.mom) { SET_MAX_DYN_LDS((conv3d_s2c32_fwd<TA, true>), lds_bytes);
+                         LAUNCH((conv3d_s2c32_fwd<TA, true>), dim3((unsigned)wgs), dim3(256), lds_bytes, stream, a); }
+            else { SET_MAX_DYN_LDS((conv3d_s2c32_fwd<TA, false>), lds_bytes);
+                   LAUNCH((conv3d_s2c32_fwd<TA, false>), dim3((unsigned)wgs), dim3(256), lds_bytes, stream, a); });
+  return LAUNCH_CHECK();
+}

@@ -27,6 +27,7 @@ def ok(r):
     dict(n=1, cin=8, cout=32, dhw=(6, 7, 9)),
     dict(n=2, cin=4, cout=32, dhw=(5, 8, 8), norm=True),
     dict(n=1, cin=32, cout=32, dhw=(9, 10, 12), stride=2),
+    dict(n=2, cin=32, cout=32, dhw=(33, 7, 18), stride=2, xld=64, yld=64, yc0=32),      # conv3d_s2c32_fwd: two z chunks, ragged column tiles, views of wider buffers
     dict(n=2, cin=8, cout=64, dhw=(8, 8, 8), stride=2, norm=True, slope=0.01),
     dict(n=2, cin=64, cout=32, dhw=(5, 6, 7), kd=1),
     dict(n=1, cin=32, cout=64, dhw=(9, 6, 7), kd=1, bias=True),
@@ -165,7 +166,8 @@ def test_groupnorm(emu_backend, kw):
     dict(n=1, cin=16, cout=64, dhw=(3, 5, 8), residual=True, chscale=True),     # 2x2 wave grid, residual with |mean| >> std, dropout scale
     dict(n=1, cin=8, cout=40, dhw=(4, 4, 8), groups_out=40),                    # partial channel tile, InstanceNorm-style groups
     dict(n=1, cin=4, cout=32, dhw=(5, 9, 9)),                                   # first-layer kernel (conv3d_c4_fwd)
-    dict(n=1, cin=32, cout=32, dhw=(9, 8, 8), stride=2, norm=False),            # stride-2 down-sampling conv
+    dict(n=1, cin=32, cout=32, dhw=(9, 8, 8), stride=2, norm=False),            # stride-2 down-sampling conv (conv3d_s2c32_fwd)
+    dict(n=2, cin=32, cout=32, dhw=(33, 7, 18), stride=2, norm=False),          # ... two z chunks per column, ragged tiles
     dict(n=1, cin=8, cout=32, dhw=(4, 4, 8), yld=64, yc0=32),                   # output written into a concat slice
 ])
 def test_conv_epilogue_moments(emu_backend, kw):

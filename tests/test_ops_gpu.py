@@ -27,6 +27,7 @@ def ok(r):
     dict(n=2, cin=32, cout=32, dhw=(48, 64, 64), norm=True, residual=True, chscale=True),     # 4x8x8 tile config
     dict(n=1, cin=64, cout=32, dhw=(32, 64, 64), norm=True, yld=64, yc0=32),
     dict(n=1, cin=32, cout=32, dhw=(33, 30, 36), stride=2),
+    dict(n=2, cin=32, cout=32, dhw=(65, 31, 36), stride=2, xld=64, yld=64, yc0=32),     # conv3d_s2c32_fwd: several z chunks, views of wider buffers
     dict(n=2, cin=64, cout=64, dhw=(16, 16, 16), stride=2),
     dict(n=1, cin=128, cout=256, dhw=(16, 16, 16), norm=True),
     dict(n=2, cin=256, cout=256, dhw=(8, 8, 8), norm=True, residual=True),
@@ -155,7 +156,8 @@ def test_groupnorm(hip_backend, kw):
     dict(n=2, cin=128, cout=256, dhw=(16, 16, 16), residual=True),                  # 2x4x8 tiles, two-level accumulation
     dict(n=2, cin=4, cout=32, dhw=(64, 64, 64)),                                    # first layer (conv3d_c4_fwd)
     dict(n=1, cin=4, cout=64, dhw=(33, 30, 36), groups_out=64),                     # DynUNet input block: ragged, InstanceNorm
-    dict(n=2, cin=32, cout=32, dhw=(64, 64, 64), stride=2, norm=False),             # stride-2 down-sampling conv
+    dict(n=2, cin=32, cout=32, dhw=(64, 64, 64), stride=2, norm=False),             # stride-2 down-sampling conv (conv3d_s2c32_fwd)
+    dict(n=1, cin=32, cout=32, dhw=(65, 31, 36), stride=2, norm=False),             # ... ragged
     dict(n=1, cin=96, cout=96, dhw=(31, 33, 17), stride=2, groups_out=96),
     dict(n=1, cin=32, cout=32, dhw=(32, 32, 32), yld=64, yc0=32),                   # written into a concat slice
 ])
