@@ -205,11 +205,161 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_s2c32_fwd(S2
   }
 }
 
-static int s2_plan(const mi355_act* y, S2Args& a) {
+// ---- weight gradient of the same layer: dw[co][ci][tap] = sum over output voxels q of dy[q][co] * x[2 q + tap - 1][ci] ----
+// The same march and the same input ring; the plane's 32 output voxels are K (16 MFMA k-steps), the 27 taps are dealt to the four waves
+// (7 / 7 / 7 / 6: tap = (wave & 3) + 4 ti; the other wave bit halves K: 512 threads, so that a thread stages 5 units instead of 10 -- with
+// 112 accumulator registers the 10-unit form spilled) whose 32 (co) x 32 (ci) accumulators stay in registers for the whole march -- no exchange; A = dy
+// (lane = co, k = voxel of the pair), B = x at the tap's offset (lane = ci): plain ds_read_b32, read one k-step ahead. The generic
+// conv3d_wgrad_mfma<3, 2, 2, 2, 8> stages a haloed 5 x 5 x 17 tile per 32 output voxels (1.7x the input) and 0.51 ms.
+// Partial tiles go to the slab workspace of conv3d_wgrad.hip ([slab][tap][32 co][32 ci]) and its deterministic reduction.
+struct S2WArgs {
+  const float* x; int xld;
+  const float* dy; int dyld;
+  float* ws;
+  int N, Di, Hi, Wi, Do, Ho, Wo;
+  int tilesY, tilesX, zchunks, zper;
+};
+
+template <typename TA>
+__global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(2) void conv3d_s2c32_wgrad(S2WArgs a) {
+  constexpr int TY = 4, TX = 8, HY = 2 * TY + 1, HX = 2 * TX + 1, HV = HY * HX;
+  constexpr int PL = HV * 32;
+  constexpr int UNITS = 2 * HV * 8, UP = (UNITS + 511) / 512;      // 512 threads: 5 staging units each (256 threads: 10, and spills)
+  constexpr int NTW = 7;                                 // taps per wave (the last wave's seventh is a duplicate that is never written)
+  const TA* const ax = reinterpret_cast<const TA*>(a.x);
+  const TA* const ady = reinterpret_cast<const TA*>(a.dy);
+  DYN_LDS(lds);
+  float* xs = lds;                                       // ring of 3 input planes, as the forward
+  float* dys = lds + 3 * PL;                             // two dy planes [parity of the output plane][voxel 32][co 32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6), half = lane >> 5, li = lane & 31;
+  int b = blockIdx.x;
+  const int zc = b % a.zchunks; b /= a.zchunks;
+  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+  const int n = b;
+  const int z_begin = zc * a.zper, z_end = z_begin + a.zper < a.Do ? z_begin + a.zper : a.Do;
+  const int iy0 = 2 * ty0 - 1, ix0 = 2 * tx0 - 1;
+
+  float4 st[UP], dst4;
+  unsigned goff[UP];                                     // (the LDS offset of a unit is recomputed at the commit: 112 accumulator registers live here)
+  unsigned okmask = 0, ppmask = 0;
+#pragma unroll
+  for (int k = 0; k < UP; ++k) {
+    int u = tid + k * 512; const bool live = u < UNITS; if (!live) u = UNITS - 1;
+    const int pp = u / (HV * 8), r = u % (HV * 8), hv = r >> 3, q = r & 7;
+    const int iy = iy0 + hv / HX, ix = ix0 + hv % HX;
+    const bool in = iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+    const int cy = iy < 0 ? 0 : (iy < a.Hi ? iy : a.Hi - 1), cx = ix < 0 ? 0 : (ix < a.Wi ? ix : a.Wi - 1);
+    goff[k] = (unsigned)((cy * a.Wi + cx) * a.xld + 4 * q);
+    okmask |= (unsigned)(in && live) << k;
+    ppmask |= (unsigned)pp << k;
+  }
+  const size_t xplane = (size_t)a.Hi * a.Wi * a.xld;
+  const TA* const xn = ax + (size_t)n * a.Di * xplane;
+  // dy plane: thread (of the first 256) = (voxel tid >> 3, channel quad tid & 7)
+  const int dv = (tid & 255) >> 3, dq = tid & 7;
+  const int doy = ty0 + (dv >> 3), dox = tx0 + (dv & 7);
+  const bool din = doy < a.Ho && dox < a.Wo;
+  const unsigned dgoff = (unsigned)(((din ? doy : 0) * a.Wo + (din ? dox : 0)) * a.dyld + 4 * dq);
+  const size_t dyplane = (size_t)a.Ho * a.Wo * a.dyld;
+  const TA* const dyn = ady + (size_t)n * a.Do * dyplane;
+  auto load_planes = [&](int p0, int zo) {               // input planes p0, p0 + 1 and the dy plane zo -> registers
+    const int z0 = p0 < 0 ? 0 : (p0 < a.Di ? p0 : a.Di - 1), z1 = p0 + 1 < 0 ? 0 : (p0 + 1 < a.Di ? p0 + 1 : a.Di - 1);
+    const TA* pA = xn + (size_t)z0 * xplane;
+    const TA* pB = xn + (size_t)z1 * xplane;
+#pragma unroll
+    for (int k = 0; k < UP; ++k) st[k] = ld4(((ppmask >> k) & 1u ? pB : pA) + goff[k]);
+    if (tid < 256) dst4 = ld4(dyn + (size_t)(zo < a.Do ? zo : a.Do - 1) * dyplane + dgoff);
+  };
+  auto commit_planes = [&](int p0, bool first_only) {
+    const bool zokA = p0 >= 0 && p0 < a.Di, zokB = p0 + 1 >= 0 && p0 + 1 < a.Di;
+    float* sA = xs + ((p0 + 3) % 3) * PL;
+    float* sB = xs + ((p0 + 4) % 3) * PL;
+#pragma unroll
+    for (int k = 0; k < UP; ++k) {
+      const int u = tid + k * 512;
+      const bool second = (ppmask >> k) & 1u;
+      if (u >= UNITS || (first_only && second)) continue;
+      const int r = u % (HV * 8);
+      const bool ok = ((okmask >> k) & 1u) && (second ? zokB : zokA);
+      *reinterpret_cast<float4*>((second ? sB : sA) + (r >> 3) * 32 + 4 * (r & 7)) = ok ? st[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit_dy = [&](int zo) {
+    if (tid < 256) *reinterpret_cast<float4*>(dys + (zo & 1) * 1024 + dv * 32 + 4 * dq) = (din && zo < a.Do) ? dst4 : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+
+  // wave = (tap group tg = w & 3: taps tg + 4 ti, K half kh = w >> 2: k-steps 8 kh .. 8 kh + 7 of the plane's 16); the taps' offsets inside a
+  // staged plane; B operand lane = ci, A operand lane = co
+  const int tg = wave & 3, kh = wave >> 2;
+  int tdz[NTW], toff[NTW];
+#pragma unroll
+  for (int ti = 0; ti < NTW; ++ti) {
+    int tap = tg + 4 * ti; if (tap > 26) tap = 26;
+    tdz[ti] = tap / 9;
+    toff[ti] = (((tap / 3) % 3) * HX + tap % 3) * 32 + li;
+  }
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int ti = 0; ti < NTW; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+
+  // ---- prologue: input planes 2 zb - 1, 2 zb, 2 zb + 1 and dy plane zb ----
+  load_planes(2 * z_begin - 1, z_begin); commit_planes(2 * z_begin - 1, false); commit_dy(z_begin);
+  load_planes(2 * z_begin + 1, z_begin); commit_planes(2 * z_begin + 1, true);
+  __syncthreads();
+
+  for (int zo = z_begin; zo < z_end; ++zo) {
+    load_planes(2 * zo + 2, zo + 1);                     // the next step's planes: in flight during the MFMAs
+    const float* pl[3] = {xs + ((2 * zo - 1 + 3) % 3) * PL, xs + ((2 * zo + 3) % 3) * PL, xs + ((2 * zo + 1 + 3) % 3) * PL};
+    const float* bp[NTW];
+#pragma unroll
+    for (int ti = 0; ti < NTW; ++ti) bp[ti] = pl[tdz[ti]] + toff[ti];
+    const float* ap = dys + (zo & 1) * 1024 + li;
+    // k-step ks: voxels 2 ks + half of the plane tile -> input voxel (2 (v >> 3), 2 (v & 7))
+    struct Ops { float a, b[NTW]; };
+    auto rd = [&](int ks, Ops& o) {
+      const int v = 2 * ks + half;
+      o.a = ap[v * 32];
+      const int xo = ((2 * (v >> 3)) * HX + 2 * (v & 7)) * 32;
+#pragma unroll
+      for (int ti = 0; ti < NTW; ++ti) o.b[ti] = bp[ti][xo];
+    };
+    Ops oa, ob;
+    rd(8 * kh, oa);
+    static_for<0, 8>([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      Ops& cur = (ks & 1) ? ob : oa;
+      Ops& nxt = (ks & 1) ? oa : ob;
+      if constexpr (ks + 1 < 8) rd(8 * kh + ks + 1, nxt);
+      SCHED_BARRIER();
+#pragma unroll
+      for (int ti = 0; ti < NTW; ++ti) acc[ti] = MFMA_32x32x2(cur.a, cur.b[ti], acc[ti]);
+      SCHED_BARRIER();
+    });
+    __syncthreads();                                     // every wave is done with the ring and this dy plane
+    commit_planes(2 * zo + 2, false);
+    commit_dy(zo + 1);
+    __syncthreads();
+  }
+
+  // ---- partial tiles: ws[slab = 2 workgroup + K half][tap][32 co][32 ci] ----
+#pragma unroll
+  for (int ti = 0; ti < NTW; ++ti) {
+    const int tap = tg + 4 * ti;
+    if (tap > 26) continue;
+    float* dst = a.ws + ((((size_t)blockIdx.x * 2 + kh) * 27 + tap) * 1024);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[ti][r];
+  }
+}
+
+static int s2_plan(const mi355_act* y, S2Args& a, int target = 512) {
   a.tilesY = ceil_div(y->h, 4); a.tilesX = ceil_div(y->w, 8);
   const long long cols = (long long)y->n * a.tilesY * a.tilesX;
   if (cols <= 0 || cols > 0x7fffffffLL) return 0;
-  int zch = (int)((512 + cols - 1) / cols);              // ~512 workgroups: two per CU, one round (1024: 0.332 -> measured below)
+  int zch = (int)((target + cols - 1) / cols);           // forward: ~512 workgroups, two per CU, one round (1024: 0.332 -> measured below)
   const int maxch = y->d >= 8 ? y->d / 8 : 1;            // >= 8 output planes per chunk (a chunk stages 3 planes before its first MFMA)
   if (zch > maxch) zch = maxch;
   if (zch < 1) zch = 1;
@@ -252,4 +402,41 @@ int mi355_conv3d_s2c32_fwd_impl(const mi355_act* x, const float* wp, const mi355
             else { SET_MAX_DYN_LDS((conv3d_s2c32_fwd<TA, false>), lds_bytes);
                    LAUNCH((conv3d_s2c32_fwd<TA, false>), dim3((unsigned)wgs), dim3(256), lds_bytes, stream, a); });
   return LAUNCH_CHECK();
+}
+
+int mi355_wgrad_reduce_launch(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles, void* stream);      // conv3d_wgrad.hip
+
+// the weight gradient of the same calls (x: input of the conv, dy: gradient of its output; plain input): MI355_S2_KERNEL=0 -> never
+int mi355_conv3d_s2c32_wgrad_ok(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  static const bool off = [] { const char* v = getenv("MI355_S2_KERNEL"); return v && v[0] == '0'; }();
+  if (off || !x || !dy || !d) return 0;
+  if (d->kd != 3 || d->stride != 2 || d->pad != 1 || x->c != 32 || dy->c != 32 || d->in_mode != MI355_IN_PLAIN || d->out_mode != MI355_OUT_PLAIN) return 0;
+  if (x->dtype != dy->dtype || !act_dtype_ok(x) || x->n != dy->n) return 0;
+  if (dy->d != (x->d - 1) / 2 + 1 || dy->h != (x->h - 1) / 2 + 1 || dy->w != (x->w - 1) / 2 + 1) return 0;
+  if (x->ld % 4 || dy->ld % 4 || ((uintptr_t)x->p & act_align_mask(x->dtype)) || ((uintptr_t)dy->p & act_align_mask(dy->dtype))) return 0;
+  return 1;
+}
+
+size_t mi355_conv3d_s2c32_wgrad_workspace(const mi355_act* dy) {
+  S2Args a; memset(&a, 0, sizeof(a));
+  if (!dy || !s2_plan(dy, a, 256)) return 0;              // one 8-wave workgroup per CU
+  return (size_t)dy->n * a.tilesY * a.tilesX * a.zchunks * 2 * 27 * 1024 * sizeof(float);
+}
+
+int mi355_conv3d_s2c32_wgrad_impl(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  if (!mi355_conv3d_s2c32_wgrad_ok(x, dy, d)) return MI355_EUNSUPPORTED;
+  S2Args pl; memset(&pl, 0, sizeof(pl));
+  if (!s2_plan(dy, pl, 256)) return MI355_EINVAL;
+  const long long wgs = (long long)dy->n * pl.tilesY * pl.tilesX * pl.zchunks;
+  if (ws_bytes < (size_t)wgs * 2 * 27 * 1024 * sizeof(float)) return MI355_EWORKSPACE;
+  S2WArgs a; memset(&a, 0, sizeof(a));
+  a.x = (const float*)x->p; a.xld = x->ld; a.dy = (const float*)dy->p; a.dyld = dy->ld; a.ws = (float*)ws;
+  a.N = x->n; a.Di = x->d; a.Hi = x->h; a.Wi = x->w; a.Do = dy->d; a.Ho = dy->h; a.Wo = dy->w;
+  a.tilesY = pl.tilesY; a.tilesX = pl.tilesX; a.zchunks = pl.zchunks; a.zper = pl.zper;
+  const int lds_bytes = (3 * 153 * 32 + 2 * 32 * 32) * (int)sizeof(float);      // 66 944 bytes; 8 waves of up to 256 registers: one workgroup per CU
+  ACT_TYPED(x->dtype, TA, SET_MAX_DYN_LDS((conv3d_s2c32_wgrad<TA>), lds_bytes);
+            LAUNCH((conv3d_s2c32_wgrad<TA>), dim3((unsigned)wgs), dim3(512), lds_bytes, stream, a));
+  const int rc = LAUNCH_CHECK(); if (rc) return rc;
+  return mi355_wgrad_reduce_launch((const float*)ws, dw, 32, 32, 27, (int)wgs * 2, 1, stream);
 }

@@ -442,6 +442,11 @@ int mi355_conv3d_c4_ok(const mi355_act* x, const mi355_conv_desc* d);
 size_t mi355_conv3d_c4_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d);
 int mi355_conv3d_c4_wgrad_impl(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d,
                                void* ws, size_t ws_bytes, void* stream);
+// conv3d_s2.hip: the z-marching 32 -> 32 channel stride-2 weight gradient
+int mi355_conv3d_s2c32_wgrad_ok(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d);
+size_t mi355_conv3d_s2c32_wgrad_workspace(const mi355_act* dy);
+int mi355_conv3d_s2c32_wgrad_impl(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d, void* ws, size_t ws_bytes,
+                                  void* stream);
 static int wgrad_uses_bf16(const mi355_conv_desc* d) {
   return d->precision != MI355_PREC_F32 && d->kd == 3 && d->stride == 1 && d->pad == 1 && d->out_mode == MI355_OUT_PLAIN &&
          (d->in_mode == MI355_IN_PLAIN || d->in_mode == MI355_IN_AFFINE_ACT);
@@ -516,6 +521,7 @@ extern "C" size_t mi355_conv3d_wgrad_workspace(const mi355_act* x, const mi355_a
   if (mi355_conv3d_c4_ok(x, d)) return mi355_conv3d_c4_wgrad_workspace(x, dy, d);
   if (d && wgrad_uses_bf16(d)) return mi355_conv3d_wgrad_bf16_workspace(x, dy, d);
   if (x && dy && d && wgrad_uses_ring(d)) { RingPlan r = plan_wgrad_ring(x, dy); return r.ok ? r.ws_bytes : 0; }
+  if (mi355_conv3d_s2c32_wgrad_ok(x, dy, d)) return mi355_conv3d_s2c32_wgrad_workspace(dy);
   WgradPlan p = plan_wgrad(x, dy, d);
   return p.ok ? p.ws_bytes : 0;
 }
@@ -545,6 +551,7 @@ extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float
   if (mi355_conv3d_c4_ok(x, d)) return mi355_conv3d_c4_wgrad_impl(x, dy, dw, d, ws, ws_bytes, stream);
   if (wgrad_uses_bf16(d)) return mi355_conv3d_wgrad_bf16_impl(x, dy, dw, d, ws, ws_bytes, stream);
   if (x->dtype != dy->dtype) return MI355_EUNSUPPORTED;       // (the first-layer kernel above takes fp32 x with either dy)
+  if (mi355_conv3d_s2c32_wgrad_ok(x, dy, d)) return mi355_conv3d_s2c32_wgrad_impl(x, dy, dw, d, ws, ws_bytes, stream);
   if (wgrad_uses_ring(d)) {
     if (x->dtype != MI355_ACT_F32) return MI355_EUNSUPPORTED;   // exact-fp32 3x3x3 arithmetic on 16-bit tensors: no kernel (and no caller)
     RingPlan r = plan_wgrad_ring(x, dy);

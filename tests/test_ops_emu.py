@@ -106,7 +106,8 @@ def test_transposed_conv_k3s2(emu_backend, kw):
     dict(n=2, cin=32, cout=32, dhw=(6, 7, 8)),
     dict(n=1, cin=4, cout=32, dhw=(8, 8, 8), norm=True),
     dict(n=1, cin=64, cout=96, dhw=(5, 5, 9), norm=True, slope=0.01),
-    dict(n=1, cin=32, cout=32, dhw=(9, 8, 12), stride=2),
+    dict(n=1, cin=32, cout=32, dhw=(9, 8, 12), stride=2),                      # conv3d_s2c32_wgrad
+    dict(n=2, cin=32, cout=32, dhw=(33, 7, 18), stride=2),                     # ... two z chunks per column, ragged tiles, odd extents
     dict(n=2, cin=64, cout=32, dhw=(5, 6, 7), kd=1),
 ])
 def test_conv_wgrad(emu_backend, kw):
