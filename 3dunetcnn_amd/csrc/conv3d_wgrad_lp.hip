@@ -1,0 +1,309 @@
+// 3x3x3 stride-1 conv3d weight gradient for 16-bit tensors (bf16 / fp16 storage with operands of the same type), gfx950:
+// a z-marching workgroup whose staging writes the tiles AS LOADED (channels-last, one 16-byte run of 8 channels per request) and whose
+// matrix operands come out of LDS already K-major through the transpose read ds_read_b64_tr_b16.
+//
+//   dw[co][ci][tap] = sum_{n,v} dy[n,v,co] * in(x)[n, v + tap - 1, ci]        (autograd of F.conv3d wrt the weight;
+//   reference layers: unet3d/models/pytorch/classification/resnet.py:12-22, input transform myronenko.py:18-19)
+//
+// What it replaces: conv3d_wgrad_k3_bf16 (conv3d_wgrad_bf16.hip) on 16-bit tensors. That kernel's producer waves transpose every 8-voxel x
+// 4-channel unit through registers (~200 vector instructions per unit) and one 64-voxel tile goes through a barrier per step: 0.17 of the bf16
+// matrix peak on the 32 -> 32 layers of the 128^3 level (1.1 ms per launch at batch 4, HBM floor 0.29 ms).
+//
+// Workgroup = 6 waves = (dz = 0..2) x (row half h = 0 / 1) on one (32 ci, 32 co) pair and one column of 8 x 16 output voxels, marching z:
+//   * ring of 4 input planes [10 rows][18 voxels][32 ci] + 2 dy planes [8 rows][16 voxels][32 co] in LDS, 64 bytes per voxel; every thread
+//     loads its units of the NEXT plane at the top of a step (in flight during the step's MFMAs), applies the fused norm + activation in
+//     channels-last form (8 fma + 8 mul/max + 4 packs per 16 bytes) and writes them at the step's end: one barrier per plane;
+//   * wave (dz, h) owns the 9 taps (dz, *, *) on output rows 4 h .. 4 h + 3: 144 accumulator registers. Per output row it reads ONE new input
+//     row (three transpose reads: 12 consecutive voxels per lane, the dx = 1 / 2 fragments are funnel shifts of them) and one dy row (two
+//     reads) for 9 MFMAs: 0.28 KB of LDS per v_mfma_f32_32x32x16 (the register-transposing kernel: 1 KB);
+//   * the transpose read: inside each group of 16 lanes the 16 addressed 8-byte rows form a 16 x 4 matrix of 16-bit elements and lane l
+//     receives column l & 3 of rows (l >> 2) + 4 j (profiles/r5_tr_read_probe.txt). Lane r of a group addresses voxel (r >> 2), channel
+//     block 4 (r & 3): lane l then holds channel (l & 15) of 4 consecutive voxels -- the operand layout of the MFMA (lane = row / column,
+//     8 consecutive k per lane and k-group) with two reads;
+//   * the two row halves are added through LDS at the end; partial tiles go to the slab workspace of conv3d_wgrad.hip and its
+//     deterministic reduction ([pair][slab = column chunk][tap][32 co][32 ci]).
+#include "gfx950_dialect.h"
+#include <cstdlib>
+#include "../../include/mi355_unet3d.h"
+#include "act_io.h"
+
+int mi355_wgrad_reduce_launch(const float* ws, float* dw, int Cout, int Cin, int T, int SL, int ciTiles, void* stream);
+
+// ds_read_b64_tr_b16 and its CPU twin for the emulated build (tools/emu: fibers, one per lane; the 16 row addresses travel by shuffle)
+#ifdef MI355_EMU
+static inline uint2 lds_read_tr16_b64(const unsigned char* p) {
+  const int l = emu::flat_tid() % 64, gb = l & ~15, a = (l & 15) >> 2, c = l & 3;
+  unsigned v[4];
+  for (int j = 0; j < 4; ++j) {
+    const unsigned char* row = emu_shfl(p, gb + a + 4 * j);
+    unsigned short e; memcpy(&e, row + 2 * c, 2); v[j] = e;
+  }
+  return make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+}
+#else
+__device__ __forceinline__ uint2 lds_read_tr16_b64(const unsigned char* p) {
+  typedef __attribute__((__vector_size__(4 * sizeof(short)))) short v4s;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  auto* q = (__attribute__((address_space(3))) v4s*)p;
+#pragma clang diagnostic pop
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(q));
+}
+#endif
+
+struct WgradTArgs {
+  const void* x; int xld;
+  const void* dy; int dyld;
+  float* ws;
+  const float* in_scale; const float* in_shift; float slope; const float* in_slope;
+  int N, D, H, W, Cin, Cout;
+  int tilesY, tilesX, zchunks, zper, ncol;      // column chunk = ((n * tilesY + ty) * tilesX + tx) * zchunks + zc
+  int ciTiles, coTiles;
+};
+
+template <int INMODE, typename TA>
+__global__ __launch_bounds__(384) void conv3d_wgrad_lp_tr(WgradTArgs a) {
+  constexpr bool F16 = std::is_same<TA, f16_t>::value;
+  constexpr int TY = 8, TX = 16, HY = TY + 2, HX = TX + 2;
+  constexpr int XPL = HY * HX * 64, DYPL = TY * TX * 64;          // bytes per staged plane
+  constexpr int NXU = HY * HX * 4, NDYU = TY * TX * 4, NT = 384;  // 16-byte units per plane: 720, 512
+  DYN_LDS(lds_f);
+  unsigned char* const xs = reinterpret_cast<unsigned char*>(lds_f);
+  unsigned char* const dys = xs + 4 * XPL;
+  const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6);
+  // workgroup -> (column chunk c, pair): the pairs of one column chunk sit on the same XCD (blockIdx % 8) next to each other in launch
+  // order, so that the tiles they share come out of that XCD's L2
+  const int P = a.ciTiles * a.coTiles;
+  const int b = blockIdx.x, grp = b / (8 * P), rem = b % (8 * P);
+  const int pair = rem >> 3, c = grp * 8 + (rem & 7);
+  if (c >= a.ncol) return;
+  const int cit = pair % a.ciTiles, cot = pair / a.ciTiles;
+  const int ci0 = cit * 32, co0 = cot * 32;
+  int cc = c;
+  const int zc = cc % a.zchunks; cc /= a.zchunks;
+  const int tx0 = (cc % a.tilesX) * TX; cc /= a.tilesX;
+  const int ty0 = (cc % a.tilesY) * TY;
+  const int n = cc / a.tilesY;
+  const int z0 = zc * a.zper, z1 = z0 + a.zper < a.D ? z0 + a.zper : a.D;
+
+  // ---- staging: per-thread constants of its (at most) two input and two dy units ----
+  const int q8 = tid & 3;                                          // the thread's channel octet (both of its units: 384 % 4 == 0)
+  unsigned xgoff[2], xloff[2], dgoff[2], dloff[2], okx = 0, okd = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int u = tid + NT * k; const bool live = u < NXU; if (!live) u = NXU - 1;
+    const int hv = u >> 2, hy = hv / HX, hx = hv % HX;
+    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+    const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const int cy = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1), cx = ix < 0 ? 0 : (ix < a.W ? ix : a.W - 1);
+    xgoff[k] = (unsigned)((cy * a.W + cx) * a.xld + ci0 + 8 * q8);
+    xloff[k] = (unsigned)(hv * 64 + 16 * q8);
+    okx |= (unsigned)(in && live) << k; okx |= (unsigned)live << (2 + k);
+    int v = tid + NT * k; const bool dlive = v < NDYU; if (!dlive) v = NDYU - 1;
+    const int dv = v >> 2, oy = ty0 + (dv >> 4), ox = tx0 + (dv & 15);
+    const bool din = oy < a.H && ox < a.W;
+    dgoff[k] = (unsigned)(((din ? oy : 0) * a.W + (din ? ox : 0)) * a.dyld + co0 + 8 * q8);
+    dloff[k] = (unsigned)(dv * 64 + 16 * q8);
+    okd |= (unsigned)(din && dlive) << k; okd |= (unsigned)dlive << (2 + k);
+  }
+  const size_t xplane = (size_t)a.H * a.W * a.xld, dyplane = (size_t)a.H * a.W * a.dyld;
+  const TA* const xn = reinterpret_cast<const TA*>(a.x) + (size_t)n * a.D * xplane;
+  const TA* const dyn = reinterpret_cast<const TA*>(a.dy) + (size_t)n * a.D * dyplane;
+  float sc[8], sh[8];
+  if (INMODE == MI355_IN_AFFINE_ACT) {
+    const float* ps = a.in_scale + (size_t)n * a.Cin + ci0 + 8 * q8;
+    const float* ph = a.in_shift + (size_t)n * a.Cin + ci0 + 8 * q8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = ps[e]; sh[e] = ph[e]; }
+  }
+  auto ld16 = [](const TA* p) { return *reinterpret_cast<const uint4*>(p); };
+  auto load_x = [&](uint4 (&r)[2], int p) {                        // input plane p (clamped: the out-of-volume planes are zeroed at the commit)
+    const TA* pl = xn + (size_t)(p < 0 ? 0 : (p < a.D ? p : a.D - 1)) * xplane;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) r[k] = ld16(pl + xgoff[k]);
+  };
+  auto load_dy = [&](uint4 (&r)[2], int p) {
+    const TA* pl = dyn + (size_t)(p < a.D ? p : a.D - 1) * dyplane;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) r[k] = ld16(pl + dgoff[k]);
+  };
+  auto commit_x = [&](const uint4 (&r)[2], int p) {
+    const bool zok = p >= 0 && p < a.D;
+    unsigned char* dstp = xs + (p & 3) * XPL;                      // (-1 & 3 == 3)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (!((okx >> (2 + k)) & 1u)) continue;
+      unsigned w[4] = {r[k].x, r[k].y, r[k].z, r[k].w};
+      if (INMODE == MI355_IN_AFFINE_ACT) {
+        float sl[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sl[e] = a.slope;
+        if (a.in_slope) {                                          // (rare: per-channel slopes of a concatenated input)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sl[e] = a.in_slope[ci0 + 8 * q8 + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float lo = lp_lo<TA>(w[e]) * sc[2 * e] + sh[2 * e], hi = lp_hi<TA>(w[e]) * sc[2 * e + 1] + sh[2 * e + 1];
+          lo = fmaxf(lo, lo * sl[2 * e]); hi = fmaxf(hi, hi * sl[2 * e + 1]);
+          w[e] = lp_pack2<TA>(lo, hi);
+        }
+      }
+      const bool ok = ((okx >> k) & 1u) && zok;
+      *reinterpret_cast<uint4*>(dstp + xloff[k]) = ok ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto commit_dy = [&](const uint4 (&r)[2], int p) {
+    unsigned char* dstp = dys + (p & 1) * DYPL;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (!((okd >> (2 + k)) & 1u)) continue;
+      const bool ok = ((okd >> k) & 1u) && p < a.D;
+      *reinterpret_cast<uint4*>(dstp + dloff[k]) = ok ? r[k] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+
+  // ---- consumers' constants: wave = (dz, h); lane = 16 g + r: rows / columns 16 (g & 1) + (l & 15) of the operand, k-group g >> 1 ----
+  const int dz = wave % 3, h = wave / 3;
+  const int g = lane >> 4, r16 = lane & 15, half = lane >> 5, li = lane & 31;
+  const unsigned lb = (unsigned)((8 * (g >> 1) + (r16 >> 2)) * 64 + 32 * (g & 1) + 8 * (r16 & 3));
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // ---- prologue: input planes z0 - 1, z0, z0 + 1 and dy plane z0 ----
+  {
+    uint4 p0[2], p1[2], p2[2], pd[2];
+    load_x(p0, z0 - 1); load_x(p1, z0); load_x(p2, z0 + 1); load_dy(pd, z0);
+    commit_x(p0, z0 - 1); commit_x(p1, z0); commit_x(p2, z0 + 1); commit_dy(pd, z0);
+  }
+  __syncthreads();
+
+  for (int z = z0; z < z1; ++z) {
+    uint4 nx[2], nd[2];
+    load_x(nx, z + 2); load_dy(nd, z + 1);                         // the next step's planes: in flight during the MFMAs
+    const unsigned char* bp = xs + ((z - 1 + dz) & 3) * XPL + lb + (4 * h) * (HX * 64);
+    const unsigned char* ap = dys + (z & 1) * DYPL + lb + (4 * h) * (TX * 64);
+    // input row rr of the wave's six: voxels 8 kg + 0 .. 9 of the row as 5 dwords; dy row r: voxels 8 kg + 0 .. 7
+    unsigned B[6][5]; uint4 A[4];
+    auto rdB = [&](int rr) {
+      const uint2 v0 = lds_read_tr16_b64(bp + rr * (HX * 64)), v1 = lds_read_tr16_b64(bp + rr * (HX * 64) + 256),
+                  v2 = lds_read_tr16_b64(bp + rr * (HX * 64) + 512);
+      B[rr][0] = v0.x; B[rr][1] = v0.y; B[rr][2] = v1.x; B[rr][3] = v1.y; B[rr][4] = v2.x;
+    };
+    auto rdA = [&](int r) {
+      const uint2 v0 = lds_read_tr16_b64(ap + r * (TX * 64)), v1 = lds_read_tr16_b64(ap + r * (TX * 64) + 256);
+      A[r] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+    };
+    rdB(0); rdB(1); rdB(2); rdA(0);
+    static_for<0, 4>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      if constexpr (r < 3) { rdB(r + 3); rdA(r + 1); }
+      SCHED_BARRIER();
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const unsigned* bb = B[r + dy];
+        const uint4 f0 = make_uint4(bb[0], bb[1], bb[2], bb[3]);
+        const uint4 f1 = make_uint4((bb[0] >> 16) | (bb[1] << 16), (bb[1] >> 16) | (bb[2] << 16), (bb[2] >> 16) | (bb[3] << 16), (bb[3] >> 16) | (bb[4] << 16));
+        const uint4 f2 = make_uint4(bb[1], bb[2], bb[3], bb[4]);
+        acc[dy * 3 + 0] = mfma_lp<F16>(A[r], f0, acc[dy * 3 + 0]);
+        acc[dy * 3 + 1] = mfma_lp<F16>(A[r], f1, acc[dy * 3 + 1]);
+        acc[dy * 3 + 2] = mfma_lp<F16>(A[r], f2, acc[dy * 3 + 2]);
+      }
+      SCHED_BARRIER();
+    });
+    commit_x(nx, z + 2); commit_dy(nd, z + 1);                     // slots last read in the previous step (closed by its barrier)
+    __syncthreads();
+  }
+
+  // ---- the two row halves through LDS, then the partial tiles: ws[pair][slab = column chunk][tap][32 co][32 ci] ----
+  float* ex = lds_f;                                               // [dz][tap 9][r 16][lane 64]
+  if (h == 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ex[((dz * 9 + t) * 16 + r) * 64 + lane] = acc[t][r];
+  }
+  __syncthreads();
+  if (h == 0) {
+    const size_t pairi = (size_t)cot * a.ciTiles + cit;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float* dst = a.ws + (((pairi * a.ncol + c) * 27 + dz * 9 + t) * 1024);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[t][r] + ex[((dz * 9 + t) * 16 + r) * 64 + lane];
+    }
+  }
+}
+
+struct WTPlan { int tilesY, tilesX, zchunks, zper, ncol, ciTiles, coTiles, ok; size_t ws_bytes; };
+
+// the calls this kernel takes: 16-bit tensors with operands of their own type (MI355_PREC_BF16 on bf16 tensors, MI355_PREC_F16 on fp16
+// tensors), 3x3x3 stride 1 pad 1, plain or normalised + activated input, plain output, channel counts in multiples of 32, 16-byte
+// aligned voxels, at least one full 8 x 16 tile per plane. MI355_WGRAD_LP_TR=0 (read once): never -- the A/B switch.
+static WTPlan plan_wt(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  WTPlan p; memset(&p, 0, sizeof(p));
+  static const bool off = [] { const char* v = getenv("MI355_WGRAD_LP_TR"); return v && v[0] == '0'; }();
+  if (off || !x || !dy || !d) return p;
+  if (d->kd != 3 || d->stride != 1 || d->pad != 1 || d->out_mode != MI355_OUT_PLAIN) return p;
+  if (d->in_mode != MI355_IN_PLAIN && d->in_mode != MI355_IN_AFFINE_ACT) return p;
+  if (d->precision != MI355_PREC_BF16 && d->precision != MI355_PREC_F16) return p;
+  if (!act_is_lp16(x->dtype) || x->dtype != dy->dtype || !act_matches_precision(x->dtype, d->precision)) return p;
+  if (x->n != dy->n || x->d != dy->d || x->h != dy->h || x->w != dy->w) return p;
+  if (x->c % 32 || dy->c % 32 || x->ld % 8 || dy->ld % 8 || ((uintptr_t)x->p & 15) || ((uintptr_t)dy->p & 15)) return p;
+  if (x->h < 8 || x->w < 16) return p;
+  if ((long long)x->h * x->w * x->ld > 0x7fffffffLL || (long long)dy->h * dy->w * dy->ld > 0x7fffffffLL) return p;
+  p.tilesY = ceil_div(x->h, 8); p.tilesX = ceil_div(x->w, 16);
+  p.ciTiles = x->c / 32; p.coTiles = dy->c / 32;
+  const long long cols = (long long)x->n * p.tilesY * p.tilesX, pairs = (long long)p.ciTiles * p.coTiles;
+  if (cols <= 0 || cols * pairs > 0x3fffffffLL) return p;
+  int zch = (int)((256 + cols * pairs - 1) / (cols * pairs));      // one 6-wave workgroup per CU: at least one round of the chip
+  const int maxch = x->d >= 8 ? x->d / 8 : 1;                      // >= 8 planes per chunk (a chunk stages 3 planes before its first MFMA)
+  if (zch > maxch) zch = maxch;
+  if (zch < 1) zch = 1;
+  p.zper = ceil_div(x->d, zch);
+  p.zchunks = ceil_div(x->d, p.zper);
+  if (cols * p.zchunks * pairs > 0x3fffffffLL) return p;
+  p.ncol = (int)(cols * p.zchunks);
+  p.ws_bytes = (size_t)pairs * p.ncol * 27 * 1024 * sizeof(float);
+  p.ok = 1;
+  return p;
+}
+
+int mi355_conv3d_wgrad_lp_tr_ok(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) { return plan_wt(x, dy, d).ok; }
+
+size_t mi355_conv3d_wgrad_lp_tr_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  const WTPlan p = plan_wt(x, dy, d);
+  return p.ok ? p.ws_bytes : 0;
+}
+
+template <int INMODE, typename TA>
+static int launch_wt(const WgradTArgs& a, unsigned grid, void* stream) {
+  constexpr int lds = 3 * 9 * 16 * 64 * 4;                         // the final exchange (110 592 bytes) > ring + dy planes (62 464)
+  static_assert(lds >= 4 * 10 * 18 * 64 + 2 * 8 * 16 * 64 + 256, "LDS");
+  SET_MAX_DYN_LDS((conv3d_wgrad_lp_tr<INMODE, TA>), lds);
+  LAUNCH((conv3d_wgrad_lp_tr<INMODE, TA>), dim3(grid), dim3(384), lds, stream, a);
+  return LAUNCH_CHECK();
+}
+
+int mi355_conv3d_wgrad_lp_tr_impl(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  const WTPlan p = plan_wt(x, dy, d);
+  if (!p.ok) return MI355_EUNSUPPORTED;
+  if (ws_bytes < p.ws_bytes) return MI355_EWORKSPACE;
+  if (d->in_mode == MI355_IN_AFFINE_ACT && (!d->in_scale || !d->in_shift)) return MI355_EINVAL;
+  WgradTArgs a; memset(&a, 0, sizeof(a));
+  a.x = x->p; a.xld = x->ld; a.dy = dy->p; a.dyld = dy->ld; a.ws = (float*)ws;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope;
+  a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Cout = dy->c;
+  a.tilesY = p.tilesY; a.tilesX = p.tilesX; a.zchunks = p.zchunks; a.zper = p.zper; a.ncol = p.ncol;
+  a.ciTiles = p.ciTiles; a.coTiles = p.coTiles;
+  const unsigned grid = (unsigned)(ceil_div(p.ncol, 8) * 8 * p.ciTiles * p.coTiles);
+  int rc;
+  if (x->dtype == MI355_ACT_BF16) rc = d->in_mode == MI355_IN_PLAIN ? launch_wt<MI355_IN_PLAIN, bf16_t>(a, grid, stream) : launch_wt<MI355_IN_AFFINE_ACT, bf16_t>(a, grid, stream);
+  else rc = d->in_mode == MI355_IN_PLAIN ? launch_wt<MI355_IN_PLAIN, f16_t>(a, grid, stream) : launch_wt<MI355_IN_AFFINE_ACT, f16_t>(a, grid, stream);
+  if (rc) return rc;
+  return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, p.ncol, p.ciTiles, stream);
+}

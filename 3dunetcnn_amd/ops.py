@@ -541,7 +541,10 @@ class Backend:
             c4 = x.c == 4 and kd == 3 and stride == 1 and pad == 1 and in_mode in (IN_PLAIN, IN_AFFINE_ACT) and out_mode == OUT_PLAIN
             s2 = (kd == 3 and stride == 2 and pad == 1 and x.c == 32 and dy.c == 32 and in_mode == IN_PLAIN and out_mode == OUT_PLAIN
                   and os.environ.get("MI355_S2_KERNEL", "1") != "0")
-            self._prof_add("conv3d_c4_wgrad (+reduce)" if c4 else "conv3d_s2c32_wgrad (+reduce)" if s2 else "conv3d_wgrad_k3_bf16<...> (+reduce)" if bf
+            tr = (bf and x.buf.element_size() == 2 and x.c % 32 == 0 and dy.c % 32 == 0 and x.shape[2] >= 8 and x.shape[3] >= 16
+                  and os.environ.get("MI355_WGRAD_LP_TR", "1") != "0")      # (plan_wt in csrc/conv3d_wgrad_lp.hip decides; this is the label)
+            self._prof_add("conv3d_c4_wgrad (+reduce)" if c4 else "conv3d_s2c32_wgrad (+reduce)" if s2 else "conv3d_wgrad_lp_tr (+reduce)" if tr
+                           else "conv3d_wgrad_k3_bf16<...> (+reduce)" if bf
                            else "conv3d_wgrad_ring (+reduce)" if (kd == 3 and stride == 1 and pad == 1 and out_mode == OUT_PLAIN)
                            else f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1)
 

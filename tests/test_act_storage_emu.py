@@ -97,6 +97,9 @@ def test_first_layer(bf16_backend):
     dict(kd=3, stride=2, cin=32, cout=32, dhw=(9, 8, 11), n=2),
     dict(kd=3, stride=1, cin=32, cout=32, dhw=(5, 6, 18), norm=True),                  # 16-bit-operand weight gradient
     dict(kd=3, stride=1, cin=32, cout=96, dhw=(3, 4, 17), norm=True),                  # ... its 64-channel workgroup form
+    dict(kd=3, stride=1, cin=32, cout=32, dhw=(5, 9, 18), norm=True),                  # conv3d_wgrad_lp_tr (H >= 8, W >= 16): ragged tiles in y and x
+    dict(kd=3, stride=1, cin=64, cout=32, dhw=(17, 8, 16), n=2),                       # ... plain input, two (ci, co) pairs, two z chunks per column
+    dict(kd=3, stride=1, cin=32, cout=64, dhw=(3, 11, 35), norm=True, n=2),            # ... fewer planes than the ring holds
 ])
 def test_weight_gradients(bf16_backend, kw):
     _all_below(S.case_wgrad(bf16_backend, **kw), dw=1e-5)
@@ -174,6 +177,7 @@ def test_fp16_first_layer_and_weight_gradients(fp16_backend):
     _all_below(S.case_wgrad(fp16_backend, kd=3, stride=2, cin=32, cout=32, dhw=(9, 8, 11), n=2), dw=1e-5)
     _all_below(S.case_wgrad(fp16_backend, kd=3, stride=1, cin=32, cout=32, dhw=(5, 6, 18), norm=True), dw=1e-5)
     _all_below(S.case_wgrad(fp16_backend, kd=3, stride=1, cin=32, cout=96, dhw=(3, 4, 17), norm=True), dw=1e-5)
+    _all_below(S.case_wgrad(fp16_backend, kd=3, stride=1, cin=32, cout=32, dhw=(4, 10, 19), norm=True), dw=1e-5)      # conv3d_wgrad_lp_tr
 
 
 def test_fp16_storage_goes_with_fp16_operands_only(emu_backend):

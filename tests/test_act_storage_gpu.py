@@ -104,6 +104,7 @@ def test_first_layer(bf16_backend, dhw):
     dict(kd=3, stride=1, cin=32, cout=32, dhw=(16, 32, 32), norm=True, n=2),           # 16-bit-operand weight gradient
     dict(kd=3, stride=1, cin=64, cout=96, dhw=(9, 15, 19), norm=True),                 # ... its 64-channel workgroup form, ragged
     dict(kd=3, stride=1, cin=256, cout=256, dhw=(8, 8, 16)),
+    dict(kd=3, stride=1, cin=32, cout=64, dhw=(19, 21, 37), norm=True, n=2),           # conv3d_wgrad_lp_tr: z chunks, ragged tiles (the three above run it too)
 ])
 def test_weight_gradients(bf16_backend, kw):
     _all_below(S.case_wgrad(bf16_backend, **kw), dw=1e-5)

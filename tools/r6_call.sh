@@ -1,7 +1,8 @@
 #!/bin/bash
 # scratch per-call script (GPU box)
-mkdir -p gpurun_out/s2w
-python tools/bench_stride2.py > gpurun_out/s2w/new.txt 2>&1
-MI355_S2_KERNEL=0 python tools/bench_stride2.py > gpurun_out/s2w/old.txt 2>&1
-python -m pytest tests/test_ops_gpu.py tests/test_act_storage_gpu.py -q -x -k "wgrad or stride" > gpurun_out/s2w/pytest.txt 2>&1
-tail -3 gpurun_out/s2w/pytest.txt; cat gpurun_out/s2w/new.txt gpurun_out/s2w/old.txt
+mkdir -p gpurun_out/wlp
+python -m pytest tests/test_act_storage_gpu.py -q -x -k "weight_gradients or fp16" > gpurun_out/wlp/pytest.txt 2>&1
+tail -3 gpurun_out/wlp/pytest.txt
+python tools/bench_wgrad_lp.py > gpurun_out/wlp/new.txt 2>&1
+MI355_WGRAD_LP_TR=0 python tools/bench_wgrad_lp.py > gpurun_out/wlp/old.txt 2>&1
+cat gpurun_out/wlp/new.txt gpurun_out/wlp/old.txt
