@@ -9,10 +9,13 @@
 // 4-channel unit through registers (~200 vector instructions per unit) and one 64-voxel tile goes through a barrier per step: 0.17 of the bf16
 // matrix peak on the 32 -> 32 layers of the 128^3 level (1.1 ms per launch at batch 4, HBM floor 0.29 ms).
 //
-// Workgroup = 6 waves = (dz = 0..2) x (row half h = 0 / 1) on one (32 ci, 32 co) pair and one column of 8 x 16 output voxels, marching z:
-//   * ring of 4 input planes [10 rows][18 voxels][32 ci] + 2 dy planes [8 rows][16 voxels][32 co] in LDS, 64 bytes per voxel; every thread
-//     loads its units of the NEXT plane at the top of a step (in flight during the step's MFMAs), applies the fused norm + activation in
-//     channels-last form (8 fma + 8 mul/max + 4 packs per 16 bytes) and writes them at the step's end: one barrier per plane;
+// Workgroup = 6 matrix waves = (dz = 0..2) x (row half h = 0 / 1) + 2 staging waves, on one (32 ci, 32 co) pair and one column of 8 x 16
+// output voxels, marching z:
+//   * ring of 4 input planes [10 rows][18 voxels][32 ci] + 2 dy planes [8 rows][16 voxels][32 co] in LDS, 64 bytes per voxel; the staging
+//     waves request the planes TWO steps ahead (two register sets), apply the fused norm + activation in channels-last form (8 fma + 8
+//     mul/max + 4 packs per 16 bytes) and write them a step ahead: one barrier per plane. Eight waves = two per SIMD: SIMDs 0 and 1 carry two
+//     matrix waves, SIMDs 2 and 3 one matrix wave and one staging wave (a wave's own vector instructions add to its MFMA time, another
+//     wave's do not: profiles/r4_mfma_valu_overlap.txt);
 //   * wave (dz, h) owns the 9 taps (dz, *, *) on output rows 4 h .. 4 h + 3: 144 accumulator registers. Per output row it reads ONE new input
 //     row (three transpose reads: 12 consecutive voxels per lane, the dx = 1 / 2 fragments are funnel shifts of them) and one dy row (two
 //     reads) for 9 MFMAs: 0.28 KB of LDS per v_mfma_f32_32x32x16 (the register-transposing kernel: 1 KB);
@@ -62,11 +65,13 @@ struct WgradTArgs {
 };
 
 template <int INMODE, typename TA>
-__global__ __launch_bounds__(384) void conv3d_wgrad_lp_tr(WgradTArgs a) {
+__global__ __launch_bounds__(512) void conv3d_wgrad_lp_tr(WgradTArgs a) {
   constexpr bool F16 = std::is_same<TA, f16_t>::value;
   constexpr int TY = 8, TX = 16, HY = TY + 2, HX = TX + 2;
   constexpr int XPL = HY * HX * 64, DYPL = TY * TX * 64;          // bytes per staged plane
-  constexpr int NXU = HY * HX * 4, NDYU = TY * TX * 4, NT = 384;  // 16-byte units per plane: 720, 512
+  constexpr int NP = 128;                                         // staging threads (waves 6, 7)
+  constexpr int NXU = HY * HX * 4, NDYU = TY * TX * 4;            // 16-byte units per plane: 720, 512
+  constexpr int UX = (NXU + NP - 1) / NP, UD = NDYU / NP;         // per staging thread: 6 input units, 4 dy units
   DYN_LDS(lds_f);
   unsigned char* const xs = reinterpret_cast<unsigned char*>(lds_f);
   unsigned char* const dys = xs + 4 * XPL;
@@ -86,84 +91,109 @@ __global__ __launch_bounds__(384) void conv3d_wgrad_lp_tr(WgradTArgs a) {
   const int n = cc / a.tilesY;
   const int z0 = zc * a.zper, z1 = z0 + a.zper < a.D ? z0 + a.zper : a.D;
 
-  // ---- staging: per-thread constants of its (at most) two input and two dy units ----
-  const int q8 = tid & 3;                                          // the thread's channel octet (both of its units: 384 % 4 == 0)
-  unsigned xgoff[2], xloff[2], dgoff[2], dloff[2], okx = 0, okd = 0;
+  if (wave >= 6) {
+    // ================================ the two staging waves ================================
+    // (waves 6, 7 share SIMDs 2, 3 with one matrix wave each; SIMDs 0, 1 carry two matrix waves: the staging arithmetic fills the lighter pair)
+    const int pt = tid - 384, q8 = pt & 3;                         // the thread's channel octet (all of its units: 128 % 4 == 0)
+    unsigned xgoff[UX], dgoff[UD], okx = 0, okd = 0;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    int u = tid + NT * k; const bool live = u < NXU; if (!live) u = NXU - 1;
-    const int hv = u >> 2, hy = hv / HX, hx = hv % HX;
-    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-    const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    const int cy = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1), cx = ix < 0 ? 0 : (ix < a.W ? ix : a.W - 1);
-    xgoff[k] = (unsigned)((cy * a.W + cx) * a.xld + ci0 + 8 * q8);
-    xloff[k] = (unsigned)(hv * 64 + 16 * q8);
-    okx |= (unsigned)(in && live) << k; okx |= (unsigned)live << (2 + k);
-    int v = tid + NT * k; const bool dlive = v < NDYU; if (!dlive) v = NDYU - 1;
-    const int dv = v >> 2, oy = ty0 + (dv >> 4), ox = tx0 + (dv & 15);
-    const bool din = oy < a.H && ox < a.W;
-    dgoff[k] = (unsigned)(((din ? oy : 0) * a.W + (din ? ox : 0)) * a.dyld + co0 + 8 * q8);
-    dloff[k] = (unsigned)(dv * 64 + 16 * q8);
-    okd |= (unsigned)(din && dlive) << k; okd |= (unsigned)dlive << (2 + k);
-  }
-  const size_t xplane = (size_t)a.H * a.W * a.xld, dyplane = (size_t)a.H * a.W * a.dyld;
-  const TA* const xn = reinterpret_cast<const TA*>(a.x) + (size_t)n * a.D * xplane;
-  const TA* const dyn = reinterpret_cast<const TA*>(a.dy) + (size_t)n * a.D * dyplane;
-  float sc[8], sh[8];
-  if (INMODE == MI355_IN_AFFINE_ACT) {
-    const float* ps = a.in_scale + (size_t)n * a.Cin + ci0 + 8 * q8;
-    const float* ph = a.in_shift + (size_t)n * a.Cin + ci0 + 8 * q8;
+    for (int k = 0; k < UX; ++k) {
+      int u = pt + NP * k; const bool live = u < NXU; if (!live) u = NXU - 1;
+      const int hv = u >> 2, hy = hv / HX, hx = hv % HX;
+      const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+      const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const int cy = iy < 0 ? 0 : (iy < a.H ? iy : a.H - 1), cx = ix < 0 ? 0 : (ix < a.W ? ix : a.W - 1);
+      xgoff[k] = (unsigned)((cy * a.W + cx) * a.xld + ci0 + 8 * q8);
+      okx |= (unsigned)(in && live) << k;
+    }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = ps[e]; sh[e] = ph[e]; }
-  }
-  auto ld16 = [](const TA* p) { return *reinterpret_cast<const uint4*>(p); };
-  auto load_x = [&](uint4 (&r)[2], int p) {                        // input plane p (clamped: the out-of-volume planes are zeroed at the commit)
-    const TA* pl = xn + (size_t)(p < 0 ? 0 : (p < a.D ? p : a.D - 1)) * xplane;
+    for (int k = 0; k < UD; ++k) {
+      const int dv = (pt + NP * k) >> 2, oy = ty0 + (dv >> 4), ox = tx0 + (dv & 15);
+      const bool din = oy < a.H && ox < a.W;
+      dgoff[k] = (unsigned)(((din ? oy : 0) * a.W + (din ? ox : 0)) * a.dyld + co0 + 8 * q8);
+      okd |= (unsigned)din << k;
+    }
+    const unsigned loff = (unsigned)(pt * 16);                     // unit u = pt + 128 k sits at byte 16 u of its plane: 64 (u >> 2) + 16 (u & 3)
+    const size_t xplane = (size_t)a.H * a.W * a.xld, dyplane = (size_t)a.H * a.W * a.dyld;
+    const TA* const xn = reinterpret_cast<const TA*>(a.x) + (size_t)n * a.D * xplane;
+    const TA* const dyn = reinterpret_cast<const TA*>(a.dy) + (size_t)n * a.D * dyplane;
+    float sc[8], sh[8], sl[8];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) r[k] = ld16(pl + xgoff[k]);
-  };
-  auto load_dy = [&](uint4 (&r)[2], int p) {
-    const TA* pl = dyn + (size_t)(p < a.D ? p : a.D - 1) * dyplane;
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; sl[e] = a.slope; }
+    if (INMODE == MI355_IN_AFFINE_ACT) {
+      const float* ps = a.in_scale + (size_t)n * a.Cin + ci0 + 8 * q8;
+      const float* ph = a.in_shift + (size_t)n * a.Cin + ci0 + 8 * q8;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) r[k] = ld16(pl + dgoff[k]);
-  };
-  auto commit_x = [&](const uint4 (&r)[2], int p) {
-    const bool zok = p >= 0 && p < a.D;
-    unsigned char* dstp = xs + (p & 3) * XPL;                      // (-1 & 3 == 3)
+      for (int e = 0; e < 8; ++e) { sc[e] = ps[e]; sh[e] = ph[e]; }
+      if (a.in_slope) {                                            // (rare: per-channel slopes of a concatenated input)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (!((okx >> (2 + k)) & 1u)) continue;
-      unsigned w[4] = {r[k].x, r[k].y, r[k].z, r[k].w};
-      if (INMODE == MI355_IN_AFFINE_ACT) {
-        float sl[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sl[e] = a.slope;
-        if (a.in_slope) {                                          // (rare: per-channel slopes of a concatenated input)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) sl[e] = a.in_slope[ci0 + 8 * q8 + e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float lo = lp_lo<TA>(w[e]) * sc[2 * e] + sh[2 * e], hi = lp_hi<TA>(w[e]) * sc[2 * e + 1] + sh[2 * e + 1];
-          lo = fmaxf(lo, lo * sl[2 * e]); hi = fmaxf(hi, hi * sl[2 * e + 1]);
-          w[e] = lp_pack2<TA>(lo, hi);
-        }
+        for (int e = 0; e < 8; ++e) sl[e] = a.in_slope[ci0 + 8 * q8 + e];
       }
-      const bool ok = ((okx >> k) & 1u) && zok;
-      *reinterpret_cast<uint4*>(dstp + xloff[k]) = ok ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
     }
-  };
-  auto commit_dy = [&](const uint4 (&r)[2], int p) {
-    unsigned char* dstp = dys + (p & 1) * DYPL;
+    auto ld16 = [](const TA* p) { return *reinterpret_cast<const uint4*>(p); };
+    auto load_x = [&](uint4 (&r)[UX], int p) {                     // input plane p (clamped: the out-of-volume planes are zeroed at the commit)
+      const TA* pl = xn + (size_t)(p < 0 ? 0 : (p < a.D ? p : a.D - 1)) * xplane;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (!((okd >> (2 + k)) & 1u)) continue;
-      const bool ok = ((okd >> k) & 1u) && p < a.D;
-      *reinterpret_cast<uint4*>(dstp + dloff[k]) = ok ? r[k] : make_uint4(0u, 0u, 0u, 0u);
+      for (int k = 0; k < UX; ++k) r[k] = ld16(pl + xgoff[k]);
+    };
+    auto load_dy = [&](uint4 (&r)[UD], int p) {
+      const TA* pl = dyn + (size_t)(p < a.D ? p : a.D - 1) * dyplane;
+#pragma unroll
+      for (int k = 0; k < UD; ++k) r[k] = ld16(pl + dgoff[k]);
+    };
+    auto commit_x = [&](const uint4 (&r)[UX], int p) {
+      const bool zok = p >= 0 && p < a.D;
+      unsigned char* dstp = xs + (p & 3) * XPL + loff;             // (-1 & 3 == 3)
+#pragma unroll
+      for (int k = 0; k < UX; ++k) {
+        if (pt + NP * k >= NXU) continue;
+        unsigned w[4] = {r[k].x, r[k].y, r[k].z, r[k].w};
+        if (INMODE == MI355_IN_AFFINE_ACT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float lo = lp_lo<TA>(w[e]) * sc[2 * e] + sh[2 * e], hi = lp_hi<TA>(w[e]) * sc[2 * e + 1] + sh[2 * e + 1];
+            lo = fmaxf(lo, lo * sl[2 * e]); hi = fmaxf(hi, hi * sl[2 * e + 1]);
+            w[e] = lp_pack2<TA>(lo, hi);
+          }
+        }
+        const bool ok = ((okx >> k) & 1u) && zok;
+        *reinterpret_cast<uint4*>(dstp + k * (NP * 16)) = ok ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    };
+    auto commit_dy = [&](const uint4 (&r)[UD], int p) {
+      unsigned char* dstp = dys + (p & 1) * DYPL + loff;
+#pragma unroll
+      for (int k = 0; k < UD; ++k) {
+        const bool ok = ((okd >> k) & 1u) && p < a.D;
+        *reinterpret_cast<uint4*>(dstp + k * (NP * 16)) = ok ? r[k] : make_uint4(0u, 0u, 0u, 0u);
+      }
+    };
+    // prologue: input planes z0 - 1, z0, z0 + 1 and dy plane z0
+    {
+      uint4 p0[UX], p1[UX], p2[UX], pd[UD];
+      load_x(p0, z0 - 1); load_x(p1, z0); load_x(p2, z0 + 1); load_dy(pd, z0);
+      commit_x(p0, z0 - 1); commit_x(p1, z0); commit_x(p2, z0 + 1); commit_dy(pd, z0);
     }
-  };
+    __syncthreads();
+    // steady state, two steps deep: during step z the planes of step z + 2 are requested and those of step z + 1 (requested a step ago) are
+    // transformed and written -- into the ring slot / dy buffer last read in step z - 1, which that step's barrier closed
+    uint4 xa[UX], da[UD], xb[UX], db[UD];
+    load_x(xa, z0 + 2); load_dy(da, z0 + 1);
+    for (int z = z0; z < z1; z += 2) {
+      load_x(xb, z + 3); load_dy(db, z + 2);
+      commit_x(xa, z + 2); commit_dy(da, z + 1);
+      __syncthreads();
+      if (z + 1 >= z1) break;
+      load_x(xa, z + 4); load_dy(da, z + 3);
+      commit_x(xb, z + 3); commit_dy(db, z + 2);
+      __syncthreads();
+    }
+    __syncthreads();                                               // (the matrix waves' exchange barrier)
+    return;
+  }
 
-  // ---- consumers' constants: wave = (dz, h); lane = 16 g + r: rows / columns 16 (g & 1) + (l & 15) of the operand, k-group g >> 1 ----
+  // ================================ the six matrix waves ================================
+  // wave = (dz, h); lane = 16 g + r: rows / columns 16 (g & 1) + (l & 15) of the operand, k-group g >> 1
   const int dz = wave % 3, h = wave / 3;
   const int g = lane >> 4, r16 = lane & 15, half = lane >> 5, li = lane & 31;
   const unsigned lb = (unsigned)((8 * (g >> 1) + (r16 >> 2)) * 64 + 32 * (g & 1) + 8 * (r16 & 3));
@@ -172,18 +202,9 @@ __global__ __launch_bounds__(384) void conv3d_wgrad_lp_tr(WgradTArgs a) {
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  // ---- prologue: input planes z0 - 1, z0, z0 + 1 and dy plane z0 ----
-  {
-    uint4 p0[2], p1[2], p2[2], pd[2];
-    load_x(p0, z0 - 1); load_x(p1, z0); load_x(p2, z0 + 1); load_dy(pd, z0);
-    commit_x(p0, z0 - 1); commit_x(p1, z0); commit_x(p2, z0 + 1); commit_dy(pd, z0);
-  }
-  __syncthreads();
+  __syncthreads();                                                 // prologue
 
   for (int z = z0; z < z1; ++z) {
-    uint4 nx[2], nd[2];
-    load_x(nx, z + 2); load_dy(nd, z + 1);                         // the next step's planes: in flight during the MFMAs
     const unsigned char* bp = xs + ((z - 1 + dz) & 3) * XPL + lb + (4 * h) * (HX * 64);
     const unsigned char* ap = dys + (z & 1) * DYPL + lb + (4 * h) * (TX * 64);
     // input row rr of the wave's six: voxels 8 kg + 0 .. 9 of the row as 5 dwords; dy row r: voxels 8 kg + 0 .. 7
@@ -214,7 +235,6 @@ __global__ __launch_bounds__(384) void conv3d_wgrad_lp_tr(WgradTArgs a) {
       }
       SCHED_BARRIER();
     });
-    commit_x(nx, z + 2); commit_dy(nd, z + 1);                     // slots last read in the previous step (closed by its barrier)
     __syncthreads();
   }
 
@@ -284,7 +304,7 @@ static int launch_wt(const WgradTArgs& a, unsigned grid, void* stream) {
   constexpr int lds = 3 * 9 * 16 * 64 * 4;                         // the final exchange (110 592 bytes) > ring + dy planes (62 464)
   static_assert(lds >= 4 * 10 * 18 * 64 + 2 * 8 * 16 * 64 + 256, "LDS");
   SET_MAX_DYN_LDS((conv3d_wgrad_lp_tr<INMODE, TA>), lds);
-  LAUNCH((conv3d_wgrad_lp_tr<INMODE, TA>), dim3(grid), dim3(384), lds, stream, a);
+  LAUNCH((conv3d_wgrad_lp_tr<INMODE, TA>), dim3(grid), dim3(512), lds, stream, a);
   return LAUNCH_CHECK();
 }
 
