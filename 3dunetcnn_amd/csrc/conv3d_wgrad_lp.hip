@@ -61,6 +61,7 @@ struct WgradTArgs {
   const float* in_scale; const float* in_shift; float slope; const float* in_slope;
   int N, D, H, W, Cin, Cout;
   int tilesY, tilesX, zchunks, zper, ncol;      // column chunk = ((n * tilesY + ty) * tilesX + tx) * zchunks + zc
+  int colsPer, nslab;                           // a workgroup walks colsPer consecutive column chunks into the same accumulators: nslab = ceil(ncol / colsPer) slabs
   int ciTiles, coTiles;
 };
 
@@ -80,21 +81,25 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_lp_tr(WgradTArgs a) {
   // order, so that the tiles they share come out of that XCD's L2
   const int P = a.ciTiles * a.coTiles;
   const int b = blockIdx.x, grp = b / (8 * P), rem = b % (8 * P);
-  const int pair = rem >> 3, c = grp * 8 + (rem & 7);
-  if (c >= a.ncol) return;
+  const int pair = rem >> 3, cg = grp * 8 + (rem & 7);             // cg: the workgroup's group of a.colsPer consecutive column chunks = its slab
+  if (cg >= a.nslab) return;
   const int cit = pair % a.ciTiles, cot = pair / a.ciTiles;
   const int ci0 = cit * 32, co0 = cot * 32;
-  int cc = c;
-  const int zc = cc % a.zchunks; cc /= a.zchunks;
-  const int tx0 = (cc % a.tilesX) * TX; cc /= a.tilesX;
-  const int ty0 = (cc % a.tilesY) * TY;
-  const int n = cc / a.tilesY;
-  const int z0 = zc * a.zper, z1 = z0 + a.zper < a.D ? z0 + a.zper : a.D;
+  const int c_begin = cg * a.colsPer, c_end = c_begin + a.colsPer < a.ncol ? c_begin + a.colsPer : a.ncol;
+#define WT_DECODE_COLUMN(c)                                                              \
+  int cc_ = (c);                                                                         \
+  const int zc = cc_ % a.zchunks; cc_ /= a.zchunks;                                      \
+  const int tx0 = (cc_ % a.tilesX) * TX; cc_ /= a.tilesX;                                \
+  const int ty0 = (cc_ % a.tilesY) * TY;                                                 \
+  const int n = cc_ / a.tilesY;                                                          \
+  const int z0 = zc * a.zper, z1 = z0 + a.zper < a.D ? z0 + a.zper : a.D
 
   if (wave >= 6) {
     // ================================ the two staging waves ================================
     // (waves 6, 7 share SIMDs 2, 3 with one matrix wave each; SIMDs 0, 1 carry two matrix waves: the staging arithmetic fills the lighter pair)
     const int pt = tid - 384, q8 = pt & 3;                         // the thread's channel octet (all of its units: 128 % 4 == 0)
+    for (int c = c_begin; c < c_end; ++c) {
+    WT_DECODE_COLUMN(c);
     unsigned xgoff[UX], dgoff[UD], okx = 0, okd = 0;
 #pragma unroll
     for (int k = 0; k < UX; ++k) {
@@ -175,18 +180,23 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_lp_tr(WgradTArgs a) {
       commit_x(p0, z0 - 1); commit_x(p1, z0); commit_x(p2, z0 + 1); commit_dy(pd, z0);
     }
     __syncthreads();
-    // steady state, two steps deep: during step z the planes of step z + 2 are requested and those of step z + 1 (requested a step ago) are
-    // transformed and written -- into the ring slot / dy buffer last read in step z - 1, which that step's barrier closed
-    uint4 xa[UX], da[UD], xb[UX], db[UD];
-    load_x(xa, z0 + 2); load_dy(da, z0 + 1);
-    for (int z = z0; z < z1; z += 2) {
-      load_x(xb, z + 3); load_dy(db, z + 2);
-      commit_x(xa, z + 2); commit_dy(da, z + 1);
-      __syncthreads();
+    // steady state, four steps deep (four register sets: the step is shorter than the memory latency under load -- with two sets the kernel
+    // ran at two steps per round trip whatever the matrix waves did): step s writes the planes requested four steps ago (input plane s + 2,
+    // dy plane s + 1) into the ring slot / dy buffer last read in step s - 1, which that step's barrier closed, and requests those of step s + 4
+    uint4 X0[UX], X1[UX], X2[UX], X3[UX], D0[UD], D1[UD], D2[UD], D3[UD];
+    load_x(X0, z0 + 2); load_dy(D0, z0 + 1); load_x(X1, z0 + 3); load_dy(D1, z0 + 2);
+    load_x(X2, z0 + 4); load_dy(D2, z0 + 3); load_x(X3, z0 + 5); load_dy(D3, z0 + 4);
+#define WT_STAGE_STEP(X, Dd, s) do { commit_x(X, (s) + 2); commit_dy(Dd, (s) + 1); load_x(X, (s) + 6); load_dy(Dd, (s) + 5); __syncthreads(); } while (0)
+    for (int z = z0; z < z1; z += 4) {
+      WT_STAGE_STEP(X0, D0, z);
       if (z + 1 >= z1) break;
-      load_x(xa, z + 4); load_dy(da, z + 3);
-      commit_x(xb, z + 3); commit_dy(db, z + 2);
-      __syncthreads();
+      WT_STAGE_STEP(X1, D1, z + 1);
+      if (z + 2 >= z1) break;
+      WT_STAGE_STEP(X2, D2, z + 2);
+      if (z + 3 >= z1) break;
+      WT_STAGE_STEP(X3, D3, z + 3);
+    }
+#undef WT_STAGE_STEP
     }
     __syncthreads();                                               // (the matrix waves' exchange barrier)
     return;
@@ -202,40 +212,74 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_lp_tr(WgradTArgs a) {
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  __syncthreads();                                                 // prologue
-
-  for (int z = z0; z < z1; ++z) {
-    const unsigned char* bp = xs + ((z - 1 + dz) & 3) * XPL + lb + (4 * h) * (HX * 64);
-    const unsigned char* ap = dys + (z & 1) * DYPL + lb + (4 * h) * (TX * 64);
-    // input row rr of the wave's six: voxels 8 kg + 0 .. 9 of the row as 5 dwords; dy row r: voxels 8 kg + 0 .. 7
-    unsigned B[6][5]; uint4 A[4];
+  struct Row { uint4 f0, f2, f1; };                                // voxels 8 kg + 0..7 / 2..9 / 1..8 of an input row: the dx = 0 / 2 / 1 operands
+  for (int c = c_begin; c < c_end; ++c) {
+    WT_DECODE_COLUMN(c);
+    (void)tx0; (void)ty0; (void)n;
+    Row B[6]; uint4 A[4];
+    const unsigned char* bp; const unsigned char* ap;
+    auto set_plane = [&](int z) {
+      bp = xs + ((z - 1 + dz) & 3) * XPL + lb + (4 * h) * (HX * 64);
+      ap = dys + (z & 1) * DYPL + lb + (4 * h) * (TX * 64);
+    };
+    // input row rr of the wave's six: four transpose reads (voxels 0..3, 4..7, 2..5, 6..9 of the lane's run); dx = 1 is a funnel shift, once per row
     auto rdB = [&](int rr) {
-      const uint2 v0 = lds_read_tr16_b64(bp + rr * (HX * 64)), v1 = lds_read_tr16_b64(bp + rr * (HX * 64) + 256),
-                  v2 = lds_read_tr16_b64(bp + rr * (HX * 64) + 512);
-      B[rr][0] = v0.x; B[rr][1] = v0.y; B[rr][2] = v1.x; B[rr][3] = v1.y; B[rr][4] = v2.x;
+      const unsigned char* q = bp + rr * (HX * 64);
+#ifndef WT_ABL
+#define WT_ABL 0
+#endif
+#if WT_ABL == 1        // timing only: two reads per row
+      const uint2 v0 = lds_read_tr16_b64(q), v1 = lds_read_tr16_b64(q + 256);
+      B[rr].f0 = make_uint4(v0.x, v0.y, v1.x, v1.y); B[rr].f2 = make_uint4(v0.y, v0.x, v1.y, v1.x);
+#elif WT_ABL == 2      // three reads per row, dx = 2 from register copies
+      const uint2 v0 = lds_read_tr16_b64(q), v1 = lds_read_tr16_b64(q + 256), v2 = lds_read_tr16_b64(q + 512);
+      B[rr].f0 = make_uint4(v0.x, v0.y, v1.x, v1.y); B[rr].f2 = make_uint4(v0.y, v1.x, v1.y, v2.x);
+#else
+      const uint2 v0 = lds_read_tr16_b64(q), v1 = lds_read_tr16_b64(q + 256), w0 = lds_read_tr16_b64(q + 128), w1 = lds_read_tr16_b64(q + 384);
+      B[rr].f0 = make_uint4(v0.x, v0.y, v1.x, v1.y); B[rr].f2 = make_uint4(w0.x, w0.y, w1.x, w1.y);
+#endif
+    };
+    auto mk1 = [&](int rr) {
+      const uint4 f0 = B[rr].f0;
+      B[rr].f1 = make_uint4((f0.x >> 16) | (f0.y << 16), (f0.y >> 16) | (f0.z << 16), (f0.z >> 16) | (f0.w << 16), (f0.w >> 16) | (B[rr].f2.w << 16));
     };
     auto rdA = [&](int r) {
       const uint2 v0 = lds_read_tr16_b64(ap + r * (TX * 64)), v1 = lds_read_tr16_b64(ap + r * (TX * 64) + 256);
       A[r] = make_uint4(v0.x, v0.y, v1.x, v1.y);
     };
-    rdB(0); rdB(1); rdB(2); rdA(0);
-    static_for<0, 4>([&](auto rc) {
-      constexpr int r = decltype(rc)::value;
-      if constexpr (r < 3) { rdB(r + 3); rdA(r + 1); }
-      SCHED_BARRIER();
+    auto mm = [&](int r) {
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const unsigned* bb = B[r + dy];
-        const uint4 f0 = make_uint4(bb[0], bb[1], bb[2], bb[3]);
-        const uint4 f1 = make_uint4((bb[0] >> 16) | (bb[1] << 16), (bb[1] >> 16) | (bb[2] << 16), (bb[2] >> 16) | (bb[3] << 16), (bb[3] >> 16) | (bb[4] << 16));
-        const uint4 f2 = make_uint4(bb[1], bb[2], bb[3], bb[4]);
-        acc[dy * 3 + 0] = mfma_lp<F16>(A[r], f0, acc[dy * 3 + 0]);
-        acc[dy * 3 + 1] = mfma_lp<F16>(A[r], f1, acc[dy * 3 + 1]);
-        acc[dy * 3 + 2] = mfma_lp<F16>(A[r], f2, acc[dy * 3 + 2]);
+      for (int dy = 0; dy < (WT_ABL == 3 ? 1 : 3); ++dy) {
+        acc[dy * 3 + 0] = mfma_lp<F16>(A[r], B[r + dy].f0, acc[dy * 3 + 0]);
+        acc[dy * 3 + 1] = mfma_lp<F16>(A[r], B[r + dy].f1, acc[dy * 3 + 1]);
+        acc[dy * 3 + 2] = mfma_lp<F16>(A[r], B[r + dy].f2, acc[dy * 3 + 2]);
       }
+    };
+    __syncthreads();                                               // the column's prologue
+    set_plane(z0);
+    rdB(0); rdB(1); rdB(2); rdA(0);
+    for (int z = z0; z < z1; ++z) {
+      // rows 0..2 with the reads one row ahead; the step's barrier sits BEFORE the last row's MFMAs (their operands are in registers), so that
+      // the first reads of the next step are in flight behind them
+      rdB(3); rdA(1);
       SCHED_BARRIER();
-    });
-    __syncthreads();
+      mk1(0); mk1(1); mk1(2); mm(0);
+      SCHED_BARRIER();
+      rdB(4); rdA(2);
+      SCHED_BARRIER();
+      mk1(3); mm(1);
+      SCHED_BARRIER();
+      rdB(5); rdA(3);
+      SCHED_BARRIER();
+      mk1(4); mm(2);
+      SCHED_BARRIER();
+      __syncthreads();                                             // every read of this step has landed: the staging waves may overwrite its oldest plane
+      mk1(5);
+      if (z + 1 < z1) { set_plane(z + 1); rdB(0); rdB(1); rdB(2); rdA(0); }
+      SCHED_BARRIER();
+      mm(3);
+      SCHED_BARRIER();
+    }
   }
 
   // ---- the two row halves through LDS, then the partial tiles: ws[pair][slab = column chunk][tap][32 co][32 ci] ----
@@ -251,14 +295,14 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_lp_tr(WgradTArgs a) {
     const size_t pairi = (size_t)cot * a.ciTiles + cit;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      float* dst = a.ws + (((pairi * a.ncol + c) * 27 + dz * 9 + t) * 1024);
+      float* dst = a.ws + (((pairi * a.nslab + cg) * 27 + dz * 9 + t) * 1024);
 #pragma unroll
       for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[t][r] + ex[((dz * 9 + t) * 16 + r) * 64 + lane];
     }
   }
 }
 
-struct WTPlan { int tilesY, tilesX, zchunks, zper, ncol, ciTiles, coTiles, ok; size_t ws_bytes; };
+struct WTPlan { int tilesY, tilesX, zchunks, zper, ncol, colsPer, nslab, ciTiles, coTiles, ok; size_t ws_bytes; };
 
 // the calls this kernel takes: 16-bit tensors with operands of their own type (MI355_PREC_BF16 on bf16 tensors, MI355_PREC_F16 on fp16
 // tensors), 3x3x3 stride 1 pad 1, plain or normalised + activated input, plain output, channel counts in multiples of 32, 16-byte
@@ -287,7 +331,10 @@ static WTPlan plan_wt(const mi355_act* x, const mi355_act* dy, const mi355_conv_
   p.zchunks = ceil_div(x->d, p.zper);
   if (cols * p.zchunks * pairs > 0x3fffffffLL) return p;
   p.ncol = (int)(cols * p.zchunks);
-  p.ws_bytes = (size_t)pairs * p.ncol * 27 * 1024 * sizeof(float);
+  p.colsPer = 1;      // (2 for more than 1024 workgroups was measured: 512 -> 256 @16^3 x4 0.259 -> 0.338 ms -- short columns want the parallelism)
+  { const char* e = getenv("MI355_WGRAD_LP_COLS"); if (e && atoi(e) > 0) p.colsPer = atoi(e); }
+  p.nslab = ceil_div(p.ncol, p.colsPer);
+  p.ws_bytes = (size_t)pairs * p.nslab * 27 * 1024 * sizeof(float);
   p.ok = 1;
   return p;
 }
@@ -319,11 +366,12 @@ int mi355_conv3d_wgrad_lp_tr_impl(const mi355_act* x, const mi355_act* dy, float
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slope = d->act_slope; a.in_slope = d->in_slope;
   a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Cout = dy->c;
   a.tilesY = p.tilesY; a.tilesX = p.tilesX; a.zchunks = p.zchunks; a.zper = p.zper; a.ncol = p.ncol;
+  a.colsPer = p.colsPer; a.nslab = p.nslab;
   a.ciTiles = p.ciTiles; a.coTiles = p.coTiles;
-  const unsigned grid = (unsigned)(ceil_div(p.ncol, 8) * 8 * p.ciTiles * p.coTiles);
+  const unsigned grid = (unsigned)(ceil_div(p.nslab, 8) * 8 * p.ciTiles * p.coTiles);
   int rc;
   if (x->dtype == MI355_ACT_BF16) rc = d->in_mode == MI355_IN_PLAIN ? launch_wt<MI355_IN_PLAIN, bf16_t>(a, grid, stream) : launch_wt<MI355_IN_AFFINE_ACT, bf16_t>(a, grid, stream);
   else rc = d->in_mode == MI355_IN_PLAIN ? launch_wt<MI355_IN_PLAIN, f16_t>(a, grid, stream) : launch_wt<MI355_IN_AFFINE_ACT, f16_t>(a, grid, stream);
   if (rc) return rc;
-  return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, p.ncol, p.ciTiles, stream);
+  return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, p.nslab, p.ciTiles, stream);
 }

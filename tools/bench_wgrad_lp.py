@@ -4,12 +4,15 @@ import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("ONE_CONV_LIB"):
+    importlib.import_module("3dunetcnn_amd._lib").LIB_PATH = os.path.abspath(os.environ["ONE_CONV_LIB"])
 ops = importlib.import_module("3dunetcnn_amd.ops")
 be = ops.default_backend()
 be.set_precision("bf16")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 tot = 0.0
-for cin, cout, s in ((32, 32, 128), (64, 32, 128), (64, 64, 64), (128, 64, 64), (128, 128, 32), (256, 128, 32), (256, 256, 16), (512, 256, 16), (512, 512, 8)):
+LAYERS = os.environ.get('LAYERS')
+for cin, cout, s in [tuple(int(v) for v in l.split(',')) for l in LAYERS.split(';')] if LAYERS else ((32, 32, 128), (64, 32, 128), (64, 64, 64), (128, 64, 64), (128, 128, 32), (256, 128, 32), (256, 256, 16), (512, 256, 16), (512, 512, 8)):
     x = be.empty_act(n, s, s, s, cin, dtype=torch.bfloat16); x.buf.normal_()
     dy = be.empty_act(n, s, s, s, cout, dtype=torch.bfloat16); dy.buf.normal_()
     dw = torch.empty(cout, cin, 3, 3, 3, device=be.device)
