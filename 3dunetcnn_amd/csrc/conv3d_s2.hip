@@ -355,11 +355,14 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(2) void conv3d_s2c32_wgrad(
   }
 }
 
-static int s2_plan(const mi355_act* y, S2Args& a, int target = 512) {
+static int s2_plan(const mi355_act* y, S2Args& a, int target = 256) {
   a.tilesY = ceil_div(y->h, 4); a.tilesX = ceil_div(y->w, 8);
-  const long long cols = (long long)y->n * a.tilesY * a.tilesX;
+  const long long cols1 = (long long)a.tilesY * a.tilesX, cols = cols1 * y->n;
   if (cols <= 0 || cols > 0x7fffffffLL) return 0;
-  int zch = (int)((target + cols - 1) / cols);           // forward: ~512 workgroups, two per CU, one round (1024: 0.332 -> measured below)
+  // z chunks PER SAMPLE (~256 workgroups per sample in the forward: two per CU and one round at batch 2; 1024 in all measured 0.332 -> below):
+  // the moments records of a sample -- and with them the bits of its normalised output -- must not depend on how many samples ride along
+  // (tests/test_fullsize_gpu.py: a sample alone equals the same sample in a batch, bit for bit)
+  int zch = (int)((target + cols1 - 1) / cols1);
   const int maxch = y->d >= 8 ? y->d / 8 : 1;            // >= 8 output planes per chunk (a chunk stages 3 planes before its first MFMA)
   if (zch > maxch) zch = maxch;
   if (zch < 1) zch = 1;
@@ -419,7 +422,7 @@ int mi355_conv3d_s2c32_wgrad_ok(const mi355_act* x, const mi355_act* dy, const m
 
 size_t mi355_conv3d_s2c32_wgrad_workspace(const mi355_act* dy) {
   S2Args a; memset(&a, 0, sizeof(a));
-  if (!dy || !s2_plan(dy, a, 256)) return 0;              // one 8-wave workgroup per CU
+  if (!dy || !s2_plan(dy, a, 128)) return 0;              // ~128 workgroups per sample: one 8-wave workgroup per CU at batch 2
   return (size_t)dy->n * a.tilesY * a.tilesX * a.zchunks * 2 * 27 * 1024 * sizeof(float);
 }
 
@@ -427,7 +430,7 @@ int mi355_conv3d_s2c32_wgrad_impl(const mi355_act* x, const mi355_act* dy, float
                                   void* stream) {
   if (!mi355_conv3d_s2c32_wgrad_ok(x, dy, d)) return MI355_EUNSUPPORTED;
   S2Args pl; memset(&pl, 0, sizeof(pl));
-  if (!s2_plan(dy, pl, 256)) return MI355_EINVAL;
+  if (!s2_plan(dy, pl, 128)) return MI355_EINVAL;
   const long long wgs = (long long)dy->n * pl.tilesY * pl.tilesX * pl.zchunks;
   if (ws_bytes < (size_t)wgs * 2 * 27 * 1024 * sizeof(float)) return MI355_EWORKSPACE;
   S2WArgs a; memset(&a, 0, sizeof(a));

@@ -452,6 +452,10 @@ int mi355_conv3d_wgrad_lp_tr_ok(const mi355_act* x, const mi355_act* dy, const m
 size_t mi355_conv3d_wgrad_lp_tr_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d);
 int mi355_conv3d_wgrad_lp_tr_impl(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d, void* ws, size_t ws_bytes,
                                   void* stream);
+int mi355_conv3d_wgrad_k1_lp_ok(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d);
+size_t mi355_conv3d_wgrad_k1_lp_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d);
+int mi355_conv3d_wgrad_k1_lp_impl(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d, void* ws, size_t ws_bytes,
+                                  void* stream);
 static int wgrad_uses_bf16(const mi355_conv_desc* d) {
   return d->precision != MI355_PREC_F32 && d->kd == 3 && d->stride == 1 && d->pad == 1 && d->out_mode == MI355_OUT_PLAIN &&
          (d->in_mode == MI355_IN_PLAIN || d->in_mode == MI355_IN_AFFINE_ACT);
@@ -525,6 +529,7 @@ static int wgrad_uses_ring(const mi355_conv_desc* d) { return d->kd == 3 && d->s
 extern "C" size_t mi355_conv3d_wgrad_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
   if (mi355_conv3d_c4_ok(x, d)) return mi355_conv3d_c4_wgrad_workspace(x, dy, d);
   if (mi355_conv3d_wgrad_lp_tr_ok(x, dy, d)) return mi355_conv3d_wgrad_lp_tr_workspace(x, dy, d);
+  if (mi355_conv3d_wgrad_k1_lp_ok(x, dy, d)) return mi355_conv3d_wgrad_k1_lp_workspace(x, dy, d);
   if (d && wgrad_uses_bf16(d)) return mi355_conv3d_wgrad_bf16_workspace(x, dy, d);
   if (x && dy && d && wgrad_uses_ring(d)) { RingPlan r = plan_wgrad_ring(x, dy); return r.ok ? r.ws_bytes : 0; }
   if (mi355_conv3d_s2c32_wgrad_ok(x, dy, d)) return mi355_conv3d_s2c32_wgrad_workspace(dy);
@@ -556,6 +561,7 @@ extern "C" int mi355_conv3d_wgrad(const mi355_act* x, const mi355_act* dy, float
   if (d->precision < MI355_PREC_F32 || d->precision > MI355_PREC_F16) return MI355_EINVAL;
   if (mi355_conv3d_c4_ok(x, d)) return mi355_conv3d_c4_wgrad_impl(x, dy, dw, d, ws, ws_bytes, stream);
   if (mi355_conv3d_wgrad_lp_tr_ok(x, dy, d)) return mi355_conv3d_wgrad_lp_tr_impl(x, dy, dw, d, ws, ws_bytes, stream);
+  if (mi355_conv3d_wgrad_k1_lp_ok(x, dy, d)) return mi355_conv3d_wgrad_k1_lp_impl(x, dy, dw, d, ws, ws_bytes, stream);
   if (wgrad_uses_bf16(d)) return mi355_conv3d_wgrad_bf16_impl(x, dy, dw, d, ws, ws_bytes, stream);
   if (x->dtype != dy->dtype) return MI355_EUNSUPPORTED;       // (the first-layer kernel above takes fp32 x with either dy)
   if (mi355_conv3d_s2c32_wgrad_ok(x, dy, d)) return mi355_conv3d_s2c32_wgrad_impl(x, dy, dw, d, ws, ws_bytes, stream);

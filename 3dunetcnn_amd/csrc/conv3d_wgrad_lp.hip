@@ -375,3 +375,193 @@ int mi355_conv3d_wgrad_lp_tr_impl(const mi355_act* x, const mi355_act* dy, float
   if (rc) return rc;
   return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, p.nslab, p.ciTiles, stream);
 }
+
+// ---- 1x1x1 weight gradient of 16-bit tensors: dw[co][ci] = sum_v dy[v][co] * x[v][ci]  (reference: the shortcut / projection convolutions,
+// unet3d/models/pytorch/classification/resnet.py:20-22, decoder.py:99-106) ----
+// HBM-bound (one MFMA per 2-6 KB of input), so the kernel is a set of independent streams: every wave walks its own contiguous voxel range in
+// chunks of 16 voxels through a wave-private LDS ring filled by LDS-DMA (one 1 KB request per [16 voxels][32 channels] tile, R chunks in
+// flight per wave, counted vmcnt waits, no barrier in the loop), reads the tiles with the transpose read above and keeps all CIT x COT output
+// tiles in registers. Products of two 16-bit values are exact in fp32 and the input is plain: the result is the exact-fp32 weight gradient
+// of the stored tensors in every precision mode (summation order aside), which is what conv3d_wgrad_mfma<1, 1> computes on the fp32 pipe at
+// 1.4 TB/s. The four waves of a workgroup add their tiles through LDS (two rounds); one slab per workgroup for the reduce of conv3d_wgrad.hip.
+__device__ const float wlp_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct WgradK1Args {
+  const void* x; int xld;
+  const void* dy; int dyld;
+  float* ws;
+  long long V, nchunks;          // voxels, 16-voxel chunks
+  int chunksPer, nslab;          // chunks per wave; workgroups = slabs
+};
+
+template <int CIT, int COT, int R, typename TA>
+__global__ __launch_bounds__(256) void conv3d_wgrad_k1_lp_tr(WgradK1Args a) {
+  constexpr bool F16 = std::is_same<TA, f16_t>::value;
+  constexpr int TI = CIT + COT, CH = TI * 1024, T = CIT * COT;
+  static_assert((R - 1) * TI <= 63, "vmcnt");
+  DYN_LDS(lds_f);
+  const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6);
+  float* const ring = lds_f + wave * (R * CH / 4);
+  const long long gw = (long long)blockIdx.x * 4 + wave;
+  const long long c_begin = gw * a.chunksPer;
+  const long long c_end = c_begin + a.chunksPer < a.nchunks ? c_begin + a.chunksPer : a.nchunks;
+  const TA* const xg = reinterpret_cast<const TA*>(a.x);
+  const TA* const dyg = reinterpret_cast<const TA*>(a.dy);
+  const int lv = lane >> 2, lq = lane & 3;                        // the lane's part of a tile: voxel, channel octet
+  // chunk -> ring slot: x tiles then dy tiles; voxels past the tensor: x re-reads the last voxel (finite), dy fetches zeros
+  auto request = [&](long long chunk, int slot) {
+    long long v = chunk * 16 + lv;
+    const bool ok = v < a.V;
+    if (!ok) v = a.V - 1;
+    const TA* xp = xg + (size_t)v * a.xld + 8 * lq;
+    const TA* dp = dyg + (size_t)v * a.dyld + 8 * lq;
+#pragma unroll
+    for (int t = 0; t < CIT; ++t) glds16(xp + 32 * t, ring + (slot * CH + t * 1024) / 4);
+#pragma unroll
+    for (int t = 0; t < COT; ++t)
+      glds16(ok ? reinterpret_cast<const void*>(dp + 32 * t) : reinterpret_cast<const void*>(wlp_zero16), ring + (slot * CH + (CIT + t) * 1024) / 4);
+  };
+  const int g = lane >> 4, r16 = lane & 15, half = lane >> 5, li = lane & 31;
+  const unsigned lb = (unsigned)((8 * (g >> 1) + (r16 >> 2)) * 64 + 32 * (g & 1) + 8 * (r16 & 3));
+  f32x16 acc[COT][CIT];
+#pragma unroll
+  for (int i = 0; i < COT; ++i)
+#pragma unroll
+    for (int j = 0; j < CIT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int k = 0; k < R - 1; ++k) request(c_begin + k, k);        // (chunks past the end are requested too: the counts below stay fixed)
+  int slot = 0;
+  for (long long c = c_begin; c < c_end; ++c) {
+    request(c + R - 1, slot == 0 ? R - 1 : slot - 1);             // the slot read in the previous step
+    COMPILER_FENCE();
+    WAIT_VMCNT_LGKM0((R - 1) * TI);                               // chunk c has landed
+    COMPILER_FENCE();
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(ring) + slot * CH + lb;
+    uint4 A[COT], B[CIT];
+#pragma unroll
+    for (int t = 0; t < CIT; ++t) {
+      const uint2 v0 = lds_read_tr16_b64(base + t * 1024), v1 = lds_read_tr16_b64(base + t * 1024 + 256);
+      B[t] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+    }
+#pragma unroll
+    for (int t = 0; t < COT; ++t) {
+      const uint2 v0 = lds_read_tr16_b64(base + (CIT + t) * 1024), v1 = lds_read_tr16_b64(base + (CIT + t) * 1024 + 256);
+      A[t] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+    }
+#pragma unroll
+    for (int i = 0; i < COT; ++i)
+#pragma unroll
+      for (int j = 0; j < CIT; ++j) acc[i][j] = mfma_lp<F16>(A[i], B[j], acc[i][j]);
+    slot = slot + 1 == R ? 0 : slot + 1;
+  }
+  COMPILER_FENCE();
+  WAIT_VMCNT_LGKM0(0);                                            // the look-ahead requests must have landed before the ring is reused
+  COMPILER_FENCE();
+  __syncthreads();
+
+  // ---- waves 2, 3 -> LDS -> waves 0, 1; wave 1 -> LDS -> wave 0 -> slab [pair = co tile * CIT + ci tile][slab][32 co][32 ci] ----
+  float* ex = lds_f;                                              // [sender 2][tile T][r 16][lane 64]
+  auto put = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < COT; ++i)
+#pragma unroll
+      for (int j = 0; j < CIT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ex[((s * T + i * CIT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+  };
+  auto get = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < COT; ++i)
+#pragma unroll
+      for (int j = 0; j < CIT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += ex[((s * T + i * CIT + j) * 16 + r) * 64 + lane];
+  };
+  if (wave >= 2) put(wave - 2);
+  __syncthreads();
+  if (wave < 2) get(wave);
+  __syncthreads();
+  if (wave == 1) put(0);
+  __syncthreads();
+  if (wave == 0) {
+    get(0);
+#pragma unroll
+    for (int i = 0; i < COT; ++i)
+#pragma unroll
+      for (int j = 0; j < CIT; ++j) {
+        float* dst = a.ws + (((size_t)(i * CIT + j) * a.nslab + blockIdx.x) * 1024);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[i][j][r];
+      }
+  }
+}
+
+struct WK1Plan { int cit, cot, chunksPer, nslab, ok; long long V, nchunks; size_t ws_bytes; };
+
+// the calls it takes: 1x1x1 stride 1, plain input and output, x and dy 16-bit tensors of one type (any precision mode: see above), the
+// (ci, co) tile counts of UNet3D's shortcut / projection convolutions (1 x 2, 2 x 1, 2 x 4, 4 x 2 tiles of 32), 16-byte aligned voxels.
+// MI355_WGRAD_LP_TR=0 (read once): never.
+static WK1Plan plan_wk1(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  WK1Plan p; memset(&p, 0, sizeof(p));
+  static const bool off = [] { const char* v = getenv("MI355_WGRAD_LP_TR"); return v && v[0] == '0'; }();
+  if (off || !x || !dy || !d) return p;
+  if (d->kd != 1 || d->stride != 1 || d->pad != 0 || d->in_mode != MI355_IN_PLAIN || d->out_mode != MI355_OUT_PLAIN) return p;
+  if (!act_is_lp16(x->dtype) || x->dtype != dy->dtype) return p;
+  if (x->n != dy->n || x->d != dy->d || x->h != dy->h || x->w != dy->w) return p;
+  if (x->c % 32 || dy->c % 32 || x->ld % 8 || dy->ld % 8 || ((uintptr_t)x->p & 15) || ((uintptr_t)dy->p & 15)) return p;
+  p.cit = x->c / 32; p.cot = dy->c / 32;
+  if (!((p.cit == 1 && p.cot == 2) || (p.cit == 2 && p.cot == 1) || (p.cit == 2 && p.cot == 4) || (p.cit == 4 && p.cot == 2))) return p;
+  p.V = (long long)x->n * x->d * x->h * x->w;
+  if (p.V < 16) return p;
+  p.nchunks = (p.V + 15) / 16;
+  long long per = (p.nchunks + 2047) / 2048;                      // ~512 workgroups of four waves: two per CU
+  if (per < 8) per = 8;                                           // (small tensors: fewer workgroups rather than shorter streams)
+  if (per > 0x7fffffffLL) return p;
+  p.chunksPer = (int)per;
+  const long long wgs = (p.nchunks + 4 * per - 1) / (4 * per);
+  if (wgs > 0x7fffffffLL) return p;
+  p.nslab = (int)wgs;
+  p.ws_bytes = (size_t)p.cit * p.cot * p.nslab * 1024 * sizeof(float);
+  p.ok = 1;
+  return p;
+}
+
+int mi355_conv3d_wgrad_k1_lp_ok(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) { return plan_wk1(x, dy, d).ok; }
+
+size_t mi355_conv3d_wgrad_k1_lp_workspace(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
+  const WK1Plan p = plan_wk1(x, dy, d);
+  return p.ok ? p.ws_bytes : 0;
+}
+
+template <int CIT, int COT, typename TA>
+static int launch_wk1(const WgradK1Args& a, void* stream) {
+  constexpr int TI = CIT + COT, R = TI <= 3 ? 6 : 3;              // 18 KB of ring per wave, 72 KB per workgroup: two workgroups per CU
+  constexpr int ring = 4 * R * TI * 1024, ex = 2 * CIT * COT * 4096;
+  constexpr int lds = ring > ex ? ring : ex;
+  SET_MAX_DYN_LDS((conv3d_wgrad_k1_lp_tr<CIT, COT, R, TA>), lds);
+  LAUNCH((conv3d_wgrad_k1_lp_tr<CIT, COT, R, TA>), dim3((unsigned)a.nslab), dim3(256), lds, stream, a);
+  return LAUNCH_CHECK();
+}
+
+template <typename TA>
+static int launch_wk1_tiles(const WK1Plan& p, const WgradK1Args& a, void* stream) {
+  if (p.cit == 1) return launch_wk1<1, 2, TA>(a, stream);
+  if (p.cit == 4) return launch_wk1<4, 2, TA>(a, stream);
+  return p.cot == 1 ? launch_wk1<2, 1, TA>(a, stream) : launch_wk1<2, 4, TA>(a, stream);
+}
+
+int mi355_conv3d_wgrad_k1_lp_impl(const mi355_act* x, const mi355_act* dy, float* dw, const mi355_conv_desc* d, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  const WK1Plan p = plan_wk1(x, dy, d);
+  if (!p.ok) return MI355_EUNSUPPORTED;
+  if (ws_bytes < p.ws_bytes) return MI355_EWORKSPACE;
+  WgradK1Args a; memset(&a, 0, sizeof(a));
+  a.x = x->p; a.xld = x->ld; a.dy = dy->p; a.dyld = dy->ld; a.ws = (float*)ws;
+  a.V = p.V; a.nchunks = p.nchunks; a.chunksPer = p.chunksPer; a.nslab = p.nslab;
+  const int rc = x->dtype == MI355_ACT_BF16 ? launch_wk1_tiles<bf16_t>(p, a, stream) : launch_wk1_tiles<f16_t>(p, a, stream);
+  if (rc) return rc;
+  return mi355_wgrad_reduce_launch((const float*)ws, dw, dy->c, x->c, 1, p.nslab, p.cit, stream);
+}

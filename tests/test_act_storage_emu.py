@@ -93,7 +93,11 @@ def test_first_layer(bf16_backend):
 
 
 @pytest.mark.parametrize("kw", [
-    dict(kd=1, stride=1, cin=64, cout=32, dhw=(4, 5, 7)),
+    dict(kd=1, stride=1, cin=64, cout=32, dhw=(4, 5, 7)),                              # conv3d_wgrad_k1_lp_tr: 2 x 1 tiles, 140 voxels (ragged last chunk)
+    dict(kd=1, stride=1, cin=32, cout=64, dhw=(5, 5, 7), n=2),                         # ... 1 x 2 tiles
+    dict(kd=1, stride=1, cin=64, cout=128, dhw=(9, 9, 17), n=2),                       # ... 2 x 4 tiles, several workgroups
+    dict(kd=1, stride=1, cin=128, cout=64, dhw=(3, 7, 11)),                            # ... 4 x 2 tiles
+    dict(kd=1, stride=1, cin=64, cout=64, dhw=(4, 5, 7)),                              # (2 x 2 tiles: the generic kernel)
     dict(kd=3, stride=2, cin=32, cout=32, dhw=(9, 8, 11), n=2),
     dict(kd=3, stride=1, cin=32, cout=32, dhw=(5, 6, 18), norm=True),                  # 16-bit-operand weight gradient
     dict(kd=3, stride=1, cin=32, cout=96, dhw=(3, 4, 17), norm=True),                  # ... its 64-channel workgroup form

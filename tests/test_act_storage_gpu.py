@@ -99,7 +99,10 @@ def test_first_layer(bf16_backend, dhw):
 
 
 @pytest.mark.parametrize("kw", [
-    dict(kd=1, stride=1, cin=64, cout=32, dhw=(16, 16, 16), n=2),
+    dict(kd=1, stride=1, cin=64, cout=32, dhw=(16, 16, 16), n=2),                      # conv3d_wgrad_k1_lp_tr (2 x 1 tiles)
+    dict(kd=1, stride=1, cin=32, cout=64, dhw=(33, 31, 29), n=2),                      # ... 1 x 2 tiles, ragged last chunk, many workgroups
+    dict(kd=1, stride=1, cin=128, cout=64, dhw=(17, 16, 19)),                          # ... 4 x 2
+    dict(kd=1, stride=1, cin=64, cout=128, dhw=(8, 24, 40), n=2),                      # ... 2 x 4
     dict(kd=3, stride=2, cin=32, cout=32, dhw=(17, 16, 19), n=2),
     dict(kd=3, stride=1, cin=32, cout=32, dhw=(16, 32, 32), norm=True, n=2),           # 16-bit-operand weight gradient
     dict(kd=3, stride=1, cin=64, cout=96, dhw=(9, 15, 19), norm=True),                 # ... its 64-channel workgroup form, ragged
