@@ -376,29 +376,36 @@ int mi355_conv3d_wgrad_lp_tr_impl(const mi355_act* x, const mi355_act* dy, float
   return mi355_wgrad_reduce_launch((const float*)ws, dw, a.Cout, a.Cin, 27, p.nslab, p.ciTiles, stream);
 }
 
-// ---- 1x1x1 weight gradient of 16-bit tensors: dw[co][ci] = sum_v dy[v][co] * x[v][ci]  (reference: the shortcut / projection convolutions,
-// unet3d/models/pytorch/classification/resnet.py:20-22, decoder.py:99-106) ----
+// ---- 1x1x1 weight gradient as a set of streams: dw[co][ci] = sum_v dy[v][co] * x[v][ci]  (reference: the shortcut / projection
+// convolutions, unet3d/models/pytorch/classification/resnet.py:20-22, decoder.py:99-106) ----
 // HBM-bound (one MFMA per 2-6 KB of input), so the kernel is a set of independent streams: every wave walks its own contiguous voxel range in
-// chunks of 16 voxels through a wave-private LDS ring filled by LDS-DMA (one 1 KB request per [16 voxels][32 channels] tile, R chunks in
-// flight per wave, counted vmcnt waits, no barrier in the loop), reads the tiles with the transpose read above and keeps all CIT x COT output
-// tiles in registers. Products of two 16-bit values are exact in fp32 and the input is plain: the result is the exact-fp32 weight gradient
-// of the stored tensors in every precision mode (summation order aside), which is what conv3d_wgrad_mfma<1, 1> computes on the fp32 pipe at
-// 1.4 TB/s. The four waves of a workgroup add their tiles through LDS (two rounds); one slab per workgroup for the reduce of conv3d_wgrad.hip.
+// chunks of CV voxels through a wave-private LDS ring filled by LDS-DMA (1 KB requests, R chunks in flight per wave, counted vmcnt waits, no
+// barrier in the loop) and keeps all CIT x COT output tiles in registers.
+//   16-bit tensors: [16 voxels][32 channels] tiles read with the transpose read above, v_mfma_f32_32x32x16. Products of two 16-bit values are
+//     exact in fp32 and the input is plain: this IS the exact-fp32 weight gradient of the stored tensors in every precision mode.
+//   fp32 tensors: [CV voxels][32 channels] tiles, lane (channel, voxel parity) reads one float per k-step (the two voxels of a k-step sit
+//     32 banks apart), v_mfma_f32_32x32x2_f32: the arithmetic of conv3d_wgrad_mfma<1, 1>.
+// What it replaces: conv3d_wgrad_mfma<1, 1> (one workgroup per (ci, co) tile pair and 256-voxel tile through a barrier per step: 1.4 TB/s on
+// 16-bit tensors, 2.8 TB/s on fp32 ones). The four waves of a workgroup add their tiles through LDS (two rounds); one slab per workgroup for
+// the reduce of conv3d_wgrad.hip.
 __device__ const float wlp_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 struct WgradK1Args {
   const void* x; int xld;
   const void* dy; int dyld;
   float* ws;
-  long long V, nchunks;          // voxels, 16-voxel chunks
+  long long V, nchunks;          // voxels, CV-voxel chunks
   int chunksPer, nslab;          // chunks per wave; workgroups = slabs
 };
 
-template <int CIT, int COT, int R, typename TA>
-__global__ __launch_bounds__(256) void conv3d_wgrad_k1_lp_tr(WgradK1Args a) {
-  constexpr bool F16 = std::is_same<TA, f16_t>::value;
-  constexpr int TI = CIT + COT, CH = TI * 1024, T = CIT * COT;
-  static_assert((R - 1) * TI <= 63, "vmcnt");
+template <int CIT, int COT, int R, int CV, typename TA>
+__global__ __launch_bounds__(256) void conv3d_wgrad_k1_stream(WgradK1Args a) {
+  constexpr bool F32 = std::is_same<TA, float>::value, F16 = std::is_same<TA, f16_t>::value;
+  constexpr int EPL = 16 / (int)sizeof(TA), LPV = 32 / EPL, VPI = 64 / LPV;      // elements per lane and request, lanes per voxel, voxels per request
+  constexpr int SUB = CV / VPI;                                                    // requests per tile
+  constexpr int TILEB = CV * 32 * (int)sizeof(TA);
+  constexpr int TI = CIT + COT, CH = TI * TILEB, T = CIT * COT, NREQ = TI * SUB;
+  static_assert(CV % VPI == 0 && (R - 1) * NREQ <= 63 && (F32 || CV == 16), "chunk");
   DYN_LDS(lds_f);
   const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6);
   float* const ring = lds_f + wave * (R * CH / 4);
@@ -407,22 +414,26 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k1_lp_tr(WgradK1Args a) {
   const long long c_end = c_begin + a.chunksPer < a.nchunks ? c_begin + a.chunksPer : a.nchunks;
   const TA* const xg = reinterpret_cast<const TA*>(a.x);
   const TA* const dyg = reinterpret_cast<const TA*>(a.dy);
-  const int lv = lane >> 2, lq = lane & 3;                        // the lane's part of a tile: voxel, channel octet
+  const int lv = lane / LPV, lq = lane % LPV;                     // the lane's part of a request: voxel, 16-byte run
   // chunk -> ring slot: x tiles then dy tiles; voxels past the tensor: x re-reads the last voxel (finite), dy fetches zeros
   auto request = [&](long long chunk, int slot) {
-    long long v = chunk * 16 + lv;
-    const bool ok = v < a.V;
-    if (!ok) v = a.V - 1;
-    const TA* xp = xg + (size_t)v * a.xld + 8 * lq;
-    const TA* dp = dyg + (size_t)v * a.dyld + 8 * lq;
 #pragma unroll
-    for (int t = 0; t < CIT; ++t) glds16(xp + 32 * t, ring + (slot * CH + t * 1024) / 4);
+    for (int sidx = 0; sidx < SUB; ++sidx) {
+      long long v = chunk * CV + sidx * VPI + lv;
+      const bool ok = v < a.V;
+      if (!ok) v = a.V - 1;
+      const TA* xp = xg + (size_t)v * a.xld + EPL * lq;
+      const TA* dp = dyg + (size_t)v * a.dyld + EPL * lq;
 #pragma unroll
-    for (int t = 0; t < COT; ++t)
-      glds16(ok ? reinterpret_cast<const void*>(dp + 32 * t) : reinterpret_cast<const void*>(wlp_zero16), ring + (slot * CH + (CIT + t) * 1024) / 4);
+      for (int t = 0; t < CIT; ++t) glds16(xp + 32 * t, ring + (slot * CH + t * TILEB + sidx * 1024) / 4);
+#pragma unroll
+      for (int t = 0; t < COT; ++t)
+        glds16(ok ? reinterpret_cast<const void*>(dp + 32 * t) : reinterpret_cast<const void*>(wlp_zero16),
+               ring + (slot * CH + (CIT + t) * TILEB + sidx * 1024) / 4);
+    }
   };
   const int g = lane >> 4, r16 = lane & 15, half = lane >> 5, li = lane & 31;
-  const unsigned lb = (unsigned)((8 * (g >> 1) + (r16 >> 2)) * 64 + 32 * (g & 1) + 8 * (r16 & 3));
+  const unsigned lb = F32 ? (unsigned)(half * 128 + 4 * li) : (unsigned)((8 * (g >> 1) + (r16 >> 2)) * 64 + 32 * (g & 1) + 8 * (r16 & 3));
   f32x16 acc[COT][CIT];
 #pragma unroll
   for (int i = 0; i < COT; ++i)
@@ -437,24 +448,39 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k1_lp_tr(WgradK1Args a) {
   for (long long c = c_begin; c < c_end; ++c) {
     request(c + R - 1, slot == 0 ? R - 1 : slot - 1);             // the slot read in the previous step
     COMPILER_FENCE();
-    WAIT_VMCNT_LGKM0((R - 1) * TI);                               // chunk c has landed
+    WAIT_VMCNT_LGKM0((R - 1) * NREQ);                             // chunk c has landed
     COMPILER_FENCE();
     const unsigned char* base = reinterpret_cast<const unsigned char*>(ring) + slot * CH + lb;
-    uint4 A[COT], B[CIT];
+    if constexpr (F32) {
 #pragma unroll
-    for (int t = 0; t < CIT; ++t) {
-      const uint2 v0 = lds_read_tr16_b64(base + t * 1024), v1 = lds_read_tr16_b64(base + t * 1024 + 256);
-      B[t] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+      for (int ks = 0; ks < CV / 2; ++ks) {
+        float A[COT], B[CIT];
+#pragma unroll
+        for (int t = 0; t < CIT; ++t) B[t] = *reinterpret_cast<const float*>(base + t * TILEB + ks * 256);
+#pragma unroll
+        for (int t = 0; t < COT; ++t) A[t] = *reinterpret_cast<const float*>(base + (CIT + t) * TILEB + ks * 256);
+#pragma unroll
+        for (int i = 0; i < COT; ++i)
+#pragma unroll
+          for (int j = 0; j < CIT; ++j) acc[i][j] = MFMA_32x32x2(A[i], B[j], acc[i][j]);
+      }
+    } else {
+      uint4 A[COT], B[CIT];
+#pragma unroll
+      for (int t = 0; t < CIT; ++t) {
+        const uint2 v0 = lds_read_tr16_b64(base + t * TILEB), v1 = lds_read_tr16_b64(base + t * TILEB + 256);
+        B[t] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+      }
+#pragma unroll
+      for (int t = 0; t < COT; ++t) {
+        const uint2 v0 = lds_read_tr16_b64(base + (CIT + t) * TILEB), v1 = lds_read_tr16_b64(base + (CIT + t) * TILEB + 256);
+        A[t] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+      }
+#pragma unroll
+      for (int i = 0; i < COT; ++i)
+#pragma unroll
+        for (int j = 0; j < CIT; ++j) acc[i][j] = mfma_lp<F16>(A[i], B[j], acc[i][j]);
     }
-#pragma unroll
-    for (int t = 0; t < COT; ++t) {
-      const uint2 v0 = lds_read_tr16_b64(base + (CIT + t) * 1024), v1 = lds_read_tr16_b64(base + (CIT + t) * 1024 + 256);
-      A[t] = make_uint4(v0.x, v0.y, v1.x, v1.y);
-    }
-#pragma unroll
-    for (int i = 0; i < COT; ++i)
-#pragma unroll
-      for (int j = 0; j < CIT; ++j) acc[i][j] = mfma_lp<F16>(A[i], B[j], acc[i][j]);
     slot = slot + 1 == R ? 0 : slot + 1;
   }
   COMPILER_FENCE();
@@ -464,21 +490,21 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k1_lp_tr(WgradK1Args a) {
 
   // ---- waves 2, 3 -> LDS -> waves 0, 1; wave 1 -> LDS -> wave 0 -> slab [pair = co tile * CIT + ci tile][slab][32 co][32 ci] ----
   float* ex = lds_f;                                              // [sender 2][tile T][r 16][lane 64]
-  auto put = [&](int s) {
+  auto put = [&](int sd) {
 #pragma unroll
     for (int i = 0; i < COT; ++i)
 #pragma unroll
       for (int j = 0; j < CIT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ex[((s * T + i * CIT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r) ex[((sd * T + i * CIT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
   };
-  auto get = [&](int s) {
+  auto get = [&](int sd) {
 #pragma unroll
     for (int i = 0; i < COT; ++i)
 #pragma unroll
       for (int j = 0; j < CIT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += ex[((s * T + i * CIT + j) * 16 + r) * 64 + lane];
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += ex[((sd * T + i * CIT + j) * 16 + r) * 64 + lane];
   };
   if (wave >= 2) put(wave - 2);
   __syncthreads();
@@ -499,24 +525,26 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k1_lp_tr(WgradK1Args a) {
   }
 }
 
-struct WK1Plan { int cit, cot, chunksPer, nslab, ok; long long V, nchunks; size_t ws_bytes; };
+struct WK1Plan { int cit, cot, cv, chunksPer, nslab, ok; long long V, nchunks; size_t ws_bytes; };
 
-// the calls it takes: 1x1x1 stride 1, plain input and output, x and dy 16-bit tensors of one type (any precision mode: see above), the
-// (ci, co) tile counts of UNet3D's shortcut / projection convolutions (1 x 2, 2 x 1, 2 x 4, 4 x 2 tiles of 32), 16-byte aligned voxels.
-// MI355_WGRAD_LP_TR=0 (read once): never.
+// the calls it takes: 1x1x1 stride 1, plain input and output, x and dy of one storage type (fp32, or 16-bit in any precision mode: see
+// above), the (ci, co) tile counts of UNet3D's shortcut / projection convolutions (1 x 2, 2 x 1, 2 x 4, 4 x 2 tiles of 32), 16-byte aligned
+// voxels. MI355_WGRAD_K1_STREAM=0 (read once): never -- the A/B switch.
 static WK1Plan plan_wk1(const mi355_act* x, const mi355_act* dy, const mi355_conv_desc* d) {
   WK1Plan p; memset(&p, 0, sizeof(p));
-  static const bool off = [] { const char* v = getenv("MI355_WGRAD_LP_TR"); return v && v[0] == '0'; }();
+  static const bool off = [] { const char* v = getenv("MI355_WGRAD_K1_STREAM"); return v && v[0] == '0'; }();
   if (off || !x || !dy || !d) return p;
   if (d->kd != 1 || d->stride != 1 || d->pad != 0 || d->in_mode != MI355_IN_PLAIN || d->out_mode != MI355_OUT_PLAIN) return p;
-  if (!act_is_lp16(x->dtype) || x->dtype != dy->dtype) return p;
+  if (!act_dtype_ok(x) || x->dtype != dy->dtype) return p;
+  const int epl = act_is_lp16(x->dtype) ? 8 : 4;
   if (x->n != dy->n || x->d != dy->d || x->h != dy->h || x->w != dy->w) return p;
-  if (x->c % 32 || dy->c % 32 || x->ld % 8 || dy->ld % 8 || ((uintptr_t)x->p & 15) || ((uintptr_t)dy->p & 15)) return p;
+  if (x->c % 32 || dy->c % 32 || x->ld % epl || dy->ld % epl || ((uintptr_t)x->p & 15) || ((uintptr_t)dy->p & 15)) return p;
   p.cit = x->c / 32; p.cot = dy->c / 32;
   if (!((p.cit == 1 && p.cot == 2) || (p.cit == 2 && p.cot == 1) || (p.cit == 2 && p.cot == 4) || (p.cit == 4 && p.cot == 2))) return p;
+  p.cv = (epl == 4 && p.cit + p.cot > 3) ? 8 : 16;                // fp32 tensors, six tiles: 8-voxel chunks (6 KB, like the others)
   p.V = (long long)x->n * x->d * x->h * x->w;
   if (p.V < 16) return p;
-  p.nchunks = (p.V + 15) / 16;
+  p.nchunks = (p.V + p.cv - 1) / p.cv;
   long long per = (p.nchunks + 2047) / 2048;                      // ~512 workgroups of four waves: two per CU
   if (per < 8) per = 8;                                           // (small tensors: fewer workgroups rather than shorter streams)
   if (per > 0x7fffffffLL) return p;
@@ -538,11 +566,15 @@ size_t mi355_conv3d_wgrad_k1_lp_workspace(const mi355_act* x, const mi355_act* d
 
 template <int CIT, int COT, typename TA>
 static int launch_wk1(const WgradK1Args& a, void* stream) {
-  constexpr int TI = CIT + COT, R = TI <= 3 ? 6 : 3;              // 18 KB of ring per wave, 72 KB per workgroup: two workgroups per CU
-  constexpr int ring = 4 * R * TI * 1024, ex = 2 * CIT * COT * 4096;
+  constexpr bool F32 = std::is_same<TA, float>::value;
+  constexpr int TI = CIT + COT;
+  constexpr int CV = (F32 && TI > 3) ? 8 : 16;
+  constexpr int chunk = TI * CV * 32 * (int)sizeof(TA);           // 3 or 6 KB
+  constexpr int R = 18432 / chunk;                                // 18 KB of ring per wave, 72 KB per workgroup: two workgroups per CU
+  constexpr int ring = 4 * R * chunk, ex = 2 * CIT * COT * 4096;
   constexpr int lds = ring > ex ? ring : ex;
-  SET_MAX_DYN_LDS((conv3d_wgrad_k1_lp_tr<CIT, COT, R, TA>), lds);
-  LAUNCH((conv3d_wgrad_k1_lp_tr<CIT, COT, R, TA>), dim3((unsigned)a.nslab), dim3(256), lds, stream, a);
+  SET_MAX_DYN_LDS((conv3d_wgrad_k1_stream<CIT, COT, R, CV, TA>), lds);
+  LAUNCH((conv3d_wgrad_k1_stream<CIT, COT, R, CV, TA>), dim3((unsigned)a.nslab), dim3(256), lds, stream, a);
   return LAUNCH_CHECK();
 }
 
@@ -561,7 +593,8 @@ int mi355_conv3d_wgrad_k1_lp_impl(const mi355_act* x, const mi355_act* dy, float
   WgradK1Args a; memset(&a, 0, sizeof(a));
   a.x = x->p; a.xld = x->ld; a.dy = dy->p; a.dyld = dy->ld; a.ws = (float*)ws;
   a.V = p.V; a.nchunks = p.nchunks; a.chunksPer = p.chunksPer; a.nslab = p.nslab;
-  const int rc = x->dtype == MI355_ACT_BF16 ? launch_wk1_tiles<bf16_t>(p, a, stream) : launch_wk1_tiles<f16_t>(p, a, stream);
+  const int rc = x->dtype == MI355_ACT_BF16 ? launch_wk1_tiles<bf16_t>(p, a, stream)
+               : x->dtype == MI355_ACT_F16 ? launch_wk1_tiles<f16_t>(p, a, stream) : launch_wk1_tiles<float>(p, a, stream);
   if (rc) return rc;
   return mi355_wgrad_reduce_launch((const float*)ws, dw, dy->c, x->c, 1, p.nslab, p.cit, stream);
 }

@@ -543,7 +543,10 @@ class Backend:
                   and os.environ.get("MI355_S2_KERNEL", "1") != "0")
             tr = (bf and x.buf.element_size() == 2 and x.c % 32 == 0 and dy.c % 32 == 0 and x.shape[2] >= 8 and x.shape[3] >= 16
                   and os.environ.get("MI355_WGRAD_LP_TR", "1") != "0")      # (plan_wt in csrc/conv3d_wgrad_lp.hip decides; this is the label)
-            self._prof_add("conv3d_c4_wgrad (+reduce)" if c4 else "conv3d_s2c32_wgrad (+reduce)" if s2 else "conv3d_wgrad_lp_tr (+reduce)" if tr
+            k1 = (kd == 1 and stride == 1 and in_mode == IN_PLAIN and out_mode == OUT_PLAIN and x.buf.dtype == dy.buf.dtype
+                  and (x.c // 32, dy.c // 32) in ((1, 2), (2, 1), (2, 4), (4, 2)) and x.c % 32 == 0 and dy.c % 32 == 0
+                  and os.environ.get("MI355_WGRAD_K1_STREAM", "1") != "0")  # (plan_wk1 in csrc/conv3d_wgrad_lp.hip decides; this is the label)
+            self._prof_add("conv3d_wgrad_k1_stream (+reduce)" if k1 else "conv3d_c4_wgrad (+reduce)" if c4 else "conv3d_s2c32_wgrad (+reduce)" if s2 else "conv3d_wgrad_lp_tr (+reduce)" if tr
                            else "conv3d_wgrad_k3_bf16<...> (+reduce)" if bf
                            else "conv3d_wgrad_ring (+reduce)" if (kd == 3 and stride == 1 and pad == 1 and out_mode == OUT_PLAIN)
                            else f"conv3d_wgrad_mfma<{kd}, {stride}> (+reduce)", flops, byts, e0, e1)

@@ -108,7 +108,11 @@ def test_transposed_conv_k3s2(emu_backend, kw):
     dict(n=1, cin=64, cout=96, dhw=(5, 5, 9), norm=True, slope=0.01),
     dict(n=1, cin=32, cout=32, dhw=(9, 8, 12), stride=2),                      # conv3d_s2c32_wgrad
     dict(n=2, cin=32, cout=32, dhw=(33, 7, 18), stride=2),                     # ... two z chunks per column, ragged tiles, odd extents
-    dict(n=2, cin=64, cout=32, dhw=(5, 6, 7), kd=1),
+    dict(n=2, cin=64, cout=32, dhw=(5, 6, 7), kd=1),                           # conv3d_wgrad_k1_stream, fp32 tensors: 2 x 1 tiles, ragged last chunk
+    dict(n=1, cin=32, cout=64, dhw=(9, 9, 9), kd=1),                           # ... 1 x 2
+    dict(n=2, cin=64, cout=128, dhw=(7, 9, 17), kd=1),                         # ... 2 x 4 (8-voxel chunks), several workgroups
+    dict(n=1, cin=128, cout=64, dhw=(3, 7, 11), kd=1),                         # ... 4 x 2
+    dict(n=1, cin=64, cout=64, dhw=(4, 5, 7), kd=1),                           # (2 x 2 tiles: conv3d_wgrad_mfma<1, 1>)
 ])
 def test_conv_wgrad(emu_backend, kw):
     assert C.case_conv_wgrad(emu_backend, **kw) < TOL

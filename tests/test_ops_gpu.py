@@ -87,6 +87,10 @@ def test_conv_dgrad_first_layer_every_precision_mode(hip_backend):
     dict(n=2, cin=256, cout=256, dhw=(8, 8, 8), norm=True),
     dict(n=1, cin=32, cout=32, dhw=(33, 32, 36), stride=2),
     dict(n=2, cin=256, cout=64, dhw=(16, 16, 16), kd=1),
+    dict(n=2, cin=64, cout=32, dhw=(33, 31, 29), kd=1),                        # conv3d_wgrad_k1_stream, fp32 tensors: 2 x 1 tiles, ragged last chunk
+    dict(n=1, cin=32, cout=64, dhw=(24, 24, 40), kd=1),                        # ... 1 x 2
+    dict(n=2, cin=64, cout=128, dhw=(8, 24, 40), kd=1),                        # ... 2 x 4 (8-voxel chunks)
+    dict(n=1, cin=128, cout=64, dhw=(17, 16, 19), kd=1),                       # ... 4 x 2
 ])
 def test_conv_wgrad(hip_backend, kw):
     assert C.case_conv_wgrad(hip_backend, **kw) < TOL

@@ -33,9 +33,10 @@ for cin, cout, s in [tuple(int(v) for v in l.split(',')) for l in LAYERS.split('
 print(f"sum {tot:.3f} ms")
 # the 1x1x1 weight gradients of the same step (plain input): conv3d_wgrad_k1_lp_tr against conv3d_wgrad_mfma<1, 1>; GB/s = input bytes / time
 tot = 0.0
+K1_DTYPE = torch.float32 if os.environ.get("K1_FP32") else torch.bfloat16
 for cin, cout, s in ((64, 32, 128), (128, 64, 64), (64, 32, 64), (128, 64, 32), (32, 64, 64), (64, 128, 32)):
-    x = be.empty_act(n, s, s, s, cin, dtype=torch.bfloat16); x.buf.normal_()
-    dy = be.empty_act(n, s, s, s, cout, dtype=torch.bfloat16); dy.buf.normal_()
+    x = be.empty_act(n, s, s, s, cin, dtype=K1_DTYPE); x.buf.normal_()
+    dy = be.empty_act(n, s, s, s, cout, dtype=K1_DTYPE); dy.buf.normal_()
     dw = torch.empty(cout, cin, 1, 1, 1, device=be.device)
     run = lambda: be.conv_wgrad(x, dy, dw, 1, 1, pad=0)
     best = 1e9
@@ -46,7 +47,6 @@ for cin, cout, s in ((64, 32, 128), (128, 64, 64), (64, 32, 64), (128, 64, 32), 
         for _ in range(10): run()
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 10)
-    print(f"1x1x1 {cin:4d} -> {cout:4d} @{s:3d}^3 x{n}: {best:7.3f} ms  {2.0 * n * s ** 3 * (cin + cout) / best / 1e6:7.1f} GB/s", flush=True)
+    print(f"1x1x1 {cin:4d} -> {cout:4d} @{s:3d}^3 x{n}: {best:7.3f} ms  {x.buf.element_size() * n * s ** 3 * (cin + cout) / best / 1e6:7.1f} GB/s", flush=True)
     tot += best
-    del x, dy
 print(f"1x1x1 sum {tot:.3f} ms")
