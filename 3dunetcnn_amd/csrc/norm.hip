@@ -180,6 +180,64 @@ __global__ void gn_bwd_apply_kernel(const T* x, int xld, const T* dA, int dald, 
   }
 }
 
+// The same pass with the (sample, channel-run) constants in registers: grid = (blocks, samples); a thread keeps ONE channel run q = tid % Q
+// and walks voxels, so scale / shift / the four coefficients per channel are loaded once per thread instead of once per 16-byte run (the
+// grid-stride form above reads 96-192 bytes of parameters beside every 32 bytes of payload through the vector L1). Two voxels per iteration.
+// Needs 256 % Q == 0 (every channel count of the networks here); otherwise the form above. Launched for 16-bit tensors (VW = 8).
+template <typename T, int VW>
+__global__ __launch_bounds__(256) void gn_bwd_apply_rows_kernel(const T* x, int xld, const T* dA, int dald, T* dx, int dxld,
+                                                              const T* addend, int addld, long long V, int C, float slope,
+                                                              const float* scale, const float* shift, const float* coef) {
+  const int Q = C / VW, VPB = 256 / Q;
+  const int n = blockIdx.y, q = threadIdx.x % Q, c = VW * q;
+  float se[VW], he[VW], k0[VW], k1[VW], k2[VW], k3[VW];
+  ldv<VW>(scale + (size_t)n * C + c, se);
+  ldv<VW>(shift + (size_t)n * C + c, he);
+#pragma unroll
+  for (int e = 0; e < VW; ++e) {
+    const float4 k = *reinterpret_cast<const float4*>(coef + ((size_t)n * C + c + e) * 4);
+    k0[e] = k.x; k1[e] = k.y; k2[e] = k.z; k3[e] = k.w;
+  }
+  const long long stride = (long long)gridDim.x * VPB;
+  const size_t nbase = (size_t)n * V;
+  auto one = [&](const float (&xe)[VW], const float (&de)[VW], float (&o)[VW]) {
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      const float u = xe[e] * se[e] + he[e];
+      const float du = u > 0.f ? de[e] : de[e] * slope;
+      o[e] = k0[e] * du + k1[e] + k2[e] * (xe[e] - k3[e]);
+    }
+  };
+  long long v = (long long)blockIdx.x * VPB + threadIdx.x / Q;
+  for (; v + stride < V; v += 2 * stride) {
+    const size_t r0 = nbase + v, r1 = r0 + stride;
+    float xa[VW], da[VW], xb[VW], db[VW], oa[VW], ob[VW];
+    ldv<VW>(x + r0 * xld + c, xa); ldv<VW>(dA + r0 * dald + c, da);
+    ldv<VW>(x + r1 * xld + c, xb); ldv<VW>(dA + r1 * dald + c, db);
+    one(xa, da, oa); one(xb, db, ob);
+    if (addend) {
+      float av[VW], bv[VW];
+      ldv<VW>(addend + r0 * addld + c, av); ldv<VW>(addend + r1 * addld + c, bv);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) { oa[e] += av[e]; ob[e] += bv[e]; }
+    }
+    stv<VW>(dx + r0 * dxld + c, oa); stv<VW>(dx + r1 * dxld + c, ob);
+  }
+  if (v < V) {
+    const size_t r0 = nbase + v;
+    float xa[VW], da[VW], oa[VW];
+    ldv<VW>(x + r0 * xld + c, xa); ldv<VW>(dA + r0 * dald + c, da);
+    one(xa, da, oa);
+    if (addend) {
+      float av[VW];
+      ldv<VW>(addend + r0 * addld + c, av);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) oa[e] += av[e];
+    }
+    stv<VW>(dx + r0 * dxld + c, oa);
+  }
+}
+
 // ---- statistics from partial moments (gn_fuse.h record format: (count, sum, M2) per (sample, block, channel)) ----
 // Standalone producer of the records: one streaming read of x. Inside a block the sums are taken about K_c = the block's first
 // voxel of that channel (a sample of the data, so they do not cancel when |mean| >> std) and converted to (count, sum, M2) once.
@@ -482,6 +540,22 @@ static int gn_act_bwd_impl(const mi355_act* x, const mi355_act* dA, const mi355_
   const long long total = (long long)N * V * Q;
   long long grid = (total + 255) / 256; if (grid > 8192) grid = 8192;
   const bool vw8 = act_vw8(x) && act_vw8(dA) && act_vw8(dx) && (!addend || (addend_ld % 8 == 0 && !((uintptr_t)addend & 15)));
+  // the rows form (constants in registers, two voxels per iteration) where a 256-thread block holds whole voxels of Q channel runs;
+  // MI355_GN_APPLY_ROWS=0 (read once): the grid-stride form everywhere -- the A/B switch
+  static const bool rows_off = [] { const char* v = getenv("MI355_GN_APPLY_ROWS"); return v && v[0] == '0'; }();
+  const int Qa = C / 8;
+  // 16-byte runs of 16-bit tensors only: there the constants are 192 bytes beside 32 bytes of payload and the rows form runs 32 ch @128^3 x 4 in
+  // 0.133 instead of 0.248 ms; on fp32 tensors both forms sit at the memory system's 5 TB/s (tools/bench_gn_bwd.py) and the step is a wash
+  if (!rows_off && vw8 && Qa <= 256 && 256 % Qa == 0 && N <= 65535) {
+    const int VPB = 256 / Qa;
+    long long gx = (V + (long long)VPB * 8 - 1) / ((long long)VPB * 8);      // >= 8 voxels per thread where the tensor allows
+    const long long cap = (8192 + N - 1) / N;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    ACT_TYPED_LP16(x->dtype, T, LAUNCH((gn_bwd_apply_rows_kernel<T, 8>), dim3((unsigned)gx, N), dim3(256), 0, stream, (const T*)x->p, x->ld, (const T*)dA->p,
+           dA->ld, (T*)dx->p, dx->ld, (const T*)addend, addend_ld, V, C, act_slope, scale, shift, (const float*)coef));
+    return LAUNCH_CHECK();
+  }
   if (vw8) {
     const long long total8 = (long long)N * V * (C / 8);
     long long grid8 = (total8 + 255) / 256; if (grid8 > 8192) grid8 = 8192;
