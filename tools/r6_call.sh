@@ -1,8 +1,9 @@
 #!/bin/bash
 # scratch per-call script (GPU box)
-mkdir -p gpurun_out/gn
-for args in "fp32 2" "bf16 4"; do for v in 1 0; do
-(cd /tmp && export TMPDIR=/tmp && MI355_GN_APPLY_ROWS=$v timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/gn/t$v -o b -- python $GRAFT_REPO_ROOT/tools/bench_gn_bwd.py $args 2>&1 | grep "ch @")
-f=$(find gpurun_out/gn/t$v -name "*kernel_stats.csv" | head -1); echo "== $args rows=$v"; grep "gn_bwd" $f | awk -F'",' '{print substr($1,1,50), $2}'
-rm -rf gpurun_out/gn/t$v
-done; done
+for a in "fp32 2" "bf16 4"; do
+  echo "== new $a"; python tools/bench_upsample.py $a 2>&1 | grep -v amdgpu
+  echo "== rows off $a"; MI355_UPSAMPLE_ROWS=0 python tools/bench_upsample.py $a 2>&1 | grep -v amdgpu
+done
+python -m pytest tests/test_ops_gpu.py tests/test_act_storage_gpu.py tests/test_model_gpu.py -q -x -k "upsample or pointwise or odd or unet3d" 2>&1 | tail -2
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-c3 --no-precision-modes 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fp32 step', d['value'], d['ms_per_step'])"
+python bench.py --config c3 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('c3', d['value'], d['ms_per_step'])"
