@@ -791,6 +791,8 @@ int mi355_conv3d_narrow_impl(const mi355_act* x, const float* wp, const mi355_ac
 int mi355_conv3d_s2c32_ok(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d);
 int32_t mi355_conv3d_s2c32_stats_blocks(const mi355_act* y);
 int mi355_conv3d_s2c32_fwd_impl(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream);
+int mi355_conv3d_s2c32_dgrad_ok(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d);
+int mi355_conv3d_s2c32_dgrad_impl(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream);
 
 extern "C" int mi355_conv3d_uses_bf16(const mi355_conv_desc* d) {
   return d && d->precision != MI355_PREC_F32 && d->kd == 3 && d->stride == 1 &&
@@ -858,6 +860,7 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
   }
   if (d->in_mode == MI355_IN_ZERO_INSERT && (d->stride != 1 || d->kd != 3 || d->pad != 1)) return MI355_EINVAL;
   if (mi355_conv3d_s2c32_ok(x, y, d)) return mi355_conv3d_s2c32_fwd_impl(x, wp, y, d, stream);
+  if (mi355_conv3d_s2c32_dgrad_ok(x, y, d)) return mi355_conv3d_s2c32_dgrad_impl(x, wp, y, d, stream);
   if (x->dtype != y->dtype) return MI355_EUNSUPPORTED;      // one storage type per call here (the first-layer kernels above take fp32 x with either y)
   const bool lp = act_is_lp16(x->dtype);
   if (lp && (y->c % 4 || y->ld % 4 || ((uintptr_t)y->p & 7))) return MI355_EINVAL;
@@ -940,6 +943,7 @@ extern "C" int mi355_conv3d_fwd_config(const mi355_act* x, const mi355_act* y, c
   }
   if (d->wformat == MI355_W_PACKED && mi355_conv3d_uses_bf16(d)) return mi355_conv3d_bf16_kernel_name(x, y, d, out, n);
   if (mi355_conv3d_s2c32_ok(x, y, d)) { snprintf(out, n, "conv3d_s2c32_fwd"); return 0; }
+  if (mi355_conv3d_s2c32_dgrad_ok(x, y, d)) { snprintf(out, n, "conv3d_s2c32_dgrad"); return 0; }
   const int cfg = select_cfg(d->kd, d->stride, (long long)d->out_d * d->out_h * d->out_w * x->n,
                              (d->kd == 1 && d->out_mode == MI355_OUT_D2S) ? 8 * y->c : y->c, d->in_mode);
   const int stride_t = d->in_mode == MI355_IN_ZERO_INSERT ? 1 : d->stride;

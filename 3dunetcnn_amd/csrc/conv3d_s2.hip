@@ -22,6 +22,7 @@ struct S2Args {
   const float* wp;                       // forward pack [27][8][32][4] (mi355_pack_conv_weight mode 0, cin = cout = 32)
   float* y; int yld;
   float* mom;                            // moment records [n][B][32][3] or NULL
+  const float* res; int resld;           // (data gradient only) NULL or a tensor of y's shape and storage type added in the epilogue: the skip gradient
   int N, Di, Hi, Wi, Do, Ho, Wo;
   int tilesY, tilesX, zchunks, zper;
 };
@@ -355,6 +356,145 @@ __global__ __launch_bounds__(512) MIN_WAVES_PER_SIMD(2) void conv3d_s2c32_wgrad(
   }
 }
 
+// ---- data gradient of the same layer: dx[i][ci] = sum over (o, k) with 2 o + k - 1 = i of dy[o][co] * w[co][ci][k]  -- the call
+// mi355_conv3d_fwd(dy, dgrad pack, dx, in_mode = MI355_IN_ZERO_INSERT) ----
+// Per dimension an even position takes one tap (k = 1, o = i / 2), an odd one two (k = 2 at o = (i - 1) / 2, k = 0 at o = (i + 1) / 2): the 8
+// parity classes of a 2 x 2 x 2 output block carry 1, 2, 2, 4, 2, 4, 4, 8 of the 27 taps. The generic template runs this as a stride-1
+// convolution over the zero-inserted dy with parity-class tiles, re-staging the 110 KB of weights for every 256 output voxels (0.57 ms).
+// Here: the forward kernel's march, mirrored. A workgroup walks a column of 4 x 8 dy voxels along z with a ring of three dy planes (5 x 9
+// voxels with the +1 halo); per dy plane it produces the two dx planes 2 m, 2 m + 1 as 8 parity classes of 32 voxels x 32 input channels. The
+// four waves split K (wave = two quads of the dy channels), each keeps the 27 weight quads of its lane in registers for the whole march (the
+// dgrad pack [27][8][32][4] = flipped taps, roles swapped: packed tap t per dimension is k = 2 - t), class after class: 1-8 taps x 4
+// MFMAs, partial tile to a double-buffered LDS exchange, one barrier, 256 threads add the four partials and store 16 bytes each.
+// pair i of the data gradient's 27 (parity class, tap) pairs, classes in order 0..7 (class c = (pz, py, px) bits, 1 / 2 / 2 / 4 / 2 / 4 / 4 / 8 taps):
+// per dimension parity 0 -> packed tap 1 at dy offset 0; parity 1 -> packed tap 0 at offset 0 and packed tap 2 at offset + 1
+struct S2DgradTap {
+  int c, t, oz, off; bool first, last;
+  static constexpr S2DgradTap at(int i) {
+    int c = 0, start = 0;
+    for (; c < 8; ++c) {
+      const int nt = (1 + (c >> 2)) * (1 + ((c >> 1) & 1)) * (1 + (c & 1));
+      if (i < start + nt) break;
+      start += nt;
+    }
+    const int pz = c >> 2, py = (c >> 1) & 1, px = c & 1, ny = 1 + py, nx = 1 + px, nt = (1 + pz) * ny * nx, k = i - start;
+    const int iz = k / (ny * nx), iy = (k / nx) % ny, ix = k % nx;
+    const int tz = pz ? 2 * iz : 1, ty = py ? 2 * iy : 1, tx = px ? 2 * ix : 1;
+    return S2DgradTap{c, (tz * 3 + ty) * 3 + tx, pz ? iz : 0, ((py ? iy : 0) * 9 + (px ? ix : 0)) * 32, k == 0, k == nt - 1};
+  }
+};
+
+template <typename TA>
+__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(2) void conv3d_s2c32_dgrad(S2Args a) {
+  // (roles in S2Args: x = dy [N][Do][Ho][Wo][32 co], y = dx [N][Di][Hi][Wi][32 ci], wp = the dgrad pack)
+  constexpr int TY = 4, TX = 8, HY = TY + 1, HX = TX + 1, HV = HY * HX;      // 5 x 9 = 45 dy voxels per plane
+  constexpr int PL = HV * 32;
+  constexpr int UNITS = HV * 8, UP = (UNITS + 255) / 256;                    // 360 units of 16 bytes per plane: 2 per thread
+  const TA* const ady = reinterpret_cast<const TA*>(a.x);
+  TA* const adx = reinterpret_cast<TA*>(a.y);
+  DYN_LDS(lds);
+  float* ds = lds;                                       // ring of 3 dy planes: plane p in slot p % 3
+  float* ex = lds + 3 * PL;                              // exchange [buffer 2][wave][voxel 32][ci 32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = WAVE_UNIFORM(tid >> 6), half = lane >> 5, li = lane & 31;
+  int b = blockIdx.x;
+  const int zc = b % a.zchunks; b /= a.zchunks;
+  const int tx0 = (b % a.tilesX) * TX; b /= a.tilesX;
+  const int ty0 = (b % a.tilesY) * TY; b /= a.tilesY;
+  const int n = b;
+  const int z_begin = zc * a.zper, z_end = z_begin + a.zper < a.Do ? z_begin + a.zper : a.Do;
+
+  float4 W[27];
+  {
+    const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
+#pragma unroll
+    for (int t = 0; t < 27; ++t) W[t] = wp4[(size_t)(t * 8 + 2 * wave + half) * 32 + li];
+  }
+  float4 st[UP];
+  unsigned goff[UP], loff[UP], okmask = 0;
+#pragma unroll
+  for (int k = 0; k < UP; ++k) {
+    int u = tid + k * 256; const bool live = u < UNITS; if (!live) u = UNITS - 1;
+    const int hv = u >> 3, q = u & 7;
+    const int oy = ty0 + hv / HX, ox = tx0 + hv % HX;
+    const bool in = oy < a.Ho && ox < a.Wo;
+    goff[k] = (unsigned)(((in ? oy : 0) * a.Wo + (in ? ox : 0)) * a.xld + 4 * q);
+    loff[k] = live ? (unsigned)(hv * 32 + 4 * q) : 0xffffffffu;
+    okmask |= (unsigned)(in && live) << k;
+  }
+  const size_t dyplane = (size_t)a.Ho * a.Wo * a.xld;
+  const TA* const dyn = ady + (size_t)n * a.Do * dyplane;
+  auto load_plane = [&](int p) {
+    const TA* pl = dyn + (size_t)(p < a.Do ? p : a.Do - 1) * dyplane;
+#pragma unroll
+    for (int k = 0; k < UP; ++k) st[k] = ld4(pl + goff[k]);
+  };
+  auto commit_plane = [&](int p) {                       // the plane past the tensor is the zero halo of the last odd dx plane
+    float* sp = ds + (p % 3) * PL;
+#pragma unroll
+    for (int k = 0; k < UP; ++k) {
+      if (loff[k] == 0xffffffffu) continue;
+      const bool ok = ((okmask >> k) & 1u) && p < a.Do;
+      *reinterpret_cast<float4*>(sp + loff[k]) = ok ? st[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  // A operand: lane li = dy voxel (row li >> 3, column li & 7) of the plane tile, lane half = which of the wave's two channel quads
+  const int abase = ((li >> 3) * HX + (li & 7)) * 32 + (2 * wave + half) * 4;
+  // final stage: thread = (voxel tid >> 3, input-channel quad tid & 7)
+  const int fv = tid >> 3, fq = tid & 7;
+  const int fy = 2 * (ty0 + (fv >> 3)), fx = 2 * (tx0 + (fv & 7));
+
+  load_plane(z_begin); commit_plane(z_begin);
+  load_plane(z_begin + 1); commit_plane(z_begin + 1);
+  __syncthreads();
+
+  for (int m = z_begin; m < z_end; ++m) {
+    load_plane(m + 2);                                   // in flight during the step; its slot held plane m - 1
+    const float* pl[2] = {ds + (m % 3) * PL, ds + ((m + 1) % 3) * PL};
+    // the 27 (class, tap) pairs as one sequence: the operand of pair i + 1 is read before the MFMAs of pair i (hipcc does not pipeline LDS reads
+    // into MFMAs by itself); a class's last pair is followed by its exchange
+    f32x16 acc;
+    float4 cur = *reinterpret_cast<const float4*>(pl[S2DgradTap::at(0).oz] + abase + S2DgradTap::at(0).off), nxt = cur;
+    static_for<0, 27>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr S2DgradTap tp = S2DgradTap::at(i);
+      if constexpr (tp.first) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      }
+      if constexpr (i + 1 < 27) {
+        constexpr S2DgradTap tn = S2DgradTap::at(i + 1);
+        nxt = *reinterpret_cast<const float4*>(pl[tn.oz] + abase + tn.off);
+      }
+      SCHED_BARRIER();
+      acc = MFMA_32x32x2(cur.x, W[tp.t].x, acc); acc = MFMA_32x32x2(cur.y, W[tp.t].y, acc);
+      acc = MFMA_32x32x2(cur.z, W[tp.t].z, acc); acc = MFMA_32x32x2(cur.w, W[tp.t].w, acc);
+      SCHED_BARRIER();
+      cur = nxt;
+      if constexpr (tp.last) {
+        constexpr int c = tp.c, pz = c >> 2, py = (c >> 1) & 1, px = c & 1;
+        float* eb = ex + (c & 1) * 4096;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) eb[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[r];
+        if constexpr (c == 7) commit_plane(m + 2);       // published by the same barrier as the last class's partials
+        __syncthreads();                                 // partials visible; the other exchange buffer (class c - 1) has been read by everyone
+        const float* e0 = eb + fv * 32 + 4 * fq;
+        const float4 p0 = *reinterpret_cast<const float4*>(e0), p1 = *reinterpret_cast<const float4*>(e0 + 1024);
+        const float4 p2 = *reinterpret_cast<const float4*>(e0 + 2048), p3 = *reinterpret_cast<const float4*>(e0 + 3072);
+        const int z = 2 * m + pz, y = fy + py, x = fx + px;
+        if (z < a.Di && y < a.Hi && x < a.Wi) {
+          const size_t vox = (((size_t)n * a.Di + z) * a.Hi + y) * a.Wi + x;
+          float4 o = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
+          if (a.res) {
+            const float4 rv = ld4(reinterpret_cast<const TA*>(a.res) + vox * a.resld + 4 * fq);
+            o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+          }
+          st4(adx + vox * a.yld + 4 * fq, o);
+        }
+      }
+    });
+  }
+}
+
 static int s2_plan(const mi355_act* y, S2Args& a, int target = 256) {
   a.tilesY = ceil_div(y->h, 4); a.tilesX = ceil_div(y->w, 8);
   const long long cols1 = (long long)a.tilesY * a.tilesX, cols = cols1 * y->n;
@@ -404,6 +544,34 @@ int mi355_conv3d_s2c32_fwd_impl(const mi355_act* x, const float* wp, const mi355
                          LAUNCH((conv3d_s2c32_fwd<TA, true>), dim3((unsigned)wgs), dim3(256), lds_bytes, stream, a); }
             else { SET_MAX_DYN_LDS((conv3d_s2c32_fwd<TA, false>), lds_bytes);
                    LAUNCH((conv3d_s2c32_fwd<TA, false>), dim3((unsigned)wgs), dim3(256), lds_bytes, stream, a); });
+  return LAUNCH_CHECK();
+}
+
+// the data gradient of the same layer (mi355_conv3d_fwd with MI355_IN_ZERO_INSERT: x = dy, y = dx, the dgrad pack; optional residual = the
+// skip gradient; no other epilogue, no window)
+int mi355_conv3d_s2c32_dgrad_ok(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d) {
+  static const bool off = [] { const char* v = getenv("MI355_S2_KERNEL"); return v && v[0] == '0'; }();
+  if (off || !x || !y || !d) return 0;
+  if (d->kd != 3 || d->stride != 1 || d->pad != 1 || x->c != 32 || y->c != 32 || d->in_mode != MI355_IN_ZERO_INSERT || d->out_mode != MI355_OUT_PLAIN) return 0;
+  if (d->bias || d->out_chscale || d->gn_bwd || d->moments_out || d->off_z || d->off_y || d->off_x) return 0;
+  if (d->residual && (d->residual_ld % 4 || ((uintptr_t)d->residual & act_align_mask(y->dtype)))) return 0;
+  if (d->wformat != MI355_W_PACKED || x->dtype != y->dtype || !act_dtype_ok(x) || x->n != y->n) return 0;
+  if (x->d != (y->d - 1) / 2 + 1 || x->h != (y->h - 1) / 2 + 1 || x->w != (y->w - 1) / 2 + 1 || d->out_d != y->d || d->out_h != y->h || d->out_w != y->w) return 0;
+  if (x->ld % 4 || y->ld % 4 || ((uintptr_t)x->p & act_align_mask(x->dtype)) || ((uintptr_t)y->p & act_align_mask(y->dtype))) return 0;
+  return 1;
+}
+
+int mi355_conv3d_s2c32_dgrad_impl(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream) {
+  if (!mi355_conv3d_s2c32_dgrad_ok(x, y, d)) return MI355_EUNSUPPORTED;
+  S2Args a; memset(&a, 0, sizeof(a));
+  if (!s2_plan(x, a)) return MI355_EINVAL;                 // columns of dy voxels
+  a.x = (const float*)x->p; a.xld = x->ld; a.wp = wp; a.y = (float*)y->p; a.yld = y->ld;
+  a.res = (const float*)d->residual; a.resld = d->residual_ld;
+  a.N = x->n; a.Do = x->d; a.Ho = x->h; a.Wo = x->w; a.Di = y->d; a.Hi = y->h; a.Wi = y->w;
+  const long long wgs = (long long)x->n * a.tilesY * a.tilesX * a.zchunks;
+  const int lds_bytes = (3 * 45 * 32 + 2 * 4 * 32 * 32) * (int)sizeof(float);      // 50 048: two (three) workgroups per CU
+  ACT_TYPED(x->dtype, TA, SET_MAX_DYN_LDS((conv3d_s2c32_dgrad<TA>), lds_bytes);
+            LAUNCH((conv3d_s2c32_dgrad<TA>), dim3((unsigned)wgs), dim3(256), lds_bytes, stream, a));
   return LAUNCH_CHECK();
 }
 

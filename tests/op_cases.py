@@ -124,8 +124,9 @@ def case_conv_fwd(be, n, cin, cout, dhw, kd=3, stride=1, norm=False, groups=None
     return e
 
 
-def case_conv_dgrad(be, n, cin, cout, dhw, stride=1, seed=1):
-    """dgrad through mi355_conv3d_fwd with the mode-1 pack (stride 1) / zero-insert (stride 2)."""
+def case_conv_dgrad(be, n, cin, cout, dhw, stride=1, seed=1, residual=False):
+    """dgrad through mi355_conv3d_fwd with the mode-1 pack (stride 1) / zero-insert (stride 2); residual: the skip gradient the network adds in
+    the epilogue of the stride-2 data gradient (unet.py: d_skips)."""
     g = torch.Generator().manual_seed(seed)
     d, h, w = dhw
     x = torch.randn(n, cin, d, h, w, generator=g, requires_grad=True)
@@ -136,11 +137,13 @@ def case_conv_dgrad(be, n, cin, cout, dhw, stride=1, seed=1):
     dya = to_act(be, dy)
     dxa = to_act(be, torch.zeros(n, cin, d, h, w))
     wpd = be.pack_weight(dev(be, wt), 1)
+    res = torch.randn(n, cin, d, h, w, generator=g) if residual else None
+    ra = to_act(be, res) if residual else None
     if stride == 1:
-        be.conv_fwd(dya, wpd, dxa, 3, 1, 1)
+        be.conv_fwd(dya, wpd, dxa, 3, 1, 1, residual=ra)
     else:
-        be.conv_fwd(dya, wpd, dxa, 3, 1, 1, in_mode=ops.IN_ZERO_INSERT, out_dhw=(d, h, w))
-    return rel_err(from_act(dxa), dx_ref)
+        be.conv_fwd(dya, wpd, dxa, 3, 1, 1, in_mode=ops.IN_ZERO_INSERT, out_dhw=(d, h, w), residual=ra)
+    return rel_err(from_act(dxa), dx_ref + res if residual else dx_ref)
 
 
 def case_tconv3(be, n, cin, cout, dhw, pad_to=None, seed=12):

@@ -51,7 +51,7 @@ def test_conv_stride2(emu_backend, kw):
     _all_below(S.case_conv_s2(emu_backend, **kw), moments=2e-5)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(window=True), dict(cin=32, cout=64)])
+@pytest.mark.parametrize("kw", [dict(), dict(window=True), dict(cin=32, cout=64), dict(cin=32, cout=32)])
 def test_conv_zero_insert(emu_backend, kw):
     _all_below(S.case_conv_zero_insert(emu_backend, **kw))
 

@@ -54,7 +54,7 @@ def test_conv_stride2(hip_backend, kw):
     _all_below(S.case_conv_s2(hip_backend, **kw), moments=2e-5)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(window=True), dict(cin=32, cout=64), dict(cin=256, cout=128)])
+@pytest.mark.parametrize("kw", [dict(), dict(window=True), dict(cin=32, cout=64), dict(cin=32, cout=32), dict(cin=256, cout=128)])
 def test_conv_zero_insert(hip_backend, kw):
     _all_below(S.case_conv_zero_insert(hip_backend, **kw))
 

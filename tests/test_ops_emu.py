@@ -52,7 +52,10 @@ def test_conv_fwd_big_tile(emu_backend):
 
 @pytest.mark.parametrize("kw", [
     dict(n=1, cin=32, cout=64, dhw=(6, 7, 8)),
-    dict(n=1, cin=32, cout=32, dhw=(8, 8, 8), stride=2),
+    dict(n=1, cin=32, cout=32, dhw=(8, 8, 8), stride=2),                  # conv3d_s2c32_dgrad: even extents
+    dict(n=2, cin=32, cout=32, dhw=(33, 7, 19), stride=2),                # ... odd extents (the last odd plane / row / column has one tap), two z chunks, ragged tiles
+    dict(n=1, cin=32, cout=32, dhw=(10, 9, 16), stride=2, residual=True), # ... with the skip gradient added in the epilogue (how the network calls it)
+    dict(n=1, cin=64, cout=32, dhw=(6, 8, 10), stride=2, residual=True),  # (the template's residual epilogue)
     dict(n=1, cin=8, cout=32, dhw=(7, 9, 8), stride=2),
     dict(n=1, cin=64, cout=32, dhw=(6, 8, 10), stride=2),     # 64 dx channels: the NT = 2 parity-class configuration
 ])
@@ -77,6 +80,19 @@ def test_conv_fwd_narrow_output_forward_pack(emu_backend):
     assert C.case_conv_fwd(emu_backend, 2, 8, 4, (4, 9, 8), yld=8, yc0=4) < TOL
     assert C.case_conv_fwd(emu_backend, 1, 16, 3, (5, 6, 7), norm=True) < TOL
     assert C.case_conv_fwd(emu_backend, 1, 16, 3, (5, 6, 7), bias=True) < TOL
+
+
+def test_stride2_dgrad_config_name(emu_backend):
+    """The zero-insert data gradient of the 32 -> 32 channel stride-2 convolution launches its own kernel; 64 dx channels stay on the template."""
+    import ctypes
+    be = emu_backend
+    name = ctypes.create_string_buffer(96)
+    for cdx, want in ((32, b"conv3d_s2c32_dgrad"), (64, b"conv3d_mfma<")):
+        dya, dxa = be.empty_act(1, 4, 4, 5, 32), be.empty_act(1, 8, 7, 9, cdx)
+        d = be._desc(3, 1, 1, C.ops.IN_ZERO_INSERT, 0.0, None, None, None, None, None, (0, 0, 0), (8, 7, 9), [])
+        xd, yd = dya.desc(), dxa.desc()
+        be.lib.mi355_conv3d_fwd_config(ctypes.byref(xd), ctypes.byref(yd), ctypes.byref(d), name, 96)
+        assert name.value.startswith(want), name.value
 
 
 def test_conv_narrow_config_name(emu_backend):

@@ -44,7 +44,8 @@ def test_conv_fwd(hip_backend, kw):
     dict(n=1, cin=32, cout=64, dhw=(16, 17, 18)),
     dict(n=2, cin=32, cout=32, dhw=(32, 64, 64)),
     dict(n=1, cin=256, cout=256, dhw=(8, 8, 8)),
-    dict(n=1, cin=32, cout=32, dhw=(32, 32, 32), stride=2),
+    dict(n=1, cin=32, cout=32, dhw=(32, 32, 32), stride=2),                    # conv3d_s2c32_dgrad
+    dict(n=2, cin=32, cout=32, dhw=(65, 31, 37), stride=2, residual=True),     # ... odd extents, several z chunks, the skip gradient in the epilogue
     dict(n=1, cin=64, cout=64, dhw=(15, 17, 16), stride=2),
 ])
 def test_conv_dgrad(hip_backend, kw):
