@@ -187,7 +187,7 @@ RECORDED_DIRECT = {"five": dict(grad=0.02, n_loose=0, max_err_vs_fp32=5e-5, logi
                    "32": dict(grad=0.02, n_loose=0, max_err_vs_fp32=3e-4, logits=2e-5)}
 
 
-@pytest.mark.parametrize("rec", ["five", "32"])
+@pytest.mark.parametrize("rec", ["32"])      # ("five" ran here too until round 6: 7 s of a suite that must stay near 8 minutes; its bounds stay recorded above)
 def test_unet3d_direct_kernels_hold_the_round2_bounds(rec, hip_backend):
     old = hip_backend.winograd, hip_backend.wgrad_form
     hip_backend.winograd, hip_backend.wgrad_form = False, "direct"
