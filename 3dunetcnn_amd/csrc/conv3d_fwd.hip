@@ -792,6 +792,9 @@ int mi355_conv3d_s2c32_ok(const mi355_act* x, const mi355_act* y, const mi355_co
 int32_t mi355_conv3d_s2c32_stats_blocks(const mi355_act* y);
 int mi355_conv3d_s2c32_fwd_impl(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream);
 int mi355_conv3d_s2c32_dgrad_ok(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d);
+// conv3d_k1_stream.hip: 1x1x1 forward / data gradient of bf16 tensors as wave streams
+int mi355_conv3d_k1_stream_ok(const mi355_act* x, const mi355_act* y, const mi355_conv_desc* d);
+int mi355_conv3d_k1_stream_impl(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream);
 int mi355_conv3d_s2c32_dgrad_impl(const mi355_act* x, const float* wp, const mi355_act* y, const mi355_conv_desc* d, void* stream);
 
 extern "C" int mi355_conv3d_uses_bf16(const mi355_conv_desc* d) {
@@ -861,6 +864,7 @@ extern "C" int mi355_conv3d_fwd(const mi355_act* x, const float* wp, const mi355
   if (d->in_mode == MI355_IN_ZERO_INSERT && (d->stride != 1 || d->kd != 3 || d->pad != 1)) return MI355_EINVAL;
   if (mi355_conv3d_s2c32_ok(x, y, d)) return mi355_conv3d_s2c32_fwd_impl(x, wp, y, d, stream);
   if (mi355_conv3d_s2c32_dgrad_ok(x, y, d)) return mi355_conv3d_s2c32_dgrad_impl(x, wp, y, d, stream);
+  if (mi355_conv3d_k1_stream_ok(x, y, d)) return mi355_conv3d_k1_stream_impl(x, wp, y, d, stream);
   if (x->dtype != y->dtype) return MI355_EUNSUPPORTED;      // one storage type per call here (the first-layer kernels above take fp32 x with either y)
   const bool lp = act_is_lp16(x->dtype);
   if (lp && (y->c % 4 || y->ld % 4 || ((uintptr_t)y->p & 7))) return MI355_EINVAL;
@@ -944,6 +948,7 @@ extern "C" int mi355_conv3d_fwd_config(const mi355_act* x, const mi355_act* y, c
   if (d->wformat == MI355_W_PACKED && mi355_conv3d_uses_bf16(d)) return mi355_conv3d_bf16_kernel_name(x, y, d, out, n);
   if (mi355_conv3d_s2c32_ok(x, y, d)) { snprintf(out, n, "conv3d_s2c32_fwd"); return 0; }
   if (mi355_conv3d_s2c32_dgrad_ok(x, y, d)) { snprintf(out, n, "conv3d_s2c32_dgrad"); return 0; }
+  if (mi355_conv3d_k1_stream_ok(x, y, d)) { snprintf(out, n, "conv3d_k1_stream_bf16"); return 0; }
   const int cfg = select_cfg(d->kd, d->stride, (long long)d->out_d * d->out_h * d->out_w * x->n,
                              (d->kd == 1 && d->out_mode == MI355_OUT_D2S) ? 8 * y->c : y->c, d->in_mode);
   const int stride_t = d->in_mode == MI355_IN_ZERO_INSERT ? 1 : d->stride;

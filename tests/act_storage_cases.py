@@ -199,11 +199,13 @@ def _conv_both(be, t, w, mode, kd, yshape, call_kw, x_ld=None, x_c0=0, res=None,
     return out
 
 
-def case_conv_k1(be, cin=64, cout=32):
+def case_conv_k1(be, cin=64, cout=32, residual=False, dhw=(4, 5, 7)):
+    """(32, 64), (64, 32), (64, 64) channels on bf16 tensors: conv3d_k1_stream_bf16; residual: the gradient accumulation of the data-gradient calls."""
     g = torch.Generator().manual_seed(4)
-    t = bf16_values((2, cin, 4, 5, 7), g)
+    t = bf16_values((2, cin, *dhw), g)
     w = torch.randn(cout, cin, 1, 1, 1, generator=g) * 0.1
-    return _conv_both(be, t, w, 0, 1, (2, cout, 4, 5, 7), {}, x_ld=cin + 8, x_c0=8, y_ld=cout + 32, y_c0=32)
+    res = acts(be, bf16_values((2, cout, *dhw), g)) if residual else None
+    return _conv_both(be, t, w, 0, 1, (2, cout, *dhw), {}, x_ld=cin + 8, x_c0=8, y_ld=cout + 32, y_c0=32, res=res)
 
 
 def case_conv_s2(be, cin=32, cout=64, moments=True):

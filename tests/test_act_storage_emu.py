@@ -41,7 +41,8 @@ def test_projection(emu_backend):
     _all_below(S.case_proj(emu_backend), dw=1e-5)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(cin=32, cout=64)])
+@pytest.mark.parametrize("kw", [dict(), dict(cin=32, cout=64), dict(cin=64, cout=64, residual=True), dict(cin=32, cout=64, residual=True, dhw=(3, 3, 5)),
+                                dict(cin=128, cout=64)])      # the first four: conv3d_k1_stream_bf16 (ragged last chunk; 90 voxels); the last: the template
 def test_conv_1x1x1(emu_backend, kw):
     _all_below(S.case_conv_k1(emu_backend, **kw))
 

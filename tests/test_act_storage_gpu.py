@@ -44,7 +44,8 @@ def test_projection(hip_backend):
     _all_below(S.case_proj(hip_backend), dw=1e-5)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(cin=32, cout=64), dict(cin=256, cout=128)])
+@pytest.mark.parametrize("kw", [dict(), dict(cin=32, cout=64), dict(cin=256, cout=128), dict(cin=64, cout=64, residual=True, dhw=(17, 19, 23)),
+                                dict(cin=64, cout=32, residual=True, dhw=(33, 30, 31))])      # conv3d_k1_stream_bf16: many workgroups, ragged last chunk
 def test_conv_1x1x1(hip_backend, kw):
     _all_below(S.case_conv_k1(hip_backend, **kw))
 
