@@ -32,7 +32,7 @@
 template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT, int INMODE, int FUSE = 0, bool F16 = false, typename TA = float>
 // LDS holds 3 workgroups of the largest tile: the register allocator must fit 3 waves per SIMD too (several variants sat one or two
 // registers above), except the 4-tile waves with a norm prologue or the norm-backward epilogue, which would spill.
-__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD((MT * NT >= 4 && (INMODE == MI355_IN_AFFINE_ACT || FUSE == 2)) ? 2 : 3)
+__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD((MT * NT >= 8 || (MT * NT >= 4 && (INMODE == MI355_IN_AFFINE_ACT || FUSE == 2))) ? 2 : 3)
 void conv3d_k3_bf16(ConvBArgs a) {
   const TA* const ax = reinterpret_cast<const TA*>(a.x);
   TA* const ay = reinterpret_cast<TA*>(a.y);
@@ -260,6 +260,7 @@ void conv3d_k3_bf16(ConvBArgs a) {
       }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
+        if constexpr (MT * NT >= 8) SCHED_BARRIER();      // one tile's reads at a time: hoisted above the previous tile they spill (265 registers)
         const int m = wm * MT + mt;
         const int mz = m / (TY / 2), my0 = (m % (TY / 2)) * 2;
         const size_t vrow = (((size_t)n * a.Do + tz0 + mz) * a.Ho + ty0 + my0) * a.Wo + tx0;      // x-row 0 of the tile, x = 0
@@ -536,6 +537,8 @@ static int launch_b(ConvBArgs& a, int in_mode, void* stream) {
       LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT, 1, F16, TA>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   } else if (a.g.gnb) {
     if (in_mode != MI355_IN_PLAIN) return MI355_EUNSUPPORTED;
+    if constexpr (MT * NT >= 8) return MI355_EUNSUPPORTED;      // 8-tile waves: the normalised tensor's reads do not fit beside 128 accumulators (265 spills)
+    else
     LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 2, F16, TA>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   } else if (in_mode == MI355_IN_PLAIN)
     LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 0, F16, TA>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
@@ -544,17 +547,42 @@ static int launch_b(ConvBArgs& a, int in_mode, void* stream) {
   return LAUNCH_CHECK();
 }
 
+// Tile configuration of a call. Spatial tile: 4 x 4 x 16 voxels on big volumes (>= 128 K voxels: 4 waves along M), 2 x 4 x 16 on small ones
+// so the grid still fills the chip. Output channels per workgroup: 32, 64, or -- round 6, one-plane operands (NS = 1), Cout % 128 == 0, no
+// norm-backward epilogue -- 128 with twice the accumulator tiles per wave (4 x 2 on the big tile, 2 x 2 on the small one): a weight
+// fragment fetched through the L1 then feeds four / two MFMAs instead of two / one. Measured at batch 4 (profiles/r6_lp_tile_wide.txt):
+// 128 -> 128 @32^3 0.149 -> 0.120 ms, 256 -> 256 @16^3 0.108 -> 0.091 ms. The norm-backward form of the 8-tile wave spills 265 registers
+// (the normalised tensor's reads beside 128 accumulators) and measured slower (0.136 -> 0.185 ms): such calls keep the 64-channel form.
+// MI355_BF16_WIDE: 0 = never, big / small = that wide form on every eligible call whatever its size (tests), otherwise by size.
+struct LpTileCfg { bool big; int nw; };      // nw: output channels per workgroup (32, 64, 128)
+static LpTileCfg lp_tile_cfg(int ns, long long vox, int cout, bool gnb) {
+  LpTileCfg c;
+  c.big = ns < 3 && vox >= 256LL * 512;      // the 3-plane tile of the big configuration would exceed the 64 KiB LDS window
+  c.nw = cout > 32 ? 64 : 32;
+  const char* e = getenv("MI355_BF16_WIDE");
+  if (ns == 1 && cout % 128 == 0 && !gnb && !(e && e[0] == '0')) {
+    if (e && e[0] == 'b') { c.big = true; c.nw = 128; }
+    else if (e && e[0] == 's') { c.big = false; c.nw = 128; }
+    else if (c.big || vox * (cout / 128) >= 128LL * 256) c.nw = 128;      // small tile: only with a workgroup per CU left
+  }
+  return c;
+}
+
 template <int NS, bool F16 = false, typename TA = float>
 static int dispatch_ns(ConvBArgs& a, int in_mode, long long vox, void* stream) {
-  // big volumes: 4x4x16 tiles (256 voxels), 4 waves along M; small: 2x4x16 tiles (128 voxels) so the grid still fills the chip
   constexpr int J = NS == 1 ? 2 : 1;      // (one 16-channel k-step per chunk for NS = 1 too: more workgroups per CU, measured 10 % slower)
-  if constexpr (NS < 3) {     // the 3-plane tile of the big configuration would exceed the 64 KiB LDS window
-    if (vox >= 256LL * 512) {
-      if (a.Cout > 32) return launch_b<4, 4, J, NS, 4, 1, 2, 2, F16, TA>(a, in_mode, stream);
+  const LpTileCfg c = lp_tile_cfg(NS, vox, a.Cout, a.g.gnb != nullptr);
+  if constexpr (NS < 3) {
+    if (c.big) {
+      if constexpr (NS == 1)
+        if (c.nw == 128) return launch_b<4, 4, J, NS, 2, 2, 4, 2, F16, TA>(a, in_mode, stream);
+      if (c.nw == 64) return launch_b<4, 4, J, NS, 4, 1, 2, 2, F16, TA>(a, in_mode, stream);
       return launch_b<4, 4, J, NS, 4, 1, 2, 1, F16, TA>(a, in_mode, stream);
     }
   }
-  if (a.Cout > 32) return launch_b<2, 4, J, NS, 2, 2, 2, 1, F16, TA>(a, in_mode, stream);
+  if constexpr (NS == 1)
+    if (c.nw == 128) return launch_b<2, 4, J, NS, 2, 2, 2, 2, F16, TA>(a, in_mode, stream);
+  if (c.nw == 64) return launch_b<2, 4, J, NS, 2, 2, 2, 1, F16, TA>(a, in_mode, stream);
   return launch_b<2, 4, J, NS, 4, 1, 1, 1, F16, TA>(a, in_mode, stream);
 }
 
@@ -570,7 +598,7 @@ int32_t mi355_conv3d_bf16_stats_blocks(const mi355_act* x, const mi355_act* y, c
     return (int32_t)((long long)zp.zsplits * zp.tilesY * zp.tilesX * (zp.use == 2 ? 8 : 1));
   }
   const long long vox = (long long)y->d * y->h * y->w * x->n;
-  const bool big = ns < 3 && vox >= 256LL * 512;
+  const bool big = lp_tile_cfg(ns, vox, y->c, d->gn_bwd != nullptr).big;
   const int tz = big ? 4 : 2, ty = 4;
   const long long b = (long long)ceil_div(y->d, tz) * ceil_div(y->h, ty) * ceil_div(y->w, 16);
   return b > 0 && b <= 0x7fffffffLL ? (int32_t)b : 0;
@@ -592,8 +620,9 @@ int mi355_conv3d_bf16_kernel_name(const mi355_act* x, const mi355_act* y, const 
   }
   const long long vox = (long long)d->out_d * d->out_h * d->out_w * x->n;
   const int J = ns == 1 ? 2 : 1;
-  const bool big = ns < 3 && vox >= 256LL * 512, wide = y->c > 32;
-  const char* tile = big ? (wide ? "4, 4, %d, %d, 4, 1, 2, 2" : "4, 4, %d, %d, 4, 1, 2, 1") : (wide ? "2, 4, %d, %d, 2, 2, 2, 1" : "2, 4, %d, %d, 4, 1, 1, 1");
+  const LpTileCfg c = lp_tile_cfg(ns, vox, y->c, d->gn_bwd != nullptr);
+  const char* tile = c.big ? (c.nw == 128 ? "4, 4, %d, %d, 2, 2, 4, 2" : c.nw == 64 ? "4, 4, %d, %d, 4, 1, 2, 2" : "4, 4, %d, %d, 4, 1, 2, 1")
+                           : (c.nw == 128 ? "2, 4, %d, %d, 2, 2, 2, 2" : c.nw == 64 ? "2, 4, %d, %d, 2, 2, 2, 1" : "2, 4, %d, %d, 4, 1, 1, 1");
   char t[64];
   snprintf(t, sizeof(t), tile, J, ns);
   snprintf(out, n, "conv3d_k3_bf16<%s, %d, %d, %s, %s>", t, d->in_mode, fuse, f16, x->dtype == MI355_ACT_BF16 ? "unsigned short" : (x->dtype == MI355_ACT_F16 ? "f16_t" : "float"));
