@@ -23,6 +23,9 @@
 #include "conv3d_lp.h"
 #include "pack_values.h"
 #include "act_io.h"
+#ifndef LP_GNB_BATCH
+#define LP_GNB_BATCH 4
+#endif
 
 // FUSE: 0 plain epilogue, 1 + moment records of the output, 2 + norm-backward sums (dgrad): as conv3d_fwd.hip
 // F16: MI355_PREC_F16 -- the single operand plane is IEEE fp16 instead of bf16 (same tile, same loop, v_mfma_f32_32x32x16_f16)
@@ -267,32 +270,40 @@ void conv3d_k3_bf16(ConvBArgs a) {
         const size_t vA = vrow + (size_t)half * a.Wo, vB = vrow + (size_t)(half ^ 1) * a.Wo;      // this lane's two x-rows
         TA* yA = ay + vA * a.yld + coc;
         TA* yB = ay + vB * a.yld + coc;
-        float gxv[16];
-        if constexpr (FUSE == 2) {
-          const TA* gA = agx + vA * a.g.gxld + coc;
-          const TA* gB = agx + vB * a.g.gxld + coc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) gxv[r] = ld1((((0x6 >> (r >> 2)) & 1) ? gB : gA) + (size_t)r * a.g.gxld);
-        }
+        // the reads of the normalised tensor in batches of GB values: all 16 of a tile at once beside the 128 accumulators of an 8-tile wave
+        // spill (LP_GNB_BATCH; 265 registers with 16)
+        constexpr int GB = (FUSE == 2 && MT * NT >= 8) ? LP_GNB_BATCH : 16;
+        const TA* gA = FUSE == 2 ? agx + vA * a.g.gxld + coc : nullptr;
+        const TA* gB = FUSE == 2 ? agx + vB * a.g.gxld + coc : nullptr;
         const TA* rA = a.res ? ares + vA * a.resld + coc : nullptr;
         const TA* rB = a.res ? ares + vB * a.resld + coc : nullptr;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool rowb = (0x6 >> (r >> 2)) & 1;
-          float v = acc[mt][nt][r] + bs;
-          if (a.res) v += ld1((rowb ? rB : rA) + (size_t)r * a.resld);
-          v *= cs;
-          if (cov) st1((rowb ? yB : yA) + (size_t)r * a.yld, v);
-          if constexpr (FUSE != 0) v = as_stored(ay, v);
-          if constexpr (FUSE == 1) {
-            if (mt == 0 && r == 0) K0 = v;
-            const float t = v - K0;
-            s0 += t; s1 += t * t;
-          } else if constexpr (FUSE == 2) {
-            const float xv = gxv[r];
-            const float u = xv * gsc + gsh;
-            const float du = u > 0.f ? v : v * a.g.gslope;
-            s0 += du; s1 += du * ((xv - gmean) * grstd);
+        for (int r0 = 0; r0 < 16; r0 += GB) {
+          float gxv[GB];
+          if constexpr (GB < 16) SCHED_BARRIER();
+          if constexpr (FUSE == 2) {
+#pragma unroll
+            for (int q = 0; q < GB; ++q) gxv[q] = ld1((((0x6 >> ((r0 + q) >> 2)) & 1) ? gB : gA) + (size_t)(r0 + q) * a.g.gxld);
+          }
+#pragma unroll
+          for (int q = 0; q < GB; ++q) {
+            const int r = r0 + q;
+            const bool rowb = (0x6 >> (r >> 2)) & 1;
+            float v = acc[mt][nt][r] + bs;
+            if (a.res) v += ld1((rowb ? rB : rA) + (size_t)r * a.resld);
+            v *= cs;
+            if (cov) st1((rowb ? yB : yA) + (size_t)r * a.yld, v);
+            if constexpr (FUSE != 0) v = as_stored(ay, v);
+            if constexpr (FUSE == 1) {
+              if (mt == 0 && r == 0) K0 = v;
+              const float t = v - K0;
+              s0 += t; s1 += t * t;
+            } else if constexpr (FUSE == 2) {
+              const float xv = gxv[q];
+              const float u = xv * gsc + gsh;
+              const float du = u > 0.f ? v : v * a.g.gslope;
+              s0 += du; s1 += du * ((xv - gmean) * grstd);
+            }
           }
         }
       }
@@ -313,6 +324,9 @@ void conv3d_k3_bf16(ConvBArgs a) {
     return;
   }
 
+  // 8-tile waves with the norm-backward sums: launched on whole tiles only (launch_b) -- with the general path below in the same kernel the
+  // allocator spills 265 registers, 33 without it
+  if constexpr (MT * NT >= 8 && FUSE == 2) __builtin_trap();
   // ---- epilogue: bias, residual, dropout scale, windowed store (channel-contiguous across lanes) ----
   if constexpr (FUSE == 0) {
 #pragma unroll
@@ -537,8 +551,8 @@ static int launch_b(ConvBArgs& a, int in_mode, void* stream) {
       LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT, 1, F16, TA>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   } else if (a.g.gnb) {
     if (in_mode != MI355_IN_PLAIN) return MI355_EUNSUPPORTED;
-    if constexpr (MT * NT >= 8) return MI355_EUNSUPPORTED;      // 8-tile waves: the normalised tensor's reads do not fit beside 128 accumulators (265 spills)
-    else
+    if constexpr (MT * NT >= 8)      // 8-tile waves carry the interior epilogue only (lp_tile_cfg routes whole-tile calls here)
+      if (a.Do % TZ || a.Ho % TY || a.Wo % 16 || a.offz || a.offy || a.offx || a.yD != a.Do || a.yH != a.Ho || a.yW != a.Wo) return MI355_EUNSUPPORTED;
     LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 2, F16, TA>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   } else if (in_mode == MI355_IN_PLAIN)
     LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 0, F16, TA>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
@@ -548,21 +562,25 @@ static int launch_b(ConvBArgs& a, int in_mode, void* stream) {
 }
 
 // Tile configuration of a call. Spatial tile: 4 x 4 x 16 voxels on big volumes (>= 128 K voxels: 4 waves along M), 2 x 4 x 16 on small ones
-// so the grid still fills the chip. Output channels per workgroup: 32, 64, or -- round 6, one-plane operands (NS = 1), Cout % 128 == 0, no
-// norm-backward epilogue -- 128 with twice the accumulator tiles per wave (4 x 2 on the big tile, 2 x 2 on the small one): a weight
-// fragment fetched through the L1 then feeds four / two MFMAs instead of two / one. Measured at batch 4 (profiles/r6_lp_tile_wide.txt):
-// 128 -> 128 @32^3 0.149 -> 0.120 ms, 256 -> 256 @16^3 0.108 -> 0.091 ms. The norm-backward form of the 8-tile wave spills 265 registers
-// (the normalised tensor's reads beside 128 accumulators) and measured slower (0.136 -> 0.185 ms): such calls keep the 64-channel form.
+// so the grid still fills the chip. Output channels per workgroup: 32, 64, or -- round 6, one-plane operands (NS = 1), Cout % 128 == 0 --
+// 128 with twice the accumulator tiles per wave (4 x 2 on the big tile, 2 x 2 on the small one): a weight fragment fetched through the
+// L1 then feeds four / two MFMAs instead of two / one. Measured at batch 4 (profiles/r6_lp_tile_wide.txt): 128 -> 128 @32^3 0.149 -> 0.120 ms,
+// 256 -> 256 @16^3 0.108 -> 0.091 ms. With the norm-backward epilogue (gnb): the big wide form on whole tiles only (`whole`: D % 4 == 0,
+// H % 4 == 0, W % 16 == 0 -- its kernel carries the interior epilogue alone; with the general one beside 128 accumulators hipcc spills 265
+// registers and the call ran slower, 0.136 -> 0.185 ms); the small wide form gains nothing there (2 instead of 3 waves per SIMD): 64 channels.
 // MI355_BF16_WIDE: 0 = never, big / small = that wide form on every eligible call whatever its size (tests), otherwise by size.
 struct LpTileCfg { bool big; int nw; };      // nw: output channels per workgroup (32, 64, 128)
-static LpTileCfg lp_tile_cfg(int ns, long long vox, int cout, bool gnb) {
+static LpTileCfg lp_tile_cfg(int ns, long long vox, int cout, bool gnb, bool whole) {
   LpTileCfg c;
   c.big = ns < 3 && vox >= 256LL * 512;      // the 3-plane tile of the big configuration would exceed the 64 KiB LDS window
   c.nw = cout > 32 ? 64 : 32;
   const char* e = getenv("MI355_BF16_WIDE");
-  if (ns == 1 && cout % 128 == 0 && !gnb && !(e && e[0] == '0')) {
-    if (e && e[0] == 'b') { c.big = true; c.nw = 128; }
-    else if (e && e[0] == 's') { c.big = false; c.nw = 128; }
+  if (ns == 1 && cout % 128 == 0 && !(e && e[0] == '0')) {
+    const bool fb = e && e[0] == 'b', fs = e && e[0] == 's';
+    if (gnb) {
+      if (whole && (fb || (!fs && c.big))) { c.big = true; c.nw = 128; }
+    } else if (fb) { c.big = true; c.nw = 128; }
+    else if (fs) { c.big = false; c.nw = 128; }
     else if (c.big || vox * (cout / 128) >= 128LL * 256) c.nw = 128;      // small tile: only with a workgroup per CU left
   }
   return c;
@@ -571,7 +589,7 @@ static LpTileCfg lp_tile_cfg(int ns, long long vox, int cout, bool gnb) {
 template <int NS, bool F16 = false, typename TA = float>
 static int dispatch_ns(ConvBArgs& a, int in_mode, long long vox, void* stream) {
   constexpr int J = NS == 1 ? 2 : 1;      // (one 16-channel k-step per chunk for NS = 1 too: more workgroups per CU, measured 10 % slower)
-  const LpTileCfg c = lp_tile_cfg(NS, vox, a.Cout, a.g.gnb != nullptr);
+  const LpTileCfg c = lp_tile_cfg(NS, vox, a.Cout, a.g.gnb != nullptr, a.Do % 4 == 0 && a.Ho % 4 == 0 && a.Wo % 16 == 0);
   if constexpr (NS < 3) {
     if (c.big) {
       if constexpr (NS == 1)
@@ -598,7 +616,7 @@ int32_t mi355_conv3d_bf16_stats_blocks(const mi355_act* x, const mi355_act* y, c
     return (int32_t)((long long)zp.zsplits * zp.tilesY * zp.tilesX * (zp.use == 2 ? 8 : 1));
   }
   const long long vox = (long long)y->d * y->h * y->w * x->n;
-  const bool big = lp_tile_cfg(ns, vox, y->c, d->gn_bwd != nullptr).big;
+  const bool big = lp_tile_cfg(ns, vox, y->c, d->gn_bwd != nullptr, y->d % 4 == 0 && y->h % 4 == 0 && y->w % 16 == 0).big;
   const int tz = big ? 4 : 2, ty = 4;
   const long long b = (long long)ceil_div(y->d, tz) * ceil_div(y->h, ty) * ceil_div(y->w, 16);
   return b > 0 && b <= 0x7fffffffLL ? (int32_t)b : 0;
@@ -620,7 +638,7 @@ int mi355_conv3d_bf16_kernel_name(const mi355_act* x, const mi355_act* y, const 
   }
   const long long vox = (long long)d->out_d * d->out_h * d->out_w * x->n;
   const int J = ns == 1 ? 2 : 1;
-  const LpTileCfg c = lp_tile_cfg(ns, vox, y->c, d->gn_bwd != nullptr);
+  const LpTileCfg c = lp_tile_cfg(ns, vox, y->c, d->gn_bwd != nullptr, d->out_d % 4 == 0 && d->out_h % 4 == 0 && d->out_w % 16 == 0);
   const char* tile = c.big ? (c.nw == 128 ? "4, 4, %d, %d, 2, 2, 4, 2" : c.nw == 64 ? "4, 4, %d, %d, 4, 1, 2, 2" : "4, 4, %d, %d, 4, 1, 2, 1")
                            : (c.nw == 128 ? "2, 4, %d, %d, 2, 2, 2, 2" : c.nw == 64 ? "2, 4, %d, %d, 2, 2, 2, 1" : "2, 4, %d, %d, 4, 1, 1, 1");
   char t[64];

@@ -413,6 +413,8 @@ class Backend:
             # one family, several kernels: the tile forms and (16-bit single-product modes, eligible shapes) the plane-ring form;
             # mi355_conv3d_fwd_config names the instantiation this call launches exactly as a rocprofv3 trace prints it
             variant = name.value.decode()
+            if os.environ.get("MI355_PROF_SHAPES") == "1":      # developer aid: one row per layer shape (tools/r6_call.sh)
+                variant += f" [{x.c}->{y.c} @{out_dhw[0]} x{x.shape[0]}]"
             name.value = b"conv3d_k3_bf16<...>"
         nvox = x.shape[0] * out_dhw[0] * out_dhw[1] * out_dhw[2]
         flops = 2.0 * nvox * x.c * y.c * kd ** 3 * (8 if (in_mode == IN_S2D or out_mode == OUT_D2S) else 1)

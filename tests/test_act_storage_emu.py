@@ -74,13 +74,18 @@ def test_conv_3x3x3_on_16bit_operands(bf16_backend, kw):
 @pytest.mark.parametrize("wide,kw", [
     ("big", dict(cin=32, cout=128, dhw=(4, 4, 16), norm=True, residual=True, moments=True)),    # 4 x 4 x 16 tile, 4 x 2 accumulator tiles per wave
     ("small", dict(cin=16, cout=128, dhw=(3, 5, 17), mode=1)),                                  # 2 x 4 x 16 tile, 2 x 2 tiles per wave, ragged
+    ("big", dict(cin=16, cout=128, dhw=(4, 4, 16), gnb=True, mode=1)),                          # norm-backward sums on whole tiles: the wide form
+    ("big", dict(cin=16, cout=128, dhw=(4, 5, 16), gnb=True, mode=1)),                          # ... ragged: the 64-channel form
 ])
 def test_conv_3x3x3_wide_tile_forms(bf16_backend, monkeypatch, wide, kw):
     """The 128-output-channel workgroups of the tile kernel (round 6, lp_tile_cfg in csrc/conv3d_bf16.hip): MI355_BF16_WIDE=big / small
     forces them on shapes far below the sizes that select them."""
     monkeypatch.setenv("MI355_BF16_WIDE", wide)
     monkeypatch.setenv("MI355_BF16_FORM", "tile")
-    _all_below(S.case_conv_k3_tile(bf16_backend, **kw), moments=2e-5)
+    r = S.case_conv_k3_tile(bf16_backend, **kw)
+    if kw.get("gnb"):
+        assert r["gnb_fused"]
+    _all_below(r, moments=2e-5, gnb=1e-5)
 
 
 @pytest.mark.parametrize("form,kw", [

@@ -81,13 +81,18 @@ def test_conv_3x3x3_on_16bit_operands(bf16_backend, kw):
     ("big", dict(cin=64, cout=256, dhw=(5, 7, 19), mode=1)),                                            # ... ragged, plain input, two channel tiles
     ("small", dict(cin=256, cout=256, dhw=(8, 8, 16), norm=True, moments=True, drop=True, n=2)),       # 2 x 4 x 16 tile, 2 x 2 tiles per wave
     ("small", dict(cin=48, cout=128, dhw=(3, 5, 17), mode=1, residual=True)),
+    ("big", dict(cin=128, cout=128, dhw=(8, 8, 32), gnb=True, mode=1, n=2)),                            # norm-backward sums: whole tiles -> the wide form
+    ("big", dict(cin=64, cout=128, dhw=(8, 9, 32), gnb=True, mode=1)),                                  # ... ragged -> the 64-channel form
 ])
 def test_conv_3x3x3_wide_tile_forms(bf16_backend, monkeypatch, wide, kw):
     """The 128-output-channel workgroups of the tile kernel (round 6, lp_tile_cfg in csrc/conv3d_bf16.hip): MI355_BF16_WIDE=big / small
     forces them on shapes far below the sizes that select them."""
     monkeypatch.setenv("MI355_BF16_WIDE", wide)
     monkeypatch.setenv("MI355_BF16_FORM", "tile")
-    _all_below(S.case_conv_k3_tile(bf16_backend, **kw), moments=2e-5)
+    r = S.case_conv_k3_tile(bf16_backend, **kw)
+    if kw.get("gnb"):
+        assert r["gnb_fused"]
+    _all_below(r, moments=2e-5, gnb=1e-5)
 
 
 @pytest.mark.parametrize("form,kw", [
