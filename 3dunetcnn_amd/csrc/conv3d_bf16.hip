@@ -35,7 +35,7 @@
 template <int TZ, int TY, int J, int NS, int WM, int WN, int MT, int NT, int INMODE, int FUSE = 0, bool F16 = false, typename TA = float>
 // LDS holds 3 workgroups of the largest tile: the register allocator must fit 3 waves per SIMD too (several variants sat one or two
 // registers above), except the 4-tile waves with a norm prologue or the norm-backward epilogue, which would spill.
-__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD((MT * NT >= 8 || (MT * NT >= 4 && (INMODE == MI355_IN_AFFINE_ACT || FUSE == 2))) ? 2 : 3)
+__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD((MT * NT >= 8 || (MT * NT >= 4 && (INMODE == MI355_IN_AFFINE_ACT || (FUSE == 2 && !(NT == 2 && WN == 2))))) ? 2 : 3)
 void conv3d_k3_bf16(ConvBArgs a) {
   const TA* const ax = reinterpret_cast<const TA*>(a.x);
   TA* const ay = reinterpret_cast<TA*>(a.y);
@@ -324,9 +324,9 @@ void conv3d_k3_bf16(ConvBArgs a) {
     return;
   }
 
-  // 8-tile waves with the norm-backward sums: launched on whole tiles only (launch_b) -- with the general path below in the same kernel the
-  // allocator spills 265 registers, 33 without it
-  if constexpr (MT * NT >= 8 && FUSE == 2) __builtin_trap();
+  // the 128-channel workgroups (WN = NT = 2) with the norm-backward sums: launched on whole tiles only (launch_b) -- with the general path
+  // below in the same kernel the allocator spills 265 registers on the 8-tile waves (33 without it)
+  if constexpr (NT == 2 && WN == 2 && FUSE == 2) __builtin_trap();
   // ---- epilogue: bias, residual, dropout scale, windowed store (channel-contiguous across lanes) ----
   if constexpr (FUSE == 0) {
 #pragma unroll
@@ -551,7 +551,7 @@ static int launch_b(ConvBArgs& a, int in_mode, void* stream) {
       LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_AFFINE_ACT, 1, F16, TA>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   } else if (a.g.gnb) {
     if (in_mode != MI355_IN_PLAIN) return MI355_EUNSUPPORTED;
-    if constexpr (MT * NT >= 8)      // 8-tile waves carry the interior epilogue only (lp_tile_cfg routes whole-tile calls here)
+    if constexpr (NT == 2 && WN == 2)      // the 128-channel workgroups carry the interior epilogue only (lp_tile_cfg routes whole-tile calls here)
       if (a.Do % TZ || a.Ho % TY || a.Wo % 16 || a.offz || a.offy || a.offx || a.yD != a.Do || a.yH != a.Ho || a.yW != a.Wo) return MI355_EUNSUPPORTED;
     LAUNCH((conv3d_k3_bf16<TZ, TY, J, NS, WM, WN, MT, NT, MI355_IN_PLAIN, 2, F16, TA>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   } else if (in_mode == MI355_IN_PLAIN)
@@ -565,12 +565,14 @@ static int launch_b(ConvBArgs& a, int in_mode, void* stream) {
 // so the grid still fills the chip. Output channels per workgroup: 32, 64, or -- round 6, one-plane operands (NS = 1), Cout % 128 == 0 --
 // 128 with twice the accumulator tiles per wave (4 x 2 on the big tile, 2 x 2 on the small one): a weight fragment fetched through the
 // L1 then feeds four / two MFMAs instead of two / one. Measured at batch 4 (profiles/r6_lp_tile_wide.txt): 128 -> 128 @32^3 0.149 -> 0.120 ms,
-// 256 -> 256 @16^3 0.108 -> 0.091 ms. With the norm-backward epilogue (gnb): the big wide form on whole tiles only (`whole`: D % 4 == 0,
-// H % 4 == 0, W % 16 == 0 -- its kernel carries the interior epilogue alone; with the general one beside 128 accumulators hipcc spills 265
-// registers and the call ran slower, 0.136 -> 0.185 ms); the small wide form gains nothing there (2 instead of 3 waves per SIMD): 64 channels.
+// 256 -> 256 @16^3 0.108 -> 0.091 ms. With the norm-backward epilogue (gnb): the wide forms on whole tiles only (`whole`, lp_whole:
+// their kernels carry the interior epilogue alone; with the general one beside 128 accumulators hipcc spills 265
+// registers and the call ran slower, 0.136 -> 0.185 ms). The small wide form is not routed there: interior-only it fits three waves per
+// SIMD (168 registers, 219 with the general epilogue) and still measured 0.111 against 0.107 ms on 256 -> 256 @16^3 (the 64-channel form).
 // MI355_BF16_WIDE: 0 = never, big / small = that wide form on every eligible call whatever its size (tests), otherwise by size.
 struct LpTileCfg { bool big; int nw; };      // nw: output channels per workgroup (32, 64, 128)
-static LpTileCfg lp_tile_cfg(int ns, long long vox, int cout, bool gnb, bool whole) {
+static int lp_whole(int d, int h, int w) { return (h % 4 == 0 && w % 16 == 0) ? (d % 4 == 0 ? 3 : (d % 2 == 0 ? 2 : 0)) : 0; }      // bit 0: whole 4 x 4 x 16 tiles, bit 1: whole 2 x 4 x 16
+static LpTileCfg lp_tile_cfg(int ns, long long vox, int cout, bool gnb, int whole) {
   LpTileCfg c;
   c.big = ns < 3 && vox >= 256LL * 512;      // the 3-plane tile of the big configuration would exceed the 64 KiB LDS window
   c.nw = cout > 32 ? 64 : 32;
@@ -578,7 +580,7 @@ static LpTileCfg lp_tile_cfg(int ns, long long vox, int cout, bool gnb, bool who
   if (ns == 1 && cout % 128 == 0 && !(e && e[0] == '0')) {
     const bool fb = e && e[0] == 'b', fs = e && e[0] == 's';
     if (gnb) {
-      if (whole && (fb || (!fs && c.big))) { c.big = true; c.nw = 128; }
+      if ((whole & 1) && (fb || (!fs && c.big))) { c.big = true; c.nw = 128; }
     } else if (fb) { c.big = true; c.nw = 128; }
     else if (fs) { c.big = false; c.nw = 128; }
     else if (c.big || vox * (cout / 128) >= 128LL * 256) c.nw = 128;      // small tile: only with a workgroup per CU left
@@ -589,7 +591,7 @@ static LpTileCfg lp_tile_cfg(int ns, long long vox, int cout, bool gnb, bool who
 template <int NS, bool F16 = false, typename TA = float>
 static int dispatch_ns(ConvBArgs& a, int in_mode, long long vox, void* stream) {
   constexpr int J = NS == 1 ? 2 : 1;      // (one 16-channel k-step per chunk for NS = 1 too: more workgroups per CU, measured 10 % slower)
-  const LpTileCfg c = lp_tile_cfg(NS, vox, a.Cout, a.g.gnb != nullptr, a.Do % 4 == 0 && a.Ho % 4 == 0 && a.Wo % 16 == 0);
+  const LpTileCfg c = lp_tile_cfg(NS, vox, a.Cout, a.g.gnb != nullptr, lp_whole(a.Do, a.Ho, a.Wo));
   if constexpr (NS < 3) {
     if (c.big) {
       if constexpr (NS == 1)
@@ -616,7 +618,7 @@ int32_t mi355_conv3d_bf16_stats_blocks(const mi355_act* x, const mi355_act* y, c
     return (int32_t)((long long)zp.zsplits * zp.tilesY * zp.tilesX * (zp.use == 2 ? 8 : 1));
   }
   const long long vox = (long long)y->d * y->h * y->w * x->n;
-  const bool big = lp_tile_cfg(ns, vox, y->c, d->gn_bwd != nullptr, y->d % 4 == 0 && y->h % 4 == 0 && y->w % 16 == 0).big;
+  const bool big = lp_tile_cfg(ns, vox, y->c, d->gn_bwd != nullptr, lp_whole(y->d, y->h, y->w)).big;
   const int tz = big ? 4 : 2, ty = 4;
   const long long b = (long long)ceil_div(y->d, tz) * ceil_div(y->h, ty) * ceil_div(y->w, 16);
   return b > 0 && b <= 0x7fffffffLL ? (int32_t)b : 0;
@@ -638,7 +640,7 @@ int mi355_conv3d_bf16_kernel_name(const mi355_act* x, const mi355_act* y, const 
   }
   const long long vox = (long long)d->out_d * d->out_h * d->out_w * x->n;
   const int J = ns == 1 ? 2 : 1;
-  const LpTileCfg c = lp_tile_cfg(ns, vox, y->c, d->gn_bwd != nullptr, d->out_d % 4 == 0 && d->out_h % 4 == 0 && d->out_w % 16 == 0);
+  const LpTileCfg c = lp_tile_cfg(ns, vox, y->c, d->gn_bwd != nullptr, lp_whole(d->out_d, d->out_h, d->out_w));
   const char* tile = c.big ? (c.nw == 128 ? "4, 4, %d, %d, 2, 2, 4, 2" : c.nw == 64 ? "4, 4, %d, %d, 4, 1, 2, 2" : "4, 4, %d, %d, 4, 1, 2, 1")
                            : (c.nw == 128 ? "2, 4, %d, %d, 2, 2, 2, 2" : c.nw == 64 ? "2, 4, %d, %d, 2, 2, 2, 1" : "2, 4, %d, %d, 4, 1, 1, 1");
   char t[64];

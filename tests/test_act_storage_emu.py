@@ -76,6 +76,7 @@ def test_conv_3x3x3_on_16bit_operands(bf16_backend, kw):
     ("small", dict(cin=16, cout=128, dhw=(3, 5, 17), mode=1)),                                  # 2 x 4 x 16 tile, 2 x 2 tiles per wave, ragged
     ("big", dict(cin=16, cout=128, dhw=(4, 4, 16), gnb=True, mode=1)),                          # norm-backward sums on whole tiles: the wide form
     ("big", dict(cin=16, cout=128, dhw=(4, 5, 16), gnb=True, mode=1)),                          # ... ragged: the 64-channel form
+    ("small", dict(cin=16, cout=128, dhw=(2, 4, 16), gnb=True, mode=1)),                        # ... the small tile keeps 64 channels with these sums
 ])
 def test_conv_3x3x3_wide_tile_forms(bf16_backend, monkeypatch, wide, kw):
     """The 128-output-channel workgroups of the tile kernel (round 6, lp_tile_cfg in csrc/conv3d_bf16.hip): MI355_BF16_WIDE=big / small

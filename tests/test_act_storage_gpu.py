@@ -83,6 +83,7 @@ def test_conv_3x3x3_on_16bit_operands(bf16_backend, kw):
     ("small", dict(cin=48, cout=128, dhw=(3, 5, 17), mode=1, residual=True)),
     ("big", dict(cin=128, cout=128, dhw=(8, 8, 32), gnb=True, mode=1, n=2)),                            # norm-backward sums: whole tiles -> the wide form
     ("big", dict(cin=64, cout=128, dhw=(8, 9, 32), gnb=True, mode=1)),                                  # ... ragged -> the 64-channel form
+    ("small", dict(cin=256, cout=256, dhw=(6, 8, 16), gnb=True, mode=1, n=2)),                          # ... the small tile keeps 64 channels with these sums
 ])
 def test_conv_3x3x3_wide_tile_forms(bf16_backend, monkeypatch, wide, kw):
     """The 128-output-channel workgroups of the tile kernel (round 6, lp_tile_cfg in csrc/conv3d_bf16.hip): MI355_BF16_WIDE=big / small
