@@ -1,6 +1,6 @@
 #!/bin/bash
 # scratch per-call script (GPU box)
-tools/sq_counters.sh r6sqw "bf16 128 128 64 fwdplain" "bf16 128 128 64 fwdnormmom" "bf16 256 256 32 fwdplain"
-MI355_BF16_WIDE=0 tools/sq_counters.sh r6sq0 "bf16 128 128 64 fwdplain" "bf16 128 128 64 fwdnormmom" "bf16 256 256 32 fwdplain"
-echo "== wide"; cat gpurun_out/r6sqw/sq_counters_conv_kernels.txt
-echo "== MI355_BF16_WIDE=0"; cat gpurun_out/r6sq0/sq_counters_conv_kernels.txt
+for i in 1 2; do
+for m in 0 2 6 7 4; do
+MI355_K1_STREAM_F32=$m python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-precision-modes --no-c3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fp32 mask $m', d['value'], d['ms_per_step'])"
+done; done
