@@ -1,9 +1,5 @@
 #!/bin/bash
 # scratch per-call script (GPU box)
-for i in 1 2; do
-for m in 0 -1; do
-MI355_MAIN_PRIORITY=$m python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-precision-modes --no-c3 --no-kernel-events 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fp32 main priority $m', d['value'], d['ms_per_step'])"
-done; done
-for m in 0 -1; do
-MI355_MAIN_PRIORITY=$m python bench.py --config c3 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-events 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('c3 main priority $m', d['value'], d['ms_per_step'])"
-done
+export ONE_CONV_LIB=tools/libvar_j4.so LAYERS="256,256,16;512,256,16;128,256,16"
+echo "== J = 4 (64-channel chunks) on the small wide form"; python tools/bench_lp_tile.py 2>&1 | grep -v amdgpu
+echo "== MI355_LP_J4=0"; MI355_LP_J4=0 python tools/bench_lp_tile.py 2>&1 | grep -v amdgpu
