@@ -1,5 +1,5 @@
 #!/bin/bash
 # scratch per-call script (GPU box)
-export ONE_CONV_LIB=tools/libvar_j4.so LAYERS="256,256,16;512,256,16;128,256,16"
-echo "== J = 4 (64-channel chunks) on the small wide form"; python tools/bench_lp_tile.py 2>&1 | grep -v amdgpu
-echo "== MI355_LP_J4=0"; MI355_LP_J4=0 python tools/bench_lp_tile.py 2>&1 | grep -v amdgpu
+out=gpurun_out/r6x; mkdir -p $out
+( time python -m pytest tests/ -x -q -m gpu --durations=12 ) > $out/pytest_gpu_workers.log 2>&1; echo "rc=$?" >> $out/pytest_gpu_workers.log
+tail -22 $out/pytest_gpu_workers.log
