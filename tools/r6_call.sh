@@ -1,5 +1,5 @@
 #!/bin/bash
 # scratch per-call script (GPU box)
-out=gpurun_out/r6x; mkdir -p $out
-( time python -m pytest tests/ -x -q -m gpu --durations=12 ) > $out/pytest_gpu_workers.log 2>&1; echo "rc=$?" >> $out/pytest_gpu_workers.log
-tail -22 $out/pytest_gpu_workers.log
+echo "== colsPer 1 (tree)"; python tools/bench_wgrad_lp.py 2>&1 | grep -v amdgpu | head -10
+echo "== MI355_WGRAD_LP_COLS=2"; MI355_WGRAD_LP_COLS=2 python tools/bench_wgrad_lp.py 2>&1 | grep -v amdgpu | head -10
+echo "== MI355_WGRAD_LP_COLS=4"; MI355_WGRAD_LP_COLS=4 python tools/bench_wgrad_lp.py 2>&1 | grep -v amdgpu | head -10
